@@ -1,0 +1,238 @@
+/*
+ * zudsmi.h - C-ABI of libzudsmi.so, the MI355X (gfx950) engine behind the
+ * ZUDS coadd / subtraction object API.
+ *
+ * The reference pipeline has no FFI on this path: it builds command strings
+ * and runs `subprocess.check_call` on SWarp, SExtractor and hotpants,
+ * exchanging FITS files.  Every entry point below replaces one of those
+ * process boundaries (cited per function, paths relative to the reference
+ * tree).  INTEGRATION.md shows the ctypes stubs a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *  - all functions return 0 on success, non-zero on failure; the message is
+ *    available per thread from zm_last_error();
+ *  - images are C-contiguous, native-endian, row-major [ny][nx]; pixel (1,1)
+ *    of FITS is element [0][0];
+ *  - pointers passed to the host entry points are borrowed for the call;
+ *    outputs are caller-allocated;
+ *  - a zm_ctx owns one HIP stream and all device scratch; one ctx per
+ *    process/GPU, not thread-safe;
+ *  - `*_dev` entry points take device pointers (hipMalloc / torch storage)
+ *    and only enqueue work on the ctx stream.
+ */
+#ifndef ZUDSMI_H
+#define ZUDSMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zm_ctx zm_ctx;
+
+#define ZM_NPV 40
+
+/* TAN (flags = 0) or TPV (flags & 1) WCS; FITS 1-based pixel convention.
+ * Replaces astropy.wcs.WCS(header) (zuds/fitsfile.py:233-238) and the
+ * `.head` files handed to SWarp (zuds/swarp.py:114-133). */
+typedef struct zm_wcs {
+    double crpix[2];
+    double crval[2];      /* degrees */
+    double cd[4];         /* CD1_1 CD1_2 CD2_1 CD2_2, degrees / pixel */
+    double pv1[ZM_NPV];   /* PV1_k; only read when flags & 1 */
+    double pv2[ZM_NPV];
+    int32_t naxis[2];     /* NAXIS1 (x), NAXIS2 (y) */
+    int32_t flags;        /* bit 0: TPV distortion present */
+    int32_t pad_;
+} zm_wcs;
+
+enum { ZM_RESAMPLE_NEAREST = 0, ZM_RESAMPLE_BILINEAR = 1, ZM_RESAMPLE_LANCZOS3 = 3 };
+enum { ZM_COMBINE_WEIGHTED = 0, ZM_COMBINE_MEDIAN = 1, ZM_COMBINE_CLIPPED = 2,
+       ZM_COMBINE_AVERAGE = 3 };
+enum { ZM_MASK_AND = 0, ZM_MASK_OR = 1 };
+
+/* ---- context ---------------------------------------------------------- */
+int zm_ctx_create(int device, zm_ctx** out);
+int zm_ctx_destroy(zm_ctx* ctx);
+/* Use an external hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream);
+int zm_ctx_synchronize(zm_ctx* ctx);
+const char* zm_last_error(void);
+const char* zm_version(void);
+
+/* ---- WCS helpers (host, fp64) ------------------------------------------ */
+/* Output grid of a coadd: SWarp CENTER_TYPE ALL / PIXELSCALE_TYPE MEDIAN /
+ * IMAGE_SIZE 0 (zuds/astromatic/makecoadd/default.swarp:40-49). */
+int zm_autogrid(int nframes, const zm_wcs* wcs, zm_wcs* out);
+/* pixel -> sky and sky -> pixel for n points (degrees, 1-based pixels). */
+int zm_wcs_pix2sky(const zm_wcs* w, int n, const double* x, const double* y,
+                   double* ra, double* dec);
+int zm_wcs_sky2pix(const zm_wcs* w, int n, const double* ra, const double* dec,
+                   double* x, double* y);
+/* input-frame pixel of output pixels (the inverse map SWarp evaluates). */
+int zm_wcs_map(const zm_wcs* wout, const zm_wcs* win, int n, const double* xo,
+               const double* yo, double* xi, double* yi);
+/* FLXSCALE x fixed pixel-area ratio (FSCALASTRO_TYPE FIXED, default.swarp:58). */
+int zm_flux_scale(const zm_wcs* win, const zm_wcs* wout, double flxscale,
+                  double* out);
+
+/* ---- resample one image onto another grid ------------------------------ */
+/* Replaces the SWarp run of run_align (zuds/swarp.py:157-204; HasWCS.aligned_to
+ * zuds/fitsfile.py:290-314): Lanczos-3 by default, no background subtraction,
+ * `wgt` NULL = WEIGHT_TYPE NONE.  out_wgt == 0 marks no-data pixels (bit 16,
+ * zuds/mask.py:26-33).  mask/out_mask may be NULL. */
+int zm_resample(zm_ctx* ctx, const float* img, const float* wgt,
+                const int32_t* mask, const zm_wcs* win, const zm_wcs* wout,
+                int kernel, double fscale, float* out_img, float* out_wgt,
+                int32_t* out_mask);
+
+/* ---- mesh background ----------------------------------------------------- */
+/* Replaces `sex ... -CHECKIMAGE_TYPE BACKGROUND,BACKGROUND_RMS,-BACKGROUND`
+ * (zuds/sextractor.py:110-150; used by zuds/hotpants.py:28 and
+ * zuds/image.py:206) and SWarp's SUBTRACT_BACK (default.swarp:77-88).
+ * wgt NULL = no weighting; any of out_bkg/out_rms/out_sub may be NULL.
+ * out_stats[0..1] = global (backmean, backsig) = medians of the mesh maps. */
+int zm_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
+                  int ny, int mesh, int filtersize, float* out_bkg,
+                  float* out_rms, float* out_sub, double* out_stats);
+
+/* ---- coadd ---------------------------------------------------------------- */
+typedef struct zm_frame {
+    const float* img;       /* [ny][nx] */
+    const float* wgt;       /* inverse variance, NULL = WEIGHT_TYPE NONE */
+    const int32_t* mask;    /* NULL = no mask */
+    zm_wcs wcs;
+    double flxscale;        /* FLXSCALE = 10^(-0.4 (MAGZP - 25)), zuds/swarp.py:31 */
+} zm_frame;
+
+typedef struct zm_coadd_params {
+    int32_t combine;          /* ZM_COMBINE_*  (COMBINE_TYPE, default CLIPPED) */
+    int32_t mask_combine;     /* ZM_MASK_*     (mask.swarp:25 AND; swarp.py:141 OR) */
+    int32_t resample;         /* ZM_RESAMPLE_* (RESAMPLING_TYPE LANCZOS3) */
+    int32_t subtract_back;    /* SUBTRACT_BACK Y */
+    int32_t back_size;        /* -BACK_SIZE 128 (zuds/swarp.py:69) */
+    int32_t back_filtersize;  /* BACK_FILTERSIZE 3 */
+    int32_t rescale_weights;  /* RESCALE_WEIGHTS Y */
+    int32_t pad_;
+    double clip_sigma;        /* CLIP_SIGMA 4.0 */
+    double clip_ampfrac;      /* CLIP_AMPFRAC 0.3 */
+    double weight_thresh;     /* WEIGHT_THRESH 1e-30 */
+} zm_coadd_params;
+
+void zm_coadd_params_default(zm_coadd_params* p);
+
+/* Replaces both SWarp runs of _coadd_from_images (zuds/coadd.py:126-163):
+ * science coadd (prepare_swarp_sci, zuds/swarp.py:20-80) and mask coadd
+ * (prepare_swarp_mask, zuds/swarp.py:83-104) on the grid `wout`.
+ * out_mask may be NULL when no frame carries a mask; out_mask_wgt (may be NULL)
+ * is the coverage map of the mask coadd (mskoutweightname, zuds/coadd.py:146-147)
+ * from which the caller sets bit 16 (zuds/mask.py:26-33). */
+int zm_coadd(zm_ctx* ctx, int nframes, const zm_frame* frames,
+             const zm_wcs* wout, const zm_coadd_params* params, float* out_img,
+             float* out_wgt, int32_t* out_mask, float* out_mask_wgt);
+
+/* ---- subtraction ------------------------------------------------------------ */
+typedef struct zm_hp_params {
+    /* flags emitted by prepare_hotpants (zuds/hotpants.py:77-93) */
+    double tu, tl, iu, il;    /* -tu -tl -iu -il valid data range */
+    double r;                 /* -r   kernel half width (2.5 SEEING) */
+    double rss;               /* -rss substamp half width (6 SEEING) */
+    double fin;               /* -fin noise fill value (BIG_RMS) */
+    double fi;                /* diff fill value, hotpants default 1e-30 */
+    int32_t nsx, nsy;         /* -nsx -nsy stamps per region */
+    int32_t nrx, nry;         /* -nrx -nry regions */
+    int32_t ko, bgo;          /* -ko -bgo spatial orders (reference: 4, 0) */
+    int32_t nss;              /* substamps per stamp (hotpants default 3) */
+    int32_t normalize;        /* 0: -n i (reference), 1: -n t */
+    double ft;                /* -ft  substamp threshold in sigma (20) */
+    double ks;                /* -ks  stamp rejection sigma (2.0) */
+    int32_t ngauss;           /* 3 */
+    int32_t deg[4];           /* 6 4 2 */
+    int32_t pad_[3];
+    double sigma[4];          /* 0.7 1.5 3.0 */
+} zm_hp_params;
+
+void zm_hp_params_default(zm_hp_params* p);
+
+typedef struct zm_hp_info {
+    int32_t nstamps_total, nstamps_used;
+    int32_t niter, ncoeff;
+    double kernel_sum;        /* mean kernel sum over regions */
+    double chi2;              /* mean figure of merit of the used stamps */
+    int32_t nmasked;          /* output pixels filled with `fi` */
+    int32_t status;
+} zm_hp_info;
+
+/* Replaces the hotpants run of Subtraction.from_images
+ * (zuds/subtraction.py:144-162; flags zuds/hotpants.py:77-93): convolve the
+ * template (-c t), D = I - (T (x) K + bg), noise = sqrt(sI^2 + sT^2 (x) K^2),
+ * masked pixels filled with fi / fin (zuds/subtraction.py:170-171).
+ * sci/ref and their rms maps are on the same grid; bpm is the boolean
+ * bad-pixel map (zuds/subtraction.py:141-142), may be NULL. */
+int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms,
+                const float* ref, const float* ref_rms, const uint8_t* bpm,
+                int nx, int ny, const zm_hp_params* params, float* out_diff,
+                float* out_rms, zm_hp_info* out_info);
+
+/* ---- robust statistics ---------------------------------------------------- */
+/* Replaces quick_background_estimate (zuds/utils.py:32-53): median and
+ * 1.4826 MAD of the pixels whose mask is 0 (mask NULL = all). */
+int zm_median_mad(zm_ctx* ctx, const float* img, const int32_t* mask, int64_t n,
+                  double* out_median, double* out_mad_sigma);
+
+/* ---- device-pointer entry points (bench, multi-GPU, pipelines) ----------- */
+/* Same arithmetic as above on device-resident buffers; enqueue only. */
+typedef struct zm_dframe {
+    const float* img;       /* device */
+    const float* wgt;       /* device or NULL */
+    const int32_t* mask;    /* device or NULL */
+    zm_wcs wcs;
+    double flxscale;
+} zm_dframe;
+
+/* Resample + combine nframes device frames; outputs are device planes.
+ * If `partial` != 0 the outputs are the partial sums S1 = sum(w v) (out_img)
+ * and S0 = sum(w) (out_wgt) of a WEIGHTED coadd, ready for an RCCL
+ * all-reduce across ranks followed by zm_coadd_finalize_dev. */
+int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
+                 const zm_wcs* wout, const zm_coadd_params* params,
+                 int partial, float* out_img, float* out_wgt, int32_t* out_mask,
+                 float* out_mask_wgt);
+int zm_coadd_finalize_dev(zm_ctx* ctx, float* s1_to_img, const float* s0,
+                          int64_t npix);
+/* Resample the frames to `wout` into a resident stack [nframes][ony][onx][2]
+ * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it). */
+int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
+                          const zm_wcs* wout, const zm_coadd_params* params,
+                          float* stack);
+/* Combine a resident stack; rows [row0, row0+nrows) of every frame. */
+int zm_combine_stack_dev(zm_ctx* ctx, int nframes, const float* stack,
+                         int64_t frame_stride_px, int64_t npix,
+                         const zm_coadd_params* params, float* out_img,
+                         float* out_wgt);
+int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms,
+                    const float* ref, const float* ref_rms, const uint8_t* bpm,
+                    int nx, int ny, const zm_hp_params* params, float* out_diff,
+                    float* out_rms, zm_hp_info* out_info_host);
+int zm_background_dev(zm_ctx* ctx, const float* img, const float* wgt, int nx,
+                      int ny, int mesh, int filtersize, float* out_bkg,
+                      float* out_rms, float* out_sub, double* out_stats_host);
+int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
+                    const int32_t* mask, const zm_wcs* win, const zm_wcs* wout,
+                    int kernel, double fscale, float* out_img, float* out_wgt,
+                    int32_t* out_mask);
+
+/* ---- timing hooks (bench.py reads per-kernel HIP-event times) ------------- */
+/* Enable recording of HIP events around the dominant kernels on the ctx
+ * stream; zm_timing_read returns accumulated milliseconds and launch counts. */
+int zm_timing_enable(zm_ctx* ctx, int on);
+int zm_timing_reset(zm_ctx* ctx);
+int zm_timing_read(zm_ctx* ctx, const char* kernel_name, double* total_ms,
+                   int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZUDSMI_H */

@@ -1,0 +1,148 @@
+"""C-ABI surface and host-side (fp64, no GPU) entry points."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import grid as ogrid
+from oracle import resample as oresample
+from oracle.wcs import map_out_to_in
+from util import pkg, synth, to_oracle_wcs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'zudsmi.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(zm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    z = pkg()
+    L = C.CDLL(str(z._lib.LIBPATH))
+    names = header_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(L, name), f'{name} declared in zudsmi.h but not exported'
+    # and the ctypes table binds every one of them
+    bound = set(z._lib.exported_symbols())
+    assert set(names) <= bound | {'zm_debug_lanczos3'}, set(names) - bound
+
+
+def test_struct_sizes_match_header():
+    z = pkg()
+    assert C.sizeof(z._lib.zm_wcs) == 8 * (2 + 2 + 4 + 40 + 40) + 16
+    assert C.sizeof(z._lib.zm_coadd_params) == 8 * 4 + 3 * 8
+    assert C.sizeof(z._lib.zm_hp_params) == 8 * 8 + 8 * 4 + 2 * 8 + 8 * 4 + 4 * 8
+    assert C.sizeof(z._lib.zm_frame) == 3 * 8 + C.sizeof(z._lib.zm_wcs) + 8
+
+
+def test_last_error_is_set_on_bad_arguments():
+    z = pkg()
+    L = z._lib.lib()
+    rc = L.zm_autogrid(0, None, None)
+    assert rc != 0
+    assert b'zm_autogrid' in L.zm_last_error()
+
+
+@pytest.mark.parametrize('tpv', [False, True])
+def test_wcs_roundtrip_and_oracle_agreement(tpv):
+    s = synth()
+    w = s.ztf_wcs(3072, 3080, dx=4.25, dy=-9.5, rot_deg=0.07, tpv=tpv)
+    ow = to_oracle_wcs(w)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-50, 3130, 200)
+    y = rng.uniform(-50, 3130, 200)
+    ra, dec = w.all_pix2world(x, y, 1)
+    ora, odec = ow.pix2sky(x, y)
+    np.testing.assert_allclose(ra, ora, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(dec, odec, rtol=0, atol=1e-11)
+    x2, y2 = w.all_world2pix(ra, dec, 1)
+    np.testing.assert_allclose(x2, x, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(y2, y, rtol=0, atol=1e-7)
+
+
+def test_wcs_origin_convention():
+    s = synth()
+    w = s.tan_wcs(100, 80)
+    ra1, dec1 = w.all_pix2world(10.0, 20.0, 1)
+    ra0, dec0 = w.all_pix2world(9.0, 19.0, 0)
+    assert ra1 == ra0 and dec1 == dec0
+    # CRPIX maps to CRVAL
+    ra, dec = w.all_pix2world(w.crpix[0], w.crpix[1], 1)
+    np.testing.assert_allclose([ra, dec], w.crval, atol=1e-12)
+
+
+def test_map_matches_oracle():
+    z = pkg()
+    s = synth()
+    wout = s.ztf_wcs(3072, 3072, tpv=True)
+    win = s.ztf_wcs(3072, 3072, dx=11.3, dy=-6.1, rot_deg=-0.09, tpv=True)
+    rng = np.random.default_rng(5)
+    xo = rng.uniform(1, 3072, 300)
+    yo = rng.uniform(1, 3072, 300)
+    xi = np.empty_like(xo)
+    yi = np.empty_like(yo)
+    a, b = z._lib.wcs_struct(wout), z._lib.wcs_struct(win)
+    z._lib.check(z._lib.lib().zm_wcs_map(C.byref(a), C.byref(b), xo.size,
+                                         xo.ctypes.data, yo.ctypes.data,
+                                         xi.ctypes.data, yi.ctypes.data))
+    oxi, oyi = map_out_to_in(to_oracle_wcs(wout), to_oracle_wcs(win), xo, yo)
+    np.testing.assert_allclose(xi, oxi, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(yi, oyi, rtol=0, atol=1e-8)
+
+
+def test_flux_scale_matches_oracle():
+    z = pkg()
+    s = synth()
+    win = s.ztf_wcs(512, 512, rot_deg=0.3)
+    wout = s.tan_wcs(600, 600, scale=3.0e-4)
+    a, b = z._lib.wcs_struct(win), z._lib.wcs_struct(wout)
+    v = C.c_double()
+    z._lib.check(z._lib.lib().zm_flux_scale(C.byref(a), C.byref(b), 0.37, C.byref(v)))
+    ref = oresample.flux_scale(to_oracle_wcs(win), to_oracle_wcs(wout), 0.37)
+    assert abs(v.value - ref) < 1e-9 * ref
+    # ratio of pixel areas: (3.0e-4)^2 / (~2.8125e-4)^2
+    assert abs(v.value / 0.37 - (3.0e-4 / 2.8125e-4) ** 2) < 2e-3
+
+
+def test_autogrid_matches_oracle_and_covers_inputs():
+    z = pkg()
+    s = synth()
+    ws = [s.ztf_wcs(495, 495, dx=dx, dy=dy, rot_deg=r, tpv=False)
+          for dx, dy, r in [(0, 0, 0.0), (24.4, -25.2, 0.05), (-10.0, 8.0, -0.1)]]
+    n = len(ws)
+    arr = (z._lib.zm_wcs * n)(*[z._lib.wcs_struct(w) for w in ws])
+    out = z._lib.zm_wcs()
+    z._lib.check(z._lib.lib().zm_autogrid(n, arr, C.byref(out)))
+    ref = ogrid.autogrid([to_oracle_wcs(w) for w in ws])
+    assert (out.naxis[0], out.naxis[1]) == ref.naxis
+    np.testing.assert_allclose(list(out.crpix), ref.crpix, atol=1e-6)
+    np.testing.assert_allclose(list(out.crval), ref.crval, atol=1e-10)
+    np.testing.assert_allclose(list(out.cd), ref.cd.ravel(), atol=1e-15)
+    # every input corner lands inside the output frame
+    wo = z.WCS.from_struct(out)
+    for w in ws:
+        fp = w.calc_footprint()
+        x, y = wo.all_world2pix(fp[:, 0], fp[:, 1], 1)
+        assert x.min() >= 0.5 - 1e-6 and x.max() <= out.naxis[0] + 0.5 + 1e-6
+        assert y.min() >= 0.5 - 1e-6 and y.max() <= out.naxis[1] + 0.5 + 1e-6
+    # union of offset frames is larger than one frame, as in the reference's
+    # test_stack (495 x 495 inputs -> 544 x 545, zuds/tests/suite/test_stack.py:26-27)
+    assert out.naxis[0] > 495 and out.naxis[1] > 495
+
+
+def test_lanczos3_taps_match_oracle():
+    z = pkg()
+    L = z._lib.lib()
+    out = np.zeros(6, dtype=np.float32)
+    worst = 0.0
+    for d in np.concatenate([np.linspace(1e-5, 1 - 1e-5, 257), [1e-4, 0.5, 0.999]]):
+        L.zm_debug_lanczos3(C.c_float(d), out.ctypes.data)
+        ref = oresample.lanczos3_taps(np.float64(np.float32(d)))
+        worst = max(worst, np.abs(out - ref).max())
+        assert abs(out.sum() - 1.0) < 1e-6
+    assert worst < 5e-7, worst

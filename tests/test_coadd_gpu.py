@@ -1,0 +1,178 @@
+"""Parity of resample + combine (zm_coadd) with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import combine as ocombine
+from oracle import resample as oresample
+from oracle import background as oback
+from util import assert_close_masked, pkg, synth, to_oracle_wcs
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_coadd(frames, wout, kind, subtract_back=False, rescale=False,
+                 clip_sigma=4.0, clip_ampfrac=0.3, mesh=128):
+    onx, ony = wout.naxis
+    ow = to_oracle_wcs(wout)
+    vals, wgts, masks, cov = [], [], [], []
+    for f in frames:
+        wi = to_oracle_wcs(f['wcs'])
+        px, py = oresample.positions(ow, wi, onx, ony)
+        img = f['img'].astype(np.float64)
+        wgt = None if f.get('wgt') is None else f['wgt'].astype(np.float64)
+        if subtract_back or rescale:
+            bkg, rms, bmean, bsig, _, _ = oback.background(img, wgt, mesh)
+            if rescale and wgt is not None:
+                with np.errstate(divide='ignore'):
+                    var = np.where(wgt > 1e-30, 1.0 / np.where(wgt > 0, wgt, 1), 0.0)
+                vb, vs = oback.mesh_maps(var, wgt, mesh)
+                vbf, _ = oback.filter_maps(vb, vs, 3)
+                level = oback.fqmedian(vbf.ravel())
+                if level > 0 and bsig > 0:
+                    wgt = wgt / (bsig * bsig / level)
+            if subtract_back:
+                img = img - bkg
+        fs = oresample.flux_scale(wi, ow, f.get('flxscale', 1.0))
+        o, w, m = oresample.resample(img, wgt, px, py, oresample.LANCZOS3, fs,
+                                     f.get('mask'))
+        vals.append(o)
+        wgts.append(w)
+        if m is not None:
+            masks.append(m)
+            ix, _, _ = oresample.split_position(px)
+            iy, _, _ = oresample.split_position(py)
+            nx, ny = f['wcs'].naxis
+            cov.append((ix - 2 >= 0) & (ix + 4 <= nx) & (iy - 2 >= 0) & (iy + 4 <= ny))
+    out, ow_, _ = ocombine.combine(np.array(vals), np.array(wgts), kind, clip_sigma, clip_ampfrac)
+    om = None
+    if masks:
+        om, ocov = ocombine.combine_masks(np.array(masks), np.array(cov), 'AND')
+    return out, ow_, om, np.array(vals), np.array(wgts)
+
+
+def small_stack(n=5, nx=180, ny=150, tpv=True, outlier=True):
+    s = synth()
+    base = s.ztf_wcs(nx, ny, tpv=tpv)
+    rng = np.random.default_rng(99)
+    xs = rng.uniform(5, nx - 5, 25)
+    ys = rng.uniform(5, ny - 5, 25)
+    fl = np.exp(rng.uniform(np.log(2e3), np.log(5e4), 25))
+    ra, dec = base.all_pix2world(xs, ys, 0)
+    frames = []
+    for i in range(n):
+        r = np.random.default_rng(500 + i)
+        w = s.ztf_wcs(nx, ny, dx=r.uniform(-6, 6), dy=r.uniform(-6, 6),
+                      rot_deg=r.uniform(-0.2, 0.2), tpv=tpv)
+        frames.append(s.make_frame(nx, ny, 500 + i, w, star_sky=(ra, dec, fl),
+                                   magzp=r.uniform(25.5, 26.5), nbad=60))
+    if outlier:
+        frames[2]['img'][70:73, 80:83] += 5000.0    # cosmic-ray like hit in one frame
+    return frames, base
+
+
+@pytest.mark.parametrize('kind', ['WEIGHTED', 'MEDIAN', 'CLIPPED', 'AVERAGE'])
+def test_combine_types_match_oracle(engine, kind):
+    z = pkg()
+    frames, wout = small_stack()
+    p = z.coadd_params(combine=kind, subtract_back=False, rescale_weights=False)
+    g_img, g_wgt, g_msk, g_mw = engine.coadd(frames, wout, p)
+    r_img, r_wgt, r_msk, vals, wgts = oracle_coadd(frames, wout, kind)
+    gv, rv = g_wgt > 0, r_wgt > 0
+    assert (gv != rv).mean() < 2e-4
+    both = gv & rv
+    # a sample sitting exactly on the clip boundary, or a validity flip of one
+    # sample, changes a pixel discretely: allow a 2e-4 fraction of such pixels
+    assert_close_masked(g_img[both], r_img[both], 3e-5, 3e-5 * 5.0, kind, max_bad_frac=2e-4)
+    assert_close_masked(g_wgt[both], r_wgt[both], 1e-4, 0, kind + ' weight', max_bad_frac=2e-4)
+    assert (g_msk != r_msk).mean() < 2e-4
+
+
+def test_clipping_rejects_the_outlier(engine):
+    z = pkg()
+    frames, wout = small_stack()
+    pc = z.coadd_params(combine='CLIPPED', subtract_back=False, rescale_weights=False)
+    pw = z.coadd_params(combine='WEIGHTED', subtract_back=False, rescale_weights=False)
+    c_img = engine.coadd(frames, wout, pc)[0]
+    w_img = engine.coadd(frames, wout, pw)[0]
+    clean = [dict(f) for f in frames]
+    clean[2] = dict(clean[2])
+    clean[2]['img'] = clean[2]['img'].copy()
+    clean[2]['img'][70:73, 80:83] -= 5000.0
+    ref = engine.coadd(clean, wout, pc)[0]
+    d_clip = np.abs(c_img - ref).max()
+    d_wgt = np.abs(w_img - ref).max()
+    assert d_wgt > 100.0          # the weighted mean is contaminated
+    assert d_clip < 5.0           # the clipped mean is not
+
+
+def test_identical_frames_coadd_to_the_frame(engine):
+    z = pkg()
+    s = synth()
+    f = s.make_frame(140, 130, 21, s.tan_wcs(140, 130), nbad=30)
+    frames = [f, f, f, f]
+    p = z.coadd_params(combine='CLIPPED', subtract_back=False, rescale_weights=False)
+    g_img, g_wgt, g_msk, g_mw = engine.coadd(frames, f['wcs'], p)
+    inner = (slice(2, -3), slice(2, -3))
+    good = f['wgt'][inner] > 0
+    np.testing.assert_allclose(g_img[inner][good], f['img'][inner][good], rtol=2e-6)
+    np.testing.assert_allclose(g_wgt[inner][good], 4 * f['wgt'][inner][good], rtol=2e-6)
+    assert np.array_equal(g_msk[inner], f['mask'][inner])
+    assert np.all(g_mw[inner] == 1) and np.all(g_mw[:2] == 0)
+
+
+def test_single_frame_clipped_is_identity_of_resample(engine):
+    # run_align uses COMBINE_TYPE CLIPPED on one image (zuds/swarp.py:141)
+    z = pkg()
+    frames, wout = small_stack(n=1, outlier=False)
+    p = z.coadd_params(combine='CLIPPED', subtract_back=False, rescale_weights=False)
+    g_img, g_wgt, _, _ = engine.coadd(frames, wout, p)
+    fs = engine.flux_scale(frames[0]['wcs'], wout, frames[0]['flxscale'])
+    r_img, r_wgt, _ = engine.resample(frames[0]['img'], frames[0]['wcs'], wout,
+                                      wgt=frames[0]['wgt'], fscale=fs)
+    assert np.array_equal(g_img, r_img)
+    np.testing.assert_allclose(g_wgt, r_wgt, rtol=1e-6)
+
+
+@pytest.mark.parametrize('n', [3, 9, 20, 40, 70])
+def test_stack_depths_use_every_kernel_variant(engine, n):
+    # register networks (4..64) and the deep LDS path (> 64)
+    z = pkg()
+    rng = np.random.default_rng(n)
+    ny, nx = 40, 50
+    vals = rng.normal(100, 10, (n, ny, nx)).astype(np.float32)
+    wgts = rng.uniform(0.01, 0.1, (n, ny, nx)).astype(np.float32)
+    wgts[rng.uniform(size=wgts.shape) < 0.2] = 0
+    vals[rng.uniform(size=vals.shape) < 0.03] += 500
+    wgts[:, 0, 0] = 0                       # a pixel with no valid sample
+    wgts[1:, 0, 1] = 0                      # a pixel with exactly one
+    for kind in ['MEDIAN', 'CLIPPED', 'WEIGHTED']:
+        g_img, g_wgt = engine.combine_stack(vals, wgts, z.coadd_params(combine=kind))
+        r_img, r_wgt, _ = ocombine.combine(vals, wgts, kind)
+        assert_close_masked(g_img, r_img, 2e-6, 1e-4, f'{kind} n={n}', max_bad_frac=1e-3)
+        assert_close_masked(g_wgt, r_wgt, 1e-5, 0, f'{kind} n={n} weight', max_bad_frac=1e-3)
+        assert g_img[0, 0] == 0 and g_wgt[0, 0] == 0
+
+
+def test_background_and_weight_rescale_in_the_coadd(engine):
+    z = pkg()
+    s = synth()
+    base = s.tan_wcs(300, 280)
+    frames = []
+    for i in range(3):
+        w = s.tan_wcs(300, 280, dx=1.5 * i, dy=-2.25 * i)
+        f = s.make_frame(300, 280, 40 + i, w, sky=150 + 20 * i, noise=5.0, nstars=30, nbad=50)
+        # a sky gradient the mesh background has to remove
+        yy, xx = np.mgrid[0:280, 0:300]
+        f['img'] = (f['img'] + 0.02 * xx + 0.01 * yy).astype(np.float32)
+        f['wgt'] = (f['wgt'] * 0.5).astype(np.float32)   # mis-scaled weights: var map says 50, truth is 25
+        frames.append(f)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True, back_size=64)
+    g_img, g_wgt, _, _ = engine.coadd(frames, base, p, want_mask=False)
+    r_img, r_wgt, _, _, _ = oracle_coadd(frames, base, 'WEIGHTED', True, True, mesh=64)
+    both = (g_wgt > 0) & (r_wgt > 0)
+    assert ((g_wgt > 0) != (r_wgt > 0)).mean() < 1e-4
+    assert_close_masked(g_img[both], r_img[both], 1e-4, 2e-3, 'bkg-subtracted coadd', max_bad_frac=1e-4)
+    assert_close_masked(g_wgt[both], r_wgt[both], 2e-3, 0, 'rescaled weights', max_bad_frac=1e-4)
+    # background is gone and the weights are back to the measured variance (3 / 25)
+    assert abs(np.median(g_img[both])) < 1.0
+    assert abs(np.median(g_wgt[both]) / (3 / 25.0) - 1) < 0.1

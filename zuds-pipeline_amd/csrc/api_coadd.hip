@@ -1,0 +1,302 @@
+// C-ABI entry points for resampling and co-addition (host- and device-pointer
+// flavours).  The host flavour copies borrowed numpy buffers to the device,
+// runs the device flavour on the ctx stream and copies the products back.
+#include <algorithm>
+#include <cmath>
+
+#include "zm_internal.h"
+#include "wcs_math.h"
+
+extern "C" void zm_coadd_params_default(zm_coadd_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->combine = ZM_COMBINE_CLIPPED;
+    p->mask_combine = ZM_MASK_AND;
+    p->resample = ZM_RESAMPLE_LANCZOS3;
+    p->subtract_back = 1;
+    p->back_size = 128;
+    p->back_filtersize = 3;
+    p->rescale_weights = 1;
+    p->clip_sigma = 4.0;
+    p->clip_ampfrac = 0.3;
+    p->weight_thresh = 1e-30;
+}
+
+static int check_wcs(const zm_wcs* w, const char* what) {
+    ZM_CHECK(w != nullptr, "%s: WCS is NULL", what);
+    ZM_CHECK(w->naxis[0] > 0 && w->naxis[1] > 0, "%s: NAXIS must be positive (got %d x %d)", what,
+             w->naxis[0], w->naxis[1]);
+    ZM_CHECK(w->naxis[0] <= 65536 && w->naxis[1] <= 65536, "%s: NAXIS too large", what);
+    double det = w->cd[0] * w->cd[3] - w->cd[1] * w->cd[2];
+    ZM_CHECK(det != 0.0 && std::isfinite(det), "%s: singular CD matrix", what);
+    return 0;
+}
+
+// LDS elements (float2) a 64 x 16 output tile needs: bound the footprint from the
+// map's Jacobian sampled over the output grid.
+static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
+    double wmax = 0, hmax = 0;
+    for (int sy = 0; sy < 3; ++sy)
+        for (int sx = 0; sx < 3; ++sx) {
+            double x = 1.0 + sx * 0.5 * (onx - 1), y = 1.0 + sy * 0.5 * (ony - 1);
+            double x0, y0, x1, y1, x2, y2;
+            zm_map_point(mp, x, y, &x0, &y0);
+            zm_map_point(mp, x + 64, y, &x1, &y1);
+            zm_map_point(mp, x, y + 16, &x2, &y2);
+            if (!std::isfinite(x0 + y0 + x1 + y1 + x2 + y2)) continue;
+            wmax = std::max(wmax, fabs(x1 - x0) + fabs(x2 - x0));
+            hmax = std::max(hmax, fabs(y1 - y0) + fabs(y2 - y0));
+        }
+    double w = ceil(wmax * 1.02) + ntaps + 6, h = ceil(hmax * 1.02) + ntaps + 5;
+    double e = w * h;
+    const int cap = 8000;   // 64,000 B + header < 64 KiB: no opt-in attribute needed
+    if (!(e > 0) || e > cap) return cap;
+    return (int)e;
+}
+
+static int ntaps_of(int kernel) {
+    return kernel == ZM_RESAMPLE_LANCZOS3 ? 6 : kernel == ZM_RESAMPLE_BILINEAR ? 2 : 1;
+}
+
+// Resample nframes device frames onto `wout` into `stack` (float2 [n][ony*onx]).
+// Also accumulates the mask coadd when acc_mask != NULL.
+static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
+                           const zm_coadd_params* P, float2* stack, int32_t* acc_mask,
+                           int32_t mask_fill, int mask_kind) {
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    const int64_t opix = (int64_t)onx * ony;
+    const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
+
+    std::vector<zm_map_params> mp_host(n);
+    std::vector<double> fscale(n);
+    std::vector<int> lds(n);
+    for (int i = 0; i < n; ++i) {
+        ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
+        zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
+        ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fscale[i]));
+        lds[i] = plan_lds(&mp_host[i], onx, ony, ntaps_of(P->resample));
+    }
+    double2* lat = nullptr;
+    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
+    for (int i = 0; i < n; ++i)
+        ZM_TRY(zm_launch_lattice(ctx, &mp_host[i], lnx, lny, lat + (size_t)i * lnx * lny));
+
+    int32_t* mtmp = nullptr;
+    if (acc_mask) ZM_TRY(ctx->get("mask_tmp", sizeof(int32_t) * opix, (void**)&mtmp));
+    bool first_mask = true;
+    for (int i = 0; i < n; ++i) {
+        const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1];
+        const int spitch = (nx + 1) & ~1;
+        float2* src = nullptr;
+        ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
+        float *bknodes = nullptr, *bstats = nullptr, *var_scale = nullptr;
+        int nbx = 0, nby = 0;
+        const float wthresh = (float)P->weight_thresh;
+        if (P->subtract_back || (P->rescale_weights && fr[i].wgt)) {
+            // everything stays on the device: no host round trip per frame
+            ZM_TRY(zm_frame_background(ctx, fr[i].img, fr[i].wgt, nx, ny, P->back_size,
+                                       P->back_filtersize, wthresh, 0, &bknodes, &bstats, &nbx,
+                                       &nby, "cbk"));
+            if (P->rescale_weights && fr[i].wgt) {
+                float *vnodes = nullptr, *vstats = nullptr;
+                int vx = 0, vy = 0;
+                ZM_TRY(zm_frame_background(ctx, nullptr, fr[i].wgt, nx, ny, P->back_size,
+                                           P->back_filtersize, wthresh, 1, &vnodes, &vstats, &vx,
+                                           &vy, "cvar"));
+                ZM_TRY(ctx->get("var_scale", 16, (void**)&var_scale));
+                ZM_TRY(zm_launch_var_scale(ctx, bstats, vstats, var_scale));
+            }
+            if (!P->subtract_back) bknodes = nullptr;
+        }
+        ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size,
+                              var_scale, wthresh, src, spitch));
+        ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat + (size_t)i * lnx * lny, lnx, lny,
+                                  P->resample, (float)fscale[i], stack + (size_t)i * opix, onx,
+                                  ony, lds[i]));
+        if (acc_mask && fr[i].mask) {
+            ZM_TRY(zm_launch_resample_mask(ctx, fr[i].mask, nx, ny, lat + (size_t)i * lnx * lny,
+                                           lnx, lny, P->resample, mtmp, onx, ony, mask_fill));
+            ZM_TRY(zm_launch_mask_accum(ctx, acc_mask, mtmp, opix, mask_kind, first_mask ? 1 : 0));
+            first_mask = false;
+        }
+    }
+    if (acc_mask && first_mask) ZM_HIP(hipMemsetAsync(acc_mask, 0xFF, sizeof(int32_t) * opix, ctx->stream));
+    return 0;
+}
+
+extern "C" int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
+                                     const zm_wcs* wout, const zm_coadd_params* params,
+                                     float* stack) {
+    ZM_CHECK(ctx && frames && wout && params && stack, "zm_resample_stack_dev: null argument");
+    ZM_CHECK(nframes >= 1, "zm_resample_stack_dev: need at least one frame");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    return resample_frames(ctx, nframes, frames, wout, params, (float2*)stack, nullptr, 0, 0);
+}
+
+extern "C" int zm_combine_stack_dev(zm_ctx* ctx, int nframes, const float* stack,
+                                    int64_t frame_stride_px, int64_t npix,
+                                    const zm_coadd_params* params, float* out_img,
+                                    float* out_wgt) {
+    ZM_CHECK(ctx && stack && params && out_img && out_wgt, "zm_combine_stack_dev: null argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    return zm_launch_combine(ctx, nframes, (const float2*)stack, frame_stride_px, npix,
+                             params->combine, (float)params->clip_sigma,
+                             (float)params->clip_ampfrac, out_img, out_wgt, 0);
+}
+
+extern "C" int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
+                            const zm_wcs* wout, const zm_coadd_params* params, int partial,
+                            float* out_img, float* out_wgt, int32_t* out_mask,
+                            float* out_mask_wgt) {
+    ZM_CHECK(ctx && frames && wout && params && out_img && out_wgt, "zm_coadd_dev: null argument");
+    ZM_CHECK(nframes >= 1, "zm_coadd_dev: need at least one frame");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    const int64_t opix = (int64_t)wout->naxis[0] * wout->naxis[1];
+    float2* stack = nullptr;
+    ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix * nframes, (void**)&stack));
+    ZM_TRY(resample_frames(ctx, nframes, frames, wout, params, stack, out_mask, -1,
+                           params->mask_combine));
+    ZM_TRY(zm_launch_combine(ctx, nframes, stack, opix, opix, params->combine,
+                             (float)params->clip_sigma, (float)params->clip_ampfrac, out_img,
+                             out_wgt, partial));
+    if (out_mask) ZM_TRY(zm_launch_mask_finalize(ctx, out_mask, out_mask_wgt, opix));
+    return 0;
+}
+
+extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
+                               const int32_t* mask, const zm_wcs* win, const zm_wcs* wout,
+                               int kernel, double fscale, float* out_img, float* out_wgt,
+                               int32_t* out_mask) {
+    ZM_CHECK(ctx && win && wout, "zm_resample_dev: null argument");
+    ZM_CHECK(img || mask, "zm_resample_dev: need an image or a mask");
+    ZM_CHECK(!img || (out_img && out_wgt), "zm_resample_dev: out_img/out_wgt required");
+    ZM_CHECK(!mask || out_mask, "zm_resample_dev: out_mask required");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(win, "input frame"));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    ZM_CHECK(kernel == ZM_RESAMPLE_LANCZOS3 || kernel == ZM_RESAMPLE_BILINEAR ||
+             kernel == ZM_RESAMPLE_NEAREST, "zm_resample_dev: unknown RESAMPLING_TYPE %d", kernel);
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    const int nx = win->naxis[0], ny = win->naxis[1];
+    const int64_t opix = (int64_t)onx * ony;
+    const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
+    zm_map_params mp_host;
+    zm_make_map(wout, win, &mp_host);
+    int lds = plan_lds(&mp_host, onx, ony, ntaps_of(kernel));
+    double2* lat = nullptr;
+    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny, (void**)&lat));
+    ZM_TRY(zm_launch_lattice(ctx, &mp_host, lnx, lny, lat));
+    if (img) {
+        const int spitch = (nx + 1) & ~1;
+        float2 *src = nullptr, *dst = nullptr;
+        ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
+        ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix, (void**)&dst));
+        ZM_TRY(zm_launch_prep(ctx, img, wgt, nx, ny, nullptr, 0, 0, 0, nullptr, 1e-30f, src, spitch));
+        ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, (float)fscale,
+                                  dst, onx, ony, lds));
+        ZM_TRY(zm_launch_split_pairs(ctx, dst, opix, out_img, out_wgt));
+    }
+    if (mask)
+        ZM_TRY(zm_launch_resample_mask(ctx, mask, nx, ny, lat, lnx, lny, kernel, out_mask, onx,
+                                       ony, 0));
+    return 0;
+}
+
+// ---- host-pointer flavours -------------------------------------------------------
+extern "C" int zm_resample(zm_ctx* ctx, const float* img, const float* wgt, const int32_t* mask,
+                           const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
+                           float* out_img, float* out_wgt, int32_t* out_mask) {
+    ZM_CHECK(ctx && win && wout, "zm_resample: null argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(win, "input frame"));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    const size_t ipix = (size_t)win->naxis[0] * win->naxis[1];
+    const size_t opix = (size_t)wout->naxis[0] * wout->naxis[1];
+    float *d_img = nullptr, *d_wgt = nullptr, *d_oimg = nullptr, *d_owgt = nullptr;
+    int32_t *d_mask = nullptr, *d_omask = nullptr;
+    if (img) {
+        ZM_TRY(ctx->get("h_img", ipix * 4, (void**)&d_img));
+        ZM_HIP(hipMemcpyAsync(d_img, img, ipix * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (wgt) {
+            ZM_TRY(ctx->get("h_wgt", ipix * 4, (void**)&d_wgt));
+            ZM_HIP(hipMemcpyAsync(d_wgt, wgt, ipix * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        ZM_TRY(ctx->get("h_oimg", opix * 4, (void**)&d_oimg));
+        ZM_TRY(ctx->get("h_owgt", opix * 4, (void**)&d_owgt));
+    }
+    if (mask) {
+        ZM_TRY(ctx->get("h_mask", ipix * 4, (void**)&d_mask));
+        ZM_HIP(hipMemcpyAsync(d_mask, mask, ipix * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZM_TRY(ctx->get("h_omask", opix * 4, (void**)&d_omask));
+    }
+    ZM_TRY(zm_resample_dev(ctx, d_img, d_wgt, d_mask, win, wout, kernel, fscale, d_oimg, d_owgt,
+                           d_omask));
+    if (img) {
+        ZM_HIP(hipMemcpyAsync(out_img, d_oimg, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZM_HIP(hipMemcpyAsync(out_wgt, d_owgt, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (mask)
+        ZM_HIP(hipMemcpyAsync(out_mask, d_omask, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int zm_coadd(zm_ctx* ctx, int nframes, const zm_frame* frames, const zm_wcs* wout,
+                        const zm_coadd_params* params, float* out_img, float* out_wgt,
+                        int32_t* out_mask, float* out_mask_wgt) {
+    ZM_CHECK(ctx && frames && wout && params && out_img && out_wgt, "zm_coadd: null argument");
+    ZM_CHECK(nframes >= 1, "zm_coadd: need at least one frame");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    std::vector<zm_dframe> df(nframes);
+    size_t total = 0;
+    for (int i = 0; i < nframes; ++i) {
+        ZM_TRY(check_wcs(&frames[i].wcs, "frame"));
+        ZM_CHECK(frames[i].img != nullptr, "zm_coadd: frame %d has no image", i);
+        size_t ip = (size_t)frames[i].wcs.naxis[0] * frames[i].wcs.naxis[1];
+        total += ip * 4 * (1 + (frames[i].wgt ? 1 : 0) + (frames[i].mask && out_mask ? 1 : 0));
+        total = (total + 255) & ~(size_t)255;
+    }
+    char* base = nullptr;
+    ZM_TRY(ctx->get("h_frames", total, (void**)&base));
+    size_t off = 0;
+    for (int i = 0; i < nframes; ++i) {
+        size_t ip = (size_t)frames[i].wcs.naxis[0] * frames[i].wcs.naxis[1];
+        df[i].wcs = frames[i].wcs;
+        df[i].flxscale = frames[i].flxscale;
+        df[i].img = (const float*)(base + off);
+        ZM_HIP(hipMemcpyAsync(base + off, frames[i].img, ip * 4, hipMemcpyHostToDevice, ctx->stream));
+        off += ip * 4;
+        df[i].wgt = nullptr;
+        if (frames[i].wgt) {
+            df[i].wgt = (const float*)(base + off);
+            ZM_HIP(hipMemcpyAsync(base + off, frames[i].wgt, ip * 4, hipMemcpyHostToDevice, ctx->stream));
+            off += ip * 4;
+        }
+        df[i].mask = nullptr;
+        if (frames[i].mask && out_mask) {
+            df[i].mask = (const int32_t*)(base + off);
+            ZM_HIP(hipMemcpyAsync(base + off, frames[i].mask, ip * 4, hipMemcpyHostToDevice, ctx->stream));
+            off += ip * 4;
+        }
+        off = (off + 255) & ~(size_t)255;
+    }
+    const size_t opix = (size_t)wout->naxis[0] * wout->naxis[1];
+    float *d_oimg = nullptr, *d_owgt = nullptr, *d_omw = nullptr;
+    int32_t* d_omask = nullptr;
+    ZM_TRY(ctx->get("h_oimg", opix * 4, (void**)&d_oimg));
+    ZM_TRY(ctx->get("h_owgt", opix * 4, (void**)&d_owgt));
+    if (out_mask) ZM_TRY(ctx->get("h_omask", opix * 4, (void**)&d_omask));
+    if (out_mask && out_mask_wgt) ZM_TRY(ctx->get("h_omw", opix * 4, (void**)&d_omw));
+    ZM_TRY(zm_coadd_dev(ctx, nframes, df.data(), wout, params, 0, d_oimg, d_owgt, d_omask, d_omw));
+    ZM_HIP(hipMemcpyAsync(out_img, d_oimg, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZM_HIP(hipMemcpyAsync(out_wgt, d_owgt, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_mask)
+        ZM_HIP(hipMemcpyAsync(out_mask, d_omask, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_mask && out_mask_wgt)
+        ZM_HIP(hipMemcpyAsync(out_mask_wgt, d_omw, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

@@ -1,0 +1,191 @@
+// Context, error string, scratch pool and HIP-event timers of libzudsmi.
+#include <cstdarg>
+
+#include "zm_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void zm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* zm_last_error(void) { return g_err; }
+extern "C" const char* zm_version(void) { return "zudsmi 0.1.0 (gfx950)"; }
+
+int zm_ctx::get(const char* name, size_t bytes, void** out) {
+    auto it = scratch.find(name);
+    if (it != scratch.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return 0;
+    }
+    if (it != scratch.end()) {
+        // the old buffer may still be in use by enqueued work
+        ZM_HIP(hipStreamSynchronize(stream));
+        ZM_HIP(hipFree(it->second.first));
+        scratch.erase(it);
+    }
+    void* p = nullptr;
+    size_t alloc = bytes + (bytes >> 3) + 256;
+    ZM_HIP(hipMalloc(&p, alloc));
+    scratch[name] = {p, alloc};
+    *out = p;
+    return 0;
+}
+
+int zm_ctx::get_pinned(const char* name, size_t bytes, void** out) {
+    auto it = pinned.find(name);
+    if (it != pinned.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return 0;
+    }
+    if (it != pinned.end()) {
+        ZM_HIP(hipStreamSynchronize(stream));
+        ZM_HIP(hipHostFree(it->second.first));
+        pinned.erase(it);
+    }
+    void* p = nullptr;
+    ZM_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    pinned[name] = {p, bytes};
+    *out = p;
+    return 0;
+}
+
+void zm_ctx::release_all() {
+    for (auto& kv : scratch) (void)hipFree(kv.second.first);
+    scratch.clear();
+    for (auto& kv : pinned) (void)hipHostFree(kv.second.first);
+    pinned.clear();
+    for (auto& kv : timers)
+        for (auto& p : kv.second.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    timers.clear();
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+    event_pool.clear();
+}
+
+extern "C" int zm_ctx_create(int device, zm_ctx** out) {
+    ZM_CHECK(out != nullptr, "zm_ctx_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        zm_set_error("zm_ctx_create: no HIP device available (%s)",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return 3;
+    }
+    ZM_CHECK(device >= 0 && device < ndev, "zm_ctx_create: device %d out of range [0,%d)",
+             device, ndev);
+    ZM_HIP(hipSetDevice(device));
+    zm_ctx* c = new zm_ctx();
+    c->device = device;
+    ZM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    *out = c;
+    return 0;
+}
+
+extern "C" int zm_ctx_destroy(zm_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->release_all();
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream) {
+    ZM_CHECK(ctx != nullptr, "zm_ctx_set_stream: ctx is NULL");
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    if (hip_stream == nullptr) {
+        if (!ctx->own_stream) {
+            ZM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            ctx->own_stream = true;
+        }
+        return 0;
+    }
+    if (ctx->own_stream && ctx->stream) ZM_HIP(hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+
+extern "C" int zm_ctx_synchronize(zm_ctx* ctx) {
+    ZM_CHECK(ctx != nullptr, "zm_ctx_synchronize: ctx is NULL");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- timers ---------------------------------------------------------------
+zm_scope_timer::zm_scope_timer(zm_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->timing) return;
+    auto take = [&]() -> hipEvent_t {
+        if (!ctx->event_pool.empty()) {
+            hipEvent_t e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    };
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+zm_scope_timer::~zm_scope_timer() {
+    if (!ctx->timing || !a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timers[name].pending.push_back({a, b});
+}
+
+extern "C" int zm_timing_enable(zm_ctx* ctx, int on) {
+    ZM_CHECK(ctx != nullptr, "zm_timing_enable: ctx is NULL");
+    ctx->timing = on != 0;
+    return 0;
+}
+
+static int drain(zm_ctx* ctx, zm_timer_slot& s) {
+    for (auto& p : s.pending) {
+        ZM_HIP(hipEventSynchronize(p.second));
+        float ms = 0.f;
+        ZM_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        s.total_ms += ms;
+        s.launches += 1;
+        ctx->event_pool.push_back(p.first);
+        ctx->event_pool.push_back(p.second);
+    }
+    s.pending.clear();
+    return 0;
+}
+
+extern "C" int zm_timing_reset(zm_ctx* ctx) {
+    ZM_CHECK(ctx != nullptr, "zm_timing_reset: ctx is NULL");
+    for (auto& kv : ctx->timers) {
+        ZM_TRY(drain(ctx, kv.second));
+        kv.second.total_ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return 0;
+}
+
+extern "C" int zm_timing_read(zm_ctx* ctx, const char* kernel_name, double* total_ms,
+                              int64_t* launches) {
+    ZM_CHECK(ctx && kernel_name && total_ms && launches, "zm_timing_read: null argument");
+    auto it = ctx->timers.find(kernel_name);
+    if (it == ctx->timers.end()) {
+        *total_ms = 0.0;
+        *launches = 0;
+        return 0;
+    }
+    ZM_TRY(drain(ctx, it->second));
+    *total_ms = it->second.total_ms;
+    *launches = it->second.launches;
+    return 0;
+}

@@ -1,0 +1,114 @@
+// Internal definitions shared by the libzudsmi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+#include "../../include/zudsmi.h"
+
+#define ZM_BIGVAR 1e30f      // variance of a bad pixel (finite: 0 * BIG == 0)
+#define ZM_BADVAR_TEST 1e14f // |interpolated variance| above this => a bad tap was hit
+#define ZM_SNAP 1e-5f        // SWarp: |frac| < 1e-5 => delta kernel
+
+void zm_set_error(const char* fmt, ...);
+
+#define ZM_HIP(call)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) {                                              \
+            zm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                \
+            return 1;                                                        \
+        }                                                                    \
+    } while (0)
+
+#define ZM_CHECK(cond, ...)                                                  \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            zm_set_error(__VA_ARGS__);                                       \
+            return 2;                                                        \
+        }                                                                    \
+    } while (0)
+
+#define ZM_TRY(expr)                                                         \
+    do {                                                                     \
+        int r_ = (expr);                                                     \
+        if (r_) return r_;                                                   \
+    } while (0)
+
+struct zm_timer_slot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct zm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    // grow-only named scratch buffers on the device
+    std::map<std::string, std::pair<void*, size_t>> scratch;
+    // pinned host staging
+    std::map<std::string, std::pair<void*, size_t>> pinned;
+    bool timing = false;
+    std::map<std::string, zm_timer_slot> timers;
+    std::vector<hipEvent_t> event_pool;
+
+    int get(const char* name, size_t bytes, void** out);
+    int get_pinned(const char* name, size_t bytes, void** out);
+    void release_all();
+};
+
+// RAII-ish helper: record start/stop events around a launch when timing is on.
+struct zm_scope_timer {
+    zm_ctx* ctx;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    zm_scope_timer(zm_ctx* c, const char* n);
+    ~zm_scope_timer();
+};
+
+static inline int zm_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device-side plans -------------------------------------------------------
+#define ZM_LATTICE_STEP 16
+
+struct zm_map_params {   // everything a lattice node needs, fp64
+    zm_wcs wout;
+    zm_wcs win;
+    double rot[9];       // in-frame axes expressed in the out-frame basis
+};
+
+// host helpers (wcs_host.cpp)
+void zm_wcs_frame(const zm_wcs* w, double fr[9]);
+void zm_make_map(const zm_wcs* wout, const zm_wcs* win, zm_map_params* mp);
+void zm_map_point(const zm_map_params* mp, double xo, double yo, double* xi, double* yi);
+double zm_pixel_area(const zm_wcs* w, double x, double y);
+
+// kernels / launchers (each in its own .hip)
+int zm_launch_lattice(zm_ctx* ctx, const zm_map_params* mp, int lnx, int lny, double2* lat_dev);
+int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
+                   const float* bknodes, int nbx, int nby, int mesh,
+                   const float* var_scale_dev, float wthresh, float2* dst, int spitch);
+int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
+                        int mesh, int fsize, float wthresh, int mode, float** nodes_dev,
+                        float** stats_dev, int* nbx_out, int* nby_out, const char* slot);
+int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out);
+int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
+                       const double2* lat, int lnx, int lny, int kernel, float fscale,
+                       float2* dst, int onx, int ony, int lds_elems);
+int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny,
+                            const double2* lat, int lnx, int lny, int kernel,
+                            int32_t* dst, int onx, int ony, int32_t fill);
+int zm_launch_combine(zm_ctx* ctx, int n, const float2* stack, int64_t frame_stride,
+                      int64_t npix, int kind, float clip_sigma, float clip_ampfrac,
+                      float* out_img, float* out_wgt, int partial);
+int zm_launch_mask_accum(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix, int kind,
+                         int first);
+int zm_launch_mask_finalize(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
+int zm_launch_split_pairs(zm_ctx* ctx, const float2* src, int64_t npix, float* a, float* b);

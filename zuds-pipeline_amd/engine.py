@@ -1,0 +1,222 @@
+"""numpy-facing wrapper of the libzudsmi context.
+
+One ``Engine`` per process/GPU.  Every method goes through the C-ABI
+(``include/zudsmi.h``); inputs are borrowed numpy arrays, outputs are fresh
+numpy arrays.  This is the edge that replaces ``subprocess.check_call`` on
+SWarp / SExtractor / hotpants in the reference (``zuds/coadd.py:133,156``,
+``zuds/swarp.py:175``, ``zuds/sextractor.py:128``, ``zuds/subtraction.py:162``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (COMBINE, MASKCOMB, RESAMPLE, as_f32, as_i32, check, ptr,
+                   wcs_struct)
+
+_default = None
+
+
+def get_engine(device=0):
+    """Process-wide engine (created on first use)."""
+    global _default
+    if _default is None:
+        _default = Engine(device)
+    return _default
+
+
+def _enum(table, v, what):
+    if isinstance(v, int):
+        return v
+    try:
+        return table[str(v).upper()]
+    except KeyError:
+        raise ValueError(f'unknown {what} "{v}"; expected one of {list(table)}')
+
+
+def coadd_params(combine='CLIPPED', mask_combine='AND', resample='LANCZOS3',
+                 subtract_back=True, back_size=128, back_filtersize=3,
+                 rescale_weights=True, clip_sigma=4.0, clip_ampfrac=0.3,
+                 weight_thresh=1e-30):
+    """zm_coadd_params with the values of default.swarp / mask.swarp."""
+    p = _lib.zm_coadd_params()
+    _lib.lib().zm_coadd_params_default(C.byref(p))
+    p.combine = _enum(COMBINE, combine, 'COMBINE_TYPE')
+    p.mask_combine = _enum(MASKCOMB, mask_combine, 'mask COMBINE_TYPE')
+    p.resample = _enum(RESAMPLE, resample, 'RESAMPLING_TYPE')
+    p.subtract_back = int(bool(subtract_back))
+    p.back_size = int(back_size)
+    p.back_filtersize = int(back_filtersize)
+    p.rescale_weights = int(bool(rescale_weights))
+    p.clip_sigma = float(clip_sigma)
+    p.clip_ampfrac = float(clip_ampfrac)
+    p.weight_thresh = float(weight_thresh)
+    return p
+
+
+class Engine(object):
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        self._ctx = C.c_void_p()
+        check(self.L.zm_ctx_create(int(device), C.byref(self._ctx)),
+              'zm_ctx_create')
+        self.device = int(device)
+
+    def close(self):
+        if self._ctx:
+            self.L.zm_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def synchronize(self):
+        check(self.L.zm_ctx_synchronize(self._ctx))
+
+    def set_stream(self, stream_handle):
+        check(self.L.zm_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)))
+
+    # -- timing ----------------------------------------------------------------
+    def timing(self, on=True):
+        check(self.L.zm_timing_enable(self._ctx, int(on)))
+
+    def timing_reset(self):
+        check(self.L.zm_timing_reset(self._ctx))
+
+    def timing_read(self, name):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(self.L.zm_timing_read(self._ctx, name.encode(), C.byref(ms),
+                                    C.byref(n)))
+        return ms.value, n.value
+
+    # -- resample ---------------------------------------------------------------
+    def resample(self, img, win, wout, wgt=None, mask=None, kernel='LANCZOS3',
+                 fscale=1.0):
+        """Resample ``img`` (+weight, +mask) from WCS ``win`` onto ``wout``.
+
+        Returns (out_img, out_wgt, out_mask); entries are None when the
+        corresponding input was None."""
+        sin, sout = wcs_struct(win), wcs_struct(wout)
+        ny, nx = (img if img is not None else mask).shape
+        if (sin.naxis[0], sin.naxis[1]) != (nx, ny):
+            raise ValueError(f'input WCS NAXIS {tuple(sin.naxis)} does not match '
+                             f'data shape {(ny, nx)}')
+        onx, ony = sout.naxis[0], sout.naxis[1]
+        img = as_f32(img)
+        wgt = as_f32(wgt)
+        mask = as_i32(mask)
+        oimg = owgt = omask = None
+        if img is not None:
+            oimg = np.empty((ony, onx), dtype=np.float32)
+            owgt = np.empty((ony, onx), dtype=np.float32)
+        if mask is not None:
+            omask = np.empty((ony, onx), dtype=np.int32)
+        check(self.L.zm_resample(self._ctx, ptr(img), ptr(wgt), ptr(mask),
+                                 C.byref(sin), C.byref(sout),
+                                 _enum(RESAMPLE, kernel, 'RESAMPLING_TYPE'),
+                                 float(fscale), ptr(oimg), ptr(owgt),
+                                 ptr(omask)), 'zm_resample')
+        return oimg, owgt, omask
+
+    # -- coadd -------------------------------------------------------------------
+    def coadd(self, frames, wout, params=None, want_mask=True):
+        """frames: list of dicts {img, wgt (or None), mask (or None), wcs,
+        flxscale}.  Returns (img, wgt, mask, mask_wgt)."""
+        if params is None:
+            params = coadd_params()
+        n = len(frames)
+        if n == 0:
+            raise ValueError('coadd needs at least one frame')
+        arr = (_lib.zm_frame * n)()
+        keep = []
+        any_mask = False
+        for i, f in enumerate(frames):
+            img = as_f32(f['img'])
+            wgt = as_f32(f.get('wgt'))
+            msk = as_i32(f.get('mask'))
+            keep += [img, wgt, msk]
+            s = wcs_struct(f['wcs'])
+            if (s.naxis[1], s.naxis[0]) != img.shape:
+                raise ValueError(f'frame {i}: WCS NAXIS {tuple(s.naxis)} does not '
+                                 f'match data shape {img.shape}')
+            arr[i].img = ptr(img)
+            arr[i].wgt = ptr(wgt)
+            arr[i].mask = ptr(msk)
+            arr[i].wcs = s
+            arr[i].flxscale = float(f.get('flxscale', 1.0))
+            any_mask |= msk is not None
+        sout = wcs_struct(wout)
+        onx, ony = sout.naxis[0], sout.naxis[1]
+        oimg = np.empty((ony, onx), dtype=np.float32)
+        owgt = np.empty((ony, onx), dtype=np.float32)
+        omask = omw = None
+        if want_mask and any_mask:
+            omask = np.empty((ony, onx), dtype=np.int32)
+            omw = np.empty((ony, onx), dtype=np.float32)
+        check(self.L.zm_coadd(self._ctx, n, arr, C.byref(sout), C.byref(params),
+                              ptr(oimg), ptr(owgt), ptr(omask), ptr(omw)),
+              'zm_coadd')
+        return oimg, owgt, omask, omw
+
+    def autogrid(self, wcss):
+        n = len(wcss)
+        arr = (_lib.zm_wcs * n)(*[wcs_struct(w) for w in wcss])
+        out = _lib.zm_wcs()
+        check(self.L.zm_autogrid(n, arr, C.byref(out)), 'zm_autogrid')
+        from .wcs import WCS
+        return WCS.from_struct(out)
+
+    def flux_scale(self, win, wout, flxscale=1.0):
+        v = C.c_double()
+        a, b = wcs_struct(win), wcs_struct(wout)
+        check(self.L.zm_flux_scale(C.byref(a), C.byref(b), float(flxscale),
+                                   C.byref(v)))
+        return v.value
+
+    # -- combine a host stack (tests, row-band exchange) ------------------------------
+    def combine_stack(self, vals, wgts, params=None):
+        """Combine host arrays vals, wgts of shape (n, ny, nx) on the device."""
+        import ctypes as C
+        from . import hipmem
+        if params is None:
+            params = coadd_params()
+        vals = as_f32(vals)
+        wgts = as_f32(wgts)
+        n = vals.shape[0]
+        npix = int(np.prod(vals.shape[1:]))
+        pairs = np.ascontiguousarray(np.stack([vals.reshape(n, npix),
+                                               wgts.reshape(n, npix)], axis=-1))
+        d_stack = hipmem.DeviceBuffer(pairs.nbytes)
+        d_img = hipmem.DeviceBuffer(npix * 4)
+        d_wgt = hipmem.DeviceBuffer(npix * 4)
+        d_stack.upload(pairs)
+        check(self.L.zm_combine_stack_dev(self._ctx, n, d_stack.ptr, npix, npix,
+                                          C.byref(params), d_img.ptr, d_wgt.ptr),
+              'zm_combine_stack_dev')
+        self.synchronize()
+        oimg = d_img.download(np.float32, vals.shape[1:])
+        owgt = d_wgt.download(np.float32, vals.shape[1:])
+        return oimg, owgt
+
+    # -- mesh background -----------------------------------------------------------------
+    def background(self, img, wgt=None, mesh=128, filtersize=3, want=('bkg', 'rms', 'sub')):
+        """(bkg, rms, sub, (backmean, backsig)); entries not in ``want`` are None."""
+        img = as_f32(img)
+        wgt = as_f32(wgt)
+        ny, nx = img.shape
+        out = {k: (np.empty((ny, nx), dtype=np.float32) if k in want else None)
+               for k in ('bkg', 'rms', 'sub')}
+        stats = (C.c_double * 2)()
+        check(self.L.zm_background(self._ctx, ptr(img), ptr(wgt), nx, ny, int(mesh),
+                                   int(filtersize), ptr(out['bkg']), ptr(out['rms']),
+                                   ptr(out['sub']), stats), 'zm_background')
+        return out['bkg'], out['rms'], out['sub'], (stats[0], stats[1])
