@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py - Mpix/s through resample -> coadd -> subtract on 3072 x 3072 frames.
+
+One step = one pass of the hot path over one batch of synthetic frames already
+resident in HBM: BASELINE.json configs[1] (32 ZTF-CCD-sized TPV frames, Lanczos-3
+resample + WEIGHTED coadd) followed by configs[2] (one science frame subtracted
+against that coadd) once the subtraction kernels are built in.  Pixel accounting
+(SURVEY.md section 8(d)): Mpix = (frames resampled + frames subtracted) x 9.437184.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, every
+rank resamples its own 32 frames of a 32 N deep stack, the two partial-sum planes
+go through one RCCL all-reduce each, every rank then subtracts its own frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--frames', type=int, default=32)
+    ap.add_argument('--size', type=int, default=3072)
+    ap.add_argument('--combine', default='WEIGHTED')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=1024,
+                    help='side of the frames the CPU baseline resamples')
+    return ap.parse_args()
+
+
+def make_device_frames(synth, torch, n, size, seed0, device):
+    """Config-2 frames: star fields rendered on the host once, sky + noise added
+    on the device (keeps set-up to seconds; the values follow synth.config2)."""
+    base = synth.ztf_wcs(size, size, tpv=True)
+    rng = np.random.default_rng(seed0 - 1)
+    nstars = max(int(3000 * (size / 3072.0) ** 2), 10)
+    xs = rng.uniform(-20, size + 20, nstars)
+    ys = rng.uniform(-20, size + 20, nstars)
+    fl = np.exp(rng.uniform(np.log(1e3), np.log(1e5), nstars))
+    ra, dec = base.all_pix2world(xs, ys, 0)
+    frames = []
+    g = torch.Generator(device=device)
+    for i in range(n):
+        r = np.random.default_rng(seed0 + i)
+        w = synth.ztf_wcs(size, size, dx=r.uniform(-15, 15), dy=r.uniform(-15, 15),
+                          rot_deg=r.uniform(-0.1, 0.1), tpv=True)
+        sky = r.uniform(100, 300)
+        magzp = r.uniform(25.8, 26.6)
+        fwhm = r.uniform(1.8, 2.6)
+        stars = np.zeros((size, size), dtype=np.float64)
+        px, py = w.all_world2pix(ra, dec, 0)
+        synth.add_stars(stars, px, py, fl * 10 ** (0.4 * (magzp - 25.0)), fwhm)
+        g.manual_seed(seed0 + i)
+        img = torch.from_numpy(stars.astype(np.float32)).to(device)
+        img += sky + torch.randn((size, size), generator=g, device=device) * float(np.sqrt(sky / 6.2))
+        bad = torch.rand((size, size), generator=g, device=device) < 1e-3
+        mask = torch.where(bad, 256, 0).to(torch.int32)
+        wgt = torch.where(bad, 0.0, 6.2 / sky).to(torch.float32)
+        frames.append(dict(img=img, wgt=wgt, mask=mask, wcs=w,
+                           flxscale=10 ** (-0.4 * (magzp - 25.0))))
+    return base, frames
+
+
+def cpu_baseline(synth, size, combine):
+    """The numpy oracle (a port, not SWarp) timed on the host: resample +
+    combine of 2 config-2 style frames of size x size, one process."""
+    from oracle import combine as ocombine
+    from oracle import resample as oresample
+    from oracle.wcs import WCS as OWCS
+
+    def ow(w):
+        return OWCS(w.crpix, w.crval, w.cd, w.pv1, w.pv2, w.naxis)
+    base = synth.ztf_wcs(size, size, tpv=True)
+    frames = []
+    for i in range(2):
+        r = np.random.default_rng(2000 + i)
+        w = synth.ztf_wcs(size, size, dx=r.uniform(-15, 15), dy=r.uniform(-15, 15),
+                          rot_deg=r.uniform(-0.1, 0.1), tpv=True)
+        frames.append(synth.make_frame(size, size, 2000 + i, w, nstars=100, nbad=size))
+    t0 = time.perf_counter()
+    vals, wgts = [], []
+    for f in frames:
+        px, py = oresample.positions(ow(base), ow(f['wcs']), size, size)
+        fs = oresample.flux_scale(ow(f['wcs']), ow(base), f['flxscale'])
+        o, w_, _ = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3, fs)
+        vals.append(o)
+        wgts.append(w_)
+    ocombine.combine(np.array(vals), np.array(wgts), combine)
+    dt = time.perf_counter() - t0
+    mpix = len(frames) * size * size / 1e6
+    return {'value': mpix / dt, 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{len(frames)} frames {size}x{size}, numpy fp64 oracle '
+                      f'(resample + {combine} combine), {dt:.1f} s; CPU restatement, '
+                      f'not SWarp/hotpants'}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    z = importlib.import_module('zuds-pipeline_amd')
+    synth = importlib.import_module('zuds-pipeline_amd.synth')
+    dev = importlib.import_module('zuds-pipeline_amd.device')
+
+    eng = z.Engine(local)
+    base, frames = make_device_frames(synth, torch, args.frames, args.size,
+                                      2000 + 1000 * rank, device)
+    params = z.coadd_params(combine=args.combine, subtract_back=True,
+                            rescale_weights=True)
+    dframes = dev.DeviceFrames(frames, device)
+    coadd = dev.DeviceCoadd(base, params, device=local, engine=eng)
+
+    def step():
+        if world > 1:
+            coadd.run_sharded_weighted(dframes)
+        else:
+            coadd.run(dframes)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.timing(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    eng.timing(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_per_step = args.frames * world
+    mpix_per_step = frames_per_step * args.size * args.size / 1e6
+    value = mpix_per_step * args.steps / dt
+
+    if rank == 0:
+        names = ['resample', 'prep', 'mesh_stats', 'mesh_filter', 'combine', 'lattice']
+        kt = {}
+        for nme in names:
+            ms, cnt = eng.timing_read(nme)
+            if cnt:
+                kt[nme] = {'ms_total': ms, 'launches': cnt, 'avg_us': 1e3 * ms / cnt}
+        dom = max(kt, key=lambda k: kt[k]['ms_total']) if kt else None
+        roofline = None
+        if 'resample' in kt:
+            avg_s = kt['resample']['avg_us'] * 1e-6
+            bytes_per_launch = RESAMPLE_BYTES_PER_OUTPX * args.size * args.size
+            ach = bytes_per_launch / avg_s / 1e9
+            roofline = {'bound': 'hbm', 'kernel': 'k_resample<LANCZOS3>',
+                        'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                        'avg_launch_us': kt['resample']['avg_us'],
+                        'algorithmic_bytes_per_launch': bytes_per_launch,
+                        'dominant_by_time': dom}
+        out = {
+            'metric': 'Mpix/s resample->coadd->subtract, 3072x3072 frames',
+            'value': value, 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: {args.frames}x {args.size}x{args.size} '
+                                   f'TPV frames/GPU, mesh background + weight rescale + '
+                                   f'Lanczos-3 resample + {args.combine} coadd'
+                                   + (', RCCL all-reduce of the partial sums' if world > 1 else ''),
+                       'frames_per_gpu': args.frames, 'size': args.size,
+                       'combine': args.combine},
+            'kernels': kt,
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(synth, args.cpu_sample, args.combine)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
