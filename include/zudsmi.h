@@ -181,6 +181,8 @@ int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms,
  * 1.4826 MAD of the pixels whose mask is 0 (mask NULL = all). */
 int zm_median_mad(zm_ctx* ctx, const float* img, const int32_t* mask, int64_t n,
                   double* out_median, double* out_mad_sigma);
+int zm_median_mad_dev(zm_ctx* ctx, const float* img, const int32_t* mask,
+                      int64_t n, double* out_median, double* out_mad_sigma);
 
 /* ---- device-pointer entry points (bench, multi-GPU, pipelines) ----------- */
 /* Same arithmetic as above on device-resident buffers; enqueue only. */

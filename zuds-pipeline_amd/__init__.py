@@ -8,6 +8,6 @@ shim at the repository root (``import zuds_amd as zuds``).
 from . import _lib
 from ._lib import ZMError
 from .wcs import WCS
-from .engine import Engine, get_engine, coadd_params
+from .engine import Engine, get_engine, coadd_params, hp_params
 
-__all__ = ['ZMError', 'WCS', 'Engine', 'get_engine', 'coadd_params']
+__all__ = ['ZMError', 'WCS', 'Engine', 'get_engine', 'coadd_params', 'hp_params']

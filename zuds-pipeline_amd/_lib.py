@@ -114,6 +114,8 @@ _SIGS = {
                                   C.POINTER(zm_hp_info)]),
     'zm_median_mad': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
+    'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
     'zm_timing_enable': (C.c_int, [_P, C.c_int]),
     'zm_timing_reset': (C.c_int, [_P]),
     'zm_timing_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double),

@@ -1,0 +1,1101 @@
+// Alard-Lupton kernel fit + spatially varying convolution + subtraction on gfx950.
+//
+// Replaces the hotpants process the reference launches from
+// zuds/subtraction.py:162 with the flags of zuds/hotpants.py:77-93
+// (-c t -n i, -r, -rss, -nsx/-nsy, -nrx/-nry, -ko, -bgo, -tni/-ini, -imi, -oni,
+// -fin).  Algorithm and every convention: oracle/hotpants.py.
+//
+// Data flow (all device resident, fp64 for the fit, fp32 for the convolution)
+//   k_hp_valid      bad[P] (u8) from bpm and the -tl/-tu/-il/-iu ranges
+//   k_hp_rowany / k_hp_colany   separable (2 hw + 1)^2 dilations of `bad`
+//   k_hp_cells      one workgroup per stamp cell: clipped sky/sigma, greedy
+//                   brightest-first substamp centres (argmax reductions)
+//   k_hp_vectors    one workgroup per cell: separable basis convolutions of the
+//                   template patch held in LDS -> X [nX][npix] fp64
+//   k_hp_gram       one workgroup per cell: G = X X^T on v_mfma_f64_16x16x4_f64
+//                   (the normal-equation GEMM; LDS-staged operands)
+//   k_hp_build      global normal matrix of a region from the per-cell Grams
+//   k_chol_*        blocked Cholesky (NB = 32), forward / back substitution
+//   k_hp_merit / k_hp_reject    stamp figure of merit, sigma clip, next substamp
+//   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
+//                   fp32 convolution of template and template variance
+#include <algorithm>
+#include <cmath>
+
+#include "zm_internal.h"
+
+#define HP_MAXX 64        // rows of the Gram tile (nc + nbg + 1 <= 64)
+#define HP_MAXPOLY 28     // (ko + 1)(ko + 2) / 2 for ko <= 6
+#define HP_MAXNSS 8
+#define HP_MAXREG 64
+#define HP_MAXF1 32       // distinct 1-D filters
+#define CH_NB 32
+#define HP_RIDGE 1e-10
+
+struct hp_plan {
+    int nx, ny, hwk, hwss, hw, step, sw, npix, npixp, pw;   // sw = 2 hwss + 1, pw = 2 hw + 1
+    int nc, nbg, nE, nX, nkp, nunk, ko, bgo;
+    int nrx, nry, nsx, nsy, nss, nreg, ncellr, ncell, nf1;
+    int normalize;
+    double tu, tl, iu, il, ft, ks;
+    float fi, fin;
+    int rx0[HP_MAXREG], rx1[HP_MAXREG], ry0[HP_MAXREG], ry1[HP_MAXREG];
+    // basis term tables
+    int tfx[HP_MAXX], tfy[HP_MAXX], tsub0[HP_MAXX];
+    double tscale[HP_MAXX];
+    int kpi[HP_MAXPOLY], kpj[HP_MAXPOLY];   // kernel spatial terms x^i y^j
+    int bpi[16], bpj[16];                   // background terms
+};
+
+// ---------------------------------------------------------------------------
+__global__ void k_hp_valid(const float* __restrict__ sci, const float* __restrict__ ref,
+                           const uint8_t* __restrict__ bpm, int64_t n, float il, float iu,
+                           float tl, float tu, uint8_t* __restrict__ bad) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float s = sci[p], t = ref[p];
+    bool ok = (s == s) && (t == t) && fabsf(s) < 3e38f && fabsf(t) < 3e38f;
+    ok = ok && s >= il && s <= iu && t >= tl && t <= tu;
+    if (bpm) ok = ok && bpm[p] == 0;
+    bad[p] = ok ? 0 : 1;
+}
+
+__global__ void k_hp_rowany(const uint8_t* __restrict__ in, int nx, int ny, int hw,
+                            uint8_t* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const uint8_t* row = in + (size_t)y * nx;
+    int a = max(x - hw, 0), b = min(x + hw, nx - 1);
+    uint8_t v = 0;
+    for (int i = a; i <= b; ++i) v |= row[i];
+    out[(size_t)y * nx + x] = v;
+}
+
+__global__ void k_hp_colany(const uint8_t* __restrict__ in, int nx, int ny, int hw, int edge,
+                            uint8_t* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    int a = max(y - hw, 0), b = min(y + hw, ny - 1);
+    uint8_t v = 0;
+    for (int j = a; j <= b; ++j) v |= in[(size_t)j * nx + x];
+    if (edge && (x < hw || x >= nx - hw || y < hw || y >= ny - hw)) v = 1;
+    out[(size_t)y * nx + x] = v;
+}
+
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ inline double block_sum256(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup per stamp cell.  centres[cell * nss + k] = (x, y) or (-1, -1).
+__global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* __restrict__ ref,
+                                                  const uint8_t* __restrict__ bad,
+                                                  const uint8_t* __restrict__ dirty,
+                                                  int2* __restrict__ centres) {
+    __shared__ double red[4];
+    __shared__ float bval[4];
+    __shared__ int bidx[4];
+    __shared__ int2 chosen[HP_MAXNSS];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    const int r = cell / P.ncellr, c = cell - r * P.ncellr;
+    const int sy = c / P.nsx, sx = c - sy * P.nsx;
+    const int cw = (P.rx1[r] - P.rx0[r]) / P.nsx, ch = (P.ry1[r] - P.ry0[r]) / P.nsy;
+    const int cx0 = P.rx0[r] + sx * cw, cy0 = P.ry0[r] + sy * ch;
+    const int n = cw * ch;
+    // clipped moments of the valid template pixels (oracle: clipped_moments)
+    double m = 0.0, s = 0.0;
+    for (int pass = 0; pass < 4; ++pass) {
+        double s0 = 0, s1 = 0;
+        for (int k = tid; k < n; k += 256) {
+            int yy = k / cw, xx = k - yy * cw;
+            size_t idx = (size_t)(cy0 + yy) * P.nx + cx0 + xx;
+            if (bad[idx]) continue;
+            double v = ref[idx];
+            if (pass == 0 || fabs(v - m) <= 3.0 * s) { s0 += 1.0; s1 += v; }
+        }
+        s0 = block_sum256(s0, red);
+        s1 = block_sum256(s1, red);
+        if (s0 < 1.0) break;
+        double mn = s1 / s0;
+        double s2 = 0;
+        for (int k = tid; k < n; k += 256) {
+            int yy = k / cw, xx = k - yy * cw;
+            size_t idx = (size_t)(cy0 + yy) * P.nx + cx0 + xx;
+            if (bad[idx]) continue;
+            double v = ref[idx];
+            if (pass == 0 || fabs(v - m) <= 3.0 * s) s2 += (v - mn) * (v - mn);
+        }
+        s2 = block_sum256(s2, red);
+        m = mn;
+        s = sqrt(s2 / s0);
+    }
+    const double thr = m + P.ft * s;
+    for (int k = 0; k < P.nss; ++k) {
+        float best = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int q = tid; q < n; q += 256) {
+            int yy = q / cw, xx = q - yy * cw;
+            int x = cx0 + xx, y = cy0 + yy;
+            size_t idx = (size_t)y * P.nx + x;
+            if (dirty[idx]) continue;
+            float v = ref[idx];
+            if (!((double)v >= thr)) continue;
+            bool excl = false;
+            for (int e = 0; e < k; ++e)
+                excl |= (abs(x - chosen[e].x) <= P.hwss) && (abs(y - chosen[e].y) <= P.hwss);
+            if (excl) continue;
+            if (v > best || (v == best && q < bi)) { best = v; bi = q; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { bval[tid >> 6] = best; bidx[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (bval[w] > best || (bval[w] == best && bidx[w] < bi)) { best = bval[w]; bi = bidx[w]; }
+            int2 cc = make_int2(-1, -1);
+            if (bi != 0x7fffffff) { int yy = bi / cw; cc = make_int2(cx0 + bi - yy * cw, cy0 + yy); }
+            chosen[k] = cc;
+            centres[cell * P.nss + k] = cc;
+        }
+        __syncthreads();
+        if (chosen[k].x < 0) {   // nothing left: the remaining slots are empty too
+            if (tid == 0)
+                for (int e = k + 1; e < P.nss; ++e) centres[cell * P.nss + e] = make_int2(-1, -1);
+            break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-cell state: active[cell] = index of the substamp in use (-1: none),
+// need[cell] = vectors / Gram must be (re)computed this round.
+// X layout: [cell][nX][npixp] fp64, rows 0..nc-1 kernel vectors, nc..nE-1
+// background terms, nE the science pixels; columns >= npix are zero.
+__global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
+                                                    const float* __restrict__ ref,
+                                                    const float* __restrict__ srms,
+                                                    const float* __restrict__ trms,
+                                                    const double* __restrict__ filt,   // [nf1][step]
+                                                    const int2* __restrict__ centres,
+                                                    const int* __restrict__ active,
+                                                    const int* __restrict__ need,
+                                                    double* __restrict__ X,
+                                                    double* __restrict__ phi,         // [cell][nkp]
+                                                    double* __restrict__ vbar) {
+    extern __shared__ double hp_smem[];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    if (!need[cell]) return;
+    const int act = active[cell];
+    if (act < 0) return;
+    const int2 cc = centres[cell * P.nss + act];
+    const int r = cell / P.ncellr;
+    const int pw = P.pw, sw = P.sw, hwk = P.hwk, hwss = P.hwss, step = P.step;
+    double* xp = hp_smem;                               // [pw][sw]
+    double* w0 = xp + (size_t)pw * sw;                  // [npix]
+    double* fl = w0 + P.npix;                           // [nf1][step]
+    double* red = fl + P.nf1 * step;                    // [4]
+    float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pw]
+    for (int k = tid; k < P.nf1 * step; k += 256) fl[k] = filt[k];
+    for (int k = tid; k < pw * pw; k += 256) {
+        int yy = k / pw, xx = k - yy * pw;
+        patch[k] = ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)];
+    }
+    const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
+    const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
+    double* Xc = X + (size_t)cell * P.nX * P.npixp;
+    // science row, background rows, variance mean, zero padding
+    double vs = 0.0;
+    for (int k = tid; k < P.npixp; k += 256) {
+        if (k < P.npix) {
+            int i = k / sw, j = k - i * sw;
+            int x = cc.x - hwss + j, y = cc.y - hwss + i;
+            size_t idx = (size_t)y * P.nx + x;
+            Xc[(size_t)P.nE * P.npixp + k] = (double)sci[idx];
+            double a = srms[idx], b = trms[idx];
+            vs += a * a + b * b;
+            double xf = (x - xc) / hx, yf = (y - yc) / hy;
+            for (int q = 0; q < P.nbg; ++q)
+                Xc[(size_t)(P.nc + q) * P.npixp + k] = pow(xf, (double)P.bpi[q]) * pow(yf, (double)P.bpj[q]);
+        } else {
+            for (int q = 0; q < P.nX; ++q) Xc[(size_t)q * P.npixp + k] = 0.0;
+        }
+    }
+    vs = block_sum256(vs, red);
+    if (tid == 0) {
+        vbar[cell] = vs / P.npix;
+        double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
+        for (int p = 0; p < P.nkp; ++p)
+            phi[(size_t)cell * P.nkp + p] = pow(fx, (double)P.kpi[p]) * pow(fy, (double)P.kpj[p]);
+    }
+    __syncthreads();
+    // basis vectors: for each x filter, one x pass, then a y pass per term using it
+    for (int f = 0; f < P.nf1; ++f) {
+        bool used = false;
+        for (int n = 0; n < P.nc; ++n) used |= (P.tfx[n] == f);
+        if (!used) continue;
+        const double* fxv = fl + f * step;
+        for (int k = tid; k < pw * sw; k += 256) {
+            int yy = k / sw, j = k - yy * sw;
+            const float* pr = patch + yy * pw + j + hwk;   // T(x - u) = patch[.. + hwk - u]
+            double acc = 0.0;
+            for (int u = -hwk; u <= hwk; ++u) acc += fxv[u + hwk] * (double)pr[-u];
+            xp[k] = acc;
+        }
+        __syncthreads();
+        for (int n = 0; n < P.nc; ++n) {
+            if (P.tfx[n] != f) continue;
+            const double* fyv = fl + P.tfy[n] * step;
+            const double sc = P.tscale[n];
+            for (int k = tid; k < P.npix; k += 256) {
+                int i = k / sw, j = k - i * sw;
+                const double* col = xp + (i + hwk) * sw + j;
+                double acc = 0.0;
+                for (int v = -hwk; v <= hwk; ++v) acc += fyv[v + hwk] * col[-v * sw];
+                acc *= sc;
+                if (n == 0) w0[k] = acc;
+                else if (P.tsub0[n]) acc -= w0[k];
+                Xc[(size_t)n * P.npixp + k] = acc;
+            }
+            if (n == 0) __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// G = X X^T, 64 x 64 fp64, on the f64 matrix cores.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define GR_KT 32
+#define GR_PITCH 34   // doubles; (4 i + 2 k) mod 64 banks are distinct for ds_read_b64
+
+__global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
+                                                 const int* __restrict__ need,
+                                                 const int* __restrict__ active,
+                                                 double* __restrict__ G) {
+    __shared__ double L[HP_MAXX * GR_PITCH];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    if (!need[cell] || active[cell] < 0) return;
+    const double* Xc = X + (size_t)cell * P.nX * P.npixp;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < P.npixp; k0 += GR_KT) {
+        __syncthreads();
+        for (int e = tid; e < HP_MAXX * GR_KT; e += 256) {
+            int row = e >> 5, col = e & 31;
+            L[row * GR_PITCH + col] = row < P.nX ? Xc[(size_t)row * P.npixp + k0 + col] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GR_KT / 4; ++kk) {
+            double a = L[(16 * wave + li) * GR_PITCH + 4 * kk + lk];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double b = L[(16 * c + li) * GR_PITCH + 4 * kk + lk];
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg
+    double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            Gc[(size_t)(16 * wave + lk + 4 * rg) * HP_MAXX + 16 * c + li] = acc[c][rg];
+}
+
+// ---------------------------------------------------------------------------
+// Global unknown c -> (source vector n, spatial term p or -1)
+__device__ inline void col_decode(const hp_plan& P, int c, int* n, int* p) {
+    if (c == 0) { *n = 0; *p = -1; return; }
+    int k = c - 1;
+    if (k < (P.nc - 1) * P.nkp) { *n = 1 + k / P.nkp; *p = k % P.nkp; return; }
+    *n = P.nc + (k - (P.nc - 1) * P.nkp);
+    *p = -1;
+}
+
+// A: [reg][nunk][nunk] lower triangle, rhs: [reg][nunk]
+__global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double* __restrict__ G,
+                                                  const double* __restrict__ phi,
+                                                  const int* __restrict__ active,
+                                                  double* __restrict__ A,
+                                                  double* __restrict__ rhs) {
+    const int reg = blockIdx.z;
+    const int c1 = blockIdx.y * 16 + (threadIdx.x >> 4), c2 = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (blockIdx.x > blockIdx.y) return;
+    if (c1 >= P.nunk || c2 >= P.nunk) return;
+    int n1, p1, n2, p2;
+    col_decode(P, c1, &n1, &p1);
+    col_decode(P, c2, &n2, &p2);
+    double acc = 0.0, racc = 0.0;
+    const bool do_rhs = (c2 == 0);
+    for (int s = 0; s < P.ncellr; ++s) {
+        const int cell = reg * P.ncellr + s;
+        if (active[cell] < 0) continue;
+        const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+        const double* ph = phi + (size_t)cell * P.nkp;
+        double w1 = p1 >= 0 ? ph[p1] : 1.0;
+        double w2 = p2 >= 0 ? ph[p2] : 1.0;
+        acc += w1 * w2 * Gc[n1 * HP_MAXX + n2];
+        if (do_rhs) racc += w1 * Gc[n1 * HP_MAXX + P.nE];
+    }
+    if (c2 <= c1) A[((size_t)reg * P.nunk + c1) * P.nunk + c2] = acc;
+    if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
+}
+
+// Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
+__global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d) {
+    int reg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double v = A[((size_t)reg * n + c) * n + c];
+    d[(size_t)reg * n + c] = v > 0.0 ? sqrt(v) : 1.0;
+}
+
+__global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ rhs,
+                           const double* __restrict__ d) {
+    int reg = blockIdx.z;
+    int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
+    if (c2 > c1 || c2 >= n) return;
+    const double* dd = d + (size_t)reg * n;
+    double v = A[((size_t)reg * n + c1) * n + c2] / (dd[c1] * dd[c2]);
+    if (c1 == c2) v += HP_RIDGE;   // keeps a rank-deficient basis solvable (oracle: RIDGE)
+    A[((size_t)reg * n + c1) * n + c2] = v;
+    if (c2 == 0) rhs[(size_t)reg * n + c1] /= dd[c1];
+}
+
+// ---- blocked Cholesky, lower, in place, batched over blockIdx.z ------------------
+// Panel step: every workgroup re-factors the 32 x 32 diagonal block in LDS, then
+// each thread solves one row of the panel below it; workgroup 0 writes L11 back.
+__global__ __launch_bounds__(256) void k_chol_panel(int n, int k0, double* __restrict__ Aall,
+                                                    int* __restrict__ fail) {
+    __shared__ double D[CH_NB][CH_NB + 1];
+    double* A = Aall + (size_t)blockIdx.z * n * n;
+    const int tid = threadIdx.x;
+    const int nb = min(CH_NB, n - k0);
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+        int i = e >> 5, j = e & 31;
+        D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        if (tid == 0) {
+            double v = D[j][j];
+            if (!(v > 1e-14)) { v = 1e-14; if (blockIdx.x == 0) atomicAdd(&fail[blockIdx.z], 1); }
+            D[j][j] = sqrt(v);
+        }
+        __syncthreads();
+        if (tid > j && tid < nb) D[tid][j] /= D[j][j];
+        __syncthreads();
+        // rank-1 update of the remaining lower triangle
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            int i = e >> 5, c = e & 31;
+            if (c > j && i >= c && i < nb) D[i][c] -= D[i][j] * D[c][j];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0)
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            int i = e >> 5, j = e & 31;
+            if (i < nb && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = D[i][j];
+        }
+    const int row = k0 + nb + blockIdx.x * 256 + tid;
+    if (row >= n) return;
+    double x[CH_NB];
+    double* ar = A + (size_t)row * n + k0;
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ar[j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) {
+        if (j < nb) {
+            double v = x[j];
+#pragma unroll
+            for (int m = 0; m < CH_NB; ++m)
+                if (m < j) v -= x[m] * D[j][m];
+            x[j] = v / D[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j)
+        if (j < nb) ar[j] = x[j];
+}
+
+// Trailing update A22 -= L21 L21^T (lower triangle), 64 x 64 tiles, 4 x 4 per thread
+__global__ __launch_bounds__(256) void k_chol_update(int n, int k0, double* __restrict__ Aall) {
+    __shared__ double Li[64][CH_NB + 1];
+    __shared__ double Lj[64][CH_NB + 1];
+    if (blockIdx.x > blockIdx.y) return;
+    double* A = Aall + (size_t)blockIdx.z * n * n;
+    const int t0 = k0 + CH_NB;
+    const int i0 = t0 + blockIdx.y * 64, j0 = t0 + blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * CH_NB; e += 256) {
+        int r = e >> 5, m = e & 31;
+        Li[r][m] = (i0 + r < n) ? A[(size_t)(i0 + r) * n + k0 + m] : 0.0;
+        Lj[r][m] = (j0 + r < n) ? A[(size_t)(j0 + r) * n + k0 + m] : 0.0;
+    }
+    __syncthreads();
+    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+    double acc[4][4] = {};
+#pragma unroll 8
+    for (int m = 0; m < CH_NB; ++m) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = Li[ti + q][m]; b[q] = Lj[tj + q][m]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = i0 + ti + p, j = j0 + tj + q;
+            if (i < n && j <= i) A[(size_t)i * n + j] -= acc[p][q];
+        }
+}
+
+// Forward + back substitution with the factor, one workgroup per region; the
+// solution overwrites rhs.  Then un-scale with d.
+__global__ __launch_bounds__(256) void k_chol_solve(int n, const double* __restrict__ Aall,
+                                                    double* __restrict__ ball,
+                                                    const double* __restrict__ dall) {
+    __shared__ double D[CH_NB][CH_NB + 1];
+    __shared__ double y[CH_NB];
+    const double* A = Aall + (size_t)blockIdx.x * n * n;
+    double* b = ball + (size_t)blockIdx.x * n;
+    const double* d = dall + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    // forward: L y = b
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            int i = e >> 5, j = e & 31;
+            D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double bi = (tid < nb) ? b[k0 + tid] : 0.0;
+            for (int j = 0; j < nb; ++j) {
+                double yj = __shfl(bi, j) / D[j][j];
+                if (tid == j) bi = yj;
+                else if (tid > j && tid < nb) bi -= D[tid][j] * yj;
+            }
+            if (tid < nb) { y[tid] = bi; b[k0 + tid] = bi; }
+        }
+        __syncthreads();
+        for (int i = k0 + nb + tid; i < n; i += 256) {
+            const double* ar = A + (size_t)i * n + k0;
+            double acc = 0.0;
+            for (int m = 0; m < nb; ++m) acc += ar[m] * y[m];
+            b[i] -= acc;
+        }
+        __syncthreads();
+    }
+    // backward: L^T x = y
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            int i = e >> 5, j = e & 31;
+            D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double bi = (tid < nb) ? b[k0 + tid] : 0.0;
+            for (int j = nb - 1; j >= 0; --j) {
+                double xj = __shfl(bi, j) / D[j][j];
+                if (tid == j) bi = xj;
+                else if (tid < j) bi -= D[j][tid] * xj;   // L^T[tid][j] = L[j][tid]
+            }
+            if (tid < nb) { y[tid] = bi; b[k0 + tid] = bi; }
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += 256) {
+            double acc = 0.0;
+            for (int m = 0; m < nb; ++m) acc += A[(size_t)(k0 + m) * n + i] * y[m];
+            b[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) b[i] /= d[i];
+}
+
+// ---------------------------------------------------------------------------
+// merit[cell] = (I.I - 2 c.b + c^T Q c) / (npix vbar), c = per-cell coefficients
+__global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* __restrict__ G,
+                                                 const double* __restrict__ phi,
+                                                 const double* __restrict__ vbar,
+                                                 const int* __restrict__ active,
+                                                 const double* __restrict__ xsol,
+                                                 double* __restrict__ merit) {
+    __shared__ double c[HP_MAXX];
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    if (active[cell] < 0) { if (lane == 0) merit[cell] = -1.0; return; }
+    const int reg = cell / P.ncellr;
+    const double* x = xsol + (size_t)reg * P.nunk;
+    const double* ph = phi + (size_t)cell * P.nkp;
+    const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+    if (lane < P.nE) {
+        double v;
+        if (lane == 0) v = x[0];
+        else if (lane < P.nc) {
+            v = 0.0;
+            for (int p = 0; p < P.nkp; ++p) v += x[1 + (lane - 1) * P.nkp + p] * ph[p];
+        } else v = x[1 + (P.nc - 1) * P.nkp + (lane - P.nc)];
+        c[lane] = v;
+    }
+    __syncthreads();
+    double part = 0.0;
+    if (lane < P.nE) {
+        double q = 0.0;
+        for (int m = 0; m < P.nE; ++m) q += Gc[lane * HP_MAXX + m] * c[m];
+        part = c[lane] * (q - 2.0 * Gc[lane * HP_MAXX + P.nE]);
+    }
+    part = wave_sum_d(part);
+    if (lane == 0) merit[cell] = (Gc[P.nE * HP_MAXX + P.nE] + part) / (P.npix * vbar[cell]);
+}
+
+// one workgroup per region: clipped moments of the merits, reject, advance
+__global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double* __restrict__ merit,
+                                                   const int2* __restrict__ centres,
+                                                   int* __restrict__ active, int* __restrict__ need,
+                                                   int* __restrict__ nrej, double* __restrict__ stats) {
+    __shared__ double red[4];
+    const int reg = blockIdx.x, tid = threadIdx.x;
+    double m = 0.0, s = 0.0;
+    for (int pass = 0; pass < 4; ++pass) {
+        double s0 = 0, s1 = 0;
+        for (int k = tid; k < P.ncellr; k += 256) {
+            double v = merit[reg * P.ncellr + k];
+            if (active[reg * P.ncellr + k] < 0) continue;
+            if (pass == 0 || fabs(v - m) <= 3.0 * s) { s0 += 1.0; s1 += v; }
+        }
+        s0 = block_sum256(s0, red);
+        s1 = block_sum256(s1, red);
+        if (s0 < 1.0) break;
+        double mn = s1 / s0, s2 = 0;
+        for (int k = tid; k < P.ncellr; k += 256) {
+            double v = merit[reg * P.ncellr + k];
+            if (active[reg * P.ncellr + k] < 0) continue;
+            if (pass == 0 || fabs(v - m) <= 3.0 * s) s2 += (v - mn) * (v - mn);
+        }
+        s2 = block_sum256(s2, red);
+        m = mn;
+        s = sqrt(s2 / s0);
+    }
+    const double lim = m + P.ks * s;
+    double cnt = 0, msum = 0, used = 0;
+    for (int k = tid; k < P.ncellr; k += 256) {
+        const int cell = reg * P.ncellr + k;
+        int a = active[cell];
+        need[cell] = 0;
+        if (a < 0) continue;
+        double v = merit[cell];
+        used += 1.0;
+        msum += v;
+        if (v > lim) {
+            cnt += 1.0;
+            a += 1;
+            if (a >= P.nss || centres[cell * P.nss + a].x < 0) a = -1;
+            else need[cell] = 1;
+            active[cell] = a;
+        }
+    }
+    cnt = block_sum256(cnt, red);
+    msum = block_sum256(msum, red);
+    used = block_sum256(used, red);
+    if (tid == 0) {
+        nrej[reg] = (int)cnt;
+        stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
+        stats[reg * 2 + 1] = used;
+    }
+}
+
+__global__ void k_hp_init_active(const hp_plan P, const int2* __restrict__ centres,
+                                 int* __restrict__ active, int* __restrict__ need,
+                                 int* __restrict__ ntotal) {
+    int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= P.ncell) return;
+    bool has = centres[cell * P.nss].x >= 0;
+    active[cell] = has ? 0 : -1;
+    need[cell] = has ? 1 : 0;
+    if (has) atomicAdd(&ntotal[cell / P.ncellr], 1);
+}
+
+// ---------------------------------------------------------------------------
+// Apply.  One workgroup = NB consecutive kernel blocks of one block row; each lane
+// owns R consecutive output pixels of one row of one block and slides a register
+// window over the LDS tile; kernel taps come from LDS (few distinct addresses per
+// wave: broadcast).  Template and template-variance planes are convolved together.
+template <int HWK> struct apply_cfg {
+    enum { STEP = 2 * HWK + 1,
+           LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? (STEP == 21 ? 3 : 2) : 3),   // lanes per block row
+           R = (STEP + LPR - 1) / LPR,
+           LPB = STEP * LPR,                 // lanes per block
+           NB = 256 / LPB > 0 ? 256 / LPB : 1 };
+};
+
+template <int HWK>
+__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, int reg,
+                                                  const float* __restrict__ sci,
+                                                  const float* __restrict__ ref,
+                                                  const float* __restrict__ srms,
+                                                  const float* __restrict__ trms,
+                                                  const uint8_t* __restrict__ outbad,
+                                                  const double* __restrict__ basis,   // [nc][STEP*STEP]
+                                                  const double* __restrict__ xsol,
+                                                  int solved,
+                                                  float* __restrict__ diff,
+                                                  float* __restrict__ noise,
+                                                  int* __restrict__ nmasked) {
+    typedef apply_cfg<HWK> C;
+    constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
+    constexpr int TW = NB * STEP + 2 * HWK;   // tile width
+    constexpr int TH = STEP + 2 * HWK;
+    extern __shared__ float ap_smem[];
+    float* tT = ap_smem;                       // [TH][TW]
+    float* tV = tT + TH * TW;                  // [TH][TW]
+    float* kc = tV + TH * TW;                  // [NB][STEP*STEP]
+    double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP + ((NB * STEP * STEP) & 1));   // [NB][nc]
+    const int tid = threadIdx.x;
+    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
+    const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
+    const int gy0 = y0r + blockIdx.y * STEP;
+    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
+    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
+    const double* x = xsol + (size_t)reg * P.nunk;
+    // per-block basis coefficients at the nominal block centre (fp64)
+    for (int e = tid; e < NB * P.nc; e += 256) {
+        int b = e / P.nc, n = e - b * P.nc;
+        double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
+        double v;
+        if (n == 0) v = x[0];
+        else {
+            v = 0.0;
+            for (int p = 0; p < P.nkp; ++p)
+                v += x[1 + (n - 1) * P.nkp + p] * pow(fx, (double)P.kpi[p]) * pow(fy, (double)P.kpj[p]);
+        }
+        cf[e] = v;
+    }
+    // tile of template and template variance (zeros outside the frame / non-finite)
+    for (int e = tid; e < TH * TW; e += 256) {
+        int yy = e / TW, xx = e - yy * TW;
+        int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
+        float t = 0.f, v = 0.f;
+        if (gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
+            size_t idx = (size_t)gy * P.nx + gx;
+            t = ref[idx];
+            float rr = trms[idx];
+            v = rr * rr;
+            if (!(fabsf(t) < 3e38f)) t = 0.f;
+            if (!(fabsf(v) < 3e38f)) v = 0.f;
+        }
+        tT[e] = t;
+        tV[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * STEP * STEP; e += 256) {
+        int b = e / (STEP * STEP), tap = e - b * STEP * STEP;
+        double acc = 0.0;
+        for (int n = 0; n < P.nc; ++n) acc += cf[b * P.nc + n] * basis[(size_t)n * STEP * STEP + tap];
+        kc[e] = (float)acc;
+    }
+    __syncthreads();
+    const int b = tid / LPB;
+    if (b >= NB) return;
+    const int l = tid - b * LPB;
+    const int row = l / LPR, strip = l - row * LPR;
+    const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
+    const int gy = gy0 + row;
+    if (gy >= y1r || gy >= P.ny) return;
+    float accT[R], accV[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { accT[q] = 0.f; accV[q] = 0.f; }
+    const float* kb = kc + b * STEP * STEP;
+    // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
+    for (int v = -HWK; v <= HWK; ++v) {
+        const float* rt = tT + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
+        const float* rv = tV + (row + HWK - v) * TW + ox0;
+        float wt[R + 2 * HWK], wv[R + 2 * HWK];
+#pragma unroll
+        for (int q = 0; q < R + 2 * HWK; ++q) { wt[q] = rt[q]; wv[q] = rv[q]; }
+        const float* kr = kb + (v + HWK) * STEP;
+#pragma unroll
+        for (int u = -HWK; u <= HWK; ++u) {
+            const float k = kr[u + HWK];
+            const float k2 = k * k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                accT[q] = fmaf(k, wt[q + HWK - u], accT[q]);
+                accV[q] = fmaf(k2, wv[q + HWK - u], accV[q]);
+            }
+        }
+    }
+    const double* bgc = x + 1 + (size_t)(P.nc - 1) * P.nkp;
+    const float norm = P.normalize ? (float)(1.0 / x[0]) : 1.f;
+    int masked = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int gx = gx0 + ox0 + q;
+        if (strip * R + q >= STEP || gx >= x1r || gx >= P.nx) continue;
+        const size_t idx = (size_t)gy * P.nx + gx;
+        float d = P.fi, nz = P.fin;
+        if (solved && !outbad[idx]) {
+            double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
+            double bg = 0.0;
+            for (int t = 0; t < P.nbg; ++t)
+                bg += bgc[t] * pow(xf, (double)P.bpi[t]) * pow(yf, (double)P.bpj[t]);
+            float sr = srms[idx];
+            d = (sci[idx] - accT[q] - (float)bg) * norm;
+            nz = sqrtf(fmaxf(sr * sr + accV[q], 0.f)) * fabsf(norm);
+        } else {
+            masked += 1;
+        }
+        diff[idx] = d;
+        noise[idx] = nz;
+    }
+    if (masked) atomicAdd(nmasked, masked);
+}
+
+// ---------------------------------------------------------------------------
+extern "C" void zm_hp_params_default(zm_hp_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->tu = 5e3; p->tl = 0.0; p->iu = 5e3; p->il = 0.0;
+    p->r = 10.0; p->rss = 15.0;
+    p->fin = sqrt(50000.0); p->fi = 1e-30;
+    p->nsx = p->nsy = 10; p->nrx = p->nry = 1;
+    p->ko = 4; p->bgo = 0; p->nss = 3; p->normalize = 0;
+    p->ft = 20.0; p->ks = 2.0;
+    p->ngauss = 3;
+    p->deg[0] = 6; p->deg[1] = 4; p->deg[2] = 2;
+    p->sigma[0] = 0.7; p->sigma[1] = 1.5; p->sigma[2] = 3.0;
+}
+
+static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::vector<double>* filt,
+                     std::vector<double>* basis) {
+    memset(P, 0, sizeof(*P));
+    P->nx = nx; P->ny = ny;
+    P->hwk = (int)hp->r; P->hwss = (int)hp->rss;
+    ZM_CHECK(P->hwk >= 1 && P->hwk <= 15, "zm_subtract: kernel half width int(r) = %d outside [1, 15]", P->hwk);
+    ZM_CHECK(P->hwss >= 1 && P->hwss <= 48, "zm_subtract: substamp half width int(rss) = %d outside [1, 48]", P->hwss);
+    P->hw = P->hwk + P->hwss;
+    P->step = 2 * P->hwk + 1; P->sw = 2 * P->hwss + 1; P->pw = 2 * P->hw + 1;
+    P->npix = P->sw * P->sw;
+    P->npixp = (P->npix + GR_KT - 1) / GR_KT * GR_KT;
+    ZM_CHECK(hp->ngauss >= 1 && hp->ngauss <= 4, "zm_subtract: ngauss %d outside [1, 4]", hp->ngauss);
+    ZM_CHECK(hp->ko >= 0 && hp->ko <= 6, "zm_subtract: -ko %d outside [0, 6]", hp->ko);
+    ZM_CHECK(hp->bgo >= 0 && hp->bgo <= 3, "zm_subtract: -bgo %d outside [0, 3]", hp->bgo);
+    ZM_CHECK(hp->nss >= 1 && hp->nss <= HP_MAXNSS, "zm_subtract: nss %d outside [1, %d]", hp->nss, HP_MAXNSS);
+    ZM_CHECK(hp->nrx >= 1 && hp->nry >= 1 && hp->nrx * hp->nry <= HP_MAXREG, "zm_subtract: bad -nrx/-nry");
+    ZM_CHECK(hp->nsx >= 1 && hp->nsy >= 1 && hp->nsx * hp->nsy <= 4096, "zm_subtract: bad -nsx/-nsy");
+    P->ko = hp->ko; P->bgo = hp->bgo; P->nss = hp->nss; P->normalize = hp->normalize;
+    P->nrx = hp->nrx; P->nry = hp->nry; P->nsx = hp->nsx; P->nsy = hp->nsy;
+    P->nreg = hp->nrx * hp->nry; P->ncellr = hp->nsx * hp->nsy; P->ncell = P->nreg * P->ncellr;
+    P->tu = hp->tu; P->tl = hp->tl; P->iu = hp->iu; P->il = hp->il; P->ft = hp->ft; P->ks = hp->ks;
+    P->fi = (float)hp->fi; P->fin = (float)hp->fin;
+    ZM_CHECK(nx / hp->nrx / hp->nsx >= 1 && ny / hp->nry / hp->nsy >= 1, "zm_subtract: stamps smaller than a pixel");
+    for (int ry = 0; ry < hp->nry; ++ry)
+        for (int rx = 0; rx < hp->nrx; ++rx) {
+            int r = ry * hp->nrx + rx;
+            P->rx0[r] = rx * (nx / hp->nrx);
+            P->rx1[r] = rx == hp->nrx - 1 ? nx : (rx + 1) * (nx / hp->nrx);
+            P->ry0[r] = ry * (ny / hp->nry);
+            P->ry1[r] = ry == hp->nry - 1 ? ny : (ry + 1) * (ny / hp->nry);
+        }
+    // 1-D filters and term tables
+    const int step = P->step, hwk = P->hwk;
+    std::vector<int> fidx;   // filter index of (g, a)
+    int nf1 = 0, nc = 0;
+    std::vector<double> fsum;
+    filt->clear();
+    int base[4] = {0, 0, 0, 0};
+    for (int g = 0; g < hp->ngauss; ++g) {
+        ZM_CHECK(hp->deg[g] >= 0 && hp->deg[g] <= 8 && hp->sigma[g] > 0, "zm_subtract: bad basis");
+        base[g] = nf1;
+        for (int a = 0; a <= hp->deg[g]; ++a) {
+            double s = 0.0;
+            for (int u = -hwk; u <= hwk; ++u) {
+                double v = exp(-(double)u * u / (2.0 * hp->sigma[g] * hp->sigma[g])) * pow((double)u, (double)a);
+                filt->push_back(v);
+                s += v;
+            }
+            fsum.push_back(s);
+            ++nf1;
+        }
+    }
+    ZM_CHECK(nf1 <= HP_MAXF1, "zm_subtract: too many 1-D filters");
+    P->nf1 = nf1;
+    for (int g = 0; g < hp->ngauss; ++g)
+        for (int a = 0; a <= hp->deg[g]; ++a)
+            for (int b = 0; b <= hp->deg[g] - a; ++b) {
+                ZM_CHECK(nc < HP_MAXX, "zm_subtract: basis too large");
+                P->tfx[nc] = base[g] + a;
+                P->tfy[nc] = base[g] + b;
+                bool ee = (a % 2 == 0) && (b % 2 == 0);
+                P->tscale[nc] = ee ? 1.0 / (fsum[base[g] + a] * fsum[base[g] + b]) : 1.0;
+                P->tsub0[nc] = (ee && nc > 0) ? 1 : 0;
+                ++nc;
+            }
+    P->nc = nc;
+    int nkp = 0;
+    for (int i = 0; i <= P->ko; ++i)
+        for (int j = 0; j <= P->ko - i; ++j) { P->kpi[nkp] = i; P->kpj[nkp] = j; ++nkp; }
+    P->nkp = nkp;
+    int nbg = 0;
+    for (int i = 0; i <= P->bgo; ++i)
+        for (int j = 0; j <= P->bgo - i; ++j) { P->bpi[nbg] = i; P->bpj[nbg] = j; ++nbg; }
+    P->nbg = nbg;
+    P->nE = nc + nbg;
+    P->nX = P->nE + 1;
+    ZM_CHECK(P->nX <= HP_MAXX, "zm_subtract: %d basis + %d background terms exceed the %d-row Gram tile", nc, nbg, HP_MAXX);
+    P->nunk = 1 + (nc - 1) * nkp + nbg;
+    // 2-D basis (hotpants normalisation), K_n[v][u]
+    basis->assign((size_t)nc * step * step, 0.0);
+    for (int n = 0; n < nc; ++n) {
+        const double* fx = filt->data() + (size_t)P->tfx[n] * step;
+        const double* fy = filt->data() + (size_t)P->tfy[n] * step;
+        for (int v = 0; v < step; ++v)
+            for (int u = 0; u < step; ++u) {
+                double k = fy[v] * fx[u] * P->tscale[n];
+                if (P->tsub0[n]) k -= (*basis)[(size_t)v * step + u];
+                (*basis)[((size_t)n * step + v) * step + u] = k;
+            }
+    }
+    return 0;
+}
+
+template <int HWK>
+static int launch_apply(zm_ctx* ctx, const hp_plan& P, int reg, const float* sci, const float* ref,
+                        const float* srms, const float* trms, const uint8_t* outbad,
+                        const double* basis, const double* xsol, int solved, float* diff,
+                        float* noise, int* nmasked) {
+    typedef apply_cfg<HWK> C;
+    constexpr int STEP = C::STEP, NB = C::NB;
+    constexpr int TW = NB * STEP + 2 * HWK, TH = STEP + 2 * HWK;
+    size_t fl = (size_t)2 * TH * TW + NB * STEP * STEP + 1;
+    size_t shmem = fl * sizeof(float) + (size_t)NB * HP_MAXX * sizeof(double) + 16;
+    static bool set = false;
+    if (!set && shmem > 65536) {
+        ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply<HWK>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        set = true;
+    }
+    int W = P.rx1[reg] - P.rx0[reg], H = P.ry1[reg] - P.ry0[reg];
+    dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), 1);
+    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, reg, sci, ref, srms,
+                       trms, outbad, basis, xsol, solved, diff, noise, nmasked);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms, const float* ref,
+                               const float* ref_rms, const uint8_t* bpm, int nx, int ny,
+                               const zm_hp_params* hp, float* out_diff, float* out_rms,
+                               zm_hp_info* info) {
+    ZM_CHECK(ctx && sci && sci_rms && ref && ref_rms && hp && out_diff && out_rms,
+             "zm_subtract_dev: null argument");
+    ZM_CHECK(nx > 0 && ny > 0, "zm_subtract_dev: empty image");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hp_plan P;
+    std::vector<double> filt, basis;
+    ZM_TRY(make_plan(hp, nx, ny, &P, &filt, &basis));
+    ZM_CHECK(nx > 2 * P.hw + 1 && ny > 2 * P.hw + 1, "zm_subtract_dev: image smaller than a substamp");
+    const int64_t np = (int64_t)nx * ny;
+    hipStream_t st = ctx->stream;
+
+    uint8_t *bad = nullptr, *tmp8 = nullptr, *dirty = nullptr, *outbad = nullptr;
+    ZM_TRY(ctx->get("hp_bad", np, (void**)&bad));
+    ZM_TRY(ctx->get("hp_tmp8", np, (void**)&tmp8));
+    ZM_TRY(ctx->get("hp_dirty", np, (void**)&dirty));
+    ZM_TRY(ctx->get("hp_outbad", np, (void**)&outbad));
+    int2* centres = nullptr;
+    int *active = nullptr, *need = nullptr, *ibuf = nullptr;
+    double *X = nullptr, *G = nullptr, *phi = nullptr, *vbar = nullptr, *A = nullptr, *rhs = nullptr,
+           *dsc = nullptr, *merit = nullptr, *stats = nullptr, *d_filt = nullptr, *d_basis = nullptr;
+    ZM_TRY(ctx->get("hp_centres", sizeof(int2) * P.ncell * P.nss, (void**)&centres));
+    ZM_TRY(ctx->get("hp_active", sizeof(int) * P.ncell, (void**)&active));
+    ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
+    ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * (3 * HP_MAXREG + 4), (void**)&ibuf));
+    int *nrej = ibuf, *ntotal = ibuf + HP_MAXREG, *fail = ibuf + 2 * HP_MAXREG, *nmasked = ibuf + 3 * HP_MAXREG;
+    ZM_TRY(ctx->get("hp_X", sizeof(double) * (size_t)P.ncell * P.nX * P.npixp, (void**)&X));
+    ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
+    ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
+    ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
+    ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * P.nunk * P.nunk, (void**)&A));
+    ZM_TRY(ctx->get("hp_rhs", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs));
+    ZM_TRY(ctx->get("hp_dsc", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&dsc));
+    ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
+    ZM_TRY(ctx->get("hp_stats", sizeof(double) * 2 * HP_MAXREG, (void**)&stats));
+    ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
+    ZM_TRY(ctx->get("hp_basis", sizeof(double) * basis.size(), (void**)&d_basis));
+    // small constant tables: staged through pinned memory owned per call generation
+    double* h_tab = nullptr;
+    ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * (filt.size() + basis.size()), (void**)&h_tab));
+    ZM_HIP(hipStreamSynchronize(st));   // the previous call may still be reading the staging area
+    memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
+    memcpy(h_tab + filt.size(), basis.data(), sizeof(double) * basis.size());
+    ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
+    ZM_HIP(hipMemcpyAsync(d_basis, h_tab + filt.size(), sizeof(double) * basis.size(), hipMemcpyHostToDevice, st));
+    ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * (3 * HP_MAXREG + 4), st));
+
+    const dim3 b256(256);
+    {
+        zm_scope_timer t(ctx, "hp_masks");
+        hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
+                           (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad);
+        dim3 g2(zm_div_up(nx, 256), ny);
+        hipLaunchKernelGGL(k_hp_rowany, g2, b256, 0, st, bad, nx, ny, P.hw, tmp8);
+        hipLaunchKernelGGL(k_hp_colany, g2, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+        hipLaunchKernelGGL(k_hp_rowany, g2, b256, 0, st, bad, nx, ny, P.hwk, tmp8);
+        hipLaunchKernelGGL(k_hp_colany, g2, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+        ZM_HIP(hipGetLastError());
+    }
+    {
+        zm_scope_timer t(ctx, "hp_cells");
+        hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+        hipLaunchKernelGGL(k_hp_init_active, dim3(zm_div_up(P.ncell, 256)), b256, 0, st, P, centres, active,
+                           need, ntotal);
+        ZM_HIP(hipGetLastError());
+    }
+    // LDS of k_hp_vectors
+    size_t vsh = sizeof(double) * ((size_t)P.pw * P.sw + P.npix + (size_t)P.nf1 * P.step + 4) +
+                 sizeof(float) * (size_t)P.pw * P.pw + 16;
+    ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
+    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh));
+
+    int rounds = 0;
+    int h_int[3 * HP_MAXREG + 4];
+    const int nblk = (P.nunk + CH_NB - 1) / CH_NB;
+    for (rounds = 1; rounds <= 8; ++rounds) {
+        {
+            zm_scope_timer t(ctx, "hp_vectors");
+            hipLaunchKernelGGL(k_hp_vectors, dim3(P.ncell), b256, vsh, st, P, sci, ref, sci_rms, ref_rms,
+                               d_filt, centres, active, need, X, phi, vbar);
+            ZM_HIP(hipGetLastError());
+        }
+        {
+            zm_scope_timer t(ctx, "hp_gram");
+            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell), b256, 0, st, P, X, need, active, G);
+            ZM_HIP(hipGetLastError());
+        }
+        {
+            zm_scope_timer t(ctx, "hp_solve");
+            int nt = zm_div_up(P.nunk, 16);
+            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, A, rhs);
+            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A, dsc);
+            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A,
+                               rhs, dsc);
+            for (int kb = 0; kb < nblk; ++kb) {
+                int k0 = kb * CH_NB;
+                int below = P.nunk - k0 - CH_NB;
+                int pch = below > 0 ? zm_div_up(below, 256) : 1;
+                hipLaunchKernelGGL(k_chol_panel, dim3(pch, 1, P.nreg), b256, 0, st, P.nunk, k0, A, fail);
+                if (below > 0) {
+                    int tt = zm_div_up(below, 64);
+                    hipLaunchKernelGGL(k_chol_update, dim3(tt, tt, P.nreg), b256, 0, st, P.nunk, k0, A);
+                }
+            }
+            hipLaunchKernelGGL(k_chol_solve, dim3(P.nreg), b256, 0, st, P.nunk, A, rhs, dsc);
+            hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
+            hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, nrej,
+                               stats);
+            ZM_HIP(hipGetLastError());
+        }
+        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipStreamSynchronize(st));
+        int tot = 0;
+        for (int r = 0; r < P.nreg; ++r) tot += h_int[r];
+        if (tot == 0) break;
+    }
+    if (rounds > 8) rounds = 8;
+    // a region is solved when it fitted at least one stamp and the factorisation held
+    std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
+    ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipStreamSynchronize(st));
+    {
+        zm_scope_timer t(ctx, "hp_apply");
+        for (int reg = 0; reg < P.nreg; ++reg) {
+            int solved = (h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
+                          std::isfinite(h_x[(size_t)reg * P.nunk])) ? 1 : 0;
+#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, reg, sci, ref, sci_rms, ref_rms, outbad, d_basis, rhs, solved, out_diff, out_rms, nmasked)); break;
+            switch (P.hwk) {
+                HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
+                HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
+                HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
+                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+            }
+#undef HP_APPLY_CASE
+        }
+    }
+    if (info) {
+        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipStreamSynchronize(st));
+        memset(info, 0, sizeof(*info));
+        double ks = 0, chi = 0;
+        int nsolved = 0;
+        for (int r = 0; r < P.nreg; ++r) {
+            info->nstamps_total += h_int[HP_MAXREG + r];
+            info->nstamps_used += (int)h_stats[2 * r + 1];
+            if (h_stats[2 * r + 1] >= 1.0 && h_int[2 * HP_MAXREG + r] == 0) {
+                ks += h_x[(size_t)r * P.nunk];
+                chi += h_stats[2 * r];
+                ++nsolved;
+            }
+        }
+        info->niter = rounds;
+        info->ncoeff = P.nunk;
+        info->kernel_sum = nsolved ? ks / nsolved : 0.0;
+        info->chi2 = nsolved ? chi / nsolved : 0.0;
+        info->nmasked = h_int[3 * HP_MAXREG];
+        info->status = nsolved == P.nreg ? 0 : 1;
+    }
+    return 0;
+}
+
+extern "C" int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms, const float* ref,
+                           const float* ref_rms, const uint8_t* bpm, int nx, int ny,
+                           const zm_hp_params* hp, float* out_diff, float* out_rms, zm_hp_info* info) {
+    ZM_CHECK(ctx && sci && sci_rms && ref && ref_rms && hp && out_diff && out_rms,
+             "zm_subtract: null argument");
+    ZM_CHECK(nx > 0 && ny > 0, "zm_subtract: empty image");
+    ZM_HIP(hipSetDevice(ctx->device));
+    const size_t np = (size_t)nx * ny;
+    float* d[6];
+    const float* h[4] = {sci, sci_rms, ref, ref_rms};
+    const char* nm[6] = {"hs_sci", "hs_srms", "hs_ref", "hs_rrms", "hs_diff", "hs_noise"};
+    for (int i = 0; i < 6; ++i) ZM_TRY(ctx->get(nm[i], np * 4, (void**)&d[i]));
+    for (int i = 0; i < 4; ++i) ZM_HIP(hipMemcpyAsync(d[i], h[i], np * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_bpm = nullptr;
+    if (bpm) {
+        ZM_TRY(ctx->get("hs_bpm", np, (void**)&d_bpm));
+        ZM_HIP(hipMemcpyAsync(d_bpm, bpm, np, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ZM_TRY(zm_subtract_dev(ctx, d[0], d[1], d[2], d[3], d_bpm, nx, ny, hp, d[4], d[5], info));
+    ZM_HIP(hipMemcpyAsync(out_diff, d[4], np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZM_HIP(hipMemcpyAsync(out_rms, d[5], np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

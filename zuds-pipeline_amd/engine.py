@@ -220,3 +220,64 @@ class Engine(object):
                                    int(filtersize), ptr(out['bkg']), ptr(out['rms']),
                                    ptr(out['sub']), stats), 'zm_background')
         return out['bkg'], out['rms'], out['sub'], (stats[0], stats[1])
+
+    # -- subtraction -------------------------------------------------------------------------
+    def subtract(self, sci, sci_rms, ref, ref_rms, bpm=None, params=None, **kw):
+        """Alard-Lupton subtraction of ``ref`` from ``sci`` (same grid).
+
+        Returns (diff, noise, info dict)."""
+        if params is None:
+            params = hp_params(**kw)
+        sci, sci_rms = as_f32(sci), as_f32(sci_rms)
+        ref, ref_rms = as_f32(ref), as_f32(ref_rms)
+        ny, nx = sci.shape
+        for a, nm in ((sci_rms, 'sci_rms'), (ref, 'ref'), (ref_rms, 'ref_rms')):
+            if a.shape != (ny, nx):
+                raise ValueError(f'{nm} has shape {a.shape}, expected {(ny, nx)}')
+        if bpm is not None:
+            bpm = np.ascontiguousarray(bpm).astype(np.uint8, copy=False)
+            if bpm.shape != (ny, nx):
+                raise ValueError(f'bpm has shape {bpm.shape}, expected {(ny, nx)}')
+        diff = np.empty((ny, nx), dtype=np.float32)
+        noise = np.empty((ny, nx), dtype=np.float32)
+        info = _lib.zm_hp_info()
+        check(self.L.zm_subtract(self._ctx, ptr(sci), ptr(sci_rms), ptr(ref), ptr(ref_rms),
+                                 ptr(bpm), nx, ny, C.byref(params), ptr(diff), ptr(noise),
+                                 C.byref(info)), 'zm_subtract')
+        return diff, noise, {k: getattr(info, k) for k, _ in info._fields_}
+
+    def median_mad(self, img, mask=None):
+        """(median, 1.4826 MAD) of the pixels whose mask is 0
+        (quick_background_estimate, zuds/utils.py:32-53)."""
+        img = as_f32(img)
+        mask = as_i32(mask)
+        if mask is not None and mask.shape != img.shape:
+            raise ValueError('mask shape does not match image shape')
+        med = C.c_double()
+        mad = C.c_double()
+        check(self.L.zm_median_mad(self._ctx, ptr(img), ptr(mask), img.size, C.byref(med),
+                                   C.byref(mad)), 'zm_median_mad')
+        return med.value, mad.value
+
+
+def hp_params(**kw):
+    """zm_hp_params with hotpants' defaults, overridden by keyword (tu, tl, iu, il,
+    r, rss, fin, fi, nsx, nsy, nrx, nry, ko, bgo, nss, normalize, ft, ks, deg,
+    sigma)."""
+    p = _lib.zm_hp_params()
+    _lib.lib().zm_hp_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == 'deg':
+            p.ngauss = len(v)
+            for i, d in enumerate(v):
+                p.deg[i] = int(d)
+        elif k == 'sigma':
+            for i, s in enumerate(v):
+                p.sigma[i] = float(s)
+        elif k in ('nsx', 'nsy', 'nrx', 'nry', 'ko', 'bgo', 'nss', 'normalize'):
+            setattr(p, k, int(v))
+        elif hasattr(p, k):
+            setattr(p, k, float(v))
+        else:
+            raise ValueError(f'unknown hotpants parameter "{k}"')
+    return p
