@@ -37,6 +37,9 @@ def parse():
     ap.add_argument('--size', type=int, default=3072)
     ap.add_argument('--combine', default='WEIGHTED')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-subtract', action='store_true')
+    ap.add_argument('--seeing', type=float, default=4.0,
+                    help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
     ap.add_argument('--cpu-sample', type=int, default=1024,
                     help='side of the frames the CPU baseline resamples')
     return ap.parse_args()
@@ -128,19 +131,51 @@ def main():
     synth = importlib.import_module('zuds-pipeline_amd.synth')
     dev = importlib.import_module('zuds-pipeline_amd.device')
 
+    import ctypes as C
     eng = z.Engine(local)
-    base, frames = make_device_frames(synth, torch, args.frames, args.size,
+    base, frames = make_device_frames(synth, torch, args.frames + 1, args.size,
                                       2000 + 1000 * rank, device)
+    sci = frames.pop()            # the science epoch of configs[2]
+    # detector defects of the science frame: 300 clustered 3x3 blobs instead of
+    # isolated pixels (a 69 x 69 substamp box must be clean to be usable)
+    g = torch.Generator(device='cpu')
+    g.manual_seed(77 + rank)
+    bx = torch.randint(2, args.size - 2, (300,), generator=g)
+    by = torch.randint(2, args.size - 2, (300,), generator=g)
+    smask = torch.zeros((args.size, args.size), dtype=torch.int32)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            smask[by + dy, bx + dx] = 256
+    sci['mask'] = smask.to(device)
+    sci['wgt'] = torch.where(sci['mask'] != 0, 0.0, float(sci['wgt'].max())).to(torch.float32)
+    sci_rms = torch.where(sci['wgt'] > 0, 1.0 / torch.sqrt(sci['wgt'].clamp_min(1e-20)),
+                          float(np.sqrt(50000.0))).to(torch.float32)
     params = z.coadd_params(combine=args.combine, subtract_back=True,
                             rescale_weights=True)
     dframes = dev.DeviceFrames(frames, device)
-    coadd = dev.DeviceCoadd(base, params, device=local, engine=eng)
+    coadd = dev.DeviceCoadd(base, params, device=local, engine=eng, want_mask=True)
+    sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng,
+                                stream=coadd.stream)
+    ref_rms = torch.empty_like(coadd.wgt)
+    npx = args.size * args.size
+    L = eng.L
 
     def step():
+        # ScienceCoadd / ReferenceImage.from_images: science + mask coadds
         if world > 1:
             coadd.run_sharded_weighted(dframes)
         else:
             coadd.run(dframes)
+        with torch.cuda.stream(coadd.stream):
+            z._lib.check(L.zm_mask_flag_dev(eng.ctx, coadd.mask.data_ptr(),
+                                            coadd.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
+            z._lib.check(L.zm_add_scalar_dev(eng.ctx, coadd.img.data_ptr(), 150.0, npx))
+            z._lib.check(L.zm_rms_from_weight_dev(eng.ctx, coadd.wgt.data_ptr(), None, npx,
+                                                  float(np.sqrt(50000.0)), ref_rms.data_ptr()))
+        if not args.no_subtract:
+            # SingleEpochSubtraction.from_images with the reference's defaults
+            sub.run(sci['img'], sci_rms, sci['mask'], sci['wgt'], coadd.img, ref_rms,
+                    coadd.mask, seeing=args.seeing, nreg_side=3)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -164,12 +199,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    frames_per_step = args.frames * world
+    frames_per_step = (args.frames + (0 if args.no_subtract else 1)) * world
     mpix_per_step = frames_per_step * args.size * args.size / 1e6
     value = mpix_per_step * args.steps / dt
 
     if rank == 0:
-        names = ['resample', 'prep', 'mesh_stats', 'mesh_filter', 'combine', 'lattice']
+        names = ['resample', 'resample_mask', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
+                 'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
+                 'hp_solve', 'hp_apply']
         kt = {}
         for nme in names:
             ms, cnt = eng.timing_read(nme)
@@ -193,12 +230,17 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: {args.frames}x {args.size}x{args.size} '
+            'config': {'workload': f'configs[1]+[2]: {args.frames}x {args.size}x{args.size} '
                                    f'TPV frames/GPU, mesh background + weight rescale + '
-                                   f'Lanczos-3 resample + {args.combine} coadd'
-                                   + (', RCCL all-reduce of the partial sums' if world > 1 else ''),
+                                   f'Lanczos-3 resample + {args.combine} coadd (+ AND mask coadd)'
+                                   + (', RCCL all-reduce of the partial sums' if world > 1 else '')
+                                   + ('' if args.no_subtract else
+                                      '; then 1 science frame/GPU: align ref, hotpants 3x3 regions '
+                                      'x 10x10 stamps, r=10, ko=4, subtract'),
                        'frames_per_gpu': args.frames, 'size': args.size,
-                       'combine': args.combine},
+                       'combine': args.combine, 'subtract': not args.no_subtract,
+                       'hotpants': None if args.no_subtract else
+                       {k: getattr(sub.info, k) for k, _ in sub.info._fields_}},
             'kernels': kt,
             'roofline': roofline,
         }

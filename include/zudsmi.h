@@ -226,6 +226,24 @@ int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
                     int kernel, double fscale, float* out_img, float* out_wgt,
                     int32_t* out_mask);
 
+/* ---- per-pixel bookkeeping on device planes ---------------------------------- */
+/* rms = 1/sqrt(w), big_rms where bad or w <= 0 (zuds/image.py:173-208). */
+int zm_rms_from_weight_dev(zm_ctx* ctx, const float* wgt, const uint8_t* bad,
+                           int64_t n, float big_rms, float* out);
+/* w = 1/rms^2, 0 where bad or img >= satur (0.9 SATURATE; zuds/image.py:136-171). */
+int zm_weight_from_rms_dev(zm_ctx* ctx, const float* rms, const uint8_t* bad,
+                           const float* img, float satur, int64_t n, float* out);
+/* out_or = a | b (b may be NULL); out_bpm = (out_or & badsum) != 0
+ * (zuds/subtraction.py:135-142, zuds/mask.py:42-72). */
+int zm_mask_bad_dev(zm_ctx* ctx, const int32_t* a, const int32_t* b,
+                    int32_t badsum, int64_t n, int32_t* out_or, uint8_t* out_bpm);
+/* mask |= bit where img == value: bit 16 from weight == 0 (zuds/mask.py:26-33),
+ * bit 17 from diff == 1e-30 (zuds/subtraction.py:170-171). */
+int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, float value,
+                     int32_t bit, int64_t n);
+/* img += v: the 150-count pedestal (zuds/coadd.py:205-206, zuds/hotpants.py:29). */
+int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n);
+
 /* ---- timing hooks (bench.py reads per-kernel HIP-event times) ------------- */
 /* Enable recording of HIP events around the dominant kernels on the ctx
  * stream; zm_timing_read returns accumulated milliseconds and launch counts. */

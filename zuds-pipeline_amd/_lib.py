@@ -116,6 +116,11 @@ _SIGS = {
                                 C.POINTER(C.c_double)]),
     'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
+    'zm_rms_from_weight_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    'zm_weight_from_rms_dev': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P]),
+    'zm_mask_bad_dev': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P]),
+    'zm_mask_flag_dev': (C.c_int, [_P, _P, _P, C.c_float, C.c_int32, C.c_int64]),
+    'zm_add_scalar_dev': (C.c_int, [_P, _P, C.c_float, C.c_int64]),
     'zm_timing_enable': (C.c_int, [_P, C.c_int]),
     'zm_timing_reset': (C.c_int, [_P]),
     'zm_timing_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double),

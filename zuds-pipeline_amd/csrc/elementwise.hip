@@ -1,0 +1,100 @@
+// Per-pixel bookkeeping kernels of the device-resident pipelines: weight <-> rms
+// maps, mask algebra, pedestal.  They restate numpy one-liners of the reference
+// (cited per entry point) so that a coadd -> subtract chain never leaves HBM.
+#include "zm_internal.h"
+
+#define EW_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream
+
+// rms = 1 / sqrt(w); BIG_RMS where the pixel is bad or w <= 0
+// (CalibratableImageBase.rms_image, zuds/image.py:173-208)
+__global__ void k_rms_from_weight(const float* __restrict__ w, const uint8_t* __restrict__ bad,
+                                  int64_t n, float big, float* __restrict__ out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float ww = w[p];
+    bool b = !(ww > 0.f) || (bad && bad[p]);
+    out[p] = b ? big : 1.0f / sqrtf(ww);
+}
+
+// w = 1 / rms^2; 0 where bad or data >= satur (zuds/image.py:136-171)
+__global__ void k_weight_from_rms(const float* __restrict__ rms, const uint8_t* __restrict__ bad,
+                                  const float* __restrict__ img, float satur, int64_t n,
+                                  float* __restrict__ out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float r = rms[p];
+    bool b = (bad && bad[p]) || (img && satur > 0.f && img[p] >= satur);
+    out[p] = b ? 0.f : 1.0f / (r * r);
+}
+
+// out_or = a | b; out_bpm = ((a | b) & badsum) > 0
+// (zuds/subtraction.py:135-142; MaskImageBase.boolean zuds/mask.py:42-72)
+__global__ void k_mask_bad(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                           int32_t badsum, int64_t n, int32_t* __restrict__ out_or,
+                           uint8_t* __restrict__ out_bpm) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int32_t m = a[p] | (b ? b[p] : 0);
+    if (out_or) out_or[p] = m;
+    if (out_bpm) out_bpm[p] = (m & badsum) != 0;
+}
+
+// mask += bit where img == value (bit 16: weight == 0, zuds/mask.py:26-33;
+// bit 17: diff == 1e-30, zuds/subtraction.py:170-171)
+__global__ void k_mask_flag(int32_t* __restrict__ mask, const float* __restrict__ img, float value,
+                            int32_t bit, int64_t n) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (img[p] == value) mask[p] |= bit;
+}
+
+// img += v (the 150-count pedestal, zuds/coadd.py:205-206, zuds/hotpants.py:29)
+__global__ void k_add_scalar(float* __restrict__ img, float v, int64_t n) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    img[p] += v;
+}
+
+extern "C" int zm_rms_from_weight_dev(zm_ctx* ctx, const float* wgt, const uint8_t* bad, int64_t n,
+                                      float big_rms, float* out) {
+    ZM_CHECK(ctx && wgt && out && n > 0, "zm_rms_from_weight_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_rms_from_weight, EW_GRID(n), wgt, bad, n, big_rms, out);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_weight_from_rms_dev(zm_ctx* ctx, const float* rms, const uint8_t* bad,
+                                      const float* img, float satur, int64_t n, float* out) {
+    ZM_CHECK(ctx && rms && out && n > 0, "zm_weight_from_rms_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_weight_from_rms, EW_GRID(n), rms, bad, img, satur, n, out);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_mask_bad_dev(zm_ctx* ctx, const int32_t* a, const int32_t* b, int32_t badsum,
+                               int64_t n, int32_t* out_or, uint8_t* out_bpm) {
+    ZM_CHECK(ctx && a && n > 0 && (out_or || out_bpm), "zm_mask_bad_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_mask_bad, EW_GRID(n), a, b, badsum, n, out_or, out_bpm);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, float value,
+                                int32_t bit, int64_t n) {
+    ZM_CHECK(ctx && mask && img && n > 0, "zm_mask_flag_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_mask_flag, EW_GRID(n), mask, img, value, bit, n);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n) {
+    ZM_CHECK(ctx && img && n > 0, "zm_add_scalar_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_add_scalar, EW_GRID(n), img, v, n);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}

@@ -109,3 +109,100 @@ class DeviceCoadd(object):
                                                       self.wgt.data_ptr(), self.img.numel()),
                   'zm_coadd_finalize_dev')
         return self.img, self.wgt
+
+
+class DeviceSubtraction(object):
+    """Device-resident single-epoch subtraction: the chain of
+    ``Subtraction.from_images`` (``zuds/subtraction.py:57-226``) and
+    ``prepare_hotpants`` (``zuds/hotpants.py:15-95``) without leaving HBM.
+
+    ref_* live on the reference grid ``wref``; sci_* on the science grid ``wsci``.
+    """
+
+    def __init__(self, wsci, wref, device=0, engine=None, stream=None):
+        from .constants import BAD_SUM, BIG_RMS, BKG_VAL
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.device('cuda', device)
+        self.engine = engine or get_engine(device)
+        if stream is None:
+            stream = torch.cuda.Stream(self.device)
+            self.engine.set_stream(stream.cuda_stream)
+        self.stream = stream
+        self.wsci = wcs_struct(wsci)
+        self.wref = wcs_struct(wref)
+        nx, ny = self.wsci.naxis[0], self.wsci.naxis[1]
+        self.shape = (ny, nx)
+        self.n = nx * ny
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.ref_al = torch.empty(self.shape, **f32)      # reference on the science grid
+        self.ref_al_w = torch.empty(self.shape, **f32)
+        self.refmask_al = torch.empty(self.shape, **i32)
+        self.refrms_al = torch.empty(self.shape, **f32)
+        self.refrms_al_w = torch.empty(self.shape, **f32)
+        self.submask = torch.empty(self.shape, **i32)
+        self.bpm = torch.empty(self.shape, dtype=torch.uint8, device=self.device)
+        self.scibkgsub = torch.empty(self.shape, **f32)
+        self.diff = torch.empty(self.shape, **f32)
+        self.noise = torch.empty(self.shape, **f32)
+        self.BAD_SUM, self.BIG_RMS, self.BKG_VAL = BAD_SUM, float(BIG_RMS), float(BKG_VAL)
+        self.info = _lib.zm_hp_info()
+
+    def run(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
+            nreg_side=3, subtract_back=True, hotpants_kws=None):
+        """All arguments are torch tensors on this device; ``seeing`` is the
+        science FWHM in pixels (header SEEING).  Returns (diff, noise, submask)."""
+        from .engine import hp_params
+        L, ctx = self.engine.L, self.engine.ctx
+        ny, nx = self.shape
+        LAN = _lib.RESAMPLE['LANCZOS3']
+        with self.torch.cuda.stream(self.stream):
+            # ref.aligned_to(sci): image (WEIGHT_TYPE NONE) + mask (OR), fitsfile.py:290-314
+            check(L.zm_resample_dev(ctx, ref.data_ptr(), None, ref_mask.data_ptr(),
+                                    C.byref(self.wref), C.byref(self.wsci), LAN, 1.0,
+                                    self.ref_al.data_ptr(), self.ref_al_w.data_ptr(),
+                                    self.refmask_al.data_ptr()), 'align ref')
+            check(L.zm_mask_flag_dev(ctx, self.refmask_al.data_ptr(), self.ref_al_w.data_ptr(),
+                                     0.0, 1 << 16, self.n), 'bit16')
+            # badpix = remapped_refmask | sci mask; boolean bpm (subtraction.py:135-142)
+            check(L.zm_mask_bad_dev(ctx, self.refmask_al.data_ptr(), sci_mask.data_ptr(),
+                                    self.BAD_SUM, self.n, self.submask.data_ptr(),
+                                    self.bpm.data_ptr()), 'submask')
+            # scimbkg = sci - mesh background + 150 (hotpants.py:27-32)
+            if subtract_back:
+                check(L.zm_background_dev(ctx, sci.data_ptr(),
+                                          sci_wgt.data_ptr() if sci_wgt is not None else None,
+                                          nx, ny, 128, 3, None, None, self.scibkgsub.data_ptr(),
+                                          None), 'sci background')
+                check(L.zm_add_scalar_dev(ctx, self.scibkgsub.data_ptr(), self.BKG_VAL, self.n),
+                      'pedestal')
+                scim = self.scibkgsub
+            else:
+                scim = sci
+            # ref rms aligned to the science grid (hotpants.py:51)
+            check(L.zm_resample_dev(ctx, ref_rms.data_ptr(), None, None, C.byref(self.wref),
+                                    C.byref(self.wsci), LAN, 1.0, self.refrms_al.data_ptr(),
+                                    self.refrms_al_w.data_ptr(), None), 'align ref rms')
+            # quick_background_estimate x 2 (hotpants.py:65-67)
+            m1, s1, m2, s2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+            check(L.zm_median_mad_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(), self.n,
+                                      C.byref(m1), C.byref(s1)), 'sci bkg')
+            check(L.zm_median_mad_dev(ctx, self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
+                                      self.n, C.byref(m2), C.byref(s2)), 'ref bkg')
+            kw = dict(hotpants_kws or {})
+            kw.setdefault('bgo', 0)
+            kw.setdefault('ko', 4)
+            p = hp_params(il=m1.value - 10 * s1.value, tl=m2.value - 10 * s2.value,
+                          tu=5e3, iu=5e3, r=2.5 * seeing, rss=6.0 * seeing,
+                          fin=self.BIG_RMS, nsx=int(nx / 100.0 / nreg_side),
+                          nsy=int(ny / 100.0 / nreg_side), nrx=nreg_side, nry=nreg_side, **kw)
+            check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
+                                    self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
+                                    self.bpm.data_ptr(), nx, ny, C.byref(p),
+                                    self.diff.data_ptr(), self.noise.data_ptr(),
+                                    C.byref(self.info)), 'zm_subtract_dev')
+            # bit 17 where hotpants masked (subtraction.py:167-177)
+            check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
+                                     1 << 17, self.n), 'bit17')
+        return self.diff, self.noise, self.submask
