@@ -1,0 +1,193 @@
+"""Host logic of the drop-in layer (no GPU): FITS I/O, file mapping, naming,
+parameter translation, job sharding."""
+import os
+
+import numpy as np
+import pytest
+
+from util import pkg, synth
+
+
+def test_fits_roundtrip_all_dtypes(tmp_path):
+    z = pkg()
+    rng = np.random.default_rng(0)
+    hdr = {'MAGZP': 26.403007, 'SEEING': 1.943, 'OBJECT': "it's a field", 'CCDID': 3,
+           'PHOTLINK': False, 'FLAG': True, 'CRVAL1': 23.34894444544, 'PV1_4': -0.0004551962017747,
+           'TINY': 1.38158428994e-05, 'BIGINT': 36217380}
+    com = {'MAGZP': 'zero point', 'SEEING': 'FWHM [pix]'}
+    for dt in [np.float32, np.float64, np.int16, np.int32, np.int64, np.uint8, np.uint16, bool]:
+        if dt is bool:
+            a = rng.uniform(size=(7, 5)) < 0.5
+        elif np.issubdtype(dt, np.floating):
+            a = rng.normal(0, 100, (7, 5)).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            a = rng.integers(max(info.min, -2**40), min(info.max, 2**40), (7, 5)).astype(dt)
+        p = tmp_path / f'a_{np.dtype(dt).name}.fits'
+        z.fits.write(p, a, hdr, com)
+        assert os.path.getsize(p) % 2880 == 0
+        b, h, c = z.fits.read(p)
+        if dt is bool:
+            assert b.dtype == np.uint8 and np.array_equal(b.astype(bool), a)
+        else:
+            assert np.array_equal(b, a) and b.dtype == np.dtype(dt)
+        assert h['NAXIS1'] == 5 and h['NAXIS2'] == 7
+        for k, v in hdr.items():
+            assert h[k] == v, (k, h[k], v)
+            assert type(h[k]) is type(v)
+        assert c['MAGZP'] == 'zero point'
+
+
+def test_fits_rejects_garbage(tmp_path):
+    z = pkg()
+    p = tmp_path / 'x.fits'
+    p.write_bytes(b'not a fits file' * 300)
+    with pytest.raises(ValueError):
+        z.fits.read(p)
+    z.fits.write(p, np.zeros((4, 4), np.float32), {})
+    raw = p.read_bytes()
+    p.write_bytes(raw[:2880 + 10])
+    with pytest.raises(ValueError):
+        z.fits.read(p)
+
+
+def test_file_mapping_semantics(tmp_path):
+    z = pkg()
+    im = z.FITSImage()
+    im.basename = 'a.fits'
+    assert not im.ismapped
+    with pytest.raises(z.UnmappedFileError):
+        im.local_path
+    with pytest.raises(z.UnmappedFileError):
+        im.unmap()
+    im.data = np.ones((3, 4), np.float32)
+    im.header = {'X': 1}
+    im.header_comments = {}
+    im.map_to_local_file(tmp_path / 'a.fits')
+    assert im.ismapped and im.local_path == str(tmp_path / 'a.fits')
+    im.save()
+    assert not hasattr(im, '_data')              # save() drops the cached data (fitsfile.py:206)
+    assert im.data.shape == (3, 4)               # and .data reloads lazily
+    im2 = z.FITSImage.from_file(tmp_path / 'a.fits')
+    assert im2.header['X'] == 1 and im2.basename == 'a.fits'
+    im2.unmap()
+    assert not im2.ismapped and not hasattr(im2, '_data')
+    # uint8 data come back as booleans (fitsfile.py:91-93)
+    b = z.FITSImage()
+    b.basename = 'b.fits'
+    b.data = np.array([[True, False]])
+    b.header, b.header_comments = {}, {}
+    b.map_to_local_file(tmp_path / 'b.fits')
+    b.save()
+    assert b.data.dtype == bool
+
+
+def test_sub_name_and_constants():
+    z = pkg()
+    assert z.sub_name('/d/ztf_1_sciimg.fits', '/r/ref.000651_c03_q1_zg.zuds5.fits') == \
+        '/d/sub.ztf_1_sciimg_ref.000651_c03_q1_zg.zuds5.fits'
+    assert z.BAD_SUM == 198589 and z.BKG_VAL == 150.0
+    assert abs(z.BIG_RMS - 50000 ** 0.5) < 1e-12 and z.BKG_BOX_SIZE == 128
+
+
+def test_mask_boolean_and_weight_rms_properties():
+    z = pkg()
+    m = z.MaskImageBase()
+    m.basename = 'x.mask.fits'
+    m.data = np.array([[0, 2, 256, 1 << 16, 1 << 17, 2048, 1]], dtype=np.int32)
+    m.header, m.header_comments = {}, {}
+    assert m.boolean.data.tolist() == [[False, False, True, True, True, False, True]]
+    assert m.boolean.basename == 'x.mask.bpm.fits'
+    im = z.CalibratableImageBase()
+    im.basename = 'x.fits'
+    im.header, im.header_comments = {'SATURATE': 1000.0}, {}
+    im.data = np.array([[10., 20., 30., 40., 50., 60., 950.]], dtype=np.float32)
+    im.mask_image = m
+    rms = z.FITSImage()
+    rms.data = np.full((1, 7), 2.0, np.float32)
+    im._rmsimg = rms
+    w = im.weight_image.data
+    assert w.tolist() == [[0.25, 0.25, 0, 0, 0, 0.25, 0]]       # bad bits and >= 0.9 SATURATE
+    del im._rmsimg
+    r = im.rms_image.data
+    np.testing.assert_allclose(r, [[2, 2, z.BIG_RMS, z.BIG_RMS, z.BIG_RMS, 2, z.BIG_RMS]], rtol=1e-6)
+
+
+def test_swarp_kws_translate_and_unknown_keys_are_dropped(tmp_path):
+    z = pkg()
+    s = synth()
+    frames = s.config1(n=2, nx=64, ny=64)
+    ims = []
+    for i, f in enumerate(frames):
+        im = z.CalibratableImageBase()
+        im.basename = f'f{i}.fits'
+        im.data, im.header, im.header_comments = f['img'], dict(f['header']), {}
+        ims.append(im)
+    call = z.prepare_swarp_sci(ims, str(tmp_path / 'o.fits'), tmp_path / 'work',
+                               swarp_kws={'combine_type': 'median', 'CLIP_SIGMA': 3.5,
+                                          'REFINED': True, 'force_map_subs': False,
+                                          'SUBTRACT_BACK': 'N'})
+    assert call.params['combine'] == 'MEDIAN' and call.params['clip_sigma'] == 3.5
+    assert call.params['subtract_back'] is False and call.params['back_size'] == 128
+    assert '-COMBINE_TYPE median' in call.command and call.command.startswith('swarp -c ')
+    assert 'REFINED' not in call.params
+    assert ims[0].header['FLXSCALE'] == 10 ** (-0.4 * (ims[0].header['MAGZP'] - 25.0))
+    assert ims[0].header['FLXSCLZP'] == 25.0
+    assert call.wgtout.endswith('o.weight.fits')
+
+
+def test_get_time_formats():
+    z = pkg()
+    class I:
+        basename = 'x'
+    i = I()
+    i.header = {'OBSJD': 2458000.5}
+    assert z.get_time(i, 'mjd') == 58000.0 and z.get_time(i, 'jd') == 2458000.5
+    i.header = {'DATE-OBS': '2017-09-04T12:00:00'}
+    assert abs(z.get_time(i, 'mjd') - 58000.5) < 1e-9
+    i.header = {}
+    with pytest.raises(ValueError):
+        z.get_time(i, 'mjd')
+
+
+def test_job_sharding_matches_array_split(tmp_path, monkeypatch):
+    z = pkg()
+    jobs = tmp_path / 'jobs.txt'
+    jobs.write_text('\n'.join(f'/data/img{i}.fits' for i in range(11)) + '\n')
+    allj = z.get_my_share_of_work(str(jobs))
+    assert len(allj) == 11
+    got = []
+    for r in range(4):
+        monkeypatch.setenv('RANK', str(r))
+        monkeypatch.setenv('WORLD_SIZE', '4')
+        got.append(list(z.get_my_share_of_work(str(jobs))))
+    assert [len(g) for g in got] == [3, 3, 3, 2]
+    assert sum(got, []) == list(allj)
+    monkeypatch.setenv('SLURM_ARRAY_JOB_ID', '1')
+    monkeypatch.setenv('SLURM_ARRAY_TASK_ID', '1')
+    monkeypatch.setenv('SLURM_ARRAY_TASK_MAX', '1')
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    assert list(z.get_my_share_of_work(str(jobs))) == list(allj[6:])
+
+
+def test_coadd_argument_checks_do_not_need_a_gpu(tmp_path):
+    z = pkg()
+    im = z.ScienceImage()
+    im.basename = 'a.fits'
+    im.header, im.header_comments = {'MAGZP': 25.0}, {}
+    im.field, im.ccdid, im.qid, im.fid = 1, 1, 1, 1
+    other = z.ScienceImage()
+    other.basename = 'b.fits'
+    other.header, other.header_comments = {'MAGZP': 25.0}, {}
+    other.field, other.ccdid, other.qid, other.fid = 2, 1, 1, 1
+    with pytest.raises(ValueError, match='same field'):
+        z.ScienceCoadd.from_images([im, other], str(tmp_path / 'o.fits'))
+    with pytest.raises(ValueError, match='does not have a mask'):
+        z.ScienceCoadd.from_images([im], str(tmp_path / 'o.fits'))
+    with pytest.raises(TypeError):
+        z.ScienceCoadd.from_images([im])
+    with pytest.raises(TypeError, match='ScienceCoadd'):
+        z.MultiEpochSubtraction.from_images(im, im)
+    with pytest.raises(ValueError, match='weight map or'):
+        z.SingleEpochSubtraction.from_images(im, im)

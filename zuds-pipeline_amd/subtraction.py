@@ -1,0 +1,182 @@
+"""Difference-image products (``zuds/subtraction.py``): same classes, signatures,
+naming (``sub.<new>_<ref>.fits`` + ``.rms.fits`` + ``.mask.fits``) and mask-bit
+semantics; the SWarp / SExtractor / hotpants processes are libzudsmi calls."""
+import os
+import uuid
+from pathlib import Path
+
+import numpy as np
+
+from .coadd import ScienceCoadd, _coadd_from_images
+from .constants import APER_KEY
+from .fitsfile import HasWCS
+from .image import CalibratableImage, CalibratedImage, FITSImage
+from .mask import MaskImage, MaskImageBase
+
+__all__ = ['sub_name', 'Subtraction', 'SingleEpochSubtraction', 'MultiEpochSubtraction']
+
+
+def sub_name(frame, template):
+    """``sub.<frame[:-5]>_<template[:-5]>.fits`` in the science directory
+    (``zuds/subtraction.py:25-37``)."""
+    frame = f'{frame}'
+    template = f'{template}'
+    refp = os.path.basename(template)[:-5]
+    newp = os.path.basename(frame)[:-5]
+    outdir = os.path.dirname(frame)
+    subp = '_'.join([newp, refp])
+    return os.path.join(outdir, 'sub.%s.fits' % subp)
+
+
+def _shallow(obj, cls):
+    """In-memory stand-in for the reference's on-disk transaction copy: a new
+    object of class ``cls`` sharing ``obj``'s arrays and header."""
+    new = cls()
+    new.basename = obj.basename
+    new.header = obj.header
+    new.header_comments = obj.header_comments
+    new.data = obj.data
+    if obj.ismapped:
+        new._path = obj.local_path
+    for prop in ('field', 'ccdid', 'qid', 'fid'):
+        if hasattr(obj, prop):
+            setattr(new, prop, getattr(obj, prop))
+    return new
+
+
+class Subtraction(HasWCS):
+
+    reference_image = None
+    target_image = None
+
+    @property
+    def mjd(self):
+        return self.target_image.mjd
+
+    @classmethod
+    def from_images(cls, sci, ref, data_product=False, tmpdir='/tmp', **kwargs):
+        """``zuds/subtraction.py:57-226``: align the reference (and its mask) to
+        the science grid, OR the masks, subtract with hotpants' algorithm, flag
+        bit 17 where the difference carries the fill value 1e-30."""
+        from .hotpants import prepare_hotpants
+
+        subtract_new_back = kwargs.get('subtract_back', True)
+        nreg_side = kwargs.get('nreg_side', 3)
+        hotpants_kws = kwargs.get('hotpants_kws', {})
+
+        if not (hasattr(sci, '_rmsimg') or hasattr(sci, '_weightimg')):
+            raise ValueError('Science image must have a weight map or '
+                             'rms map defined prior to subtraction.')
+        if getattr(sci, 'mask_image', None) is None or getattr(ref, 'mask_image', None) is None:
+            raise ValueError('Science and reference images must have masks.')
+
+        directory = Path(tmpdir) / uuid.uuid4().hex
+        final_dir = os.path.dirname(sci.local_path)
+        final_out = os.path.join(final_dir, os.path.basename(
+            sub_name(sci.local_path, ref.local_path)))
+        outmask = final_out.replace('.fits', '.mask.fits')
+
+        # The reference works on transaction copies whose masks are plain
+        # MaskImageBase objects (zuds/subtraction.py:94-99): aligning such a mask
+        # uses COMBINE_TYPE OR but does not add bit 16 (zuds/swarp.py:184-191).
+        transact_ref = _shallow(ref, ref.__class__)
+        transact_ref.mask_image = _shallow(ref.mask_image, MaskImageBase)
+        transact_ref._weightimg = ref.weight_image
+
+        # remapped ref and remapped ref mask on the science grid
+        remapped_ref = transact_ref.aligned_to(sci, tmpdir=tmpdir)
+        remapped_refmask = remapped_ref.mask_image
+        remapped_ref.parent_image = transact_ref
+
+        # a totally new copy of the mask
+        submask = MaskImageBase()
+        submask.basename = os.path.basename(outmask)
+        for prop in ('field', 'ccdid', 'qid', 'fid'):
+            setattr(submask, prop, getattr(sci, prop, None))
+        submask.map_to_local_file(outmask)
+        badpix = remapped_refmask.data.astype(np.int32) | sci.mask_image.data.astype(np.int32)
+        submask.data = badpix
+        submask.header = dict(sci.mask_image.header or {})
+        submask.header_comments = dict(sci.mask_image.header_comments or {})
+
+        call = prepare_hotpants(sci, remapped_ref, final_out, submask.boolean, directory,
+                                tmpdir=tmpdir, nreg_side=nreg_side,
+                                subtract_new_back=subtract_new_back,
+                                hotpants_kws=hotpants_kws)
+        try:
+            os.rmdir(directory)
+        except OSError:
+            pass
+        sd, _ = call.run()                       # writes final_out and its .rms.fits
+
+        # flip bit 17 where hotpants masked the output (zuds/subtraction.py:167-177)
+        hotbad = np.zeros_like(submask.data, dtype=np.int32)
+        hotbad[sd == np.float32(1e-30)] = 2 ** 17
+        submask.data = submask.data | hotbad
+        submask.header['BIT17'] = 17
+        submask.header_comments['BIT17'] = 'MASKED BY HOTPANTS (1e-30) / DG'
+        submask.save()
+
+        sub = cls.from_file(final_out, load_others=False) \
+            if issubclass(cls, CalibratableImage) else cls.from_file(final_out)
+        finalsubmask = MaskImage.from_file(outmask)
+        sub._rmsimg = FITSImage.from_file(final_out.replace('.fits', '.rms.fits'))
+        for img in (sub, finalsubmask):
+            for prop in ('field', 'ccdid', 'qid', 'fid'):
+                v = getattr(sci, prop, None)
+                setattr(img, prop, v)
+                if v is not None:
+                    img.header[prop.upper()] = v
+        sub.mask_image = finalsubmask
+        finalsubmask.parent_image = sub
+        sub.reference_image = ref
+        sub.target_image = sci
+        sub.hotpants_info = call.info
+        sub.header['SEEING'] = sci.header['SEEING']
+        sub.header_comments['SEEING'] = (sci.header_comments or {}).get('SEEING', '')
+        if isinstance(sub, CalibratedImage):
+            for key in ('MAGZP', APER_KEY):
+                if key in sci.header:
+                    sub.header[key] = sci.header[key]
+                    sub.header_comments[key] = (sci.header_comments or {}).get(key, '')
+        sub.save()
+        sub.mask_image.save()
+        return sub
+
+
+class SingleEpochSubtraction(Subtraction, CalibratedImage):
+    """``zuds/subtraction.py:229-240``."""
+
+
+class MultiEpochSubtraction(Subtraction, CalibratableImage):
+    """A CLIPPED coadd of single-epoch subtractions (``zuds/subtraction.py:261-319``)."""
+
+    input_images = None
+
+    @classmethod
+    def from_images(cls, sci, ref, data_product=False, tmpdir='/tmp', **kwargs):
+        force_map_subs = kwargs.pop('force_map_subs', True)
+        if not isinstance(sci, ScienceCoadd):
+            raise TypeError(f'Input science image "{sci.basename}" must be '
+                            f'an instance of ScienceCoadd, got {type(sci)}.')
+        # without a database the single-epoch subtractions are handed over, or
+        # looked up as attributes of the stack inputs
+        images = kwargs.pop('single_epoch_subtractions', None)
+        if images is None:
+            images = [getattr(i, 'single_epoch_subtraction', None) for i in sci.input_images]
+            images = [i for i in images if i is not None and i.reference_image is ref]
+        if len(images) != len(sci.input_images):
+            raise ValueError('Number of single-epoch subtractions != number'
+                             f' of stack inputs. Stack inputs: '
+                             f'{[i.basename for i in sci.input_images]}, '
+                             f'Single-epoch subtractions: '
+                             f'{[i.basename for i in images]}')
+        outfile_name = sub_name(sci.local_path, ref.local_path)
+        coadd = _coadd_from_images(cls, images, outfile_name, sci_swarp_kws=kwargs,
+                                   mask_swarp_kws=kwargs, addbkg=False,
+                                   calculate_seeing=False, tmpdir=tmpdir)
+        coadd.reference_image = ref
+        coadd.target_image = sci
+        coadd.header['SEEING'] = sci.header['SEEING']
+        coadd.save()
+        return coadd
