@@ -1,0 +1,129 @@
+"""The N > 1 coadd path on CPU: 2 processes, gloo, an oracle-backed arithmetic
+backend.  What is under test is the sharding / collective logic of
+zuds-pipeline_amd/parallel.py; the HIP backend shares it unchanged."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import combine as ocombine
+from oracle import resample as oresample
+from util import pkg, synth, to_oracle_wcs
+
+
+class OracleBackend(object):
+    """Same interface as parallel.HipBackend, arithmetic from the oracle (CPU)."""
+
+    def __init__(self, wout, kind):
+        self.wout, self.kind = wout, kind
+        self.shape = (wout.naxis[1], wout.naxis[0])
+
+    def resample_stack(self, frames):
+        onx, ony = self.wout.naxis
+        out = np.zeros((len(frames), ony, onx, 2))
+        for i, f in enumerate(frames):
+            px, py = oresample.positions(to_oracle_wcs(self.wout), to_oracle_wcs(f['wcs']), onx, ony)
+            v, w, _ = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3,
+                                         f['flxscale'])
+            out[i, ..., 0], out[i, ..., 1] = v, w
+        return torch.from_numpy(out)
+
+    def combine(self, stack):
+        s = stack.numpy()
+        if s.shape[1] == 0:
+            return torch.zeros(s.shape[1:3], dtype=torch.float64), torch.zeros(s.shape[1:3], dtype=torch.float64)
+        v, w, _ = ocombine.combine(s[..., 0], s[..., 1], self.kind)
+        return torch.from_numpy(v), torch.from_numpy(w)
+
+    def partial_sums(self, frames):
+        s = self.resample_stack(frames).numpy()
+        w = np.where(s[..., 1] > 0, s[..., 1], 0.0)
+        return torch.from_numpy((w * s[..., 0]).sum(0)), torch.from_numpy(w.sum(0))
+
+    def finalize(self, s1, s0):
+        s1[:] = torch.where(s0 > 0, s1 / torch.where(s0 > 0, s0, torch.ones_like(s0)), torch.zeros_like(s1))
+        return s1, s0
+
+    def scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def empty(self, shape):
+        return torch.empty(shape, dtype=torch.float64)
+
+
+def make_frames():
+    s = synth()
+    base = s.ztf_wcs(96, 75, tpv=True)      # 75 rows: bands of 38 and 37
+    frames = []
+    for i in range(5):
+        r = np.random.default_rng(700 + i)
+        w = s.ztf_wcs(96, 75, dx=r.uniform(-3, 3), dy=r.uniform(-3, 3), rot_deg=r.uniform(-0.2, 0.2))
+        f = s.make_frame(96, 75, 700 + i, w, nstars=10, nbad=30)
+        frames.append(f)
+    frames[1]['img'][30:32, 40:42] += 4000
+    return base, frames
+
+
+def worker(rank, world, port, kind, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = pkg().parallel if hasattr(pkg(), 'parallel') else __import__('importlib').import_module('zuds-pipeline_amd.parallel')
+    base, frames = make_frames()
+    mine = frames[:3] if rank == 0 else frames[3:]      # uneven shards: 3 + 2
+    sc = par.ShardedCoadd(OracleBackend(base, kind))
+    if kind == 'WEIGHTED':
+        img, wgt = sc.weighted(mine)
+    else:
+        img, wgt = sc.exact(mine)
+    q.put((rank, img.numpy().copy(), wgt.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('kind', ['CLIPPED', 'MEDIAN', 'WEIGHTED'])
+def test_two_rank_coadd_equals_single_process(kind):
+    base, frames = make_frames()
+    ob = OracleBackend(base, kind)
+    stack = ob.resample_stack(frames)
+    ref_img, ref_wgt = ob.combine(stack) if kind != 'WEIGHTED' else ob.finalize(*ob.partial_sums(frames))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, img, wgt in results:
+        if kind == 'WEIGHTED':
+            np.testing.assert_allclose(img, ref_img.numpy(), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(wgt, ref_wgt.numpy(), rtol=1e-12)
+        else:
+            # the row-band transpose does not change any arithmetic: bit identical
+            assert np.array_equal(img, ref_img.numpy()), f'rank {rank}'
+            assert np.array_equal(wgt, ref_wgt.numpy()), f'rank {rank}'
+
+
+def test_band_bounds_follow_array_split():
+    par = __import__('importlib').import_module('zuds-pipeline_amd.parallel')
+    for n in [1, 7, 75, 3072, 3080]:
+        for w in [1, 2, 3, 8]:
+            b = par.band_bounds(n, w)
+            ref = np.cumsum([0] + [len(c) for c in np.array_split(np.arange(n), w)]).tolist()
+            assert b == ref
