@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--combine', default='WEIGHTED')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-subtract', action='store_true')
+    ap.add_argument('--no-mask', action='store_true', help='skip the mask coadd (dev only)')
     ap.add_argument('--seeing', type=float, default=4.0,
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
     ap.add_argument('--cpu-sample', type=int, default=1024,
@@ -153,7 +154,7 @@ def main():
     params = z.coadd_params(combine=args.combine, subtract_back=True,
                             rescale_weights=True)
     dframes = dev.DeviceFrames(frames, device)
-    coadd = dev.DeviceCoadd(base, params, device=local, engine=eng, want_mask=True)
+    coadd = dev.DeviceCoadd(base, params, device=local, engine=eng, want_mask=not args.no_mask)
     sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng,
                                 stream=coadd.stream)
     ref_rms = torch.empty_like(coadd.wgt)
@@ -167,8 +168,9 @@ def main():
         else:
             coadd.run(dframes)
         with torch.cuda.stream(coadd.stream):
-            z._lib.check(L.zm_mask_flag_dev(eng.ctx, coadd.mask.data_ptr(),
-                                            coadd.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
+            if coadd.mask is not None:
+                z._lib.check(L.zm_mask_flag_dev(eng.ctx, coadd.mask.data_ptr(),
+                                                coadd.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
             z._lib.check(L.zm_add_scalar_dev(eng.ctx, coadd.img.data_ptr(), 150.0, npx))
             z._lib.check(L.zm_rms_from_weight_dev(eng.ctx, coadd.wgt.data_ptr(), None, npx,
                                                   float(np.sqrt(50000.0)), ref_rms.data_ptr()))

@@ -52,12 +52,17 @@ def mesh_histogram_stats(pix):
     nlevels = int(step * npix + 1)
     if nlevels > QUANTIF_NMAXLEVELS:
         nlevels = QUANTIF_NMAXLEVELS
-    qscale = 2.0 * QUANTIF_NSIGMA * sig / nlevels if sig > 0 else 1.0
-    qzero = mean - QUANTIF_NSIGMA * sig
-    b = np.floor((pix - qzero) / qscale + 0.5).astype(np.int64)
+    # SExtractor keeps mean, sigma, qscale, qzero and the bin offset in floats and
+    # bins with (int)(pix / qscale + cste): float arithmetic, truncation toward 0
+    f32 = np.float32
+    mean32, sig32 = f32(mean), f32(sig)
+    qscale = f32(2.0 * QUANTIF_NSIGMA * np.float64(sig32) / nlevels) if sig32 > 0 else f32(1.0)
+    qzero = f32(np.float64(mean32) - QUANTIF_NSIGMA * np.float64(sig32))
+    cste = f32(0.499999 - np.float64(qzero / qscale))
+    b = np.trunc(pix.astype(f32) / qscale + cste).astype(np.int64)
     b = b[(b >= 0) & (b < nlevels)]
     histo = np.bincount(b, minlength=nlevels).astype(np.int64)
-    return dict(mean=mean, sigma=sig, qzero=qzero, qscale=qscale,
+    return dict(mean=float(mean32), sigma=float(sig32), qzero=float(qzero), qscale=float(qscale),
                 nlevels=nlevels, histo=histo)
 
 

@@ -81,8 +81,6 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     for (int i = 0; i < n; ++i)
         ZM_TRY(zm_launch_lattice(ctx, &mp_host[i], lnx, lny, lat + (size_t)i * lnx * lny));
 
-    int32_t* mtmp = nullptr;
-    if (acc_mask) ZM_TRY(ctx->get("mask_tmp", sizeof(int32_t) * opix, (void**)&mtmp));
     bool first_mask = true;
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1];
@@ -93,32 +91,27 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
         int nbx = 0, nby = 0;
         const float wthresh = (float)P->weight_thresh;
         if (P->subtract_back || (P->rescale_weights && fr[i].wgt)) {
-            // everything stays on the device: no host round trip per frame
+            // image background and variance level in one launch pair; everything
+            // stays on the device: no host round trip per frame
+            const int nmode = (P->rescale_weights && fr[i].wgt) ? 2 : 1;
             ZM_TRY(zm_frame_background(ctx, fr[i].img, fr[i].wgt, nx, ny, P->back_size,
-                                       P->back_filtersize, wthresh, 0, &bknodes, &bstats, &nbx,
-                                       &nby, "cbk"));
-            if (P->rescale_weights && fr[i].wgt) {
-                float *vnodes = nullptr, *vstats = nullptr;
-                int vx = 0, vy = 0;
-                ZM_TRY(zm_frame_background(ctx, nullptr, fr[i].wgt, nx, ny, P->back_size,
-                                           P->back_filtersize, wthresh, 1, &vnodes, &vstats, &vx,
-                                           &vy, "cvar"));
+                                       P->back_filtersize, wthresh, 0, nmode, &bknodes, &bstats,
+                                       &nbx, &nby, "cbk"));
+            if (nmode == 2) {
                 ZM_TRY(ctx->get("var_scale", 16, (void**)&var_scale));
-                ZM_TRY(zm_launch_var_scale(ctx, bstats, vstats, var_scale));
+                ZM_TRY(zm_launch_var_scale(ctx, bstats, bstats + 2, var_scale));
             }
             if (!P->subtract_back) bknodes = nullptr;
         }
         ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size,
                               var_scale, wthresh, src, spitch));
+        // the mask rides along with its frame: same tile, same positions
+        const bool with_mask = acc_mask && fr[i].mask;
         ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat + (size_t)i * lnx * lny, lnx, lny,
                                   P->resample, (float)fscale[i], stack + (size_t)i * opix, onx,
-                                  ony, lds[i]));
-        if (acc_mask && fr[i].mask) {
-            ZM_TRY(zm_launch_resample_mask(ctx, fr[i].mask, nx, ny, lat + (size_t)i * lnx * lny,
-                                           lnx, lny, P->resample, mtmp, onx, ony, mask_fill));
-            ZM_TRY(zm_launch_mask_accum(ctx, acc_mask, mtmp, opix, mask_kind, first_mask ? 1 : 0));
-            first_mask = false;
-        }
+                                  ony, lds[i], fr[i].mask, acc_mask, with_mask ? 2 : 0, mask_kind,
+                                  first_mask ? 1 : 0));
+        if (with_mask) first_mask = false;
     }
     if (acc_mask && first_mask) ZM_HIP(hipMemsetAsync(acc_mask, 0xFF, sizeof(int32_t) * opix, ctx->stream));
     return 0;
@@ -195,12 +188,12 @@ extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
         ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix, (void**)&dst));
         ZM_TRY(zm_launch_prep(ctx, img, wgt, nx, ny, nullptr, 0, 0, 0, nullptr, 1e-30f, src, spitch));
         ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, (float)fscale,
-                                  dst, onx, ony, lds));
+                                  dst, onx, ony, lds, mask, out_mask, mask ? 1 : 0, 0, 1));
         ZM_TRY(zm_launch_split_pairs(ctx, dst, opix, out_img, out_wgt));
-    }
-    if (mask)
+    } else if (mask) {
         ZM_TRY(zm_launch_resample_mask(ctx, mask, nx, ny, lat, lnx, lny, kernel, out_mask, onx,
                                        ony, 0));
+    }
     return 0;
 }
 

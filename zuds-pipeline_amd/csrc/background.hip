@@ -31,28 +31,428 @@ __device__ inline double block_sum(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+#define BK_PER (BK_NLEVELS / BK_THREADS)   // 16 histogram bins per thread
+
+// 21 KB per workgroup, so several meshes share a CU: only the count prefix is
+// kept per bin; the first and second moment prefixes are kept per 16-bin block
+// and completed on demand from the counts.
 struct mesh_lds {
     int histo[BK_NLEVELS];          // counts, then inclusive prefix P0
-    long long p1[BK_NLEVELS];       // inclusive prefix of h * i
-    long long p2[BK_NLEVELS];       // inclusive prefix of h * i * i
+    long long b1[BK_THREADS];       // sum of h * i over the bins before block t
+    long long b2[BK_THREADS];       // sum of h * i * i over the bins before block t
     double red[4];
-    long long sred[3][BK_THREADS];
+    long long wsum[3][4];
 };
 
-// mode 0: statistic of img; mode 1: statistic of 1 / wgt (variance level)
-__global__ __launch_bounds__(BK_THREADS) void k_mesh_stats(const float* __restrict__ img,
-                                                           const float* __restrict__ wgt,
-                                                           int nx, int ny, int mesh, int nbx,
-                                                           float wthresh, int mode,
-                                                           float* __restrict__ back,
-                                                           float* __restrict__ sigm) {
+// Histogram quantisation exactly as SExtractor's backstat / backhisto: the mesh
+// mean and sigma are rounded to float, qscale / qzero / cste are floats, the bin
+// is (int)(pix / qscale + cste) in float arithmetic (truncation toward zero).
+struct bk_quant {
+    float qscale, qzero, cste;
+    int nlevels;
+};
+
+__device__ inline bk_quant make_quant(double mean, double sig, double npix) {
+    bk_quant q;
+    const float mean32 = (float)mean, sig32 = (float)sig;
+    int nl = (int)(0.7978845608028654 * 5.0 / 4.0 * npix + 1.0);
+    q.nlevels = nl > BK_NLEVELS ? BK_NLEVELS : nl;
+    q.qscale = sig32 > 0.f ? (float)(2.0 * 5.0 * (double)sig32 / q.nlevels) : 1.0f;
+    q.qzero = (float)((double)mean32 - 5.0 * (double)sig32);
+    q.cste = (float)(0.499999 - (double)(q.qzero / q.qscale));
+    return q;
+}
+
+// Iterated +-3 sigma clip of `backguess` on the prefix arrays (exact integers).
+// Run by one whole wave: the two-pointer median walk is replaced by its
+// merge-path equivalent, searched 64 candidates at a time.
+__device__ inline void backguess_wave(const int* __restrict__ P0, const long long* __restrict__ B1,
+                                      const long long* __restrict__ B2, const bk_quant q,
+                                      double mean0, float* ob, float* os) {
+    const int lane = threadIdx.x & 63;
+    auto p0 = [&](int i) -> long long { return i < 0 ? 0 : (long long)P0[i]; };
+    const int nlm1 = q.nlevels - 1;
+    if (p0(nlm1) == 0) {
+        if (lane == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
+        return;
+    }
+    int lcut = 0, hcut = nlm1;
+    double sg = 10.0 * nlm1, sg1 = 1.0, mea = mean0, med = mean0;
+    for (int n = 100; n-- && sg >= 0.1 && fabs(sg / sg1 - 1.0) > 1e-4;) {
+        sg1 = sg;
+        // moments over [lcut, hcut]: lanes 0-15 complete the prefix at hcut, lanes
+        // 16-31 the prefix at lcut - 1, from the per-block sums and the counts
+        long long m1 = 0, m2 = 0;
+        {
+            const int grp = lane >> 4, l16 = lane & 15;
+            const int x = grp == 0 ? hcut : lcut - 1;
+            long long c1 = 0, c2 = 0;
+            if (grp < 2 && x >= 0) {
+                const int t = x >> 4, i = 16 * t + l16;
+                if (i <= x) {
+                    long long hh = p0(i) - p0(i - 1);
+                    c1 = hh * i;
+                    c2 = c1 * i;
+                }
+                if (l16 == 0) { c1 += B1[t]; c2 += B2[t]; }
+            }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+            m1 = __shfl(c1, 0) - __shfl(c1, 16);
+            m2 = __shfl(c2, 0) - __shfl(c2, 16);
+        }
+        const long long sum = p0(hcut) - p0(lcut - 1);
+        mea = (double)m1;
+        sg = (double)m2;
+        // largest a in [0, T] with a == 0 or L(a - 1) < H(T - a)
+        const int T = hcut - lcut + 1;
+        const long long base_lo = p0(lcut - 1), top = p0(hcut);
+        int lo = 0, hi = T;
+        while (hi > lo) {
+            const int span = hi - lo;
+            const int step = (span + 63) >> 6;
+            const int a = lo + (lane + 1) * step;
+            bool ok = false;
+            if (a <= hi) {
+                long long La = p0(lcut + a - 2) - base_lo;
+                long long Hb = top - p0(hcut - (T - a));
+                ok = La < Hb;
+            }
+            const int k = __popcll(__ballot(ok));      // predicate is monotone: k leading trues
+            const int nlo = lo + k * step;
+            const int nhi = lo + (k + 1) * step - 1;
+            lo = nlo < hi ? nlo : hi;
+            hi = nhi < hi ? nhi : hi;
+            if (lo > hi) hi = lo;
+        }
+        const int a = lo, b = T - a;
+        const long long lowsum = p0(lcut + a - 1) - base_lo;
+        const long long highsum = top - p0(hcut - b);
+        const int ihigh = hcut - b, ilow = lcut + a;
+        if (ihigh >= 0) {
+            long long ha = p0(ilow) - p0(ilow - 1), hb = p0(ihigh) - p0(ihigh - 1);
+            double den = 2.0 * (double)(ha > hb ? ha : hb);
+            med = ihigh + 0.5 + (den > 0 ? (double)(highsum - lowsum) / den : 0.0);
+        } else {
+            med = 0.0;
+        }
+        if (sum) {
+            mea /= (double)sum;
+            sg = sg / (double)sum - mea * mea;
+        }
+        sg = sg > 0.0 ? sqrt(sg) : 0.0;
+        double ft = med - 3.0 * sg;
+        lcut = ft > 0.0 ? (int)(ft + 0.5) : 0;
+        ft = med + 3.0 * sg;
+        hcut = ft < nlm1 ? (ft > 0.0 ? (int)(ft + 0.5) : (int)(ft - 0.5)) : nlm1;
+    }
+    const double qz = q.qzero, qs = q.qscale;
+    double modev;
+    if (sg > 0.0)
+        modev = fabs((mea - med) / sg) < 0.3 ? qz + (2.5 * med - 1.5 * mea) * qs : qz + med * qs;
+    else
+        modev = qz + mea * qs;
+    if (lane == 0) { *ob = (float)modev; *os = (float)(sg * qs); }
+}
+
+// In-place inclusive prefix of the counts, plus the exclusive block sums of
+// h * i and h * i * i (one 16-bin block per thread).
+__device__ inline void histo_prefix(mesh_lds* S) {
+    const int tid = threadIdx.x;
+    long long a0 = 0, a1 = 0, a2 = 0;
+    int hloc[BK_PER];
+#pragma unroll
+    for (int k = 0; k < BK_PER; ++k) {
+        const int i = tid * BK_PER + k;
+        const int hh = S->histo[i];
+        hloc[k] = hh;
+        a0 += hh;
+        a1 += (long long)hh * i;
+        a2 += (long long)hh * i * i;
+    }
+    long long e0 = a0, e1 = a1, e2 = a2;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        long long t0 = __shfl_up(e0, o), t1 = __shfl_up(e1, o), t2 = __shfl_up(e2, o);
+        if (lane >= o) { e0 += t0; e1 += t1; e2 += t2; }
+    }
+    if (lane == 63) { S->wsum[0][wave] = e0; S->wsum[1][wave] = e1; S->wsum[2][wave] = e2; }
+    __syncthreads();
+    long long o0 = 0, o1 = 0, o2 = 0;
+    for (int w = 0; w < wave; ++w) { o0 += S->wsum[0][w]; o1 += S->wsum[1][w]; o2 += S->wsum[2][w]; }
+    S->b1[tid] = o1 + e1 - a1;
+    S->b2[tid] = o2 + e2 - a2;
+    int run = (int)(o0 + e0 - a0);
+#pragma unroll
+    for (int k = 0; k < BK_PER; ++k) {
+        run += hloc[k];
+        S->histo[tid * BK_PER + k] = run;
+    }
+    __syncthreads();
+}
+
+// Fast path: mesh area <= 16384 px.  1024 threads per mesh, 16 px per thread in
+// registers (four 16-byte loads per plane), so HBM is read once and a mesh's
+// latency chain is short.  blockIdx.z selects the statistic: mode0 + z, mode 0 =
+// image, mode 1 = 1 / weight (variance level).
+#define BKF_THREADS 512
+#define BKF_WAVES (BKF_THREADS / 64)
+#define BKF_PX 32
+#define BKF_ROWS (BKF_THREADS / 32)   // mesh rows covered per load pass
+
+struct meshf_lds {
+    int histo[BK_NLEVELS];
+    double red[BKF_WAVES];
+    long long wsum[3][4];
+};
+
+// per-mesh hand-off from k_mesh_stats_fast to k_mesh_guess (global memory)
+struct mesh_dump {
+    int p0[BK_NLEVELS];              // inclusive prefix of the counts
+    long long b1[BK_THREADS];        // exclusive block sums of h i
+    long long b2[BK_THREADS];        // exclusive block sums of h i i
+    bk_quant q;
+    double mean0;
+    int valid;
+    int pad_;
+};
+
+__device__ inline double blockf_sum(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < BKF_WAVES; ++w) t += red[w];     // fixed order: deterministic
+    return t;
+}
+
+__global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const float* __restrict__ img,
+                                                                 const float* __restrict__ wgt,
+                                                                 int nx, int ny, int mesh, int nbx,
+                                                                 int nby, float wthresh, int mode0,
+                                                                 int vec_ok, int dbg,
+                                                                 mesh_dump* __restrict__ dump) {
     extern __shared__ char smem_raw[];
-    mesh_lds* S = reinterpret_cast<mesh_lds*>(smem_raw);
+    meshf_lds* S = reinterpret_cast<meshf_lds*>(smem_raw);
+    const int mode = mode0 + blockIdx.z;
     const int mi = blockIdx.x, mj = blockIdx.y;
     const int x0 = mi * mesh, y0 = mj * mesh;
     const int w = min(mesh, nx - x0), h = min(mesh, ny - y0);
     const int area = w * h;
     const int tid = threadIdx.x;
+    const float qnan = __builtin_nanf("");
+
+    // ---- load: BKF_PX / 4 passes of BKF_ROWS rows x 128 columns, 4 px per thread per pass
+    float v[BKF_PX];
+    const int c4 = (tid & 31) * 4, r32 = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < BKF_PX / 4; ++k) {
+        const int row = BKF_ROWS * k + r32;
+        float pv[4] = {qnan, qnan, qnan, qnan};
+        float pw[4] = {1.f, 1.f, 1.f, 1.f};
+        if (row < h && c4 < w) {
+            const size_t idx = (size_t)(y0 + row) * nx + x0 + c4;
+            if (vec_ok && c4 + 3 < w) {
+                if (mode == 0) {
+                    float4 a = *reinterpret_cast<const float4*>(img + idx);
+                    pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+                }
+                if (wgt) {
+                    float4 b = *reinterpret_cast<const float4*>(wgt + idx);
+                    pw[0] = b.x; pw[1] = b.y; pw[2] = b.z; pw[3] = b.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c4 + j < w) {
+                        if (mode == 0) pv[j] = img[idx + j];
+                        if (wgt) pw[j] = wgt[idx + j];
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool good = (row < h) && (c4 + j < w);
+            if (wgt) good = good && pw[j] > wthresh;
+            float val = pv[j];
+            if (mode == 1) val = good ? 1.0f / pw[j] : qnan;
+            good = good && (val > -BK_BIG) && (val == val);
+            v[4 * k + j] = good ? val : qnan;
+        }
+    }
+    if (dbg == 1) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BKF_PX; ++k) a += v[k];
+        if (a == 12345.f) dump[0].valid = 7;
+        return;
+    }
+    // ---- pass 1: all valid pixels; variance about the mean (two sweeps over the
+    // registers: exact 0 for a constant mesh, like numpy's var in the oracle)
+    double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        float x = v[k];
+        if (x == x) { s0 += 1.0; s1 += x; }
+    }
+    s0 = blockf_sum(s0, S->red);
+    s1 = blockf_sum(s1, S->red);
+    if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
+        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        return;
+    }
+    double mean = s1 / s0;
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        float x = v[k];
+        if (x == x) { double dlt = (double)x - mean; s2 += dlt * dlt; }
+    }
+    s2 = blockf_sum(s2, S->red);
+    double var = s2 / s0;
+    double sig = var > 0 ? sqrt(var) : 0.0;
+    const double lc = mean - 2.0 * sig, hc = mean + 2.0 * sig;
+    // ---- pass 2: 2-sigma clipped
+    s0 = s1 = s2 = 0;
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        float x = v[k];
+        if (x == x && x >= lc && x <= hc) { s0 += 1.0; s1 += x; }
+    }
+    s0 = blockf_sum(s0, S->red);
+    s1 = blockf_sum(s1, S->red);
+    if (s0 < 1.0) {
+        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        return;
+    }
+    mean = s1 / s0;
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        float x = v[k];
+        if (x == x && x >= lc && x <= hc) { double dlt = (double)x - mean; s2 += dlt * dlt; }
+    }
+    s2 = blockf_sum(s2, S->red);
+    var = s2 / s0;
+    sig = var > 0 ? sqrt(var) : 0.0;
+    const bk_quant q = make_quant(mean, sig, s0);
+    if (dbg == 2) { if (sig == 12345.0) dump[0].valid = 7; return; }
+    // ---- histogram
+    for (int k = tid; k < BK_NLEVELS; k += BKF_THREADS) S->histo[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        float x = v[k];
+        int b = -1;
+        if (x == x) b = (int)(x / q.qscale + q.cste);
+        const bool in = b >= 0 && b < q.nlevels;
+        // flat maps (variance planes) put a whole wave into one bin: add once
+        const unsigned long long act = __ballot(in);
+        if (act) {
+            const int first = __ffsll((long long)act) - 1;
+            const int b0 = __shfl(b, first);
+            if (__ballot(in && b == b0) == act) {
+                if ((tid & 63) == first) atomicAdd(&S->histo[b0], __popcll(act));
+            } else if (in) {
+                atomicAdd(&S->histo[b], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg == 3) { if (S->histo[tid] == -5) dump[0].valid = 7; return; }
+    // ---- prefix: the first 256 threads own 16 bins each; the prefix arrays and the
+    // quantisation go to global memory, the clip iterations run in k_mesh_guess
+    // (one wave per mesh, every mesh of the frame in flight at once)
+    {
+        long long a0 = 0, a1 = 0, a2 = 0, e0 = 0, e1 = 0, e2 = 0;
+        int hloc[BK_PER];
+        const int lane = tid & 63, wave = tid >> 6;
+        if (tid < BK_THREADS) {
+#pragma unroll
+            for (int k = 0; k < BK_PER; ++k) {
+                const int i = tid * BK_PER + k;
+                const int hh = S->histo[i];
+                hloc[k] = hh;
+                a0 += hh;
+                a1 += (long long)hh * i;
+                a2 += (long long)hh * i * i;
+            }
+            e0 = a0; e1 = a1; e2 = a2;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                long long t0 = __shfl_up(e0, o), t1 = __shfl_up(e1, o), t2 = __shfl_up(e2, o);
+                if (lane >= o) { e0 += t0; e1 += t1; e2 += t2; }
+            }
+            if (lane == 63) { S->wsum[0][wave] = e0; S->wsum[1][wave] = e1; S->wsum[2][wave] = e2; }
+        }
+        __syncthreads();
+        if (tid < BK_THREADS) {
+            long long o0 = 0, o1 = 0, o2 = 0;
+            for (int ww = 0; ww < wave; ++ww) { o0 += S->wsum[0][ww]; o1 += S->wsum[1][ww]; o2 += S->wsum[2][ww]; }
+            mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
+            D->b1[tid] = o1 + e1 - a1;
+            D->b2[tid] = o2 + e2 - a2;
+            int run = (int)(o0 + e0 - a0);
+            int4* dst = reinterpret_cast<int4*>(D->p0 + tid * BK_PER);
+#pragma unroll
+            for (int k = 0; k < BK_PER; k += 4) {
+                int4 o;
+                run += hloc[k]; o.x = run;
+                run += hloc[k + 1]; o.y = run;
+                run += hloc[k + 2]; o.z = run;
+                run += hloc[k + 3]; o.w = run;
+                dst[k / 4] = o;
+            }
+            if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
+        }
+    }
+}
+
+// One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
+__global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__ dump, int n,
+                                                   float* __restrict__ raw) {
+    __shared__ int P0[BK_NLEVELS];
+    __shared__ long long B1[BK_THREADS];
+    __shared__ long long B2[BK_THREADS];
+    const int m = blockIdx.x, mode = blockIdx.y, lane = threadIdx.x;
+    const mesh_dump* D = dump + (size_t)mode * n + m;
+    float* ob = raw + (size_t)mode * 2 * n + m;
+    float* os = ob + n;
+    if (!D->valid) {
+        if (lane == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
+        return;
+    }
+    const int4* src = reinterpret_cast<const int4*>(D->p0);
+    int4* dst = reinterpret_cast<int4*>(P0);
+#pragma unroll
+    for (int k = 0; k < BK_NLEVELS / 4 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < BK_THREADS / 64; ++k) {
+        B1[k * 64 + lane] = D->b1[k * 64 + lane];
+        B2[k * 64 + lane] = D->b2[k * 64 + lane];
+    }
+    __syncthreads();
+    backguess_wave(P0, B1, B2, D->q, D->mean0, ob, os);
+}
+
+// Generic path (any mesh size): three passes over global memory.
+__global__ __launch_bounds__(BK_THREADS) void k_mesh_stats(const float* __restrict__ img,
+                                                           const float* __restrict__ wgt,
+                                                           int nx, int ny, int mesh, int nbx,
+                                                           int nby, float wthresh, int mode0,
+                                                           float* __restrict__ raw) {
+    extern __shared__ char smem_raw[];
+    mesh_lds* S = reinterpret_cast<mesh_lds*>(smem_raw);
+    const int mode = mode0 + blockIdx.z;
+    const int mi = blockIdx.x, mj = blockIdx.y;
+    const int x0 = mi * mesh, y0 = mj * mesh;
+    const int w = min(mesh, nx - x0), h = min(mesh, ny - y0);
+    const int area = w * h;
+    const int tid = threadIdx.x;
+    float* ob = raw + (size_t)blockIdx.z * 2 * nbx * nby + (size_t)mj * nbx + mi;
+    float* os = ob + (size_t)nbx * nby;
 
     auto value = [&](int k, bool* ok) -> float {
         int yy = k / w, xx = k - yy * w;
@@ -72,144 +472,63 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_stats(const float* __restri
         return v;
     };
 
-    // pass 1
     double s0 = 0, s1 = 0, s2 = 0;
     for (int k = tid; k < area; k += BK_THREADS) {
         bool ok;
         float v = value(k, &ok);
-        if (ok) { s0 += 1.0; s1 += v; s2 += (double)v * v; }
+        if (ok) { s0 += 1.0; s1 += v; }
     }
     s0 = block_sum(s0, S->red);
     s1 = block_sum(s1, S->red);
-    s2 = block_sum(s2, S->red);
-    float* ob = back + (size_t)mj * nbx + mi;
-    float* os = sigm + (size_t)mj * nbx + mi;
     if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
         if (tid == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
         return;
     }
     double mean = s1 / s0;
-    double var = s2 / s0 - mean * mean;
+    for (int k = tid; k < area; k += BK_THREADS) {
+        bool ok;
+        float v = value(k, &ok);
+        if (ok) { double dlt = (double)v - mean; s2 += dlt * dlt; }
+    }
+    s2 = block_sum(s2, S->red);
+    double var = s2 / s0;
     double sig = var > 0 ? sqrt(var) : 0.0;
     const double lc = mean - 2.0 * sig, hc = mean + 2.0 * sig;
-    // pass 2
     s0 = s1 = s2 = 0;
     for (int k = tid; k < area; k += BK_THREADS) {
         bool ok;
         float v = value(k, &ok);
-        if (ok && v >= lc && v <= hc) { s0 += 1.0; s1 += v; s2 += (double)v * v; }
+        if (ok && v >= lc && v <= hc) { s0 += 1.0; s1 += v; }
     }
     s0 = block_sum(s0, S->red);
     s1 = block_sum(s1, S->red);
-    s2 = block_sum(s2, S->red);
     if (s0 < 1.0) {
         if (tid == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
         return;
     }
     mean = s1 / s0;
-    var = s2 / s0 - mean * mean;
+    for (int k = tid; k < area; k += BK_THREADS) {
+        bool ok;
+        float v = value(k, &ok);
+        if (ok && v >= lc && v <= hc) { double dlt = (double)v - mean; s2 += dlt * dlt; }
+    }
+    s2 = block_sum(s2, S->red);
+    var = s2 / s0;
     sig = var > 0 ? sqrt(var) : 0.0;
-    int nlevels = (int)(0.7978845608028654 * 5.0 / 4.0 * s0 + 1.0);
-    if (nlevels > BK_NLEVELS) nlevels = BK_NLEVELS;
-    const double qscale = sig > 0 ? 2.0 * 5.0 * sig / nlevels : 1.0;
-    const double qzero = mean - 5.0 * sig;
-
-    // histogram
+    const bk_quant q = make_quant(mean, sig, s0);
     for (int k = tid; k < BK_NLEVELS; k += BK_THREADS) S->histo[k] = 0;
     __syncthreads();
     for (int k = tid; k < area; k += BK_THREADS) {
         bool ok;
         float v = value(k, &ok);
         if (ok) {
-            double b = floor(((double)v - qzero) / qscale + 0.5);
-            if (b >= 0.0 && b < (double)nlevels) atomicAdd(&S->histo[(int)b], 1);
+            int b = (int)(v / q.qscale + q.cste);
+            if (b >= 0 && b < q.nlevels) atomicAdd(&S->histo[b], 1);
         }
     }
     __syncthreads();
-    // inclusive prefix sums of h, h*i, h*i^2 (16 bins per thread + block scan)
-    {
-        const int per = BK_NLEVELS / BK_THREADS;
-        long long a0 = 0, a1 = 0, a2 = 0;
-        for (int k = 0; k < per; ++k) {
-            int i = tid * per + k;
-            long long hh = S->histo[i];
-            a0 += hh; a1 += hh * i; a2 += hh * i * (long long)i;
-        }
-        S->sred[0][tid] = a0; S->sred[1][tid] = a1; S->sred[2][tid] = a2;
-        __syncthreads();
-        if (tid < 3) {   // three serial 256-element exclusive scans
-            long long run = 0;
-            for (int t = 0; t < BK_THREADS; ++t) {
-                long long v = S->sred[tid][t];
-                S->sred[tid][t] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        a0 = S->sred[0][tid]; a1 = S->sred[1][tid]; a2 = S->sred[2][tid];
-        for (int k = 0; k < per; ++k) {
-            int i = tid * per + k;
-            long long hh = S->histo[i];
-            a0 += hh; a1 += hh * i; a2 += hh * i * (long long)i;
-            S->p1[i] = a1; S->p2[i] = a2;
-            S->histo[i] = (int)a0;
-        }
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    // ---- backguess, thread 0, exact integer arithmetic on the prefix arrays ----
-    const int* P0 = S->histo;
-    auto p0 = [&](int i) -> long long { return i < 0 ? 0 : (long long)P0[i]; };
-    auto q1 = [&](int i) -> long long { return i < 0 ? 0 : S->p1[i]; };
-    auto q2 = [&](int i) -> long long { return i < 0 ? 0 : S->p2[i]; };
-    auto hbin = [&](int i) -> long long { return p0(i) - p0(i - 1); };
-    if (p0(nlevels - 1) == 0) { *ob = -BK_BIG; *os = -BK_BIG; return; }
-    const int nlm1 = nlevels - 1;
-    int lcut = 0, hcut = nlm1;
-    double sg = 10.0 * nlm1, sg1 = 1.0, mea = mean, med = mean;
-    for (int n = 100; n-- && sg >= 0.1 && fabs(sg / sg1 - 1.0) > 1e-4;) {
-        sg1 = sg;
-        const long long sum = p0(hcut) - p0(lcut - 1);
-        mea = (double)(q1(hcut) - q1(lcut - 1));
-        sg = (double)(q2(hcut) - q2(lcut - 1));
-        // two-pointer walk == merge path: largest a with a == 0 or L(a-1) < H(T-a)
-        const int T = hcut - lcut + 1;
-        int lo = 0, hi = T;
-        while (lo < hi) {
-            int a = (lo + hi + 1) >> 1;
-            long long La = p0(lcut + a - 2) - p0(lcut - 1);       // L(a-1)
-            long long Hb = p0(hcut) - p0(hcut - (T - a));         // H(T-a)
-            if (La < Hb) lo = a; else hi = a - 1;
-        }
-        const int a = lo, b = T - a;
-        const long long lowsum = p0(lcut + a - 1) - p0(lcut - 1);
-        const long long highsum = p0(hcut) - p0(hcut - b);
-        const int ihigh = hcut - b, ilow = lcut + a;
-        if (ihigh >= 0) {
-            long long ha = hbin(ilow), hb = hbin(ihigh);
-            double den = 2.0 * (double)(ha > hb ? ha : hb);
-            med = ihigh + 0.5 + (den > 0 ? (double)(highsum - lowsum) / den : 0.0);
-        } else {
-            med = 0.0;
-        }
-        if (sum) {
-            mea /= (double)sum;
-            sg = sg / (double)sum - mea * mea;
-        }
-        sg = sg > 0.0 ? sqrt(sg) : 0.0;
-        double ft = med - 3.0 * sg;
-        lcut = ft > 0.0 ? (int)(ft + 0.5) : 0;
-        ft = med + 3.0 * sg;
-        hcut = ft < nlm1 ? (ft > 0.0 ? (int)(ft + 0.5) : (int)(ft - 0.5)) : nlm1;
-    }
-    double modev;
-    if (sg > 0.0)
-        modev = fabs((mea - med) / sg) < 0.3 ? qzero + (2.5 * med - 1.5 * mea) * qscale
-                                             : qzero + med * qscale;
-    else
-        modev = qzero + mea * qscale;
-    *ob = (float)modev;
-    *os = (float)(sg * qscale);
+    histo_prefix(S);
+    if (tid < 64) backguess_wave(S->histo, S->b1, S->b2, q, (double)(float)mean, ob, os);
 }
 
 // ---------------------------------------------------------------------------
@@ -223,46 +542,92 @@ __device__ inline float small_median(float* v, int n) {
     return (n & 1) ? v[n / 2] : 0.5f * (v[n / 2 - 1] + v[n / 2]);
 }
 
-// natural cubic spline second derivatives / 6 along a strided line (unit spacing)
+// 9-element sorting network (25 compare-exchanges) and a register pick
+__device__ inline void cswap(float& x, float& y) {
+    float lo = fminf(x, y), hi = fmaxf(x, y);
+    x = lo; y = hi;
+}
+__device__ inline void sort9(float (&a)[9]) {
+    cswap(a[0], a[1]); cswap(a[3], a[4]); cswap(a[6], a[7]);
+    cswap(a[1], a[2]); cswap(a[4], a[5]); cswap(a[7], a[8]);
+    cswap(a[0], a[1]); cswap(a[3], a[4]); cswap(a[6], a[7]);
+    cswap(a[0], a[3]); cswap(a[3], a[6]); cswap(a[0], a[3]);
+    cswap(a[1], a[4]); cswap(a[4], a[7]); cswap(a[1], a[4]);
+    cswap(a[2], a[5]); cswap(a[5], a[8]); cswap(a[2], a[5]);
+    cswap(a[1], a[3]); cswap(a[5], a[7]);
+    cswap(a[2], a[6]); cswap(a[4], a[6]); cswap(a[2], a[4]);
+    cswap(a[2], a[3]); cswap(a[5], a[6]);
+}
+__device__ inline float pick9(const float (&a)[9], int idx) {
+    float r = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) r = (i == idx) ? a[i] : r;
+    return r;
+}
+
+// natural cubic spline second derivatives / 6 along a strided line (unit spacing);
+// the recurrence state stays in registers, LDS only holds the per-node results
 __device__ inline void spline_line(const float* a, float* d, float* u, int n, int stride) {
-    for (int k = 0; k < n; ++k) d[k * stride] = 0.f;
-    if (n < 3) return;
-    u[0] = 0.f;
-    for (int y = 1; y < n - 1; ++y) {
-        float temp = -1.f / (d[(y - 1) * stride] + 4.f);
-        d[y * stride] = temp;
-        u[y * stride] = temp * (u[(y - 1) * stride]
-                                - 6.f * (a[(y + 1) * stride] + a[(y - 1) * stride]
-                                         - 2.f * a[y * stride]));
+    if (n < 3) {
+        for (int k = 0; k < n; ++k) d[k * stride] = 0.f;
+        return;
     }
-    d[(n - 1) * stride] = 0.f;
-    for (int y = n - 2; y >= 1; --y)
-        d[y * stride] = d[y * stride] * d[(y + 1) * stride] + u[y * stride];
+    float dp = 0.f, up = 0.f;
+    float am = a[0], ac = a[stride];
     d[0] = 0.f;
-    for (int k = 0; k < n; ++k) d[k * stride] *= (1.f / 6.f);
+    for (int y = 1; y < n - 1; ++y) {
+        const float an = a[(y + 1) * stride];
+        const float temp = -1.f / (dp + 4.f);
+        up = temp * (up - 6.f * (an + am - 2.f * ac));
+        dp = temp;
+        d[y * stride] = dp;
+        u[y * stride] = up;
+        am = ac;
+        ac = an;
+    }
+    float dn = 0.f;
+    d[(n - 1) * stride] = 0.f;
+    for (int y = n - 2; y >= 1; --y) {
+        dn = d[y * stride] * dn + u[y * stride];
+        d[y * stride] = dn * (1.f / 6.f);
+    }
 }
 
 #define BK_MAXMESH 4096
 
-// raw[0..n) mode map, raw[n..2n) sigma map (may hold -BIG); nodes: 2 maps x 4 planes;
-// stats: {backmean, backsig}
-__global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restrict__ raw,
+// One workgroup per statistic (blockIdx.x = mode index).  raw: [mode][2][n] mode /
+// sigma maps (may hold -BIG); nodes: [mode][2 maps][4 planes][n]; stats: [mode][2]
+// = {median of the filtered mode map, median of the filtered sigma map}.
+// Everything is staged in LDS: the spline recurrences are latency chains.
+__global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restrict__ raw_all,
                                                             int nbx, int nby, int fsize,
-                                                            float* __restrict__ nodes,
-                                                            float* __restrict__ stats) {
-    __shared__ float sb[2][BK_MAXMESH];   // filled maps
-    __shared__ float fb[2][BK_MAXMESH];   // filtered maps
-    __shared__ float tmp[BK_MAXMESH];     // spline scratch
-    __shared__ int ngood;
+                                                            float* __restrict__ nodes_all,
+                                                            float* __restrict__ stats_all) {
+    extern __shared__ float mf_smem[];
     const int n = nbx * nby, tid = threadIdx.x;
+    const float* raw = raw_all + (size_t)blockIdx.x * 2 * n;
+    float* nodes = nodes_all + (size_t)blockIdx.x * 8 * n;
+    float* stats = stats_all + blockIdx.x * 2;
+    float* sb0 = mf_smem;            // filled maps
+    float* sb1 = sb0 + n;
+    float* fb0 = sb1 + n;            // filtered maps
+    float* fb1 = fb0 + n;
+    float* tmp = fb1 + n;            // spline scratch
+    float* pl = tmp + n;             // 4 node planes of the current map
+    __shared__ int ngood;
+    __shared__ float med[4];
     if (tid == 0) ngood = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += BK_THREADS)
-        if (raw[k] > -BK_BIG) atomicAdd(&ngood, 1);
+    for (int k = tid; k < n; k += BK_THREADS) {
+        float b = raw[k];
+        sb0[k] = b;
+        sb1[k] = raw[n + k];
+        if (b > -BK_BIG) atomicAdd(&ngood, 1);
+    }
     __syncthreads();
     // 1. fill bad meshes from the nearest good ones (ties averaged)
     for (int k = tid; k < n; k += BK_THREADS) {
-        float b = raw[k], s = raw[n + k];
+        float b = sb0[k], s = sb1[k];
         if (!(b > -BK_BIG)) {
             if (ngood == 0) { b = 0.f; s = 1.f; }
             else {
@@ -270,61 +635,83 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
                 int dmin = 0x7fffffff, cnt = 0;
                 float vb = 0.f, vs = 0.f;
                 for (int q = 0; q < n; ++q) {
-                    if (!(raw[q] > -BK_BIG)) continue;
+                    float rq = sb0[q];
+                    if (!(rq > -BK_BIG)) continue;
                     int qj = q / nbx, qi = q - qj * nbx;
                     int d2 = (qi - i) * (qi - i) + (qj - j) * (qj - j);
-                    if (d2 < dmin) { dmin = d2; vb = raw[q]; vs = raw[n + q]; cnt = 1; }
-                    else if (d2 == dmin) { vb += raw[q]; vs += raw[n + q]; ++cnt; }
+                    if (d2 < dmin) { dmin = d2; vb = rq; vs = sb1[q]; cnt = 1; }
+                    else if (d2 == dmin) { vb += rq; vs += sb1[q]; ++cnt; }
                 }
                 b = vb / cnt; s = vs / cnt;
             }
         }
-        sb[0][k] = b; sb[1][k] = s;
+        fb0[k] = b; fb1[k] = s;      // staged here, copied back below
     }
+    __syncthreads();
+    for (int k = tid; k < n; k += BK_THREADS) { sb0[k] = fb0[k]; sb1[k] = fb1[k]; }
     __syncthreads();
     // 2. fsize x fsize median filter (window clipped at the borders)
     const int hb = fsize / 2;
     for (int k = tid; k < n; k += BK_THREADS) {
         int j = k / nbx, i = k - j * nbx;
-        if (fsize > 1) {
-            float wv[2][49];
+        if (fsize == 3) {
+            // registers only: clipped cells carry +inf and sort to the end
+            float a[9], b[9];
+            int c = 0;
+#pragma unroll
+            for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+                for (int di = -1; di <= 1; ++di) {
+                    const int jj = j + dj, ii = i + di;
+                    const bool in = jj >= 0 && jj < nby && ii >= 0 && ii < nbx;
+                    const int q = in ? jj * nbx + ii : k;
+                    a[(dj + 1) * 3 + di + 1] = in ? sb0[q] : __builtin_inff();
+                    b[(dj + 1) * 3 + di + 1] = in ? sb1[q] : __builtin_inff();
+                    c += in ? 1 : 0;
+                }
+            sort9(a);
+            sort9(b);
+            fb0[k] = 0.5f * (pick9(a, (c - 1) >> 1) + pick9(a, c >> 1));
+            fb1[k] = 0.5f * (pick9(b, (c - 1) >> 1) + pick9(b, c >> 1));
+        } else if (fsize > 1) {
+            float w0[49], w1[49];
             int c = 0;
             for (int jj = max(j - hb, 0); jj <= min(j + hb, nby - 1); ++jj)
-                for (int ii = max(i - hb, 0); ii <= min(i + hb, nbx - 1); ++ii) {
-                    if (c < 49) { wv[0][c] = sb[0][jj * nbx + ii]; wv[1][c] = sb[1][jj * nbx + ii]; ++c; }
-                }
-            fb[0][k] = small_median(wv[0], c);
-            fb[1][k] = small_median(wv[1], c);
+                for (int ii = max(i - hb, 0); ii <= min(i + hb, nbx - 1); ++ii)
+                    if (c < 49) { w0[c] = sb0[jj * nbx + ii]; w1[c] = sb1[jj * nbx + ii]; ++c; }
+            fb0[k] = small_median(w0, c);
+            fb1[k] = small_median(w1, c);
         } else {
-            fb[0][k] = sb[0][k]; fb[1][k] = sb[1][k];
+            fb0[k] = sb0[k]; fb1[k] = sb1[k];
         }
     }
     __syncthreads();
-    // 3. global medians by rank counting (exact, O(n^2 / threads))
+    // 3. global medians by rank counting (exact)
     for (int m = 0; m < 2; ++m) {
+        const float* fb = m ? fb1 : fb0;
         for (int k = tid; k < n; k += BK_THREADS) {
-            float v = fb[m][k];
+            float v = fb[k];
             int less = 0, eq = 0;
-            for (int q = 0; q < n; ++q) { less += fb[m][q] < v; eq += fb[m][q] == v; }
-            // v occupies sorted positions [less, less + eq)
+            for (int q = 0; q < n; ++q) { float o = fb[q]; less += o < v; eq += o == v; }
             int i1 = (n - 1) / 2, i2 = n / 2;
-            if (i1 >= less && i1 < less + eq) tmp[2 * m] = v;
-            if (i2 >= less && i2 < less + eq) tmp[2 * m + 1] = v;
+            if (i1 >= less && i1 < less + eq) med[2 * m] = v;
+            if (i2 >= less && i2 < less + eq) med[2 * m + 1] = v;
         }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        stats[0] = 0.5f * (tmp[0] + tmp[1]);
-        stats[1] = 0.5f * (tmp[2] + tmp[3]);
     }
     __syncthreads();
+    if (tid == 0) {
+        stats[0] = 0.5f * (med[0] + med[1]);
+        stats[1] = 0.5f * (med[2] + med[3]);
+    }
     // 4. node planes: V, DY (along y per column), A (along x of V), B (along x of DY)
     for (int m = 0; m < 2; ++m) {
-        float* V = nodes + (size_t)m * 4 * n;
-        float* DY = V + n;
-        float* A = V + 2 * n;
-        float* B = V + 3 * n;
-        for (int k = tid; k < n; k += BK_THREADS) V[k] = fb[m][k];
+        const float* fb = m ? fb1 : fb0;
+        float* V = pl;
+        float* DY = pl + n;
+        float* A = pl + 2 * n;
+        float* B = pl + 3 * n;
+        __syncthreads();
+        for (int k = tid; k < n; k += BK_THREADS) V[k] = fb[k];
         __syncthreads();
         for (int i = tid; i < nbx; i += BK_THREADS) spline_line(V + i, DY + i, tmp + i, nby, nbx);
         __syncthreads();
@@ -332,6 +719,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
         __syncthreads();
         for (int j = tid; j < nby; j += BK_THREADS) spline_line(DY + j * nbx, B + j * nbx, tmp + j * nbx, nbx, 1);
         __syncthreads();
+        float* out = nodes + (size_t)m * 4 * n;
+        for (int k = tid; k < 4 * n; k += BK_THREADS) out[k] = pl[k];
     }
 }
 
@@ -380,39 +769,59 @@ __global__ void k_var_scale(const float* __restrict__ bstats, const float* __res
 }
 
 // ---------------------------------------------------------------------------
-// Runs stats + filter for one frame.  Node planes (bkg map then sigma map, 4
-// planes each) and the {backmean, backsig} pair stay on the device in scratch
-// slots "<slot>_nodes" / "<slot>_stats".
+// Runs stats + filter for one frame: `nmode` statistics starting at `mode0`
+// (0 = image background, 1 = variance level of 1 / wgt) in one launch each.
+// Node planes [mode][2 maps][4][n] and stats [mode][2] stay on the device in the
+// scratch slots "<slot>_nodes" / "<slot>_stats".
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
-                        int mesh, int fsize, float wthresh, int mode, float** nodes_dev,
-                        float** stats_dev, int* nbx_out, int* nby_out, const char* slot) {
+                        int mesh, int fsize, float wthresh, int mode0, int nmode,
+                        float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
+                        const char* slot) {
     ZM_CHECK(mesh >= 8 && mesh <= 4096, "background: BACK_SIZE %d out of range [8, 4096]", mesh);
     ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
+    ZM_CHECK(nmode >= 1 && mode0 >= 0 && mode0 + nmode <= 2, "background: bad statistic selection");
+    ZM_CHECK(mode0 + nmode < 2 || wgt != nullptr, "background: the variance level needs a weight map");
+    ZM_CHECK(mode0 > 0 || img != nullptr, "background: image is NULL");
     const int nbx = (nx - 1) / mesh + 1, nby = (ny - 1) / mesh + 1;
-    ZM_CHECK(nbx * nby <= BK_MAXMESH, "background: %d x %d meshes exceed %d; raise BACK_SIZE",
-             nbx, nby, BK_MAXMESH);
+    const int n = nbx * nby;
+    ZM_CHECK(n <= BK_MAXMESH, "background: %d x %d meshes exceed %d; raise BACK_SIZE", nbx, nby,
+             BK_MAXMESH);
     std::string s(slot);
     float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
-    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * nbx * nby, (void**)&raw));
-    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 8 * nbx * nby, (void**)&nodes));
+    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * n, (void**)&raw));
+    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n, (void**)&nodes));
     ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4, (void**)&stats));
+    const size_t fsh = sizeof(float) * 9 * (size_t)n;
     static bool attr_set = false;
     if (!attr_set) {
-        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_stats,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_stats, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(mesh_lds)));
+        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024 - 64));
         attr_set = true;
     }
     {
         zm_scope_timer t(ctx, "mesh_stats");
-        hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, 1), dim3(BK_THREADS, 1, 1),
-                           sizeof(mesh_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, wthresh,
-                           mode, raw, raw + nbx * nby);
+        if (mesh <= 128) {
+            const int vec_ok = (mesh % 4 == 0) && (nx % 4 == 0) &&
+                               (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
+            mesh_dump* dump = nullptr;
+            ZM_TRY(ctx->get((s + "_dump").c_str(), sizeof(mesh_dump) * 2 * (size_t)n, (void**)&dump));
+            hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode), dim3(BKF_THREADS, 1, 1),
+                               sizeof(meshf_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
+                               wthresh, mode0, vec_ok, getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0, dump);
+            hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode, 1), dim3(64, 1, 1), 0, ctx->stream,
+                               dump, n, raw);
+        } else {
+            hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, nmode), dim3(BK_THREADS, 1, 1),
+                               sizeof(mesh_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
+                               wthresh, mode0, raw);
+        }
         ZM_HIP(hipGetLastError());
     }
     {
         zm_scope_timer t(ctx, "mesh_filter");
-        hipLaunchKernelGGL(k_mesh_filter, dim3(1, 1, 1), dim3(BK_THREADS, 1, 1), 0, ctx->stream,
+        hipLaunchKernelGGL(k_mesh_filter, dim3(nmode, 1, 1), dim3(BK_THREADS, 1, 1), fsh, ctx->stream,
                            raw, nbx, nby, fsize, nodes, stats);
         ZM_HIP(hipGetLastError());
     }
@@ -437,7 +846,7 @@ extern "C" int zm_background_dev(zm_ctx* ctx, const float* img, const float* wgt
     ZM_HIP(hipSetDevice(ctx->device));
     float *nodes = nullptr, *stats = nullptr;
     int nbx = 0, nby = 0;
-    ZM_TRY(zm_frame_background(ctx, img, wgt, nx, ny, mesh, filtersize, 1e-30f, 0, &nodes, &stats,
+    ZM_TRY(zm_frame_background(ctx, img, wgt, nx, ny, mesh, filtersize, 1e-30f, 0, 1, &nodes, &stats,
                                &nbx, &nby, "bkg"));
     if (out_bkg || out_rms || out_sub) {
         zm_scope_timer t(ctx, "bk_expand");

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
         acc += w1 * w2 * Gc[n1 * HP_MAXX + n2];
         if (do_rhs) racc += w1 * Gc[n1 * HP_MAXX + P.nE];
     }
-    if (c2 <= c1) A[((size_t)reg * P.nunk + c1) * P.nunk + c2] = acc;
+    if (c2 <= c1) A[(size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2] = acc;
     if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
 __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d) {
     int reg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    double v = A[((size_t)reg * n + c) * n + c];
+    double v = A[(size_t)reg * (size_t)(n + 1) * n + (size_t)c * n + c];
     d[(size_t)reg * n + c] = v > 0.0 ? sqrt(v) : 1.0;
 }
 
@@ -377,168 +377,177 @@ __global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ r
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
-    double v = A[((size_t)reg * n + c1) * n + c2] / (dd[c1] * dd[c2]);
+    double* Ar = A + (size_t)reg * (size_t)(n + 1) * n;
+    double v = Ar[(size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
     if (c1 == c2) v += HP_RIDGE;   // keeps a rank-deficient basis solvable (oracle: RIDGE)
-    A[((size_t)reg * n + c1) * n + c2] = v;
-    if (c2 == 0) rhs[(size_t)reg * n + c1] /= dd[c1];
+    Ar[(size_t)c1 * n + c2] = v;
+    if (c2 == 0) Ar[(size_t)n * n + c1] = rhs[(size_t)reg * n + c1] / dd[c1];   // rhs row
 }
 
 // ---- blocked Cholesky, lower, in place, batched over blockIdx.z ------------------
-// Panel step: every workgroup re-factors the 32 x 32 diagonal block in LDS, then
-// each thread solves one row of the panel below it; workgroup 0 writes L11 back.
-__global__ __launch_bounds__(256) void k_chol_panel(int n, int k0, double* __restrict__ Aall,
-                                                    int* __restrict__ fail) {
+// The right-hand side rides along as row n of the (n + 1) x n lower-triangular
+// storage: factoring the augmented matrix leaves y = L^-1 b in that row, so the
+// forward substitution costs nothing extra.  One launch per 32-column block
+// (left-looking): every workgroup (a) applies all previous block columns to the
+// diagonal block and to its own 64 rows with an LDS-tiled fp64 GEMM, (b) factors
+// the 32 x 32 diagonal block (redundantly, one wave, no inter-workgroup
+// dependency), (c) solves its rows against it.
+#define CH_ROWS 64                      // panel rows per workgroup
+#define CH_KT 32                        // K tile of the update GEMM
+
+__device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail) {
+    // wave 0, lanes own entries of the trailing block; LDS only, no barriers needed
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < nb; ++j) {
+        double v = D[j][j];
+        if (!(v > 1e-14)) { v = 1e-14; if (lane == 0 && fail) atomicAdd(fail, 1); }
+        const double dj = sqrt(v);
+        const double inv = 1.0 / dj;
+        if (lane == 0) D[j][j] = dj;
+        if (lane > j && lane < nb) D[lane][j] *= inv;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS visible across the wave's lanes
+        __builtin_amdgcn_wave_barrier();
+        // rank-1 update of the remaining lower triangle: entries (i, c), j < c <= i < nb
+        const int m = nb - j - 1;                 // remaining dimension
+        for (int e = lane; e < m * m; e += 64) {
+            const int ii = e / m, cc = e - ii * m;
+            const int i = j + 1 + ii, c = j + 1 + cc;
+            if (c <= i) D[i][c] -= D[i][j] * D[c][j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// A: [reg][(n + 1)][n]; rows 0..n-1 lower triangle, row n = rhs / y.
+__global__ __launch_bounds__(256) void k_chol_step(int n, int k0, double* __restrict__ Aall,
+                                                   int* __restrict__ fail) {
+    __shared__ double Lr[CH_NB + CH_ROWS][CH_KT + 1];   // rows of the diag block, then my rows
     __shared__ double D[CH_NB][CH_NB + 1];
-    double* A = Aall + (size_t)blockIdx.z * n * n;
+    double* A = Aall + (size_t)blockIdx.z * (size_t)(n + 1) * n;
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - k0);
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        int i = e >> 5, j = e & 31;
-        D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (tid == 0) {
-            double v = D[j][j];
-            if (!(v > 1e-14)) { v = 1e-14; if (blockIdx.x == 0) atomicAdd(&fail[blockIdx.z], 1); }
-            D[j][j] = sqrt(v);
+    const int nrows = n + 1;                             // including the rhs row
+    const int r0 = k0 + nb + blockIdx.x * CH_ROWS;       // first panel row of this workgroup
+    // thread tile of the update: 3 rows x 4 cols of the 96 x 32 output
+    const int tr = (tid >> 3) * 3, tc = (tid & 7) * 4;
+    double acc[3][4] = {};
+    auto grow = [&](int lr) -> int { return lr < CH_NB ? k0 + lr : r0 + (lr - CH_NB); };
+    for (int m0 = 0; m0 < k0; m0 += CH_KT) {
+        __syncthreads();
+        for (int e = tid; e < (CH_NB + CH_ROWS) * CH_KT; e += 256) {
+            const int lr = e >> 5, m = e & 31;
+            const int gr = grow(lr);
+            const bool ok = (lr < CH_NB ? lr < nb : gr < nrows) && (m0 + m < k0);
+            Lr[lr][m] = ok ? A[(size_t)gr * n + m0 + m] : 0.0;
         }
         __syncthreads();
-        if (tid > j && tid < nb) D[tid][j] /= D[j][j];
-        __syncthreads();
-        // rank-1 update of the remaining lower triangle
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            int i = e >> 5, c = e & 31;
-            if (c > j && i >= c && i < nb) D[i][c] -= D[i][j] * D[c][j];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0)
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            int i = e >> 5, j = e & 31;
-            if (i < nb && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = D[i][j];
-        }
-    const int row = k0 + nb + blockIdx.x * 256 + tid;
-    if (row >= n) return;
-    double x[CH_NB];
-    double* ar = A + (size_t)row * n + k0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ar[j] : 0.0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        if (j < nb) {
-            double v = x[j];
-#pragma unroll
-            for (int m = 0; m < CH_NB; ++m)
-                if (m < j) v -= x[m] * D[j][m];
-            x[j] = v / D[j][j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j)
-        if (j < nb) ar[j] = x[j];
-}
-
-// Trailing update A22 -= L21 L21^T (lower triangle), 64 x 64 tiles, 4 x 4 per thread
-__global__ __launch_bounds__(256) void k_chol_update(int n, int k0, double* __restrict__ Aall) {
-    __shared__ double Li[64][CH_NB + 1];
-    __shared__ double Lj[64][CH_NB + 1];
-    if (blockIdx.x > blockIdx.y) return;
-    double* A = Aall + (size_t)blockIdx.z * n * n;
-    const int t0 = k0 + CH_NB;
-    const int i0 = t0 + blockIdx.y * 64, j0 = t0 + blockIdx.x * 64;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * CH_NB; e += 256) {
-        int r = e >> 5, m = e & 31;
-        Li[r][m] = (i0 + r < n) ? A[(size_t)(i0 + r) * n + k0 + m] : 0.0;
-        Lj[r][m] = (j0 + r < n) ? A[(size_t)(j0 + r) * n + k0 + m] : 0.0;
-    }
-    __syncthreads();
-    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
-    double acc[4][4] = {};
 #pragma unroll 8
-    for (int m = 0; m < CH_NB; ++m) {
-        double a[4], b[4];
+        for (int m = 0; m < CH_KT; ++m) {
+            double a[3], b[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { a[q] = Li[ti + q][m]; b[q] = Lj[tj + q][m]; }
+            for (int p = 0; p < 3; ++p) a[p] = Lr[tr + p][m];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+            for (int q = 0; q < 4; ++q) b[q] = Lr[tc + q][m];      // rows of the diag block = columns
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+        }
     }
+    __syncthreads();
+    // updated diagonal block -> D, updated panel rows -> Lr (reused as 64 x 32)
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 3; ++p) {
+        const int lr = tr + p, gr = grow(lr);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int i = i0 + ti + p, j = j0 + tj + q;
-            if (i < n && j <= i) A[(size_t)i * n + j] -= acc[p][q];
+            const int c = tc + q;
+            double v = 0.0;
+            if (lr < CH_NB) {
+                if (lr < nb && c <= lr && c < nb) v = A[(size_t)gr * n + k0 + c] - acc[p][q];
+                else v = (lr == c) ? 1.0 : 0.0;
+                D[lr][c] = v;
+            } else {
+                if (gr < nrows && c < nb) v = A[(size_t)gr * n + k0 + c] - acc[p][q];
+                Lr[lr][c] = v;
+            }
         }
+    }
+    __syncthreads();
+    if (tid < 64) chol_diag_wave(D, nb, blockIdx.x == 0 ? &fail[blockIdx.z] : nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            const int i = e >> 5, j = e & 31;
+            if (i < nb && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = D[i][j];
+        }
+    // panel solve: one thread per row, x L11^T = r
+    if (tid < CH_ROWS) {
+        const int gr = r0 + tid;
+        if (gr < nrows) {
+            double x[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) x[j] = Lr[CH_NB + tid][j];
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                if (j < nb) {
+                    double v = x[j];
+#pragma unroll
+                    for (int m = 0; m < CH_NB; ++m)
+                        if (m < j) v -= x[m] * D[j][m];
+                    x[j] = v / D[j][j];
+                }
+            }
+            double* ar = A + (size_t)gr * n + k0;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j)
+                if (j < nb) ar[j] = x[j];
+        }
+    }
 }
 
-// Forward + back substitution with the factor, one workgroup per region; the
-// solution overwrites rhs.  Then un-scale with d.
-__global__ __launch_bounds__(256) void k_chol_solve(int n, const double* __restrict__ Aall,
-                                                    double* __restrict__ ball,
-                                                    const double* __restrict__ dall) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    __shared__ double y[CH_NB];
-    const double* A = Aall + (size_t)blockIdx.x * n * n;
-    double* b = ball + (size_t)blockIdx.x * n;
+// Back substitution L^T x = y (y = row n of the factored storage), one workgroup
+// of 1024 threads per region; then x /= d (Jacobi scaling) into xout.
+__global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restrict__ Aall,
+                                                    const double* __restrict__ dall,
+                                                    double* __restrict__ xall) {
+    extern __shared__ double cb_smem[];
+    double* y = cb_smem;                                   // [n]
+    double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(cb_smem + ((n + 1) & ~1));
+    const double* A = Aall + (size_t)blockIdx.x * (size_t)(n + 1) * n;
     const double* d = dall + (size_t)blockIdx.x * n;
+    double* xo = xall + (size_t)blockIdx.x * n;
     const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) y[i] = A[(size_t)n * n + i];
     const int nblk = (n + CH_NB - 1) / CH_NB;
-    // forward: L y = b
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            int i = e >> 5, j = e & 31;
-            D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            double bi = (tid < nb) ? b[k0 + tid] : 0.0;
-            for (int j = 0; j < nb; ++j) {
-                double yj = __shfl(bi, j) / D[j][j];
-                if (tid == j) bi = yj;
-                else if (tid > j && tid < nb) bi -= D[tid][j] * yj;
-            }
-            if (tid < nb) { y[tid] = bi; b[k0 + tid] = bi; }
-        }
-        __syncthreads();
-        for (int i = k0 + nb + tid; i < n; i += 256) {
-            const double* ar = A + (size_t)i * n + k0;
-            double acc = 0.0;
-            for (int m = 0; m < nb; ++m) acc += ar[m] * y[m];
-            b[i] -= acc;
-        }
-        __syncthreads();
-    }
-    // backward: L^T x = y
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            int i = e >> 5, j = e & 31;
+        __syncthreads();
+        {
+            const int i = tid >> 5, j = tid & 31;          // 1024 threads = 32 x 32
             D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
         }
         __syncthreads();
         if (tid < 64) {
-            double bi = (tid < nb) ? b[k0 + tid] : 0.0;
+            double bi = (tid < nb) ? y[k0 + tid] : 0.0;
             for (int j = nb - 1; j >= 0; --j) {
                 double xj = __shfl(bi, j) / D[j][j];
                 if (tid == j) bi = xj;
-                else if (tid < j) bi -= D[j][tid] * xj;   // L^T[tid][j] = L[j][tid]
+                else if (tid < j) bi -= D[j][tid] * xj;    // L^T[tid][j] = L[j][tid]
             }
-            if (tid < nb) { y[tid] = bi; b[k0 + tid] = bi; }
+            if (tid < nb) y[k0 + tid] = bi;
         }
         __syncthreads();
-        for (int i = tid; i < k0; i += 256) {
+        for (int c = tid; c < k0; c += 1024) {
             double acc = 0.0;
-            for (int m = 0; m < nb; ++m) acc += A[(size_t)(k0 + m) * n + i] * y[m];
-            b[i] -= acc;
+#pragma unroll 8
+            for (int m = 0; m < nb; ++m) acc += A[(size_t)(k0 + m) * n + c] * y[k0 + m];
+            y[c] -= acc;
         }
-        __syncthreads();
     }
-    for (int i = tid; i < n; i += 256) b[i] /= d[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) xo[i] = y[i] / d[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -943,7 +952,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
     ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
     ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
-    ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * P.nunk * P.nunk, (void**)&A));
+    ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A));
     ZM_TRY(ctx->get("hp_rhs", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs));
     ZM_TRY(ctx->get("hp_dsc", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&dsc));
     ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
@@ -1008,16 +1017,24 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A,
                                rhs, dsc);
             for (int kb = 0; kb < nblk; ++kb) {
-                int k0 = kb * CH_NB;
-                int below = P.nunk - k0 - CH_NB;
-                int pch = below > 0 ? zm_div_up(below, 256) : 1;
-                hipLaunchKernelGGL(k_chol_panel, dim3(pch, 1, P.nreg), b256, 0, st, P.nunk, k0, A, fail);
-                if (below > 0) {
-                    int tt = zm_div_up(below, 64);
-                    hipLaunchKernelGGL(k_chol_update, dim3(tt, tt, P.nreg), b256, 0, st, P.nunk, k0, A);
-                }
+                const int k0 = kb * CH_NB;
+                const int nb = std::min(CH_NB, P.nunk - k0);
+                const int below = P.nunk + 1 - k0 - nb;            // panel rows incl. the rhs row
+                const int pch = std::max(zm_div_up(below, CH_ROWS), 1);
+                hipLaunchKernelGGL(k_chol_step, dim3(pch, 1, P.nreg), b256, 0, st, P.nunk, k0, A, fail);
             }
-            hipLaunchKernelGGL(k_chol_solve, dim3(P.nreg), b256, 0, st, P.nunk, A, rhs, dsc);
+            {
+                const size_t bsh = sizeof(double) * (((size_t)P.nunk + 1) & ~(size_t)1) +
+                                   sizeof(double) * CH_NB * (CH_NB + 1);
+                static bool bset = false;
+                if (!bset && bsh > 65536) {
+                    ZM_HIP(hipFuncSetAttribute((const void*)k_chol_back,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                    bset = true;
+                }
+                ZM_CHECK(bsh <= 160 * 1024 - 64, "zm_subtract: %d unknowns exceed the solver's LDS", P.nunk);
+                hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, A, dsc, rhs);
+            }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
             hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, nrej,
                                stats);

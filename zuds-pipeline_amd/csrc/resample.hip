@@ -130,38 +130,52 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
 
 // ---------------------------------------------------------------------------
 // Unit-sum Lanczos-3 taps for d in [SNAP, 1 - SNAP]; offsets k = -2..3.
-// t_k ~ n_k / (d - k)^2 with n = {n1, n2, n3, n1, n2, n3}, the sin recurrence of
-// SWarp's make_kernel (sin(a +- 2 pi / 3) expanded), sin/cos by polynomial on
-// a = pi d / 3 in [0, pi/3].
-__host__ __device__ inline void zm_lanczos3(float d, float t[6]) {
-    const float a = d * 1.0471975511965976f;
-    const float a2 = a * a;
-    float s = a * (1.f + a2 * (-1.6666667e-1f + a2 * (8.3333333e-3f + a2 * (-1.98412698e-4f
-              + a2 * (2.7557319e-6f + a2 * -2.5052108e-8f)))));
-    float c = 1.f + a2 * (-0.5f + a2 * (4.1666667e-2f + a2 * (-1.3888889e-3f
-              + a2 * (2.4801587e-5f + a2 * (-2.7557319e-7f + a2 * 2.0876757e-9f)))));
-    float n1 = 0.5f * s - 0.8660254037844386f * c;
-    float n2 = 0.5f * s + 0.8660254037844386f * c;
-    float n3 = -s;
-    float x0 = d + 2.f, x1 = d + 1.f, x2 = d, x3 = d - 1.f, x4 = d - 2.f, x5 = d - 3.f;
+//   t_k ~ n_k / x_k^2,  x_k = d + 2 - k,  n = {n1, n2, n3, n1, n2, n3}
+// with the sin recurrence of SWarp's make_kernel (sin(a +- 2 pi / 3) expanded,
+// a = pi d / 3 in [0, pi/3], sin / cos by polynomial).  Since the taps are
+// normalised anyway they are evaluated over the common denominator
+//   prod x_k^2 = (p1 p2 p3)^2,  p1 = x0 x5 = q - 6, p2 = x1 x4 = q - 2, p3 = x2 x3 = q,
+//   q = d^2 - d,
+// i.e. t_0 ~ n1 (x5 p2 p3)^2, t_5 ~ n3 (x0 p2 p3)^2, ... : no per-tap reciprocal,
+// one reciprocal for the sum.  Every operation is written on a 2-vector holding
+// the x axis in lane 0 and the y axis in lane 1, which maps onto the packed fp32
+// VALU (v_pk_mul / v_pk_add / v_pk_fma): a VALU instruction costs 4 cycles per
+// wave whatever it computes, so the instruction count is what bounds this kernel.
+typedef float zm_v2f __attribute__((ext_vector_type(2)));
+
+__host__ __device__ inline zm_v2f zm_rcp2(zm_v2f v) {
 #ifdef __HIP_DEVICE_COMPILE__
-    float r0 = __builtin_amdgcn_rcpf(x0 * x0), r1 = __builtin_amdgcn_rcpf(x1 * x1),
-          r2 = __builtin_amdgcn_rcpf(x2 * x2), r3 = __builtin_amdgcn_rcpf(x3 * x3),
-          r4 = __builtin_amdgcn_rcpf(x4 * x4), r5 = __builtin_amdgcn_rcpf(x5 * x5);
+    return (zm_v2f){__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)};
 #else
-    float r0 = 1.f / (x0 * x0), r1 = 1.f / (x1 * x1), r2 = 1.f / (x2 * x2),
-          r3 = 1.f / (x3 * x3), r4 = 1.f / (x4 * x4), r5 = 1.f / (x5 * x5);
+    return (zm_v2f){1.f / v.x, 1.f / v.y};
 #endif
-    t[0] = n1 * r0; t[1] = n2 * r1; t[2] = n3 * r2;
-    t[3] = n1 * r3; t[4] = n2 * r4; t[5] = n3 * r5;
-    float sum = ((t[0] + t[1]) + (t[2] + t[3])) + (t[4] + t[5]);
-#ifdef __HIP_DEVICE_COMPILE__
-    float inv = __builtin_amdgcn_rcpf(sum);
-#else
-    float inv = 1.f / sum;
-#endif
+}
+
+__host__ __device__ inline void zm_lanczos3_pair(zm_v2f d, zm_v2f t[6]) {
+    const zm_v2f a = d * 1.0471975511965976f;
+    const zm_v2f a2 = a * a;
+    const zm_v2f s = a * (1.f + a2 * (-1.6666667e-1f + a2 * (8.3333333e-3f + a2 * (-1.98412698e-4f
+                     + a2 * (2.7557319e-6f + a2 * -2.5052108e-8f)))));
+    const zm_v2f c = 1.f + a2 * (-0.5f + a2 * (4.1666667e-2f + a2 * (-1.3888889e-3f
+                     + a2 * (2.4801587e-5f + a2 * (-2.7557319e-7f + a2 * 2.0876757e-9f)))));
+    const zm_v2f hs = 0.5f * s, hc = 0.8660254037844386f * c;
+    const zm_v2f n1 = hs - hc, n2 = hs + hc, n3 = -s;
+    const zm_v2f x0 = d + 2.f, x1 = d + 1.f, x2 = d, x3 = d - 1.f, x4 = d - 2.f, x5 = d - 3.f;
+    const zm_v2f q = d * d - d;
+    const zm_v2f p1 = q - 6.f, p2 = q - 2.f, p3 = q;
+    const zm_v2f p23 = p2 * p3, p13 = p1 * p3, p12 = p1 * p2;
+    zm_v2f u0 = x5 * p23, u5 = x0 * p23, u1 = x4 * p13, u4 = x1 * p13, u2 = x3 * p12, u3 = x2 * p12;
+    t[0] = n1 * (u0 * u0); t[1] = n2 * (u1 * u1); t[2] = n3 * (u2 * u2);
+    t[3] = n1 * (u3 * u3); t[4] = n2 * (u4 * u4); t[5] = n3 * (u5 * u5);
+    const zm_v2f inv = zm_rcp2(((t[0] + t[1]) + (t[2] + t[3])) + (t[4] + t[5]));
 #pragma unroll
     for (int k = 0; k < 6; ++k) t[k] *= inv;
+}
+
+__host__ __device__ inline void zm_lanczos3(float d, float t[6]) {
+    zm_v2f tt[6];
+    zm_lanczos3_pair((zm_v2f){d, d}, tt);
+    for (int k = 0; k < 6; ++k) t[k] = tt[k].x;
 }
 
 extern "C" void zm_debug_lanczos3(float d, float* out6) { zm_lanczos3(d, out6); }
@@ -182,14 +196,23 @@ template <int KIND> struct taps_traits;
 template <> struct taps_traits<ZM_RESAMPLE_LANCZOS3> { enum { N = 6, OFF = -2 }; };
 template <> struct taps_traits<ZM_RESAMPLE_BILINEAR> { enum { N = 2, OFF = 0 }; };
 
+// taps of both axes at once: t[k].x along x, t[k].y along y
 template <int KIND>
-__device__ inline void make_taps(float d, bool delta, float* t) {
+__device__ inline void make_taps2(float dx, float dy, bool ddx, bool ddy, zm_v2f* t) {
     if (KIND == ZM_RESAMPLE_LANCZOS3) {
-        zm_lanczos3(delta ? 0.5f : d, t);
-        if (delta) { t[0] = 0.f; t[1] = 0.f; t[2] = 1.f; t[3] = 0.f; t[4] = 0.f; t[5] = 0.f; }
+        zm_lanczos3_pair((zm_v2f){ddx ? 0.5f : dx, ddy ? 0.5f : dy}, t);
+        // delta kernels are rare (aligned grids): patch them under a wave-uniform test
+        if (__any(ddx || ddy)) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float dl = (k == 2) ? 1.f : 0.f;
+                t[k].x = ddx ? dl : t[k].x;
+                t[k].y = ddy ? dl : t[k].y;
+            }
+        }
     } else {
-        t[0] = 1.f - d;
-        t[1] = d;
+        t[0] = (zm_v2f){1.f - dx, 1.f - dy};
+        t[1] = (zm_v2f){dx, dy};
     }
 }
 
@@ -251,17 +274,65 @@ __device__ inline void tile_position(const tile_hdr* h, int tx, int ty, float* p
     *py = ya + fy * (yb - ya);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ src, int nx, int ny,
+// LDS row reads as single ds_read_b64 instructions.  Left to the compiler, the six
+// adjacent {value, variance} pairs of a tap row become ds_read2_b64, which moves
+// half the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table).  The wait is part
+// of the same statement sequence and carries the values, so no consumer can be
+// scheduled above it.
+template <int NT> struct lds_row;
+template <> struct lds_row<6> {
+    static __device__ inline void read(const float2* p, float2 (&s)[6]) {
+        const unsigned a = (unsigned)(size_t)p;
+        unsigned long long r0, r1, r2, r3, r4, r5;
+        asm volatile("ds_read_b64 %0, %6\n\t"
+                     "ds_read_b64 %1, %6 offset:8\n\t"
+                     "ds_read_b64 %2, %6 offset:16\n\t"
+                     "ds_read_b64 %3, %6 offset:24\n\t"
+                     "ds_read_b64 %4, %6 offset:32\n\t"
+                     "ds_read_b64 %5, %6 offset:40\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+                     : "v"(a)
+                     : "memory");
+        const unsigned long long r[6] = {r0, r1, r2, r3, r4, r5};
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            s[c] = make_float2(__uint_as_float((unsigned)r[c]), __uint_as_float((unsigned)(r[c] >> 32)));
+    }
+};
+template <> struct lds_row<2> {
+    static __device__ inline void read(const float2* p, float2 (&s)[2]) {
+        const unsigned a = (unsigned)(size_t)p;
+        unsigned long long r0, r1;
+        asm volatile("ds_read_b64 %0, %2\n\t"
+                     "ds_read_b64 %1, %2 offset:8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1)
+                     : "v"(a)
+                     : "memory");
+        s[0] = make_float2(__uint_as_float((unsigned)r0), __uint_as_float((unsigned)(r0 >> 32)));
+        s[1] = make_float2(__uint_as_float((unsigned)r1), __uint_as_float((unsigned)(r1 >> 32)));
+    }
+};
+
+// MASKOP 0: no mask; 1: store the resampled mask (0 where not covered);
+// 2: accumulate into macc with `mkind` (AND / OR), -1 = "no frame covered yet".
+template <int KIND, int MASKOP>
+__global__ __launch_bounds__(256, MASKOP ? 4 : 8) void k_resample(const float2* __restrict__ src, int nx, int ny,
                                                   int spitch, const double2* __restrict__ lat,
                                                   int lnx, int lny, float fscale,
                                                   float2* __restrict__ dst, int onx, int ony,
-                                                  int lds_cap) {
+                                                  int lds_cap, const int32_t* __restrict__ mask,
+                                                  int32_t* __restrict__ macc, int mkind,
+                                                  int mfirst, int dbg) {
     extern __shared__ float4 smem4[];
     tile_hdr* hdr = reinterpret_cast<tile_hdr*>(smem4);
     float2* tile = reinterpret_cast<float2*>(smem4) + HDR_FLOATS / 2;
+    int32_t* mt = reinterpret_cast<int32_t*>(tile + lds_cap);   // raw mask tile
+    int32_t* mx = mt + lds_cap;                                 // OR over the NT columns to the right
     constexpr int NT = taps_traits<KIND>::N;
     constexpr int OFF = taps_traits<KIND>::OFF;
+    constexpr int CI = -OFF;                                     // tap index of a delta kernel
 
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
@@ -270,26 +341,66 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ src
     const int bx0 = hdr->bx0, by0 = hdr->by0, bw = hdr->bw, bh = hdr->bh;
     // the footprint may miss the frame entirely: nothing to stage then
     const bool touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
-    const bool use_lds = touches && ((long long)bw * bh <= (long long)lds_cap);
+    const bool use_lds = touches && ((long long)bw * bh <= (long long)lds_cap) && dbg != 2;
+    if (dbg == 3) return;
 
     if (use_lds) {
         const int wave = tid >> 6, lane = tid & 63;
         const int bw2 = bw >> 1;
         const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+        const bool m_vec = MASKOP && ((nx & 1) == 0);   // int2 loads need even rows (bx0 is even)
         for (int r = wave; r < bh; r += 4) {
             int gy = by0 + r;
             bool rowok = (gy >= 0) && (gy < ny);
             const float2* srow = src + (size_t)(rowok ? gy : 0) * spitch;
-            for (int c2 = lane; c2 < bw2; c2 += 64) {
+            const int32_t* mrow = MASKOP ? mask + (size_t)(rowok ? gy : 0) * nx : nullptr;
+            // every lane takes part in the shuffles below, so the column loop is wave-uniform
+            for (int c0 = 0; c0 < bw2; c0 += 64) {
+                const int c2 = c0 + lane;
+                const bool incol = c2 < bw2;
                 int gx = bx0 + 2 * c2;
-                float4 v = fill;
-                if (rowok && gx >= 0 && gx < spitch)
-                    v = *reinterpret_cast<const float4*>(srow + gx);
-                *reinterpret_cast<float4*>(tile + r * bw + 2 * c2) = v;
+                if (incol) {
+                    float4 v = fill;
+                    if (rowok && gx >= 0 && gx < spitch)
+                        v = *reinterpret_cast<const float4*>(srow + gx);
+                    *reinterpret_cast<float4*>(tile + r * bw + 2 * c2) = v;
+                }
+                if (MASKOP) {
+                    int m0 = 0, m1 = 0;
+                    if (incol && rowok) {
+                        if (m_vec && gx >= 0 && gx + 1 < nx) {
+                            int2 mm = *reinterpret_cast<const int2*>(mrow + gx);
+                            m0 = mm.x; m1 = mm.y;
+                        } else {
+                            if (gx >= 0 && gx < nx) m0 = mrow[gx];
+                            if (gx + 1 >= 0 && gx + 1 < nx) m1 = mrow[gx + 1];
+                        }
+                    }
+                    // row OR over the NT columns to the right, from the neighbouring lanes
+                    // (columns past this 128-px chunk count as 0: no tap reaches them)
+                    const int pr = m0 | m1;
+                    int x0 = pr, x1 = m1;
+                    if (NT == 6) {
+                        const int p1 = __shfl_down(pr, 1), p2 = __shfl_down(pr, 2);
+                        const int f3 = __shfl_down(m0, 3);
+                        const int q1 = lane + 1 < 64 ? p1 : 0, q2 = lane + 2 < 64 ? p2 : 0;
+                        const int g3 = lane + 3 < 64 ? f3 : 0;
+                        x0 = pr | q1 | q2;
+                        x1 = m1 | q1 | q2 | g3;
+                    } else {
+                        const int f1 = __shfl_down(m0, 1);
+                        x1 = m1 | (lane + 1 < 64 ? f1 : 0);
+                    }
+                    if (incol) {
+                        *reinterpret_cast<int2*>(mt + r * bw + 2 * c2) = make_int2(m0, m1);
+                        *reinterpret_cast<int2*>(mx + r * bw + 2 * c2) = make_int2(x0, x1);
+                    }
+                }
             }
         }
     }
     __syncthreads();
+    if (dbg == 1) return;
 
     const int tx = tid & 63, tyb = tid >> 6;
     const int ox = ox0 + tx;
@@ -306,27 +417,39 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ src
         split_pos(px, &ixr, &dx, &ddx);
         split_pos(py, &iyr, &dy, &ddy);
         const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;   // first tap, absolute
-        const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
+        const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny) && dbg != 4;
         float2 res = make_float2(0.f, 0.f);
+        int32_t mres = 0;
         if (inb) {
-            float txw[NT], tyw[NT];
-            make_taps<KIND>(dx, ddx, txw);
-            make_taps<KIND>(dy, ddy, tyw);
+            zm_v2f tw[NT];
+            make_taps2<KIND>(dx, dy, ddx, ddy, tw);
             float acc = 0.f, vacc = 0.f;
             if (use_lds) {
                 const float2* p = tile + (iyr + OFF) * bw + (ixr + OFF);
+                zm_v2f av = (zm_v2f){0.f, 0.f};     // {value, variance} accumulators
 #pragma unroll
                 for (int r = 0; r < NT; ++r) {
-                    float ra = 0.f, rv = 0.f;
+                    float2 s[NT];
+                    lds_row<NT>::read(p, s);
+                    zm_v2f rv2 = (zm_v2f){0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) {
-                        float2 s = p[c];
-                        ra = fmaf(txw[c], s.x, ra);
-                        rv = fmaf(txw[c], s.y, rv);
-                    }
-                    acc = fmaf(tyw[r], ra, acc);
-                    vacc = fmaf(tyw[r], rv, vacc);
+                    for (int c = 0; c < NT; ++c)
+                        rv2 = __builtin_elementwise_fma((zm_v2f){tw[c].x, tw[c].x},
+                                                        (zm_v2f){s[c].x, s[c].y}, rv2);
+                    av = __builtin_elementwise_fma((zm_v2f){tw[r].y, tw[r].y}, rv2, av);
                     p += bw;
+                }
+                acc = av.x;
+                vacc = av.y;
+                if (MASKOP) {
+                    // delta kernels only touch the centre tap; otherwise every tap is non-zero
+                    const int32_t* mp = (ddx ? mt + ixr + OFF + CI : mx + ixr + OFF) + (iyr + OFF) * bw;
+                    if (ddy) {
+                        mres = mp[CI * bw];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NT; ++r) mres |= mp[r * bw];
+                    }
                 }
             } else {
                 const float2* p = src + (size_t)iy * spitch + ix;
@@ -336,12 +459,20 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ src
 #pragma unroll
                     for (int c = 0; c < NT; ++c) {
                         float2 s = p[c];
-                        ra = fmaf(txw[c], s.x, ra);
-                        rv = fmaf(txw[c], s.y, rv);
+                        ra = fmaf(tw[c].x, s.x, ra);
+                        rv = fmaf(tw[c].x, s.y, rv);
                     }
-                    acc = fmaf(tyw[r], ra, acc);
-                    vacc = fmaf(tyw[r], rv, vacc);
+                    acc = fmaf(tw[r].y, ra, acc);
+                    vacc = fmaf(tw[r].y, rv, vacc);
                     p += spitch;
+                }
+                if (MASKOP) {
+                    const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
+                    const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
+                    for (int r = r0; r < r1; ++r) {
+                        const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
+                        for (int c = c0; c < c1; ++c) mres |= mp[c];
+                    }
                 }
             }
             if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
@@ -349,7 +480,18 @@ __global__ __launch_bounds__(256) void k_resample(const float2* __restrict__ src
                 res.y = 1.f / (vacc * fscale * fscale);
             }
         }
-        dst[(size_t)oy * onx + ox] = res;
+        const size_t oidx = (size_t)oy * onx + ox;
+        dst[oidx] = res;
+        if (MASKOP == 1) {
+            macc[oidx] = mres;
+        } else if (MASKOP == 2) {
+            int32_t a = mfirst ? -1 : macc[oidx];       // -1: nothing covered yet
+            if (inb) {
+                if (a == -1) a = mres;
+                else a = (mkind == ZM_MASK_AND) ? (a & mres) : (a | mres);
+            }
+            macc[oidx] = a;
+        }
     }
 }
 
@@ -385,27 +527,65 @@ __global__ __launch_bounds__(256) void k_resample_nearest(const float2* __restri
     }
 }
 
-int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
-                       const double2* lat, int lnx, int lny, int kernel, float fscale,
-                       float2* dst, int onx, int ony, int lds_elems) {
-    dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
-    size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * sizeof(float2);
-    zm_scope_timer t(ctx, "resample");
-    if (kernel == ZM_RESAMPLE_LANCZOS3) {
-        hipLaunchKernelGGL(k_resample<ZM_RESAMPLE_LANCZOS3>, grd, blk, shmem, ctx->stream, src, nx,
-                           ny, spitch, lat, lnx, lny, fscale, dst, onx, ony, lds_elems);
-    } else if (kernel == ZM_RESAMPLE_BILINEAR) {
-        hipLaunchKernelGGL(k_resample<ZM_RESAMPLE_BILINEAR>, grd, blk, shmem, ctx->stream, src, nx,
-                           ny, spitch, lat, lnx, lny, fscale, dst, onx, ony, lds_elems);
-    } else if (kernel == ZM_RESAMPLE_NEAREST) {
-        hipLaunchKernelGGL(k_resample_nearest, grd, blk, 0, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony);
-    } else {
-        zm_set_error("zm_launch_resample: unknown kernel %d", kernel);
-        return 2;
-    }
+static int zm_dbg() { static int v = getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0; return v; }
+
+template <int KIND>
+static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float2* src, int nx, int ny,
+                                int spitch, const double2* lat, int lnx, int lny, float fscale,
+                                float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
+                                int32_t* macc, int mop, int mkind, int mfirst) {
+    dim3 blk(256, 1, 1);
+    if (mop == 0)
+        hipLaunchKernelGGL((k_resample<KIND, 0>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
+    else if (mop == 1)
+        hipLaunchKernelGGL((k_resample<KIND, 1>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
+    else
+        hipLaunchKernelGGL((k_resample<KIND, 2>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
     ZM_HIP(hipGetLastError());
     return 0;
+}
+
+// mop 0: image only; 1: also store the resampled mask into macc; 2: accumulate it
+// into macc with mkind (ZM_MASK_AND / ZM_MASK_OR), mfirst = first frame of the stack.
+int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
+                       const double2* lat, int lnx, int lny, int kernel, float fscale,
+                       float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
+                       int32_t* macc, int mop, int mkind, int mfirst) {
+    dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
+    if (!mask || !macc) mop = 0;
+    // image tile + (mask tile + its row-OR) when a mask rides along; keep within 64 KiB
+    if (mop && lds_elems > 4000) lds_elems = 4000;
+    size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * (sizeof(float2) + (mop ? 8 : 0));
+    zm_scope_timer t(ctx, "resample");
+    if (kernel == ZM_RESAMPLE_LANCZOS3)
+        return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, grd, shmem, src, nx, ny, spitch, lat, lnx,
+                                                          lny, fscale, dst, onx, ony, lds_elems, mask,
+                                                          macc, mop, mkind, mfirst);
+    if (kernel == ZM_RESAMPLE_BILINEAR)
+        return launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, grd, shmem, src, nx, ny, spitch, lat, lnx,
+                                                          lny, fscale, dst, onx, ony, lds_elems, mask,
+                                                          macc, mop, mkind, mfirst);
+    if (kernel == ZM_RESAMPLE_NEAREST) {
+        hipLaunchKernelGGL(k_resample_nearest, grd, blk, 0, ctx->stream, src, nx, ny, spitch, lat, lnx,
+                           lny, fscale, dst, onx, ony);
+        ZM_HIP(hipGetLastError());
+        if (mop) {
+            // nearest neighbour has no footprint: the stand-alone mask kernel + accumulate
+            int32_t* tmp = nullptr;
+            const int64_t opix = (int64_t)onx * ony;
+            if (mop == 1) return zm_launch_resample_mask(ctx, mask, nx, ny, lat, lnx, lny, kernel, macc,
+                                                         onx, ony, 0);
+            ZM_TRY(ctx->get("mask_tmp", sizeof(int32_t) * opix, (void**)&tmp));
+            ZM_TRY(zm_launch_resample_mask(ctx, mask, nx, ny, lat, lnx, lny, kernel, tmp, onx, ony, -1));
+            return zm_launch_mask_accum(ctx, macc, tmp, opix, mkind, mfirst);
+        }
+        return 0;
+    }
+    zm_set_error("zm_launch_resample: unknown kernel %d", kernel);
+    return 2;
 }
 
 // ---------------------------------------------------------------------------

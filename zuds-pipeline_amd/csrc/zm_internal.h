@@ -96,12 +96,14 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
                    const float* bknodes, int nbx, int nby, int mesh,
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch);
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
-                        int mesh, int fsize, float wthresh, int mode, float** nodes_dev,
-                        float** stats_dev, int* nbx_out, int* nby_out, const char* slot);
+                        int mesh, int fsize, float wthresh, int mode0, int nmode,
+                        float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
+                        const char* slot);
 int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out);
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
-                       float2* dst, int onx, int ony, int lds_elems);
+                       float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
+                       int32_t* macc, int mop, int mkind, int mfirst);
 int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny,
                             const double2* lat, int lnx, int lny, int kernel,
                             int32_t* dst, int onx, int ony, int32_t fill);
