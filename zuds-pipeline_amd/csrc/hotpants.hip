@@ -395,116 +395,124 @@ __global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ r
 #define CH_ROWS 64                      // panel rows per workgroup
 #define CH_KT 32                        // K tile of the update GEMM
 
+__device__ inline double readlane_d(double v, int src) {
+    // src is wave-uniform (a compile-time constant after unrolling): v_readlane_b32 x 2
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// 32 x 32 Cholesky by one wave, the block held in registers (lane i = row i):
+// column j is scaled in place, then broadcast lane by lane for the rank-1 update.
 __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail) {
-    // wave 0, lanes own entries of the trailing block; LDS only, no barriers needed
     const int lane = threadIdx.x & 63;
-    for (int j = 0; j < nb; ++j) {
-        double v = D[j][j];
-        if (!(v > 1e-14)) { v = 1e-14; if (lane == 0 && fail) atomicAdd(fail, 1); }
-        const double dj = sqrt(v);
-        const double inv = 1.0 / dj;
-        if (lane == 0) D[j][j] = dj;
-        if (lane > j && lane < nb) D[lane][j] *= inv;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS visible across the wave's lanes
-        __builtin_amdgcn_wave_barrier();
-        // rank-1 update of the remaining lower triangle: entries (i, c), j < c <= i < nb
-        const int m = nb - j - 1;                 // remaining dimension
-        for (int e = lane; e < m * m; e += 64) {
-            const int ii = e / m, cc = e - ii * m;
-            const int i = j + 1 + ii, c = j + 1 + cc;
-            if (c <= i) D[i][c] -= D[i][j] * D[c][j];
+    const int row = lane & 31;
+    double a[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) a[c] = D[row][c];     // rows >= nb are identity rows
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) {
+        double ajj = readlane_d(a[j], j);
+        if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
+        const double dj = sqrt(ajj);
+        const double lj = (row == j) ? dj : a[j] / dj;    // L[row][j] (meaningful for row >= j)
+        a[j] = lj;
+#pragma unroll
+        for (int c = j + 1; c < CH_NB; ++c) {
+            const double lc = readlane_d(lj, c);          // L[c][j]
+            a[c] -= lj * lc;                              // entries with row >= c are the live ones
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
     }
+    if (lane < CH_NB) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c)
+            if (c <= row) D[row][c] = a[c];
+    }
+    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
 }
 
 // A: [reg][(n + 1)][n]; rows 0..n-1 lower triangle, row n = rhs / y.
-__global__ __launch_bounds__(256) void k_chol_step(int n, int k0, double* __restrict__ Aall,
-                                                   int* __restrict__ fail) {
-    __shared__ double Lr[CH_NB + CH_ROWS][CH_KT + 1];   // rows of the diag block, then my rows
+// Right-looking step, two launches per 32-column block so that the trailing
+// update runs on many workgroups:
+//   k_chol_panel  every workgroup factors the diagonal block (one wave, registers)
+//                 and solves 256 panel rows against it; workgroup 0 stores L11;
+//   k_chol_update A22 -= L21 L21^T on 64 x 64 tiles (lower triangle + rhs row).
+__global__ __launch_bounds__(256) void k_chol_panel(int n, int k0, double* __restrict__ Aall,
+                                                    int* __restrict__ fail) {
     __shared__ double D[CH_NB][CH_NB + 1];
     double* A = Aall + (size_t)blockIdx.z * (size_t)(n + 1) * n;
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - k0);
-    const int nrows = n + 1;                             // including the rhs row
-    const int r0 = k0 + nb + blockIdx.x * CH_ROWS;       // first panel row of this workgroup
-    // thread tile of the update: 3 rows x 4 cols of the 96 x 32 output
-    const int tr = (tid >> 3) * 3, tc = (tid & 7) * 4;
-    double acc[3][4] = {};
-    auto grow = [&](int lr) -> int { return lr < CH_NB ? k0 + lr : r0 + (lr - CH_NB); };
-    for (int m0 = 0; m0 < k0; m0 += CH_KT) {
-        __syncthreads();
-        for (int e = tid; e < (CH_NB + CH_ROWS) * CH_KT; e += 256) {
-            const int lr = e >> 5, m = e & 31;
-            const int gr = grow(lr);
-            const bool ok = (lr < CH_NB ? lr < nb : gr < nrows) && (m0 + m < k0);
-            Lr[lr][m] = ok ? A[(size_t)gr * n + m0 + m] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int m = 0; m < CH_KT; ++m) {
-            double a[3], b[4];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = Lr[tr + p][m];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = Lr[tc + q][m];      // rows of the diag block = columns
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
-        }
-    }
-    __syncthreads();
-    // updated diagonal block -> D, updated panel rows -> Lr (reused as 64 x 32)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int lr = tr + p, gr = grow(lr);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = tc + q;
-            double v = 0.0;
-            if (lr < CH_NB) {
-                if (lr < nb && c <= lr && c < nb) v = A[(size_t)gr * n + k0 + c] - acc[p][q];
-                else v = (lr == c) ? 1.0 : 0.0;
-                D[lr][c] = v;
-            } else {
-                if (gr < nrows && c < nb) v = A[(size_t)gr * n + k0 + c] - acc[p][q];
-                Lr[lr][c] = v;
-            }
-        }
+    const int nrows = n + 1;
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+        int i = e >> 5, j = e & 31;
+        D[i][j] = (i < nb && j <= i && j < nb) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < 64) chol_diag_wave(D, nb, blockIdx.x == 0 ? &fail[blockIdx.z] : nullptr);
     __syncthreads();
     if (blockIdx.x == 0)
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int i = e >> 5, j = e & 31;
+            int i = e >> 5, j = e & 31;
             if (i < nb && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = D[i][j];
         }
-    // panel solve: one thread per row, x L11^T = r
-    if (tid < CH_ROWS) {
-        const int gr = r0 + tid;
-        if (gr < nrows) {
-            double x[CH_NB];
+    const int row = k0 + nb + blockIdx.x * 256 + tid;
+    if (row >= nrows) return;
+    double x[CH_NB];
+    double* ar = A + (size_t)row * n + k0;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) x[j] = Lr[CH_NB + tid][j];
+    for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ar[j] : 0.0;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                if (j < nb) {
-                    double v = x[j];
+    for (int j = 0; j < CH_NB; ++j) {
+        if (j < nb) {
+            double v = x[j];
 #pragma unroll
-                    for (int m = 0; m < CH_NB; ++m)
-                        if (m < j) v -= x[m] * D[j][m];
-                    x[j] = v / D[j][j];
-                }
-            }
-            double* ar = A + (size_t)gr * n + k0;
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j)
-                if (j < nb) ar[j] = x[j];
+            for (int m = 0; m < CH_NB; ++m)
+                if (m < j) v -= x[m] * D[j][m];
+            x[j] = v / D[j][j];
         }
     }
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j)
+        if (j < nb) ar[j] = x[j];
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(int n, int k0, double* __restrict__ Aall) {
+    __shared__ double Li[64][CH_NB + 1];
+    __shared__ double Lj[64][CH_NB + 1];
+    if (blockIdx.x > blockIdx.y) return;
+    double* A = Aall + (size_t)blockIdx.z * (size_t)(n + 1) * n;
+    const int nrows = n + 1;
+    const int t0 = k0 + CH_NB;
+    const int i0 = t0 + blockIdx.y * 64, j0 = t0 + blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * CH_NB; e += 256) {
+        int r = e >> 5, m = e & 31;
+        Li[r][m] = (i0 + r < nrows) ? A[(size_t)(i0 + r) * n + k0 + m] : 0.0;
+        Lj[r][m] = (j0 + r < n) ? A[(size_t)(j0 + r) * n + k0 + m] : 0.0;
+    }
+    __syncthreads();
+    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+    double acc[4][4] = {};
+#pragma unroll 8
+    for (int m = 0; m < CH_NB; ++m) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = Li[ti + q][m]; b[q] = Lj[tj + q][m]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = i0 + ti + p, j = j0 + tj + q;
+            if (i < nrows && j < n && j <= i) A[(size_t)i * n + j] -= acc[p][q];
+        }
 }
 
 // Back substitution L^T x = y (y = row n of the factored storage), one workgroup
@@ -1020,8 +1028,12 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 const int k0 = kb * CH_NB;
                 const int nb = std::min(CH_NB, P.nunk - k0);
                 const int below = P.nunk + 1 - k0 - nb;            // panel rows incl. the rhs row
-                const int pch = std::max(zm_div_up(below, CH_ROWS), 1);
-                hipLaunchKernelGGL(k_chol_step, dim3(pch, 1, P.nreg), b256, 0, st, P.nunk, k0, A, fail);
+                hipLaunchKernelGGL(k_chol_panel, dim3(std::max(zm_div_up(below, 256), 1), 1, P.nreg), b256, 0,
+                                   st, P.nunk, k0, A, fail);
+                if (below > 0 && nb == CH_NB) {
+                    const int tt = zm_div_up(below, 64);
+                    hipLaunchKernelGGL(k_chol_update, dim3(tt, tt, P.nreg), b256, 0, st, P.nunk, k0, A);
+                }
             }
             {
                 const size_t bsh = sizeof(double) * (((size_t)P.nunk + 1) & ~(size_t)1) +
