@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
 // need[cell] = vectors / Gram must be (re)computed this round.
 // X layout: [cell][nX][npixp] fp64, rows 0..nc-1 kernel vectors, nc..nE-1
 // background terms, nE the science pixels; columns >= npix are zero.
+#define HV_R 8     // outputs per thread along the filter direction (register sliding window)
+
+template <int HWK>
 __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
                                                     const float* __restrict__ ref,
                                                     const float* __restrict__ srms,
@@ -199,19 +202,21 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                                                     double* __restrict__ phi,         // [cell][nkp]
                                                     double* __restrict__ vbar) {
     extern __shared__ double hp_smem[];
+    constexpr int STEP = 2 * HWK + 1;
+    constexpr int WIN = HV_R + 2 * HWK;
     const int cell = blockIdx.x, tid = threadIdx.x;
     if (!need[cell]) return;
     const int act = active[cell];
     if (act < 0) return;
     const int2 cc = centres[cell * P.nss + act];
     const int r = cell / P.ncellr;
-    const int pw = P.pw, sw = P.sw, hwk = P.hwk, hwss = P.hwss, step = P.step;
+    const int pw = P.pw, sw = P.sw, hwss = P.hwss;
     double* xp = hp_smem;                               // [pw][sw]
     double* w0 = xp + (size_t)pw * sw;                  // [npix]
     double* fl = w0 + P.npix;                           // [nf1][step]
-    double* red = fl + P.nf1 * step;                    // [4]
+    double* red = fl + P.nf1 * STEP;                    // [4]
     float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pw]
-    for (int k = tid; k < P.nf1 * step; k += 256) fl[k] = filt[k];
+    for (int k = tid; k < P.nf1 * STEP; k += 256) fl[k] = filt[k];
     for (int k = tid; k < pw * pw; k += 256) {
         int yy = k / pw, xx = k - yy * pw;
         patch[k] = ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)];
@@ -244,33 +249,67 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             phi[(size_t)cell * P.nkp + p] = pow(fx, (double)P.kpi[p]) * pow(fy, (double)P.kpj[p]);
     }
     __syncthreads();
-    // basis vectors: for each x filter, one x pass, then a y pass per term using it
+    const int nstrip = (sw + HV_R - 1) / HV_R;
+    // basis vectors: for each x filter, one x pass, then a y pass per term using it.
+    // Both passes slide a register window: HV_R outputs share HV_R + 2 HWK loads.
     for (int f = 0; f < P.nf1; ++f) {
         bool used = false;
         for (int n = 0; n < P.nc; ++n) used |= (P.tfx[n] == f);
         if (!used) continue;
-        const double* fxv = fl + f * step;
-        for (int k = tid; k < pw * sw; k += 256) {
-            int yy = k / sw, j = k - yy * sw;
-            const float* pr = patch + yy * pw + j + hwk;   // T(x - u) = patch[.. + hwk - u]
-            double acc = 0.0;
-            for (int u = -hwk; u <= hwk; ++u) acc += fxv[u + hwk] * (double)pr[-u];
-            xp[k] = acc;
+        const double* fxv = fl + f * STEP;
+        // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
+        for (int e = tid; e < pw * nstrip; e += 256) {
+            const int yy = e / nstrip, j0 = (e - yy * nstrip) * HV_R;
+            const float* pr = patch + yy * pw + j0;
+            double wv[WIN];
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) wv[k] = (j0 + k < pw) ? (double)pr[k] : 0.0;
+            double acc[HV_R];
+#pragma unroll
+            for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int m = 0; m < STEP; ++m) {
+                const double cf = fxv[2 * HWK - m];
+#pragma unroll
+                for (int q = 0; q < HV_R; ++q) acc[q] += cf * wv[q + m];
+            }
+#pragma unroll
+            for (int q = 0; q < HV_R; ++q)
+                if (j0 + q < sw) xp[yy * sw + j0 + q] = acc[q];
         }
         __syncthreads();
         for (int n = 0; n < P.nc; ++n) {
             if (P.tfx[n] != f) continue;
-            const double* fyv = fl + P.tfy[n] * step;
+            const double* fyv = fl + P.tfy[n] * STEP;
             const double sc = P.tscale[n];
-            for (int k = tid; k < P.npix; k += 256) {
-                int i = k / sw, j = k - i * sw;
-                const double* col = xp + (i + hwk) * sw + j;
-                double acc = 0.0;
-                for (int v = -hwk; v <= hwk; ++v) acc += fyv[v + hwk] * col[-v * sw];
-                acc *= sc;
-                if (n == 0) w0[k] = acc;
-                else if (P.tsub0[n]) acc -= w0[k];
-                Xc[(size_t)n * P.npixp + k] = acc;
+            // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
+            for (int e = tid; e < sw * nstrip; e += 256) {
+                const int s = e / sw, j = e - s * sw;      // consecutive lanes = consecutive columns
+                const int i0 = s * HV_R;
+                const double* col = xp + i0 * sw + j;
+                double wv[WIN];
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) wv[k] = (i0 + k < pw) ? col[k * sw] : 0.0;
+                double acc[HV_R];
+#pragma unroll
+                for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
+#pragma unroll
+                for (int m = 0; m < STEP; ++m) {
+                    const double cf = fyv[2 * HWK - m];
+#pragma unroll
+                    for (int q = 0; q < HV_R; ++q) acc[q] += cf * wv[q + m];
+                }
+#pragma unroll
+                for (int q = 0; q < HV_R; ++q) {
+                    const int i = i0 + q;
+                    if (i < sw) {
+                        const int k = i * sw + j;
+                        double v = acc[q] * sc;
+                        if (n == 0) w0[k] = v;
+                        else if (P.tsub0[n]) v -= w0[k];
+                        Xc[(size_t)n * P.npixp + k] = v;
+                    }
+                }
             }
             if (n == 0) __syncthreads();
         }
@@ -1000,7 +1039,6 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     size_t vsh = sizeof(double) * ((size_t)P.pw * P.sw + P.npix + (size_t)P.nf1 * P.step + 4) +
                  sizeof(float) * (size_t)P.pw * P.pw + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
-    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh));
 
     int rounds = 0;
     int h_int[3 * HP_MAXREG + 4];
@@ -1008,8 +1046,17 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     for (rounds = 1; rounds <= 8; ++rounds) {
         {
             zm_scope_timer t(ctx, "hp_vectors");
-            hipLaunchKernelGGL(k_hp_vectors, dim3(P.ncell), b256, vsh, st, P, sci, ref, sci_rms, ref_rms,
-                               d_filt, centres, active, need, X, phi, vbar);
+#define HP_VEC_CASE(H) case H: \
+    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
+    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
+                       centres, active, need, X, phi, vbar); break;
+            switch (P.hwk) {
+                HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
+                HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
+                HP_VEC_CASE(11) HP_VEC_CASE(12) HP_VEC_CASE(13) HP_VEC_CASE(14) HP_VEC_CASE(15)
+                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+            }
+#undef HP_VEC_CASE
             ZM_HIP(hipGetLastError());
         }
         {

@@ -17,13 +17,15 @@
 // One workgroup = one 64 x 16 output tile = 4 x 1 lattice cells; its input
 // footprint (bounding box of the 10 tile nodes + kernel support) is staged in
 // LDS with 16-byte loads and read back as 8-byte {value, variance} pairs.
+#include <algorithm>
+
 #include "zm_internal.h"
 #include "wcs_math.h"
 
 #define TW 64
 #define TH 16
 #define LSTEP ZM_LATTICE_STEP
-#define HDR_FLOATS 64   // LDS header: 20 node floats + bbox ints, 256 B keeps 16-B alignment
+#define HDR_FLOATS 96   // LDS header ring: 3 x (20 node floats + bbox ints + flags) in 384 B
 
 // ---------------------------------------------------------------------------
 // The map travels as a by-value kernel argument (1.5 KB): no host staging buffer
@@ -317,181 +319,231 @@ template <> struct lds_row<2> {
 
 // MASKOP 0: no mask; 1: store the resampled mask (0 where not covered);
 // 2: accumulate into macc with `mkind` (AND / OR), -1 = "no frame covered yet".
-template <int KIND, int MASKOP>
-__global__ __launch_bounds__(256, MASKOP ? 4 : 8) void k_resample(const float2* __restrict__ src, int nx, int ny,
-                                                  int spitch, const double2* __restrict__ lat,
-                                                  int lnx, int lny, float fscale,
-                                                  float2* __restrict__ dst, int onx, int ony,
-                                                  int lds_cap, const int32_t* __restrict__ mask,
-                                                  int32_t* __restrict__ macc, int mkind,
-                                                  int mfirst, int dbg) {
-    extern __shared__ float4 smem4[];
-    tile_hdr* hdr = reinterpret_cast<tile_hdr*>(smem4);
-    float2* tile = reinterpret_cast<float2*>(smem4) + HDR_FLOATS / 2;
-    int32_t* mt = reinterpret_cast<int32_t*>(tile + lds_cap);   // raw mask tile
-    int32_t* mx = mt + lds_cap;                                 // OR over the NT columns to the right
+//
+// Persistent, software-pipelined: a workgroup walks tiles t, t + G, t + 2G, ...
+// While it interpolates tile k out of LDS, the global loads of tile k + 1 are in
+// flight into registers and wave 0 builds the header of tile k + 2, so neither
+// the lattice / pixel load latency nor the block launch cost sits on the critical
+// path.  PF float4 (+ int2) registers per thread bound the staged tile; larger
+// footprints (strong rotation / scale change) gather from global memory instead.
+#define RS_PF 5                      // prefetch slots per thread: 5 x 256 float4 = 2560 px
+#define RS_PFCAP (RS_PF * 256 * 2)
+
+struct rs_hdr {
+    tile_hdr h;
+    int use_lds, touches;
+};
+
+template <int KIND>
+__device__ inline void rs_build_header(const double2* __restrict__ lat, int lnx, int lny, int t,
+                                       int ntx, int nx, int ny, int lds_cap, rs_hdr* H) {
     constexpr int NT = taps_traits<KIND>::N;
     constexpr int OFF = taps_traits<KIND>::OFF;
-    constexpr int CI = -OFF;                                     // tap index of a delta kernel
+    const int tyi = t / ntx, txi = t - tyi * ntx;
+    build_tile_header(lat, lnx, lny, txi * (TW / LSTEP), tyi * (TH / LSTEP), OFF, OFF + NT - 1, &H->h);
+    if ((threadIdx.x & 63) == 0) {
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
+        const int touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
+        const long long area = (long long)bw * bh;
+        H->touches = touches;
+        H->use_lds = touches && area <= (long long)lds_cap && area <= RS_PFCAP;
+    }
+}
 
+template <int KIND, int MASKOP>
+__global__ __launch_bounds__(256, MASKOP ? 3 : 5) void k_resample(
+    const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
+    int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
+    const int32_t* __restrict__ mask, int32_t* __restrict__ macc, int mkind, int mfirst, int ntx,
+    int ntiles) {
+    extern __shared__ float4 smem4[];
+    rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
+    float2* tile = reinterpret_cast<float2*>(smem4) + HDR_FLOATS / 2;
+    int32_t* mt = reinterpret_cast<int32_t*>(tile + lds_cap);      // raw mask tile
+    int32_t* mx = mt + lds_cap;                                    // OR over the NT columns to the right
+    constexpr int NT = taps_traits<KIND>::N;
+    constexpr int OFF = taps_traits<KIND>::OFF;
+    constexpr int CI = -OFF;                                       // tap index of a delta kernel
     const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
-    if (tid < 64) build_tile_header(lat, lnx, lny, ox0 / LSTEP, oy0 / LSTEP, OFF, OFF + NT - 1, hdr);
-    __syncthreads();
-    const int bx0 = hdr->bx0, by0 = hdr->by0, bw = hdr->bw, bh = hdr->bh;
-    // the footprint may miss the frame entirely: nothing to stage then
-    const bool touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
-    const bool use_lds = touches && ((long long)bw * bh <= (long long)lds_cap) && dbg != 2;
-    if (dbg == 3) return;
+    const int G = gridDim.x;
+    const float fscale2 = fscale * fscale;
+    const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
 
-    if (use_lds) {
-        const int wave = tid >> 6, lane = tid & 63;
-        const int bw2 = bw >> 1;
-        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
-        const bool m_vec = MASKOP && ((nx & 1) == 0);   // int2 loads need even rows (bx0 is even)
-        for (int r = wave; r < bh; r += 4) {
-            int gy = by0 + r;
-            bool rowok = (gy >= 0) && (gy < ny);
-            const float2* srow = src + (size_t)(rowok ? gy : 0) * spitch;
-            const int32_t* mrow = MASKOP ? mask + (size_t)(rowok ? gy : 0) * nx : nullptr;
-            // every lane takes part in the shuffles below, so the column loop is wave-uniform
-            for (int c0 = 0; c0 < bw2; c0 += 64) {
-                const int c2 = c0 + lane;
-                const bool incol = c2 < bw2;
-                int gx = bx0 + 2 * c2;
-                if (incol) {
-                    float4 v = fill;
-                    if (rowok && gx >= 0 && gx < spitch)
-                        v = *reinterpret_cast<const float4*>(srow + gx);
-                    *reinterpret_cast<float4*>(tile + r * bw + 2 * c2) = v;
-                }
-                if (MASKOP) {
-                    int m0 = 0, m1 = 0;
-                    if (incol && rowok) {
-                        if (m_vec && gx >= 0 && gx + 1 < nx) {
-                            int2 mm = *reinterpret_cast<const int2*>(mrow + gx);
-                            m0 = mm.x; m1 = mm.y;
-                        } else {
-                            if (gx >= 0 && gx < nx) m0 = mrow[gx];
-                            if (gx + 1 >= 0 && gx + 1 < nx) m1 = mrow[gx + 1];
-                        }
-                    }
-                    // row OR over the NT columns to the right, from the neighbouring lanes
-                    // (columns past this 128-px chunk count as 0: no tap reaches them)
-                    const int pr = m0 | m1;
-                    int x0 = pr, x1 = m1;
-                    if (NT == 6) {
-                        const int p1 = __shfl_down(pr, 1), p2 = __shfl_down(pr, 2);
-                        const int f3 = __shfl_down(m0, 3);
-                        const int q1 = lane + 1 < 64 ? p1 : 0, q2 = lane + 2 < 64 ? p2 : 0;
-                        const int g3 = lane + 3 < 64 ? f3 : 0;
-                        x0 = pr | q1 | q2;
-                        x1 = m1 | q1 | q2 | g3;
-                    } else {
-                        const int f1 = __shfl_down(m0, 1);
-                        x1 = m1 | (lane + 1 < 64 ? f1 : 0);
-                    }
-                    if (incol) {
-                        *reinterpret_cast<int2*>(mt + r * bw + 2 * c2) = make_int2(m0, m1);
-                        *reinterpret_cast<int2*>(mx + r * bw + 2 * c2) = make_int2(x0, x1);
-                    }
+    float4 pf[RS_PF];
+    int2 pm[RS_PF];
+    // issue the loads of tile `t` (header H) into the prefetch registers
+    auto prefetch = [&](const rs_hdr* H) {
+        if (!H->use_lds) return;
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bw2 = H->h.bw >> 1;
+        const int n4 = bw2 * H->h.bh;
+        const float inv = 1.0f / (float)bw2;
+#pragma unroll
+        for (int k = 0; k < RS_PF; ++k) {
+            const int e = tid + 256 * k;
+            pf[k] = fill;
+            pm[k] = make_int2(0, 0);
+            if (e < n4) {
+                const int r = (int)(((float)e + 0.5f) * inv);
+                const int c2 = e - r * bw2;
+                const int gy = by0 + r, gx = bx0 + 2 * c2;
+                if (gy >= 0 && gy < ny && gx >= 0 && gx < spitch)
+                    pf[k] = *reinterpret_cast<const float4*>(src + (size_t)gy * spitch + gx);
+                if (MASKOP && gy >= 0 && gy < ny) {
+                    const int32_t* mrow = mask + (size_t)gy * nx;
+                    if (gx >= 0 && gx < nx) pm[k].x = mrow[gx];
+                    if (gx + 1 >= 0 && gx + 1 < nx) pm[k].y = mrow[gx + 1];
                 }
             }
         }
+    };
+    auto store = [&](const rs_hdr* H) {
+        if (!H->use_lds) return;
+        const int n4 = (H->h.bw >> 1) * H->h.bh;
+#pragma unroll
+        for (int k = 0; k < RS_PF; ++k) {
+            const int e = tid + 256 * k;
+            if (e < n4) {
+                *reinterpret_cast<float4*>(tile + 2 * e) = pf[k];      // rows are bw = 2 bw2 wide: linear
+                if (MASKOP) *reinterpret_cast<int2*>(mt + 2 * e) = pm[k];
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    if (tid < 64) {
+        rs_build_header<KIND>(lat, lnx, lny, t, ntx, nx, ny, lds_cap, &HR[0]);
+        if (t + G < ntiles) rs_build_header<KIND>(lat, lnx, lny, t + G, ntx, nx, ny, lds_cap, &HR[1]);
     }
     __syncthreads();
-    if (dbg == 1) return;
+    prefetch(&HR[0]);
+    int slot = 0;
+    for (; t < ntiles; t += G) {
+        const rs_hdr* H = &HR[slot];
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        const int nnslot = nslot == 2 ? 0 : nslot + 1;
+        store(H);
+        __syncthreads();
+        const bool use_lds = H->use_lds, touches = H->touches;
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
+        if (MASKOP && use_lds) {
+            // mx[r][c] = OR of mt[r][c .. c + NT - 1]: 4 columns per thread, sliding window
+            const int groups = (bw + 3) >> 2;
+            for (int e = tid; e < bh * groups; e += 256) {
+                const int r = e / groups, c = (e - r * groups) * 4;
+                int w[4 + NT - 1];
+#pragma unroll
+                for (int k = 0; k < 4 + NT - 1; ++k) w[k] = (c + k < bw) ? mt[r * bw + c + k] : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int o = 0;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) o |= w[j + k];
+                    if (c + j < bw) mx[r * bw + c + j] = o;
+                }
+            }
+            __syncthreads();
+        }
+        // next tile's pixels into registers, the tile after that gets its header
+        if (t + G < ntiles) prefetch(&HR[nslot]);
+        if (tid < 64 && t + 2 * G < ntiles)
+            rs_build_header<KIND>(lat, lnx, lny, t + 2 * G, ntx, nx, ny, lds_cap, &HR[nnslot]);
 
-    const int tx = tid & 63, tyb = tid >> 6;
-    const int ox = ox0 + tx;
+        const int tyi = t / ntx, txi = t - tyi * ntx;
+        const int ox0 = txi * TW, oy0 = tyi * TH;
+        const int tx = tid & 63, tyb = tid >> 6;
+        const int ox = ox0 + tx;
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        const int ty = tyb + 4 * q;
-        const int oy = oy0 + ty;
-        if (ox >= onx || oy >= ony) continue;
-        float px, py;
-        tile_position(hdr, tx, ty, &px, &py);
-        int ixr, iyr;
-        float dx, dy;
-        bool ddx, ddy;
-        split_pos(px, &ixr, &dx, &ddx);
-        split_pos(py, &iyr, &dy, &ddy);
-        const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;   // first tap, absolute
-        const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny) && dbg != 4;
-        float2 res = make_float2(0.f, 0.f);
-        int32_t mres = 0;
-        if (inb) {
-            zm_v2f tw[NT];
-            make_taps2<KIND>(dx, dy, ddx, ddy, tw);
-            float acc = 0.f, vacc = 0.f;
-            if (use_lds) {
-                const float2* p = tile + (iyr + OFF) * bw + (ixr + OFF);
-                zm_v2f av = (zm_v2f){0.f, 0.f};     // {value, variance} accumulators
-#pragma unroll
-                for (int r = 0; r < NT; ++r) {
-                    float2 s[NT];
-                    lds_row<NT>::read(p, s);
-                    zm_v2f rv2 = (zm_v2f){0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < NT; ++c)
-                        rv2 = __builtin_elementwise_fma((zm_v2f){tw[c].x, tw[c].x},
-                                                        (zm_v2f){s[c].x, s[c].y}, rv2);
-                    av = __builtin_elementwise_fma((zm_v2f){tw[r].y, tw[r].y}, rv2, av);
-                    p += bw;
-                }
-                acc = av.x;
-                vacc = av.y;
-                if (MASKOP) {
-                    // delta kernels only touch the centre tap; otherwise every tap is non-zero
-                    const int32_t* mp = (ddx ? mt + ixr + OFF + CI : mx + ixr + OFF) + (iyr + OFF) * bw;
-                    if (ddy) {
-                        mres = mp[CI * bw];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < NT; ++r) mres |= mp[r * bw];
-                    }
-                }
-            } else {
-                const float2* p = src + (size_t)iy * spitch + ix;
-#pragma unroll
-                for (int r = 0; r < NT; ++r) {
-                    float ra = 0.f, rv = 0.f;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) {
-                        float2 s = p[c];
-                        ra = fmaf(tw[c].x, s.x, ra);
-                        rv = fmaf(tw[c].x, s.y, rv);
-                    }
-                    acc = fmaf(tw[r].y, ra, acc);
-                    vacc = fmaf(tw[r].y, rv, vacc);
-                    p += spitch;
-                }
-                if (MASKOP) {
-                    const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
-                    const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
-                    for (int r = r0; r < r1; ++r) {
-                        const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
-                        for (int c = c0; c < c1; ++c) mres |= mp[c];
-                    }
-                }
-            }
-            if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
-                res.x = acc * fscale;
-                res.y = 1.f / (vacc * fscale * fscale);
-            }
-        }
-        const size_t oidx = (size_t)oy * onx + ox;
-        dst[oidx] = res;
-        if (MASKOP == 1) {
-            macc[oidx] = mres;
-        } else if (MASKOP == 2) {
-            int32_t a = mfirst ? -1 : macc[oidx];       // -1: nothing covered yet
+        for (int q = 0; q < 4; ++q) {
+            const int ty = tyb + 4 * q;
+            const int oy = oy0 + ty;
+            if (ox >= onx || oy >= ony) continue;
+            float px, py;
+            tile_position(&H->h, tx, ty, &px, &py);
+            int ixr, iyr;
+            float dx, dy;
+            bool ddx, ddy;
+            split_pos(px, &ixr, &dx, &ddx);
+            split_pos(py, &iyr, &dy, &ddy);
+            const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;   // first tap, absolute
+            const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
+            float2 res = make_float2(0.f, 0.f);
+            int32_t mres = 0;
             if (inb) {
-                if (a == -1) a = mres;
-                else a = (mkind == ZM_MASK_AND) ? (a & mres) : (a | mres);
+                zm_v2f tw[NT];
+                make_taps2<KIND>(dx, dy, ddx, ddy, tw);
+                float acc = 0.f, vacc = 0.f;
+                if (use_lds) {
+                    const float2* p = tile + (iyr + OFF) * bw + (ixr + OFF);
+                    zm_v2f av = (zm_v2f){0.f, 0.f};     // {value, variance} accumulators
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) {
+                        float2 s[NT];
+                        lds_row<NT>::read(p, s);
+                        zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < NT; ++c)
+                            rv2 = __builtin_elementwise_fma((zm_v2f){tw[c].x, tw[c].x},
+                                                            (zm_v2f){s[c].x, s[c].y}, rv2);
+                        av = __builtin_elementwise_fma((zm_v2f){tw[r].y, tw[r].y}, rv2, av);
+                        p += bw;
+                    }
+                    acc = av.x;
+                    vacc = av.y;
+                    if (MASKOP) {
+                        // delta kernels only touch the centre tap; otherwise every tap is non-zero
+                        const int32_t* mp = (ddx ? mt + ixr + OFF + CI : mx + ixr + OFF) + (iyr + OFF) * bw;
+                        if (ddy) {
+                            mres = mp[CI * bw];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NT; ++r) mres |= mp[r * bw];
+                        }
+                    }
+                } else {
+                    const float2* p = src + (size_t)iy * spitch + ix;
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) {
+                        float ra = 0.f, rv = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) {
+                            float2 s = p[c];
+                            ra = fmaf(tw[c].x, s.x, ra);
+                            rv = fmaf(tw[c].x, s.y, rv);
+                        }
+                        acc = fmaf(tw[r].y, ra, acc);
+                        vacc = fmaf(tw[r].y, rv, vacc);
+                        p += spitch;
+                    }
+                    if (MASKOP) {
+                        const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
+                        const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
+                        for (int r = r0; r < r1; ++r) {
+                            const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
+                            for (int c = c0; c < c1; ++c) mres |= mp[c];
+                        }
+                    }
+                }
+                if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
+                    res.x = acc * fscale;
+                    res.y = __builtin_amdgcn_rcpf(vacc * fscale2);      // 1 ulp: one instruction
+                }
             }
-            macc[oidx] = a;
+            const size_t oidx = (size_t)oy * onx + ox;
+            dst[oidx] = res;
+            if (MASKOP == 1) {
+                macc[oidx] = mres;
+            } else if (MASKOP == 2) {
+                int32_t a = mfirst ? -1 : macc[oidx];       // -1: nothing covered yet
+                if (inb) {
+                    if (a == -1) a = mres;
+                    else a = (mkind == ZM_MASK_AND) ? (a & mres) : (a | mres);
+                }
+                macc[oidx] = a;
+            }
         }
+        __syncthreads();          // everyone is done with the LDS tile and with header `slot`
+        slot = nslot;
     }
 }
 
@@ -527,23 +579,24 @@ __global__ __launch_bounds__(256) void k_resample_nearest(const float2* __restri
     }
 }
 
-static int zm_dbg() { static int v = getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0; return v; }
-
 template <int KIND>
 static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float2* src, int nx, int ny,
                                 int spitch, const double2* lat, int lnx, int lny, float fscale,
                                 float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
                                 int32_t* macc, int mop, int mkind, int mfirst) {
     dim3 blk(256, 1, 1);
+    const int ntx = grd.x, ntiles = grd.x * grd.y;
+    // persistent grid: a few workgroups per CU, each walking ntiles / G tiles
+    dim3 pgrd(std::min(ntiles, 256 * (mop ? 3 : 5)), 1, 1);
     if (mop == 0)
-        hipLaunchKernelGGL((k_resample<KIND, 0>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
+        hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
     else if (mop == 1)
-        hipLaunchKernelGGL((k_resample<KIND, 1>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
+        hipLaunchKernelGGL((k_resample<KIND, 1>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
     else
-        hipLaunchKernelGGL((k_resample<KIND, 2>), grd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, zm_dbg());
+        hipLaunchKernelGGL((k_resample<KIND, 2>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -557,7 +610,7 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
     if (!mask || !macc) mop = 0;
     // image tile + (mask tile + its row-OR) when a mask rides along; keep within 64 KiB
-    if (mop && lds_elems > 4000) lds_elems = 4000;
+    if (lds_elems > RS_PFCAP) lds_elems = RS_PFCAP;      // what the prefetch registers can stage
     size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * (sizeof(float2) + (mop ? 8 : 0));
     zm_scope_timer t(ctx, "resample");
     if (kernel == ZM_RESAMPLE_LANCZOS3)
