@@ -599,7 +599,7 @@ __device__ inline void spline_line(const float* a, float* d, float* u, int n, in
 // sigma maps (may hold -BIG); nodes: [mode][2 maps][4 planes][n]; stats: [mode][2]
 // = {median of the filtered mode map, median of the filtered sigma map}.
 // Everything is staged in LDS: the spline recurrences are latency chains.
-__global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restrict__ raw_all,
+__global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ raw_all,
                                                             int nbx, int nby, int fsize,
                                                             float* __restrict__ nodes_all,
                                                             float* __restrict__ stats_all) {
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
     __shared__ float med[4];
     if (tid == 0) ngood = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += BK_THREADS) {
+    for (int k = tid; k < n; k += 1024) {
         float b = raw[k];
         sb0[k] = b;
         sb1[k] = raw[n + k];
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
     }
     __syncthreads();
     // 1. fill bad meshes from the nearest good ones (ties averaged)
-    for (int k = tid; k < n; k += BK_THREADS) {
+    for (int k = tid; k < n; k += 1024) {
         float b = sb0[k], s = sb1[k];
         if (!(b > -BK_BIG)) {
             if (ngood == 0) { b = 0.f; s = 1.f; }
@@ -648,11 +648,11 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
         fb0[k] = b; fb1[k] = s;      // staged here, copied back below
     }
     __syncthreads();
-    for (int k = tid; k < n; k += BK_THREADS) { sb0[k] = fb0[k]; sb1[k] = fb1[k]; }
+    for (int k = tid; k < n; k += 1024) { sb0[k] = fb0[k]; sb1[k] = fb1[k]; }
     __syncthreads();
     // 2. fsize x fsize median filter (window clipped at the borders)
     const int hb = fsize / 2;
-    for (int k = tid; k < n; k += BK_THREADS) {
+    for (int k = tid; k < n; k += 1024) {
         int j = k / nbx, i = k - j * nbx;
         if (fsize == 3) {
             // registers only: clipped cells carry +inf and sort to the end
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
     // 3. global medians by rank counting (exact)
     for (int m = 0; m < 2; ++m) {
         const float* fb = m ? fb1 : fb0;
-        for (int k = tid; k < n; k += BK_THREADS) {
+        for (int k = tid; k < n; k += 1024) {
             float v = fb[k];
             int less = 0, eq = 0;
             for (int q = 0; q < n; ++q) { float o = fb[q]; less += o < v; eq += o == v; }
@@ -711,16 +711,16 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_filter(const float* __restr
         float* A = pl + 2 * n;
         float* B = pl + 3 * n;
         __syncthreads();
-        for (int k = tid; k < n; k += BK_THREADS) V[k] = fb[k];
+        for (int k = tid; k < n; k += 1024) V[k] = fb[k];
         __syncthreads();
-        for (int i = tid; i < nbx; i += BK_THREADS) spline_line(V + i, DY + i, tmp + i, nby, nbx);
+        for (int i = tid; i < nbx; i += 1024) spline_line(V + i, DY + i, tmp + i, nby, nbx);
         __syncthreads();
-        for (int j = tid; j < nby; j += BK_THREADS) spline_line(V + j * nbx, A + j * nbx, tmp + j * nbx, nbx, 1);
+        for (int j = tid; j < nby; j += 1024) spline_line(V + j * nbx, A + j * nbx, tmp + j * nbx, nbx, 1);
         __syncthreads();
-        for (int j = tid; j < nby; j += BK_THREADS) spline_line(DY + j * nbx, B + j * nbx, tmp + j * nbx, nbx, 1);
+        for (int j = tid; j < nby; j += 1024) spline_line(DY + j * nbx, B + j * nbx, tmp + j * nbx, nbx, 1);
         __syncthreads();
         float* out = nodes + (size_t)m * 4 * n;
-        for (int k = tid; k < 4 * n; k += BK_THREADS) out[k] = pl[k];
+        for (int k = tid; k < 4 * n; k += 1024) out[k] = pl[k];
     }
 }
 
@@ -821,7 +821,7 @@ int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
     }
     {
         zm_scope_timer t(ctx, "mesh_filter");
-        hipLaunchKernelGGL(k_mesh_filter, dim3(nmode, 1, 1), dim3(BK_THREADS, 1, 1), fsh, ctx->stream,
+        hipLaunchKernelGGL(k_mesh_filter, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
                            raw, nbx, nby, fsize, nodes, stats);
         ZM_HIP(hipGetLastError());
     }

@@ -442,6 +442,14 @@ __device__ inline double readlane_d(double v, int src) {
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+template <int N>
+__device__ inline double readlane_dyn(const double (&a)[N], int idx) {
+    double r = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = (i == idx) ? a[i] : r;
+    return r;
+}
+
 // 32 x 32 Cholesky by one wave, the block held in registers (lane i = row i):
 // column j is scaled in place, then broadcast lane by lane for the rank-1 update.
 __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail) {
@@ -455,8 +463,12 @@ __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail)
     for (int j = 0; j < CH_NB; ++j) {
         double ajj = readlane_d(a[j], j);
         if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
-        const double dj = sqrt(ajj);
-        const double lj = (row == j) ? dj : a[j] / dj;    // L[row][j] (meaningful for row >= j)
+        // 1 / sqrt by hardware estimate + two Newton steps (full fp64 accuracy), no divide
+        double ri = __builtin_amdgcn_rsq(ajj);
+        ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+        ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+        const double dj = ajj * ri;
+        const double lj = (row == j) ? dj : a[j] * ri;    // L[row][j] (meaningful for row >= j)
         a[j] = lj;
 #pragma unroll
         for (int c = j + 1; c < CH_NB; ++c) {
@@ -468,6 +480,9 @@ __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail)
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c)
             if (c <= row) D[row][c] = a[c];
+        // reciprocal of the diagonal in the (unused) upper corner D[0][1..]: the panel
+        // solve multiplies instead of dividing
+        D[row][CH_NB] = 1.0 / readlane_dyn(a, row);
     }
     if (bad && lane == 0 && fail) atomicAdd(fail, 1);
 }
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(int n, int k0, double* __res
 #pragma unroll
             for (int m = 0; m < CH_NB; ++m)
                 if (m < j) v -= x[m] * D[j][m];
-            x[j] = v / D[j][j];
+            x[j] = v * D[j][CH_NB];            // reciprocal diagonal (padding column)
         }
     }
 #pragma unroll
