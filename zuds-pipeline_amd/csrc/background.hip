@@ -776,7 +776,7 @@ __global__ void k_var_scale(const float* __restrict__ bstats, const float* __res
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
-                        const char* slot) {
+                        const char* slot, int index, int count) {
     ZM_CHECK(mesh >= 8 && mesh <= 4096, "background: BACK_SIZE %d out of range [8, 4096]", mesh);
     ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
     ZM_CHECK(nmode >= 1 && mode0 >= 0 && mode0 + nmode <= 2, "background: bad statistic selection");
@@ -789,8 +789,12 @@ int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
     std::string s(slot);
     float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
     ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * n, (void**)&raw));
-    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n, (void**)&nodes));
-    ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4, (void**)&stats));
+    // nodes / stats are kept per frame (`index` of `count`): a later kernel on another
+    // stream reads them; raw maps and dumps are consumed in order on this stream
+    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n * (size_t)count, (void**)&nodes));
+    ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4 * (size_t)count, (void**)&stats));
+    nodes += (size_t)index * 2 * 8 * n;
+    stats += (size_t)index * 4;
     const size_t fsh = sizeof(float) * 9 * (size_t)n;
     static bool attr_set = false;
     if (!attr_set) {

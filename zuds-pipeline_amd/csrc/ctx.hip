@@ -66,6 +66,8 @@ void zm_ctx::release_all() {
     timers.clear();
     for (auto e : event_pool) (void)hipEventDestroy(e);
     event_pool.clear();
+    for (auto e : sync_events) (void)hipEventDestroy(e);
+    sync_events.clear();
 }
 
 extern "C" int zm_ctx_create(int device, zm_ctx** out) {
@@ -83,6 +85,7 @@ extern "C" int zm_ctx_create(int device, zm_ctx** out) {
     zm_ctx* c = new zm_ctx();
     c->device = device;
     ZM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    ZM_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     c->own_stream = true;
     *out = c;
     return 0;
@@ -93,6 +96,7 @@ extern "C" int zm_ctx_destroy(zm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->release_all();
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -111,6 +115,16 @@ extern "C" int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream) {
     if (ctx->own_stream && ctx->stream) ZM_HIP(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    return 0;
+}
+
+int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out) {
+    while ((int)ctx->sync_events.size() < n) {
+        hipEvent_t e = nullptr;
+        ZM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+    }
+    *out = ctx->sync_events.data();
     return 0;
 }
 

@@ -351,7 +351,7 @@ __device__ inline void rs_build_header(const double2* __restrict__ lat, int lnx,
 }
 
 template <int KIND, int MASKOP>
-__global__ __launch_bounds__(256, MASKOP ? 3 : 5) void k_resample(
+__global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
     const int32_t* __restrict__ mask, int32_t* __restrict__ macc, int mkind, int mfirst, int ntx,
@@ -444,15 +444,25 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 5) void k_resample(
             }
             __syncthreads();
         }
+        const int tyi = t / ntx, txi = t - tyi * ntx;
+        const int ox0 = txi * TW, oy0 = tyi * TH;
+        const int tx = tid & 63, tyb = tid >> 6;
+        const int ox = ox0 + tx;
+        // the running mask coadd of this thread's four pixels: loaded before the prefetch
+        // so that waiting for it (vmcnt is in order) does not wait for the next tile
+        int32_t aprev[4] = {-1, -1, -1, -1};
+        if (MASKOP == 2 && !mfirst) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oy = oy0 + tyb + 4 * q;
+                if (ox < onx && oy < ony) aprev[q] = macc[(size_t)oy * onx + ox];
+            }
+        }
         // next tile's pixels into registers, the tile after that gets its header
         if (t + G < ntiles) prefetch(&HR[nslot]);
         if (tid < 64 && t + 2 * G < ntiles)
             rs_build_header<KIND>(lat, lnx, lny, t + 2 * G, ntx, nx, ny, lds_cap, &HR[nnslot]);
 
-        const int tyi = t / ntx, txi = t - tyi * ntx;
-        const int ox0 = txi * TW, oy0 = tyi * TH;
-        const int tx = tid & 63, tyb = tid >> 6;
-        const int ox = ox0 + tx;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const int ty = tyb + 4 * q;
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 5) void k_resample(
             if (MASKOP == 1) {
                 macc[oidx] = mres;
             } else if (MASKOP == 2) {
-                int32_t a = mfirst ? -1 : macc[oidx];       // -1: nothing covered yet
+                int32_t a = q == 0 ? aprev[0] : q == 1 ? aprev[1] : q == 2 ? aprev[2] : aprev[3];
                 if (inb) {
                     if (a == -1) a = mres;
                     else a = (mkind == ZM_MASK_AND) ? (a & mres) : (a | mres);
@@ -587,7 +597,7 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
     dim3 blk(256, 1, 1);
     const int ntx = grd.x, ntiles = grd.x * grd.y;
     // persistent grid: a few workgroups per CU, each walking ntiles / G tiles
-    dim3 pgrd(std::min(ntiles, 256 * (mop ? 3 : 5)), 1, 1);
+    dim3 pgrd(std::min(ntiles, 256 * (mop ? 3 : 4)), 1, 1);
     if (mop == 0)
         hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
                            lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);

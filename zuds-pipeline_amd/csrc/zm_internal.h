@@ -55,6 +55,8 @@ struct zm_ctx {
     std::map<std::string, std::pair<void*, size_t>> scratch;
     // pinned host staging
     std::map<std::string, std::pair<void*, size_t>> pinned;
+    hipStream_t aux = nullptr;                 // second stream: background statistics run beside resampling
+    std::vector<hipEvent_t> sync_events;       // cross-stream ordering (no timing)
     bool timing = false;
     std::map<std::string, zm_timer_slot> timers;
     std::vector<hipEvent_t> event_pool;
@@ -98,7 +100,8 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
-                        const char* slot);
+                        const char* slot, int index = 0, int count = 1);
+int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out);
 int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out);
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
