@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
+MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
 
 
 def parse():
@@ -41,7 +42,7 @@ def parse():
     ap.add_argument('--no-mask', action='store_true', help='skip the mask coadd (dev only)')
     ap.add_argument('--seeing', type=float, default=4.0,
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
-    ap.add_argument('--cpu-sample', type=int, default=1024,
+    ap.add_argument('--cpu-sample', type=int, default=640,
                     help='side of the frames the CPU baseline resamples')
     return ap.parse_args()
 
@@ -79,6 +80,20 @@ def make_device_frames(synth, torch, n, size, seed0, device):
     return base, frames
 
 
+def pmc_traffic(args):
+    """HBM bytes per k_resample launch from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is); None when the
+    profile does not match this workload."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_resample.json')
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get('size') != args.size or bool(d.get('mask')) != (not args.no_mask):
+        return None
+    return d.get('hbm_bytes_per_launch')
+
+
 def cpu_baseline(synth, size, combine):
     """The numpy oracle (a port, not SWarp) timed on the host: resample +
     combine of 2 config-2 style frames of size x size, one process."""
@@ -103,13 +118,23 @@ def cpu_baseline(synth, size, combine):
         o, w_, _ = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3, fs)
         vals.append(o)
         wgts.append(w_)
-    ocombine.combine(np.array(vals), np.array(wgts), combine)
-    dt = time.perf_counter() - t0
-    mpix = len(frames) * size * size / 1e6
+    ref, refw, _ = ocombine.combine(np.array(vals), np.array(wgts), combine)
+    t1 = time.perf_counter()
+    # one subtraction of the same size against that coadd (hotpants restatement)
+    from oracle import hotpants as ohp
+    sci = frames[0]
+    rrms = np.where(refw > 0, 1.0 / np.sqrt(np.where(refw > 0, refw, 1)), np.sqrt(50000.0))
+    srms = np.where(sci['wgt'] > 0, 1.0 / np.sqrt(np.where(sci['wgt'] > 0, sci['wgt'], 1)), np.sqrt(50000.0))
+    ohp.subtract(vals[0] + 150.0, ref + 150.0, srms, rrms, (wgts[0] <= 0).astype(np.uint8),
+                 r=5.0, rss=12.0, nsx=max(size // 100, 1), nsy=max(size // 100, 1), ko=2, bgo=0,
+                 tu=5e3, iu=5e3, tl=-100.0, il=-100.0)
+    t2 = time.perf_counter()
+    dt = t2 - t0
+    mpix = (len(frames) + 1) * size * size / 1e6
     return {'value': mpix / dt, 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{len(frames)} frames {size}x{size}, numpy fp64 oracle '
-                      f'(resample + {combine} combine), {dt:.1f} s; CPU restatement, '
-                      f'not SWarp/hotpants'}
+            'sample': f'{len(frames)} frames {size}x{size} resample + {combine} combine '
+                      f'({t1 - t0:.1f} s) + 1 subtraction r=5 ko=2 ({t2 - t1:.1f} s), numpy fp64 '
+                      f'oracle, one process; CPU restatement, not SWarp/hotpants'}
 
 
 def main():
@@ -218,11 +243,14 @@ def main():
         roofline = None
         if 'resample' in kt:
             avg_s = kt['resample']['avg_us'] * 1e-6
-            bytes_per_launch = RESAMPLE_BYTES_PER_OUTPX * args.size * args.size
+            bpp = RESAMPLE_BYTES_PER_OUTPX + (0 if args.no_mask else MASK_BYTES_PER_OUTPX)
+            bytes_per_launch = bpp * args.size * args.size
             ach = bytes_per_launch / avg_s / 1e9
-            roofline = {'bound': 'hbm', 'kernel': 'k_resample<LANCZOS3>',
+            roofline = {'bound': 'hbm',
+                        'kernel': 'k_resample<LANCZOS3, mask fused>' if not args.no_mask
+                        else 'k_resample<LANCZOS3>',
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
                         'avg_launch_us': kt['resample']['avg_us'],
                         'algorithmic_bytes_per_launch': bytes_per_launch,
                         'dominant_by_time': dom}
