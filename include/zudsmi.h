@@ -184,6 +184,21 @@ int zm_median_mad(zm_ctx* ctx, const float* img, const int32_t* mask, int64_t n,
 int zm_median_mad_dev(zm_ctx* ctx, const float* img, const int32_t* mask,
                       int64_t n, double* out_median, double* out_mad_sigma);
 
+/* ---- forced aperture photometry ------------------------------------------- */
+/* Replaces photutils.aperture_photometry(method='exact') + the bounding-box flag
+ * OR of raw_aperture_photometry / aperture_photometry (zuds/photometry.py:61-113,
+ * 116-249): x, y are 0-based pixel positions, radius in pixels (APERTURE_RADIUS = 3,
+ * zuds/constants.py:14); flux = sum(img frac), err = sqrt(sum(rms^2 frac)),
+ * flags = OR of mask over the aperture bounding box.  rms / mask may be NULL. */
+int zm_aperture_photometry(zm_ctx* ctx, const float* img, const float* rms,
+                           const int32_t* mask, int nx, int ny, int npos,
+                           const double* x, const double* y, double radius,
+                           double* out_flux, double* out_err, int32_t* out_flags);
+int zm_aperture_photometry_dev(zm_ctx* ctx, const float* img, const float* rms,
+                               const int32_t* mask, int nx, int ny, int npos,
+                               const double* x, const double* y, double radius,
+                               double* out_flux, double* out_err, int32_t* out_flags);
+
 /* ---- device-pointer entry points (bench, multi-GPU, pipelines) ----------- */
 /* Same arithmetic as above on device-resident buffers; enqueue only. */
 typedef struct zm_dframe {

@@ -21,6 +21,7 @@ from .hotpants import *
 from .coadd import *
 from .subtraction import *
 from .mpi import *
+from .photometry import *
 from . import synth, fits
 
 # same DB-free entry points as the reference

@@ -271,6 +271,27 @@ class Engine(object):
         return med.value, mad.value
 
 
+def _engine_aperture(self, img, x, y, rms=None, mask=None, radius=3.0):
+    """Forced circular apertures at 0-based pixel positions: (flux, fluxerr, flags)."""
+    img, rms, mask = as_f32(img), as_f32(rms), as_i32(mask)
+    ny, nx = img.shape
+    x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+    y = np.ascontiguousarray(np.atleast_1d(y), dtype=np.float64)
+    if x.shape != y.shape:
+        raise ValueError('x and y must have the same shape')
+    n = x.size
+    flux = np.zeros(n)
+    err = np.zeros(n)
+    flags = np.zeros(n, dtype=np.int32)
+    check(self.L.zm_aperture_photometry(self._ctx, ptr(img), ptr(rms), ptr(mask), nx, ny, n,
+                                        ptr(x), ptr(y), float(radius), ptr(flux), ptr(err),
+                                        ptr(flags)), 'zm_aperture_photometry')
+    return flux, err, flags
+
+
+Engine.aperture_photometry = _engine_aperture
+
+
 def hp_params(**kw):
     """zm_hp_params with hotpants' defaults, overridden by keyword (tu, tl, iu, il,
     r, rss, fin, fi, nsx, nsy, nrx, nry, ko, bgo, nss, normalize, ft, ks, deg,
