@@ -1,0 +1,149 @@
+"""Size-independent properties at BASELINE.json's full frame size (3072 x 3072 and
+the real ZTF quadrant 3072 x 3080), where the oracle is too slow to run: exact
+identities, linearity, idempotence, round trips and fill patterns."""
+import numpy as np
+import pytest
+from scipy.ndimage import maximum_filter
+
+from util import pkg, synth
+
+pytestmark = pytest.mark.gpu
+
+NX, NY = 3072, 3080
+
+
+@pytest.fixture(scope='module')
+def frame():
+    s = synth()
+    rng = np.random.default_rng(42)
+    w = s.ztf_wcs(NX, NY, tpv=True)
+    img = rng.normal(200.0, 6.0, (NY, NX)).astype(np.float32)
+    xs, ys = rng.uniform(20, NX - 20, 1500), rng.uniform(20, NY - 20, 1500)
+    fl = np.exp(rng.uniform(np.log(2e3), np.log(4e4), 1500))
+    s.add_stars(img, xs, ys, fl, 2.1)
+    mask = np.zeros((NY, NX), np.int32)
+    bad = rng.integers(0, NX * NY, 9000)
+    mask.ravel()[bad] = rng.choice([1, 256, 2, 2048], bad.size)
+    wgt = np.where((mask & 198589) > 0, 0.0, 1.0 / 36.0).astype(np.float32)
+    return dict(img=img, wgt=wgt, mask=mask, wcs=w, flxscale=1.0, stars=(xs, ys, fl))
+
+
+def test_identity_resample_is_bit_exact(engine, frame):
+    o, ow, om = engine.resample(frame['img'], frame['wcs'], frame['wcs'], wgt=frame['wgt'],
+                                mask=frame['mask'])
+    inner = (slice(2, -3), slice(2, -3))
+    good = frame['wgt'][inner] > 0
+    assert np.array_equal(o[inner][good], frame['img'][inner][good])
+    assert np.array_equal(ow[inner] > 0, good)
+    assert np.array_equal(om[inner], frame['mask'][inner])
+    assert not ow[:2].any() and not ow[:, -3:].any()
+
+
+def test_integer_shift_is_bit_exact_through_tpv(engine, frame):
+    s = synth()
+    wout = s.ztf_wcs(NX, NY, dx=-11.0, dy=6.0, tpv=True)     # out (x, y) = in (x + 11, y - 6)
+    o, ow, _ = engine.resample(frame['img'], frame['wcs'], wout)
+    ys, xs = np.nonzero(ow > 0)
+    assert ys.size > 9_000_000
+    assert np.array_equal(o[ys, xs], frame['img'][ys - 6, xs + 11])
+
+
+def test_resample_is_linear(engine, frame):
+    s = synth()
+    wout = s.ztf_wcs(NX, NY, dx=7.3, dy=-4.6, rot_deg=0.08, tpv=True)
+    rng = np.random.default_rng(3)
+    other = rng.normal(0, 50, (NY, NX)).astype(np.float32)
+    ra, wa, _ = engine.resample(frame['img'], frame['wcs'], wout)
+    rb, _, _ = engine.resample(other, frame['wcs'], wout)
+    rc, _, _ = engine.resample((2.0 * frame['img'] - 0.5 * other).astype(np.float32), frame['wcs'], wout)
+    ok = wa > 0
+    err = np.abs(rc - (2.0 * ra - 0.5 * rb))[ok]
+    assert err.max() < 2e-5 * (np.abs(ra[ok]).max() + 200.0)
+    # constant in, constant out (unit-sum taps)
+    one, _, _ = engine.resample(np.ones((NY, NX), np.float32), frame['wcs'], wout)
+    np.testing.assert_allclose(one[ok], 1.0, rtol=3e-6)
+
+
+def test_coadd_of_identical_frames_is_the_frame(engine, frame):
+    z = pkg()
+    p = z.coadd_params(combine='CLIPPED', subtract_back=False, rescale_weights=False)
+    frames = [frame] * 6
+    o, ow, om, omw = engine.coadd(frames, frame['wcs'], p)
+    inner = (slice(2, -3), slice(2, -3))
+    good = frame['wgt'][inner] > 0
+    np.testing.assert_allclose(o[inner][good], frame['img'][inner][good], rtol=3e-6)
+    np.testing.assert_allclose(ow[inner][good], 6 * frame['wgt'][inner][good], rtol=3e-6)
+    assert np.array_equal(om[inner], frame['mask'][inner])       # AND of identical masks
+    assert (omw[inner] == 1).all()
+
+
+def test_clipped_coadd_is_immune_to_single_frame_outliers(engine, frame):
+    z = pkg()
+    s = synth()
+    rng = np.random.default_rng(8)
+    frames, dirty = [], []
+    for i in range(5):
+        w = s.ztf_wcs(NX, NY, dx=rng.uniform(-8, 8), dy=rng.uniform(-8, 8), rot_deg=rng.uniform(-0.05, 0.05))
+        f = dict(frame, wcs=w)
+        frames.append(f)
+    hit = dict(frames[2])
+    im = hit['img'].copy()
+    yy, xx = rng.integers(50, NY - 50, 400), rng.integers(50, NX - 50, 400)
+    im[yy, xx] += 30000.0                      # 400 cosmic-ray like hits in one frame
+    hit['img'] = im
+    dirty = frames[:2] + [hit] + frames[3:]
+    p = z.coadd_params(combine='CLIPPED', subtract_back=False, rescale_weights=False)
+    clean = engine.coadd(frames, frame['wcs'], p, want_mask=False)[0]
+    got = engine.coadd(dirty, frame['wcs'], p, want_mask=False)[0]
+    # the five frames show different sky (same pixels through different WCS), so the
+    # outlier is 30000 over a spread of a few sigma: always clipped
+    assert np.abs(got - clean).max() < 60.0
+    pw = z.coadd_params(combine='WEIGHTED', subtract_back=False, rescale_weights=False)
+    assert np.abs(engine.coadd(dirty, frame['wcs'], pw, want_mask=False)[0] - clean).max() > 1000.0
+
+
+def test_background_plus_residual_is_the_image(engine, frame):
+    bkg, rms, sub, stats = engine.background(frame['img'], frame['wgt'], mesh=128)
+    np.testing.assert_allclose(bkg + sub, frame['img'], rtol=2e-7, atol=2e-4)   # fp32 round trip
+    assert abs(stats[0] - 200.0) < 0.3 and abs(stats[1] - 6.0) < 0.2
+    assert np.abs(bkg - 200.0).max() < 2.5 and np.abs(rms - 6.0).max() < 1.0
+
+
+def test_median_mad_is_exact_on_nine_megapixels(engine, frame):
+    med, mad = engine.median_mad(frame['img'], frame['mask'])
+    pix = frame['img'][frame['mask'] == 0]
+    rmed = np.median(pix)
+    assert med == float(rmed)
+    assert abs(mad - 1.4826 * np.median(np.abs(pix - rmed))) < 1e-6
+
+
+def test_subtracting_a_convolved_scaled_copy_leaves_nothing(engine, frame):
+    # sci = 1.7 (ref (x) Gaussian) + 25, both noise free: the kernel basis can represent
+    # it, so the residual is small everywhere, the kernel sum is the flux ratio and the
+    # fill pattern is the bad-pixel map grown by the kernel half width
+    from scipy.ndimage import gaussian_filter
+    s = synth()
+    xs, ys, fl = frame['stars']
+    ref = np.full((NY, NX), 200.0)
+    s.add_stars(ref, xs, ys, fl, 2.1)
+    sci = (1.7 * gaussian_filter(ref, 0.9, mode='nearest') + 25.0).astype(np.float32)
+    ref = ref.astype(np.float32)
+    bpm = ((frame['mask'] & 198589) > 0).astype(np.uint8)
+    rms = np.full((NY, NX), 6.0, np.float32)
+    kw = dict(r=5.0, rss=12.0, nsx=10, nsy=10, nrx=3, nry=3, ko=2, bgo=0, tu=1e6, iu=1e6,
+              tl=-1e3, il=-1e3)
+    d, n, info = engine.subtract(sci, rms, ref, rms, bpm, **kw)
+    assert info['status'] == 0 and info['nstamps_used'] > 100
+    assert abs(info['kernel_sum'] - 1.7) < 1e-3
+    hw = 5
+    grown = maximum_filter(bpm, size=2 * hw + 1, mode='constant', cval=0).astype(bool)
+    grown[:hw] = grown[-hw:] = True
+    grown[:, :hw] = grown[:, -hw:] = True
+    assert np.array_equal(d == np.float32(1e-30), grown)
+    good = ~grown
+    assert np.abs(d[good]).max() < 5e-3 * np.abs(sci).max()
+    assert np.abs(d[good]).mean() < 0.05
+    # noise = sqrt(6^2 + 6^2 sum K^2), K = 1.7 x Gaussian(sigma 0.9): sum K^2 = 1.7^2 / (4 pi 0.81)
+    expect = 6.0 * np.sqrt(1 + 1.7 ** 2 / (4 * np.pi * 0.81))
+    assert abs(np.median(n[good]) - expect) < 0.15
+    assert np.all(n[grown] == np.float32(np.sqrt(50000.0)))
