@@ -114,11 +114,12 @@ class WCS(object):
         return (x - (1 - origin)).reshape(shp), (y - (1 - origin)).reshape(shp)
 
     def calc_footprint(self):
-        """Sky positions of the four pixel corners, as astropy's
-        ``calc_footprint`` (used by ``zuds/fitsfile.py:247``)."""
+        """Sky positions of the centres of the four corner pixels, in the order
+        and with the ``center=True`` default of astropy's ``calc_footprint``
+        (used by ``zuds/fitsfile.py:247``; pinned by tests/golden/astropy_wcs.json)."""
         nx, ny = self.naxis
-        xs = np.array([0.5, 0.5, nx + 0.5, nx + 0.5])
-        ys = np.array([0.5, ny + 0.5, ny + 0.5, 0.5])
+        xs = np.array([1.0, 1.0, nx, nx], dtype=np.float64)
+        ys = np.array([1.0, ny, ny, 1.0], dtype=np.float64)
         ra, dec = self.all_pix2world(xs, ys, 1)
         return np.stack([ra, dec], axis=1)
 
