@@ -183,6 +183,12 @@ int zm_median_mad(zm_ctx* ctx, const float* img, const int32_t* mask, int64_t n,
                   double* out_median, double* out_mad_sigma);
 int zm_median_mad_dev(zm_ctx* ctx, const float* img, const int32_t* mask,
                       int64_t n, double* out_median, double* out_mad_sigma);
+/* The two estimates prepare_hotpants needs (science and aligned reference,
+ * zuds/hotpants.py:65-67) in one set of launches: out4 = {median_a, mad_a,
+ * median_b, mad_b}.  Both images have n pixels. */
+int zm_median_mad2_dev(zm_ctx* ctx, const float* img_a, const int32_t* mask_a,
+                       const float* img_b, const int32_t* mask_b, int64_t n,
+                       double* out4);
 
 /* ---- forced aperture photometry ------------------------------------------- */
 /* Replaces photutils.aperture_photometry(method='exact') + the bounding-box flag

@@ -162,6 +162,16 @@ def test_median_mad_matches_numpy(engine):
         assert abs(mad - rmad) <= 1e-6 * max(rmad, 1e-30), (n, mad, rmad)
     med, mad = engine.median_mad(np.array([[-3.0, 5.0], [1.0, -0.0]], np.float32))
     assert med == 0.5 and abs(mad - 1.4826 * 2.0) < 1e-6
+    # the two middle ranks of an even count in different top-level bins (-1 | +2), NaNs
+    # skipped, constant arrays, sign changes, no mask
+    for arr in ([-1.0, -1.0, 2.0, 2.0], [np.nan, 4.0, np.nan, -2.0, 1e30, -1e30],
+                [7.25] * 1001, [-5.0, -4.0, -3.0, 0.0, 1e-38, 3.0], list(np.linspace(-1, 1, 4096))):
+        a = np.array(arr, np.float32)
+        med, mad = engine.median_mad(a)
+        pix = a[~np.isnan(a)]
+        rmed = np.median(pix)
+        assert med == float(rmed), (arr[:6], med, rmed)
+        assert mad == pytest.approx(1.4826 * float(np.median(np.abs(pix - rmed))), rel=1e-7, abs=0)
     z = pkg()
     with pytest.raises(z.ZMError):
         engine.median_mad(np.ones(4, np.float32), np.ones(4, np.int32))

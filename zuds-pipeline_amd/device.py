@@ -185,11 +185,11 @@ class DeviceSubtraction(object):
                                     C.byref(self.wsci), LAN, 1.0, self.refrms_al.data_ptr(),
                                     self.refrms_al_w.data_ptr(), None), 'align ref rms')
             # quick_background_estimate x 2 (hotpants.py:65-67)
-            m1, s1, m2, s2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
-            check(L.zm_median_mad_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(), self.n,
-                                      C.byref(m1), C.byref(s1)), 'sci bkg')
-            check(L.zm_median_mad_dev(ctx, self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
-                                      self.n, C.byref(m2), C.byref(s2)), 'ref bkg')
+            mm = (C.c_double * 4)()
+            check(L.zm_median_mad2_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
+                                       self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
+                                       self.n, mm), 'sci / ref bkg')
+            m1, s1, m2, s2 = (C.c_double(v) for v in mm)
             kw = dict(hotpants_kws or {})
             kw.setdefault('bgo', 0)
             kw.setdefault('ko', 4)
