@@ -18,6 +18,7 @@ SOURCES = ['ctx.hip', 'wcs_host.hip', 'resample.hip', 'combine.hip',
            'background.hip', 'api_coadd.hip', 'hotpants.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']
+EXTRA_FLAGS = {}     # per-source additions, e.g. {'x.hip': ['-mllvm', '...']}
 
 
 def _hipcc():
@@ -49,7 +50,7 @@ def build(force=False, verbose=True):
         o = objdir / (s.stem + '.o')
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', str(s), '-o', str(o)]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', str(s), '-o', str(o)]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

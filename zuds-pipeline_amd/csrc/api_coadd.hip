@@ -78,56 +78,34 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     }
     double2* lat = nullptr;
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
-    for (int i = 0; i < n; ++i)
-        ZM_TRY(zm_launch_lattice(ctx, &mp_host[i], lnx, lny, lat + (size_t)i * lnx * lny));
 
-    // Background statistics can run on the auxiliary stream (one event per frame) while
-    // prep + resample follow on the main stream.  Measured on MI355X the two kinds of
-    // kernel only time-share the CUs (29.8 vs 30.5 ms per 32-frame step) and the per-kernel
-    // timings stop being attributable, so the overlap is opt-in (ZM_OVERLAP=1).
-    // NB with overlap the shared prep buffer is still ordered: prep(i) runs on the main stream.
+    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat));
+
+    // One stream, frame by frame: stats(i) filter(i) prep(i) resample(i), so that prep re-reads
+    // the frame while it is still in the Infinity Cache.  (Tried on MI355X: the filter and the
+    // lattices on a second stream, software-pipelined against the neighbouring frames.  The
+    // persistent resample kernel partitions its tiles statically, so two foreign workgroups
+    // on its CUs stretch it by a quarter, and issuing stats(i + 1) ahead of prep(i) costs the
+    // cache residency: no gain over a filter that is simply fast.)
     const float wthresh = (float)P->weight_thresh;
-    static const bool overlap = getenv("ZM_OVERLAP") && atoi(getenv("ZM_OVERLAP")) != 0;
-    hipEvent_t* ev = nullptr;
     float* vs_all = nullptr;
-    bool any_bk = false;
-    for (int i = 0; i < n; ++i) any_bk |= (P->subtract_back || (P->rescale_weights && fr[i].wgt));
-    hipStream_t main_stream = ctx->stream;
-    if (any_bk) {
-        ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&vs_all));
-        if (overlap) {
-            ZM_TRY(zm_get_sync_events(ctx, n + 1, &ev));
-            ZM_HIP(hipEventRecord(ev[n], main_stream));
-            ZM_HIP(hipStreamWaitEvent(ctx->aux, ev[n], 0));
-        }
-    }
+    ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&vs_all));
     bool first_mask = true;
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1];
         const int spitch = (nx + 1) & ~1;
         float *bknodes = nullptr, *vscale = nullptr;
         int nbx = 0, nby = 0;
-        const bool bk = P->subtract_back || (P->rescale_weights && fr[i].wgt);
-        if (bk) {
-            // frame by frame, so that prep re-reads the frame while it is still in
-            // the Infinity Cache
+        if (P->subtract_back || (P->rescale_weights && fr[i].wgt)) {
             const int nmode = (P->rescale_weights && fr[i].wgt) ? 2 : 1;
             float *nodes = nullptr, *bstats = nullptr;
-            ctx->stream = overlap ? ctx->aux : main_stream;    // launchers enqueue on ctx->stream
-            int rc = zm_frame_background(ctx, fr[i].img, fr[i].wgt, nx, ny, P->back_size,
-                                         P->back_filtersize, wthresh, 0, nmode, &nodes, &bstats, &nbx,
-                                         &nby, "cbk", i, n);
-            if (!rc && nmode == 2) {
+            ZM_TRY(zm_frame_background(ctx, fr[i].img, fr[i].wgt, nx, ny, P->back_size,
+                                       P->back_filtersize, wthresh, 0, nmode, &nodes, &bstats, &nbx,
+                                       &nby, "cbk", i, n));
+            if (nmode == 2) {
                 vscale = vs_all + 4 * i;
-                rc = zm_launch_var_scale(ctx, bstats, bstats + 2, vscale);
+                ZM_TRY(zm_launch_var_scale(ctx, bstats, bstats + 2, vscale));
             }
-            if (!rc && overlap && hipEventRecord(ev[i], ctx->aux) != hipSuccess) {
-                zm_set_error("hipEventRecord failed");
-                rc = 1;
-            }
-            ctx->stream = main_stream;
-            if (rc) return rc;
-            if (overlap) ZM_HIP(hipStreamWaitEvent(main_stream, ev[i], 0));
             if (P->subtract_back) bknodes = nodes;
         }
         float2* src = nullptr;

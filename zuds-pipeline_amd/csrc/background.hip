@@ -14,6 +14,8 @@
 // k_mesh_filter  one workgroup: bad-mesh fill, 3x3 median filter, global medians,
 //                natural-spline second derivatives (4 node planes per map).
 // k_bk_expand    per pixel bicubic-spline evaluation (also fused into k_prep).
+#include <algorithm>
+
 #include "zm_internal.h"
 
 #define BK_BIG 1e30f
@@ -599,6 +601,11 @@ __device__ inline void spline_line(const float* a, float* d, float* u, int n, in
 // sigma maps (may hold -BIG); nodes: [mode][2 maps][4 planes][n]; stats: [mode][2]
 // = {median of the filtered mode map, median of the filtered sigma map}.
 // Everything is staged in LDS: the spline recurrences are latency chains.
+// FAST (n <= 1024 meshes, i.e. every ZTF frame at BACK_SIZE >= 96): the two global
+// medians come from one bitonic sort of both maps (55 compare-exchange rounds instead
+// of n^2 rank counting), and the six spline passes of the two maps run as two phases
+// (all y lines, then all x lines) instead of six.
+template <bool FAST>
 __global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ raw_all,
                                                             int nbx, int nby, int fsize,
                                                             float* __restrict__ nodes_all,
@@ -612,8 +619,8 @@ __global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ 
     float* sb1 = sb0 + n;
     float* fb0 = sb1 + n;            // filtered maps
     float* fb1 = fb0 + n;
-    float* tmp = fb1 + n;            // spline scratch
-    float* pl = tmp + n;             // 4 node planes of the current map
+    float* tmp = fb1 + n;            // spline scratch (FAST: 4 n, one per concurrent line set)
+    float* pl = tmp + (FAST ? 4 : 1) * n;   // 4 node planes of the current map (FAST: of both)
     __shared__ int ngood;
     __shared__ float med[4];
     if (tid == 0) ngood = 0;
@@ -686,6 +693,47 @@ __global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ 
         }
     }
     __syncthreads();
+    if (FAST) {
+        // 3. global medians: ascending bitonic sort of both maps, padded to 1024 with +inf
+        float* srt = pl;                                   // 2 x 1024, before pl is needed
+        srt[tid] = tid < n ? fb0[tid] : __builtin_inff();
+        srt[1024 + tid] = tid < n ? fb1[tid] : __builtin_inff();
+        __syncthreads();
+        float* my = srt + (tid >> 9) * 1024;
+        const int i = tid & 511;
+        for (int k = 2; k <= 1024; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int lo = 2 * j * (i / j) + (i % j), hi = lo + j;
+                const float a = my[lo], b = my[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { my[lo] = b; my[hi] = a; }
+                __syncthreads();
+            }
+        if (tid == 0) {
+            stats[0] = 0.5f * (srt[(n - 1) / 2] + srt[n / 2]);
+            stats[1] = 0.5f * (srt[1024 + (n - 1) / 2] + srt[1024 + n / 2]);
+        }
+        __syncthreads();
+        // 4. node planes of both maps: V, DY (along y per column), A (along x of V), B (along x of DY)
+        for (int k = tid; k < n; k += 1024) { pl[k] = fb0[k]; pl[4 * n + k] = fb1[k]; }
+        __syncthreads();
+        for (int e = tid; e < 2 * nbx; e += 1024) {
+            const int m = e / nbx, c = e - m * nbx;
+            float* P = pl + m * 4 * n;
+            spline_line(P + c, P + n + c, tmp + m * n + c, nby, nbx);
+        }
+        __syncthreads();
+        for (int e = tid; e < 4 * nby; e += 1024) {
+            const int m = e / (2 * nby), r = e - m * 2 * nby;
+            const int which = r / nby, row = r - which * nby;
+            float* P = pl + m * 4 * n;
+            spline_line(P + which * n + row * nbx, P + (2 + which) * n + row * nbx,
+                        tmp + (2 * m + which) * n + row * nbx, nbx, 1);
+        }
+        __syncthreads();
+        for (int k = tid; k < 8 * n; k += 1024) nodes[k] = pl[k];
+        return;
+    }
     // 3. global medians by rank counting (exact)
     for (int m = 0; m < 2; ++m) {
         const float* fb = m ? fb1 : fb0;
@@ -769,64 +817,97 @@ __global__ void k_var_scale(const float* __restrict__ bstats, const float* __res
 }
 
 // ---------------------------------------------------------------------------
-// Runs stats + filter for one frame: `nmode` statistics starting at `mode0`
-// (0 = image background, 1 = variance level of 1 / wgt) in one launch each.
-// Node planes [mode][2 maps][4][n] and stats [mode][2] stay on the device in the
-// scratch slots "<slot>_nodes" / "<slot>_stats".
-int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
-                        int mesh, int fsize, float wthresh, int mode0, int nmode,
-                        float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
-                        const char* slot, int index, int count) {
-    ZM_CHECK(mesh >= 8 && mesh <= 4096, "background: BACK_SIZE %d out of range [8, 4096]", mesh);
-    ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
-    ZM_CHECK(nmode >= 1 && mode0 >= 0 && mode0 + nmode <= 2, "background: bad statistic selection");
-    ZM_CHECK(mode0 + nmode < 2 || wgt != nullptr, "background: the variance level needs a weight map");
-    ZM_CHECK(mode0 > 0 || img != nullptr, "background: image is NULL");
+// Background of one frame in two enqueue steps, so that a caller can put the
+// (two-workgroup, latency-bound) filter on another stream than the statistics:
+//   zm_frame_stats   `nmode` statistics starting at `mode0` (0 = image background,
+//                    1 = variance level of 1 / wgt) -> raw mesh maps [mode][2][n]
+//   zm_frame_filter  raw maps -> node planes [mode][2 maps][4][n] and stats [mode][2]
+// Raw maps, node planes and stats are kept per frame (`index` of `count`) in the
+// scratch slots "<slot>_raw" / "<slot>_nodes" / "<slot>_stats"; the histogram dumps
+// are consumed in order on the statistics stream.
+static int frame_slots(zm_ctx* ctx, int nx, int ny, int mesh, const char* slot, int index, int count,
+                       int* nbx_out, int* nby_out, float** raw, float** nodes, float** stats) {
     const int nbx = (nx - 1) / mesh + 1, nby = (ny - 1) / mesh + 1;
     const int n = nbx * nby;
     ZM_CHECK(n <= BK_MAXMESH, "background: %d x %d meshes exceed %d; raise BACK_SIZE", nbx, nby,
              BK_MAXMESH);
     std::string s(slot);
+    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * n * (size_t)count, (void**)raw));
+    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n * (size_t)count, (void**)nodes));
+    ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4 * (size_t)count, (void**)stats));
+    *raw += (size_t)index * 2 * 2 * n;
+    *nodes += (size_t)index * 2 * 8 * n;
+    *stats += (size_t)index * 4;
+    *nbx_out = nbx;
+    *nby_out = nby;
+    return 0;
+}
+
+int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny, int mesh,
+                   float wthresh, int mode0, int nmode, const char* slot, int index, int count) {
+    ZM_CHECK(mesh >= 8 && mesh <= 4096, "background: BACK_SIZE %d out of range [8, 4096]", mesh);
+    ZM_CHECK(nmode >= 1 && mode0 >= 0 && mode0 + nmode <= 2, "background: bad statistic selection");
+    ZM_CHECK(mode0 + nmode < 2 || wgt != nullptr, "background: the variance level needs a weight map");
+    ZM_CHECK(mode0 > 0 || img != nullptr, "background: image is NULL");
+    int nbx, nby;
     float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
-    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * n, (void**)&raw));
-    // nodes / stats are kept per frame (`index` of `count`): a later kernel on another
-    // stream reads them; raw maps and dumps are consumed in order on this stream
-    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n * (size_t)count, (void**)&nodes));
-    ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4 * (size_t)count, (void**)&stats));
-    nodes += (size_t)index * 2 * 8 * n;
-    stats += (size_t)index * 4;
-    const size_t fsh = sizeof(float) * 9 * (size_t)n;
+    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index, count, &nbx, &nby, &raw, &nodes, &stats));
+    const int n = nbx * nby;
     static bool attr_set = false;
     if (!attr_set) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_stats, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(mesh_lds)));
-        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024 - 64));
+        attr_set = true;
+    }
+    zm_scope_timer t(ctx, "mesh_stats");
+    if (mesh <= 128) {
+        const int vec_ok = (mesh % 4 == 0) && (nx % 4 == 0) &&
+                           (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
+        static const int dbg = getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0;
+        mesh_dump* dump = nullptr;
+        ZM_TRY(ctx->get((std::string(slot) + "_dump").c_str(), sizeof(mesh_dump) * 2 * (size_t)n,
+                        (void**)&dump));
+        hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode), dim3(BKF_THREADS, 1, 1),
+                           sizeof(meshf_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
+                           wthresh, mode0, vec_ok, dbg, dump);
+        hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode, 1), dim3(64, 1, 1), 0, ctx->stream,
+                           dump, n, raw);
+    } else {
+        hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, nmode), dim3(BK_THREADS, 1, 1),
+                           sizeof(mesh_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
+                           wthresh, mode0, raw);
+    }
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode, float** nodes_dev,
+                    float** stats_dev, int* nbx_out, int* nby_out, const char* slot, int index,
+                    int count) {
+    ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
+    int nbx, nby;
+    float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
+    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index, count, &nbx, &nby, &raw, &nodes, &stats));
+    const int n = nbx * nby;
+    const bool fast = n <= 1024;
+    // FAST: 4 n maps + 4 n spline scratch + max(8 n planes, 2 x 1024 sort buffer)
+    const size_t fsh = sizeof(float) * (fast ? (size_t)8 * n + std::max(8 * n, 2048) : (size_t)9 * n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_set = true;
     }
     {
-        zm_scope_timer t(ctx, "mesh_stats");
-        if (mesh <= 128) {
-            const int vec_ok = (mesh % 4 == 0) && (nx % 4 == 0) &&
-                               (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
-            mesh_dump* dump = nullptr;
-            ZM_TRY(ctx->get((s + "_dump").c_str(), sizeof(mesh_dump) * 2 * (size_t)n, (void**)&dump));
-            hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode), dim3(BKF_THREADS, 1, 1),
-                               sizeof(meshf_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
-                               wthresh, mode0, vec_ok, getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0, dump);
-            hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode, 1), dim3(64, 1, 1), 0, ctx->stream,
-                               dump, n, raw);
-        } else {
-            hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, nmode), dim3(BK_THREADS, 1, 1),
-                               sizeof(mesh_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
-                               wthresh, mode0, raw);
-        }
-        ZM_HIP(hipGetLastError());
-    }
-    {
         zm_scope_timer t(ctx, "mesh_filter");
-        hipLaunchKernelGGL(k_mesh_filter, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
-                           raw, nbx, nby, fsize, nodes, stats);
+        if (fast)
+            hipLaunchKernelGGL(k_mesh_filter<true>, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
+                               raw, nbx, nby, fsize, nodes, stats);
+        else
+            hipLaunchKernelGGL(k_mesh_filter<false>, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
+                               raw, nbx, nby, fsize, nodes, stats);
         ZM_HIP(hipGetLastError());
     }
     *nodes_dev = nodes;
@@ -834,6 +915,16 @@ int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
     *nbx_out = nbx;
     *nby_out = nby;
     return 0;
+}
+
+int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
+                        int mesh, int fsize, float wthresh, int mode0, int nmode,
+                        float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
+                        const char* slot, int index, int count) {
+    ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
+    ZM_TRY(zm_frame_stats(ctx, img, wgt, nx, ny, mesh, wthresh, mode0, nmode, slot, index, count));
+    return zm_frame_filter(ctx, nx, ny, mesh, fsize, nmode, nodes_dev, stats_dev, nbx_out, nby_out,
+                           slot, index, count);
 }
 
 int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out) {

@@ -40,6 +40,39 @@ __global__ void k_lattice(const zm_map_params mp, int lnx, int lny, double2* __r
     lat[(size_t)gy * lnx + gx] = make_double2(xi - 1.0, yi - 1.0);
 }
 
+// every frame of a stack in one launch: blockIdx.z = frame, maps read from device memory
+__global__ void k_lattice_batch(const zm_map_params* __restrict__ mps, int lnx, int lny,
+                                double2* __restrict__ lat) {
+    int gx = blockIdx.x * blockDim.x + threadIdx.x;
+    int gy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (gx >= lnx || gy >= lny) return;
+    const zm_map_params* mp = mps + blockIdx.z;
+    double xi, yi;
+    zm_map_out_to_in(&mp->wout, &mp->win, mp->rot, 1.0 + (double)gx * LSTEP,
+                     1.0 + (double)gy * LSTEP, &xi, &yi);
+    lat[((size_t)blockIdx.z * lny + gy) * lnx + gx] = make_double2(xi - 1.0, yi - 1.0);
+}
+
+// mp_host: n maps (any host memory); staged through a pinned buffer guarded by an event, so
+// that a later call cannot overwrite the staging area of a copy still in flight
+int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, int lnx, int lny,
+                            double2* lat_dev) {
+    zm_map_params *pin = nullptr, *dev = nullptr;
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 1, &ev));
+    ZM_HIP(hipEventSynchronize(ev[0]));
+    ZM_TRY(ctx->get_pinned("map_params_h", sizeof(zm_map_params) * (size_t)n, (void**)&pin));
+    ZM_TRY(ctx->get("map_params", sizeof(zm_map_params) * (size_t)n, (void**)&dev));
+    memcpy(pin, mp_host, sizeof(zm_map_params) * (size_t)n);
+    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_map_params) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    ZM_HIP(hipEventRecord(ev[0], ctx->stream));
+    dim3 blk(16, 16, 1), grd(zm_div_up(lnx, 16), zm_div_up(lny, 16), n);
+    zm_scope_timer t(ctx, "lattice");
+    hipLaunchKernelGGL(k_lattice_batch, grd, blk, 0, ctx->stream, dev, lnx, lny, lat_dev);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
 int zm_launch_lattice(zm_ctx* ctx, const zm_map_params* mp, int lnx, int lny, double2* lat_dev) {
     dim3 blk(16, 16, 1), grd(zm_div_up(lnx, 16), zm_div_up(lny, 16), 1);
     zm_scope_timer t(ctx, "lattice");

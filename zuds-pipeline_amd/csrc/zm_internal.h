@@ -94,6 +94,8 @@ double zm_pixel_area(const zm_wcs* w, double x, double y);
 
 // kernels / launchers (each in its own .hip)
 int zm_launch_lattice(zm_ctx* ctx, const zm_map_params* mp, int lnx, int lny, double2* lat_dev);
+int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, int lnx, int lny,
+                            double2* lat_dev);
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh,
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch);
@@ -101,6 +103,11 @@ int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
                         const char* slot, int index = 0, int count = 1);
+int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny, int mesh,
+                   float wthresh, int mode0, int nmode, const char* slot, int index, int count);
+int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode, float** nodes_dev,
+                    float** stats_dev, int* nbx_out, int* nby_out, const char* slot, int index,
+                    int count);
 int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out);
 int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out);
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
