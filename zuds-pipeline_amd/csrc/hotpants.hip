@@ -28,6 +28,7 @@
 #define HP_MAXPOLY 28     // (ko + 1)(ko + 2) / 2 for ko <= 6
 #define HP_MAXNSS 8
 #define HP_MAXREG 64
+#define CF_BAR_STRIDE 32                // one k_chol_fused barrier counter per region, 128 B apart
 #define HP_MAXF1 32       // distinct 1-D filters
 #define CH_NB 32
 #define HP_RIDGE 1e-10
@@ -411,9 +412,10 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
 }
 
 __global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ rhs,
-                           const double* __restrict__ d) {
+                           const double* __restrict__ d, unsigned* __restrict__ bar) {
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
+    if (c1 == 0 && c2 == 0) { bar[reg * CF_BAR_STRIDE] = 0; bar[reg * CF_BAR_STRIDE + 1] = 0; }   // arms k_chol_fused's barrier
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
     double* Ar = A + (size_t)reg * (size_t)(n + 1) * n;
@@ -569,6 +571,216 @@ __global__ __launch_bounds__(256) void k_chol_update(int n, int k0, double* __re
         }
 }
 
+// ---- the whole factorisation in one launch ----------------------------------------
+// W workgroups per region walk the 32-column blocks together; a region-wide barrier (a
+// monotone counter in global memory, agent-scope release / acquire) separates the panel
+// solve from the trailing update and the update from the next panel.  Replaces 2 launches
+// per block (45 for 722 unknowns) whose cost was launch latency, not arithmetic.
+// Launched cooperatively: every workgroup is resident, and every workgroup reaches every
+// barrier (the loop bounds depend on n only).
+// All traffic on the shared matrix goes through agent-scope relaxed atomics (sc1 loads and
+// write-through stores, served at the memory side of the per-XCD L2s), so the barrier needs
+// no cache maintenance: an agent-scope release / acquire pair would write back and
+// invalidate the whole L2 twice per step (measured: 3.5 x slower than separate launches).
+__device__ inline double ld_sh(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void st_sh(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ctr[0]: arrivals (monotone); ctr[1]: set when a workgroup gave up waiting (the launch is
+// sized to be fully resident, so this only happens when something else holds the GPU).
+// The wait is bounded: no hang, the factorisation is reported as failed instead.
+#define CF_SPIN_LIMIT (1 << 16)
+__device__ inline bool region_barrier(unsigned* ctr, unsigned target) {
+    __shared__ int dead;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are done
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, d = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > CF_SPIN_LIMIT || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = 1;
+                break;
+            }
+        }
+        dead = d;
+    }
+    __syncthreads();
+    return dead != 0;
+}
+
+// A: [reg][(n + 1)][n]; Dg: [reg][32][33] published diagonal factors.
+// Step k:  every workgroup reads the factored diagonal block (published by workgroup 0),
+//          solves its slice of the panel rows (one thread per row)            | barrier
+//          trailing update on 64 x 64 tiles with the f64 matrix cores; workgroup 0 takes
+//          only the first tile, which holds the next diagonal block, factors it (one wave,
+//          registers) and publishes it while the others finish their tiles    | barrier
+__global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, double* Dgall, int* fail,
+                                                    unsigned* bar, long long* prof) {
+    __shared__ double D[CH_NB][CH_NB + 1];
+    __shared__ double Li[64][CH_NB + 2];        // pitch 34: conflict-free ds_read_b64 of MFMA operands
+    __shared__ double Lj[64][CH_NB + 2];
+    const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
+    double* A = Aall + (size_t)reg * (size_t)(n + 1) * n;
+    double* Dg = Dgall + (size_t)reg * CH_NB * (CH_NB + 1);
+    unsigned* ctr = bar + reg * CF_BAR_STRIDE;
+    const int tid = threadIdx.x;
+    const int nrows = n + 1;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    unsigned gen = 0;
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // phase clocks (100 MHz), prof != NULL only
+#define CF_TICK(k) do { if (prof) { long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
+    if (prof) tc = wall_clock64();
+    // factor the diagonal block held (unfactored, lower triangle) in D; publish it
+    auto factor_and_publish = [&](int k0, int nb) {
+        __syncthreads();
+        if (tid < 64) chol_diag_wave(D, nb, &fail[reg]);
+        __syncthreads();
+        for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) st_sh(&Dg[e], D[e / (CH_NB + 1)][e % (CH_NB + 1)]);
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            const int i = e >> 5, j = e & 31;
+            if (i < nb && j <= i) st_sh(&A[(size_t)(k0 + i) * n + k0 + j], D[i][j]);
+        }
+    };
+    auto load_diag_raw = [&](int k0, int nb) {
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            const int i = e >> 5, j = e & 31;
+            D[i][j] = (i < nb && j <= i && j < nb) ? ld_sh(&A[(size_t)(k0 + i) * n + k0 + j]) : (i == j ? 1.0 : 0.0);
+        }
+    };
+    if (w == 0) {
+        load_diag_raw(0, min(CH_NB, n));
+        factor_and_publish(0, min(CH_NB, n));
+    }
+    gen += W;
+    bool dead = region_barrier(ctr, gen);
+    for (int kb = 0; kb < nblk && !dead; ++kb) {
+        const int k0 = kb * CH_NB;
+        const int nb = min(CH_NB, n - k0);
+        // (a) + (b): the published factor and this thread's panel row in one memory latency
+        const int below = nrows - k0 - nb;
+        const int per = (below + W - 1) / W;
+        const int pend = min((w + 1) * per, below);
+        const int p0 = w * per + tid;
+        double x[CH_NB];
+        if (p0 < pend) {
+            const double* ar = A + (size_t)(k0 + nb + p0) * n + k0;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ld_sh(&ar[j]) : 0.0;
+        }
+        __syncthreads();                                         // D of the previous step is consumed
+        for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
+        __syncthreads();
+        CF_TICK(0);
+        for (int p = p0; p < pend; p += 256) {
+            double* ar = A + (size_t)(k0 + nb + p) * n + k0;
+            if (p != p0) {
+#pragma unroll
+                for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ld_sh(&ar[j]) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                if (j < nb) {
+                    double v = x[j];
+#pragma unroll
+                    for (int m = 0; m < CH_NB; ++m)
+                        if (m < j) v -= x[m] * D[j][m];
+                    x[j] = v * D[j][CH_NB];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j)
+                if (j < nb) st_sh(&ar[j], x[j]);
+        }
+        if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CF_TICK(2);
+        gen += W;
+        dead = region_barrier(ctr, gen);
+        CF_TICK(3);
+        if (dead) break;
+        // (c) trailing update A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle.
+        // Tile 0 (the next diagonal block in its corner) belongs to workgroup 0 alone.
+        const int t0 = k0 + CH_NB;
+        const int T = (below + 63) / 64;
+        const int ntile = T * (T + 1) / 2;
+        const int Wu = W > 1 ? W - 1 : 1;                        // workgroups sharing tiles 1 ..
+        const int tfirst = (W == 1) ? 0 : (w == 0 ? 0 : w);      // w >= 1 starts at tile w
+        const int tstep = (W == 1) ? 1 : (w == 0 ? ntile : Wu);
+        for (int t = tfirst; t < ntile; t += tstep) {
+            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            const int i0 = t0 + ti * 64, j0 = t0 + tj * 64;
+            // f64 matrix cores: wave v owns rows 16 v .. 16 v + 15 of the tile; C layout of
+            // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.  The tile is
+            // loaded together with the two panels: one memory latency.
+            const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+            double4_t acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                    acc[c][rg] = (i < nrows && j < n && j <= i) ? ld_sh(&A[(size_t)i * n + j]) : 0.0;
+                }
+            __syncthreads();                       // the previous tile's panels are consumed
+            for (int e = tid; e < 64 * CH_NB; e += 256) {
+                const int r = e >> 5, m = e & 31;
+                Li[r][m] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * n + k0 + m]) : 0.0;
+                Lj[r][m] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * n + k0 + m]) : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                const double a = Li[16 * wave + li][4 * kk + lk];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double b = Lj[16 * c + li][4 * kk + lk];
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                }
+            }
+            if (t == 0) {
+                // the next diagonal block straight from the accumulators into D
+                const int nbn = min(CH_NB, n - t0);
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int i = 16 * wave + lk + 4 * rg, j = 16 * c + li;
+                        if (i < CH_NB) D[i][j] = (i < nbn && j <= i && j < nbn) ? acc[c][rg] : (i == j ? 1.0 : 0.0);
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                    // the corner of tile 0 is stored factored, by factor_and_publish
+                    const bool corner = (t == 0) && i < t0 + min(CH_NB, n - t0);   // j <= i: inside the block
+                    if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * n + j], acc[c][rg]);
+                }
+            if (t == 0) factor_and_publish(t0, min(CH_NB, n - t0));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CF_TICK(4);
+        gen += W;
+        dead = region_barrier(ctr, gen);
+        CF_TICK(5);
+    }
+    if (dead && tid == 0) atomicAdd(&fail[reg], 1);
+    if (prof && tid == 0)
+        for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
+#undef CF_TICK
+}
+
 // Back substitution L^T x = y (y = row n of the factored storage), one workgroup
 // of 1024 threads per region; then x /= d (Jacobi scaling) into xout.
 __global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restrict__ Aall,
@@ -588,13 +800,15 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restr
         __syncthreads();
         {
             const int i = tid >> 5, j = tid & 31;          // 1024 threads = 32 x 32
-            D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+            const double v = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+            D[i][j] = v;
+            if (i == j) D[i][CH_NB] = 1.0 / v;             // 32 divisions side by side, none in the chain
         }
         __syncthreads();
         if (tid < 64) {
             double bi = (tid < nb) ? y[k0 + tid] : 0.0;
             for (int j = nb - 1; j >= 0; --j) {
-                double xj = __shfl(bi, j) / D[j][j];
+                double xj = __shfl(bi, j) * D[j][CH_NB];
                 if (tid == j) bi = xj;
                 else if (tid < j) bi -= D[j][tid] * xj;    // L^T[tid][j] = L[j][tid]
             }
@@ -1010,6 +1224,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
     ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * (3 * HP_MAXREG + 4), (void**)&ibuf));
     int *nrej = ibuf, *ntotal = ibuf + HP_MAXREG, *fail = ibuf + 2 * HP_MAXREG, *nmasked = ibuf + 3 * HP_MAXREG;
+    unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
+    ZM_TRY(ctx->get("hp_cbar", sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG, (void**)&cbar));
+    double* cdg = nullptr;               // published diagonal factors of k_chol_fused
+    ZM_TRY(ctx->get("hp_cdg", sizeof(double) * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));
     ZM_TRY(ctx->get("hp_X", sizeof(double) * (size_t)P.ncell * P.nX * P.npixp, (void**)&X));
     ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
     ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
@@ -1085,16 +1303,42 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, A, rhs);
             hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A, dsc);
             hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A,
-                               rhs, dsc);
-            for (int kb = 0; kb < nblk; ++kb) {
-                const int k0 = kb * CH_NB;
-                const int nb = std::min(CH_NB, P.nunk - k0);
-                const int below = P.nunk + 1 - k0 - nb;            // panel rows incl. the rhs row
-                hipLaunchKernelGGL(k_chol_panel, dim3(std::max(zm_div_up(below, 256), 1), 1, P.nreg), b256, 0,
-                                   st, P.nunk, k0, A, fail);
-                if (below > 0 && nb == CH_NB) {
-                    const int tt = zm_div_up(below, 64);
-                    hipLaunchKernelGGL(k_chol_update, dim3(tt, tt, P.nreg), b256, 0, st, P.nunk, k0, A);
+                               rhs, dsc, cbar);
+            {
+                // one cooperative launch: W workgroups per region, all resident
+                static int coop_cap = 0;                  // resident workgroups the device grants this kernel
+                if (!coop_cap) {
+                    int occ = 0, ncu = 0;
+                    ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
+                    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+                    coop_cap = std::max(1, occ * ncu);
+                    if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
+                }
+                ZM_CHECK(P.nreg <= coop_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, coop_cap);
+                int W = std::max(1, std::min(40, std::min(coop_cap, 400) / P.nreg));
+                int nunk = P.nunk;
+                double* Aarg = A;
+                int* farg = fail;
+                unsigned* barg = cbar;
+                double* dgarg = cdg;
+                // ZM_CHOL_PROF=1: per-phase clocks of every workgroup, printed after the launch
+                static const bool want_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
+                long long* parg = nullptr;
+                if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
+                // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
+                // order against the following launches of the stream on its first use)
+                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, W, Aarg, dgarg, farg, barg, parg);
+                ZM_HIP(hipGetLastError());
+                if (want_prof) {
+                    std::vector<long long> hp((size_t)6 * P.nreg * W);
+                    ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
+                    ZM_HIP(hipStreamSynchronize(st));
+                    static const char* nm[6] = {"load", "-", "panel", "barrier1", "update", "barrier2"};
+                    for (int wg : {0, 1, W - 1, W, (P.nreg - 1) * W}) {
+                        fprintf(stderr, "chol wg %3d:", wg);
+                        for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f us", nm[k], hp[(size_t)wg * 6 + k] * 0.01);
+                        fprintf(stderr, "\n");
+                    }
                 }
             }
             {
