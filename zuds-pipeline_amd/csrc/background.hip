@@ -206,6 +206,7 @@ __device__ inline void histo_prefix(mesh_lds* S) {
 struct meshf_lds {
     int histo[BK_NLEVELS];
     double red[BKF_WAVES];
+    double red3[3][BKF_WAVES];
     long long wsum[3][4];
 };
 
@@ -230,6 +231,26 @@ __device__ inline double blockf_sum(double v, double* red) {
 #pragma unroll
     for (int w = 0; w < BKF_WAVES; ++w) t += red[w];     // fixed order: deterministic
     return t;
+}
+
+// three sums in one pass of barriers; fixed order: deterministic
+__device__ inline void blockf_sum3(double& a, double& b, double& c, double (*red)[BKF_WAVES]) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+        red[2][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    a = b = c = 0.0;
+#pragma unroll
+    for (int w = 0; w < BKF_WAVES; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
 }
 
 __global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const float* __restrict__ img,
@@ -293,74 +314,97 @@ __global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const float* __
         if (a == 12345.f) dump[0].valid = 7;
         return;
     }
-    // ---- pass 1: all valid pixels; variance about the mean (two sweeps over the
-    // registers: exact 0 for a constant mesh, like numpy's var in the oracle)
+    // ---- pivot: some valid pixel of the mesh.  Moments are accumulated about it, in fp64:
+    // (x - K) is exact, a constant mesh gives exactly zero variance (as numpy's two-pass var
+    // in the oracle does) and a nearly flat map loses nothing to cancellation, in one sweep
+    // per clipping pass instead of two.
+    float kf = qnan;
+#pragma unroll
+    for (int k = BKF_PX - 1; k >= 0; --k) kf = (v[k] == v[k]) ? v[k] : kf;
+    {
+        const unsigned long long has = __ballot(kf == kf);
+        const int src = has ? __ffsll((long long)has) - 1 : 0;
+        kf = __shfl(kf, src);                                // first valid value of the wave (or NaN)
+        __syncthreads();
+        if ((tid & 63) == 0) S->red[tid >> 6] = (double)kf;
+        __syncthreads();
+        double kd = __builtin_nan("");
+#pragma unroll
+        for (int w8 = BKF_WAVES - 1; w8 >= 0; --w8) { const double c = S->red[w8]; kd = (c == c) ? c : kd; }
+        kf = (float)kd;
+    }
+    if (!(kf == kf)) {                                       // no valid pixel at all
+        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        return;
+    }
+    const double K = (double)kf;
+    // ---- pass 1: all valid pixels
     double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < BKF_PX; ++k) {
-        float x = v[k];
-        if (x == x) { s0 += 1.0; s1 += x; }
+        const float x = v[k];
+        if (x == x) { const double d = (double)x - K; s0 += 1.0; s1 += d; s2 += d * d; }
     }
-    s0 = blockf_sum(s0, S->red);
-    s1 = blockf_sum(s1, S->red);
+    blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
         if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
         return;
     }
-    double mean = s1 / s0;
-#pragma unroll
-    for (int k = 0; k < BKF_PX; ++k) {
-        float x = v[k];
-        if (x == x) { double dlt = (double)x - mean; s2 += dlt * dlt; }
-    }
-    s2 = blockf_sum(s2, S->red);
-    double var = s2 / s0;
+    double dm = s1 / s0;                                     // mean - K
+    double var = s2 / s0 - dm * dm;
     double sig = var > 0 ? sqrt(var) : 0.0;
-    const double lc = mean - 2.0 * sig, hc = mean + 2.0 * sig;
+    const double lc = K + dm - 2.0 * sig, hc = K + dm + 2.0 * sig;
     // ---- pass 2: 2-sigma clipped
     s0 = s1 = s2 = 0;
 #pragma unroll
     for (int k = 0; k < BKF_PX; ++k) {
-        float x = v[k];
-        if (x == x && x >= lc && x <= hc) { s0 += 1.0; s1 += x; }
+        const float x = v[k];
+        if (x == x && x >= lc && x <= hc) { const double d = (double)x - K; s0 += 1.0; s1 += d; s2 += d * d; }
     }
-    s0 = blockf_sum(s0, S->red);
-    s1 = blockf_sum(s1, S->red);
+    blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < 1.0) {
         if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
         return;
     }
-    mean = s1 / s0;
-#pragma unroll
-    for (int k = 0; k < BKF_PX; ++k) {
-        float x = v[k];
-        if (x == x && x >= lc && x <= hc) { double dlt = (double)x - mean; s2 += dlt * dlt; }
-    }
-    s2 = blockf_sum(s2, S->red);
-    var = s2 / s0;
+    dm = s1 / s0;
+    const double mean = K + dm;
+    var = s2 / s0 - dm * dm;
     sig = var > 0 ? sqrt(var) : 0.0;
     const bk_quant q = make_quant(mean, sig, s0);
     if (dbg == 2) { if (sig == 12345.0) dump[0].valid = 7; return; }
-    // ---- histogram
+    // ---- histogram.  bin = (int)(x / qscale + cste) with a correctly rounded quotient:
+    // y = RN(1 / qscale), q0 = RN(x y), r = RN(x - q0 qscale), q = RN(q0 + r y) is the
+    // correctly rounded x / qscale (Markstein) unless the significand of qscale is all
+    // ones; three instructions instead of the ten of a division.  Consecutive pixels of a
+    // thread that fall into one bin (flat variance maps: all of them) are added at once.
     for (int k = tid; k < BK_NLEVELS; k += BKF_THREADS) S->histo[k] = 0;
     __syncthreads();
+    {
+        const float qinv = 1.0f / q.qscale;
+        const bool slow_div = (__float_as_uint(q.qscale) & 0x7fffffu) == 0x7fffffu;
+        int cur = -1, run = 0;
 #pragma unroll
-    for (int k = 0; k < BKF_PX; ++k) {
-        float x = v[k];
-        int b = -1;
-        if (x == x) b = (int)(x / q.qscale + q.cste);
-        const bool in = b >= 0 && b < q.nlevels;
-        // flat maps (variance planes) put a whole wave into one bin: add once
-        const unsigned long long act = __ballot(in);
-        if (act) {
-            const int first = __ffsll((long long)act) - 1;
-            const int b0 = __shfl(b, first);
-            if (__ballot(in && b == b0) == act) {
-                if ((tid & 63) == first) atomicAdd(&S->histo[b0], __popcll(act));
-            } else if (in) {
-                atomicAdd(&S->histo[b], 1);
+        for (int k = 0; k < BKF_PX; ++k) {
+            const float x = v[k];
+            int b = -1;
+            if (x == x) {
+                float qq;
+                if (slow_div) qq = x / q.qscale;
+                else {
+                    const float q0 = x * qinv;
+                    qq = fmaf(fmaf(-q0, q.qscale, x), qinv, q0);
+                }
+                b = (int)(qq + q.cste);
             }
+            if (!(b >= 0 && b < q.nlevels)) b = -1;
+            if (b != cur) {
+                if (cur >= 0) atomicAdd(&S->histo[cur], run);
+                cur = b;
+                run = 0;
+            }
+            ++run;
         }
+        if (cur >= 0) atomicAdd(&S->histo[cur], run);
     }
     __syncthreads();
     if (dbg == 3) { if (S->histo[tid] == -5) dump[0].valid = 7; return; }
