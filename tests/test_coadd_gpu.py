@@ -177,3 +177,26 @@ def test_background_and_weight_rescale_in_the_coadd(engine):
     # background is gone and the weights are back to the measured variance (3 / 25)
     assert abs(np.median(g_img[both])) < 1.0
     assert abs(np.median(g_wgt[both]) / (3 / 25.0) - 1) < 0.1
+
+
+def test_ragged_stack_with_backgrounds(engine):
+    """Frames of different sizes, one without a weight map: the per-frame background
+    products of a stack live side by side (batched statistics, one slot per frame)."""
+    z = pkg()
+    s = synth()
+    base = s.tan_wcs(320, 300)
+    shapes = [(300, 280), (200, 260), (300, 280), (340, 150)]
+    frames = []
+    for i, (nx, ny) in enumerate(shapes):
+        w = s.tan_wcs(nx, ny, dx=1.5 * i - 3.0, dy=2.0 - 1.25 * i)
+        f = s.make_frame(nx, ny, 70 + i, w, sky=120 + 30 * i, noise=4.0 + i, nstars=20, nbad=30)
+        yy, xx = np.mgrid[0:ny, 0:nx]
+        f['img'] = (f['img'] + 0.03 * xx - 0.02 * yy).astype(np.float32)
+        frames.append(f)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True, back_size=64)
+    g_img, g_wgt, _, _ = engine.coadd(frames, base, p, want_mask=False)
+    r_img, r_wgt, _, _, _ = oracle_coadd(frames, base, 'WEIGHTED', True, True, mesh=64)
+    both = (g_wgt > 0) & (r_wgt > 0)
+    assert ((g_wgt > 0) != (r_wgt > 0)).mean() < 1e-4
+    assert_close_masked(g_img[both], r_img[both], 1e-4, 2e-3, 'ragged coadd', max_bad_frac=1e-4)
+    assert_close_masked(g_wgt[both], r_wgt[both], 2e-3, 0, 'ragged weights', max_bad_frac=1e-4)

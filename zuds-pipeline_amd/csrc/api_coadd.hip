@@ -81,31 +81,52 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
 
     ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat));
 
-    // One stream, frame by frame: stats(i) filter(i) prep(i) resample(i), so that prep re-reads
-    // the frame while it is still in the Infinity Cache.  (Tried on MI355X: the filter and the
-    // lattices on a second stream, software-pipelined against the neighbouring frames.  The
-    // persistent resample kernel partitions its tiles statically, so two foreign workgroups
-    // on its CUs stretch it by a quarter, and issuing stats(i + 1) ahead of prep(i) costs the
-    // cache residency: no gain over a filter that is simply fast.)
+    // Phase 1: mesh statistics, filter and variance rescale of every frame, batched over runs
+    // of equally sized frames (one launch each per run instead of one per frame: the
+    // statistics grid of a single 3072^2 frame is 1152 workgroups against 1024 resident, and
+    // every per-frame launch costs a ~10 us gap).  Phase 2: prep + resample, frame by frame.
+    // (Tried on MI355X and dropped: the filter / lattices on a second stream pipelined
+    // against the neighbouring frames - foreign workgroups on its CUs stretch the statically
+    // partitioned persistent resample kernel by a quarter.)
     const float wthresh = (float)P->weight_thresh;
     float* vs_all = nullptr;
     ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&vs_all));
+    auto has_bk = [&](int i) { return P->subtract_back || (P->rescale_weights && fr[i].wgt); };
+    auto nmode_of = [&](int i) { return (P->rescale_weights && fr[i].wgt) ? 2 : 1; };
+    int nslot = 1;                       // meshes of the largest frame: the scratch slot of every frame
+    for (int i = 0; i < n; ++i)
+        nslot = std::max(nslot, ((fr[i].wcs.naxis[0] - 1) / std::max(P->back_size, 1) + 1) *
+                                    ((fr[i].wcs.naxis[1] - 1) / std::max(P->back_size, 1) + 1));
+    for (int i0 = 0; i0 < n;) {
+        if (!has_bk(i0)) { ++i0; continue; }
+        int i1 = i0 + 1;
+        while (i1 < n && has_bk(i1) && nmode_of(i1) == nmode_of(i0) &&
+               fr[i1].wcs.naxis[0] == fr[i0].wcs.naxis[0] && fr[i1].wcs.naxis[1] == fr[i0].wcs.naxis[1])
+            ++i1;
+        const int nf = i1 - i0, nx = fr[i0].wcs.naxis[0], ny = fr[i0].wcs.naxis[1], nmode = nmode_of(i0);
+        std::vector<const float*> imgs(nf), wgts(nf);
+        for (int f = 0; f < nf; ++f) { imgs[f] = fr[i0 + f].img; wgts[f] = fr[i0 + f].wgt; }
+        ZM_TRY(zm_batch_stats(ctx, nf, imgs.data(), wgts.data(), nx, ny, P->back_size, wthresh, 0, nmode,
+                              "cbk", i0, n, nslot));
+        ZM_TRY(zm_batch_filter(ctx, nf, nx, ny, P->back_size, P->back_filtersize, nmode, "cbk", i0, n, nslot));
+        if (nmode == 2) {
+            float *nodes = nullptr, *bstats = nullptr;
+            int nbx = 0, nby = 0;
+            ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i0, n, nslot, &nodes, &bstats, &nbx, &nby));
+            ZM_TRY(zm_batch_var_scale(ctx, nf, bstats, vs_all + 4 * (size_t)i0));
+        }
+        i0 = i1;
+    }
     bool first_mask = true;
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1];
         const int spitch = (nx + 1) & ~1;
         float *bknodes = nullptr, *vscale = nullptr;
         int nbx = 0, nby = 0;
-        if (P->subtract_back || (P->rescale_weights && fr[i].wgt)) {
-            const int nmode = (P->rescale_weights && fr[i].wgt) ? 2 : 1;
+        if (has_bk(i)) {
             float *nodes = nullptr, *bstats = nullptr;
-            ZM_TRY(zm_frame_background(ctx, fr[i].img, fr[i].wgt, nx, ny, P->back_size,
-                                       P->back_filtersize, wthresh, 0, nmode, &nodes, &bstats, &nbx,
-                                       &nby, "cbk", i, n));
-            if (nmode == 2) {
-                vscale = vs_all + 4 * i;
-                ZM_TRY(zm_launch_var_scale(ctx, bstats, bstats + 2, vscale));
-            }
+            ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i, n, nslot, &nodes, &bstats, &nbx, &nby));
+            if (nmode_of(i) == 2) vscale = vs_all + 4 * (size_t)i;
             if (P->subtract_back) bknodes = nodes;
         }
         float2* src = nullptr;

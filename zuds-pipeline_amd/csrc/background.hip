@@ -253,15 +253,24 @@ __device__ inline void blockf_sum3(double& a, double& b, double& c, double (*red
     for (int w = 0; w < BKF_WAVES; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
 }
 
-__global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const float* __restrict__ img,
-                                                                 const float* __restrict__ wgt,
+// up to BK_BATCH equally sized frames per launch: blockIdx.z = frame * nmode + statistic
+#define BK_BATCH 64
+struct bk_batch {
+    const float* img[BK_BATCH];
+    const float* wgt[BK_BATCH];
+};
+
+__global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const bk_batch B, int nmode,
                                                                  int nx, int ny, int mesh, int nbx,
                                                                  int nby, float wthresh, int mode0,
                                                                  int vec_ok, int dbg,
                                                                  mesh_dump* __restrict__ dump) {
     extern __shared__ char smem_raw[];
     meshf_lds* S = reinterpret_cast<meshf_lds*>(smem_raw);
-    const int mode = mode0 + blockIdx.z;
+    const int frame = blockIdx.z / nmode;
+    const int mode = mode0 + (blockIdx.z - frame * nmode);
+    const float* __restrict__ img = B.img[frame];
+    const float* __restrict__ wgt = B.wgt[frame];
     const int mi = blockIdx.x, mj = blockIdx.y;
     const int x0 = mi * mesh, y0 = mj * mesh;
     const int w = min(mesh, nx - x0), h = min(mesh, ny - y0);
@@ -457,14 +466,15 @@ __global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const float* __
 }
 
 // One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
-__global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__ dump, int n,
-                                                   float* __restrict__ raw) {
+__global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__ dump, int n, int nmode,
+                                                   int nslot, float* __restrict__ raw) {
     __shared__ int P0[BK_NLEVELS];
     __shared__ long long B1[BK_THREADS];
     __shared__ long long B2[BK_THREADS];
-    const int m = blockIdx.x, mode = blockIdx.y, lane = threadIdx.x;
-    const mesh_dump* D = dump + (size_t)mode * n + m;
-    float* ob = raw + (size_t)mode * 2 * n + m;
+    const int m = blockIdx.x, z = blockIdx.y, lane = threadIdx.x;
+    const int frame = z / nmode, mode = z - frame * nmode;
+    const mesh_dump* D = dump + (size_t)z * n + m;
+    float* ob = raw + (size_t)frame * 4 * nslot + (size_t)mode * 2 * n + m;   // raw: [frame: 4 nslot][statistic][2 maps][n]
     float* os = ob + n;
     if (!D->valid) {
         if (lane == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
@@ -651,14 +661,16 @@ __device__ inline void spline_line(const float* a, float* d, float* u, int n, in
 // (all y lines, then all x lines) instead of six.
 template <bool FAST>
 __global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ raw_all,
-                                                            int nbx, int nby, int fsize,
+                                                            int nbx, int nby, int fsize, int nmode, int nslot,
                                                             float* __restrict__ nodes_all,
                                                             float* __restrict__ stats_all) {
     extern __shared__ float mf_smem[];
     const int n = nbx * nby, tid = threadIdx.x;
-    const float* raw = raw_all + (size_t)blockIdx.x * 2 * n;
-    float* nodes = nodes_all + (size_t)blockIdx.x * 8 * n;
-    float* stats = stats_all + blockIdx.x * 2;
+    // blockIdx.x = frame * nmode + statistic; per-frame strides hold two statistics
+    const int frame = blockIdx.x / nmode, zm = blockIdx.x - frame * nmode;
+    const float* raw = raw_all + (size_t)frame * 4 * nslot + (size_t)zm * 2 * n;
+    float* nodes = nodes_all + (size_t)frame * 16 * nslot + (size_t)zm * 8 * n;
+    float* stats = stats_all + ((size_t)frame * 2 + zm) * 2;
     float* sb0 = mf_smem;            // filled maps
     float* sb1 = sb0 + n;
     float* fb0 = sb1 + n;            // filtered maps
@@ -860,6 +872,14 @@ __global__ void k_var_scale(const float* __restrict__ bstats, const float* __res
     out[0] = (level > 0.f && backsig > 0.f) ? backsig * backsig / level : 1.f;
 }
 
+// stats: [frame][{backmean, backsig, varlevel, varsig}]; out: [frame][4]
+__global__ void k_var_scale_batch(const float* __restrict__ stats, float* __restrict__ out, int nf) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const float backsig = stats[4 * f + 1], level = stats[4 * f + 2];
+    out[4 * f] = (level > 0.f && backsig > 0.f) ? backsig * backsig / level : 1.f;
+}
+
 // ---------------------------------------------------------------------------
 // Background of one frame in two enqueue steps, so that a caller can put the
 // (two-workgroup, latency-bound) filter on another stream than the statistics:
@@ -869,34 +889,45 @@ __global__ void k_var_scale(const float* __restrict__ bstats, const float* __res
 // Raw maps, node planes and stats are kept per frame (`index` of `count`) in the
 // scratch slots "<slot>_raw" / "<slot>_nodes" / "<slot>_stats"; the histogram dumps
 // are consumed in order on the statistics stream.
+// Frame `index` of `count` owns a slot of `nslot` meshes (>= its own mesh count; the largest
+// of a ragged stack) in each scratch buffer, so that every frame's products can coexist.
 static int frame_slots(zm_ctx* ctx, int nx, int ny, int mesh, const char* slot, int index, int count,
-                       int* nbx_out, int* nby_out, float** raw, float** nodes, float** stats) {
+                       int nslot, int* nbx_out, int* nby_out, float** raw, float** nodes, float** stats) {
     const int nbx = (nx - 1) / mesh + 1, nby = (ny - 1) / mesh + 1;
     const int n = nbx * nby;
     ZM_CHECK(n <= BK_MAXMESH, "background: %d x %d meshes exceed %d; raise BACK_SIZE", nbx, nby,
              BK_MAXMESH);
+    if (nslot < n) nslot = n;
     std::string s(slot);
-    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * n * (size_t)count, (void**)raw));
-    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * n * (size_t)count, (void**)nodes));
+    ZM_TRY(ctx->get((s + "_raw").c_str(), sizeof(float) * 2 * 2 * nslot * (size_t)count, (void**)raw));
+    ZM_TRY(ctx->get((s + "_nodes").c_str(), sizeof(float) * 2 * 8 * nslot * (size_t)count, (void**)nodes));
     ZM_TRY(ctx->get((s + "_stats").c_str(), sizeof(float) * 4 * (size_t)count, (void**)stats));
-    *raw += (size_t)index * 2 * 2 * n;
-    *nodes += (size_t)index * 2 * 8 * n;
+    *raw += (size_t)index * 2 * 2 * nslot;
+    *nodes += (size_t)index * 2 * 8 * nslot;
     *stats += (size_t)index * 4;
     *nbx_out = nbx;
     *nby_out = nby;
     return 0;
 }
 
-int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny, int mesh,
-                   float wthresh, int mode0, int nmode, const char* slot, int index, int count) {
+// nf equally sized frames (slots index0 .. index0 + nf - 1 of `count`) per call; launches
+// carry up to BK_BATCH frames each, so a 32-deep stack is 1 + 1 launches instead of 64 and
+// the statistics grid (1152 workgroups per frame against 1024 resident) loses its tail.
+int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* const* wgts, int nx,
+                   int ny, int mesh, float wthresh, int mode0, int nmode, const char* slot, int index0,
+                   int count, int nslot) {
     ZM_CHECK(mesh >= 8 && mesh <= 4096, "background: BACK_SIZE %d out of range [8, 4096]", mesh);
     ZM_CHECK(nmode >= 1 && mode0 >= 0 && mode0 + nmode <= 2, "background: bad statistic selection");
-    ZM_CHECK(mode0 + nmode < 2 || wgt != nullptr, "background: the variance level needs a weight map");
-    ZM_CHECK(mode0 > 0 || img != nullptr, "background: image is NULL");
+    ZM_CHECK(nf >= 1 && index0 >= 0 && index0 + nf <= count, "background: bad frame range");
+    for (int f = 0; f < nf; ++f) {
+        ZM_CHECK(mode0 + nmode < 2 || wgts[f] != nullptr, "background: the variance level needs a weight map");
+        ZM_CHECK(mode0 > 0 || imgs[f] != nullptr, "background: image is NULL");
+    }
     int nbx, nby;
     float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
-    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index, count, &nbx, &nby, &raw, &nodes, &stats));
+    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index0, count, nslot, &nbx, &nby, &raw, &nodes, &stats));
     const int n = nbx * nby;
+    if (nslot < n) nslot = n;
     static bool attr_set = false;
     if (!attr_set) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_stats, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -905,34 +936,44 @@ int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
     }
     zm_scope_timer t(ctx, "mesh_stats");
     if (mesh <= 128) {
-        const int vec_ok = (mesh % 4 == 0) && (nx % 4 == 0) &&
-                           (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
         static const int dbg = getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0;
-        mesh_dump* dump = nullptr;
-        ZM_TRY(ctx->get((std::string(slot) + "_dump").c_str(), sizeof(mesh_dump) * 2 * (size_t)n,
-                        (void**)&dump));
-        hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode), dim3(BKF_THREADS, 1, 1),
-                           sizeof(meshf_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
-                           wthresh, mode0, vec_ok, dbg, dump);
-        hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode, 1), dim3(64, 1, 1), 0, ctx->stream,
-                           dump, n, raw);
+        for (int f0 = 0; f0 < nf; f0 += BK_BATCH) {
+            const int nb = std::min(BK_BATCH, nf - f0);
+            bk_batch B;
+            memset(&B, 0, sizeof(B));
+            int vec_ok = (mesh % 4 == 0) && (nx % 4 == 0);
+            for (int f = 0; f < nb; ++f) {
+                B.img[f] = imgs[f0 + f];
+                B.wgt[f] = wgts[f0 + f];
+                if (((uintptr_t)B.img[f] & 15) || ((uintptr_t)B.wgt[f] & 15)) vec_ok = 0;
+            }
+            mesh_dump* dump = nullptr;
+            ZM_TRY(ctx->get((std::string(slot) + "_dump").c_str(),
+                            sizeof(mesh_dump) * 2 * (size_t)n * std::min(nf, BK_BATCH), (void**)&dump));
+            hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode * nb), dim3(BKF_THREADS, 1, 1),
+                               sizeof(meshf_lds), ctx->stream, B, nmode, nx, ny, mesh, nbx, nby,
+                               wthresh, mode0, vec_ok, dbg, dump);
+            hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode * nb, 1), dim3(64, 1, 1), 0, ctx->stream,
+                               dump, n, nmode, nslot, raw + (size_t)f0 * 4 * nslot);
+        }
     } else {
-        hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, nmode), dim3(BK_THREADS, 1, 1),
-                           sizeof(mesh_lds), ctx->stream, img, wgt, nx, ny, mesh, nbx, nby,
-                           wthresh, mode0, raw);
+        for (int f = 0; f < nf; ++f)
+            hipLaunchKernelGGL(k_mesh_stats, dim3(nbx, nby, nmode), dim3(BK_THREADS, 1, 1),
+                               sizeof(mesh_lds), ctx->stream, imgs[f], wgts[f], nx, ny, mesh, nbx, nby,
+                               wthresh, mode0, raw + (size_t)f * 4 * nslot);
     }
     ZM_HIP(hipGetLastError());
     return 0;
 }
 
-int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode, float** nodes_dev,
-                    float** stats_dev, int* nbx_out, int* nby_out, const char* slot, int index,
-                    int count) {
+int zm_batch_filter(zm_ctx* ctx, int nf, int nx, int ny, int mesh, int fsize, int nmode,
+                    const char* slot, int index0, int count, int nslot) {
     ZM_CHECK(fsize >= 1 && fsize <= 7, "background: BACK_FILTERSIZE %d out of range [1, 7]", fsize);
     int nbx, nby;
     float *raw = nullptr, *nodes = nullptr, *stats = nullptr;
-    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index, count, &nbx, &nby, &raw, &nodes, &stats));
+    ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index0, count, nslot, &nbx, &nby, &raw, &nodes, &stats));
     const int n = nbx * nby;
+    if (nslot < n) nslot = n;
     const bool fast = n <= 1024;
     // FAST: 4 n maps + 4 n spline scratch + max(8 n planes, 2 x 1024 sort buffer)
     const size_t fsh = sizeof(float) * (fast ? (size_t)8 * n + std::max(8 * n, 2048) : (size_t)9 * n);
@@ -944,21 +985,42 @@ int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_set = true;
     }
-    {
-        zm_scope_timer t(ctx, "mesh_filter");
-        if (fast)
-            hipLaunchKernelGGL(k_mesh_filter<true>, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
-                               raw, nbx, nby, fsize, nodes, stats);
-        else
-            hipLaunchKernelGGL(k_mesh_filter<false>, dim3(nmode, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
-                               raw, nbx, nby, fsize, nodes, stats);
-        ZM_HIP(hipGetLastError());
-    }
-    *nodes_dev = nodes;
-    *stats_dev = stats;
-    *nbx_out = nbx;
-    *nby_out = nby;
+    zm_scope_timer t(ctx, "mesh_filter");
+    if (fast)
+        hipLaunchKernelGGL(k_mesh_filter<true>, dim3(nmode * nf, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
+                           raw, nbx, nby, fsize, nmode, nslot, nodes, stats);
+    else
+        hipLaunchKernelGGL(k_mesh_filter<false>, dim3(nmode * nf, 1, 1), dim3(1024, 1, 1), fsh, ctx->stream,
+                           raw, nbx, nby, fsize, nmode, nslot, nodes, stats);
+    ZM_HIP(hipGetLastError());
     return 0;
+}
+
+// device pointers of frame `index`: node planes [2 statistics][2 maps][4][n], stats [2][2]
+int zm_frame_products(zm_ctx* ctx, int nx, int ny, int mesh, const char* slot, int index, int count,
+                      int nslot, float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out) {
+    float* raw = nullptr;
+    return frame_slots(ctx, nx, ny, mesh, slot, index, count, nslot, nbx_out, nby_out, &raw, nodes_dev,
+                       stats_dev);
+}
+
+// variance rescale factors of nf frames: out[4 f] = backsig^2 / variance level
+int zm_batch_var_scale(zm_ctx* ctx, int nf, const float* stats, float* out) {
+    hipLaunchKernelGGL(k_var_scale_batch, dim3(zm_div_up(nf, 64)), dim3(64), 0, ctx->stream, stats, out, nf);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny, int mesh,
+                   float wthresh, int mode0, int nmode, const char* slot, int index, int count) {
+    return zm_batch_stats(ctx, 1, &img, &wgt, nx, ny, mesh, wthresh, mode0, nmode, slot, index, count, 0);
+}
+
+int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode, float** nodes_dev,
+                    float** stats_dev, int* nbx_out, int* nby_out, const char* slot, int index,
+                    int count) {
+    ZM_TRY(zm_batch_filter(ctx, 1, nx, ny, mesh, fsize, nmode, slot, index, count, 0));
+    return zm_frame_products(ctx, nx, ny, mesh, slot, index, count, 0, nodes_dev, stats_dev, nbx_out, nby_out);
 }
 
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,

@@ -103,6 +103,14 @@ int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
                         const char* slot, int index = 0, int count = 1);
+int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* const* wgts, int nx,
+                   int ny, int mesh, float wthresh, int mode0, int nmode, const char* slot, int index0,
+                   int count, int nslot);
+int zm_batch_filter(zm_ctx* ctx, int nf, int nx, int ny, int mesh, int fsize, int nmode,
+                    const char* slot, int index0, int count, int nslot);
+int zm_frame_products(zm_ctx* ctx, int nx, int ny, int mesh, const char* slot, int index, int count,
+                      int nslot, float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out);
+int zm_batch_var_scale(zm_ctx* ctx, int nf, const float* stats, float* out);
 int zm_frame_stats(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny, int mesh,
                    float wthresh, int mode0, int nmode, const char* slot, int index, int count);
 int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode, float** nodes_dev,
