@@ -189,6 +189,11 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
 // X layout: [cell][nX][npixp] fp64, rows 0..nc-1 kernel vectors, nc..nE-1
 // background terms, nE the science pixels; columns >= npix are zero.
 #define HV_R 8     // outputs per thread along the filter direction (register sliding window)
+// Workgroups per cell (blockIdx.y): the x filters in use are dealt round-robin, each
+// workgroup runs its x passes and the y passes of the terms built on them.  After the first
+// round only the few cells with a replaced substamp are recomputed, so a cell's latency,
+// not the throughput, sets the kernel time.
+#define HV_SPLIT 5
 
 template <int HWK>
 __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     constexpr int STEP = 2 * HWK + 1;
     constexpr int WIN = HV_R + 2 * HWK;
     const int cell = blockIdx.x, tid = threadIdx.x;
+    const int part = blockIdx.y, nparts = gridDim.y;
     if (!need[cell]) return;
     const int act = active[cell];
     if (act < 0) return;
@@ -225,9 +231,9 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
     double* Xc = X + (size_t)cell * P.nX * P.npixp;
-    // science row, background rows, variance mean, zero padding
+    // science row, background rows, variance mean, zero padding: part 0
     double vs = 0.0;
-    for (int k = tid; k < P.npixp; k += 256) {
+    for (int k = tid; part == 0 && k < P.npixp; k += 256) {
         if (k < P.npix) {
             int i = k / sw, j = k - i * sw;
             int x = cc.x - hwss + j, y = cc.y - hwss + i;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         }
     }
     vs = block_sum256(vs, red);
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
         vbar[cell] = vs / P.npix;
         double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
         for (int p = 0; p < P.nkp; ++p)
@@ -253,10 +259,17 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     const int nstrip = (sw + HV_R - 1) / HV_R;
     // basis vectors: for each x filter, one x pass, then a y pass per term using it.
     // Both passes slide a register window: HV_R outputs share HV_R + 2 HWK loads.
+    // term 0 (subtracted from the later terms, P.tsub0) is built by every part for itself;
+    // only the owner of its x filter stores it
+    int fidx = 0;
     for (int f = 0; f < P.nf1; ++f) {
         bool used = false;
         for (int n = 0; n < P.nc; ++n) used |= (P.tfx[n] == f);
         if (!used) continue;
+        const bool mine = (fidx % nparts) == part;
+        ++fidx;
+        const bool for_w0 = (P.tfx[0] == f);
+        if (!mine && !for_w0) continue;
         const double* fxv = fl + f * STEP;
         // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
         for (int e = tid; e < pw * nstrip; e += 256) {
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         __syncthreads();
         for (int n = 0; n < P.nc; ++n) {
             if (P.tfx[n] != f) continue;
+            if (!mine && n != 0) continue;
             const double* fyv = fl + P.tfy[n] * STEP;
             const double sc = P.tscale[n];
             // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                         double v = acc[q] * sc;
                         if (n == 0) w0[k] = v;
                         else if (P.tsub0[n]) v -= w0[k];
-                        Xc[(size_t)n * P.npixp + k] = v;
+                        if (mine) Xc[(size_t)n * P.npixp + k] = v;
                     }
                 }
             }
@@ -325,20 +339,27 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define GR_KT 32
 #define GR_PITCH 34   // doubles; (4 i + 2 k) mod 64 banks are distinct for ds_read_b64
 
+// blockIdx.y = slice of the pixel axis (GR_SPLIT slices of whole K tiles): partial Gram
+// matrices go to Gp[cell][slice], k_hp_gram_sum adds them in slice order (deterministic).
+// As for the vectors: after the first round a cell's latency sets the kernel time.
+#define GR_SPLIT 4
 __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
                                                  const int* __restrict__ need,
                                                  const int* __restrict__ active,
-                                                 double* __restrict__ G) {
+                                                 double* __restrict__ Gp) {
     __shared__ double L[HP_MAXX * GR_PITCH];
     const int cell = blockIdx.x, tid = threadIdx.x;
     if (!need[cell] || active[cell] < 0) return;
     const double* Xc = X + (size_t)cell * P.nX * P.npixp;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
+    const int ntile = P.npixp / GR_KT;                     // npixp is a multiple of GR_KT
+    const int per = (ntile + GR_SPLIT - 1) / GR_SPLIT;
+    const int kbeg = blockIdx.y * per * GR_KT, kend = min((int)(blockIdx.y + 1) * per, ntile) * GR_KT;
     double4_t acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < P.npixp; k0 += GR_KT) {
+    for (int k0 = kbeg; k0 < kend; k0 += GR_KT) {
         __syncthreads();
         for (int e = tid; e < HP_MAXX * GR_KT; e += 256) {
             int row = e >> 5, col = e & 31;
@@ -356,12 +377,28 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg
-    double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+    double* Gc = Gp + ((size_t)cell * GR_SPLIT + blockIdx.y) * HP_MAXX * HP_MAXX;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
             Gc[(size_t)(16 * wave + lk + 4 * rg) * HP_MAXX + 16 * c + li] = acc[c][rg];
+}
+
+__global__ __launch_bounds__(256) void k_hp_gram_sum(const double* __restrict__ Gp,
+                                                     const int* __restrict__ need,
+                                                     const int* __restrict__ active,
+                                                     double* __restrict__ G) {
+    const int cell = blockIdx.x;
+    if (!need[cell] || active[cell] < 0) return;
+    const double* src = Gp + (size_t)cell * GR_SPLIT * HP_MAXX * HP_MAXX;
+    double* dst = G + (size_t)cell * HP_MAXX * HP_MAXX;
+    for (int e = threadIdx.x; e < HP_MAXX * HP_MAXX; e += 256) {
+        double v = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < GR_SPLIT; ++sl) v += src[(size_t)sl * HP_MAXX * HP_MAXX + e];
+        dst[e] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1230,6 +1267,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_cdg", sizeof(double) * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));
     ZM_TRY(ctx->get("hp_X", sizeof(double) * (size_t)P.ncell * P.nX * P.npixp, (void**)&X));
     ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
+    double* Gp = nullptr;                // per-slice partial Gram matrices
+    ZM_TRY(ctx->get("hp_Gp", sizeof(double) * (size_t)P.ncell * GR_SPLIT * HP_MAXX * HP_MAXX, (void**)&Gp));
     ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
     ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
     ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A));
@@ -1281,7 +1320,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             zm_scope_timer t(ctx, "hp_vectors");
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
+    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, HV_SPLIT), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
                        centres, active, need, X, phi, vbar); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
@@ -1294,7 +1333,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         }
         {
             zm_scope_timer t(ctx, "hp_gram");
-            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell), b256, 0, st, P, X, need, active, G);
+            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell, GR_SPLIT), b256, 0, st, P, X, need, active, Gp);
+            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G);
             ZM_HIP(hipGetLastError());
         }
         {
