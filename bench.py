@@ -231,7 +231,7 @@ def main():
     value = mpix_per_step * args.steps / dt
 
     if rank == 0:
-        names = ['resample', 'resample_mask', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
+        names = ['resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
                  'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
                  'hp_solve', 'hp_apply']
         kt = {}

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
 // workgroup runs its x passes and the y passes of the terms built on them.  After the first
 // round only the few cells with a replaced substamp are recomputed, so a cell's latency,
 // not the throughput, sets the kernel time.
-#define HV_SPLIT 5
+#define HV_SPLIT 8
 
 template <int HWK>
 __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
@@ -342,7 +342,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // blockIdx.y = slice of the pixel axis (GR_SPLIT slices of whole K tiles): partial Gram
 // matrices go to Gp[cell][slice], k_hp_gram_sum adds them in slice order (deterministic).
 // As for the vectors: after the first round a cell's latency sets the kernel time.
-#define GR_SPLIT 4
+#define GR_SPLIT 8
 __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
                                                  const int* __restrict__ need,
                                                  const int* __restrict__ active,

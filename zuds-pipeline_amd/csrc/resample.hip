@@ -383,17 +383,51 @@ __device__ inline void rs_build_header(const double2* __restrict__ lat, int lnx,
     }
 }
 
+// Box OR of an integer mask: B[y][x] = OR of m[y .. y + NT - 1][x .. x + NT - 1] where the
+// whole window lies on the frame (other entries are never read).  One 64 x 16 tile per
+// workgroup, separable in LDS.  The resample kernel then needs a single gather per pixel.
+template <int NT>
+__global__ __launch_bounds__(256) void k_mask_box(const int32_t* __restrict__ m, int nx, int ny,
+                                                  int32_t* __restrict__ B) {
+    constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
+    __shared__ int32_t t0[IH * IP];
+    __shared__ int32_t h[IH * TWB];
+    const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int r = e / IW, c = e - r * IW;
+        const int x = x0 + c, y = y0 + r;
+        t0[r * IP + c] = (x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < IH * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        int32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) o |= t0[r * IP + c + k];
+        h[e] = o;
+    }
+    __syncthreads();
+    for (int e = tid; e < THB * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        const int x = x0 + c, y = y0 + r;
+        if (x + NT <= nx && y + NT <= ny) {
+            int32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
+            B[(size_t)y * nx + x] = o;
+        }
+    }
+}
+
 template <int KIND, int MASKOP>
-__global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
+__global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
-    const int32_t* __restrict__ mask, int32_t* __restrict__ macc, int mkind, int mfirst, int ntx,
-    int ntiles) {
+    const int32_t* __restrict__ mask, const int32_t* __restrict__ mbox, int32_t* __restrict__ macc,
+    int mkind, int mfirst, int ntx, int ntiles) {
     extern __shared__ float4 smem4[];
     rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
     float2* tile = reinterpret_cast<float2*>(smem4) + HDR_FLOATS / 2;
-    int32_t* mt = reinterpret_cast<int32_t*>(tile + lds_cap);      // raw mask tile
-    int32_t* mx = mt + lds_cap;                                    // OR over the NT columns to the right
     constexpr int NT = taps_traits<KIND>::N;
     constexpr int OFF = taps_traits<KIND>::OFF;
     constexpr int CI = -OFF;                                       // tap index of a delta kernel
@@ -403,7 +437,6 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
     const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
 
     float4 pf[RS_PF];
-    int2 pm[RS_PF];
     // issue the loads of tile `t` (header H) into the prefetch registers
     auto prefetch = [&](const rs_hdr* H) {
         if (!H->use_lds) return;
@@ -414,18 +447,12 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
         for (int k = 0; k < RS_PF; ++k) {
             const int e = tid + 256 * k;
             pf[k] = fill;
-            pm[k] = make_int2(0, 0);
             if (e < n4) {
                 const int r = (int)(((float)e + 0.5f) * inv);
                 const int c2 = e - r * bw2;
                 const int gy = by0 + r, gx = bx0 + 2 * c2;
                 if (gy >= 0 && gy < ny && gx >= 0 && gx < spitch)
                     pf[k] = *reinterpret_cast<const float4*>(src + (size_t)gy * spitch + gx);
-                if (MASKOP && gy >= 0 && gy < ny) {
-                    const int32_t* mrow = mask + (size_t)gy * nx;
-                    if (gx >= 0 && gx < nx) pm[k].x = mrow[gx];
-                    if (gx + 1 >= 0 && gx + 1 < nx) pm[k].y = mrow[gx + 1];
-                }
             }
         }
     };
@@ -435,10 +462,8 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
 #pragma unroll
         for (int k = 0; k < RS_PF; ++k) {
             const int e = tid + 256 * k;
-            if (e < n4) {
+            if (e < n4)
                 *reinterpret_cast<float4*>(tile + 2 * e) = pf[k];      // rows are bw = 2 bw2 wide: linear
-                if (MASKOP) *reinterpret_cast<int2*>(mt + 2 * e) = pm[k];
-            }
         }
     };
 
@@ -459,24 +484,6 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
         __syncthreads();
         const bool use_lds = H->use_lds, touches = H->touches;
         const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
-        if (MASKOP && use_lds) {
-            // mx[r][c] = OR of mt[r][c .. c + NT - 1]: 4 columns per thread, sliding window
-            const int groups = (bw + 3) >> 2;
-            for (int e = tid; e < bh * groups; e += 256) {
-                const int r = e / groups, c = (e - r * groups) * 4;
-                int w[4 + NT - 1];
-#pragma unroll
-                for (int k = 0; k < 4 + NT - 1; ++k) w[k] = (c + k < bw) ? mt[r * bw + c + k] : 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int o = 0;
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) o |= w[j + k];
-                    if (c + j < bw) mx[r * bw + c + j] = o;
-                }
-            }
-            __syncthreads();
-        }
         const int tyi = t / ntx, txi = t - tyi * ntx;
         const int ox0 = txi * TW, oy0 = tyi * TH;
         const int tx = tid & 63, tyb = tid >> 6;
@@ -513,6 +520,21 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
             float2 res = make_float2(0.f, 0.f);
             int32_t mres = 0;
             if (inb) {
+                if (MASKOP) {
+                    // every tap of a non-delta axis is non-zero: the OR over the NT x NT footprint
+                    // is one gather from the box-OR plane (k_mask_box); delta kernels (aligned
+                    // grids) only touch the centre tap of that axis and read the raw mask
+                    if (!(ddx || ddy)) {
+                        mres = mbox[(size_t)iy * nx + ix];
+                    } else {
+                        const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
+                        const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
+                        for (int r = r0; r < r1; ++r) {
+                            const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
+                            for (int c = c0; c < c1; ++c) mres |= mp[c];
+                        }
+                    }
+                }
                 zm_v2f tw[NT];
                 make_taps2<KIND>(dx, dy, ddx, ddy, tw);
                 float acc = 0.f, vacc = 0.f;
@@ -533,16 +555,6 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
                     }
                     acc = av.x;
                     vacc = av.y;
-                    if (MASKOP) {
-                        // delta kernels only touch the centre tap; otherwise every tap is non-zero
-                        const int32_t* mp = (ddx ? mt + ixr + OFF + CI : mx + ixr + OFF) + (iyr + OFF) * bw;
-                        if (ddy) {
-                            mres = mp[CI * bw];
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < NT; ++r) mres |= mp[r * bw];
-                        }
-                    }
                 } else {
                     const float2* p = src + (size_t)iy * spitch + ix;
 #pragma unroll
@@ -557,14 +569,6 @@ __global__ __launch_bounds__(256, MASKOP ? 3 : 4) void k_resample(
                         acc = fmaf(tw[r].y, ra, acc);
                         vacc = fmaf(tw[r].y, rv, vacc);
                         p += spitch;
-                    }
-                    if (MASKOP) {
-                        const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
-                        const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
-                        for (int r = r0; r < r1; ++r) {
-                            const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
-                            for (int c = c0; c < c1; ++c) mres |= mp[c];
-                        }
                     }
                 }
                 if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
@@ -629,17 +633,26 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
                                 int32_t* macc, int mop, int mkind, int mfirst) {
     dim3 blk(256, 1, 1);
     const int ntx = grd.x, ntiles = grd.x * grd.y;
+    int32_t* mbox = nullptr;
+    if (mop) {
+        constexpr int NT = taps_traits<KIND>::N;
+        ZM_TRY(ctx->get("mask_box", sizeof(int32_t) * (size_t)nx * ny, (void**)&mbox));
+        zm_scope_timer tb(ctx, "mask_box");
+        hipLaunchKernelGGL(k_mask_box<NT>, dim3(zm_div_up(nx, 64), zm_div_up(ny, 16)), blk, 0, ctx->stream,
+                           mask, nx, ny, mbox);
+    }
+    zm_scope_timer t(ctx, "resample");
     // persistent grid: a few workgroups per CU, each walking ntiles / G tiles
-    dim3 pgrd(std::min(ntiles, 256 * (mop ? 3 : 4)), 1, 1);
+    dim3 pgrd(std::min(ntiles, 256 * 4), 1, 1);
     if (mop == 0)
         hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
     else if (mop == 1)
         hipLaunchKernelGGL((k_resample<KIND, 1>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
     else
         hipLaunchKernelGGL((k_resample<KIND, 2>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -652,10 +665,8 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
                        int32_t* macc, int mop, int mkind, int mfirst) {
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
     if (!mask || !macc) mop = 0;
-    // image tile + (mask tile + its row-OR) when a mask rides along; keep within 64 KiB
     if (lds_elems > RS_PFCAP) lds_elems = RS_PFCAP;      // what the prefetch registers can stage
-    size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * (sizeof(float2) + (mop ? 8 : 0));
-    zm_scope_timer t(ctx, "resample");
+    size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * sizeof(float2);
     if (kernel == ZM_RESAMPLE_LANCZOS3)
         return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, grd, shmem, src, nx, ny, spitch, lat, lnx,
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
@@ -665,6 +676,7 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
                                                           macc, mop, mkind, mfirst);
     if (kernel == ZM_RESAMPLE_NEAREST) {
+        zm_scope_timer t(ctx, "resample");
         hipLaunchKernelGGL(k_resample_nearest, grd, blk, 0, ctx->stream, src, nx, ny, spitch, lat, lnx,
                            lny, fscale, dst, onx, ony);
         ZM_HIP(hipGetLastError());
