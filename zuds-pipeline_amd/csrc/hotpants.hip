@@ -1355,7 +1355,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
                 }
                 ZM_CHECK(P.nreg <= coop_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, coop_cap);
-                int W = std::max(1, std::min(40, std::min(coop_cap, 400) / P.nreg));
+                int W = std::max(1, std::min(40, std::min(coop_cap - coop_cap / 16, 400) / P.nreg));   // margin below the API figure
                 int nunk = P.nunk;
                 double* Aarg = A;
                 int* farg = fail;
