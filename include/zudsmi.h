@@ -225,6 +225,15 @@ int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
                  float* out_mask_wgt);
 int zm_coadd_finalize_dev(zm_ctx* ctx, float* s1_to_img, const float* s0,
                           int64_t npix);
+/* Mask coadd across ranks: zm_coadd_dev(partial = 1) leaves -1 ("no frame of this rank
+ * covers the pixel") in out_mask instead of finalising it.  zm_mask_accum_dev folds
+ * another partial mask in (AND / OR over the covering frames, -1 = identity; first != 0
+ * initialises acc from m), zm_mask_finalize_dev turns the marker into 0 and writes the
+ * coverage plane (cov may be NULL) - the mask SWarp run of zuds/swarp.py:83-104 sharded
+ * by frame. */
+int zm_mask_accum_dev(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix,
+                      int kind, int first);
+int zm_mask_finalize_dev(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
 /* Resample the frames to `wout` into a resident stack [nframes][ony][onx][2]
  * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it). */
 int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,

@@ -86,6 +86,73 @@ def worker(rank, world, port, kind, q):
     dist.destroy_process_group()
 
 
+def partial_mask(frames, base, kind):
+    """Oracle mask coadd of some frames with the -1 'nothing covered' marker left in."""
+    onx, ony = base.naxis
+    masks, cov = [], []
+    for f in frames:
+        px, py = oresample.positions(to_oracle_wcs(base), to_oracle_wcs(f['wcs']), onx, ony)
+        _, _, m = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3, 1.0, f['mask'])
+        ix, _, _ = oresample.split_position(px)
+        iy, _, _ = oresample.split_position(py)
+        nx, ny = f['wcs'].naxis
+        masks.append(m)
+        cov.append((ix - 2 >= 0) & (ix + 4 <= nx) & (iy - 2 >= 0) & (iy + 4 <= ny))
+    m, c = ocombine.combine_masks(np.array(masks), np.array(cov), kind)
+    return np.where(c > 0, m, -1).astype(np.int32)
+
+
+def np_accum(kind):
+    def accum(acc, m, first):
+        a, v = acc.numpy(), m.numpy()
+        if first:
+            a[:] = -1
+        both = (a != -1) & (v != -1)
+        out = np.where(a == -1, v, a)
+        out = np.where(both, (a & v) if kind == 'AND' else (a | v), out)
+        a[:] = out
+    return accum
+
+
+def np_finalize(acc):
+    a = acc.numpy()
+    a[a == -1] = 0
+
+
+def mask_worker(rank, world, port, kind, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = __import__('importlib').import_module('zuds-pipeline_amd.parallel')
+    base, frames = make_frames()
+    mine = frames[:3] if rank == 0 else frames[3:]
+    acc = torch.from_numpy(partial_mask(mine, base, kind))
+    par.reduce_masks(acc, np_accum(kind), np_finalize)
+    q.put((rank, acc.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['AND', 'OR'])
+def test_two_rank_mask_coadd_equals_single_process(kind):
+    base, frames = make_frames()
+    ref = partial_mask(frames, base, kind)
+    ref[ref == -1] = 0
+    assert (ref != 0).any()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=mask_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, m in results:
+        assert np.array_equal(m, ref), f'rank {rank}'
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

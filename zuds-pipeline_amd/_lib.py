@@ -116,6 +116,8 @@ _SIGS = {
                                 C.POINTER(C.c_double)]),
     'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
+    'zm_mask_accum_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int]),
+    'zm_mask_finalize_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
     'zm_median_mad2_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_double)]),
     'zm_rms_from_weight_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     'zm_weight_from_rms_dev': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P]),

@@ -182,8 +182,24 @@ extern "C" int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
     ZM_TRY(zm_launch_combine(ctx, nframes, stack, opix, opix, params->combine,
                              (float)params->clip_sigma, (float)params->clip_ampfrac, out_img,
                              out_wgt, partial));
-    if (out_mask) ZM_TRY(zm_launch_mask_finalize(ctx, out_mask, out_mask_wgt, opix));
+    // a partial coadd leaves the "nothing covered yet" marker (-1) in place: the caller folds the
+    // partial masks of the other ranks in (zm_mask_accum_dev) and finalises (zm_mask_finalize_dev)
+    if (out_mask && !partial) ZM_TRY(zm_launch_mask_finalize(ctx, out_mask, out_mask_wgt, opix));
     return 0;
+}
+
+extern "C" int zm_mask_accum_dev(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix, int kind,
+                                 int first) {
+    ZM_CHECK(ctx && acc && m, "zm_mask_accum_dev: null argument");
+    ZM_CHECK(kind == ZM_MASK_AND || kind == ZM_MASK_OR, "zm_mask_accum_dev: unknown combine %d", kind);
+    ZM_HIP(hipSetDevice(ctx->device));
+    return zm_launch_mask_accum(ctx, acc, m, npix, kind, first);
+}
+
+extern "C" int zm_mask_finalize_dev(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix) {
+    ZM_CHECK(ctx && acc, "zm_mask_finalize_dev: null argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    return zm_launch_mask_finalize(ctx, acc, cov, npix);
 }
 
 extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,

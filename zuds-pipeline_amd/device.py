@@ -100,14 +100,28 @@ class DeviceCoadd(object):
         if self.params.combine not in (_lib.COMBINE['WEIGHTED'], _lib.COMBINE['AVERAGE']):
             raise ValueError('a sum-reduce coadd needs COMBINE_TYPE WEIGHTED or AVERAGE; '
                              'use run_sharded_exact for CLIPPED / MEDIAN')
+        from .parallel import reduce_masks
+        L, ctx = self.engine.L, self.engine.ctx
         self.run(dframes, partial=True)
         with self.torch.cuda.stream(self.stream):
             if dist.is_initialized() and dist.get_world_size(group) > 1:
                 dist.all_reduce(self.img, op=dist.ReduceOp.SUM, group=group)
                 dist.all_reduce(self.wgt, op=dist.ReduceOp.SUM, group=group)
-            check(self.engine.L.zm_coadd_finalize_dev(self.engine.ctx, self.img.data_ptr(),
-                                                      self.wgt.data_ptr(), self.img.numel()),
-                  'zm_coadd_finalize_dev')
+            check(L.zm_coadd_finalize_dev(ctx, self.img.data_ptr(), self.wgt.data_ptr(),
+                                          self.img.numel()), 'zm_coadd_finalize_dev')
+            if self.mask is not None:
+                # the mask coadd of the whole stack: partial masks of all ranks, folded locally
+                n, kind = self.mask.numel(), int(self.params.mask_combine)
+                reduce_masks(
+                    self.mask,
+                    lambda acc, m, first: check(L.zm_mask_accum_dev(ctx, acc.data_ptr(), m.data_ptr(),
+                                                                    n, kind, int(first)),
+                                                'zm_mask_accum_dev'),
+                    lambda acc: check(L.zm_mask_finalize_dev(
+                        ctx, acc.data_ptr(),
+                        self.mask_wgt.data_ptr() if self.mask_wgt is not None else None, n),
+                        'zm_mask_finalize_dev'),
+                    group)
         return self.img, self.wgt
 
 

@@ -31,6 +31,27 @@ def band_bounds(nrows, world):
     return b
 
 
+def reduce_masks(acc, accum, finalize, group=None):
+    """Fold the partial mask coadds of all ranks into ``acc`` (in place) and finalise.
+
+    ``acc``: this rank's partial mask (tensor, -1 where none of its frames covers the
+    pixel).  ``accum(acc, m, first)`` folds one partial mask in, ``finalize(acc)`` turns the
+    marker into 0 / writes the coverage plane.  AND / OR are associative and commutative,
+    so every rank ends with the same mask whatever the order; NCCL / RCCL have no bitwise
+    reductions, hence an all-gather (world x 4 B / px) and a local fold.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world > 1:
+        parts = [torch.empty_like(acc) for _ in range(world)]
+        dist.all_gather(parts, acc.contiguous(), group=group)
+        for r, m in enumerate(parts):
+            accum(acc, m, r == 0)
+    finalize(acc)
+    return acc
+
+
 class HipBackend(object):
     """libzudsmi on this rank's GPU; tensors are CUDA (HIP) tensors."""
 
