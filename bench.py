@@ -145,13 +145,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    # one rank per GPU over RCCL ('nccl').  Rehearsal on a one-GPU box: ZM_DIST_BACKEND=gloo puts
+    # several ranks on the same card (local rank modulo the device count).
+    backend = os.environ.get('ZM_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
 
     z = importlib.import_module('zuds-pipeline_amd')
     synth = importlib.import_module('zuds-pipeline_amd.synth')
@@ -207,7 +211,7 @@ def main():
     def sync():
         torch.cuda.synchronize(device)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if backend == 'nccl' else dist.barrier()
             torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
