@@ -42,8 +42,8 @@ def parse():
     ap.add_argument('--no-mask', action='store_true', help='skip the mask coadd (dev only)')
     ap.add_argument('--seeing', type=float, default=4.0,
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
-    ap.add_argument('--cpu-sample', type=int, default=640,
-                    help='side of the frames the CPU baseline resamples')
+    ap.add_argument('--cpu-frames', type=int, default=8,
+                    help='full-size frames the CPU baseline resamples and coadds')
     return ap.parse_args()
 
 
@@ -94,18 +94,21 @@ def pmc_traffic(args):
     return d.get('hbm_bytes_per_launch')
 
 
-def cpu_baseline(synth, size, combine):
-    """The numpy oracle (a port, not SWarp) timed on the host: resample +
-    combine of 2 config-2 style frames of size x size, one process."""
-    from oracle import combine as ocombine
-    from oracle import resample as oresample
+def cpu_baseline(synth, size, combine, nframes=8, sub_size=640):
+    """CPU restatement timed on this box's host cores (a port, NOT SWarp / hotpants, which
+    are not installed): the C / OpenMP port of the oracle (oracle/cport, all cores) on the
+    resample -> coadd leg of `nframes` config-2 frames of the full size, plus - reported in
+    the sample text only - the numpy hotpants restatement on one small frame."""
+    from oracle import cport
     from oracle.wcs import WCS as OWCS
 
     def ow(w):
         return OWCS(w.crpix, w.crval, w.cd, w.pv1, w.pv2, w.naxis)
+    c = cport.load(native=True)
+    c.set_threads(int(os.environ.get('ZM_CPU_THREADS', 0)) or cport.host_cores())
     base = synth.ztf_wcs(size, size, tpv=True)
     frames = []
-    for i in range(2):
+    for i in range(nframes):
         r = np.random.default_rng(2000 + i)
         w = synth.ztf_wcs(size, size, dx=r.uniform(-15, 15), dy=r.uniform(-15, 15),
                           rot_deg=r.uniform(-0.1, 0.1), tpv=True)
@@ -113,28 +116,34 @@ def cpu_baseline(synth, size, combine):
     t0 = time.perf_counter()
     vals, wgts = [], []
     for f in frames:
-        px, py = oresample.positions(ow(base), ow(f['wcs']), size, size)
-        fs = oresample.flux_scale(ow(f['wcs']), ow(base), f['flxscale'])
-        o, w_, _ = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3, fs)
+        px, py = c.positions(ow(base), ow(f['wcs']), size, size)
+        o, w_, _ = c.resample(f['img'], f['wgt'], px, py, 3, f['flxscale'], f['mask'])
         vals.append(o)
         wgts.append(w_)
-    ref, refw, _ = ocombine.combine(np.array(vals), np.array(wgts), combine)
+    ref, refw = c.combine(np.array(vals), np.array(wgts), combine)
     t1 = time.perf_counter()
-    # one subtraction of the same size against that coadd (hotpants restatement)
+    mpix = nframes * size * size / 1e6
+    # one subtraction against a small coadd (numpy hotpants restatement, one core)
     from oracle import hotpants as ohp
-    sci = frames[0]
-    rrms = np.where(refw > 0, 1.0 / np.sqrt(np.where(refw > 0, refw, 1)), np.sqrt(50000.0))
-    srms = np.where(sci['wgt'] > 0, 1.0 / np.sqrt(np.where(sci['wgt'] > 0, sci['wgt'], 1)), np.sqrt(50000.0))
-    ohp.subtract(vals[0] + 150.0, ref + 150.0, srms, rrms, (wgts[0] <= 0).astype(np.uint8),
-                 r=5.0, rss=12.0, nsx=max(size // 100, 1), nsy=max(size // 100, 1), ko=2, bgo=0,
-                 tu=5e3, iu=5e3, tl=-100.0, il=-100.0)
+    from oracle import resample as oresample
+    ss = sub_size
+    sbase = synth.ztf_wcs(ss, ss, tpv=True)
+    sf = synth.make_frame(ss, ss, 2100, synth.ztf_wcs(ss, ss, dx=2.0, dy=-3.0, tpv=True), nstars=100, nbad=ss)
+    spx, spy = oresample.positions(ow(sbase), ow(sf['wcs']), ss, ss)
+    sv, sw, _ = oresample.resample(sf['img'], sf['wgt'], spx, spy, oresample.LANCZOS3, 1.0)
+    srms = np.where(sw > 0, 1.0 / np.sqrt(np.where(sw > 0, sw, 1)), np.sqrt(50000.0))
     t2 = time.perf_counter()
-    dt = t2 - t0
-    mpix = (len(frames) + 1) * size * size / 1e6
-    return {'value': mpix / dt, 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{len(frames)} frames {size}x{size} resample + {combine} combine '
-                      f'({t1 - t0:.1f} s) + 1 subtraction r=5 ko=2 ({t2 - t1:.1f} s), numpy fp64 '
-                      f'oracle, one process; CPU restatement, not SWarp/hotpants'}
+    ohp.subtract(sv + 150.0, sv + 150.0, srms, srms, (sw <= 0).astype(np.uint8),
+                 r=5.0, rss=12.0, nsx=max(ss // 100, 1), nsy=max(ss // 100, 1), ko=2, bgo=0,
+                 tu=5e3, iu=5e3, tl=-100.0, il=-100.0)
+    t3 = time.perf_counter()
+    return {'value': mpix / (t1 - t0), 'unit': 'Mpix/s', 'cores': c.threads(), 'kind': 'port',
+            'sample': f'{nframes} frames {size}x{size}: per-pixel TPV inverse map + Lanczos-3 resample '
+                      f'(image, variance, mask) + {combine} combine in {t1 - t0:.1f} s, C / OpenMP port of '
+                      f'the oracle on {c.threads()} threads ({os.cpu_count()} host CPUs visible; gcc -O3 '
+                      f'-march=native); separately the numpy hotpants restatement, one core, one '
+                      f'{ss}x{ss} subtraction r=5 ko=2: {t3 - t2:.1f} s = {ss * ss / 1e6 / (t3 - t2):.2f} Mpix/s. '
+                      f'CPU restatement, not SWarp / hotpants (not installed)'}
 
 
 def main():
@@ -279,7 +288,7 @@ def main():
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(synth, args.cpu_sample, args.combine)
+            out['cpu_baseline'] = cpu_baseline(synth, args.size, args.combine, args.cpu_frames)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
