@@ -274,6 +274,18 @@ int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, float value,
 /* img += v: the 150-count pedestal (zuds/coadd.py:205-206, zuds/hotpants.py:29). */
 int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n);
 
+/* ---- FITS data blocks on the device ------------------------------------------ */
+/* Replaces the host-side decode / encode astropy does inside FITSFile.load_data / save
+ * (zuds/fitsfile.py:69-94,146-206): raw_dev holds the big-endian data block of a primary
+ * HDU as it lies on disk (n pixels of BITPIX 8 / 16 / 32 / -32 / -64); the decoded plane
+ * is float32 (out_kind 0), int32 (1) or uint8 (2) with physical = bzero + bscale * stored.
+ * Encode: float32 -> BITPIX -32 (in_kind 0), int32 -> 32 (1), uint8 -> 8 (2),
+ * int32 -> BITPIX 16 (3). */
+int zm_fits_decode_dev(zm_ctx* ctx, const void* raw_dev, int bitpix, double bscale,
+                       double bzero, int64_t n, int out_kind, void* out_dev);
+int zm_fits_encode_dev(zm_ctx* ctx, const void* in_dev, int in_kind, int64_t n,
+                       void* raw_dev);
+
 /* ---- timing hooks (bench.py reads per-kernel HIP-event times) ------------- */
 /* Enable recording of HIP events around the dominant kernels on the ctx
  * stream; zm_timing_read returns accumulated milliseconds and launch counts. */

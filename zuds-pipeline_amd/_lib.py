@@ -116,6 +116,8 @@ _SIGS = {
                                 C.POINTER(C.c_double)]),
     'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
+    'zm_fits_decode_dev': (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int, _P]),
+    'zm_fits_encode_dev': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'zm_mask_accum_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int]),
     'zm_mask_finalize_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
     'zm_median_mad2_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_double)]),
@@ -143,11 +145,39 @@ def exported_symbols():
     return [k for k in _SIGS if k != 'zm_debug_lanczos3']
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as
+    /opt/rocm).  A process must run on ONE copy: if libzudsmi pulled in the system runtime
+    first, a later ``import torch`` + first CUDA call would find "No HIP GPUs".  So when torch
+    is installed but not imported yet, its runtime is loaded first and libzudsmi's NEEDED
+    entries resolve to it by SONAME - the same arrangement as with torch imported first."""
+    import importlib.util
+    import os
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load libzudsmi.so once; raise if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _one_hip_runtime()
     if not LIBPATH.exists():
         raise ZMError(f'{LIBPATH} is missing: run __graft_entry__.build() '
                       f'(python zuds-pipeline_amd/build.py). There is no CPU '

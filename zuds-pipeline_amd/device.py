@@ -220,3 +220,104 @@ class DeviceSubtraction(object):
             check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
                                      1 << 17, self.n), 'bit17')
         return self.diff, self.noise, self.submask
+
+
+# ---------------------------------------------------------------------------
+# FITS files <-> HBM without a host-side decode
+_KIND = {'f32': 0, 'i32': 1, 'u8': 2}
+
+
+class FITSDeviceIO(object):
+    """Reads the data block of a primary HDU straight into pinned memory, sends it over PCIe
+    as it lies on disk and decodes it (byte swap, BSCALE / BZERO) on the GPU; the reverse for
+    products.  Stands in for the numpy decode inside ``FITSFile.load_data`` / ``save``
+    (``zuds/fitsfile.py:69-94,146-206``) when the consumer is the device-resident pipeline.
+
+    Two pinned staging buffers alternate, so the read of file i + 1 overlaps the copy and
+    the decode of file i."""
+
+    def __init__(self, device=0, engine=None, stream=None):
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.device('cuda', device)
+        self.engine = engine or get_engine(device)
+        if stream is None:
+            stream = torch.cuda.Stream(self.device)
+            self.engine.set_stream(stream.cuda_stream)
+        self.stream = stream
+        self._pin = [None, None]
+        self._busy = [None, None]          # event: the async copy out of the buffer is done
+        self._turn = 0
+
+    def _staging(self, nbytes):
+        torch = self.torch
+        k = self._turn
+        self._turn ^= 1
+        if self._busy[k] is not None:
+            self._busy[k].synchronize()
+        if self._pin[k] is None or self._pin[k].numel() < nbytes:
+            self._pin[k] = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, pin_memory=True)
+        return k, self._pin[k]
+
+    def load(self, path, kind='f32'):
+        """(tensor on the device, header dict).  kind: 'f32', 'i32' or 'u8'."""
+        from . import fits
+        torch = self.torch
+        hdr, _, off = fits.read_header(path)
+        nbytes = abs(int(hdr['BITPIX'])) // 8 * int(np.prod([int(hdr[f'NAXIS{i}'])
+                                                             for i in range(1, int(hdr['NAXIS']) + 1)]))
+        k, pin = self._staging(nbytes)
+        raw, hdr, _, info = fits.read_raw(path, out=pin.numpy())
+        dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8}[kind]
+        out = torch.empty(info['shape'], dtype=dt, device=self.device)
+        with torch.cuda.stream(self.stream):
+            d_raw = pin[:info['nbytes']].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._busy[k] = ev
+            check(self.engine.L.zm_fits_decode_dev(self.engine.ctx, d_raw.data_ptr(), info['bitpix'],
+                                                   info['bscale'], info['bzero'], info['count'],
+                                                   _KIND[kind], out.data_ptr()), 'zm_fits_decode_dev')
+            d_raw.record_stream(self.stream)
+        return out, hdr
+
+    def save(self, path, tensor, header=None, comments=None, bitpix=None):
+        """Encode on the device, copy back, write.  float32 -> BITPIX -32, int32 -> 32 (or 16
+        with ``bitpix=16``), uint8 -> 8.  Blocks until the file is written."""
+        from . import fits
+        torch = self.torch
+        t = tensor.contiguous()
+        if t.dtype == torch.float32:
+            kind, bp = 0, -32
+        elif t.dtype == torch.int32:
+            kind, bp = (3, 16) if bitpix == 16 else (1, 32)
+        elif t.dtype in (torch.uint8, torch.bool):
+            t = t.to(torch.uint8)
+            kind, bp = 2, 8
+        else:
+            raise ValueError(f'cannot write {t.dtype} to FITS from the device')
+        nbytes = t.numel() * abs(bp) // 8
+        k, pin = self._staging(nbytes)
+        with torch.cuda.stream(self.stream):
+            d_raw = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(self.engine.L.zm_fits_encode_dev(self.engine.ctx, t.data_ptr(), kind, t.numel(),
+                                                   d_raw.data_ptr()), 'zm_fits_encode_dev')
+            pin[:nbytes].copy_(d_raw, non_blocking=True)
+        self.stream.synchronize()
+        fits.write_raw(path, pin[:nbytes].numpy(), tuple(t.shape), bp, header, comments)
+
+    def load_frames(self, sci_paths, weight_paths=None, mask_paths=None, zp_key='MAGZP'):
+        """A DeviceFrames for ``zm_coadd_dev`` from science / weight / mask files
+        (``FLXSCALE = 10^(-0.4 (MAGZP - 25))``, ``zuds/swarp.py:31``)."""
+        from .wcs import WCS
+        frames = []
+        for i, sp in enumerate(sci_paths):
+            img, hdr = self.load(sp, 'f32')
+            f = dict(img=img, wcs=WCS.from_header(hdr), header=hdr,
+                     flxscale=10 ** (-0.4 * (float(hdr.get(zp_key, 25.0)) - 25.0)))
+            if weight_paths is not None and weight_paths[i] is not None:
+                f['wgt'] = self.load(weight_paths[i], 'f32')[0]
+            if mask_paths is not None and mask_paths[i] is not None:
+                f['mask'] = self.load(mask_paths[i], 'i32')[0]
+            frames.append(f)
+        return DeviceFrames(frames, self.device), frames

@@ -117,6 +117,72 @@ def read(path, header_only=False):
     return data, header, comments
 
 
+def read_raw(path, out=None):
+    """The data block of the primary HDU as it lies on disk, undecoded.
+
+    Returns (raw uint8 array of nbytes, header, comments, info) with info =
+    dict(bitpix, shape, bscale, bzero, count).  ``out``: optional writable uint8 buffer
+    (e.g. pinned memory) of at least nbytes to read into.  Decoding is left to
+    ``zm_fits_decode_dev`` on the device (``device.load_fits``)."""
+    header, comments, off = read_header(path)
+    naxis = int(header.get('NAXIS', 0))
+    if naxis == 0:
+        raise ValueError(f'{path}: no image data in the primary HDU')
+    shape = tuple(int(header[f'NAXIS{i}']) for i in range(naxis, 0, -1))
+    bitpix = int(header['BITPIX'])
+    if bitpix not in _BITPIX_DTYPE:
+        raise ValueError(f'{path}: unsupported BITPIX {bitpix}')
+    count = int(np.prod(shape))
+    nbytes = count * abs(bitpix) // 8
+    if out is None:
+        out = np.empty(nbytes, dtype=np.uint8)
+    buf = memoryview(out)[:nbytes]
+    with open(path, 'rb', buffering=0) as f:
+        f.seek(off)
+        got = 0
+        while got < nbytes:
+            k = f.readinto(buf[got:])
+            if not k:
+                raise ValueError(f'{path}: truncated FITS data ({got} of {nbytes} bytes)')
+            got += k
+    info = dict(bitpix=bitpix, shape=shape, count=count, nbytes=nbytes,
+                bscale=float(header.get('BSCALE', 1)), bzero=float(header.get('BZERO', 0)))
+    return out[:nbytes], header, comments, info
+
+
+def header_block(data_shape, bitpix, header=None, comments=None, extra=()):
+    """The padded header bytes ``write`` would emit for an array of this shape / BITPIX."""
+    header = dict(header or {})
+    comments = comments or {}
+    cards = [_card('SIMPLE', True, 'conforms to FITS standard'),
+             _card('BITPIX', bitpix, 'array data type'),
+             _card('NAXIS', len(data_shape), 'number of array dimensions')]
+    for i, n in enumerate(reversed(tuple(data_shape))):
+        cards.append(_card(f'NAXIS{i + 1}', int(n)))
+    skip = set(_MANDATORY) | {'BSCALE', 'BZERO', 'END'} | {f'NAXIS{i}' for i in range(1, 10)}
+    for k, v, c in extra:
+        cards.append(_card(k, v, c))
+    for k, v in header.items():
+        ku = str(k).upper()
+        if ku in skip or v is None:
+            continue
+        if not isinstance(v, (int, float, str, bool, np.integer, np.floating, np.bool_)):
+            continue
+        cards.append(_card(ku, v, comments.get(k, '') or ''))
+    cards.append('END'.ljust(80))
+    hdr = ''.join(cards).encode('ascii', 'replace')
+    return hdr + b' ' * (-len(hdr) % BLOCK)
+
+
+def write_raw(path, raw, data_shape, bitpix, header=None, comments=None):
+    """Write a primary HDU from an already encoded (big-endian) data block."""
+    raw = memoryview(raw)
+    with open(path, 'wb') as f:
+        f.write(header_block(data_shape, bitpix, header, comments))
+        f.write(raw)
+        f.write(b'\0' * (-raw.nbytes % BLOCK))
+
+
 def _fmt_value(v):
     if isinstance(v, (bool, np.bool_)):
         return f"{'T' if v else 'F':>20}"
@@ -180,24 +246,7 @@ def write(path, data, header=None, comments=None):
         data = data.astype(np.int16)
     else:
         raise ValueError(f'cannot write dtype {kind} to FITS')
-    cards = [_card('SIMPLE', True, 'conforms to FITS standard'),
-             _card('BITPIX', bitpix, 'array data type'),
-             _card('NAXIS', data.ndim, 'number of array dimensions')]
-    for i, n in enumerate(reversed(data.shape)):
-        cards.append(_card(f'NAXIS{i + 1}', int(n)))
-    skip = set(_MANDATORY) | {'BSCALE', 'BZERO', 'END'} | {f'NAXIS{i}' for i in range(1, 10)}
-    for k, v, c in extra:
-        cards.append(_card(k, v, c))
-    for k, v in header.items():
-        ku = str(k).upper()
-        if ku in skip or v is None:
-            continue
-        if not isinstance(v, (int, float, str, bool, np.integer, np.floating, np.bool_)):
-            continue
-        cards.append(_card(ku, v, comments.get(k, '') or ''))
-    cards.append('END'.ljust(80))
-    hdr = ''.join(cards).encode('ascii', 'replace')
-    hdr += b' ' * (-len(hdr) % BLOCK)
+    hdr = header_block(data.shape, bitpix, header, comments, extra)
     raw = np.ascontiguousarray(data).astype(np.dtype(_BITPIX_DTYPE[bitpix])).tobytes()
     with open(path, 'wb') as f:
         f.write(hdr)
