@@ -82,6 +82,10 @@ class DeviceCoadd(object):
     def run(self, dframes, partial=False):
         """Enqueue resample + combine of ``dframes`` (a DeviceFrames)."""
         L = self.engine.L
+        # several device-side objects may share one engine: each binds it to its own stream
+        # before enqueueing, and waits for whatever the caller's current stream produced
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
         with self.torch.cuda.stream(self.stream):
             check(L.zm_coadd_dev(self.engine.ctx, dframes.n, dframes.arr,
                                  C.byref(self.wout), C.byref(self.params),
@@ -171,6 +175,7 @@ class DeviceSubtraction(object):
         L, ctx = self.engine.L, self.engine.ctx
         ny, nx = self.shape
         LAN = _lib.RESAMPLE['LANCZOS3']
+        self.engine.set_stream(self.stream.cuda_stream)
         with self.torch.cuda.stream(self.stream):
             # ref.aligned_to(sci): image (WEIGHT_TYPE NONE) + mask (OR), fitsfile.py:290-314
             check(L.zm_resample_dev(ctx, ref.data_ptr(), None, ref_mask.data_ptr(),
@@ -270,6 +275,7 @@ class FITSDeviceIO(object):
         raw, hdr, _, info = fits.read_raw(path, out=pin.numpy())
         dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8}[kind]
         out = torch.empty(info['shape'], dtype=dt, device=self.device)
+        self.engine.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             d_raw = pin[:info['nbytes']].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
@@ -298,6 +304,8 @@ class FITSDeviceIO(object):
             raise ValueError(f'cannot write {t.dtype} to FITS from the device')
         nbytes = t.numel() * abs(bp) // 8
         k, pin = self._staging(nbytes)
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             d_raw = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             check(self.engine.L.zm_fits_encode_dev(self.engine.ctx, t.data_ptr(), kind, t.numel(),
@@ -320,4 +328,7 @@ class FITSDeviceIO(object):
             if mask_paths is not None and mask_paths[i] is not None:
                 f['mask'] = self.load(mask_paths[i], 'i32')[0]
             frames.append(f)
+        # consumers on other streams order against the loads through the current stream
+        torch = self.torch
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return DeviceFrames(frames, self.device), frames
