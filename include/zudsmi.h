@@ -274,6 +274,28 @@ int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, float value,
 /* img += v: the 150-count pedestal (zuds/coadd.py:205-206, zuds/hotpants.py:29). */
 int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n);
 
+/* ---- seeing estimate and detection cuts from pixels -------------------------- */
+/* Pixel-only stand-ins for the parts of estimate_seeing (zuds/seeing.py:10-118) and
+ * filter_sexcat (zuds/filterobjects.py:57-195) that the reference feeds from SExtractor
+ * catalogs and Gaia queries.
+ * zm_find_stars: isolated local maxima (strict over the (2 isolation + 1)^2 box, ties to the
+ *   first pixel in raster order) with thresh_lo < peak < thresh_hi, no bad (bad[] != 0) or
+ *   NaN pixel in the box, at least `border` pixels from the edges.  Unordered; *out_n is the
+ *   number found (may exceed max_out: only max_out are returned).
+ * zm_star_fwhm: FWHM (pixels) and centroid of each star from adaptive Gaussian-weighted
+ *   second moments in a (2 half + 1)^2 window; NaN when the iteration fails.
+ * zm_negpix_test: out_bad[k] = 1 when the 11 x 11 cutout around (X_IMAGE, Y_IMAGE) (1-based)
+ *   holds a pixel below median - 5 sigma with a 3 x 3 neighbour above median + 5 sigma. */
+int zm_find_stars(zm_ctx* ctx, const float* img, const uint8_t* bad, int nx, int ny,
+                  float thresh_lo, float thresh_hi, int isolation, int border,
+                  int max_out, int* out_x, int* out_y, float* out_peak, int* out_n);
+int zm_star_fwhm(zm_ctx* ctx, const float* img, int nx, int ny, int nstar,
+                 const int* x, const int* y, int half, double* out_fwhm,
+                 double* out_cx, double* out_cy);
+int zm_negpix_test(zm_ctx* ctx, const float* img, int nx, int ny, int npos,
+                   const double* x, const double* y, double median, double sigma,
+                   int32_t* out_bad);
+
 /* ---- FITS data blocks on the device ------------------------------------------ */
 /* Replaces the host-side decode / encode astropy does inside FITSFile.load_data / save
  * (zuds/fitsfile.py:69-94,146-206): raw_dev holds the big-endian data block of a primary

@@ -22,6 +22,8 @@ from .coadd import *
 from .subtraction import *
 from .mpi import *
 from .photometry import *
+from .seeing import *
+from .filterobjects import *
 from . import synth, fits
 
 # same DB-free entry points as the reference

@@ -15,7 +15,7 @@ LIBDIR = HERE / 'lib'
 LIBNAME = 'libzudsmi.so'
 
 SOURCES = ['ctx.hip', 'wcs_host.hip', 'resample.hip', 'combine.hip',
-           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip']
+           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip', 'detect.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']
 EXTRA_FLAGS = {}     # per-source additions, e.g. {'x.hip': ['-mllvm', '...']}

@@ -112,14 +112,18 @@ def _coadd_from_images(cls, images, outname=None, data_product=False, tmpdir='/t
         coadd.header_comments['MJD-OBS'] = 'Median MJD of the coadd inputs (DG)'
     coadd.save()
     coaddmask.save()
-    if calculate_seeing and 'SEEING' not in coadd.header:
-        # the reference measures the seeing from a source catalog matched to Gaia
-        # (zuds/seeing.py:10-118, network); keep the inputs' median FWHM instead
-        see = [i.header['SEEING'] for i in images if 'SEEING' in i.header]
-        if see:
-            coadd.header['SEEING'] = float(np.median(see))
-            coadd.header_comments['SEEING'] = 'Median SEEING of the coadd inputs (pixels)'
-            coadd.save()
+    if calculate_seeing:
+        # zuds/coadd.py:225-226; the stars come from the pixels instead of a Gaia match
+        # (seeing.py).  A coadd without a usable star keeps the inputs' median FWHM.
+        from .seeing import estimate_seeing
+        try:
+            estimate_seeing(coadd)
+        except RuntimeError:
+            see = [i.header['SEEING'] for i in images if 'SEEING' in i.header]
+            if see:
+                coadd.header['SEEING'] = float(np.median(see))
+                coadd.header_comments['SEEING'] = 'Median SEEING of the coadd inputs (pixels)'
+                coadd.save()
     if data_product:
         warnings.warn('data_product=True: archiving is not part of this package')
     return coadd

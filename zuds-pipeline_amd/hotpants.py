@@ -69,9 +69,10 @@ def prepare_hotpants(sci, ref, outname, submask, directory, tmpdir='/tmp',
     else:
         scimbkg = sci
     if 'SEEING' not in sci.header:
-        raise ValueError(f'"{sci.basename}" has no SEEING keyword; estimating it needs '
-                         f'a source catalog and Gaia (zuds/seeing.py), outside this path. '
-                         f'Set header["SEEING"] (FWHM in pixels) and retry.')
+        # zuds/hotpants.py:38-42: measured here from the pixels (seeing.py)
+        from .seeing import estimate_seeing
+        estimate_seeing(sci)
+        sci.save()
     seepix = sci.header['SEEING']   # header seeing is FWHM in pixels
     r = 2.5 * seepix
     rss = 6. * seepix
