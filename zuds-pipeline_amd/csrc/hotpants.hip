@@ -979,7 +979,7 @@ template <int HWK> struct apply_cfg {
 };
 
 template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, int reg,
+__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long long solved_mask,
                                                   const float* __restrict__ sci,
                                                   const float* __restrict__ ref,
                                                   const float* __restrict__ srms,
@@ -987,10 +987,12 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, int reg,
                                                   const uint8_t* __restrict__ outbad,
                                                   const double* __restrict__ basis,   // [nc][STEP*STEP]
                                                   const double* __restrict__ xsol,
-                                                  int solved,
                                                   float* __restrict__ diff,
                                                   float* __restrict__ noise,
                                                   int* __restrict__ nmasked) {
+    // every region in one launch: blockIdx.z = region (the grid covers the largest one)
+    const int reg = blockIdx.z;
+    const int solved = (int)((solved_mask >> reg) & 1ull);
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
     constexpr int TW = NB * STEP + 2 * HWK;   // tile width
@@ -1004,6 +1006,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, int reg,
     const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
     const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
     const int gy0 = y0r + blockIdx.y * STEP;
+    if (gx0 >= x1r || gy0 >= y1r) return;              // beyond this (smaller) region
     const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
     const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
     const double* x = xsol + (size_t)reg * P.nunk;
@@ -1209,10 +1212,10 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
 }
 
 template <int HWK>
-static int launch_apply(zm_ctx* ctx, const hp_plan& P, int reg, const float* sci, const float* ref,
-                        const float* srms, const float* trms, const uint8_t* outbad,
-                        const double* basis, const double* xsol, int solved, float* diff,
-                        float* noise, int* nmasked) {
+static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved_mask, const float* sci,
+                        const float* ref, const float* srms, const float* trms, const uint8_t* outbad,
+                        const double* basis, const double* xsol, float* diff, float* noise,
+                        int* nmasked) {
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, NB = C::NB;
     constexpr int TW = NB * STEP + 2 * HWK, TH = STEP + 2 * HWK;
@@ -1224,10 +1227,14 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, int reg, const float* sci
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         set = true;
     }
-    int W = P.rx1[reg] - P.rx0[reg], H = P.ry1[reg] - P.ry0[reg];
-    dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), 1);
-    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, reg, sci, ref, srms,
-                       trms, outbad, basis, xsol, solved, diff, noise, nmasked);
+    int W = 0, H = 0;
+    for (int reg = 0; reg < P.nreg; ++reg) {
+        W = std::max(W, P.rx1[reg] - P.rx0[reg]);
+        H = std::max(H, P.ry1[reg] - P.ry0[reg]);
+    }
+    dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
+    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
+                       trms, outbad, basis, xsol, diff, noise, nmasked);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -1412,10 +1419,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_HIP(hipStreamSynchronize(st));
     {
         zm_scope_timer t(ctx, "hp_apply");
-        for (int reg = 0; reg < P.nreg; ++reg) {
-            int solved = (h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
-                          std::isfinite(h_x[(size_t)reg * P.nunk])) ? 1 : 0;
-#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, reg, sci, ref, sci_rms, ref_rms, outbad, d_basis, rhs, solved, out_diff, out_rms, nmasked)); break;
+        unsigned long long solved_mask = 0;
+        for (int reg = 0; reg < P.nreg; ++reg)
+            if (h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
+                std::isfinite(h_x[(size_t)reg * P.nunk]))
+                solved_mask |= 1ull << reg;
+        {
+#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_basis, rhs, out_diff, out_rms, nmasked)); break;
             switch (P.hwk) {
                 HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
                 HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)

@@ -11,7 +11,14 @@ _hip = None
 def hip():
     global _hip
     if _hip is None:
-        _hip = C.CDLL('libamdhip64.so')
+        # the HIP runtime libzudsmi runs on (one copy per process, see _lib._one_hip_runtime):
+        # asking for the SONAME returns the copy that is already loaded
+        from . import _lib
+        _lib.lib()
+        try:
+            _hip = C.CDLL('libamdhip64.so.7')
+        except OSError:
+            _hip = C.CDLL('libamdhip64.so')
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip.hipFree.argtypes = [C.c_void_p]
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
