@@ -188,6 +188,14 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
 // need[cell] = vectors / Gram must be (re)computed this round.
 // X layout: [cell][nX][npixp] fp64, rows 0..nc-1 kernel vectors, nc..nE-1
 // background terms, nE the science pixels; columns >= npix are zero.
+// x^n for the small non-negative integer exponents of the spatial polynomials: a handful of
+// multiplications instead of the ~200 instructions of a general fp64 pow()
+__device__ inline double ipowd(double x, int n) {
+    double r = 1.0;
+    for (int k = 0; k < n; ++k) r *= x;
+    return r;
+}
+
 #define HV_R 8     // outputs per thread along the filter direction (register sliding window)
 // Workgroups per cell (blockIdx.y): the x filters in use are dealt round-robin, each
 // workgroup runs its x passes and the y passes of the terms built on them.  After the first
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             vs += a * a + b * b;
             double xf = (x - xc) / hx, yf = (y - yc) / hy;
             for (int q = 0; q < P.nbg; ++q)
-                Xc[(size_t)(P.nc + q) * P.npixp + k] = pow(xf, (double)P.bpi[q]) * pow(yf, (double)P.bpj[q]);
+                Xc[(size_t)(P.nc + q) * P.npixp + k] = ipowd(xf, P.bpi[q]) * ipowd(yf, P.bpj[q]);
         } else {
             for (int q = 0; q < P.nX; ++q) Xc[(size_t)q * P.npixp + k] = 0.0;
         }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         vbar[cell] = vs / P.npix;
         double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
         for (int p = 0; p < P.nkp; ++p)
-            phi[(size_t)cell * P.nkp + p] = pow(fx, (double)P.kpi[p]) * pow(fy, (double)P.kpj[p]);
+            phi[(size_t)cell * P.nkp + p] = ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
     }
     __syncthreads();
     const int nstrip = (sw + HV_R - 1) / HV_R;
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
         else {
             v = 0.0;
             for (int p = 0; p < P.nkp; ++p)
-                v += x[1 + (n - 1) * P.nkp + p] * pow(fx, (double)P.kpi[p]) * pow(fy, (double)P.kpj[p]);
+                v += x[1 + (n - 1) * P.nkp + p] * ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
         }
         cf[e] = v;
     }
@@ -1090,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
             double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
             double bg = 0.0;
             for (int t = 0; t < P.nbg; ++t)
-                bg += bgc[t] * pow(xf, (double)P.bpi[t]) * pow(yf, (double)P.bpj[t]);
+                bg += bgc[t] * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
             float sr = srms[idx];
             d = (sci[idx] - accT[q] - (float)bg) * norm;
             nz = sqrtf(fmaxf(sr * sr + accV[q], 0.f)) * fabsf(norm);
