@@ -381,6 +381,18 @@ __global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const bk_batch 
     sig = var > 0 ? sqrt(var) : 0.0;
     const bk_quant q = make_quant(mean, sig, s0);
     if (dbg == 2) { if (sig == 12345.0) dump[0].valid = 7; return; }
+    if (sig == 0.0) {
+        // a constant mesh (flat variance maps, most of the time): qscale = 1 and every pixel
+        // falls into bin 0, so backguess returns exactly qzero = (float)mean and sigma 0 -
+        // no histogram, no prefix arrays, no dump
+        if (tid == 0) {
+            mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
+            D->q = q;
+            D->mean0 = (double)(float)mean;
+            D->valid = 2;
+        }
+        return;
+    }
     // ---- histogram.  bin = (int)(x / qscale + cste) with a correctly rounded quotient:
     // y = RN(1 / qscale), q0 = RN(x y), r = RN(x - q0 qscale), q = RN(q0 + r y) is the
     // correctly rounded x / qscale (Markstein) unless the significand of qscale is all
@@ -478,6 +490,10 @@ __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__
     float* os = ob + n;
     if (!D->valid) {
         if (lane == 0) { *ob = -BK_BIG; *os = -BK_BIG; }
+        return;
+    }
+    if (D->valid == 2) {                 // constant mesh: see k_mesh_stats_fast
+        if (lane == 0) { *ob = D->q.qzero; *os = 0.f; }
         return;
     }
     const int4* src = reinterpret_cast<const int4*>(D->p0);
