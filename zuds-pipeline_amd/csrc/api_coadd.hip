@@ -131,10 +131,11 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
         }
         float2* src = nullptr;
         ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
-        ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size,
-                              vscale, wthresh, src, spitch));
         // the mask rides along with its frame: same tile, same positions
         const bool with_mask = acc_mask && fr[i].mask;
+        ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size,
+                              vscale, wthresh, src, spitch, with_mask ? fr[i].mask : nullptr,
+                              ntaps_of(P->resample)));
         ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat + (size_t)i * lnx * lny, lnx, lny,
                                   P->resample, (float)fscale[i], stack + (size_t)i * opix, onx,
                                   ony, lds[i], fr[i].mask, acc_mask, with_mask ? 2 : 0, mask_kind,

@@ -117,18 +117,10 @@ __device__ inline float bk_eval(const float* __restrict__ bk, int nbx, int nby, 
     return dx1 * r0 + dx * r1 + cdx1 * e0 + cdx * e1;
 }
 
-__global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
-                                              const float* __restrict__ wgt, int nx, int ny,
-                                              const float* __restrict__ bk, int nbx, int nby,
-                                              float invmesh,
-                                              const float* __restrict__ var_scale_dev,
-                                              float wthresh, float2* __restrict__ dst,
-                                              int spitch) {
-    int xp = blockIdx.x * blockDim.x + threadIdx.x;   // pixel pair index
-    int y = blockIdx.y;
-    int x = xp * 2;
-    if (x >= spitch) return;
-    const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
+// one pair of prepped pixels (x even): {value, variance, value, variance}
+__device__ inline float4 prep_pair(const float* __restrict__ img, const float* __restrict__ wgt, int nx,
+                                   const float* __restrict__ bk, int nbx, int nby, float invmesh,
+                                   float var_scale, float wthresh, int x, int y) {
     float2 o[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -148,19 +140,23 @@ __global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
             o[k] = make_float2(0.f, ZM_BIGVAR);
         }
     }
-    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)y * spitch + x);
-    *d4 = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    return make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
 }
 
-int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
-                   const float* bknodes, int nbx, int nby, int mesh, const float* var_scale_dev,
-                   float wthresh, float2* dst, int spitch) {
-    dim3 blk(256, 1, 1), grd(zm_div_up(spitch / 2, 256), ny, 1);
-    zm_scope_timer t(ctx, "prep");
-    hipLaunchKernelGGL(k_prep, grd, blk, 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx, nby,
-                       mesh > 0 ? 1.0f / mesh : 0.f, var_scale_dev, wthresh, dst, spitch);
-    ZM_HIP(hipGetLastError());
-    return 0;
+__global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
+                                              const float* __restrict__ wgt, int nx, int ny,
+                                              const float* __restrict__ bk, int nbx, int nby,
+                                              float invmesh,
+                                              const float* __restrict__ var_scale_dev,
+                                              float wthresh, float2* __restrict__ dst,
+                                              int spitch) {
+    int xp = blockIdx.x * blockDim.x + threadIdx.x;   // pixel pair index
+    int y = blockIdx.y;
+    int x = xp * 2;
+    if (x >= spitch) return;
+    const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)y * spitch + x);
+    *d4 = prep_pair(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, x, y);
 }
 
 // ---------------------------------------------------------------------------
@@ -419,6 +415,84 @@ __global__ __launch_bounds__(256) void k_mask_box(const int32_t* __restrict__ m,
     }
 }
 
+// k_prep and k_mask_box of one frame in one launch (one 64 x 16 tile of input pixels per
+// workgroup): a stack is launch-gap bound between its three per-frame kernels.
+template <int NT>
+__global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
+                                                  const float* __restrict__ wgt, int nx, int ny,
+                                                  const float* __restrict__ bk, int nbx, int nby,
+                                                  float invmesh, const float* __restrict__ var_scale_dev,
+                                                  float wthresh, float2* __restrict__ dst, int spitch,
+                                                  const int32_t* __restrict__ m, int32_t* __restrict__ B) {
+    constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
+    __shared__ int32_t t0[IH * IP];
+    __shared__ int32_t h[IH * TWB];
+    const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int r = e / IW, c = e - r * IW;
+        const int x = x0 + c, y = y0 + r;
+        t0[r * IP + c] = (x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+    }
+    // the prep of this tile while the mask loads are in flight: 512 pixel pairs
+    const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
+    for (int e = tid; e < THB * TWB / 2; e += 256) {
+        const int r = e / (TWB / 2), x = x0 + 2 * (e - r * (TWB / 2)), y = y0 + r;
+        if (y < ny && x < spitch)
+            *reinterpret_cast<float4*>(dst + (size_t)y * spitch + x) =
+                prep_pair(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, x, y);
+    }
+    __syncthreads();
+    for (int e = tid; e < IH * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        int32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) o |= t0[r * IP + c + k];
+        h[e] = o;
+    }
+    __syncthreads();
+    for (int e = tid; e < THB * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        const int x = x0 + c, y = y0 + r;
+        if (x + NT <= nx && y + NT <= ny) {
+            int32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
+            B[(size_t)y * nx + x] = o;
+        }
+    }
+}
+
+// mask_for_box != NULL (box_nt = taps of the resampling kernel, 6 or 2): also fill the
+// "mask_box" scratch plane for the zm_launch_resample call that follows
+int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
+                   const float* bknodes, int nbx, int nby, int mesh, const float* var_scale_dev,
+                   float wthresh, float2* dst, int spitch, const int32_t* mask_for_box, int box_nt) {
+    const float invmesh = mesh > 0 ? 1.0f / mesh : 0.f;
+    ctx->box_ready_for = nullptr;
+    if (mask_for_box && (box_nt == 6 || box_nt == 2)) {
+        int32_t* mbox = nullptr;
+        ZM_TRY(ctx->get("mask_box", sizeof(int32_t) * (size_t)nx * ny, (void**)&mbox));
+        dim3 grd(zm_div_up(spitch, 64), zm_div_up(ny, 16), 1);
+        zm_scope_timer t(ctx, "prep");
+        if (box_nt == 6)
+            hipLaunchKernelGGL(k_prep_box<6>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
+                               nby, invmesh, var_scale_dev, wthresh, dst, spitch, mask_for_box, mbox);
+        else
+            hipLaunchKernelGGL(k_prep_box<2>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
+                               nby, invmesh, var_scale_dev, wthresh, dst, spitch, mask_for_box, mbox);
+        ZM_HIP(hipGetLastError());
+        ctx->box_ready_for = mask_for_box;
+        ctx->box_ready_nt = box_nt;
+        return 0;
+    }
+    dim3 blk(256, 1, 1), grd(zm_div_up(spitch / 2, 256), ny, 1);
+    zm_scope_timer t(ctx, "prep");
+    hipLaunchKernelGGL(k_prep, grd, blk, 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx, nby, invmesh,
+                       var_scale_dev, wthresh, dst, spitch);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int KIND, int MASKOP>
 __global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
@@ -637,9 +711,12 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
     if (mop) {
         constexpr int NT = taps_traits<KIND>::N;
         ZM_TRY(ctx->get("mask_box", sizeof(int32_t) * (size_t)nx * ny, (void**)&mbox));
-        zm_scope_timer tb(ctx, "mask_box");
-        hipLaunchKernelGGL(k_mask_box<NT>, dim3(zm_div_up(nx, 64), zm_div_up(ny, 16)), blk, 0, ctx->stream,
-                           mask, nx, ny, mbox);
+        if (ctx->box_ready_for != (const void*)mask || ctx->box_ready_nt != NT) {
+            zm_scope_timer tb(ctx, "mask_box");
+            hipLaunchKernelGGL(k_mask_box<NT>, dim3(zm_div_up(nx, 64), zm_div_up(ny, 16)), blk, 0, ctx->stream,
+                               mask, nx, ny, mbox);
+        }
+        ctx->box_ready_for = nullptr;
     }
     zm_scope_timer t(ctx, "resample");
     // persistent grid: a few workgroups per CU, each walking ntiles / G tiles

@@ -57,6 +57,10 @@ struct zm_ctx {
     std::map<std::string, std::pair<void*, size_t>> pinned;
     hipStream_t aux = nullptr;                 // second stream: background statistics run beside resampling
     std::vector<hipEvent_t> sync_events;       // cross-stream ordering (no timing)
+    // set by zm_launch_prep when it also produced the box-OR plane of a mask (scratch slot
+    // "mask_box"): zm_launch_resample then skips its own k_mask_box launch
+    const void* box_ready_for = nullptr;
+    int box_ready_nt = 0;
     bool timing = false;
     std::map<std::string, zm_timer_slot> timers;
     std::vector<hipEvent_t> event_pool;
@@ -98,7 +102,8 @@ int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, in
                             double2* lat_dev);
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh,
-                   const float* var_scale_dev, float wthresh, float2* dst, int spitch);
+                   const float* var_scale_dev, float wthresh, float2* dst, int spitch,
+                   const int32_t* mask_for_box = nullptr, int box_nt = 0);
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
