@@ -67,19 +67,7 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     const int64_t opix = (int64_t)onx * ony;
     const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
 
-    std::vector<zm_map_params> mp_host(n);
-    std::vector<double> fscale(n);
-    std::vector<int> lds(n);
-    for (int i = 0; i < n; ++i) {
-        ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
-        zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
-        ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fscale[i]));
-        lds[i] = plan_lds(&mp_host[i], onx, ony, ntaps_of(P->resample));
-    }
-    double2* lat = nullptr;
-    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
-
-    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat));
+    for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
 
     // Phase 1: mesh statistics, filter and variance rescale of every frame, batched over runs
     // of equally sized frames (one launch each per run instead of one per frame: the
@@ -117,6 +105,20 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
         }
         i0 = i1;
     }
+    // The maps, flux scales and LDS plans are host work (fp64 TPV inversions): done here, while
+    // the GPU runs phase 1, not before the first launch.
+    std::vector<zm_map_params> mp_host(n);
+    std::vector<double> fscale(n);
+    std::vector<int> lds(n);
+    for (int i = 0; i < n; ++i) {
+        zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
+        ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fscale[i]));
+        lds[i] = plan_lds(&mp_host[i], onx, ony, ntaps_of(P->resample));
+    }
+    double2* lat = nullptr;
+    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
+    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat));
+
     bool first_mask = true;
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1];

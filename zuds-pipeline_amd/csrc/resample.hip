@@ -117,30 +117,90 @@ __device__ inline float bk_eval(const float* __restrict__ bk, int nbx, int nby, 
     return dx1 * r0 + dx * r1 + cdx1 * e0 + cdx * e1;
 }
 
-// one pair of prepped pixels (x even): {value, variance, value, variance}
-__device__ inline float4 prep_pair(const float* __restrict__ img, const float* __restrict__ wgt, int nx,
-                                   const float* __restrict__ bk, int nbx, int nby, float invmesh,
-                                   float var_scale, float wthresh, int x, int y) {
-    float2 o[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int xx = x + k;
-        if (xx < nx) {
-            size_t idx = (size_t)y * nx + xx;
-            float v = img[idx];
-            if (bk) v -= bk_eval(bk, nbx, nby, invmesh, xx, y);
-            float var = var_scale;
-            if (wgt) {
-                float w = wgt[idx];
-                var = (w > wthresh) ? var_scale / w : ZM_BIGVAR;
-            }
-            if (!(v == v)) { v = 0.f; var = ZM_BIGVAR; }   // NaN pixels are bad
-            o[k] = make_float2(v, var);
-        } else {
-            o[k] = make_float2(0.f, ZM_BIGVAR);
-        }
+// Background of four consecutive pixels of a row (x a multiple of 4).  The y part of the
+// tensor-product spline (4 x 4 node loads, 16 FMAs) is shared when the four pixels lie in one
+// mesh column, which they always do when BACK_SIZE is a multiple of 8.
+__device__ inline void bk_eval4(const float* __restrict__ bk, int nbx, int nby, float invmesh, int x,
+                                int y, float out[4]) {
+    const float tx0 = (x + 0.5f) * invmesh - 0.5f, tx3 = (x + 3.5f) * invmesh - 0.5f;
+    int i0 = 0, i3 = 0;
+    if (nbx > 1) {
+        i0 = min(max((int)floorf(tx0), 0), nbx - 2);
+        i3 = min(max((int)floorf(tx3), 0), nbx - 2);
     }
-    return make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    if (i0 != i3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = bk_eval(bk, nbx, nby, invmesh, x + k, y);
+        return;
+    }
+    const size_t pl = (size_t)nbx * nby;
+    const float ty = (y + 0.5f) * invmesh - 0.5f;
+    int j0 = 0;
+    float dy = 0.f;
+    if (nby > 1) {
+        j0 = min(max((int)floorf(ty), 0), nby - 2);
+        dy = ty - j0;
+    }
+    const int j1 = nby > 1 ? j0 + 1 : j0, i1 = nbx > 1 ? i0 + 1 : i0;
+    const float dy1 = 1.f - dy;
+    const float cdy = dy * dy * dy - dy, cdy1 = dy1 * dy1 * dy1 - dy1;
+    const float* V = bk;
+    const float* DY = bk + pl;
+    const float* A = bk + 2 * pl;
+    const float* B = bk + 3 * pl;
+    const int a00 = j0 * nbx + i0, a01 = j0 * nbx + i1, a10 = j1 * nbx + i0, a11 = j1 * nbx + i1;
+    const float r0 = dy1 * V[a00] + dy * V[a10] + cdy1 * DY[a00] + cdy * DY[a10];
+    const float r1 = dy1 * V[a01] + dy * V[a11] + cdy1 * DY[a01] + cdy * DY[a11];
+    const float e0 = dy1 * A[a00] + dy * A[a10] + cdy1 * B[a00] + cdy * B[a10];
+    const float e1 = dy1 * A[a01] + dy * A[a11] + cdy1 * B[a01] + cdy * B[a11];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float dx = 0.f;
+        if (nbx > 1) dx = ((x + k) + 0.5f) * invmesh - 0.5f - i0;
+        const float dx1 = 1.f - dx;
+        const float cdx = dx * dx * dx - dx, cdx1 = dx1 * dx1 * dx1 - dx1;
+        out[k] = dx1 * r0 + dx * r1 + cdx1 * e0 + cdx * e1;
+    }
+}
+
+// four prepped pixels (x a multiple of 4): two float4 {value, variance, value, variance}
+__device__ inline void prep_quad(const float* __restrict__ img, const float* __restrict__ wgt, int nx,
+                                 const float* __restrict__ bk, int nbx, int nby, float invmesh,
+                                 float var_scale, float wthresh, int vec_ok, int x, int y, float4 o[2]) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {1.f, 1.f, 1.f, 1.f};
+    const size_t idx = (size_t)y * nx + x;
+    if (vec_ok && x + 3 < nx) {
+        const float4 a = *reinterpret_cast<const float4*>(img + idx);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        if (wgt) {
+            const float4 b = *reinterpret_cast<const float4*>(wgt + idx);
+            w[0] = b.x; w[1] = b.y; w[2] = b.z; w[3] = b.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x + k < nx) {
+                v[k] = img[idx + k];
+                if (wgt) w[k] = wgt[idx + k];
+            }
+    }
+    float bg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bk) bk_eval4(bk, nbx, nby, invmesh, x, y, bg);
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float val = 0.f, var = ZM_BIGVAR;
+        if (x + k < nx) {
+            val = v[k] - bg[k];
+            var = var_scale;
+            if (wgt) var = (w[k] > wthresh) ? var_scale / w[k] : ZM_BIGVAR;
+            if (!(val == val)) { val = 0.f; var = ZM_BIGVAR; }   // NaN pixels are bad
+        }
+        r[2 * k] = val;
+        r[2 * k + 1] = var;
+    }
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
 }
 
 __global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
@@ -148,15 +208,17 @@ __global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
                                               const float* __restrict__ bk, int nbx, int nby,
                                               float invmesh,
                                               const float* __restrict__ var_scale_dev,
-                                              float wthresh, float2* __restrict__ dst,
+                                              float wthresh, int vec_ok, float2* __restrict__ dst,
                                               int spitch) {
-    int xp = blockIdx.x * blockDim.x + threadIdx.x;   // pixel pair index
-    int y = blockIdx.y;
-    int x = xp * 2;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // pixel quad
+    const int y = blockIdx.y;
     if (x >= spitch) return;
     const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
+    float4 o[2];
+    prep_quad(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, vec_ok, x, y, o);
     float4* d4 = reinterpret_cast<float4*>(dst + (size_t)y * spitch + x);
-    *d4 = prep_pair(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, x, y);
+    d4[0] = o[0];
+    if (x + 2 < spitch) d4[1] = o[1];
 }
 
 // ---------------------------------------------------------------------------
@@ -422,8 +484,9 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
                                                   const float* __restrict__ wgt, int nx, int ny,
                                                   const float* __restrict__ bk, int nbx, int nby,
                                                   float invmesh, const float* __restrict__ var_scale_dev,
-                                                  float wthresh, float2* __restrict__ dst, int spitch,
-                                                  const int32_t* __restrict__ m, int32_t* __restrict__ B) {
+                                                  float wthresh, int vec_ok, float2* __restrict__ dst,
+                                                  int spitch, const int32_t* __restrict__ m,
+                                                  int32_t* __restrict__ B) {
     constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
@@ -433,13 +496,17 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
         const int x = x0 + c, y = y0 + r;
         t0[r * IP + c] = (x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
     }
-    // the prep of this tile while the mask loads are in flight: 512 pixel pairs
-    const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
-    for (int e = tid; e < THB * TWB / 2; e += 256) {
-        const int r = e / (TWB / 2), x = x0 + 2 * (e - r * (TWB / 2)), y = y0 + r;
-        if (y < ny && x < spitch)
-            *reinterpret_cast<float4*>(dst + (size_t)y * spitch + x) =
-                prep_pair(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, x, y);
+    // the prep of this tile while the mask loads are in flight: one pixel quad per thread
+    {
+        const float var_scale = var_scale_dev ? var_scale_dev[0] : 1.0f;
+        const int r = tid / (TWB / 4), x = x0 + 4 * (tid - r * (TWB / 4)), y = y0 + r;
+        if (y < ny && x < spitch) {
+            float4 o[2];
+            prep_quad(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, vec_ok, x, y, o);
+            float4* d4 = reinterpret_cast<float4*>(dst + (size_t)y * spitch + x);
+            d4[0] = o[0];
+            if (x + 2 < spitch) d4[1] = o[1];
+        }
     }
     __syncthreads();
     for (int e = tid; e < IH * TWB; e += 256) {
@@ -468,6 +535,7 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
                    const float* bknodes, int nbx, int nby, int mesh, const float* var_scale_dev,
                    float wthresh, float2* dst, int spitch, const int32_t* mask_for_box, int box_nt) {
     const float invmesh = mesh > 0 ? 1.0f / mesh : 0.f;
+    const int vec_ok = (nx % 4 == 0) && (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
     ctx->box_ready_for = nullptr;
     if (mask_for_box && (box_nt == 6 || box_nt == 2)) {
         int32_t* mbox = nullptr;
@@ -476,19 +544,19 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
         zm_scope_timer t(ctx, "prep");
         if (box_nt == 6)
             hipLaunchKernelGGL(k_prep_box<6>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
-                               nby, invmesh, var_scale_dev, wthresh, dst, spitch, mask_for_box, mbox);
+                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox);
         else
             hipLaunchKernelGGL(k_prep_box<2>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
-                               nby, invmesh, var_scale_dev, wthresh, dst, spitch, mask_for_box, mbox);
+                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox);
         ZM_HIP(hipGetLastError());
         ctx->box_ready_for = mask_for_box;
         ctx->box_ready_nt = box_nt;
         return 0;
     }
-    dim3 blk(256, 1, 1), grd(zm_div_up(spitch / 2, 256), ny, 1);
+    dim3 blk(256, 1, 1), grd(zm_div_up(zm_div_up(spitch, 4), 256), ny, 1);
     zm_scope_timer t(ctx, "prep");
     hipLaunchKernelGGL(k_prep, grd, blk, 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx, nby, invmesh,
-                       var_scale_dev, wthresh, dst, spitch);
+                       var_scale_dev, wthresh, vec_ok, dst, spitch);
     ZM_HIP(hipGetLastError());
     return 0;
 }
