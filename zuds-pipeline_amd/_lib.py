@@ -150,11 +150,15 @@ def exported_symbols():
 
 
 def _one_hip_runtime():
-    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as
-    /opt/rocm).  A process must run on ONE copy: if libzudsmi pulled in the system runtime
-    first, a later ``import torch`` + first CUDA call would find "No HIP GPUs".  So when torch
-    is installed but not imported yet, its runtime is loaded first and libzudsmi's NEEDED
-    entries resolve to it by SONAME - the same arrangement as with torch imported first."""
+    """One HIP runtime per process, initialised in one order.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as
+    /opt/rocm).  If libzudsmi pulls in the system runtime first, a later ``import torch`` finds
+    "No HIP GPUs"; pre-loading torch's copies fixes that, but a torch that initialises after
+    libzudsmi has already run kernels was seen to hang on MI355X (2 of 3 runs).  The one
+    arrangement that has been stable is torch first - so when torch is installed it is
+    imported here, before libzudsmi is loaded (ZM_NO_TORCH=1 skips this for torch-free use;
+    the device-resident classes of device.py / parallel.py need torch anyway)."""
     import importlib.util
     import os
     import sys
@@ -166,6 +170,12 @@ def _one_hip_runtime():
         spec = None
     if not spec or not spec.origin:
         return
+    if not os.environ.get('ZM_NO_TORCH'):
+        try:
+            import torch  # noqa: F401
+            return
+        except Exception:
+            pass
     d = os.path.join(os.path.dirname(spec.origin), 'lib')
     for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
         p = os.path.join(d, name)

@@ -645,13 +645,28 @@ __global__ __launch_bounds__(256, 4) void k_resample(
         if (tid < 64 && t + 2 * G < ntiles)
             rs_build_header<KIND>(lat, lnx, lny, t + 2 * G, ntx, nx, ny, lds_cap, &HR[nnslot]);
 
+        // the four pixels of a thread share their column: the x part of the bilinear lattice
+        // interpolation is done once, each pixel adds its row fraction (same operations and
+        // order as tile_position)
+        float pxa, pxd, pya, pyd;
+        {
+            const int cell = tx >> 4;
+            const float fx = (float)(tx & 15) * (1.f / LSTEP);
+            const float x00 = H->h.nrel[0][cell][0], x10 = H->h.nrel[0][cell + 1][0];
+            const float x01 = H->h.nrel[1][cell][0], x11 = H->h.nrel[1][cell + 1][0];
+            const float y00 = H->h.nrel[0][cell][1], y10 = H->h.nrel[0][cell + 1][1];
+            const float y01 = H->h.nrel[1][cell][1], y11 = H->h.nrel[1][cell + 1][1];
+            const float xa = x00 + fx * (x10 - x00), xb = x01 + fx * (x11 - x01);
+            const float ya = y00 + fx * (y10 - y00), yb = y01 + fx * (y11 - y01);
+            pxa = xa; pxd = xb - xa; pya = ya; pyd = yb - ya;
+        }
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const int ty = tyb + 4 * q;
             const int oy = oy0 + ty;
             if (ox >= onx || oy >= ony) continue;
-            float px, py;
-            tile_position(&H->h, tx, ty, &px, &py);
+            const float fy = (float)ty * (1.f / LSTEP);
+            const float px = pxa + fy * pxd, py = pya + fy * pyd;
             int ixr, iyr;
             float dx, dy;
             bool ddx, ddy;
