@@ -10,12 +10,14 @@
 //   k_hp_rowany / k_hp_colany   separable (2 hw + 1)^2 dilations of `bad`
 //   k_hp_cells      one workgroup per stamp cell: clipped sky/sigma, greedy
 //                   brightest-first substamp centres (argmax reductions)
-//   k_hp_vectors    one workgroup per cell: separable basis convolutions of the
+//   k_hp_vectors    5 workgroups per cell: separable basis convolutions of the
 //                   template patch held in LDS -> X [nX][npix] fp64
-//   k_hp_gram       one workgroup per cell: G = X X^T on v_mfma_f64_16x16x4_f64
-//                   (the normal-equation GEMM; LDS-staged operands)
+//   k_hp_gram       8 K-slices per cell: G = X X^T on v_mfma_f64_16x16x4_f64 (the
+//                   normal-equation GEMM; LDS-staged operands), k_hp_gram_sum adds them
 //   k_hp_build      global normal matrix of a region from the per-cell Grams
-//   k_chol_*        blocked Cholesky (NB = 32), forward / back substitution
+//   k_chol_fused    blocked Cholesky (NB = 32) of every region in one launch: region
+//                   barriers, MFMA trailing update, look-ahead diagonal factor
+//   k_chol_back     back substitution
 //   k_hp_merit / k_hp_reject    stamp figure of merit, sigma clip, next substamp
 //   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
 //                   fp32 convolution of template and template variance
@@ -470,16 +472,10 @@ __global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ r
     if (c2 == 0) Ar[(size_t)n * n + c1] = rhs[(size_t)reg * n + c1] / dd[c1];   // rhs row
 }
 
-// ---- blocked Cholesky, lower, in place, batched over blockIdx.z ------------------
-// The right-hand side rides along as row n of the (n + 1) x n lower-triangular
-// storage: factoring the augmented matrix leaves y = L^-1 b in that row, so the
-// forward substitution costs nothing extra.  One launch per 32-column block
-// (left-looking): every workgroup (a) applies all previous block columns to the
-// diagonal block and to its own 64 rows with an LDS-tiled fp64 GEMM, (b) factors
-// the 32 x 32 diagonal block (redundantly, one wave, no inter-workgroup
-// dependency), (c) solves its rows against it.
-#define CH_ROWS 64                      // panel rows per workgroup
-#define CH_KT 32                        // K tile of the update GEMM
+// ---- blocked Cholesky, lower, in place ------------------------------------------------
+// The right-hand side rides along as row n of the (n + 1) x n lower-triangular storage:
+// factoring the augmented matrix leaves y = L^-1 b in that row, so the forward substitution
+// costs nothing extra.  Block size 32; see k_chol_fused below.
 
 __device__ inline double readlane_d(double v, int src) {
     // src is wave-uniform (a compile-time constant after unrolling): v_readlane_b32 x 2
@@ -532,88 +528,6 @@ __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail)
         D[row][CH_NB] = 1.0 / readlane_dyn(a, row);
     }
     if (bad && lane == 0 && fail) atomicAdd(fail, 1);
-}
-
-// A: [reg][(n + 1)][n]; rows 0..n-1 lower triangle, row n = rhs / y.
-// Right-looking step, two launches per 32-column block so that the trailing
-// update runs on many workgroups:
-//   k_chol_panel  every workgroup factors the diagonal block (one wave, registers)
-//                 and solves 256 panel rows against it; workgroup 0 stores L11;
-//   k_chol_update A22 -= L21 L21^T on 64 x 64 tiles (lower triangle + rhs row).
-__global__ __launch_bounds__(256) void k_chol_panel(int n, int k0, double* __restrict__ Aall,
-                                                    int* __restrict__ fail) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    double* A = Aall + (size_t)blockIdx.z * (size_t)(n + 1) * n;
-    const int tid = threadIdx.x;
-    const int nb = min(CH_NB, n - k0);
-    const int nrows = n + 1;
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        int i = e >> 5, j = e & 31;
-        D[i][j] = (i < nb && j <= i && j < nb) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < 64) chol_diag_wave(D, nb, blockIdx.x == 0 ? &fail[blockIdx.z] : nullptr);
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            int i = e >> 5, j = e & 31;
-            if (i < nb && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = D[i][j];
-        }
-    const int row = k0 + nb + blockIdx.x * 256 + tid;
-    if (row >= nrows) return;
-    double x[CH_NB];
-    double* ar = A + (size_t)row * n + k0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ar[j] : 0.0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        if (j < nb) {
-            double v = x[j];
-#pragma unroll
-            for (int m = 0; m < CH_NB; ++m)
-                if (m < j) v -= x[m] * D[j][m];
-            x[j] = v * D[j][CH_NB];            // reciprocal diagonal (padding column)
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j)
-        if (j < nb) ar[j] = x[j];
-}
-
-__global__ __launch_bounds__(256) void k_chol_update(int n, int k0, double* __restrict__ Aall) {
-    __shared__ double Li[64][CH_NB + 1];
-    __shared__ double Lj[64][CH_NB + 1];
-    if (blockIdx.x > blockIdx.y) return;
-    double* A = Aall + (size_t)blockIdx.z * (size_t)(n + 1) * n;
-    const int nrows = n + 1;
-    const int t0 = k0 + CH_NB;
-    const int i0 = t0 + blockIdx.y * 64, j0 = t0 + blockIdx.x * 64;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * CH_NB; e += 256) {
-        int r = e >> 5, m = e & 31;
-        Li[r][m] = (i0 + r < nrows) ? A[(size_t)(i0 + r) * n + k0 + m] : 0.0;
-        Lj[r][m] = (j0 + r < n) ? A[(size_t)(j0 + r) * n + k0 + m] : 0.0;
-    }
-    __syncthreads();
-    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
-    double acc[4][4] = {};
-#pragma unroll 8
-    for (int m = 0; m < CH_NB; ++m) {
-        double a[4], b[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a[q] = Li[ti + q][m]; b[q] = Lj[tj + q][m]; }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int i = i0 + ti + p, j = j0 + tj + q;
-            if (i < nrows && j < n && j <= i) A[(size_t)i * n + j] -= acc[p][q];
-        }
 }
 
 // ---- the whole factorisation in one launch ----------------------------------------
