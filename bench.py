@@ -199,9 +199,26 @@ def main():
     npx = args.size * args.size
     L = eng.L
 
+    sum_type = args.combine.upper() in ('WEIGHTED', 'AVERAGE')
+    sharded = None
+    if world > 1 and not sum_type:
+        # exact CLIPPED / MEDIAN of the 32 N deep stack: row-band exchange (BASELINE config 4)
+        par = importlib.import_module('zuds-pipeline_amd.parallel')
+        sharded = par.ShardedCoadd(par.HipBackend(base, params, device=local, engine=eng))
+
     def step():
         # ScienceCoadd / ReferenceImage.from_images: science + mask coadds
-        if world > 1:
+        if sharded is not None:
+            img, wgt = sharded.exact(dframes, want_mask=coadd.mask is not None)
+            with torch.cuda.stream(coadd.stream):
+                coadd.stream.wait_stream(sharded.backend.stream)
+                coadd.img.copy_(img)
+                coadd.wgt.copy_(wgt)
+                if coadd.mask is not None:
+                    m = sharded.backend.reduce_mask(cov=coadd.mask_wgt)
+                    coadd.stream.wait_stream(sharded.backend.stream)
+                    coadd.mask.copy_(m)
+        elif world > 1:
             coadd.run_sharded_weighted(dframes)
         else:
             coadd.run(dframes)
@@ -276,7 +293,7 @@ def main():
             'config': {'workload': f'configs[1]+[2]: {args.frames}x {args.size}x{args.size} '
                                    f'TPV frames/GPU, mesh background + weight rescale + '
                                    f'Lanczos-3 resample + {args.combine} coadd (+ AND mask coadd)'
-                                   + (', RCCL all-reduce of the partial sums' if world > 1 else '')
+                                   + ((', RCCL all-reduce of the partial sums' if sum_type else ', row-band exchange over RCCL') if world > 1 else '')
                                    + ('' if args.no_subtract else
                                       '; then 1 science frame/GPU: align ref, hotpants 3x3 regions '
                                       'x 10x10 stamps, r=10, ko=4, subtract'),

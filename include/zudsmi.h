@@ -235,10 +235,12 @@ int zm_mask_accum_dev(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix,
                       int kind, int first);
 int zm_mask_finalize_dev(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
 /* Resample the frames to `wout` into a resident stack [nframes][ony][onx][2]
- * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it). */
+ * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it).
+ * out_mask_partial (may be NULL): the mask coadd of these frames with the -1 marker
+ * left in, as zm_coadd_dev(partial = 1) leaves it. */
 int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
                           const zm_wcs* wout, const zm_coadd_params* params,
-                          float* stack);
+                          float* stack, int32_t* out_mask_partial);
 /* Combine a resident stack; rows [row0, row0+nrows) of every frame. */
 int zm_combine_stack_dev(zm_ctx* ctx, int nframes, const float* stack,
                          int64_t frame_stride_px, int64_t npix,

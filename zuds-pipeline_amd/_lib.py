@@ -98,7 +98,7 @@ _SIGS = {
     'zm_coadd_finalize_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
     'zm_resample_stack_dev': (C.c_int, [_P, C.c_int, C.POINTER(zm_frame),
                                         C.POINTER(zm_wcs),
-                                        C.POINTER(zm_coadd_params), _P]),
+                                        C.POINTER(zm_coadd_params), _P, _P]),
     'zm_combine_stack_dev': (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64,
                                        C.POINTER(zm_coadd_params), _P, _P]),
     'zm_background': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,

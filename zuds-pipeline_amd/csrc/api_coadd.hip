@@ -150,12 +150,13 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
 
 extern "C" int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
                                      const zm_wcs* wout, const zm_coadd_params* params,
-                                     float* stack) {
+                                     float* stack, int32_t* out_mask_partial) {
     ZM_CHECK(ctx && frames && wout && params && stack, "zm_resample_stack_dev: null argument");
     ZM_CHECK(nframes >= 1, "zm_resample_stack_dev: need at least one frame");
     ZM_HIP(hipSetDevice(ctx->device));
     ZM_TRY(check_wcs(wout, "output grid"));
-    return resample_frames(ctx, nframes, frames, wout, params, (float2*)stack, nullptr, 0, 0);
+    return resample_frames(ctx, nframes, frames, wout, params, (float2*)stack, out_mask_partial, -1,
+                           params->mask_combine);
 }
 
 extern "C" int zm_combine_stack_dev(zm_ctx* ctx, int nframes, const float* stack,

@@ -71,16 +71,20 @@ class HipBackend(object):
         from .device import DeviceFrames
         return frames if isinstance(frames, DeviceFrames) else DeviceFrames(frames, self.device)
 
-    def resample_stack(self, frames):
-        """(n, ny, nx, 2) float32 {value, weight} stack of this rank's frames."""
+    def resample_stack(self, frames, want_mask=False):
+        """(n, ny, nx, 2) float32 {value, weight} stack of this rank's frames; with
+        ``want_mask`` also the partial mask coadd (-1 = not covered) as ``self.partial_mask``."""
         torch = self.torch
         df = self.frames(frames)
         ny, nx = self.shape
         stack = torch.empty((df.n, ny, nx, 2), dtype=torch.float32, device=self.device)
+        self.partial_mask = torch.empty((ny, nx), dtype=torch.int32, device=self.device) if want_mask else None
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
-            check(self.engine.L.zm_resample_stack_dev(self.engine.ctx, df.n, df.arr,
-                                                      C.byref(self.wout), C.byref(self.params),
-                                                      stack.data_ptr()), 'zm_resample_stack_dev')
+            check(self.engine.L.zm_resample_stack_dev(
+                self.engine.ctx, df.n, df.arr, C.byref(self.wout), C.byref(self.params), stack.data_ptr(),
+                self.partial_mask.data_ptr() if want_mask else None), 'zm_resample_stack_dev')
         return stack
 
     def combine(self, stack):
@@ -92,6 +96,7 @@ class HipBackend(object):
         wgt = torch.empty((rows, nx), dtype=torch.float32, device=self.device)
         if rows * nx == 0:
             return img, wgt
+        self.engine.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             check(self.engine.L.zm_combine_stack_dev(self.engine.ctx, n, stack.data_ptr(),
                                                      rows * nx, rows * nx, C.byref(self.params),
@@ -104,6 +109,7 @@ class HipBackend(object):
         df = self.frames(frames)
         s1 = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         s0 = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        self.engine.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             check(self.engine.L.zm_coadd_dev(self.engine.ctx, df.n, df.arr, C.byref(self.wout),
                                              C.byref(self.params), 1, s1.data_ptr(),
@@ -111,11 +117,29 @@ class HipBackend(object):
         return s1, s0
 
     def finalize(self, s1, s0):
+        self.engine.set_stream(self.stream.cuda_stream)
         with self.torch.cuda.stream(self.stream):
             check(self.engine.L.zm_coadd_finalize_dev(self.engine.ctx, s1.data_ptr(),
                                                       s0.data_ptr(), s1.numel()),
                   'zm_coadd_finalize_dev')
         return s1, s0
+
+    def reduce_mask(self, group=None, cov=None):
+        """Fold the partial masks of all ranks (after ``resample_stack(want_mask=True)``) and
+        finalise; returns the mask tensor (``cov``: optional float32 coverage plane)."""
+        L, ctx = self.engine.L, self.engine.ctx
+        m = self.partial_mask
+        n, kind = m.numel(), int(self.params.mask_combine)
+        self.engine.set_stream(self.stream.cuda_stream)
+        with self.torch.cuda.stream(self.stream):
+            reduce_masks(m,
+                         lambda acc, x, first: check(L.zm_mask_accum_dev(ctx, acc.data_ptr(), x.data_ptr(), n,
+                                                                         kind, int(first)), 'zm_mask_accum_dev'),
+                         lambda acc: check(L.zm_mask_finalize_dev(ctx, acc.data_ptr(),
+                                                                  cov.data_ptr() if cov is not None else None,
+                                                                  n), 'zm_mask_finalize_dev'),
+                         group)
+        return m
 
     def scope(self):
         return self.torch.cuda.stream(self.stream)
@@ -152,13 +176,15 @@ class ShardedCoadd(object):
                 dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=self.group)
         return self.backend.finalize(s1, s0)
 
-    def exact(self, frames):
+    def exact(self, frames, want_mask=False):
         """Exact CLIPPED / MEDIAN (or any combine) through the row-band
-        transpose; every rank returns the full (img, wgt)."""
+        transpose; every rank returns the full (img, wgt).  ``want_mask``: the backend also
+        keeps this rank's partial mask coadd (``backend.reduce_mask()`` folds the ranks)."""
         import torch
         import torch.distributed as dist
         rank, world = self._world()
-        stack = self.backend.resample_stack(frames)          # (n_local, ny, nx, 2)
+        stack = (self.backend.resample_stack(frames, want_mask=True) if want_mask
+                 else self.backend.resample_stack(frames))   # (n_local, ny, nx, 2)
         n_local, ny, nx, _ = stack.shape
         if world == 1:
             return self.backend.combine(stack)
