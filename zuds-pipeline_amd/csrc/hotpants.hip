@@ -765,11 +765,19 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restr
         }
         __syncthreads();
         if (tid < 64) {
+            // lane i keeps column i of the block (L[j][i], j = 0 .. 31) and the reciprocal
+            // diagonal in registers, so a step of the chain is a readlane, a multiply and an
+            // FMA - no LDS round trip, no ds_bpermute (rows >= nb are identity rows)
+            const int li = tid & 31;
+            double col[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) col[j] = D[j][li];
+            const double rdl = D[li][CH_NB];                 // lane j holds 1 / L[j][j]
             double bi = (tid < nb) ? y[k0 + tid] : 0.0;
-            for (int j = nb - 1; j >= 0; --j) {
-                double xj = __shfl(bi, j) * D[j][CH_NB];
-                if (tid == j) bi = xj;
-                else if (tid < j) bi -= D[j][tid] * xj;    // L^T[tid][j] = L[j][tid]
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 0; --j) {
+                const double xj = readlane_d(bi, j) * readlane_d(rdl, j);
+                bi = (li == j) ? xj : ((li < j) ? bi - col[j] * xj : bi);   // L^T[i][j] = L[j][i]
             }
             if (tid < nb) y[k0 + tid] = bi;
         }
