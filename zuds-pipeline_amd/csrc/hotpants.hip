@@ -621,40 +621,38 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
     for (int kb = 0; kb < nblk && !dead; ++kb) {
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
-        // (a) + (b): the published factor and this thread's panel row in one memory latency
+        // (a) the published factor
         const int below = nrows - k0 - nb;
         const int per = (below + W - 1) / W;
         const int pend = min((w + 1) * per, below);
-        const int p0 = w * per + tid;
-        double x[CH_NB];
-        if (p0 < pend) {
-            const double* ar = A + (size_t)(k0 + nb + p0) * n + k0;
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ld_sh(&ar[j]) : 0.0;
-        }
         __syncthreads();                                         // D of the previous step is consumed
         for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
         __syncthreads();
         CF_TICK(0);
-        for (int p = p0; p < pend; p += 256) {
-            double* ar = A + (size_t)(k0 + nb + p) * n + k0;
-            if (p != p0) {
+        // (b) panel rows X L^T = B, two rows per wave (one per half): lane i of a half keeps row i
+        // of L in registers; step m broadcasts the finished x_m with a readlane and every lane
+        // i > m subtracts L[i][m] x_m - a 32-step register chain per row pair instead of 496
+        // dependent LDS reads per row
+        {
+            const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+            double lrow[CH_NB];
 #pragma unroll
-                for (int j = 0; j < CH_NB; ++j) x[j] = j < nb ? ld_sh(&ar[j]) : 0.0;
-            }
+            for (int m = 0; m < CH_NB; ++m) lrow[m] = D[li][m];
+            const double rdl = D[li][CH_NB];                     // lane m holds 1 / L[m][m]
+            for (int pp = w * per + 2 * wave; pp < pend; pp += 8) {
+                const int p = pp + half;
+                const bool act = p < pend && li < nb;
+                double* ar = A + (size_t)(k0 + nb + (act ? p : 0)) * n + k0;
+                double bj = act ? ld_sh(&ar[li]) : 0.0;
 #pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                if (j < nb) {
-                    double v = x[j];
-#pragma unroll
-                    for (int m = 0; m < CH_NB; ++m)
-                        if (m < j) v -= x[m] * D[j][m];
-                    x[j] = v * D[j][CH_NB];
+                for (int m = 0; m < CH_NB; ++m) {
+                    const double r = readlane_d(rdl, m);
+                    const double xa = readlane_d(bj, m) * r, xb = readlane_d(bj, 32 + m) * r;
+                    const double xm = half ? xb : xa;
+                    bj = (li == m) ? xm : ((li > m) ? bj - lrow[m] * xm : bj);
                 }
+                if (act) st_sh(&ar[li], bj);
             }
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j)
-                if (j < nb) st_sh(&ar[j], x[j]);
         }
         if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
