@@ -462,7 +462,8 @@ __global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ r
                            const double* __restrict__ d, unsigned* __restrict__ bar) {
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
-    if (c1 == 0 && c2 == 0) { bar[reg * CF_BAR_STRIDE] = 0; bar[reg * CF_BAR_STRIDE + 1] = 0; }   // arms k_chol_fused's barrier
+    if (c1 == 0 && c2 == 0)
+        for (int k = 0; k < 4; ++k) bar[reg * CF_BAR_STRIDE + k] = 0;          // arms k_chol_fused's two region barriers
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
     double* Ar = A + (size_t)reg * (size_t)(n + 1) * n;
@@ -573,12 +574,25 @@ __device__ inline bool region_barrier(unsigned* ctr, unsigned target) {
     return dead != 0;
 }
 
-// A: [reg][(n + 1)][n]; Dg: [reg][32][33] published diagonal factors.
-// Step k:  every workgroup reads the factored diagonal block (published by workgroup 0),
-//          solves its slice of the panel rows (one thread per row)            | barrier
-//          trailing update on 64 x 64 tiles with the f64 matrix cores; workgroup 0 takes
-//          only the first tile, which holds the next diagonal block, factors it (one wave,
-//          registers) and publishes it while the others finish their tiles    | barrier
+// arrival without waiting (the look-ahead workgroup at the panel barrier)
+__device__ inline void region_arrive(unsigned* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A: [reg][(n + 1)][n]; Dg: [reg][2][32][33] published diagonal factors (two slots: the factor
+// of block k + 1 is written while slower workgroups may still read that of block k).
+// Step k, W >= 2 workgroups per region:
+//   all   read the published factor of block k, solve their panel rows X L^T = B (register
+//         chain, two rows per wave).  Workgroup 0 owns the first 32 panel rows - the rows of
+//         the next diagonal block - the others share the rest.                 | arrive b1
+//   wg 0  does not wait: next diagonal block = A11' - X X^T from its own rows, factors it (one
+//         wave, block in registers) and publishes it, while
+//   wg>0  wait b1, then update the trailing 64 x 64 tiles on the f64 matrix cores (tile 0
+//         without the corner that workgroup 0 holds)                           | barrier b2
+// so the 32 x 32 factorisation - the longest serial piece - overlaps the panel barrier and the
+// trailing update instead of following them.
 __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, double* Dgall, int* fail,
                                                     unsigned* bar, long long* prof) {
     __shared__ double D[CH_NB][CH_NB + 1];
@@ -586,17 +600,19 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
     __shared__ double Lj[64][CH_NB + 2];
     const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
     double* A = Aall + (size_t)reg * (size_t)(n + 1) * n;
-    double* Dg = Dgall + (size_t)reg * CH_NB * (CH_NB + 1);
-    unsigned* ctr = bar + reg * CF_BAR_STRIDE;
+    double* Dg2 = Dgall + (size_t)reg * 2 * CH_NB * (CH_NB + 1);
+    unsigned* ctr1 = bar + reg * CF_BAR_STRIDE;          // [0] panel barrier, [1] timed-out flag,
+    unsigned* ctr2 = ctr1 + 2;                           // [2] update barrier (its flag is [3])
     const int tid = threadIdx.x;
     const int nrows = n + 1;
     const int nblk = (n + CH_NB - 1) / CH_NB;
-    unsigned gen = 0;
+    unsigned gen1 = 0, gen2 = 0;
     long long pt[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // phase clocks (100 MHz), prof != NULL only
 #define CF_TICK(k) do { if (prof) { long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
     if (prof) tc = wall_clock64();
-    // factor the diagonal block held (unfactored, lower triangle) in D; publish it
-    auto factor_and_publish = [&](int k0, int nb) {
+    // factor the diagonal block held (unfactored, lower triangle) in D; publish it in `slot`
+    auto factor_and_publish = [&](int k0, int nb, int slot) {
+        double* Dg = Dg2 + (size_t)slot * CH_NB * (CH_NB + 1);
         __syncthreads();
         if (tid < 64) chol_diag_wave(D, nb, &fail[reg]);
         __syncthreads();
@@ -606,130 +622,179 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
             if (i < nb && j <= i) st_sh(&A[(size_t)(k0 + i) * n + k0 + j], D[i][j]);
         }
     };
-    auto load_diag_raw = [&](int k0, int nb) {
+    if (w == 0) {
+        const int nb0 = min(CH_NB, n);
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
             const int i = e >> 5, j = e & 31;
-            D[i][j] = (i < nb && j <= i && j < nb) ? ld_sh(&A[(size_t)(k0 + i) * n + k0 + j]) : (i == j ? 1.0 : 0.0);
+            D[i][j] = (i < nb0 && j <= i) ? ld_sh(&A[(size_t)i * n + j]) : (i == j ? 1.0 : 0.0);
         }
-    };
-    if (w == 0) {
-        load_diag_raw(0, min(CH_NB, n));
-        factor_and_publish(0, min(CH_NB, n));
+        factor_and_publish(0, nb0, 0);
     }
-    gen += W;
-    bool dead = region_barrier(ctr, gen);
+    gen2 += W;
+    bool dead = region_barrier(ctr2, gen2);
+    const int wave = tid >> 6, lane = tid & 63;
     for (int kb = 0; kb < nblk && !dead; ++kb) {
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
-        // (a) the published factor
-        const int below = nrows - k0 - nb;
-        const int per = (below + W - 1) / W;
-        const int pend = min((w + 1) * per, below);
+        const int k1 = k0 + nb;                                  // first trailing row / column
+        const int below = nrows - k1;                            // panel rows (the rhs row included)
+        const int nbn = max(0, min(CH_NB, n - k1));              // size of the next diagonal block
+        // rows [0, r0n) of the panel belong to workgroup 0, the rest is dealt to the others
+        const int r0n = min(CH_NB, below);
+        const int per = (W > 1) ? (below - r0n + W - 2) / (W - 1) : 0;
+        const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
+        const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
+        // workgroup 0: the unfactored next diagonal block, fetched ahead of its use
+        double cpre[4] = {0.0, 0.0, 0.0, 0.0};
+        if (w == 0 && nb == CH_NB)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, i = e >> 5, j = e & 31;
+                if (i < nbn && j <= i) cpre[q] = ld_sh(&A[(size_t)(k1 + i) * n + k1 + j]);
+            }
+        // (a) the published factor of block kb
         __syncthreads();                                         // D of the previous step is consumed
-        for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
+        {
+            const double* Dg = Dg2 + (size_t)(kb & 1) * CH_NB * (CH_NB + 1);
+            for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
+        }
         __syncthreads();
         CF_TICK(0);
         // (b) panel rows X L^T = B, two rows per wave (one per half): lane i of a half keeps row i
         // of L in registers; step m broadcasts the finished x_m with a readlane and every lane
         // i > m subtracts L[i][m] x_m - a 32-step register chain per row pair instead of 496
-        // dependent LDS reads per row
+        // dependent LDS reads per row.  Workgroup 0 also keeps its rows in LDS (Li) for the
+        // look-ahead.
         {
-            const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+            const int half = lane >> 5, li = lane & 31;
             double lrow[CH_NB];
 #pragma unroll
             for (int m = 0; m < CH_NB; ++m) lrow[m] = D[li][m];
             const double rdl = D[li][CH_NB];                     // lane m holds 1 / L[m][m]
-            for (int pp = w * per + 2 * wave; pp < pend; pp += 8) {
-                const int p = pp + half;
-                const bool act = p < pend && li < nb;
-                double* ar = A + (size_t)(k0 + nb + (act ? p : 0)) * n + k0;
-                double bj = act ? ld_sh(&ar[li]) : 0.0;
+            // four row pairs at a time: their loads go out together (one memory latency) and
+            // the four register chains interleave
+            for (int pp0 = pbeg + 2 * wave; pp0 < pend; pp0 += 32) {
+                double bj[4];
+                bool act[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = pp0 + 8 * q + half;
+                    act[q] = p < pend && li < nb;
+                    bj[q] = act[q] ? ld_sh(&A[(size_t)(k1 + p) * n + k0 + li]) : 0.0;
+                }
 #pragma unroll
                 for (int m = 0; m < CH_NB; ++m) {
                     const double r = readlane_d(rdl, m);
-                    const double xa = readlane_d(bj, m) * r, xb = readlane_d(bj, 32 + m) * r;
-                    const double xm = half ? xb : xa;
-                    bj = (li == m) ? xm : ((li > m) ? bj - lrow[m] * xm : bj);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double xa = readlane_d(bj[q], m) * r, xb = readlane_d(bj[q], 32 + m) * r;
+                        const double xm = half ? xb : xa;
+                        bj[q] = (li == m) ? xm : ((li > m) ? bj[q] - lrow[m] * xm : bj[q]);
+                    }
                 }
-                if (act) st_sh(&ar[li], bj);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = pp0 + 8 * q + half;
+                    if (act[q]) st_sh(&A[(size_t)(k1 + p) * n + k0 + li], bj[q]);
+                    if (w == 0 && p < CH_NB) Li[p][li] = (p < pend) ? bj[q] : 0.0;
+                }
             }
         }
         if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CF_TICK(2);
-        gen += W;
-        dead = region_barrier(ctr, gen);
-        CF_TICK(3);
-        if (dead) break;
-        // (c) trailing update A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle.
-        // Tile 0 (the next diagonal block in its corner) belongs to workgroup 0 alone.
-        const int t0 = k0 + CH_NB;
         const int T = (below + 63) / 64;
         const int ntile = T * (T + 1) / 2;
-        const int Wu = W > 1 ? W - 1 : 1;                        // workgroups sharing tiles 1 ..
-        const int tfirst = (W == 1) ? 0 : (w == 0 ? 0 : w);      // w >= 1 starts at tile w
-        const int tstep = (W == 1) ? 1 : (w == 0 ? ntile : Wu);
-        for (int t = tfirst; t < ntile; t += tstep) {
-            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-            while (ti * (ti + 1) / 2 > t) --ti;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            const int tj = t - ti * (ti + 1) / 2;
-            const int i0 = t0 + ti * 64, j0 = t0 + tj * 64;
-            // f64 matrix cores: wave v owns rows 16 v .. 16 v + 15 of the tile; C layout of
-            // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.  The tile is
-            // loaded together with the two panels: one memory latency.
-            const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-            double4_t acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                    acc[c][rg] = (i < nrows && j < n && j <= i) ? ld_sh(&A[(size_t)i * n + j]) : 0.0;
-                }
-            __syncthreads();                       // the previous tile's panels are consumed
-            for (int e = tid; e < 64 * CH_NB; e += 256) {
-                const int r = e >> 5, m = e & 31;
-                Li[r][m] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * n + k0 + m]) : 0.0;
-                Lj[r][m] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * n + k0 + m]) : 0.0;
-            }
+        if (w == 0 && W > 1) {
+            // panel rows published: arrive, do not wait - nothing below needs the others' rows
+            region_arrive(ctr1);
+            gen1 += W;
+            // next diagonal block (k1 .. k1 + nbn) = prefetched A - X X^T, X = rows 0 .. nbn - 1
+            // of this workgroup's panel slice (in Li); then factor and publish it
+            for (int p = pend; p < CH_NB; ++p)                   // rows this slice does not have
+                if (tid < CH_NB) Li[p][tid] = 0.0;
             __syncthreads();
 #pragma unroll
-            for (int kk = 0; kk < CH_NB / 4; ++kk) {
-                const double a = Li[16 * wave + li][4 * kk + lk];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const double b = Lj[16 * c + li][4 * kk + lk];
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, i = e >> 5, j = e & 31;
+                double v = (i == j) ? 1.0 : 0.0;
+                if (i < nbn && j <= i) {
+                    v = cpre[q];
+#pragma unroll 8
+                    for (int m = 0; m < CH_NB; ++m) v -= Li[i][m] * Li[j][m];
                 }
+                D[i][j] = v;
             }
-            if (t == 0) {
-                // the next diagonal block straight from the accumulators into D
-                const int nbn = min(CH_NB, n - t0);
-                __syncthreads();
+            factor_and_publish(k1, nbn, (kb + 1) & 1);
+            CF_TICK(4);
+        } else {
+            gen1 += W;
+            dead = region_barrier(ctr1, gen1);
+            CF_TICK(3);
+            if (dead) break;
+            // (c) trailing update A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle; the
+            // corner of tile 0 (the next diagonal block) is workgroup 0's
+            const int Wu = (W > 1) ? W - 1 : 1, wu = (W > 1) ? w - 1 : 0;
+            for (int t = wu; t < ntile; t += Wu) {
+                int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+                while (ti * (ti + 1) / 2 > t) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                const int i0 = k1 + ti * 64, j0 = k1 + tj * 64;
+                const bool skip_corner = (t == 0) && (W > 1);
+                // f64 matrix cores: wave v owns rows 16 v .. 16 v + 15 of the tile; C layout of
+                // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.  The tile is
+                // loaded together with the two panels: one memory latency.
+                const int li = lane & 15, lk = lane >> 4;
+                double4_t acc[4];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const int i = 16 * wave + lk + 4 * rg, j = 16 * c + li;
-                        if (i < CH_NB) D[i][j] = (i < nbn && j <= i && j < nbn) ? acc[c][rg] : (i == j ? 1.0 : 0.0);
+                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                        const bool corner = skip_corner && i < k1 + nbn;           // j <= i: in the block
+                        acc[c][rg] = (i < nrows && j < n && j <= i && !corner) ? ld_sh(&A[(size_t)i * n + j]) : 0.0;
                     }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                    // the corner of tile 0 is stored factored, by factor_and_publish
-                    const bool corner = (t == 0) && i < t0 + min(CH_NB, n - t0);   // j <= i: inside the block
-                    if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * n + j], acc[c][rg]);
+                __syncthreads();                       // the previous tile's panels are consumed
+                for (int e = tid; e < 64 * CH_NB; e += 256) {
+                    const int r = e >> 5, m = e & 31;
+                    Li[r][m] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * n + k0 + m]) : 0.0;
+                    Lj[r][m] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * n + k0 + m]) : 0.0;
                 }
-            if (t == 0) factor_and_publish(t0, min(CH_NB, n - t0));
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                    const double a = Li[16 * wave + li][4 * kk + lk];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double b = Lj[16 * c + li][4 * kk + lk];
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+                if (W == 1 && t == 0) {
+                    // a lone workgroup factors the next block here, straight from the accumulators
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int i = 16 * wave + lk + 4 * rg, j = 16 * c + li;
+                            if (i < CH_NB) D[i][j] = (i < nbn && j <= i && j < nbn) ? acc[c][rg] : (i == j ? 1.0 : 0.0);
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                        const bool corner = (t == 0) && i < k1 + nbn;              // stored factored instead
+                        if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * n + j], acc[c][rg]);
+                    }
+                if (W == 1 && t == 0) factor_and_publish(k1, nbn, (kb + 1) & 1);
+            }
+            CF_TICK(4);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CF_TICK(4);
-        gen += W;
-        dead = region_barrier(ctr, gen);
+        gen2 += W;
+        dead = region_barrier(ctr2, gen2);
         CF_TICK(5);
     }
     if (dead && tid == 0) atomicAdd(&fail[reg], 1);
@@ -1199,7 +1264,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
     ZM_TRY(ctx->get("hp_cbar", sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG, (void**)&cbar));
     double* cdg = nullptr;               // published diagonal factors of k_chol_fused
-    ZM_TRY(ctx->get("hp_cdg", sizeof(double) * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));
+    ZM_TRY(ctx->get("hp_cdg", sizeof(double) * 2 * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));
     ZM_TRY(ctx->get("hp_X", sizeof(double) * (size_t)P.ncell * P.nX * P.npixp, (void**)&X));
     ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
     double* Gp = nullptr;                // per-slice partial Gram matrices
@@ -1290,7 +1355,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
                 }
                 ZM_CHECK(P.nreg <= coop_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, coop_cap);
-                int W = std::max(1, std::min(40, std::min(coop_cap - coop_cap / 16, 400) / P.nreg));   // margin below the API figure
+                int W = std::max(2, std::min(68, (coop_cap - coop_cap / 16) / P.nreg));   // margin below the API figure
                 int nunk = P.nunk;
                 double* Aarg = A;
                 int* farg = fail;
