@@ -253,14 +253,17 @@ __device__ inline void blockf_sum3(double& a, double& b, double& c, double (*red
     for (int w = 0; w < BKF_WAVES; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
 }
 
-// up to BK_BATCH equally sized frames per launch: blockIdx.z = frame * nmode + statistic
+// up to BK_BATCH equally sized frames per launch: blockIdx.z = frame * nmode + statistic.
+// __launch_bounds__(512, 4): HIP's second argument is waves per SIMD - 4 = two workgroups per
+// CU at <= 128 VGPRs (left alone the kernel takes 206 and one workgroup per CU: 2 waves per
+// SIMD on average, 52 % of the wave cycles waiting).
 #define BK_BATCH 64
 struct bk_batch {
     const float* img[BK_BATCH];
     const float* wgt[BK_BATCH];
 };
 
-__global__ __launch_bounds__(BKF_THREADS) void k_mesh_stats_fast(const bk_batch B, int nmode,
+__global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_batch B, int nmode,
                                                                  int nx, int ny, int mesh, int nbx,
                                                                  int nby, float wthresh, int mode0,
                                                                  int vec_ok, int dbg,
