@@ -1346,16 +1346,19 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                                rhs, dsc, cbar);
             {
                 // one cooperative launch: W workgroups per region, all resident
-                static int coop_cap = 0;                  // resident workgroups the device grants this kernel
-                if (!coop_cap) {
+                // One workgroup per CU: a second one on the same CU slows the serial chains of the
+                // look-ahead workgroup (measured: 806 us at 26 workgroups per region, 917 at 32).
+                // The occupancy API only bounds it (it can be one block per CU high; keep a margin).
+                static int wg_cap = 0;
+                if (!wg_cap) {
                     int occ = 0, ncu = 0;
                     ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
                     ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-                    coop_cap = std::max(1, occ * ncu);
+                    wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
                     if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
                 }
-                ZM_CHECK(P.nreg <= coop_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, coop_cap);
-                int W = std::max(2, std::min(68, (coop_cap - coop_cap / 16) / P.nreg));   // margin below the API figure
+                ZM_CHECK(2 * P.nreg <= wg_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, wg_cap);
+                int W = std::max(2, std::min(68, wg_cap / P.nreg));
                 int nunk = P.nunk;
                 double* Aarg = A;
                 int* farg = fail;
