@@ -421,10 +421,16 @@ __device__ inline void col_decode(const hp_plan& P, int c, int* n, int* p) {
     *p = -1;
 }
 
-// A: [reg][nunk][nunk] lower triangle, rhs: [reg][nunk]
+// A0: [reg][nunk][nunk] lower triangle of the unscaled normal matrix, rhs0: [reg][nunk]; both
+// persist over the rejection rounds.  sign == 0: built from every active cell.  sign == -1 / +1:
+// only the contribution of the cells whose substamp the last rejection changed (chg[cell]) is
+// taken out (with the old Gram matrix and spatial terms, before they are recomputed) / put
+// back in (with the new ones, cells that still have a substamp): a round touches a few cells
+// of a hundred.
 __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double* __restrict__ G,
                                                   const double* __restrict__ phi,
                                                   const int* __restrict__ active,
+                                                  const int* __restrict__ chg, int sign,
                                                   double* __restrict__ A,
                                                   double* __restrict__ rhs) {
     const int reg = blockIdx.z;
@@ -436,9 +442,13 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
     col_decode(P, c2, &n2, &p2);
     double acc = 0.0, racc = 0.0;
     const bool do_rhs = (c2 == 0);
-    for (int s = 0; s < P.ncellr; ++s) {
-        const int cell = reg * P.ncellr + s;
-        if (active[cell] < 0) continue;
+    bool any = false;
+    const int* list = chg + P.ncell + reg * (P.ncellr + 1);
+    const int ncand = (sign == 0) ? P.ncellr : list[0];
+    for (int s = 0; s < ncand; ++s) {
+        const int cell = (sign == 0) ? reg * P.ncellr + s : list[1 + s];
+        if (active[cell] < 0 && sign >= 0) continue;
+        any = true;
         const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
         const double* ph = phi + (size_t)cell * P.nkp;
         double w1 = p1 >= 0 ? ph[p1] : 1.0;
@@ -446,8 +456,14 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
         acc += w1 * w2 * Gc[n1 * HP_MAXX + n2];
         if (do_rhs) racc += w1 * Gc[n1 * HP_MAXX + P.nE];
     }
-    if (c2 <= c1) A[(size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2] = acc;
-    if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
+    const size_t ia = (size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2;
+    if (sign == 0) {
+        if (c2 <= c1) A[ia] = acc;
+        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
+    } else if (any) {
+        if (c2 <= c1) A[ia] += sign * acc;
+        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] += sign * racc;
+    }
 }
 
 // Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
@@ -458,19 +474,19 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
     d[(size_t)reg * n + c] = v > 0.0 ? sqrt(v) : 1.0;
 }
 
-__global__ void k_hp_scale(int n, double* __restrict__ A, double* __restrict__ rhs,
-                           const double* __restrict__ d, unsigned* __restrict__ bar) {
+__global__ void k_hp_scale(int n, const double* __restrict__ A0, const double* __restrict__ rhs0,
+                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar) {
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
     if (c1 == 0 && c2 == 0)
         for (int k = 0; k < 4; ++k) bar[reg * CF_BAR_STRIDE + k] = 0;          // arms k_chol_fused's two region barriers
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
-    double* Ar = A + (size_t)reg * (size_t)(n + 1) * n;
-    double v = Ar[(size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
+    const size_t base = (size_t)reg * (size_t)(n + 1) * n;
+    double v = A0[base + (size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
     if (c1 == c2) v += HP_RIDGE;   // keeps a rank-deficient basis solvable (oracle: RIDGE)
-    Ar[(size_t)c1 * n + c2] = v;
-    if (c2 == 0) Ar[(size_t)n * n + c1] = rhs[(size_t)reg * n + c1] / dd[c1];   // rhs row
+    A[base + (size_t)c1 * n + c2] = v;
+    if (c2 == 0) A[base + (size_t)n * n + c1] = rhs0[(size_t)reg * n + c1] / dd[c1];   // rhs row
 }
 
 // ---- blocked Cholesky, lower, in place ------------------------------------------------
@@ -895,7 +911,8 @@ __global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* 
 __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double* __restrict__ merit,
                                                    const int2* __restrict__ centres,
                                                    int* __restrict__ active, int* __restrict__ need,
-                                                   int* __restrict__ nrej, double* __restrict__ stats) {
+                                                   int* __restrict__ chg, int* __restrict__ nrej,
+                                                   double* __restrict__ stats) {
     __shared__ double red[4];
     const int reg = blockIdx.x, tid = threadIdx.x;
     double m = 0.0, s = 0.0;
@@ -925,6 +942,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
         const int cell = reg * P.ncellr + k;
         int a = active[cell];
         need[cell] = 0;
+        chg[cell] = 0;
         if (a < 0) continue;
         double v = merit[cell];
         used += 1.0;
@@ -935,6 +953,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
             if (a >= P.nss || centres[cell * P.nss + a].x < 0) a = -1;
             else need[cell] = 1;
             active[cell] = a;
+            chg[cell] = 1;              // its contribution leaves the normal matrix (and may come back)
         }
     }
     cnt = block_sum256(cnt, red);
@@ -944,6 +963,16 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
         nrej[reg] = (int)cnt;
         stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
         stats[reg * 2 + 1] = used;
+    }
+    // the changed cells of the region in cell order (a fixed order: the incremental normal
+    // matrix sums their contributions in it): chg[cell] flags -> list behind the flags
+    __syncthreads();
+    if (tid == 0) {
+        int* list = chg + P.ncell + reg * (P.ncellr + 1);     // [count, cells ...]
+        int k = 0;
+        for (int c = 0; c < P.ncellr; ++c)
+            if (chg[reg * P.ncellr + c]) list[1 + k++] = reg * P.ncellr + c;
+        list[0] = k;
     }
 }
 
@@ -1259,6 +1288,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_centres", sizeof(int2) * P.ncell * P.nss, (void**)&centres));
     ZM_TRY(ctx->get("hp_active", sizeof(int) * P.ncell, (void**)&active));
     ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
+    int* chg = nullptr;                  // cells whose substamp the last rejection changed
+    ZM_TRY(ctx->get("hp_chg", sizeof(int) * (2 * (size_t)P.ncell + P.nreg), (void**)&chg));   // flags + per-region lists
     ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * (3 * HP_MAXREG + 4), (void**)&ibuf));
     int *nrej = ibuf, *ntotal = ibuf + HP_MAXREG, *fail = ibuf + 2 * HP_MAXREG, *nmasked = ibuf + 3 * HP_MAXREG;
     unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
@@ -1273,6 +1304,9 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
     ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A));
     ZM_TRY(ctx->get("hp_rhs", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs));
+    double *A0 = nullptr, *rhs0 = nullptr;   // unscaled normal matrix / right-hand side, kept over the rounds
+    ZM_TRY(ctx->get("hp_A0", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A0));
+    ZM_TRY(ctx->get("hp_rhs0", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs0));
     ZM_TRY(ctx->get("hp_dsc", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&dsc));
     ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
     ZM_TRY(ctx->get("hp_stats", sizeof(double) * 2 * HP_MAXREG, (void**)&stats));
@@ -1316,6 +1350,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     int h_int[3 * HP_MAXREG + 4];
     const int nblk = (P.nunk + CH_NB - 1) / CH_NB;
     for (rounds = 1; rounds <= 8; ++rounds) {
+        if (rounds > 1) {
+            // the rejected cells leave the normal matrix with their old Gram matrices / spatial
+            // terms, before k_hp_vectors / k_hp_gram overwrite them
+            zm_scope_timer t(ctx, "hp_solve");
+            int nt = zm_div_up(P.nunk, 16);
+            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0);
+        }
         {
             zm_scope_timer t(ctx, "hp_vectors");
 #define HP_VEC_CASE(H) case H: \
@@ -1340,10 +1381,11 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         {
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, A, rhs);
-            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A, dsc);
-            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A,
-                               rhs, dsc, cbar);
+            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                               rounds == 1 ? 0 : 1, A0, rhs0);
+            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc);
+            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A0,
+                               rhs0, A, dsc, cbar);
             {
                 // one cooperative launch: W workgroups per region, all resident
                 // One workgroup per CU: a second one on the same CU slows the serial chains of the
@@ -1397,8 +1439,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, A, dsc, rhs);
             }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
-            hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, nrej,
-                               stats);
+            hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
+                               nrej, stats);
             ZM_HIP(hipGetLastError());
         }
         ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
