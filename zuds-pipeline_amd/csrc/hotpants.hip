@@ -1019,11 +1019,14 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
     constexpr int TW = NB * STEP + 2 * HWK;   // tile width
     constexpr int TH = STEP + 2 * HWK;
+    // LDS: template and template variance interleaved ({T, V} pairs), the per-block kernel as
+    // {k, k^2} pairs: one v_pk_fma_f32 per tap and pixel feeds both planes, one ds_read_b64 per
+    // operand
+    typedef float ap_v2f __attribute__((ext_vector_type(2)));
     extern __shared__ float ap_smem[];
-    float* tT = ap_smem;                       // [TH][TW]
-    float* tV = tT + TH * TW;                  // [TH][TW]
-    float* kc = tV + TH * TW;                  // [NB][STEP*STEP]
-    double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP + ((NB * STEP * STEP) & 1));   // [NB][nc]
+    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TW]
+    ap_v2f* kc = tTV + TH * TW;                                    // [NB][STEP*STEP]
+    double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP);  // [NB][nc]
     const int tid = threadIdx.x;
     const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
     const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
@@ -1058,15 +1061,15 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
             if (!(fabsf(t) < 3e38f)) t = 0.f;
             if (!(fabsf(v) < 3e38f)) v = 0.f;
         }
-        tT[e] = t;
-        tV[e] = v;
+        tTV[e] = (ap_v2f){t, v};
     }
     __syncthreads();
     for (int e = tid; e < NB * STEP * STEP; e += 256) {
         int b = e / (STEP * STEP), tap = e - b * STEP * STEP;
         double acc = 0.0;
         for (int n = 0; n < P.nc; ++n) acc += cf[b * P.nc + n] * basis[(size_t)n * STEP * STEP + tap];
-        kc[e] = (float)acc;
+        const float k = (float)acc;
+        kc[e] = (ap_v2f){k, k * k};
     }
     __syncthreads();
     const int b = tid / LPB;
@@ -1076,29 +1079,27 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
     const int gy = gy0 + row;
     if (gy >= y1r || gy >= P.ny) return;
-    float accT[R], accV[R];
+    ap_v2f acc2[R];                                    // {sum k T, sum k^2 V}
 #pragma unroll
-    for (int q = 0; q < R; ++q) { accT[q] = 0.f; accV[q] = 0.f; }
-    const float* kb = kc + b * STEP * STEP;
+    for (int q = 0; q < R; ++q) acc2[q] = (ap_v2f){0.f, 0.f};
+    const ap_v2f* kb = kc + b * STEP * STEP;
     // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
     for (int v = -HWK; v <= HWK; ++v) {
-        const float* rt = tT + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
-        const float* rv = tV + (row + HWK - v) * TW + ox0;
-        float wt[R + 2 * HWK], wv[R + 2 * HWK];
+        const ap_v2f* rt = tTV + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
+        ap_v2f w2[R + 2 * HWK];
 #pragma unroll
-        for (int q = 0; q < R + 2 * HWK; ++q) { wt[q] = rt[q]; wv[q] = rv[q]; }
-        const float* kr = kb + (v + HWK) * STEP;
+        for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[q];
+        const ap_v2f* kr = kb + (v + HWK) * STEP;
 #pragma unroll
         for (int u = -HWK; u <= HWK; ++u) {
-            const float k = kr[u + HWK];
-            const float k2 = k * k;
+            const ap_v2f k2 = kr[u + HWK];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                accT[q] = fmaf(k, wt[q + HWK - u], accT[q]);
-                accV[q] = fmaf(k2, wv[q + HWK - u], accV[q]);
-            }
+            for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
         }
     }
+    float accT[R], accV[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { accT[q] = acc2[q].x; accV[q] = acc2[q].y; }
     const double* bgc = x + 1 + (size_t)(P.nc - 1) * P.nkp;
     const float norm = P.normalize ? (float)(1.0 / x[0]) : 1.f;
     int masked = 0;
@@ -1241,7 +1242,7 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, NB = C::NB;
     constexpr int TW = NB * STEP + 2 * HWK, TH = STEP + 2 * HWK;
-    size_t fl = (size_t)2 * TH * TW + NB * STEP * STEP + 1;
+    size_t fl = (size_t)2 * TH * TW + (size_t)2 * NB * STEP * STEP;      // {T, V} tile + {k, k^2} kernels
     size_t shmem = fl * sizeof(float) + (size_t)NB * HP_MAXX * sizeof(double) + 16;
     static bool set = false;
     if (!set && shmem > 65536) {
