@@ -63,26 +63,58 @@ __global__ void k_hp_valid(const float* __restrict__ sci, const float* __restric
     bad[p] = ok ? 0 : 1;
 }
 
-__global__ void k_hp_rowany(const uint8_t* __restrict__ in, int nx, int ny, int hw,
-                            uint8_t* __restrict__ out) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= nx) return;
+// (2 hw + 1)-wide "any" along rows: one workgroup per row, inclusive prefix count of the row
+// in LDS, out = count(x - hw .. x + hw) > 0.  Replaces a 2 hw + 1 byte-load loop per pixel.
+#define HP_ROWMAX 16384
+__global__ __launch_bounds__(256) void k_hp_rowany(const uint8_t* __restrict__ in, int nx, int ny, int hw,
+                                                   uint8_t* __restrict__ out) {
+    extern __shared__ int ra_pre[];                       // [nx + 1], ra_pre[0] = 0
+    __shared__ int wsum[4];
+    const int y = blockIdx.x, tid = threadIdx.x;
     const uint8_t* row = in + (size_t)y * nx;
-    int a = max(x - hw, 0), b = min(x + hw, nx - 1);
-    uint8_t v = 0;
-    for (int i = a; i <= b; ++i) v |= row[i];
-    out[(size_t)y * nx + x] = v;
+    const int per = (nx + 255) / 256;                     // consecutive pixels per thread
+    const int x0 = tid * per, x1 = min(x0 + per, nx);
+    int loc = 0;
+    for (int x = x0; x < x1; ++x) loc += row[x] ? 1 : 0;
+    int inc = loc;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - loc;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (tid == 0) ra_pre[0] = 0;
+    int run = base;
+    for (int x = x0; x < x1; ++x) { run += row[x] ? 1 : 0; ra_pre[x + 1] = run; }
+    __syncthreads();
+    for (int x = tid; x < nx; x += 256) {
+        const int a = max(x - hw, 0), b = min(x + hw, nx - 1);
+        out[(size_t)y * nx + x] = (ra_pre[b + 1] - ra_pre[a]) > 0;
+    }
 }
 
-__global__ void k_hp_colany(const uint8_t* __restrict__ in, int nx, int ny, int hw, int edge,
-                            uint8_t* __restrict__ out) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+// the same along columns: one thread per column walks a strip of rows with a running count
+// of the window (coalesced row reads); edge != 0 also flags the hw-wide frame border
+#define HP_COLSTRIP 96
+__global__ __launch_bounds__(256) void k_hp_colany(const uint8_t* __restrict__ in, int nx, int ny, int hw,
+                                                   int edge, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = blockIdx.y * HP_COLSTRIP, y1 = min(y0 + HP_COLSTRIP, ny);
     if (x >= nx) return;
-    int a = max(y - hw, 0), b = min(y + hw, ny - 1);
-    uint8_t v = 0;
-    for (int j = a; j <= b; ++j) v |= in[(size_t)j * nx + x];
-    if (edge && (x < hw || x >= nx - hw || y < hw || y >= ny - hw)) v = 1;
-    out[(size_t)y * nx + x] = v;
+    int cnt = 0;
+    for (int j = max(y0 - hw, 0); j <= min(y0 + hw, ny - 1); ++j) cnt += in[(size_t)j * nx + x] ? 1 : 0;
+    for (int y = y0; y < y1; ++y) {
+        uint8_t v = cnt > 0;
+        if (edge && (x < hw || x >= nx - hw || y < hw || y >= ny - hw)) v = 1;
+        out[(size_t)y * nx + x] = v;
+        const int add = y + 1 + hw, sub = y - hw;           // window of row y + 1
+        if (add < ny) cnt += in[(size_t)add * nx + x] ? 1 : 0;
+        if (sub >= 0) cnt -= in[(size_t)sub * nx + x] ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1328,11 +1360,19 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         zm_scope_timer t(ctx, "hp_masks");
         hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
                            (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad);
-        dim3 g2(zm_div_up(nx, 256), ny);
-        hipLaunchKernelGGL(k_hp_rowany, g2, b256, 0, st, bad, nx, ny, P.hw, tmp8);
-        hipLaunchKernelGGL(k_hp_colany, g2, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
-        hipLaunchKernelGGL(k_hp_rowany, g2, b256, 0, st, bad, nx, ny, P.hwk, tmp8);
-        hipLaunchKernelGGL(k_hp_colany, g2, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+        ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
+        const size_t rsh = sizeof(int) * ((size_t)nx + 1);
+        dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));
+        static bool rset = false;
+        if (!rset && rsh > 65536) {
+            ZM_HIP(hipFuncSetAttribute((const void*)k_hp_rowany, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(int) * (HP_ROWMAX + 1))));
+            rset = true;
+        }
+        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
+        hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hwk, tmp8);
+        hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
         ZM_HIP(hipGetLastError());
     }
     {
