@@ -134,7 +134,7 @@ def test_single_frame_clipped_is_identity_of_resample(engine):
     np.testing.assert_allclose(g_wgt, r_wgt, rtol=1e-6)
 
 
-@pytest.mark.parametrize('n', [3, 9, 20, 40, 70])
+@pytest.mark.parametrize('n', [3, 9, 20, 40, 70, 256])
 def test_stack_depths_use_every_kernel_variant(engine, n):
     # register networks (4..64) and the deep LDS path (> 64)
     z = pkg()
