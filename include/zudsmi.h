@@ -314,6 +314,10 @@ int zm_fits_encode_dev(zm_ctx* ctx, const void* in_dev, int in_kind, int64_t n,
 /* Enable recording of HIP events around the dominant kernels on the ctx
  * stream; zm_timing_read returns accumulated milliseconds and launch counts. */
 int zm_timing_enable(zm_ctx* ctx, int on);
+/* Time only the scope `only` (e.g. "resample"); NULL = every scope.  The two event records
+ * around a launch cost a few microseconds of dispatch latency each, so a throughput
+ * measurement times just the kernel it needs. */
+int zm_timing_filter(zm_ctx* ctx, const char* only);
 int zm_timing_reset(zm_ctx* ctx);
 int zm_timing_read(zm_ctx* ctx, const char* kernel_name, double* total_ms,
                    int64_t* launches);

@@ -11,4 +11,4 @@ if not lines:
     sys.exit(1)
 d = json.loads(lines[-1])
 print(f"{d['value']:.0f} Mpix/s  {d['ms_per_step']:.2f} ms/step  roofline frac {d['roofline']['frac']:.3f}")
-print({k: (round(v['ms_total'] / d['steps'], 2), round(v['avg_us'], 1)) for k, v in d['kernels'].items()})
+print({k: (round(v['ms_per_step'], 2), round(v['avg_us'], 1)) for k, v in d['kernels'].items()})

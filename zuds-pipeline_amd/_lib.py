@@ -135,6 +135,7 @@ _SIGS = {
     'zm_aperture_photometry_dev': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P,
                                              C.c_double, _P, _P, _P]),
     'zm_timing_enable': (C.c_int, [_P, C.c_int]),
+    'zm_timing_filter': (C.c_int, [_P, C.c_char_p]),
     'zm_timing_reset': (C.c_int, [_P]),
     'zm_timing_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),

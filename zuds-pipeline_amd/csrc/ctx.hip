@@ -138,6 +138,7 @@ extern "C" int zm_ctx_synchronize(zm_ctx* ctx) {
 // ---- timers ---------------------------------------------------------------
 zm_scope_timer::zm_scope_timer(zm_ctx* c, const char* n) : ctx(c), name(n) {
     if (!ctx->timing) return;
+    if (!ctx->timing_only.empty() && ctx->timing_only != n) return;
     auto take = [&]() -> hipEvent_t {
         if (!ctx->event_pool.empty()) {
             hipEvent_t e = ctx->event_pool.back();
@@ -176,6 +177,12 @@ static int drain(zm_ctx* ctx, zm_timer_slot& s) {
         ctx->event_pool.push_back(p.second);
     }
     s.pending.clear();
+    return 0;
+}
+
+extern "C" int zm_timing_filter(zm_ctx* ctx, const char* only_or_null) {
+    ZM_CHECK(ctx != nullptr, "zm_timing_filter: ctx is NULL");
+    ctx->timing_only = only_or_null ? only_or_null : "";
     return 0;
 }
 

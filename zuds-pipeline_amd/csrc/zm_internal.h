@@ -62,6 +62,7 @@ struct zm_ctx {
     const void* box_ready_for = nullptr;
     int box_ready_nt = 0;
     bool timing = false;
+    std::string timing_only;                   // non-empty: only this scope is timed
     std::map<std::string, zm_timer_slot> timers;
     std::vector<hipEvent_t> event_pool;
 

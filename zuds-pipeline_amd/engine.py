@@ -85,7 +85,9 @@ class Engine(object):
         check(self.L.zm_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)))
 
     # -- timing ----------------------------------------------------------------
-    def timing(self, on=True):
+    def timing(self, on=True, only=None):
+        """HIP-event timers around the launches; ``only``: time just that scope."""
+        check(self.L.zm_timing_filter(self._ctx, only.encode() if only else None))
         check(self.L.zm_timing_enable(self._ctx, int(on)))
 
     def timing_reset(self):
