@@ -119,7 +119,7 @@ def np_finalize(acc):
     a[a == -1] = 0
 
 
-def mask_worker(rank, world, port, kind, q):
+def mask_worker(rank, world, port, kind, q, banded=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -127,14 +127,14 @@ def mask_worker(rank, world, port, kind, q):
     base, frames = make_frames()
     mine = frames[:3] if rank == 0 else frames[3:]
     acc = torch.from_numpy(partial_mask(mine, base, kind))
-    par.reduce_masks(acc, np_accum(kind), np_finalize)
+    par.reduce_masks(acc, np_accum(kind), np_finalize, banded=banded)
     q.put((rank, acc.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['AND', 'OR'])
-def test_two_rank_mask_coadd_equals_single_process(kind):
+@pytest.mark.parametrize('kind,banded', [('AND', False), ('OR', False), ('AND', True), ('OR', True)])
+def test_two_rank_mask_coadd_equals_single_process(kind, banded):
     base, frames = make_frames()
     ref = partial_mask(frames, base, kind)
     ref[ref == -1] = 0
@@ -142,7 +142,7 @@ def test_two_rank_mask_coadd_equals_single_process(kind):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=mask_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    procs = [ctx.Process(target=mask_worker, args=(r, 2, port, kind, q, banded)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]

@@ -119,7 +119,7 @@ class DeviceCoadd(object):
                 reduce_masks(
                     self.mask,
                     lambda acc, m, first: check(L.zm_mask_accum_dev(ctx, acc.data_ptr(), m.data_ptr(),
-                                                                    n, kind, int(first)),
+                                                                    acc.numel(), kind, int(first)),
                                                 'zm_mask_accum_dev'),
                     lambda acc: check(L.zm_mask_finalize_dev(
                         ctx, acc.data_ptr(),

@@ -31,23 +31,65 @@ def band_bounds(nrows, world):
     return b
 
 
-def reduce_masks(acc, accum, finalize, group=None):
+def reduce_masks(acc, accum, finalize, group=None, banded=None):
     """Fold the partial mask coadds of all ranks into ``acc`` (in place) and finalise.
 
-    ``acc``: this rank's partial mask (tensor, -1 where none of its frames covers the
+    ``acc``: this rank's partial mask (2-D tensor, -1 where none of its frames covers the
     pixel).  ``accum(acc, m, first)`` folds one partial mask in, ``finalize(acc)`` turns the
-    marker into 0 / writes the coverage plane.  AND / OR are associative and commutative,
-    so every rank ends with the same mask whatever the order; NCCL / RCCL have no bitwise
-    reductions, hence an all-gather (world x 4 B / px) and a local fold.
+    marker into 0 / writes the coverage plane.  AND / OR are associative and commutative, so
+    every rank ends with the same mask whatever the order.  NCCL / RCCL have no bitwise
+    reductions; two exact schedules:
+
+    * all-gather of the whole masks and a local fold: world x 4 B / px per rank (default: one
+      collective of the most travelled kind);
+    * ``banded`` (``banded=True`` or ZM_MASK_BANDED=1): a reduce-scatter by hand - rank g
+      receives row band g of every rank (grouped send / recv, as the CLIPPED exchange), folds
+      it, and the folded bands are all-gathered: 2 x 4 B / px per rank whatever the world size.
     """
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world > 1:
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    if banded is None:
+        import os
+        banded = os.environ.get('ZM_MASK_BANDED', '0') not in ('', '0')
+    if world > 1 and not banded:
         parts = [torch.empty_like(acc) for _ in range(world)]
         dist.all_gather(parts, acc.contiguous(), group=group)
         for r, m in enumerate(parts):
             accum(acc, m, r == 0)
+    elif world > 1:
+        ny = acc.shape[0]
+        bounds = band_bounds(ny, world)
+        peer = (lambda g: g) if group is None else (lambda g: dist.get_global_rank(group, g))
+        mine = acc[bounds[rank]:bounds[rank + 1]]
+        recv = [torch.empty_like(mine) for _ in range(world)]
+        recv[rank].copy_(mine)
+        ops = []
+        for g in range(world):
+            if g == rank:
+                continue
+            band = acc[bounds[g]:bounds[g + 1]].contiguous()
+            if band.numel():
+                ops.append(dist.P2POp(dist.isend, band, peer(g), group))
+            if recv[g].numel():
+                ops.append(dist.P2POp(dist.irecv, recv[g], peer(g), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        folded = torch.empty_like(mine)
+        for r, m in enumerate(recv):
+            if m.numel():
+                accum(folded, m, r == 0)
+        # bands may differ by one row: gather through padded buffers
+        maxr = max(bounds[g + 1] - bounds[g] for g in range(world))
+        pad = torch.empty((maxr,) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
+        pad[:folded.shape[0]] = folded
+        allp = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(allp, pad, group=group)
+        for g in range(world):
+            acc[bounds[g]:bounds[g + 1]] = allp[g][:bounds[g + 1] - bounds[g]]
     finalize(acc)
     return acc
 
@@ -133,8 +175,9 @@ class HipBackend(object):
         self.engine.set_stream(self.stream.cuda_stream)
         with self.torch.cuda.stream(self.stream):
             reduce_masks(m,
-                         lambda acc, x, first: check(L.zm_mask_accum_dev(ctx, acc.data_ptr(), x.data_ptr(), n,
-                                                                         kind, int(first)), 'zm_mask_accum_dev'),
+                         lambda acc, x, first: check(L.zm_mask_accum_dev(ctx, acc.data_ptr(), x.data_ptr(),
+                                                                         acc.numel(), kind, int(first)),
+                                                     'zm_mask_accum_dev'),
                          lambda acc: check(L.zm_mask_finalize_dev(ctx, acc.data_ptr(),
                                                                   cov.data_ptr() if cov is not None else None,
                                                                   n), 'zm_mask_finalize_dev'),
