@@ -506,7 +506,7 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
     d[(size_t)reg * n + c] = v > 0.0 ? sqrt(v) : 1.0;
 }
 
-__global__ void k_hp_scale(int n, const double* __restrict__ A0, const double* __restrict__ rhs0,
+__global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
                            double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar) {
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
@@ -514,11 +514,12 @@ __global__ void k_hp_scale(int n, const double* __restrict__ A0, const double* _
         for (int k = 0; k < 4; ++k) bar[reg * CF_BAR_STRIDE + k] = 0;          // arms k_chol_fused's two region barriers
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
-    const size_t base = (size_t)reg * (size_t)(n + 1) * n;
-    double v = A0[base + (size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
+    const size_t base0 = (size_t)reg * (size_t)(n + 1) * n;
+    const size_t base = (size_t)reg * (size_t)(n + 1) * lda;     // rows of A are padded to whole 128-B lines
+    double v = A0[base0 + (size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
     if (c1 == c2) v += HP_RIDGE;   // keeps a rank-deficient basis solvable (oracle: RIDGE)
-    A[base + (size_t)c1 * n + c2] = v;
-    if (c2 == 0) A[base + (size_t)n * n + c1] = rhs0[(size_t)reg * n + c1] / dd[c1];   // rhs row
+    A[base + (size_t)c1 * lda + c2] = v;
+    if (c2 == 0) A[base + (size_t)n * lda + c1] = rhs0[(size_t)reg * n + c1] / dd[c1];   // rhs row
 }
 
 // ---- blocked Cholesky, lower, in place ------------------------------------------------
@@ -629,7 +630,8 @@ __device__ inline void region_arrive(unsigned* ctr) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A: [reg][(n + 1)][n]; Dg: [reg][2][32][33] published diagonal factors (two slots: the factor
+// A: [reg][(n + 1)][lda], lda = n rounded up to 16 doubles so that every 16-column segment
+// of a tile is one 128-B line; Dg: [reg][2][32][33] published diagonal factors (two slots: the factor
 // of block k + 1 is written while slower workgroups may still read that of block k).
 // Step k, W >= 2 workgroups per region:
 //   all   read the published factor of block k, solve their panel rows X L^T = B (register
@@ -641,13 +643,13 @@ __device__ inline void region_arrive(unsigned* ctr) {
 //         without the corner that workgroup 0 holds)                           | barrier b2
 // so the 32 x 32 factorisation - the longest serial piece - overlaps the panel barrier and the
 // trailing update instead of following them.
-__global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, double* Dgall, int* fail,
+__global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
                                                     unsigned* bar, long long* prof) {
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ double Li[64][CH_NB + 2];        // pitch 34: conflict-free ds_read_b64 of MFMA operands
     __shared__ double Lj[64][CH_NB + 2];
     const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
-    double* A = Aall + (size_t)reg * (size_t)(n + 1) * n;
+    double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
     double* Dg2 = Dgall + (size_t)reg * 2 * CH_NB * (CH_NB + 1);
     unsigned* ctr1 = bar + reg * CF_BAR_STRIDE;          // [0] panel barrier, [1] timed-out flag,
     unsigned* ctr2 = ctr1 + 2;                           // [2] update barrier (its flag is [3])
@@ -667,14 +669,14 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
         for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) st_sh(&Dg[e], D[e / (CH_NB + 1)][e % (CH_NB + 1)]);
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
             const int i = e >> 5, j = e & 31;
-            if (i < nb && j <= i) st_sh(&A[(size_t)(k0 + i) * n + k0 + j], D[i][j]);
+            if (i < nb && j <= i) st_sh(&A[(size_t)(k0 + i) * lda + k0 + j], D[i][j]);
         }
     };
     if (w == 0) {
         const int nb0 = min(CH_NB, n);
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
             const int i = e >> 5, j = e & 31;
-            D[i][j] = (i < nb0 && j <= i) ? ld_sh(&A[(size_t)i * n + j]) : (i == j ? 1.0 : 0.0);
+            D[i][j] = (i < nb0 && j <= i) ? ld_sh(&A[(size_t)i * lda + j]) : (i == j ? 1.0 : 0.0);
         }
         factor_and_publish(0, nb0, 0);
     }
@@ -698,11 +700,71 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q, i = e >> 5, j = e & 31;
-                if (i < nbn && j <= i) cpre[q] = ld_sh(&A[(size_t)(k1 + i) * n + k1 + j]);
+                if (i < nbn && j <= i) cpre[q] = ld_sh(&A[(size_t)(k1 + i) * lda + k1 + j]);
             }
-        // (a) the published factor of block kb
+        // trailing update: 64 x 64 tiles of the lower triangle dealt to workgroups 1 .. W - 1.
+        // The loop over a workgroup's tiles is software-pipelined (the next tile is requested
+        // before the matrix cores run on the current one), and the accumulators of its first tile
+        // - trailing-matrix entries, final since the last barrier - are requested here, ahead of
+        // the panel solve, so that only the panels are left to fetch after the panel barrier.
+        const int T = (max(below, 0) + 63) / 64;
+        const int ntile = T * (T + 1) / 2;
+        const int Wu = (W > 1) ? W - 1 : 1, wu = (W > 1) ? w - 1 : 0;
+        auto tile_of = [&](int t, int& i0, int& j0) {
+            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            i0 = k1 + ti * 64;
+            j0 = k1 + tj * 64;
+        };
+        // f64 matrix cores: wave v owns rows 16 v .. 16 v + 15 of the tile; C layout of
+        // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.
+        const int li = lane & 15, lk = lane >> 4;
+        double4_t accn[4];
+        double pa[8], pb[8];
+        auto tile_fetch_acc = [&](int t) {
+            int i0, j0;
+            tile_of(t, i0, j0);
+            const bool skip_corner = (t == 0) && (W > 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                    const bool corner = skip_corner && i < k1 + nbn;           // j <= i: in the block
+                    accn[c][rg] = (i < nrows && j < n && j <= i && !corner) ? ld_sh(&A[(size_t)i * lda + j]) : 0.0;
+                }
+        };
+        auto tile_fetch_panels = [&](int t) {
+            int i0, j0;
+            tile_of(t, i0, j0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 256 * q, r = e >> 5, m = e & 31;
+                pa[q] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * lda + k0 + m]) : 0.0;
+                pb[q] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * lda + k0 + m]) : 0.0;
+            }
+        };
+        if ((w != 0 || W == 1) && nb == CH_NB && wu < ntile) tile_fetch_acc(wu);
+        // the first panel rows of this step are requested before anything waits: they were
+        // final at the last barrier, so their latency overlaps that of the published factor
+        const int half = lane >> 5, pli = lane & 31;
+        double bj[4];
+        bool act[4];
+        auto panel_fetch = [&](int pp0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = pp0 + 8 * q + half;
+                act[q] = p < pend && pli < nb;
+                bj[q] = act[q] ? ld_sh(&A[(size_t)(k1 + p) * lda + k0 + pli]) : 0.0;
+            }
+        };
+        int pp0 = pbeg + 2 * wave;
+        if (pp0 < pend) panel_fetch(pp0);
+        // (a) the published factor of block kb; workgroup 0 factored it itself and still has it in D
         __syncthreads();                                         // D of the previous step is consumed
-        {
+        if (w != 0) {
             const double* Dg = Dg2 + (size_t)(kb & 1) * CH_NB * (CH_NB + 1);
             for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
         }
@@ -714,22 +776,13 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
         // dependent LDS reads per row.  Workgroup 0 also keeps its rows in LDS (Li) for the
         // look-ahead.
         {
-            const int half = lane >> 5, li = lane & 31;
             double lrow[CH_NB];
 #pragma unroll
-            for (int m = 0; m < CH_NB; ++m) lrow[m] = D[li][m];
-            const double rdl = D[li][CH_NB];                     // lane m holds 1 / L[m][m]
+            for (int m = 0; m < CH_NB; ++m) lrow[m] = D[pli][m];
+            const double rdl = D[pli][CH_NB];                    // lane m holds 1 / L[m][m]
             // four row pairs at a time: their loads go out together (one memory latency) and
             // the four register chains interleave
-            for (int pp0 = pbeg + 2 * wave; pp0 < pend; pp0 += 32) {
-                double bj[4];
-                bool act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = pp0 + 8 * q + half;
-                    act[q] = p < pend && li < nb;
-                    bj[q] = act[q] ? ld_sh(&A[(size_t)(k1 + p) * n + k0 + li]) : 0.0;
-                }
+            while (pp0 < pend) {
 #pragma unroll
                 for (int m = 0; m < CH_NB; ++m) {
                     const double r = readlane_d(rdl, m);
@@ -737,21 +790,21 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
                     for (int q = 0; q < 4; ++q) {
                         const double xa = readlane_d(bj[q], m) * r, xb = readlane_d(bj[q], 32 + m) * r;
                         const double xm = half ? xb : xa;
-                        bj[q] = (li == m) ? xm : ((li > m) ? bj[q] - lrow[m] * xm : bj[q]);
+                        bj[q] = (pli == m) ? xm : ((pli > m) ? bj[q] - lrow[m] * xm : bj[q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int p = pp0 + 8 * q + half;
-                    if (act[q]) st_sh(&A[(size_t)(k1 + p) * n + k0 + li], bj[q]);
-                    if (w == 0 && p < CH_NB) Li[p][li] = (p < pend) ? bj[q] : 0.0;
+                    if (act[q]) st_sh(&A[(size_t)(k1 + p) * lda + k0 + pli], bj[q]);
+                    if (w == 0 && p < CH_NB) Li[p][pli] = (p < pend) ? bj[q] : 0.0;
                 }
+                pp0 += 32;
+                if (pp0 < pend) panel_fetch(pp0);
             }
         }
         if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
         CF_TICK(2);
-        const int T = (below + 63) / 64;
-        const int ntile = T * (T + 1) / 2;
         if (w == 0 && W > 1) {
             // panel rows published: arrive, do not wait - nothing below needs the others' rows
             region_arrive(ctr1);
@@ -781,34 +834,25 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
             if (dead) break;
             // (c) trailing update A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle; the
             // corner of tile 0 (the next diagonal block) is workgroup 0's
-            const int Wu = (W > 1) ? W - 1 : 1, wu = (W > 1) ? w - 1 : 0;
-            for (int t = wu; t < ntile; t += Wu) {
-                int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-                while (ti * (ti + 1) / 2 > t) --ti;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                const int i0 = k1 + ti * 64, j0 = k1 + tj * 64;
-                const bool skip_corner = (t == 0) && (W > 1);
-                // f64 matrix cores: wave v owns rows 16 v .. 16 v + 15 of the tile; C layout of
-                // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.  The tile is
-                // loaded together with the two panels: one memory latency.
-                const int li = lane & 15, lk = lane >> 4;
+            int t = wu;
+            if (t < ntile) tile_fetch_panels(t);
+            while (t < ntile) {
+                int i0, j0;
+                tile_of(t, i0, j0);
                 double4_t acc[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                        const bool corner = skip_corner && i < k1 + nbn;           // j <= i: in the block
-                        acc[c][rg] = (i < nrows && j < n && j <= i && !corner) ? ld_sh(&A[(size_t)i * n + j]) : 0.0;
-                    }
+                for (int c = 0; c < 4; ++c) acc[c] = accn[c];
                 __syncthreads();                       // the previous tile's panels are consumed
-                for (int e = tid; e < 64 * CH_NB; e += 256) {
-                    const int r = e >> 5, m = e & 31;
-                    Li[r][m] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * n + k0 + m]) : 0.0;
-                    Lj[r][m] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * n + k0 + m]) : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + 256 * q, r = e >> 5, m = e & 31;
+                    Li[r][m] = pa[q];
+                    Lj[r][m] = pb[q];
                 }
                 __syncthreads();
+                CF_TICK(1);
+                const int tn = t + Wu;
+                if (tn < ntile) { tile_fetch_acc(tn); tile_fetch_panels(tn); }
 #pragma unroll
                 for (int kk = 0; kk < CH_NB / 4; ++kk) {
                     const double a = Li[16 * wave + li][4 * kk + lk];
@@ -835,9 +879,10 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
                     for (int rg = 0; rg < 4; ++rg) {
                         const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
                         const bool corner = (t == 0) && i < k1 + nbn;              // stored factored instead
-                        if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * n + j], acc[c][rg]);
+                        if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * lda + j], acc[c][rg]);
                     }
                 if (W == 1 && t == 0) factor_and_publish(k1, nbn, (kb + 1) & 1);
+                t = tn;
             }
             CF_TICK(4);
         }
@@ -853,24 +898,24 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int W, double* Aall, 
 
 // Back substitution L^T x = y (y = row n of the factored storage), one workgroup
 // of 1024 threads per region; then x /= d (Jacobi scaling) into xout.
-__global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restrict__ Aall,
+__global__ __launch_bounds__(1024) void k_chol_back(int n, int lda, const double* __restrict__ Aall,
                                                     const double* __restrict__ dall,
                                                     double* __restrict__ xall) {
     extern __shared__ double cb_smem[];
     double* y = cb_smem;                                   // [n]
     double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(cb_smem + ((n + 1) & ~1));
-    const double* A = Aall + (size_t)blockIdx.x * (size_t)(n + 1) * n;
+    const double* A = Aall + (size_t)blockIdx.x * (size_t)(n + 1) * lda;
     const double* d = dall + (size_t)blockIdx.x * n;
     double* xo = xall + (size_t)blockIdx.x * n;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 1024) y[i] = A[(size_t)n * n + i];
+    for (int i = tid; i < n; i += 1024) y[i] = A[(size_t)n * lda + i];
     const int nblk = (n + CH_NB - 1) / CH_NB;
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
         __syncthreads();
         {
             const int i = tid >> 5, j = tid & 31;          // 1024 threads = 32 x 32
-            const double v = (i < nb && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+            const double v = (i < nb && j <= i) ? A[(size_t)(k0 + i) * lda + k0 + j] : (i == j ? 1.0 : 0.0);
             D[i][j] = v;
             if (i == j) D[i][CH_NB] = 1.0 / v;             // 32 divisions side by side, none in the chain
         }
@@ -896,7 +941,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, const double* __restr
         for (int c = tid; c < k0; c += 1024) {
             double acc = 0.0;
 #pragma unroll 8
-            for (int m = 0; m < nb; ++m) acc += A[(size_t)(k0 + m) * n + c] * y[k0 + m];
+            for (int m = 0; m < nb; ++m) acc += A[(size_t)(k0 + m) * lda + c] * y[k0 + m];
             y[c] -= acc;
         }
     }
@@ -1335,7 +1380,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_Gp", sizeof(double) * (size_t)P.ncell * GR_SPLIT * HP_MAXX * HP_MAXX, (void**)&Gp));
     ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
     ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
-    ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A));
+    const int lda = (P.nunk + 15) & ~15;       // factored storage: rows padded to whole 128-B lines
+    ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * lda, (void**)&A));
     ZM_TRY(ctx->get("hp_rhs", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs));
     double *A0 = nullptr, *rhs0 = nullptr;   // unscaled normal matrix / right-hand side, kept over the rounds
     ZM_TRY(ctx->get("hp_A0", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk, (void**)&A0));
@@ -1425,8 +1471,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
                                rounds == 1 ? 0 : 1, A0, rhs0);
             hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc);
-            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, A0,
-                               rhs0, A, dsc, cbar);
+            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
+                               A0, rhs0, A, dsc, cbar);
             {
                 // one cooperative launch: W workgroups per region, all resident
                 // One workgroup per CU: a second one on the same CU slows the serial chains of the
@@ -1453,13 +1499,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
                 // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
                 // order against the following launches of the stream on its first use)
-                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, W, Aarg, dgarg, farg, barg, parg);
+                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, barg, parg);
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
                     std::vector<long long> hp((size_t)6 * P.nreg * W);
                     ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
                     ZM_HIP(hipStreamSynchronize(st));
-                    static const char* nm[6] = {"load", "-", "panel", "barrier1", "update", "barrier2"};
+                    static const char* nm[6] = {"load", "tilewait", "panel", "barrier1", "update", "barrier2"};
                     for (int wg : {0, 1, W - 1, W, (P.nreg - 1) * W}) {
                         fprintf(stderr, "chol wg %3d:", wg);
                         for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f us", nm[k], hp[(size_t)wg * 6 + k] * 0.01);
@@ -1477,7 +1523,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     bset = true;
                 }
                 ZM_CHECK(bsh <= 160 * 1024 - 64, "zm_subtract: %d unknowns exceed the solver's LDS", P.nunk);
-                hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, A, dsc, rhs);
+                hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs);
             }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
             hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
