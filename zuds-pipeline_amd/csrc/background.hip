@@ -351,11 +351,21 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
     }
     const double K = (double)kf;
     // ---- pass 1: all valid pixels
+    // branch-free: an excluded pixel is replaced by the pivot (d = 0 adds nothing, exactly) and
+    // counted with integers, so a pixel costs one conversion and three fp64 operations
     double s0 = 0, s1 = 0, s2 = 0;
+    {
+        int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < BKF_PX; ++k) {
-        const float x = v[k];
-        if (x == x) { const double d = (double)x - K; s0 += 1.0; s1 += d; s2 += d * d; }
+        for (int k = 0; k < BKF_PX; ++k) {
+            const float x = v[k];
+            const bool in = (x == x);
+            const double d = (double)(in ? x : kf) - K;
+            cnt += in ? 1 : 0;
+            s1 += d;
+            s2 = fma(d, d, s2);
+        }
+        s0 = (double)cnt;
     }
     blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
@@ -368,10 +378,23 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
     const double lc = K + dm - 2.0 * sig, hc = K + dm + 2.0 * sig;
     // ---- pass 2: 2-sigma clipped
     s0 = s1 = s2 = 0;
+    {
+        // x >= lc (double) <=> x >= the smallest float >= lc; likewise for the upper cut: the
+        // comparisons run in fp32 with the same outcome
+        float lcf = (float)lc, hcf = (float)hc;
+        if ((double)lcf < lc) lcf = nextafterf(lcf, INFINITY);
+        if ((double)hcf > hc) hcf = nextafterf(hcf, -INFINITY);
+        int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < BKF_PX; ++k) {
-        const float x = v[k];
-        if (x == x && x >= lc && x <= hc) { const double d = (double)x - K; s0 += 1.0; s1 += d; s2 += d * d; }
+        for (int k = 0; k < BKF_PX; ++k) {
+            const float x = v[k];
+            const bool in = (x >= lcf) && (x <= hcf);          // false for NaN
+            const double d = (double)(in ? x : kf) - K;
+            cnt += in ? 1 : 0;
+            s1 += d;
+            s2 = fma(d, d, s2);
+        }
+        s0 = (double)cnt;
     }
     blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < 1.0) {

@@ -17,7 +17,7 @@
 //   k_hp_build      global normal matrix of a region from the per-cell Grams
 //   k_chol_fused    blocked Cholesky (NB = 32) of every region in one launch: region
 //                   barriers, MFMA trailing update, look-ahead diagonal factor
-//   k_chol_back     back substitution
+//   k_chol_back     back substitution (k_chol_back_cols: column per thread, up to 960 unknowns)
 //   k_hp_merit / k_hp_reject    stamp figure of merit, sigma clip, next substamp
 //   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
 //                   fp32 convolution of template and template variance
@@ -949,6 +949,100 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, int lda, const double
     for (int i = tid; i < n; i += 1024) xo[i] = y[i] / d[i];
 }
 
+// Back substitution for n <= CBC_COLS unknowns, one workgroup per region: thread 64 + c owns
+// column c and keeps y[c] in a register, wave 0 only runs the 32-step chain of each diagonal
+// block.  The 32 rows of L a column thread needs for block kb - 1 are requested as soon as those
+// of block kb are consumed, and the diagonal block one step further ahead, so the chain of one
+// block covers the memory latency of the next: a step costs the chain plus two barriers
+// (k_chol_back above pays a dependent global load per block on top of it).
+#define CBC_THREADS 1024
+#define CBC_COLS (CBC_THREADS - 64)
+__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, const double* __restrict__ Aall,
+                                                                const double* __restrict__ dall,
+                                                                double* __restrict__ xall) {
+    __shared__ double Dn[CH_NB][CH_NB + 1];      // diagonal block of the coming chain, 1 / diag in column 32
+    __shared__ double xs[CH_NB];                 // the block just solved
+    __shared__ double ys[CH_NB];                 // right-hand side of the coming chain
+    const double* A = Aall + (size_t)blockIdx.x * (size_t)(n + 1) * lda;
+    const int tid = threadIdx.x;
+    const bool chain = tid < 64;
+    const int c = tid - 64;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    double yc = 0.0, a[CH_NB], dnext[2] = {0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < CH_NB; ++m) a[m] = 0.0;
+    // element e of a diagonal block (row e >> 5, column e & 31); rows >= nb are identity rows
+    auto diag_elem = [&](int k0, int nb, int e) -> double {
+        const int i = e >> 5, j = e & 31;
+        return (i < nb && j <= i) ? A[(size_t)(k0 + i) * lda + k0 + j] : (i == j ? 1.0 : 0.0);
+    };
+    auto diag_put = [&](int e, double v) {
+        const int i = e >> 5, j = e & 31;
+        Dn[i][j] = v;
+        if (i == j) Dn[i][CH_NB] = 1.0 / v;
+    };
+    {
+        const int kb = nblk - 1, k0 = kb * CH_NB, nb = n - k0;
+        if (!chain) {
+            yc = (c < n) ? A[(size_t)n * lda + c] : 0.0;
+            diag_put(c, diag_elem(k0, nb, c));
+            if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, diag_elem(k0, nb, c + CBC_COLS));
+            if (c >= k0 && c < k0 + CH_NB) ys[c - k0] = yc;          // 0 beyond column n - 1
+#pragma unroll
+            for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0 && m < nb) ? A[(size_t)(k0 + m) * lda + c] : 0.0;
+            if (kb > 0) {
+                dnext[0] = diag_elem(k0 - CH_NB, CH_NB, c);
+                if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0 - CH_NB, CH_NB, c + CBC_COLS);
+            }
+        }
+    }
+    __syncthreads();
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        if (chain) {
+            // lane i keeps column i of the block (L[j][i], j = 0 .. 31) and the reciprocal
+            // diagonal in registers: a step of the chain is a readlane, a multiply and an FMA
+            const int li = tid & 31;
+            double col[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) col[j] = Dn[j][li];
+            const double rdl = Dn[li][CH_NB];
+            double bi = ys[li];
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 0; --j) {
+                const double xj = readlane_d(bi, j) * readlane_d(rdl, j);
+                bi = (li == j) ? xj : ((li < j) ? bi - col[j] * xj : bi);   // L^T[i][j] = L[j][i]
+            }
+            if (tid < CH_NB) xs[tid] = bi;
+        }
+        __syncthreads();                                   // xs is ready; Dn and ys are consumed
+        if (!chain) {
+            if (c >= k0 && c < k0 + nb) {
+                yc = xs[c - k0];
+            } else if (c < k0) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < CH_NB; ++m) acc += a[m] * xs[m];
+                yc -= acc;
+            }
+            if (kb > 0) {
+                const int k0n = k0 - CH_NB;
+                diag_put(c, dnext[0]);
+                if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, dnext[1]);
+                if (c >= k0n && c < k0) ys[c - k0n] = yc;
+#pragma unroll
+                for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0n) ? A[(size_t)(k0n + m) * lda + c] : 0.0;
+                if (kb > 1) {
+                    dnext[0] = diag_elem(k0n - CH_NB, CH_NB, c);
+                    if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0n - CH_NB, CH_NB, c + CBC_COLS);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!chain && c < n) xall[(size_t)blockIdx.x * n + c] = yc / dall[(size_t)blockIdx.x * n + c];
+}
+
 // ---------------------------------------------------------------------------
 // merit[cell] = (I.I - 2 c.b + c^T Q c) / (npix vbar), c = per-cell coefficients
 __global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* __restrict__ G,
@@ -1523,7 +1617,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     bset = true;
                 }
                 ZM_CHECK(bsh <= 160 * 1024 - 64, "zm_subtract: %d unknowns exceed the solver's LDS", P.nunk);
-                hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs);
+                if (P.nunk <= CBC_COLS)
+                    hipLaunchKernelGGL(k_chol_back_cols, dim3(P.nreg), dim3(CBC_THREADS), 0, st, P.nunk, lda, A, dsc, rhs);
+                else
+                    hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs);
             }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
             hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
