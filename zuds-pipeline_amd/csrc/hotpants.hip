@@ -234,8 +234,10 @@ __device__ inline double ipowd(double x, int n) {
 // Workgroups per cell (blockIdx.y): the x filters in use are dealt round-robin, each
 // workgroup runs its x passes and the y passes of the terms built on them.  After the first
 // round only the few cells with a replaced substamp are recomputed, so a cell's latency,
-// not the throughput, sets the kernel time.
-#define HV_SPLIT 8
+// not the throughput, sets the kernel time: the first round runs HV_SPLIT_ALL parts per cell
+// (less of term 0 rebuilt), the later ones HV_SPLIT_FEW.
+#define HV_SPLIT_ALL 5
+#define HV_SPLIT_FEW 15
 
 template <int HWK>
 __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
@@ -1542,7 +1544,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             zm_scope_timer t(ctx, "hp_vectors");
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, HV_SPLIT), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
+    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
                        centres, active, need, X, phi, vbar); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
