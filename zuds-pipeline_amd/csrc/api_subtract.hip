@@ -114,41 +114,63 @@ __global__ __launch_bounds__(256) void k_rsel_hist(const rs_batch B, int vec_ok,
 __global__ __launch_bounds__(256) void k_rsel_scan(int pass, int mode, int shift, int nbins,
                                                    rs_state* __restrict__ st,
                                                    unsigned int* __restrict__ hist) {
-    __shared__ unsigned long long part[256];
+    __shared__ unsigned long long wtot[4];
     __shared__ rs_state S;
     const int im = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     unsigned int* h = hist + (size_t)im * 2 * RS_BINS;
     if (tid == 0) S = st[im];
     __syncthreads();
     const bool two = S.prefix[1] != S.prefix[0];
     const int per = nbins / 256;                         // 8 or 4 bins per thread
+    // rank k falls into the first run of `per` bins whose cumulative count exceeds it (the last
+    // run if none does), then into the first such bin of that run: a block-wide prefix sum
+    // finds the run, its owner walks its own bins
     for (int t = 0; t < 2; ++t) {
         const unsigned int* ht = h + (two && t == 1 ? RS_BINS : 0);
+        unsigned int hl[8];
         unsigned long long loc = 0;
-        for (int j = 0; j < per; ++j) loc += ht[tid * per + j];
-        part[tid] = loc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hl[j] = j < per ? ht[tid * per + j] : 0u;
+            loc += hl[j];
+        }
+        unsigned long long inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wtot[wave] = inc;
         __syncthreads();
-        if (tid == 0) {
-            unsigned long long tot = 0;
-            for (int j = 0; j < 256; ++j) tot += part[j];
-            if (pass == 0 && t == 0) {
-                S.count = tot;
-                S.k[0] = tot ? (tot - 1) / 2 : 0;
-                S.k[1] = tot / 2 < tot ? tot / 2 : (tot ? tot - 1 : 0);
-            }
-            unsigned long long k = S.k[t], runsum = 0;
-            int blk = 0;
-            for (; blk < 255; ++blk) {
-                if (runsum + part[blk] > k) break;
-                runsum += part[blk];
-            }
-            int b = blk * per;
-            for (; b < blk * per + per - 1; ++b) {
-                if (runsum + ht[b] > k) break;
-                runsum += ht[b];
-            }
+        unsigned long long off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) off += wtot[w];
+            tot += wtot[w];
+        }
+        const unsigned long long excl = off + inc - loc;
+        if (pass == 0 && t == 0 && tid == 0) {
+            S.count = tot;
+            S.k[0] = tot ? (tot - 1) / 2 : 0;
+            S.k[1] = tot / 2 < tot ? tot / 2 : (tot ? tot - 1 : 0);
+        }
+        __syncthreads();
+        const unsigned long long k = S.k[t];
+        __syncthreads();
+        const bool hit = (tid == 255) ? (k >= excl) : (k >= excl && k < excl + loc);
+        if (hit) {
+            unsigned long long runsum = excl;
+            int jsel = per - 1;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (!found && j < per - 1) {
+                    if (runsum + hl[j] > k) { jsel = j; found = true; }
+                    else runsum += hl[j];
+                }
             S.k[t] = k - runsum;
-            S.prefix[t] |= (uint32_t)b << shift;
+            S.prefix[t] |= (uint32_t)(tid * per + jsel) << shift;
         }
         __syncthreads();
     }
