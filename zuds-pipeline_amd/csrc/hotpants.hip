@@ -217,6 +217,118 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
     }
 }
 
+// The same for cells of at most 256 * HC_PX pixels: a thread keeps its pixels (k = tid + 256 i,
+// the order of the loops above, so the sums are the same to the last bit) and their two flags in
+// registers; the eight clipping sweeps and the greedy picks then read no memory at all.
+#define HC_PX 48
+__global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const float* __restrict__ ref,
+                                                      const uint8_t* __restrict__ bad,
+                                                      const uint8_t* __restrict__ dirty,
+                                                      int2* __restrict__ centres) {
+    __shared__ double red[4];
+    __shared__ float bval[4];
+    __shared__ int bidx[4];
+    __shared__ int2 chosen[HP_MAXNSS];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    const int r = cell / P.ncellr, c = cell - r * P.ncellr;
+    const int sy = c / P.nsx, sx = c - sy * P.nsx;
+    const int cw = (P.rx1[r] - P.rx0[r]) / P.nsx, ch = (P.ry1[r] - P.ry0[r]) / P.nsy;
+    const int cx0 = P.rx0[r] + sx * cw, cy0 = P.ry0[r] + sy * ch;
+    const int n = cw * ch;
+    const int dyy = 256 / cw, dxx = 256 - dyy * cw;        // (yy, xx) advance by 256 pixels
+    const int yy0 = tid / cw, xx0 = tid - yy0 * cw;
+    float v[HC_PX];
+    unsigned long long okm = 0, cleanm = 0;                // bit i: pixel i is not bad / not dirty
+    {
+        int yy = yy0, xx = xx0;
+#pragma unroll
+        for (int i = 0; i < HC_PX; ++i) {
+            const int k = tid + 256 * i;
+            float val = 0.f;
+            if (k < n) {
+                const size_t idx = (size_t)(cy0 + yy) * P.nx + cx0 + xx;
+                val = ref[idx];
+                if (!bad[idx]) okm |= 1ull << i;
+                if (!dirty[idx]) cleanm |= 1ull << i;
+            }
+            v[i] = val;
+            xx += dxx; yy += dyy;
+            if (xx >= cw) { xx -= cw; ++yy; }
+        }
+    }
+    double m = 0.0, s = 0.0;
+    for (int pass = 0; pass < 4; ++pass) {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < HC_PX; ++i) {
+            const double vv = v[i];
+            if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) { s0 += 1.0; s1 += vv; }
+        }
+        s0 = block_sum256(s0, red);
+        s1 = block_sum256(s1, red);
+        if (s0 < 1.0) break;
+        const double mn = s1 / s0;
+        double s2 = 0;
+#pragma unroll
+        for (int i = 0; i < HC_PX; ++i) {
+            const double vv = v[i];
+            if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) s2 += (vv - mn) * (vv - mn);
+        }
+        s2 = block_sum256(s2, red);
+        m = mn;
+        s = sqrt(s2 / s0);
+    }
+    const double thr = m + P.ft * s;
+    // candidates: clean pixels at or above the threshold
+    unsigned long long cand = 0;
+#pragma unroll
+    for (int i = 0; i < HC_PX; ++i)
+        if ((cleanm >> i & 1) && ((double)v[i] >= thr)) cand |= 1ull << i;
+    for (int k = 0; k < P.nss; ++k) {
+        float best = -__builtin_inff();
+        int bi = 0x7fffffff;
+        {
+            int yy = yy0, xx = xx0;
+#pragma unroll
+            for (int i = 0; i < HC_PX; ++i) {
+                if (cand >> i & 1) {
+                    const int x = cx0 + xx, y = cy0 + yy, q = tid + 256 * i;
+                    bool excl = false;
+                    for (int e = 0; e < k; ++e)
+                        excl |= (abs(x - chosen[e].x) <= P.hwss) && (abs(y - chosen[e].y) <= P.hwss);
+                    if (excl) cand &= ~(1ull << i);          // stays excluded for the later picks
+                    else if (v[i] > best || (v[i] == best && q < bi)) { best = v[i]; bi = q; }
+                }
+                xx += dxx; yy += dyy;
+                if (xx >= cw) { xx -= cw; ++yy; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { bval[tid >> 6] = best; bidx[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (bval[w] > best || (bval[w] == best && bidx[w] < bi)) { best = bval[w]; bi = bidx[w]; }
+            int2 cc = make_int2(-1, -1);
+            if (bi != 0x7fffffff) { int yy = bi / cw; cc = make_int2(cx0 + bi - yy * cw, cy0 + yy); }
+            chosen[k] = cc;
+            centres[cell * P.nss + k] = cc;
+        }
+        __syncthreads();
+        if (chosen[k].x < 0) {   // nothing left: the remaining slots are empty too
+            if (tid == 0)
+                for (int e = k + 1; e < P.nss; ++e) centres[cell * P.nss + e] = make_int2(-1, -1);
+            break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Per-cell state: active[cell] = index of the substamp in use (-1: none),
 // need[cell] = vectors / Gram must be (re)computed this round.
@@ -1519,7 +1631,15 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     }
     {
         zm_scope_timer t(ctx, "hp_cells");
-        hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+        {
+            int maxcell = 0;
+            for (int r = 0; r < P.nreg; ++r)
+                maxcell = std::max(maxcell, ((P.rx1[r] - P.rx0[r]) / P.nsx) * ((P.ry1[r] - P.ry0[r]) / P.nsy));
+            if (maxcell <= 256 * HC_PX)
+                hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+            else
+                hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+        }
         hipLaunchKernelGGL(k_hp_init_active, dim3(zm_div_up(P.ncell, 256)), b256, 0, st, P, centres, active,
                            need, ntotal);
         ZM_HIP(hipGetLastError());
