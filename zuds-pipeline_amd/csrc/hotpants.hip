@@ -48,6 +48,7 @@ struct hp_plan {
     double tscale[HP_MAXX];
     int kpi[HP_MAXPOLY], kpj[HP_MAXPOLY];   // kernel spatial terms x^i y^j
     int bpi[16], bpj[16];                   // background terms
+    int ngauss, gdeg[4], gbase[4], gterm0[4];   // per Gaussian: degree, first 1-D filter, first term
 };
 
 // ---------------------------------------------------------------------------
@@ -1272,6 +1273,11 @@ __global__ void k_hp_init_active(const hp_plan P, const int2* __restrict__ centr
     if (has) atomicAdd(&ntotal[cell / P.ncellr], 1);
 }
 
+// background coefficient t of a region's solution vector
+__device__ inline double xs_bg(const double* __restrict__ xsol, int reg, const hp_plan& P, int t) {
+    return xsol[(size_t)reg * P.nunk + 1 + (size_t)(P.nc - 1) * P.nkp + t];
+}
+
 // ---------------------------------------------------------------------------
 // Apply.  One workgroup = NB consecutive kernel blocks of one block row; each lane
 // owns R consecutive output pixels of one row of one block and slides a register
@@ -1292,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
                                                   const float* __restrict__ srms,
                                                   const float* __restrict__ trms,
                                                   const uint8_t* __restrict__ outbad,
-                                                  const double* __restrict__ basis,   // [nc][STEP*STEP]
+                                                  const double* __restrict__ filt,    // [nf1][STEP] 1-D filters
                                                   const double* __restrict__ xsol,
                                                   float* __restrict__ diff,
                                                   float* __restrict__ noise,
@@ -1310,8 +1316,17 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     typedef float ap_v2f __attribute__((ext_vector_type(2)));
     extern __shared__ float ap_smem[];
     ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TW]
-    ap_v2f* kc = tTV + TH * TW;                                    // [NB][STEP*STEP]
+    // the tile's space first serves the kernel evaluation (solution vector, term scales, 1-D
+    // filters, g_f, s0: nunk + nc + (NB + 1) nf1 STEP + NB doubles) and last the output staging
+    const int tvn = max(TH * TW, P.nunk + P.nc + (NB + 1) * P.nf1 * STEP + NB);
+    ap_v2f* kc = tTV + tvn;                                        // [NB][STEP*STEP]
     double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP);  // [NB][nc]
+    __shared__ int wmask[4];
+    double* xs = reinterpret_cast<double*>(ap_smem);                // [nunk] this region's solution
+    double* ts = xs + P.nunk;                                       // [nc] term scales
+    double* fl = ts + P.nc;                                         // [nf1][STEP]
+    double* gf = fl + P.nf1 * STEP;                                 // [NB][nf1][STEP]
+    double* s0v = gf + NB * P.nf1 * STEP;                           // [NB] sum of the c_n with sub0_n
     const int tid = threadIdx.x;
     const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
     const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
@@ -1320,95 +1335,183 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
     const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
     const double* x = xsol + (size_t)reg * P.nunk;
+    for (int e = tid; e < P.nunk; e += 256) xs[e] = x[e];
+    for (int e = tid; e < P.nc; e += 256) ts[e] = P.tscale[e];
+    for (int e = tid; e < P.nf1 * STEP; e += 256) fl[e] = filt[e];
+    __syncthreads();
     // per-block basis coefficients at the nominal block centre (fp64)
     for (int e = tid; e < NB * P.nc; e += 256) {
         int b = e / P.nc, n = e - b * P.nc;
         double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
         double v;
-        if (n == 0) v = x[0];
+        if (n == 0) v = xs[0];
         else {
             v = 0.0;
             for (int p = 0; p < P.nkp; ++p)
-                v += x[1 + (n - 1) * P.nkp + p] * ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
+                v += xs[1 + (n - 1) * P.nkp + p] * ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
         }
         cf[e] = v;
     }
-    // tile of template and template variance (zeros outside the frame / non-finite)
-    for (int e = tid; e < TH * TW; e += 256) {
-        int yy = e / TW, xx = e - yy * TW;
-        int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
-        float t = 0.f, v = 0.f;
-        if (gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
-            size_t idx = (size_t)gy * P.nx + gx;
-            t = ref[idx];
-            float rr = trms[idx];
-            v = rr * rr;
-            if (!(fabsf(t) < 3e38f)) t = 0.f;
-            if (!(fabsf(v) < 3e38f)) v = 0.f;
+    __syncthreads();
+    if (tid < NB) {
+        double t = 0.0;
+        for (int n = 0; n < P.nc; ++n)
+            if (P.tsub0[n]) t += cf[tid * P.nc + n];
+        s0v[tid] = t;
+    }
+    __syncthreads();
+    // the block kernels from the separable form of the basis, all operands in LDS:
+    //   K[v][u] = sum_n c_n (s_n fy_n[v] fx_n[u] - [sub0_n] s_0 fy_0[v] fx_0[u]) = sum_f fx_f[u] g_f[v],
+    //   g_f[v] = sum_{n: fx_n = f} c_n s_n fy_n[v]  -  [f = fx_0] (sum_{n: sub0_n} c_n) s_0 fy_0[v]
+    // 15 terms per tap instead of 49 fp64 rows of the 2-D basis fetched from L2.  The terms of
+    // Gaussian g are ordered (a, b): those sharing the x filter base_g + a are consecutive.
+    for (int e = tid; e < NB * STEP * P.ngauss; e += 256) {
+        const int g = e / (NB * STEP), r = e - g * NB * STEP;
+        const int b = r / STEP, v = r - b * STEP;
+        const double* cb = cf + b * P.nc;
+        const int deg = P.gdeg[g], fb = P.gbase[g];
+        int n = P.gterm0[g];
+        for (int a = 0; a <= deg; ++a) {
+            double acc = 0.0;
+            for (int bb = 0; bb <= deg - a; ++bb, ++n) acc += cb[n] * ts[n] * fl[(fb + bb) * STEP + v];
+            if (fb + a == P.tfx[0])                                 // the x filter of term 0
+                acc -= s0v[b] * ts[0] * fl[P.tfy[0] * STEP + v];
+            gf[((size_t)b * P.nf1 + fb + a) * STEP + v] = acc;
         }
-        tTV[e] = (ap_v2f){t, v};
     }
     __syncthreads();
     for (int e = tid; e < NB * STEP * STEP; e += 256) {
-        int b = e / (STEP * STEP), tap = e - b * STEP * STEP;
+        const int b = e / (STEP * STEP), tap = e - b * STEP * STEP;
+        const int v = tap / STEP, u = tap - v * STEP;
+        const double* gb = gf + (size_t)b * P.nf1 * STEP + v;
         double acc = 0.0;
-        for (int n = 0; n < P.nc; ++n) acc += cf[b * P.nc + n] * basis[(size_t)n * STEP * STEP + tap];
+#pragma unroll 5
+        for (int f = 0; f < P.nf1; ++f) acc += fl[f * STEP + u] * gb[f * STEP];
         const float k = (float)acc;
         kc[e] = (ap_v2f){k, k * k};
     }
+    const double bg0 = xs[1 + (size_t)(P.nc - 1) * P.nkp];       // constant background term
+    const float norm = P.normalize ? (float)(1.0 / xs[0]) : 1.f;
+    __syncthreads();                                   // the evaluation scratch is free
+    // tile of template and template variance (zeros outside the frame / non-finite)
+    // (every load of a thread goes out before the first LDS store: one memory latency per
+    // workgroup instead of one per loop iteration)
+    {
+        constexpr int NIT = (TH * TW + 255) / 256;
+        float tt[NIT], tr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it;
+            const int yy = e / TW, xx = e - yy * TW;
+            const int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
+            tt[it] = 0.f;
+            tr[it] = 0.f;
+            if (e < TH * TW && gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
+                const size_t idx = (size_t)gy * P.nx + gx;
+                tt[it] = ref[idx];
+                tr[it] = trms[idx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it;
+            float t = tt[it], v = tr[it] * tr[it];
+            if (!(fabsf(t) < 3e38f)) t = 0.f;
+            if (!(fabsf(v) < 3e38f)) v = 0.f;
+            if (e < TH * TW) tTV[e] = (ap_v2f){t, v};
+        }
+    }
     __syncthreads();
     const int b = tid / LPB;
-    if (b >= NB) return;
     const int l = tid - b * LPB;
     const int row = l / LPR, strip = l - row * LPR;
     const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
-    const int gy = gy0 + row;
-    if (gy >= y1r || gy >= P.ny) return;
+    const bool live = b < NB && gy0 + row < y1r && gy0 + row < P.ny;
     ap_v2f acc2[R];                                    // {sum k T, sum k^2 V}
 #pragma unroll
     for (int q = 0; q < R; ++q) acc2[q] = (ap_v2f){0.f, 0.f};
-    const ap_v2f* kb = kc + b * STEP * STEP;
-    // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
-    for (int v = -HWK; v <= HWK; ++v) {
-        const ap_v2f* rt = tTV + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
-        ap_v2f w2[R + 2 * HWK];
+    if (live) {
+        const ap_v2f* kb = kc + b * STEP * STEP;
+        // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
+        for (int v = -HWK; v <= HWK; ++v) {
+            const ap_v2f* rt = tTV + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
+            ap_v2f w2[R + 2 * HWK];
 #pragma unroll
-        for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[q];
-        const ap_v2f* kr = kb + (v + HWK) * STEP;
+            for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[q];
+            const ap_v2f* kr = kb + (v + HWK) * STEP;
 #pragma unroll
-        for (int u = -HWK; u <= HWK; ++u) {
-            const ap_v2f k2 = kr[u + HWK];
+            for (int u = -HWK; u <= HWK; ++u) {
+                const ap_v2f k2 = kr[u + HWK];
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
+                for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
+            }
         }
     }
-    float accT[R], accV[R];
+    // the sums go through LDS (the tile's space) so that the science / noise planes are read and
+    // the outputs written along rows: NB STEP consecutive pixels per row instead of R per thread
+    constexpr int OW = NB * STEP;
+    __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) { accT[q] = acc2[q].x; accV[q] = acc2[q].y; }
-    const double* bgc = x + 1 + (size_t)(P.nc - 1) * P.nkp;
-    const float norm = P.normalize ? (float)(1.0 / x[0]) : 1.f;
+        for (int q = 0; q < R; ++q)
+            if (strip * R + q < STEP) tTV[row * OW + ox0 + q] = acc2[q];
+    }
+    __syncthreads();
     int masked = 0;
+    {
+        constexpr int NE = (STEP * OW + 255) / 256;
+        float es[NE], er[NE];
+        bool eb[NE], ein[NE];
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const int gx = gx0 + ox0 + q;
-        if (strip * R + q >= STEP || gx >= x1r || gx >= P.nx) continue;
-        const size_t idx = (size_t)gy * P.nx + gx;
-        float d = P.fi, nz = P.fin;
-        if (solved && !outbad[idx]) {
-            double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
-            double bg = 0.0;
-            for (int t = 0; t < P.nbg; ++t)
-                bg += bgc[t] * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
-            float sr = srms[idx];
-            d = (sci[idx] - accT[q] - (float)bg) * norm;
-            nz = sqrtf(fmaxf(sr * sr + accV[q], 0.f)) * fabsf(norm);
-        } else {
-            masked += 1;
+        for (int it = 0; it < NE; ++it) {
+            const int e = tid + 256 * it;
+            const int orow = e / OW, ocol = e - orow * OW;
+            const int gx = gx0 + ocol, gy = gy0 + orow;
+            ein[it] = e < STEP * OW && gx < x1r && gx < P.nx && gy < y1r && gy < P.ny;
+            es[it] = er[it] = 0.f;
+            eb[it] = true;
+            if (ein[it]) {
+                const size_t idx = (size_t)gy * P.nx + gx;
+                eb[it] = outbad[idx] != 0;
+                es[it] = sci[idx];
+                er[it] = srms[idx];
+            }
         }
-        diff[idx] = d;
-        noise[idx] = nz;
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            if (!ein[it]) continue;
+            const int e = tid + 256 * it;
+            const int orow = e / OW, ocol = e - orow * OW;
+            const int gx = gx0 + ocol, gy = gy0 + orow;
+            const size_t idx = (size_t)gy * P.nx + gx;
+            float d = P.fi, nz = P.fin;
+            if (solved && !eb[it]) {
+                double bg = bg0;
+                if (P.nbg > 1) {
+                    const double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
+                    bg = 0.0;
+                    for (int t = 0; t < P.nbg; ++t)
+                        bg += xs_bg(xsol, reg, P, t) * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
+                }
+                const ap_v2f a = tTV[e];
+                d = (es[it] - a.x - (float)bg) * norm;
+                nz = sqrtf(fmaxf(er[it] * er[it] + a.y, 0.f)) * fabsf(norm);
+            } else {
+                masked += 1;
+            }
+            diff[idx] = d;
+            noise[idx] = nz;
+        }
     }
-    if (masked) atomicAdd(nmasked, masked);
+    // one atomic per workgroup
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) masked += __shfl_xor(masked, o);
+    if ((tid & 63) == 0) wmask[tid >> 6] = masked;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wmask[0] + wmask[1] + wmask[2] + wmask[3];
+        if (tot) atomicAdd(nmasked, tot);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1467,6 +1570,8 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
     for (int g = 0; g < hp->ngauss; ++g) {
         ZM_CHECK(hp->deg[g] >= 0 && hp->deg[g] <= 8 && hp->sigma[g] > 0, "zm_subtract: bad basis");
         base[g] = nf1;
+        P->gdeg[g] = hp->deg[g];
+        P->gbase[g] = nf1;
         for (int a = 0; a <= hp->deg[g]; ++a) {
             double s = 0.0;
             for (int u = -hwk; u <= hwk; ++u) {
@@ -1480,10 +1585,12 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
     }
     ZM_CHECK(nf1 <= HP_MAXF1, "zm_subtract: too many 1-D filters");
     P->nf1 = nf1;
+    P->ngauss = hp->ngauss;
     for (int g = 0; g < hp->ngauss; ++g)
         for (int a = 0; a <= hp->deg[g]; ++a)
             for (int b = 0; b <= hp->deg[g] - a; ++b) {
                 ZM_CHECK(nc < HP_MAXX, "zm_subtract: basis too large");
+                if (a == 0 && b == 0) P->gterm0[g] = nc;
                 P->tfx[nc] = base[g] + a;
                 P->tfy[nc] = base[g] + b;
                 bool ee = (a % 2 == 0) && (b % 2 == 0);
@@ -1522,18 +1629,19 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
 template <int HWK>
 static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved_mask, const float* sci,
                         const float* ref, const float* srms, const float* trms, const uint8_t* outbad,
-                        const double* basis, const double* xsol, float* diff, float* noise,
+                        const double* filt, const double* xsol, float* diff, float* noise,
                         int* nmasked) {
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, NB = C::NB;
     constexpr int TW = NB * STEP + 2 * HWK, TH = STEP + 2 * HWK;
-    size_t fl = (size_t)2 * TH * TW + (size_t)2 * NB * STEP * STEP;      // {T, V} tile + {k, k^2} kernels
+    const size_t tvn = std::max((size_t)TH * TW, (size_t)P.nunk + P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB);
+    size_t fl = 2 * tvn + (size_t)2 * NB * STEP * STEP;      // {T, V} tile (or the evaluation scratch) + {k, k^2} kernels
     size_t shmem = fl * sizeof(float) + (size_t)NB * HP_MAXX * sizeof(double) + 16;
-    static bool set = false;
-    if (!set && shmem > 65536) {
+    static size_t set_max = 65536;
+    if (shmem > set_max) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply<HWK>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        set = true;
+        set_max = shmem;
     }
     int W = 0, H = 0;
     for (int reg = 0; reg < P.nreg; ++reg) {
@@ -1542,7 +1650,7 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     }
     dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
     hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
-                       trms, outbad, basis, xsol, diff, noise, nmasked);
+                       trms, outbad, filt, xsol, diff, noise, nmasked);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -1570,7 +1678,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     int2* centres = nullptr;
     int *active = nullptr, *need = nullptr, *ibuf = nullptr;
     double *X = nullptr, *G = nullptr, *phi = nullptr, *vbar = nullptr, *A = nullptr, *rhs = nullptr,
-           *dsc = nullptr, *merit = nullptr, *stats = nullptr, *d_filt = nullptr, *d_basis = nullptr;
+           *dsc = nullptr, *merit = nullptr, *stats = nullptr, *d_filt = nullptr;
     ZM_TRY(ctx->get("hp_centres", sizeof(int2) * P.ncell * P.nss, (void**)&centres));
     ZM_TRY(ctx->get("hp_active", sizeof(int) * P.ncell, (void**)&active));
     ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
@@ -1598,15 +1706,12 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
     ZM_TRY(ctx->get("hp_stats", sizeof(double) * 2 * HP_MAXREG, (void**)&stats));
     ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
-    ZM_TRY(ctx->get("hp_basis", sizeof(double) * basis.size(), (void**)&d_basis));
     // small constant tables: staged through pinned memory owned per call generation
     double* h_tab = nullptr;
-    ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * (filt.size() + basis.size()), (void**)&h_tab));
+    ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * filt.size(), (void**)&h_tab));
     ZM_HIP(hipStreamSynchronize(st));   // the previous call may still be reading the staging area
     memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
-    memcpy(h_tab + filt.size(), basis.data(), sizeof(double) * basis.size());
     ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
-    ZM_HIP(hipMemcpyAsync(d_basis, h_tab + filt.size(), sizeof(double) * basis.size(), hipMemcpyHostToDevice, st));
     ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * (3 * HP_MAXREG + 4), st));
 
     const dim3 b256(256);
@@ -1769,7 +1874,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 std::isfinite(h_x[(size_t)reg * P.nunk]))
                 solved_mask |= 1ull << reg;
         {
-#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_basis, rhs, out_diff, out_rms, nmasked)); break;
+#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
             switch (P.hwk) {
                 HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
                 HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
