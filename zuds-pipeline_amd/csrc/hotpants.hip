@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                                                     const int* __restrict__ need,
                                                     double* __restrict__ X,
                                                     double* __restrict__ phi,         // [cell][nkp]
-                                                    double* __restrict__ vbar) {
+                                                    double* __restrict__ vbar, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double hp_smem[];
     constexpr int STEP = 2 * HWK + 1;
     constexpr int WIN = HV_R + 2 * HWK;
@@ -503,7 +504,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
                                                  const int* __restrict__ need,
                                                  const int* __restrict__ active,
-                                                 double* __restrict__ Gp) {
+                                                 double* __restrict__ Gp, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double L[HP_MAXX * GR_PITCH];
     const int cell = blockIdx.x, tid = threadIdx.x;
     if (!need[cell] || active[cell] < 0) return;
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
 __global__ __launch_bounds__(256) void k_hp_gram_sum(const double* __restrict__ Gp,
                                                      const int* __restrict__ need,
                                                      const int* __restrict__ active,
-                                                     double* __restrict__ G) {
+                                                     double* __restrict__ G, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     const int cell = blockIdx.x;
     if (!need[cell] || active[cell] < 0) return;
     const double* src = Gp + (size_t)cell * GR_SPLIT * HP_MAXX * HP_MAXX;
@@ -579,7 +582,8 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
                                                   const int* __restrict__ active,
                                                   const int* __restrict__ chg, int sign,
                                                   double* __restrict__ A,
-                                                  double* __restrict__ rhs) {
+                                                  double* __restrict__ rhs, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     const int reg = blockIdx.z;
     const int c1 = blockIdx.y * 16 + (threadIdx.x >> 4), c2 = blockIdx.x * 16 + (threadIdx.x & 15);
     if (blockIdx.x > blockIdx.y) return;
@@ -614,7 +618,8 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
 }
 
 // Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
-__global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d) {
+__global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     int reg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     double v = A[(size_t)reg * (size_t)(n + 1) * n + (size_t)c * n + c];
@@ -622,7 +627,8 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
 }
 
 __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
-                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar) {
+                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
     if (c1 == 0 && c2 == 0)
@@ -759,7 +765,8 @@ __device__ inline void region_arrive(unsigned* ctr) {
 // so the 32 x 32 factorisation - the longest serial piece - overlaps the panel barrier and the
 // trailing update instead of following them.
 __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
-                                                    unsigned* bar, long long* prof) {
+                                                    unsigned* bar, long long* prof, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ double Li[64][CH_NB + 2];        // pitch 34: conflict-free ds_read_b64 of MFMA operands
     __shared__ double Lj[64][CH_NB + 2];
@@ -1015,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 // of 1024 threads per region; then x /= d (Jacobi scaling) into xout.
 __global__ __launch_bounds__(1024) void k_chol_back(int n, int lda, const double* __restrict__ Aall,
                                                     const double* __restrict__ dall,
-                                                    double* __restrict__ xall) {
+                                                    double* __restrict__ xall, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double cb_smem[];
     double* y = cb_smem;                                   // [n]
     double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(cb_smem + ((n + 1) & ~1));
@@ -1074,7 +1082,8 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, int lda, const double
 #define CBC_COLS (CBC_THREADS - 64)
 __global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, const double* __restrict__ Aall,
                                                                 const double* __restrict__ dall,
-                                                                double* __restrict__ xall) {
+                                                                double* __restrict__ xall, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double Dn[CH_NB][CH_NB + 1];      // diagonal block of the coming chain, 1 / diag in column 32
     __shared__ double xs[CH_NB];                 // the block just solved
     __shared__ double ys[CH_NB];                 // right-hand side of the coming chain
@@ -1165,7 +1174,8 @@ __global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* 
                                                  const double* __restrict__ vbar,
                                                  const int* __restrict__ active,
                                                  const double* __restrict__ xsol,
-                                                 double* __restrict__ merit) {
+                                                 double* __restrict__ merit, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double c[HP_MAXX];
     const int cell = blockIdx.x, lane = threadIdx.x;
     if (active[cell] < 0) { if (lane == 0) merit[cell] = -1.0; return; }
@@ -1198,7 +1208,8 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
                                                    const int2* __restrict__ centres,
                                                    int* __restrict__ active, int* __restrict__ need,
                                                    int* __restrict__ chg, int* __restrict__ nrej,
-                                                   double* __restrict__ stats) {
+                                                   double* __restrict__ stats, const int* __restrict__ guard, int* __restrict__ round_flag) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double red[4];
     const int reg = blockIdx.x, tid = threadIdx.x;
     double m = 0.0, s = 0.0;
@@ -1247,6 +1258,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
     used = block_sum256(used, red);
     if (tid == 0) {
         nrej[reg] = (int)cnt;
+        if (cnt > 0) atomicAdd(round_flag, (int)cnt);        // any rejection: the next round is live
         stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
         stats[reg * 2 + 1] = used;
     }
@@ -1754,23 +1766,35 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                  sizeof(float) * (size_t)P.pw * P.pw + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
 
-    int rounds = 0;
     int h_int[3 * HP_MAXREG + 4];
     const int nblk = (P.nunk + CH_NB - 1) / CH_NB;
-    for (rounds = 1; rounds <= 8; ++rounds) {
+    // Rejection rounds without a host round trip on the critical path: round r + 1 is enqueued
+    // before the host learns whether round r rejected anything.  k_hp_reject of round r adds its
+    // rejections to rflags[r]; every kernel of round r + 1 starts with `if (rflags[r] == 0)
+    // return`, so a round enqueued in vain costs a dozen empty launches while the GPU never
+    // waits for the host in between.
+    int* rflags = nullptr;
+    int* h_rflags = nullptr;
+    hipEvent_t* evs = nullptr;
+    ZM_TRY(ctx->get("hp_rflags", sizeof(int) * 16, (void**)&rflags));
+    ZM_TRY(ctx->get_pinned("hp_rflags_h", sizeof(int) * 16, (void**)&h_rflags));
+    ZM_TRY(zm_get_sync_events(ctx, 3, &evs));
+    ZM_HIP(hipMemsetAsync(rflags, 0, sizeof(int) * 16, st));
+    auto enqueue_round = [&](const int rounds) -> int {
+        const int* guard = rounds > 1 ? rflags + (rounds - 1) : nullptr;
         if (rounds > 1) {
             // the rejected cells leave the normal matrix with their old Gram matrices / spatial
             // terms, before k_hp_vectors / k_hp_gram overwrite them
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0);
+            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
         }
         {
             zm_scope_timer t(ctx, "hp_vectors");
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
     hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar); break;
+                       centres, active, need, X, phi, vbar, guard); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
                 HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
@@ -1782,18 +1806,18 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         }
         {
             zm_scope_timer t(ctx, "hp_gram");
-            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell, GR_SPLIT), b256, 0, st, P, X, need, active, Gp);
-            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G);
+            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell, GR_SPLIT), b256, 0, st, P, X, need, active, Gp, guard);
+            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G, guard);
             ZM_HIP(hipGetLastError());
         }
         {
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
             hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
-                               rounds == 1 ? 0 : 1, A0, rhs0);
-            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc);
+                               rounds == 1 ? 0 : 1, A0, rhs0, guard);
+            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc, guard);
             hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
-                               A0, rhs0, A, dsc, cbar);
+                               A0, rhs0, A, dsc, cbar, guard);
             {
                 // one cooperative launch: W workgroups per region, all resident
                 // One workgroup per CU: a second one on the same CU slows the serial chains of the
@@ -1820,7 +1844,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
                 // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
                 // order against the following launches of the stream on its first use)
-                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, barg, parg);
+                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, barg, parg, guard);
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
                     std::vector<long long> hp((size_t)6 * P.nreg * W);
@@ -1845,24 +1869,30 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 }
                 ZM_CHECK(bsh <= 160 * 1024 - 64, "zm_subtract: %d unknowns exceed the solver's LDS", P.nunk);
                 if (P.nunk <= CBC_COLS)
-                    hipLaunchKernelGGL(k_chol_back_cols, dim3(P.nreg), dim3(CBC_THREADS), 0, st, P.nunk, lda, A, dsc, rhs);
+                    hipLaunchKernelGGL(k_chol_back_cols, dim3(P.nreg), dim3(CBC_THREADS), 0, st, P.nunk, lda, A, dsc, rhs, guard);
                 else
-                    hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs);
+                    hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs, guard);
             }
-            hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit);
+            hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard);
             hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
-                               nrej, stats);
+                               nrej, stats, guard, rflags + rounds);
             ZM_HIP(hipGetLastError());
         }
-        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipStreamSynchronize(st));
-        int tot = 0;
-        for (int r = 0; r < P.nreg; ++r) tot += h_int[r];
-        if (tot == 0) break;
+        ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipEventRecord(evs[1 + (rounds & 1)], st));
+        return 0;
+    };
+    int rounds = 0;
+    ZM_TRY(enqueue_round(1));
+    for (int r = 1; r <= 8; ++r) {
+        if (r < 8) ZM_TRY(enqueue_round(r + 1));          // void if round r rejects nothing
+        ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
+        rounds = r;
+        if (h_rflags[r] == 0) break;
     }
-    if (rounds > 8) rounds = 8;
     // a region is solved when it fitted at least one stamp and the factorisation held
     std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
+    ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipStreamSynchronize(st));
