@@ -864,7 +864,9 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + 256 * q, r = e >> 5, m = e & 31;
-                pa[q] = (i0 + r < nrows) ? -ld_sh(&A[(size_t)(i0 + r) * lda + k0 + m]) : 0.0;
+                // (negated when it is written to LDS: arithmetic here would make every one of these
+                // loads wait for itself)
+                pa[q] = (i0 + r < nrows) ? ld_sh(&A[(size_t)(i0 + r) * lda + k0 + m]) : 0.0;
                 pb[q] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * lda + k0 + m]) : 0.0;
             }
         };
@@ -887,8 +889,20 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         // (a) the published factor of block kb; workgroup 0 factored it itself and still has it in D
         __syncthreads();                                         // D of the previous step is consumed
         if (w != 0) {
+            // all five loads of a thread first, then the LDS stores: one latency, not five
             const double* Dg = Dg2 + (size_t)(kb & 1) * CH_NB * (CH_NB + 1);
-            for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = ld_sh(&Dg[e]);
+            constexpr int ND = (CH_NB * (CH_NB + 1) + 255) / 256;
+            double dv[ND];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = tid + 256 * q;
+                dv[q] = e < CH_NB * (CH_NB + 1) ? ld_sh(&Dg[e]) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = tid + 256 * q;
+                if (e < CH_NB * (CH_NB + 1)) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = dv[q];
+            }
         }
         __syncthreads();
         CF_TICK(0);
@@ -968,7 +982,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int e = tid + 256 * q, r = e >> 5, m = e & 31;
-                    Li[r][m] = pa[q];
+                    Li[r][m] = -pa[q];
                     Lj[r][m] = pb[q];
                 }
                 __syncthreads();
