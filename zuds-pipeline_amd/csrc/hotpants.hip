@@ -912,23 +912,26 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         // dependent LDS reads per row.  Workgroup 0 also keeps its rows in LDS (Li) for the
         // look-ahead.
         {
+            // u_m = b_m - sum_{k<m} x_k L[m][k] is carried unscaled: lane i subtracts
+            // u_m (L[i][m] / L[m][m]) for m < i and multiplies by 1 / L[i][i] once at the end, so a
+            // step is the broadcast of u_m (readlanes, one per half) and one FMA per row
             double lrow[CH_NB];
 #pragma unroll
-            for (int m = 0; m < CH_NB; ++m) lrow[m] = D[pli][m];
-            const double rdl = D[pli][CH_NB];                    // lane m holds 1 / L[m][m]
+            for (int m = 0; m < CH_NB; ++m) lrow[m] = (pli > m) ? -(D[pli][m] * D[m][CH_NB]) : 0.0;
+            const double rdl = D[pli][CH_NB];                    // 1 / L[i][i]
             // four row pairs at a time: their loads go out together (one memory latency) and
             // the four register chains interleave
             while (pp0 < pend) {
 #pragma unroll
                 for (int m = 0; m < CH_NB; ++m) {
-                    const double r = readlane_d(rdl, m);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const double xa = readlane_d(bj[q], m) * r, xb = readlane_d(bj[q], 32 + m) * r;
-                        const double xm = half ? xb : xa;
-                        bj[q] = (pli == m) ? xm : ((pli > m) ? bj[q] - lrow[m] * xm : bj[q]);
+                        const double ua = readlane_d(bj[q], m), ub = readlane_d(bj[q], 32 + m);
+                        bj[q] = fma(lrow[m], half ? ub : ua, bj[q]);
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bj[q] *= rdl;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int p = pp0 + 8 * q + half;
