@@ -596,16 +596,36 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
     bool any = false;
     const int* list = chg + P.ncell + reg * (P.ncellr + 1);
     const int ncand = (sign == 0) ? P.ncellr : list[0];
-    for (int s = 0; s < ncand; ++s) {
-        const int cell = (sign == 0) ? reg * P.ncellr + s : list[1 + s];
-        if (active[cell] < 0 && sign >= 0) continue;
-        any = true;
-        const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
-        const double* ph = phi + (size_t)cell * P.nkp;
-        double w1 = p1 >= 0 ? ph[p1] : 1.0;
-        double w2 = p2 >= 0 ? ph[p2] : 1.0;
-        acc += w1 * w2 * Gc[n1 * HP_MAXX + n2];
-        if (do_rhs) racc += w1 * Gc[n1 * HP_MAXX + P.nE];
+    // eight candidates at a time: their loads go out together, the sums keep the cell order
+    for (int s0 = 0; s0 < ncand; s0 += 8) {
+        double g[8], gr[8], w1[8], w2[8];
+        bool on[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u;
+            on[u] = false;
+            g[u] = gr[u] = 0.0;
+            w1[u] = w2[u] = 1.0;
+            if (s < ncand) {
+                const int cell = (sign == 0) ? reg * P.ncellr + s : list[1 + s];
+                on[u] = !(active[cell] < 0 && sign >= 0);
+                if (on[u]) {
+                    const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+                    const double* ph = phi + (size_t)cell * P.nkp;
+                    if (p1 >= 0) w1[u] = ph[p1];
+                    if (p2 >= 0) w2[u] = ph[p2];
+                    g[u] = Gc[n1 * HP_MAXX + n2];
+                    if (do_rhs) gr[u] = Gc[n1 * HP_MAXX + P.nE];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (on[u]) {
+                any = true;
+                acc += w1[u] * w2[u] * g[u];
+                if (do_rhs) racc += w1[u] * gr[u];
+            }
     }
     const size_t ia = (size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2;
     if (sign == 0) {
