@@ -381,29 +381,62 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     double* fl = w0 + P.npix;                           // [nf1][step]
     double* red = fl + P.nf1 * STEP;                    // [4]
     float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pw]
-    for (int k = tid; k < P.nf1 * STEP; k += 256) fl[k] = filt[k];
-    for (int k = tid; k < pw * pw; k += 256) {
-        int yy = k / pw, xx = k - yy * pw;
-        patch[k] = ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)];
+    // (loads in batches, stores after: a loop of load -> store pays one memory latency per
+    // iteration, and after the first round a cell's latency is the kernel time)
+    for (int k0 = tid; k0 < P.nf1 * STEP; k0 += 256 * 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (k0 + 256 * u < P.nf1 * STEP) ? filt[k0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 256 * u < P.nf1 * STEP) fl[k0 + 256 * u] = t[u];
+    }
+    for (int k0 = tid; k0 < pw * pw; k0 += 256 * 10) {
+        float t[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int k = k0 + 256 * u;
+            const int yy = k / pw, xx = k - yy * pw;
+            t[u] = (k < pw * pw) ? ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            if (k0 + 256 * u < pw * pw) patch[k0 + 256 * u] = t[u];
     }
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
     double* Xc = X + (size_t)cell * P.nX * P.npixp;
     // science row, background rows, variance mean, zero padding: part 0
     double vs = 0.0;
-    for (int k = tid; part == 0 && k < P.npixp; k += 256) {
-        if (k < P.npix) {
-            int i = k / sw, j = k - i * sw;
-            int x = cc.x - hwss + j, y = cc.y - hwss + i;
-            size_t idx = (size_t)y * P.nx + x;
-            Xc[(size_t)P.nE * P.npixp + k] = (double)sci[idx];
-            double a = srms[idx], b = trms[idx];
-            vs += a * a + b * b;
-            double xf = (x - xc) / hx, yf = (y - yc) / hy;
-            for (int q = 0; q < P.nbg; ++q)
-                Xc[(size_t)(P.nc + q) * P.npixp + k] = ipowd(xf, P.bpi[q]) * ipowd(yf, P.bpj[q]);
-        } else {
-            for (int q = 0; q < P.nX; ++q) Xc[(size_t)q * P.npixp + k] = 0.0;
+    for (int k0 = tid; part == 0 && k0 < P.npixp; k0 += 256 * 5) {
+        float ts[5], ta[5], tb[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = k0 + 256 * u;
+            ts[u] = ta[u] = tb[u] = 0.f;
+            if (k < P.npix) {
+                const int i = k / sw, j = k - i * sw;
+                const size_t idx = (size_t)(cc.y - hwss + i) * P.nx + (cc.x - hwss + j);
+                ts[u] = sci[idx];
+                ta[u] = srms[idx];
+                tb[u] = trms[idx];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = k0 + 256 * u;
+            if (k < P.npix) {
+                const int i = k / sw, j = k - i * sw;
+                const int x = cc.x - hwss + j, y = cc.y - hwss + i;
+                Xc[(size_t)P.nE * P.npixp + k] = (double)ts[u];
+                const double a = ta[u], b = tb[u];
+                vs += a * a + b * b;
+                const double xf = (x - xc) / hx, yf = (y - yc) / hy;
+                for (int q = 0; q < P.nbg; ++q)
+                    Xc[(size_t)(P.nc + q) * P.npixp + k] = ipowd(xf, P.bpi[q]) * ipowd(yf, P.bpj[q]);
+            } else if (k < P.npixp) {
+                for (int q = 0; q < P.nX; ++q) Xc[(size_t)q * P.npixp + k] = 0.0;
+            }
         }
     }
     vs = block_sum256(vs, red);
@@ -518,13 +551,28 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
     double4_t acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // a K tile = 64 rows x 32 columns = 8 doubles per thread: fetched into registers one tile
+    // ahead (all eight loads in flight together, and under the matrix cores' work on the
+    // current tile), stored to LDS after the barrier
+    constexpr int GR_LD = HP_MAXX * GR_KT / 256;
+    double nxt[GR_LD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < GR_LD; ++q) {
+            const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+            nxt[q] = row < P.nX ? Xc[(size_t)row * P.npixp + k0 + col] : 0.0;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GR_KT) {
         __syncthreads();
-        for (int e = tid; e < HP_MAXX * GR_KT; e += 256) {
-            int row = e >> 5, col = e & 31;
-            L[row * GR_PITCH + col] = row < P.nX ? Xc[(size_t)row * P.npixp + k0 + col] : 0.0;
+#pragma unroll
+        for (int q = 0; q < GR_LD; ++q) {
+            const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+            L[row * GR_PITCH + col] = nxt[q];
         }
         __syncthreads();
+        if (k0 + GR_KT < kend) fetch(k0 + GR_KT);
 #pragma unroll
         for (int kk = 0; kk < GR_KT / 4; ++kk) {
             double a = L[(16 * wave + li) * GR_PITCH + 4 * kk + lk];
