@@ -1380,12 +1380,41 @@ __device__ inline double xs_bg(const double* __restrict__ xsol, int reg, const h
 // owns R consecutive output pixels of one row of one block and slides a register
 // window over the LDS tile; kernel taps come from LDS (few distinct addresses per
 // wave: broadcast).  Template and template-variance planes are convolved together.
+// worst number of lanes of a half wave that meet in one of the 64 LDS banks when lane l reads the
+// float2 at (l / lpr) * pitch + (l % lpr) * r: the window loads of the convolution
+constexpr int apply_bank_passes(int pitch, int lpr, int r, int step) {
+    int worst = 0;
+    for (int half = 0; half < 2; ++half) {
+        int cnt[64] = {};
+        for (int l = 32 * half; l < 32 * half + 32; ++l) {
+            const int row = l / lpr, strip = l % lpr;
+            if (row >= step) continue;
+            const int e = row * pitch + strip * r;
+            ++cnt[(2 * e) % 64];
+            ++cnt[(2 * e + 1) % 64];
+        }
+        for (int b = 0; b < 64; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+    }
+    return worst;
+}
+// smallest row pitch >= width (at most 16 more) with the fewest bank conflicts
+constexpr int apply_pitch(int width, int lpr, int r, int step) {
+    int best = width, bw = apply_bank_passes(width, lpr, r, step);
+    for (int p = width + 1; p <= width + 16; ++p) {
+        const int w = apply_bank_passes(p, lpr, r, step);
+        if (w < bw) { bw = w; best = p; }
+    }
+    return best;
+}
+
 template <int HWK> struct apply_cfg {
     enum { STEP = 2 * HWK + 1,
            LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? (STEP == 21 ? 3 : 2) : 3),   // lanes per block row
            R = (STEP + LPR - 1) / LPR,
            LPB = STEP * LPR,                 // lanes per block
-           NB = 256 / LPB > 0 ? 256 / LPB : 1 };
+           NB = 256 / LPB > 0 ? 256 / LPB : 1,
+           TW = NB * STEP + 2 * HWK,         // tile width
+           TP = apply_pitch(NB * STEP + 2 * HWK, LPR, (STEP + LPR - 1) / LPR, STEP) };   // tile row pitch
 };
 
 template <int HWK>
@@ -1405,17 +1434,18 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     const int solved = (int)((solved_mask >> reg) & 1ull);
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
-    constexpr int TW = NB * STEP + 2 * HWK;   // tile width
+    constexpr int TW = C::TW;                 // tile width
+    constexpr int TP = C::TP;                 // row pitch of the tile in LDS (bank-conflict padding)
     constexpr int TH = STEP + 2 * HWK;
     // LDS: template and template variance interleaved ({T, V} pairs), the per-block kernel as
     // {k, k^2} pairs: one v_pk_fma_f32 per tap and pixel feeds both planes, one ds_read_b64 per
     // operand
     typedef float ap_v2f __attribute__((ext_vector_type(2)));
     extern __shared__ float ap_smem[];
-    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TW]
+    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TP]
     // the tile's space first serves the kernel evaluation (solution vector, term scales, 1-D
     // filters, g_f, s0: nunk + nc + (NB + 1) nf1 STEP + NB doubles) and last the output staging
-    const int tvn = max(TH * TW, P.nunk + P.nc + (NB + 1) * P.nf1 * STEP + NB);
+    const int tvn = max(TH * TP, P.nunk + P.nc + (NB + 1) * P.nf1 * STEP + NB + 2 * NB * P.nkp);
     ap_v2f* kc = tTV + tvn;                                        // [NB][STEP*STEP]
     double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP);  // [NB][nc]
     __shared__ int wmask[4];
@@ -1424,6 +1454,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     double* fl = ts + P.nc;                                         // [nf1][STEP]
     double* gf = fl + P.nf1 * STEP;                                 // [NB][nf1][STEP]
     double* s0v = gf + NB * P.nf1 * STEP;                           // [NB] sum of the c_n with sub0_n
+    double* pxy = s0v + NB;                                         // [NB][nkp][2] x^i, y^j at the block centres
     const int tid = threadIdx.x;
     const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
     const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
@@ -1432,20 +1463,43 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
     const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
     const double* x = xsol + (size_t)reg * P.nunk;
-    for (int e = tid; e < P.nunk; e += 256) xs[e] = x[e];
+    // tables into LDS, every load of a thread issued before its first store (a copy loop pays a
+    // memory latency per iteration; the exponent tables sit in the kernel-argument segment, and
+    // indexing them inside the polynomial loop below would cost two latencies per term)
+    for (int e0 = tid; e0 < P.nunk; e0 += 256 * 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (e0 + 256 * u < P.nunk) ? x[e0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + 256 * u < P.nunk) xs[e0 + 256 * u] = t[u];
+    }
+    for (int e0 = tid; e0 < P.nf1 * STEP; e0 += 256 * 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (e0 + 256 * u < P.nf1 * STEP) ? filt[e0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + 256 * u < P.nf1 * STEP) fl[e0 + 256 * u] = t[u];
+    }
     for (int e = tid; e < P.nc; e += 256) ts[e] = P.tscale[e];
-    for (int e = tid; e < P.nf1 * STEP; e += 256) fl[e] = filt[e];
+    for (int e = tid; e < NB * P.nkp; e += 256) {
+        const int b = e / P.nkp, pp = e - b * P.nkp;
+        const double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
+        pxy[2 * e] = ipowd(fx, P.kpi[pp]);
+        pxy[2 * e + 1] = ipowd(fy, P.kpj[pp]);
+    }
     __syncthreads();
     // per-block basis coefficients at the nominal block centre (fp64)
     for (int e = tid; e < NB * P.nc; e += 256) {
         int b = e / P.nc, n = e - b * P.nc;
-        double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
         double v;
         if (n == 0) v = xs[0];
         else {
             v = 0.0;
-            for (int p = 0; p < P.nkp; ++p)
-                v += xs[1 + (n - 1) * P.nkp + p] * ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
+            const double* xb = xs + 1 + (n - 1) * P.nkp;
+            const double* pb = pxy + 2 * b * P.nkp;
+            for (int p = 0; p < P.nkp; ++p) v += xb[p] * pb[2 * p] * pb[2 * p + 1];
         }
         cf[e] = v;
     }
@@ -1515,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
             float t = tt[it], v = tr[it] * tr[it];
             if (!(fabsf(t) < 3e38f)) t = 0.f;
             if (!(fabsf(v) < 3e38f)) v = 0.f;
-            if (e < TH * TW) tTV[e] = (ap_v2f){t, v};
+            if (e < TH * TW) tTV[(e / TW) * TP + e % TW] = (ap_v2f){t, v};
         }
     }
     __syncthreads();
@@ -1531,7 +1585,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
         const ap_v2f* kb = kc + b * STEP * STEP;
         // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
         for (int v = -HWK; v <= HWK; ++v) {
-            const ap_v2f* rt = tTV + (row + HWK - v) * TW + ox0;    // T(x - u): column ox0 + q + HWK - u
+            const ap_v2f* rt = tTV + (row + HWK - v) * TP + ox0;    // T(x - u): column ox0 + q + HWK - u
             ap_v2f w2[R + 2 * HWK];
 #pragma unroll
             for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[q];
@@ -1730,10 +1784,10 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
                         int* nmasked) {
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, NB = C::NB;
-    constexpr int TW = NB * STEP + 2 * HWK, TH = STEP + 2 * HWK;
-    const size_t tvn = std::max((size_t)TH * TW, (size_t)P.nunk + P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB);
+    constexpr int TP = C::TP, TH = STEP + 2 * HWK;
+    const size_t tvn = std::max((size_t)TH * TP, (size_t)P.nunk + P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB + (size_t)2 * NB * P.nkp);
     size_t fl = 2 * tvn + (size_t)2 * NB * STEP * STEP;      // {T, V} tile (or the evaluation scratch) + {k, k^2} kernels
-    size_t shmem = fl * sizeof(float) + (size_t)NB * HP_MAXX * sizeof(double) + 16;
+    size_t shmem = fl * sizeof(float) + (size_t)NB * P.nc * sizeof(double);
     static size_t set_max = 65536;
     if (shmem > set_max) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply<HWK>,
