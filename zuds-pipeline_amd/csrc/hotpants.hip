@@ -427,21 +427,16 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     const int2 cc = centres[cell * P.nss + act];
     const int r = cell / P.ncellr;
     const int pw = P.pw, sw = P.sw, hwss = P.hwss;
-    double* xp = hp_smem;                               // [pw][sw]
-    double* w0 = xp + (size_t)pw * sw;                  // [npix]
-    double* fl = w0 + P.npix;                           // [nf1][step]
-    double* red = fl + P.nf1 * STEP;                    // [4]
-    float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pw]
+    // xp has HV_R zero rows below, patch HV_R zero columns to the right of the data: the register
+    // windows of the two passes run over the edge unconditionally (a conditional LDS read is
+    // waited for one by one)
+    const int pp = pw + HV_R;                           // patch row pitch
+    double* xp = hp_smem;                               // [pw + HV_R][sw]
+    double* w0 = xp + (size_t)(pw + HV_R) * sw;         // [npix]
+    double* red = w0 + P.npix;                          // [4]
+    float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pp]
     // (loads in batches, stores after: a loop of load -> store pays one memory latency per
     // iteration, and after the first round a cell's latency is the kernel time)
-    for (int k0 = tid; k0 < P.nf1 * STEP; k0 += 256 * 4) {
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = (k0 + 256 * u < P.nf1 * STEP) ? filt[k0 + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (k0 + 256 * u < P.nf1 * STEP) fl[k0 + 256 * u] = t[u];
-    }
     for (int k0 = tid; k0 < pw * pw; k0 += 256 * 10) {
         float t[10];
 #pragma unroll
@@ -451,9 +446,14 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             t[u] = (k < pw * pw) ? ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 10; ++u)
-            if (k0 + 256 * u < pw * pw) patch[k0 + 256 * u] = t[u];
+        for (int u = 0; u < 10; ++u) {
+            const int k = k0 + 256 * u;
+            const int yy = k / pw, xx = k - yy * pw;
+            if (k < pw * pw) patch[yy * pp + xx] = t[u];
+        }
     }
+    for (int k = tid; k < pw * HV_R; k += 256) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
+    for (int k = tid; k < HV_R * sw; k += 256) xp[(size_t)pw * sw + k] = 0.0;
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
     double* Xc = X + (size_t)cell * P.nX * P.npixp;
@@ -512,14 +512,14 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         ++fidx;
         const bool for_w0 = (P.tfx[0] == f);
         if (!mine && !for_w0) continue;
-        const double* fxv = fl + f * STEP;
+        const double* fxv = filt + f * STEP;            // uniform address: scalar loads, no LDS traffic
         // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
         for (int e = tid; e < pw * nstrip; e += 256) {
             const int yy = e / nstrip, j0 = (e - yy * nstrip) * HV_R;
-            const float* pr = patch + yy * pw + j0;
+            const float* pr = patch + yy * pp + j0;
             double wv[WIN];
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) wv[k] = (j0 + k < pw) ? (double)pr[k] : 0.0;
+            for (int k = 0; k < WIN; ++k) wv[k] = (double)pr[k];      // j0 + k < pw + HV_R: zeros beyond pw
             double acc[HV_R];
 #pragma unroll
             for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         for (int n = 0; n < P.nc; ++n) {
             if (P.tfx[n] != f) continue;
             if (!mine && n != 0) continue;
-            const double* fyv = fl + P.tfy[n] * STEP;
+            const double* fyv = filt + P.tfy[n] * STEP;
             const double sc = P.tscale[n];
             // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
             for (int e = tid; e < sw * nstrip; e += 256) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                 const double* col = xp + i0 * sw + j;
                 double wv[WIN];
 #pragma unroll
-                for (int k = 0; k < WIN; ++k) wv[k] = (i0 + k < pw) ? col[k * sw] : 0.0;
+                for (int k = 0; k < WIN; ++k) wv[k] = col[k * sw];        // rows >= pw are zero
                 double acc[HV_R];
 #pragma unroll
                 for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
@@ -1956,8 +1956,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         ZM_HIP(hipGetLastError());
     }
     // LDS of k_hp_vectors
-    size_t vsh = sizeof(double) * ((size_t)P.pw * P.sw + P.npix + (size_t)P.nf1 * P.step + 4) +
-                 sizeof(float) * (size_t)P.pw * P.pw + 16;
+    size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 4) +
+                 sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
 
     int h_int[3 * HP_MAXREG + 4];
