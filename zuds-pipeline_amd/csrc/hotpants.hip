@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
 #pragma unroll
     for (int i = 0; i < HC_PX; ++i)
         if ((cleanm >> i & 1) && ((double)v[i] >= thr)) cand |= 1ull << i;
+    int2 last = make_int2(-1000000, -1000000);           // the pick of the previous round (registers)
     for (int k = 0; k < P.nss; ++k) {
         float best = -__builtin_inff();
         int bi = 0x7fffffff;
@@ -344,10 +345,10 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
 #pragma unroll
             for (int i = 0; i < HC_PX; ++i) {
                 if (cand >> i & 1) {
+                    // candidates near an earlier pick were struck out when it was made: only the
+                    // latest pick is new
                     const int x = cx0 + xx, y = cy0 + yy, q = tid + 256 * i;
-                    bool excl = false;
-                    for (int e = 0; e < k; ++e)
-                        excl |= (abs(x - chosen[e].x) <= P.hwss) && (abs(y - chosen[e].y) <= P.hwss);
+                    const bool excl = (abs(x - last.x) <= P.hwss) && (abs(y - last.y) <= P.hwss);
                     if (excl) cand &= ~(1ull << i);          // stays excluded for the later picks
                     else if (v[i] > best || (v[i] == best && q < bi)) { best = v[i]; bi = q; }
                 }
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
             centres[cell * P.nss + k] = cc;
         }
         __syncthreads();
-        if (chosen[k].x < 0) {   // nothing left: the remaining slots are empty too
+        last = chosen[k];
+        if (last.x < 0) {   // nothing left: the remaining slots are empty too
             if (tid == 0)
                 for (int e = k + 1; e < P.nss; ++e) centres[cell * P.nss + e] = make_int2(-1, -1);
             break;
