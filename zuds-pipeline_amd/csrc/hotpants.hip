@@ -1036,9 +1036,18 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             // u_m = b_m - sum_{k<m} x_k L[m][k] is carried unscaled: lane i subtracts
             // u_m (L[i][m] / L[m][m]) for m < i and multiplies by 1 / L[i][i] once at the end, so a
             // step is the broadcast of u_m (readlanes, one per half) and one FMA per row
+            // (all LDS reads first, unconditionally: reads inside a condition are waited for one by one)
             double lrow[CH_NB];
+            {
+                double lr[CH_NB], rr[CH_NB];
 #pragma unroll
-            for (int m = 0; m < CH_NB; ++m) lrow[m] = (pli > m) ? -(D[pli][m] * D[m][CH_NB]) : 0.0;
+                for (int m = 0; m < CH_NB; ++m) { lr[m] = D[pli][m]; rr[m] = D[m][CH_NB]; }
+#pragma unroll
+                for (int m = 0; m < CH_NB; ++m) {
+                    const double t = -(lr[m] * rr[m]);
+                    lrow[m] = (pli > m) ? t : 0.0;
+                }
+            }
             const double rdl = D[pli][CH_NB];                    // 1 / L[i][i]
             // four row pairs at a time: their loads go out together (one memory latency) and
             // the four register chains interleave
