@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
             bool good = (row < h) && (c4 + j < w);
             if (wgt) good = good && pw[j] > wthresh;
             float val = pv[j];
-            if (mode == 1) val = good ? 1.0f / pw[j] : qnan;
+            if (mode == 1) val = good ? pw[j] : qnan;            // inverted below, unless the mesh is flat
             good = good && (val > -BK_BIG) && (val == val);
             v[4 * k + j] = good ? val : qnan;
         }
@@ -325,6 +325,56 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
         for (int k = 0; k < BKF_PX; ++k) a += v[k];
         if (a == 12345.f) dump[0].valid = 7;
         return;
+    }
+    if (mode == 1) {
+        // Variance statistic: most weight maps are flat inside a mesh.  Then every 1 / w is the
+        // same float, the clipped mean is that value exactly and sigma is 0 - the result of the
+        // general path below - and a min / max / count of the weights (three fp32 operations per
+        // pixel) replaces the divisions and the two fp64 moment passes.
+        float wmn = __builtin_inff(), wmx = -__builtin_inff();
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < BKF_PX; ++k) {
+            const float x = v[k];
+            const bool in = (x == x);
+            wmn = in ? fminf(wmn, x) : wmn;
+            wmx = in ? fmaxf(wmx, x) : wmx;
+            cnt += in ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            wmn = fminf(wmn, __shfl_xor(wmn, o));
+            wmx = fmaxf(wmx, __shfl_xor(wmx, o));
+            cnt += __shfl_xor(cnt, o);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { S->red3[0][tid >> 6] = wmn; S->red3[1][tid >> 6] = wmx; S->red3[2][tid >> 6] = cnt; }
+        __syncthreads();
+        double bmn = S->red3[0][0], bmx = S->red3[1][0], bc = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < BKF_WAVES; ++w8) {
+            bmn = fmin(bmn, S->red3[0][w8]);
+            bmx = fmax(bmx, S->red3[1][w8]);
+            bc += S->red3[2][w8];
+        }
+        const float inv = 1.0f / (float)bmn;
+        if (bc >= 1.0 && bc >= area * 0.5 && bmn == bmx && inv > -BK_BIG && inv == inv) {
+            if (tid == 0) {
+                mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
+                D->q = make_quant((double)inv, 0.0, bc);
+                D->mean0 = (double)inv;
+                D->valid = 2;
+            }
+            return;
+        }
+        __syncthreads();                                   // red3 is reused below
+#pragma unroll
+        for (int k = 0; k < BKF_PX; ++k) {
+            const float x = v[k];
+            float val = 1.0f / x;
+            const bool ok = (x == x) && (val > -BK_BIG) && (val == val);
+            v[k] = ok ? val : qnan;
+        }
     }
     // ---- pivot: some valid pixel of the mesh.  Moments are accumulated about it, in fp64:
     // (x - K) is exact, a constant mesh gives exactly zero variance (as numpy's two-pass var
