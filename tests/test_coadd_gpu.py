@@ -179,6 +179,30 @@ def test_background_and_weight_rescale_in_the_coadd(engine):
     assert abs(np.median(g_wgt[both]) / (3 / 25.0) - 1) < 0.1
 
 
+def test_weight_rescale_with_a_varying_weight_map(engine):
+    """A weight map that varies inside every mesh: the variance statistic takes its general
+    path (histogram + clipping), not the flat-mesh shortcut."""
+    z = pkg()
+    s = synth()
+    base = s.tan_wcs(300, 280)
+    frames = []
+    rng = np.random.default_rng(11)
+    for i in range(3):
+        w = s.tan_wcs(300, 280, dx=1.25 * i, dy=-1.75 * i)
+        f = s.make_frame(300, 280, 50 + i, w, sky=160 + 10 * i, noise=5.0, nstars=30, nbad=50)
+        yy, xx = np.mgrid[0:280, 0:300]
+        var = 50.0 * (1.0 + 0.3 * np.sin(xx / 37.0) * np.cos(yy / 53.0)) * rng.uniform(0.95, 1.05, (280, 300))
+        f['wgt'] = np.where(f['wgt'] > 0, 1.0 / var, 0.0).astype(np.float32)
+        frames.append(f)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True, back_size=64)
+    g_img, g_wgt, _, _ = engine.coadd(frames, base, p, want_mask=False)
+    r_img, r_wgt, _, _, _ = oracle_coadd(frames, base, 'WEIGHTED', True, True, mesh=64)
+    both = (g_wgt > 0) & (r_wgt > 0)
+    assert ((g_wgt > 0) != (r_wgt > 0)).mean() < 1e-4
+    assert_close_masked(g_img[both], r_img[both], 1e-4, 2e-3, 'coadd, varying weights', max_bad_frac=1e-4)
+    assert_close_masked(g_wgt[both], r_wgt[both], 2e-3, 0, 'rescaled varying weights', max_bad_frac=1e-4)
+
+
 def test_ragged_stack_with_backgrounds(engine):
     """Frames of different sizes, one without a weight map: the per-frame background
     products of a stack live side by side (batched statistics, one slot per frame)."""
