@@ -738,6 +738,75 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
     }
 }
 
+#define BB_CH 128
+// The same sums by blocks of source-vector pairs: workgroup (n1, n2 <= n1) of a region owns the
+// nkp x nkp unknowns (n1, p1) x (n2, p2); per cell it needs ONE Gram entry G[n1][n2] (a uniform,
+// scalar load) and the spatial terms of its threads, i.e. 2 loads and 3 flops per unknown pair and
+// cell where k_hp_build decodes and gathers per pair (1.2 x 10^8 pair-cell products per round-1
+// build).  Same products, same cell order: the results are identical to the last bit.
+__global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const double* __restrict__ G,
+                                                      const double* __restrict__ phi,
+                                                      const int* __restrict__ active,
+                                                      const int* __restrict__ chg, int sign,
+                                                      double* __restrict__ A,
+                                                      double* __restrict__ rhs, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
+    const int reg = blockIdx.z, n1 = blockIdx.y, n2 = blockIdx.x;
+    if (n2 > n1) return;
+    const int p1 = threadIdx.x >> 4, p2 = threadIdx.x & 15;
+    const bool k1 = n1 >= 1 && n1 < P.nc, k2 = n2 >= 1 && n2 < P.nc;   // kernel terms carry spatial factors
+    const int nk = (P.nc - 1) * P.nkp;
+    const int c1 = n1 == 0 ? 0 : (k1 ? 1 + (n1 - 1) * P.nkp + p1 : 1 + nk + (n1 - P.nc));
+    const int c2 = n2 == 0 ? 0 : (k2 ? 1 + (n2 - 1) * P.nkp + p2 : 1 + nk + (n2 - P.nc));
+    const bool live = p1 < (k1 ? P.nkp : 1) && p2 < (k2 ? P.nkp : 1) && c2 <= c1;
+    double acc = 0.0, racc = 0.0;
+    const bool do_rhs = (c2 == 0);
+    bool any = false;
+    const int* list = chg + P.ncell + reg * (P.ncellr + 1);
+    const int ncand = (sign == 0) ? P.ncellr : list[0];
+    // the candidates' Gram entries, right-hand-side entries, spatial terms and flags are staged in
+    // LDS, BB_CH cells at a time (one memory latency per chunk); the sums then run out of LDS
+    __shared__ double gs[BB_CH], grs[BB_CH], phs[BB_CH * 16];
+    __shared__ int ons[BB_CH];
+    const int tid = threadIdx.x;
+    for (int s0 = 0; s0 < ncand; s0 += BB_CH) {
+        const int nch = min(BB_CH, ncand - s0);
+        __syncthreads();
+        if (tid < nch) {
+            const int cell = (sign == 0) ? reg * P.ncellr + s0 + tid : list[1 + s0 + tid];
+            const int on = !(active[cell] < 0 && sign >= 0);
+            const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+            ons[tid] = on;
+            gs[tid] = on ? Gc[n1 * HP_MAXX + n2] : 0.0;
+            grs[tid] = (on && n2 == 0) ? Gc[n1 * HP_MAXX + P.nE] : 0.0;
+        }
+        for (int e = tid; e < nch * P.nkp; e += 256) {
+            const int k = e / P.nkp, pp = e - k * P.nkp;
+            const int cell = (sign == 0) ? reg * P.ncellr + s0 + k : list[1 + s0 + k];
+            phs[k * 16 + pp] = phi[(size_t)cell * P.nkp + pp];
+        }
+        __syncthreads();
+        if (live) {
+            for (int k = 0; k < nch; ++k) {
+                if (!ons[k]) continue;
+                any = true;
+                const double w1 = k1 ? phs[k * 16 + p1] : 1.0, w2 = k2 ? phs[k * 16 + p2] : 1.0;
+                acc += w1 * w2 * gs[k];
+                if (do_rhs) racc += w1 * grs[k];
+            }
+        }
+    }
+    if (!live) return;
+    const size_t ia = (size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2;
+    if (sign == 0) {
+        A[ia] = acc;
+        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
+    } else if (any) {
+        A[ia] += sign * acc;
+        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] += sign * racc;
+    }
+}
+
 // Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
 __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
@@ -1992,7 +2061,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             // terms, before k_hp_vectors / k_hp_gram overwrite them
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
+            if (P.nkp <= 16)
+                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
+            else
+                hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
         }
         {
             zm_scope_timer t(ctx, "hp_vectors");
@@ -2018,8 +2090,12 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         {
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
-                               rounds == 1 ? 0 : 1, A0, rhs0, guard);
+            if (P.nkp <= 16)
+                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                                   rounds == 1 ? 0 : 1, A0, rhs0, guard);
+            else
+                hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                                   rounds == 1 ? 0 : 1, A0, rhs0, guard);
             hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc, guard);
             hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
                                A0, rhs0, A, dsc, cbar, guard);
