@@ -1490,6 +1490,93 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
     }
 }
 
+// The same for regions of at most 256 cells, by one wave: lane l keeps cells l, l + 64, l + 128,
+// l + 192 in registers and every sum is a wave reduction - no barrier (the 256-thread version
+// spends its time in fifteen two-barrier block sums over a hundred values).
+__global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const double* __restrict__ merit,
+                                                       const int2* __restrict__ centres,
+                                                       int* __restrict__ active, int* __restrict__ need,
+                                                       int* __restrict__ chg, int* __restrict__ nrej,
+                                                       double* __restrict__ stats, const int* __restrict__ guard,
+                                                       int* __restrict__ round_flag) {
+    if (guard && *guard == 0) return;
+    const int reg = blockIdx.x, lane = threadIdx.x;
+    double mv[4];
+    int av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * u;
+        mv[u] = k < P.ncellr ? merit[reg * P.ncellr + k] : 0.0;
+        av[u] = k < P.ncellr ? active[reg * P.ncellr + k] : -1;
+    }
+    double m = 0.0, s = 0.0;
+    for (int pass = 0; pass < 4; ++pass) {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (av[u] >= 0 && (pass == 0 || fabs(mv[u] - m) <= 3.0 * s)) { s0 += 1.0; s1 += mv[u]; }
+        s0 = wave_sum_d(s0);
+        s1 = wave_sum_d(s1);
+        if (s0 < 1.0) break;
+        const double mn = s1 / s0;
+        double s2 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (av[u] >= 0 && (pass == 0 || fabs(mv[u] - m) <= 3.0 * s)) s2 += (mv[u] - mn) * (mv[u] - mn);
+        s2 = wave_sum_d(s2);
+        m = mn;
+        s = sqrt(s2 / s0);
+    }
+    const double lim = m + P.ks * s;
+    double cnt = 0, msum = 0, used = 0;
+    unsigned long long chm[4];                                // changed-cell ballots, cell order
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * u;
+        bool changed = false;
+        if (k < P.ncellr) {
+            const int cell = reg * P.ncellr + k;
+            int a = av[u];
+            int nd = 0;
+            if (a >= 0) {
+                used += 1.0;
+                msum += mv[u];
+                if (mv[u] > lim) {
+                    cnt += 1.0;
+                    a += 1;
+                    if (a >= P.nss || centres[cell * P.nss + a].x < 0) a = -1;
+                    else nd = 1;
+                    active[cell] = a;
+                    changed = true;              // its contribution leaves the normal matrix (and may come back)
+                }
+            }
+            need[cell] = nd;
+            chg[cell] = changed ? 1 : 0;
+        }
+        chm[u] = __ballot(changed);
+    }
+    cnt = wave_sum_d(cnt);
+    msum = wave_sum_d(msum);
+    used = wave_sum_d(used);
+    if (lane == 0) {
+        nrej[reg] = (int)cnt;
+        if (cnt > 0) atomicAdd(round_flag, (int)cnt);        // any rejection: the next round is live
+        stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
+        stats[reg * 2 + 1] = used;
+    }
+    // the changed cells in cell order behind the flags: [count, cells ...]
+    int* list = chg + P.ncell + reg * (P.ncellr + 1);
+    int base = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned long long bm = chm[u];
+        if (bm >> lane & 1ull)
+            list[1 + base + __popcll(bm & ((1ull << lane) - 1ull))] = reg * P.ncellr + lane + 64 * u;
+        base += __popcll(bm);
+    }
+    if (lane == 0) list[0] = base;
+}
+
 __global__ void k_hp_init_active(const hp_plan P, const int2* __restrict__ centres,
                                  int* __restrict__ active, int* __restrict__ need,
                                  int* __restrict__ ntotal) {
@@ -2155,8 +2242,12 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs, guard);
             }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard);
-            hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
-                               nrej, stats, guard, rflags + rounds);
+            if (P.ncellr <= 256)
+                hipLaunchKernelGGL(k_hp_reject_wave, dim3(P.nreg), dim3(64), 0, st, P, merit, centres, active, need,
+                                   chg, nrej, stats, guard, rflags + rounds);
+            else
+                hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
+                                   nrej, stats, guard, rflags + rounds);
             ZM_HIP(hipGetLastError());
         }
         ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
