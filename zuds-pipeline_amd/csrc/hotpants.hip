@@ -1007,11 +1007,13 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
         const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
         // workgroup 0: the unfactored next diagonal block, fetched ahead of its use
+        // (in the accumulator layout of the f64 matrix cores: wave = 16 x 16 quadrant (ti, tj) of
+        // the block, column = lane & 15, row = (lane >> 4) + 4 reg)
         double cpre[4] = {0.0, 0.0, 0.0, 0.0};
         if (w == 0 && nb == CH_NB)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q, i = e >> 5, j = e & 31;
+                const int i = 16 * (wave >> 1) + (lane >> 4) + 4 * q, j = 16 * (wave & 1) + (lane & 15);
                 if (i < nbn && j <= i) cpre[q] = ld_sh(&A[(size_t)(k1 + i) * lda + k1 + j]);
             }
         // trailing update: 64 x 64 tiles of the lower triangle dealt to workgroups 1 .. W - 1.
@@ -1152,16 +1154,24 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             for (int p = pend; p < CH_NB; ++p)                   // rows this slice does not have
                 if (tid < CH_NB) Li[p][tid] = 0.0;
             __syncthreads();
+            {
+                // one quadrant per wave on the f64 matrix cores (8 MFMAs, 16 LDS reads per lane
+                // instead of 256 for the scalar dot products); the upper quadrant is not needed
+                const int ti = wave >> 1, tj = wave & 1;
+                double4_t c4 = {cpre[0], cpre[1], cpre[2], cpre[3]};
+                if (tj <= ti) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q, i = e >> 5, j = e & 31;
-                double v = (i == j) ? 1.0 : 0.0;
-                if (i < nbn && j <= i) {
-                    v = cpre[q];
-#pragma unroll 8
-                    for (int m = 0; m < CH_NB; ++m) v -= Li[i][m] * Li[j][m];
+                    for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                        const double a = -Li[16 * ti + li][4 * kk + lk];
+                        const double b = Li[16 * tj + li][4 * kk + lk];
+                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                    }
                 }
-                D[i][j] = v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
+                    D[i][j] = (i < nbn && j <= i) ? c4[q] : ((i == j) ? 1.0 : 0.0);
+                }
             }
             factor_and_publish(k1, nbn, (kb + 1) & 1);
             CF_TICK(4);
