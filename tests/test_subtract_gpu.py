@@ -85,6 +85,12 @@ def test_three_by_three_regions(engine):
     compare(engine, data, r=4.0, rss=9.0, nsx=3, nsy=3, nrx=3, nry=3, ko=1, bgo=0, **COMMON)
 
 
+def test_odd_frame_width(engine):
+    # a width that is not a multiple of 4: the byte-wise dilation and scalar load paths
+    data = scene(nx=381, ny=350, seed=8, nstars=150, gradient=0.2)
+    compare(engine, data, r=5.0, rss=11.0, nsx=4, nsy=4, nrx=2, nry=1, ko=1, bgo=0, **COMMON)
+
+
 def test_reference_orders_ko4_bgo0(engine):
     # -ko 4 -bgo 0 are the orders the reference passes (zuds/hotpants.py:89-93)
     data = scene(nx=512, ny=480, seed=4, nstars=500, gradient=0.3)
