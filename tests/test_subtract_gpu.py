@@ -91,6 +91,19 @@ def test_odd_frame_width(engine):
     compare(engine, data, r=5.0, rss=11.0, nsx=4, nsy=4, nrx=2, nry=1, ko=1, bgo=0, **COMMON)
 
 
+def test_large_cells_many_cells_and_high_order(engine):
+    """Configurations beyond the fast paths' limits: cells of more than 12288 pixels (stamp
+    search from global memory), more than 256 cells per region (block-wide rejection) and more
+    than 16 spatial terms (per-pair normal-matrix build)."""
+    data = scene(nx=384, ny=352, seed=12, nstars=160)
+    compare(engine, data, r=4.0, rss=9.0, nsx=2, nsy=2, ko=1, bgo=0, **COMMON)          # 192 x 176 px cells
+    data = scene(nx=540, ny=510, seed=13, nstars=500)
+    compare(engine, data, r=3.0, rss=6.0, nsx=17, nsy=16, ko=1, bgo=0, **COMMON)        # 272 cells
+    data = scene(nx=448, ny=416, seed=14, nstars=400)
+    d, n, info, rd = compare(engine, data, tol=2e-4, r=3.0, rss=7.0, nsx=8, nsy=8, ko=5, bgo=0, **COMMON)
+    assert info['ncoeff'] == 1 + 48 * 21 + 1            # 21 spatial terms: 1010 unknowns (> 960: 1024-thread back substitution)
+
+
 def test_reference_orders_ko4_bgo0(engine):
     # -ko 4 -bgo 0 are the orders the reference passes (zuds/hotpants.py:89-93)
     data = scene(nx=512, ny=480, seed=4, nstars=500, gradient=0.3)
