@@ -21,7 +21,8 @@ def make(nx, ny, seed, grad=True, nstars=60):
 
 @pytest.mark.parametrize('shape,mesh', [((512, 512), 128), ((300, 280), 64),
                                          ((257, 130), 64), ((100, 90), 128),
-                                         ((560, 540), 16)])   # 35 x 34 = 1190 meshes: generic filter path
+                                         ((560, 540), 16),    # 35 x 34 = 1190 meshes: generic filter path
+                                         ((600, 560), 256)])  # meshes of more than 16384 px: generic statistics kernel
 def test_background_matches_oracle(engine, shape, mesh):
     nx, ny = shape
     f = make(nx, ny, nx + ny)
