@@ -49,6 +49,7 @@ struct hp_plan {
     int kpi[HP_MAXPOLY], kpj[HP_MAXPOLY];   // kernel spatial terms x^i y^j
     int bpi[16], bpj[16];                   // background terms
     int ngauss, gdeg[4], gbase[4], gterm0[4];   // per Gaussian: degree, first 1-D filter, first term
+    int tf0[HP_MAXF1], tfn[HP_MAXF1];           // terms whose x filter is f: tf0[f] .. tf0[f] + tfn[f] - 1 (consecutive)
 };
 
 // ---------------------------------------------------------------------------
@@ -507,9 +508,10 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     // only the owner of its x filter stores it
     int fidx = 0;
     for (int f = 0; f < P.nf1; ++f) {
-        bool used = false;
-        for (int n = 0; n < P.nc; ++n) used |= (P.tfx[n] == f);
-        if (!used) continue;
+        // (the per-filter term ranges come from the plan: scanning the term table here costs a
+        // scalar load and its latency per entry, 15 x 49 of them per workgroup)
+        const int tn0 = P.tf0[f], tn1 = tn0 + P.tfn[f];
+        if (tn1 == tn0) continue;
         const bool mine = (fidx % nparts) == part;
         ++fidx;
         const bool for_w0 = (P.tfx[0] == f);
@@ -536,8 +538,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                 if (j0 + q < sw) xp[yy * sw + j0 + q] = acc[q];
         }
         __syncthreads();
-        for (int n = 0; n < P.nc; ++n) {
-            if (P.tfx[n] != f) continue;
+        for (int n = tn0; n < tn1; ++n) {
             if (!mine && n != 0) continue;
             const double* fyv = filt + P.tfy[n] * STEP;
             const double sc = P.tscale[n];
@@ -1978,6 +1979,12 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
                 ++nc;
             }
     P->nc = nc;
+    for (int f = 0; f < HP_MAXF1; ++f) { P->tf0[f] = 0; P->tfn[f] = 0; }
+    for (int n = 0; n < nc; ++n) {                       // terms are ordered (g, a, b): equal tfx are consecutive
+        const int f = P->tfx[n];
+        if (P->tfn[f] == 0) P->tf0[f] = n;
+        P->tfn[f] += 1;
+    }
     int nkp = 0;
     for (int i = 0; i <= P->ko; ++i)
         for (int j = 0; j <= P->ko - i; ++j) { P->kpi[nkp] = i; P->kpj[nkp] = j; ++nkp; }
