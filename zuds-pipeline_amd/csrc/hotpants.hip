@@ -1674,13 +1674,14 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TP]
     // the tile's space first serves the kernel evaluation (solution vector, term scales, 1-D
     // filters, g_f, s0: nunk + nc + (NB + 1) nf1 STEP + NB doubles) and last the output staging
-    const int tvn = max(TH * TP, P.nunk + P.nc + (NB + 1) * P.nf1 * STEP + NB + 2 * NB * P.nkp);
+    const int tvn = max(TH * TP, P.nunk + 2 * P.nc + (NB + 1) * P.nf1 * STEP + NB + 2 * NB * P.nkp);
     ap_v2f* kc = tTV + tvn;                                        // [NB][STEP*STEP]
     double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP);  // [NB][nc]
     __shared__ int wmask[4];
     double* xs = reinterpret_cast<double*>(ap_smem);                // [nunk] this region's solution
     double* ts = xs + P.nunk;                                       // [nc] term scales
-    double* fl = ts + P.nc;                                         // [nf1][STEP]
+    double* sb = ts + P.nc;                                         // [nc] 1.0 where term 0 is subtracted, else 0.0
+    double* fl = sb + P.nc;                                         // [nf1][STEP]
     double* gf = fl + P.nf1 * STEP;                                 // [NB][nf1][STEP]
     double* s0v = gf + NB * P.nf1 * STEP;                           // [NB] sum of the c_n with sub0_n
     double* pxy = s0v + NB;                                         // [NB][nkp][2] x^i, y^j at the block centres
@@ -1711,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
         for (int u = 0; u < 4; ++u)
             if (e0 + 256 * u < P.nf1 * STEP) fl[e0 + 256 * u] = t[u];
     }
-    for (int e = tid; e < P.nc; e += 256) ts[e] = P.tscale[e];
+    for (int e = tid; e < P.nc; e += 256) { ts[e] = P.tscale[e]; sb[e] = P.tsub0[e] ? 1.0 : 0.0; }
     for (int e = tid; e < NB * P.nkp; e += 256) {
         const int b = e / P.nkp, pp = e - b * P.nkp;
         const double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
@@ -1734,9 +1735,10 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
     }
     __syncthreads();
     if (tid < NB) {
+        // (flags staged in LDS with the scales: a scalar table load per term would sit in this
+        // loop's critical path while the rest of the workgroup waits at the barrier)
         double t = 0.0;
-        for (int n = 0; n < P.nc; ++n)
-            if (P.tsub0[n]) t += cf[tid * P.nc + n];
+        for (int n = 0; n < P.nc; ++n) t += cf[tid * P.nc + n] * sb[n];
         s0v[tid] = t;
     }
     __syncthreads();
@@ -2020,7 +2022,7 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, NB = C::NB;
     constexpr int TP = C::TP, TH = STEP + 2 * HWK;
-    const size_t tvn = std::max((size_t)TH * TP, (size_t)P.nunk + P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB + (size_t)2 * NB * P.nkp);
+    const size_t tvn = std::max((size_t)TH * TP, (size_t)P.nunk + 2 * (size_t)P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB + (size_t)2 * NB * P.nkp);
     size_t fl = 2 * tvn + (size_t)2 * NB * STEP * STEP;      // {T, V} tile (or the evaluation scratch) + {k, k^2} kernels
     size_t shmem = fl * sizeof(float) + (size_t)NB * P.nc * sizeof(double);
     static size_t set_max = 65536;
