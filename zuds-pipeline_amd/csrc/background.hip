@@ -212,7 +212,7 @@ struct meshf_lds {
 
 // per-mesh hand-off from k_mesh_stats_fast to k_mesh_guess (global memory)
 struct mesh_dump {
-    int p0[BK_NLEVELS];              // inclusive prefix of the counts
+    unsigned short p0[BK_NLEVELS];   // inclusive prefix of the counts (a fast-path mesh has at most 16384 pixels)
     long long b1[BK_THREADS];        // exclusive block sums of h i
     long long b2[BK_THREADS];        // exclusive block sums of h i i
     bk_quant q;
@@ -538,15 +538,18 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
             D->b1[tid] = o1 + e1 - a1;
             D->b2[tid] = o2 + e2 - a2;
             int run = (int)(o0 + e0 - a0);
-            int4* dst = reinterpret_cast<int4*>(D->p0 + tid * BK_PER);
+            int4* dst = reinterpret_cast<int4*>(D->p0 + tid * BK_PER);      // 8 prefixes of 16 bits per int4
 #pragma unroll
-            for (int k = 0; k < BK_PER; k += 4) {
-                int4 o;
-                run += hloc[k]; o.x = run;
-                run += hloc[k + 1]; o.y = run;
-                run += hloc[k + 2]; o.z = run;
-                run += hloc[k + 3]; o.w = run;
-                dst[k / 4] = o;
+            for (int k = 0; k < BK_PER; k += 8) {
+                unsigned w[4];
+#pragma unroll
+                for (int h2 = 0; h2 < 4; ++h2) {
+                    run += hloc[k + 2 * h2];
+                    const unsigned lo = (unsigned)run;
+                    run += hloc[k + 2 * h2 + 1];
+                    w[h2] = lo | ((unsigned)run << 16);
+                }
+                dst[k / 8] = make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]);
             }
             if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
         }
@@ -572,10 +575,14 @@ __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__
         if (lane == 0) { *ob = D->q.qzero; *os = 0.f; }
         return;
     }
-    const int4* src = reinterpret_cast<const int4*>(D->p0);
-    int4* dst = reinterpret_cast<int4*>(P0);
+    const int4* src = reinterpret_cast<const int4*>(D->p0);          // 8 prefixes of 16 bits per int4
 #pragma unroll
-    for (int k = 0; k < BK_NLEVELS / 4 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) {
+        const int4 v = src[k * 64 + lane];
+        int4* dst = reinterpret_cast<int4*>(P0 + (k * 64 + lane) * 8);
+        dst[0] = make_int4(v.x & 0xffff, (int)((unsigned)v.x >> 16), v.y & 0xffff, (int)((unsigned)v.y >> 16));
+        dst[1] = make_int4(v.z & 0xffff, (int)((unsigned)v.z >> 16), v.w & 0xffff, (int)((unsigned)v.w >> 16));
+    }
 #pragma unroll
     for (int k = 0; k < BK_THREADS / 64; ++k) {
         B1[k * 64 + lane] = D->b1[k * 64 + lane];
