@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             if (!mine && n != 0) continue;
             const double* fyv = filt + P.tfy[n] * STEP;
             const double sc = P.tscale[n];
+            const bool sub0 = n != 0 && P.tsub0[n] != 0;
             // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
             for (int e = tid; e < sw * nstrip; e += 256) {
                 const int s = e / sw, j = e - s * sw;      // consecutive lanes = consecutive columns
@@ -559,14 +560,22 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
 #pragma unroll
                     for (int q = 0; q < HV_R; ++q) acc[q] += cf * wv[q + m];
                 }
+                // term 0's vector is read for all eight outputs at once, outside any per-pixel
+                // condition (rows beyond the stamp read a clamped, unused entry)
+                double wsub[HV_R];
+#pragma unroll
+                for (int q = 0; q < HV_R; ++q) wsub[q] = 0.0;
+                if (sub0) {
+#pragma unroll
+                    for (int q = 0; q < HV_R; ++q) wsub[q] = w0[min(i0 + q, sw - 1) * sw + j];
+                }
 #pragma unroll
                 for (int q = 0; q < HV_R; ++q) {
                     const int i = i0 + q;
+                    const int k = i * sw + j;
+                    const double v = acc[q] * sc - wsub[q];
                     if (i < sw) {
-                        const int k = i * sw + j;
-                        double v = acc[q] * sc;
                         if (n == 0) w0[k] = v;
-                        else if (P.tsub0[n]) v -= w0[k];
                         if (mine) Xc[(size_t)n * P.npixp + k] = v;
                     }
                 }
