@@ -1647,7 +1647,7 @@ constexpr int apply_pitch(int width, int lpr, int r, int step) {
 
 template <int HWK> struct apply_cfg {
     enum { STEP = 2 * HWK + 1,
-           LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? (STEP == 21 ? 3 : 2) : 3),   // lanes per block row
+           LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? 2 : 3),   // lanes per block row
            R = (STEP + LPR - 1) / LPR,
            LPB = STEP * LPR,                 // lanes per block
            NB = 256 / LPB > 0 ? 256 / LPB : 1,
