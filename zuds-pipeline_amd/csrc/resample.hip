@@ -444,9 +444,18 @@ __device__ inline void rs_build_header(const double2* __restrict__ lat, int lnx,
 // Box OR of an integer mask: B[y][x] = OR of m[y .. y + NT - 1][x .. x + NT - 1] where the
 // whole window lies on the frame (other entries are never read).  One 64 x 16 tile per
 // workgroup, separable in LDS.  The resample kernel then needs a single gather per pixel.
+// The plane holds 16 bits per pixel (ZTF masks are 16-bit: 2 B written here and gathered by the
+// resample kernel instead of 4).  Where the OR has a bit above 15 - a reference mask carrying
+// bit 16 - the entry is ZM_BOX_RAW and the resample kernel ORs the raw mask under that footprint
+// itself (the path it already has for delta kernels); a genuine 0xffff takes that path too.
+#define ZM_BOX_RAW 0xffffu
+__device__ inline uint16_t box_entry(int32_t o) {
+    return ((uint32_t)o >> 16) ? (uint16_t)ZM_BOX_RAW : (uint16_t)o;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_mask_box(const int32_t* __restrict__ m, int nx, int ny,
-                                                  int32_t* __restrict__ B) {
+                                                  uint16_t* __restrict__ B) {
     constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(256) void k_mask_box(const int32_t* __restrict__ m,
             int32_t o = 0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
-            B[(size_t)y * nx + x] = o;
+            B[(size_t)y * nx + x] = box_entry(o);
         }
     }
 }
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
                                                   float invmesh, const float* __restrict__ var_scale_dev,
                                                   float wthresh, int vec_ok, float2* __restrict__ dst,
                                                   int spitch, const int32_t* __restrict__ m,
-                                                  int32_t* __restrict__ B) {
+                                                  uint16_t* __restrict__ B) {
     constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
             int32_t o = 0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
-            B[(size_t)y * nx + x] = o;
+            B[(size_t)y * nx + x] = box_entry(o);
         }
     }
 }
@@ -538,8 +547,8 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
     const int vec_ok = (nx % 4 == 0) && (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
     ctx->box_ready_for = nullptr;
     if (mask_for_box && (box_nt == 6 || box_nt == 2)) {
-        int32_t* mbox = nullptr;
-        ZM_TRY(ctx->get("mask_box", sizeof(int32_t) * (size_t)nx * ny, (void**)&mbox));
+        uint16_t* mbox = nullptr;
+        ZM_TRY(ctx->get("mask_box", sizeof(uint16_t) * (size_t)nx * ny, (void**)&mbox));
         dim3 grd(zm_div_up(spitch, 64), zm_div_up(ny, 16), 1);
         zm_scope_timer t(ctx, "prep");
         if (box_nt == 6)
@@ -565,7 +574,7 @@ template <int KIND, int MASKOP>
 __global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
-    const int32_t* __restrict__ mask, const int32_t* __restrict__ mbox, int32_t* __restrict__ macc,
+    const int32_t* __restrict__ mask, const uint16_t* __restrict__ mbox, int32_t* __restrict__ macc,
     int mkind, int mfirst, int ntx, int ntiles) {
     extern __shared__ float4 smem4[];
     rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
@@ -676,13 +685,16 @@ __global__ __launch_bounds__(256, 4) void k_resample(
             const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
             float2 res = make_float2(0.f, 0.f);
             int32_t mres = 0;
+            uint32_t m16 = 0;                     // box-OR entry of a non-delta footprint
             if (inb) {
                 if (MASKOP) {
                     // every tap of a non-delta axis is non-zero: the OR over the NT x NT footprint
                     // is one gather from the box-OR plane (k_mask_box); delta kernels (aligned
                     // grids) only touch the centre tap of that axis and read the raw mask
+                    // (the entry is only looked at after the interpolation below: its latency
+                    // hides behind the taps)
                     if (!(ddx || ddy)) {
-                        mres = mbox[(size_t)iy * nx + ix];
+                        m16 = mbox[(size_t)iy * nx + ix];
                     } else {
                         const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
                         const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
@@ -731,6 +743,16 @@ __global__ __launch_bounds__(256, 4) void k_resample(
                 if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
                     res.x = acc * fscale;
                     res.y = __builtin_amdgcn_rcpf(vacc * fscale2);      // 1 ulp: one instruction
+                }
+                if (MASKOP && !(ddx || ddy)) {
+                    if (m16 != ZM_BOX_RAW) {
+                        mres = (int32_t)m16;
+                    } else {                        // bits above 15 somewhere under the footprint
+                        for (int r = 0; r < NT; ++r) {
+                            const int32_t* mp = mask + (size_t)(iy + r) * nx + ix;
+                            for (int c = 0; c < NT; ++c) mres |= mp[c];
+                        }
+                    }
                 }
             }
             const size_t oidx = (size_t)oy * onx + ox;
@@ -790,10 +812,10 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
                                 int32_t* macc, int mop, int mkind, int mfirst) {
     dim3 blk(256, 1, 1);
     const int ntx = grd.x, ntiles = grd.x * grd.y;
-    int32_t* mbox = nullptr;
+    uint16_t* mbox = nullptr;
     if (mop) {
         constexpr int NT = taps_traits<KIND>::N;
-        ZM_TRY(ctx->get("mask_box", sizeof(int32_t) * (size_t)nx * ny, (void**)&mbox));
+        ZM_TRY(ctx->get("mask_box", sizeof(uint16_t) * (size_t)nx * ny, (void**)&mbox));
         if (ctx->box_ready_for != (const void*)mask || ctx->box_ready_nt != NT) {
             zm_scope_timer tb(ctx, "mask_box");
             hipLaunchKernelGGL(k_mask_box<NT>, dim3(zm_div_up(nx, 64), zm_div_up(ny, 16)), blk, 0, ctx->stream,
