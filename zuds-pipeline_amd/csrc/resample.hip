@@ -500,10 +500,16 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
     const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
-    for (int e = tid; e < IH * IW; e += 256) {
+    // the mask loads of this thread go out together and land in LDS after the prep below (a loop
+    // of load -> LDS store is waited for load by load)
+    constexpr int NLD = (IH * IW + 255) / 256;
+    int32_t mm[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
         const int r = e / IW, c = e - r * IW;
         const int x = x0 + c, y = y0 + r;
-        t0[r * IP + c] = (x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+        mm[q] = (e < IH * IW && x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
     }
     // the prep of this tile while the mask loads are in flight: one pixel quad per thread
     {
@@ -516,6 +522,11 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
             d4[0] = o[0];
             if (x + 2 < spitch) d4[1] = o[1];
         }
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
+        if (e < IH * IW) t0[(e / IW) * IP + (e % IW)] = mm[q];
     }
     __syncthreads();
     for (int e = tid; e < IH * TWB; e += 256) {
