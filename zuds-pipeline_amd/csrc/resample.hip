@@ -460,10 +460,19 @@ __global__ __launch_bounds__(256) void k_mask_box(const int32_t* __restrict__ m,
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
     const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
-    for (int e = tid; e < IH * IW; e += 256) {
+    constexpr int NLD = (IH * IW + 255) / 256;          // loads first, LDS stores after: one latency
+    int32_t mm[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
         const int r = e / IW, c = e - r * IW;
         const int x = x0 + c, y = y0 + r;
-        t0[r * IP + c] = (x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+        mm[q] = (e < IH * IW && x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
+        if (e < IH * IW) t0[(e / IW) * IP + (e % IW)] = mm[q];
     }
     __syncthreads();
     for (int e = tid; e < IH * TWB; e += 256) {
