@@ -68,7 +68,8 @@ __device__ inline bk_quant make_quant(double mean, double sig, double npix) {
 // Iterated +-3 sigma clip of `backguess` on the prefix arrays (exact integers).
 // Run by one whole wave: the two-pointer median walk is replaced by its
 // merge-path equivalent, searched 64 candidates at a time.
-__device__ inline void backguess_wave(const int* __restrict__ P0, const long long* __restrict__ B1,
+template <typename PT>
+__device__ inline void backguess_wave(const PT* __restrict__ P0, const long long* __restrict__ B1,
                                       const long long* __restrict__ B2, const bk_quant q,
                                       double mean0, float* ob, float* os) {
     const int lane = threadIdx.x & 63;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
 // One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
 __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__ dump, int n, int nmode,
                                                    int nslot, float* __restrict__ raw) {
-    __shared__ int P0[BK_NLEVELS];
+    __shared__ unsigned short P0[BK_NLEVELS];      // 16-bit as handed over: 16 KB of LDS per mesh, not 24
     __shared__ long long B1[BK_THREADS];
     __shared__ long long B2[BK_THREADS];
     const int m = blockIdx.x, z = blockIdx.y, lane = threadIdx.x;
@@ -576,13 +577,9 @@ __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__
         return;
     }
     const int4* src = reinterpret_cast<const int4*>(D->p0);          // 8 prefixes of 16 bits per int4
+    int4* dst = reinterpret_cast<int4*>(P0);
 #pragma unroll
-    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) {
-        const int4 v = src[k * 64 + lane];
-        int4* dst = reinterpret_cast<int4*>(P0 + (k * 64 + lane) * 8);
-        dst[0] = make_int4(v.x & 0xffff, (int)((unsigned)v.x >> 16), v.y & 0xffff, (int)((unsigned)v.y >> 16));
-        dst[1] = make_int4(v.z & 0xffff, (int)((unsigned)v.z >> 16), v.w & 0xffff, (int)((unsigned)v.w >> 16));
-    }
+    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
 #pragma unroll
     for (int k = 0; k < BK_THREADS / 64; ++k) {
         B1[k * 64 + lane] = D->b1[k * 64 + lane];
