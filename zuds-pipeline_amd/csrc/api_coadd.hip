@@ -76,6 +76,11 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     // (Tried on MI355X and dropped: the filter / lattices on a second stream pipelined
     // against the neighbouring frames - foreign workgroups on its CUs stretch the statically
     // partitioned persistent resample kernel by a quarter.)
+    // everything older on the main stream (the resamples of a previous call read the lattice
+    // buffer): the lattices of this call may start once that has drained
+    hipEvent_t* evs = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 5, &evs));
+    ZM_HIP(hipEventRecord(evs[3], ctx->stream));
     const float wthresh = (float)P->weight_thresh;
     float* vs_all = nullptr;
     ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&vs_all));
@@ -117,7 +122,7 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     }
     double2* lat = nullptr;
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
-    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat));
+    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat, evs[3]));
 
     bool first_mask = true;
     for (int i = 0; i < n; ++i) {

@@ -55,21 +55,36 @@ __global__ void k_lattice_batch(const zm_map_params* __restrict__ mps, int lnx, 
 
 // mp_host: n maps (any host memory); staged through a pinned buffer guarded by an event, so
 // that a later call cannot overwrite the staging area of a copy still in flight
+// after != NULL: the lattices depend on the WCS only, so the kernel goes to the second stream,
+// ordered after `after` (an event recorded on the main stream before the caller enqueued the
+// mesh statistics - nothing older may still read the lattice buffer) and therefore free to run
+// beside those statistics; the main stream resumes behind it.
 int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, int lnx, int lny,
-                            double2* lat_dev) {
+                            double2* lat_dev, hipEvent_t after) {
     zm_map_params *pin = nullptr, *dev = nullptr;
     hipEvent_t* ev = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 1, &ev));
+    ZM_TRY(zm_get_sync_events(ctx, 5, &ev));
     ZM_HIP(hipEventSynchronize(ev[0]));
     ZM_TRY(ctx->get_pinned("map_params_h", sizeof(zm_map_params) * (size_t)n, (void**)&pin));
     ZM_TRY(ctx->get("map_params", sizeof(zm_map_params) * (size_t)n, (void**)&dev));
     memcpy(pin, mp_host, sizeof(zm_map_params) * (size_t)n);
-    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_map_params) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    ZM_HIP(hipEventRecord(ev[0], ctx->stream));
+    // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
+    const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "lattice");
+    const bool side = after != nullptr && ctx->aux != nullptr && !timed;
+    hipStream_t s = side ? ctx->aux : ctx->stream;
+    if (side) ZM_HIP(hipStreamWaitEvent(s, after, 0));
+    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_map_params) * (size_t)n, hipMemcpyHostToDevice, s));
+    ZM_HIP(hipEventRecord(ev[0], s));
     dim3 blk(16, 16, 1), grd(zm_div_up(lnx, 16), zm_div_up(lny, 16), n);
-    zm_scope_timer t(ctx, "lattice");
-    hipLaunchKernelGGL(k_lattice_batch, grd, blk, 0, ctx->stream, dev, lnx, lny, lat_dev);
+    {
+        zm_scope_timer t(ctx, "lattice");
+        hipLaunchKernelGGL(k_lattice_batch, grd, blk, 0, s, dev, lnx, lny, lat_dev);
+    }
     ZM_HIP(hipGetLastError());
+    if (side) {
+        ZM_HIP(hipEventRecord(ev[4], s));
+        ZM_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
+    }
     return 0;
 }
 

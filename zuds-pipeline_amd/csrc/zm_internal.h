@@ -100,7 +100,7 @@ double zm_pixel_area(const zm_wcs* w, double x, double y);
 // kernels / launchers (each in its own .hip)
 int zm_launch_lattice(zm_ctx* ctx, const zm_map_params* mp, int lnx, int lny, double2* lat_dev);
 int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, int lnx, int lny,
-                            double2* lat_dev);
+                            double2* lat_dev, hipEvent_t after = nullptr);
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh,
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch,
