@@ -32,7 +32,7 @@ static int check_wcs(const zm_wcs* w, const char* what) {
     return 0;
 }
 
-// LDS elements (float2) a 64 x 16 output tile needs: bound the footprint from the
+// LDS elements (float2) a 64 x 32 output tile of k_resample needs: bound the footprint from the
 // map's Jacobian sampled over the output grid.
 static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
     double wmax = 0, hmax = 0;
@@ -42,7 +42,7 @@ static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
             double x0, y0, x1, y1, x2, y2;
             zm_map_point(mp, x, y, &x0, &y0);
             zm_map_point(mp, x + 64, y, &x1, &y1);
-            zm_map_point(mp, x, y + 16, &x2, &y2);
+            zm_map_point(mp, x, y + 32, &x2, &y2);
             if (!std::isfinite(x0 + y0 + x1 + y1 + x2 + y2)) continue;
             wmax = std::max(wmax, fabs(x1 - x0) + fabs(x2 - x0));
             hmax = std::max(hmax, fabs(y1 - y0) + fabs(y2 - y0));

@@ -25,7 +25,8 @@
 #define TW 64
 #define TH 16
 #define LSTEP ZM_LATTICE_STEP
-#define HDR_FLOATS 96   // LDS header ring: 3 x (20 node floats + bbox ints + flags) in 384 B
+#define RTH 32          // output rows of a k_resample tile (two lattice cells: the other kernels keep TH)
+#define HDR_FLOATS 128  // LDS header ring of k_resample: 3 x (30 node floats + bbox ints + flags) in 512 B
 
 // ---------------------------------------------------------------------------
 // The map travels as a by-value kernel argument (1.5 KB): no host staging buffer
@@ -368,6 +369,48 @@ __device__ inline void build_tile_header(const double2* __restrict__ lat, int ln
     if (lane == 0) { h->bx0 = bx0; h->by0 = by0; h->bw = bw; h->bh = bh; }
 }
 
+// the same for the 64 x 32 tiles of k_resample: 3 x 5 nodes
+struct tile_hdr3 {
+    float nrel[3][5][2];
+    int bx0, by0, bw, bh;
+};
+
+__device__ inline void build_tile_header3(const double2* __restrict__ lat, int lnx, int lny,
+                                          int cx0, int cy0, int support_lo, int support_hi,
+                                          tile_hdr3* h) {
+    // executed by the first wave; lanes 0..14 own one node each
+    int lane = threadIdx.x & 63;
+    int ngx = min(cx0 + (lane % 5), lnx - 1);
+    int ngy = min(cy0 + (lane / 5), lny - 1);
+    double2 nd = make_double2(0.0, 0.0);
+    double mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
+    if (lane < 15) {
+        nd = lat[(size_t)ngy * lnx + ngx];
+        mnx = mxx = nd.x;
+        mny = mxy = nd.y;
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        mnx = fmin(mnx, __shfl_xor(mnx, o));
+        mxx = fmax(mxx, __shfl_xor(mxx, o));
+        mny = fmin(mny, __shfl_xor(mny, o));
+        mxy = fmax(mxy, __shfl_xor(mxy, o));
+    }
+    mnx = fmax(fmin(mnx, 1e8), -1e8); mxx = fmax(fmin(mxx, 1e8), -1e8);
+    mny = fmax(fmin(mny, 1e8), -1e8); mxy = fmax(fmin(mxy, 1e8), -1e8);
+    int bx0 = ((int)floor(mnx) + support_lo - 1) & ~1;
+    int by0 = (int)floor(mny) + support_lo - 1;
+    int bx1 = (int)floor(mxx) + support_hi + 2;
+    int by1 = (int)floor(mxy) + support_hi + 2;
+    int bw = (bx1 - bx0 + 2) & ~1;
+    int bh = by1 - by0 + 1;
+    if (lane < 15) {
+        h->nrel[lane / 5][lane % 5][0] = (float)(nd.x - bx0);
+        h->nrel[lane / 5][lane % 5][1] = (float)(nd.y - by0);
+    }
+    if (lane == 0) { h->bx0 = bx0; h->by0 = by0; h->bw = bw; h->bh = bh; }
+}
+
 __device__ inline void tile_position(const tile_hdr* h, int tx, int ty, float* px, float* py) {
     int cell = tx >> 4;
     float fx = (float)(tx & 15) * (1.f / LSTEP);
@@ -432,11 +475,11 @@ template <> struct lds_row<2> {
 // the lattice / pixel load latency nor the block launch cost sits on the critical
 // path.  PF float4 (+ int2) registers per thread bound the staged tile; larger
 // footprints (strong rotation / scale change) gather from global memory instead.
-#define RS_PF 5                      // prefetch slots per thread: 5 x 256 float4 = 2560 px
+#define RS_PF 7                      // prefetch slots per thread: 7 x 256 float4 = 3584 px
 #define RS_PFCAP (RS_PF * 256 * 2)
 
 struct rs_hdr {
-    tile_hdr h;
+    tile_hdr3 h;
     int use_lds, touches;
 };
 
@@ -446,7 +489,7 @@ __device__ inline void rs_build_header(const double2* __restrict__ lat, int lnx,
     constexpr int NT = taps_traits<KIND>::N;
     constexpr int OFF = taps_traits<KIND>::OFF;
     const int tyi = t / ntx, txi = t - tyi * ntx;
-    build_tile_header(lat, lnx, lny, txi * (TW / LSTEP), tyi * (TH / LSTEP), OFF, OFF + NT - 1, &H->h);
+    build_tile_header3(lat, lnx, lny, txi * (TW / LSTEP), tyi * (RTH / LSTEP), OFF, OFF + NT - 1, &H->h);
     if ((threadIdx.x & 63) == 0) {
         const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
         const int touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
@@ -671,15 +714,17 @@ __global__ __launch_bounds__(256, 4) void k_resample(
         const bool use_lds = H->use_lds, touches = H->touches;
         const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
         const int tyi = t / ntx, txi = t - tyi * ntx;
-        const int ox0 = txi * TW, oy0 = tyi * TH;
+        const int ox0 = txi * TW, oy0 = tyi * RTH;
         const int tx = tid & 63, tyb = tid >> 6;
         const int ox = ox0 + tx;
         // the running mask coadd of this thread's four pixels: loaded before the prefetch
         // so that waiting for it (vmcnt is in order) does not wait for the next tile
-        int32_t aprev[4] = {-1, -1, -1, -1};
+        int32_t aprev[RTH / 4];
+#pragma unroll
+        for (int q = 0; q < RTH / 4; ++q) aprev[q] = -1;
         if (MASKOP == 2 && !mfirst) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < RTH / 4; ++q) {
                 const int oy = oy0 + tyb + 4 * q;
                 if (ox < onx && oy < ony) aprev[q] = macc[(size_t)oy * onx + ox];
             }
@@ -692,25 +737,31 @@ __global__ __launch_bounds__(256, 4) void k_resample(
         // the four pixels of a thread share their column: the x part of the bilinear lattice
         // interpolation is done once, each pixel adds its row fraction (same operations and
         // order as tile_position)
-        float pxa, pxd, pya, pyd;
+        // (a tile spans two lattice cells in y: node rows 0 / 1 for its upper 16 rows, 1 / 2 below)
+        float pxa[2], pxd[2], pya[2], pyd[2];
         {
             const int cell = tx >> 4;
             const float fx = (float)(tx & 15) * (1.f / LSTEP);
-            const float x00 = H->h.nrel[0][cell][0], x10 = H->h.nrel[0][cell + 1][0];
-            const float x01 = H->h.nrel[1][cell][0], x11 = H->h.nrel[1][cell + 1][0];
-            const float y00 = H->h.nrel[0][cell][1], y10 = H->h.nrel[0][cell + 1][1];
-            const float y01 = H->h.nrel[1][cell][1], y11 = H->h.nrel[1][cell + 1][1];
-            const float xa = x00 + fx * (x10 - x00), xb = x01 + fx * (x11 - x01);
-            const float ya = y00 + fx * (y10 - y00), yb = y01 + fx * (y11 - y01);
-            pxa = xa; pxd = xb - xa; pya = ya; pyd = yb - ya;
+            float xr[3], yr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float x0 = H->h.nrel[r][cell][0], x1 = H->h.nrel[r][cell + 1][0];
+                const float y0 = H->h.nrel[r][cell][1], y1 = H->h.nrel[r][cell + 1][1];
+                xr[r] = x0 + fx * (x1 - x0);
+                yr[r] = y0 + fx * (y1 - y0);
+            }
+            pxa[0] = xr[0]; pxd[0] = xr[1] - xr[0]; pya[0] = yr[0]; pyd[0] = yr[1] - yr[0];
+            pxa[1] = xr[1]; pxd[1] = xr[2] - xr[1]; pya[1] = yr[1]; pyd[1] = yr[2] - yr[1];
         }
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RTH / 4; ++q) {
             const int ty = tyb + 4 * q;
             const int oy = oy0 + ty;
             if (ox >= onx || oy >= ony) continue;
-            const float fy = (float)ty * (1.f / LSTEP);
-            const float px = pxa + fy * pxd, py = pya + fy * pyd;
+            const int cr = q >> 2;                                   // ty >> 4: the lattice cell row
+            const float fy = (float)(ty & 15) * (1.f / LSTEP);
+            const float px = (cr ? pxa[1] : pxa[0]) + fy * (cr ? pxd[1] : pxd[0]);
+            const float py = (cr ? pya[1] : pya[0]) + fy * (cr ? pyd[1] : pyd[0]);
             int ixr, iyr;
             float dx, dy;
             bool ddx, ddy;
@@ -795,7 +846,9 @@ __global__ __launch_bounds__(256, 4) void k_resample(
             if (MASKOP == 1) {
                 macc[oidx] = mres;
             } else if (MASKOP == 2) {
-                int32_t a = q == 0 ? aprev[0] : q == 1 ? aprev[1] : q == 2 ? aprev[2] : aprev[3];
+                int32_t a = aprev[0];
+#pragma unroll
+                for (int k = 1; k < RTH / 4; ++k) a = (q == k) ? aprev[k] : a;
                 if (inb) {
                     if (a == -1) a = mres;
                     else a = (mkind == ZM_MASK_AND) ? (a & mres) : (a | mres);
@@ -881,15 +934,16 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
                        float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
                        int32_t* macc, int mop, int mkind, int mfirst) {
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
+    dim3 rgrd(zm_div_up(onx, TW), zm_div_up(ony, RTH), 1);     // k_resample: 64 x 32 tiles
     if (!mask || !macc) mop = 0;
     if (lds_elems > RS_PFCAP) lds_elems = RS_PFCAP;      // what the prefetch registers can stage
     size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * sizeof(float2);
     if (kernel == ZM_RESAMPLE_LANCZOS3)
-        return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, grd, shmem, src, nx, ny, spitch, lat, lnx,
+        return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
                                                           macc, mop, mkind, mfirst);
     if (kernel == ZM_RESAMPLE_BILINEAR)
-        return launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, grd, shmem, src, nx, ny, spitch, lat, lnx,
+        return launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
                                                           macc, mop, mkind, mfirst);
     if (kernel == ZM_RESAMPLE_NEAREST) {
