@@ -738,11 +738,10 @@ __global__ __launch_bounds__(256, 4) void k_resample(
         // interpolation is done once, each pixel adds its row fraction (same operations and
         // order as tile_position)
         // (a tile spans two lattice cells in y: node rows 0 / 1 for its upper 16 rows, 1 / 2 below)
-        float pxa[2], pxd[2], pya[2], pyd[2];
+        float xr[3], yr[3];
         {
             const int cell = tx >> 4;
             const float fx = (float)(tx & 15) * (1.f / LSTEP);
-            float xr[3], yr[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const float x0 = H->h.nrel[r][cell][0], x1 = H->h.nrel[r][cell + 1][0];
@@ -750,8 +749,6 @@ __global__ __launch_bounds__(256, 4) void k_resample(
                 xr[r] = x0 + fx * (x1 - x0);
                 yr[r] = y0 + fx * (y1 - y0);
             }
-            pxa[0] = xr[0]; pxd[0] = xr[1] - xr[0]; pya[0] = yr[0]; pyd[0] = yr[1] - yr[0];
-            pxa[1] = xr[1]; pxd[1] = xr[2] - xr[1]; pya[1] = yr[1]; pyd[1] = yr[2] - yr[1];
         }
 #pragma unroll 1
         for (int q = 0; q < RTH / 4; ++q) {
@@ -760,8 +757,9 @@ __global__ __launch_bounds__(256, 4) void k_resample(
             if (ox >= onx || oy >= ony) continue;
             const int cr = q >> 2;                                   // ty >> 4: the lattice cell row
             const float fy = (float)(ty & 15) * (1.f / LSTEP);
-            const float px = (cr ? pxa[1] : pxa[0]) + fy * (cr ? pxd[1] : pxd[0]);
-            const float py = (cr ? pya[1] : pya[0]) + fy * (cr ? pyd[1] : pyd[0]);
+            const float xa = cr ? xr[1] : xr[0], xb = cr ? xr[2] : xr[1];
+            const float ya = cr ? yr[1] : yr[0], yb = cr ? yr[2] : yr[1];
+            const float px = xa + fy * (xb - xa), py = ya + fy * (yb - ya);
             int ixr, iyr;
             float dx, dy;
             bool ddx, ddy;
