@@ -48,6 +48,31 @@ def test_integer_shift_is_bit_exact_through_tpv(engine, frame):
     assert np.array_equal(o[ys, xs], frame['img'][ys - 6, xs + 11])
 
 
+def test_mask_resample_is_the_or_under_the_footprint(engine, frame):
+    """A sub-pixel translation: every output mask value is the OR of the 6 x 6 input pixels under
+    the Lanczos-3 footprint - also where bits above 15 make the 16-bit box-OR plane defer to the
+    raw mask (a block with bit 16, a block with every low bit and bit 17)."""
+    s = synth()
+    mask = frame['mask'].copy()
+    mask[1000:1100, 500:600] |= 1 << 16
+    mask[2000:2010, 2000:2010] |= (1 << 17) | 0xffff
+    mask[300:303, 700:703] = 0xffff                      # all sixteen low bits, no high bit
+    wout = s.ztf_wcs(NX, NY, dx=-11.4, dy=6.3, tpv=True)   # out (x, y) = in (x + 11.4, y - 6.3)
+    _, ow, om = engine.resample(frame['img'], frame['wcs'], wout, mask=mask)
+    want = np.zeros_like(mask)
+    ys, xs = np.arange(NY)[:, None], np.arange(NX)[None, :]
+    inside = np.ones((NY, NX), bool)
+    for r in range(-9, -3):                              # rows floor(y - 6.3) - 2 .. + 3
+        for c in range(9, 15):                           # columns floor(x + 11.4) - 2 .. + 3
+            yy, xx = ys + r, xs + c
+            ok = (yy >= 0) & (yy < NY) & (xx >= 0) & (xx < NX)
+            inside &= ok
+            want |= np.where(ok, mask[np.clip(yy, 0, NY - 1), np.clip(xx, 0, NX - 1)], 0)
+    assert np.array_equal(ow > 0, inside)
+    assert np.array_equal(om[inside], want[inside])
+    assert (om[inside] >> 16).any() and (om[inside] == 0xffff).any()
+
+
 def test_resample_is_linear(engine, frame):
     s = synth()
     wout = s.ztf_wcs(NX, NY, dx=7.3, dy=-4.6, rot_deg=0.08, tpv=True)
