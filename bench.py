@@ -206,6 +206,9 @@ def main():
         par = importlib.import_module('zuds-pipeline_amd.parallel')
         sharded = par.ShardedCoadd(par.HipBackend(base, params, device=local, engine=eng))
 
+    # --no-mask: the reference has no mask coadd; the subtraction still takes a (zero) reference mask
+    no_ref_mask = torch.zeros((args.size, args.size), dtype=torch.int32, device=device) if args.no_mask else None
+
     def step():
         # ScienceCoadd / ReferenceImage.from_images: science + mask coadds
         if sharded is not None:
@@ -232,7 +235,7 @@ def main():
         if not args.no_subtract:
             # SingleEpochSubtraction.from_images with the reference's defaults
             sub.run(sci['img'], sci_rms, sci['mask'], sci['wgt'], coadd.img, ref_rms,
-                    coadd.mask, seeing=args.seeing, nreg_side=3)
+                    coadd.mask if coadd.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3)
 
     def sync():
         torch.cuda.synchronize(device)
