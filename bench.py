@@ -7,9 +7,14 @@ resample + WEIGHTED coadd) followed by configs[2] (one science frame subtracted
 against that coadd) once the subtraction kernels are built in.  Pixel accounting
 (SURVEY.md section 8(d)): Mpix = (frames resampled + frames subtracted) x 9.437184.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, every
-rank resamples its own 32 frames of a 32 N deep stack, the two partial-sum planes
-go through one RCCL all-reduce each, every rank then subtracts its own frame.
+N > 1: one rank per GPU over RCCL, weak scaling - every rank resamples its own 32 frames
+of a 32 N deep stack, the partial sums are reduced across ranks, every rank then subtracts
+its own frame.  Either the driver starts the ranks (torch.distributed.run: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or `python bench.py --gpus N` starts them itself:
+the parent never imports torch nor touches a GPU, it spawns N children of this script with
+the rendezvous environment set, relays rank 0's JSON line and exits non-zero when a child
+fails (the reference's analogue is `srun -n 64` + get_my_share_of_work,
+nersc/controller.py:101, zuds/mpi.py:36-64).
 """
 import argparse
 import importlib
@@ -27,6 +32,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
+VALU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: max shader clock
+PMC_PROFILES = ['r02_pmc_resample.json', 'r01_pmc_resample.json']     # newest first
 
 
 def parse():
@@ -42,6 +49,8 @@ def parse():
     ap.add_argument('--no-mask', action='store_true', help='skip the mask coadd (dev only)')
     ap.add_argument('--seeing', type=float, default=4.0,
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the CLIPPED secondary line')
+    ap.add_argument('--no-clocks', action='store_true', help='skip the PCIe / FITS clocks')
     ap.add_argument('--cpu-frames', type=int, default=8,
                     help='full-size frames the CPU baseline resamples and coadds')
     return ap.parse_args()
@@ -80,18 +89,18 @@ def make_device_frames(synth, torch, n, size, seed0, device):
     return base, frames
 
 
-def pmc_traffic(args):
-    """HBM bytes per k_resample launch from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is); None when the
-    profile does not match this workload."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_resample.json')
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get('size') != args.size or bool(d.get('mask')) != (not args.no_mask):
-        return None
-    return d.get('hbm_bytes_per_launch')
+def pmc_profile(args):
+    """Counter figures per k_resample launch from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; SQ_INSTS_VALU); {} when
+    no committed profile matches this workload."""
+    for name in PMC_PROFILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        except (OSError, ValueError):
+            continue
+        if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask):
+            return d
+    return {}
 
 
 def cpu_baseline(synth, size, combine, nframes=8, sub_size=640):
@@ -146,8 +155,81 @@ def cpu_baseline(synth, size, combine, nframes=8, sub_size=640):
                       f'CPU restatement, not SWarp / hotpants (not installed)'}
 
 
+def launch(args):
+    """`--gpus N` without a rendezvous environment: start the N ranks ourselves.  Nothing in
+    this process may initialise the GPU (a process that has must not exec or be replaced;
+    children are plain subprocesses)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   ZM_BENCH_LAUNCHER='bench.py')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
+        return 1
+    return 0
+
+
+def reference_tools(workdir, files, hip_products):
+    """when the reference's own binaries exist on this box, run the commands the
+    reference would run (zuds/swarp.py:68-78, zuds/hotpants.py:77-93) on the same FITS files,
+    time them and report the pixel disagreement with the HIP products.  None of them is
+    installed on the pool images seen so far; the probe result is part of the line either way."""
+    import shutil
+    import subprocess
+    found = {t: shutil.which(t) for t in ('swarp', 'hotpants', 'sex')}
+    rep = {'found': {k: v for k, v in found.items() if v}, 'probed': sorted(found)}
+    if not found['swarp'] or files is None:
+        return rep
+    z = importlib.import_module('zuds-pipeline_amd')
+    try:
+        inlist, wlist = os.path.join(workdir, 'images.in'), os.path.join(workdir, 'weight.in')
+        open(inlist, 'w').write('\n'.join(files['sci']) + '\n')
+        open(wlist, 'w').write('\n'.join(files['wgt']) + '\n')
+        out = os.path.join(workdir, 'swarp.coadd.fits')
+        # default.swarp of the reference spelled out as flags (zuds/astromatic/makecoadd/default.swarp)
+        cmd = (f'swarp @{inlist} -BACK_SIZE 128 -IMAGEOUT_NAME {out} -VMEM_DIR {workdir} '
+               f'-RESAMPLE_DIR {workdir} -WEIGHT_IMAGE @{wlist} -WEIGHTOUT_NAME {out[:-5]}.weight.fits '
+               f'-COMBINE_TYPE {files["combine"]} -WEIGHT_TYPE MAP_WEIGHT -RESCALE_WEIGHTS Y '
+               f'-WEIGHT_THRESH 1e-30 -CLIP_AMPFRAC 0.3 -CLIP_SIGMA 4.0 -CELESTIAL_TYPE NATIVE '
+               f'-PROJECTION_TYPE TPV -CENTER_TYPE ALL -PIXELSCALE_TYPE MEDIAN -IMAGE_SIZE 0 '
+               f'-RESAMPLE Y -RESAMPLING_TYPE LANCZOS3 -OVERSAMPLING 0 -INTERPOLATE N '
+               f'-FSCALASTRO_TYPE FIXED -FSCALE_KEYWORD FLXSCALE -SUBTRACT_BACK Y -BACK_TYPE AUTO '
+               f'-BACK_FILTERSIZE 3 -NTHREADS 1 -VERBOSE_TYPE QUIET')
+        t0 = time.perf_counter()
+        subprocess.check_call(cmd.split())
+        dt = time.perf_counter() - t0
+        ref = z.fits.read(out)[0]
+        mine = hip_products['coadd']
+        rep['swarp'] = {'seconds': dt, 'mpix_s': len(files['sci']) * mine.size / 1e6 / dt, 'nthreads': 1,
+                        'shape': list(ref.shape), 'hip_shape': list(mine.shape)}
+        if ref.shape == mine.shape:
+            good = (ref != 0) & (mine != 0)
+            rel = np.abs(ref[good] - mine[good]) / np.maximum(np.abs(ref[good]), 1e-3)
+            rep['swarp']['median_rel_diff'] = float(np.median(rel))
+            rep['swarp']['p99_rel_diff'] = float(np.percentile(rel, 99))
+    except Exception as e:                                   # noqa: a probe must not fail the bench
+        rep['swarp_error'] = repr(e)
+    return rep
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch(args))
     import torch
     import torch.distributed as dist
 
@@ -157,7 +239,9 @@ def main():
     # one rank per GPU over RCCL ('nccl').  Rehearsal on a one-GPU box: ZM_DIST_BACKEND=gloo puts
     # several ranks on the same card (local rank modulo the device count).
     backend = os.environ.get('ZM_DIST_BACKEND', 'nccl')
-    local = local % max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_card = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
@@ -169,8 +253,8 @@ def main():
     z = importlib.import_module('zuds-pipeline_amd')
     synth = importlib.import_module('zuds-pipeline_amd.synth')
     dev = importlib.import_module('zuds-pipeline_amd.device')
+    check = z._lib.check
 
-    import ctypes as C
     eng = z.Engine(local)
     base, frames = make_device_frames(synth, torch, args.frames + 1, args.size,
                                       2000 + 1000 * rank, device)
@@ -187,8 +271,8 @@ def main():
             smask[by + dy, bx + dx] = 256
     sci['mask'] = smask.to(device)
     sci['wgt'] = torch.where(sci['mask'] != 0, 0.0, float(sci['wgt'].max())).to(torch.float32)
-    sci_rms = torch.where(sci['wgt'] > 0, 1.0 / torch.sqrt(sci['wgt'].clamp_min(1e-20)),
-                          float(np.sqrt(50000.0))).to(torch.float32)
+    sci['rms'] = torch.where(sci['wgt'] > 0, 1.0 / torch.sqrt(sci['wgt'].clamp_min(1e-20)),
+                             float(np.sqrt(50000.0))).to(torch.float32)
     params = z.coadd_params(combine=args.combine, subtract_back=True,
                             rescale_weights=True)
     dframes = dev.DeviceFrames(frames, device)
@@ -198,6 +282,7 @@ def main():
     ref_rms = torch.empty_like(coadd.wgt)
     npx = args.size * args.size
     L = eng.L
+    big_rms = float(np.sqrt(50000.0))
 
     sum_type = args.combine.upper() in ('WEIGHTED', 'AVERAGE')
     sharded = None
@@ -209,39 +294,67 @@ def main():
     # --no-mask: the reference has no mask coadd; the subtraction still takes a (zero) reference mask
     no_ref_mask = torch.zeros((args.size, args.size), dtype=torch.int32, device=device) if args.no_mask else None
 
-    def step():
-        # ScienceCoadd / ReferenceImage.from_images: science + mask coadds
+    def coadd_leg(co, dfr):
+        # ScienceCoadd / ReferenceImage.from_images: science + mask coadds, bit 16, pedestal, rms map
         if sharded is not None:
-            img, wgt = sharded.exact(dframes, want_mask=coadd.mask is not None)
-            with torch.cuda.stream(coadd.stream):
-                coadd.stream.wait_stream(sharded.backend.stream)
-                coadd.img.copy_(img)
-                coadd.wgt.copy_(wgt)
-                if coadd.mask is not None:
-                    m = sharded.backend.reduce_mask(cov=coadd.mask_wgt)
-                    coadd.stream.wait_stream(sharded.backend.stream)
-                    coadd.mask.copy_(m)
+            img, wgt = sharded.exact(dfr, want_mask=co.mask is not None)
+            with torch.cuda.stream(co.stream):
+                co.stream.wait_stream(sharded.backend.stream)
+                co.img.copy_(img)
+                co.wgt.copy_(wgt)
+                if co.mask is not None:
+                    m = sharded.backend.reduce_mask(cov=co.mask_wgt)
+                    co.stream.wait_stream(sharded.backend.stream)
+                    co.mask.copy_(m)
         elif world > 1:
-            coadd.run_sharded_weighted(dframes)
+            co.run_sharded_weighted(dfr)
         else:
-            coadd.run(dframes)
-        with torch.cuda.stream(coadd.stream):
-            if coadd.mask is not None:
-                z._lib.check(L.zm_mask_flag_dev(eng.ctx, coadd.mask.data_ptr(),
-                                                coadd.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
-            z._lib.check(L.zm_add_scalar_dev(eng.ctx, coadd.img.data_ptr(), 150.0, npx))
-            z._lib.check(L.zm_rms_from_weight_dev(eng.ctx, coadd.wgt.data_ptr(), None, npx,
-                                                  float(np.sqrt(50000.0)), ref_rms.data_ptr()))
+            co.run(dfr)
+        with torch.cuda.stream(co.stream):
+            if co.mask is not None:
+                check(L.zm_mask_flag_dev(eng.ctx, co.mask.data_ptr(), co.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
+            check(L.zm_add_scalar_dev(eng.ctx, co.img.data_ptr(), 150.0, npx))
+            check(L.zm_rms_from_weight_dev(eng.ctx, co.wgt.data_ptr(), None, npx, big_rms, ref_rms.data_ptr()))
+
+    def sub_leg(co, sc):
+        # SingleEpochSubtraction.from_images with the reference's defaults (the tested object:
+        # tests/test_device_chain_gpu.py)
+        def one():
+            sub.run(sc['img'], sc['rms'], sc['mask'], sc['wgt'], co.img, ref_rms,
+                    co.mask if co.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3)
+        if not shared_card:
+            return one()
+        # rehearsal with several ranks on one card: the fused Cholesky sizes its grid for a GPU of
+        # its own, so the ranks of a card take turns
+        for r in range(world):
+            if r == rank:
+                one()
+                torch.cuda.synchronize(device)
+            dist.barrier()
+
+    def step(co=coadd, dfr=dframes, sc=sci):
+        coadd_leg(co, dfr)
         if not args.no_subtract:
-            # SingleEpochSubtraction.from_images with the reference's defaults
-            sub.run(sci['img'], sci_rms, sci['mask'], sci['wgt'], coadd.img, ref_rms,
-                    coadd.mask if coadd.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3)
+            sub_leg(co, sc)
 
     def sync():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier(device_ids=[local]) if backend == 'nccl' else dist.barrier()
             torch.cuda.synchronize(device)
+
+    def timed(fn, n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     for _ in range(args.warmup):
         step()
@@ -251,26 +364,48 @@ def main():
     # table comes from one more, untimed-for-throughput step with every scope timed.
     eng.timing(True, only='resample')
     eng.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps)
     eng.timing(False)
     rs_ms, rs_cnt = eng.timing_read('resample')
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     eng.timing_reset()
     eng.timing(True)
     step()
     sync()
     eng.timing(False)
+    if sub.info.status != 0 and not args.no_subtract:
+        print(f'rank {rank}: subtraction status {sub.info.status}', file=sys.stderr)
+        sys.exit(3)
 
     frames_per_step = (args.frames + (0 if args.no_subtract else 1)) * world
     mpix_per_step = frames_per_step * args.size * args.size / 1e6
     value = mpix_per_step * args.steps / dt
+
+    # per-leg rates (same objects, same inputs; each leg bracketed by its own sync)
+    legs = {}
+    dt_c = timed(lambda: coadd_leg(coadd, dframes), args.steps)
+    legs['coadd_ms'] = 1e3 * dt_c / args.steps
+    legs['coadd_mpix_s'] = args.frames * world * npx / 1e6 * args.steps / dt_c
+    if not args.no_subtract:
+        dt_s = timed(lambda: sub_leg(coadd, sci), args.steps)
+        legs['subtract_ms'] = 1e3 * dt_s / args.steps
+        legs['subtract_mpix_s'] = world * npx / 1e6 * args.steps / dt_s
+
+    # who ran where: the world RCCL / gloo actually formed
+    me = {'rank': rank, 'device': local, 'name': torch.cuda.get_device_name(local), 'pid': os.getpid()}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+
+    secondary = None
+    clocks = None
+    tools = None
+    if world == 1 and rank == 0:
+        if sum_type and not args.no_secondary:
+            secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx)
+        if not args.no_clocks:
+            clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
+                                                 ref_rms, step, timed, 1e3 * dt / args.steps)
 
     if rank == 0:
         names = ['resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
@@ -291,14 +426,23 @@ def main():
             bpp = RESAMPLE_BYTES_PER_OUTPX + (0 if args.no_mask else MASK_BYTES_PER_OUTPX)
             bytes_per_launch = bpp * args.size * args.size
             ach = bytes_per_launch / avg_s / 1e9
+            pmc = pmc_profile(args)
             roofline = {'bound': 'hbm',
                         'kernel': 'k_resample<LANCZOS3, mask fused>' if not args.no_mask
                         else 'k_resample<LANCZOS3>',
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(args),
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch'),
                         'avg_launch_us': kt['resample']['avg_us'],
                         'algorithmic_bytes_per_launch': bytes_per_launch,
                         'dominant_by_time': dom}
+            # the limit this kernel actually runs into is vector issue, not HBM: VALU
+            # instructions per launch from the committed SQ_INSTS_VALU pass x issue cycles
+            # (MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2
+            # cycles, packed fp32 for 4 - tools/valu_rate.hip) over the SIMD-cycles of the launch
+            if pmc.get('valu_cycles_per_launch'):
+                simd_cycles = avg_s * VALU_CLOCK_HZ * 256 * 4
+                roofline['valu_frac'] = pmc['valu_cycles_per_launch'] / simd_cycles
+                roofline['valu_insts_per_px'] = pmc.get('valu_insts_per_px')
         out = {
             'metric': 'Mpix/s resample->coadd->subtract, 3072x3072 frames',
             'value': value, 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
@@ -308,7 +452,7 @@ def main():
             'config': {'workload': f'configs[1]+[2]: {args.frames}x {args.size}x{args.size} '
                                    f'TPV frames/GPU, mesh background + weight rescale + '
                                    f'Lanczos-3 resample + {args.combine} coadd (+ AND mask coadd)'
-                                   + ((', RCCL all-reduce of the partial sums' if sum_type else ', row-band exchange over RCCL') if world > 1 else '')
+                                   + ((', RCCL reduce of the partial sums' if sum_type else ', row-band exchange over RCCL') if world > 1 else '')
                                    + ('' if args.no_subtract else
                                       '; then 1 science frame/GPU: align ref, hotpants 3x3 regions '
                                       'x 10x10 stamps, r=10, ko=4, subtract'),
@@ -316,14 +460,139 @@ def main():
                        'combine': args.combine, 'subtract': not args.no_subtract,
                        'hotpants': None if args.no_subtract else
                        {k: getattr(sub.info, k) for k, _ in sub.info._fields_}},
+            'world': {'backend': backend if world > 1 else None, 'world_size': world,
+                      'launcher': os.environ.get('ZM_BENCH_LAUNCHER', 'external' if world > 1 else 'none'),
+                      'ranks': ranks},
+            'legs': legs,
             'kernels': kt,      # one extra step with every scope timed ('resample': the timed region)
             'roofline': roofline,
         }
+        if secondary is not None:
+            out['secondary'] = secondary
+        if clocks is not None:
+            out['clocks'] = clocks
+        if tools is not None:
+            out['reference_tools'] = tools
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(synth, args.size, args.combine, args.cpu_frames)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx):
+    """configs[1] with the reference's science COMBINE_TYPE (CLIPPED 4.0 / 0.3,
+    zuds/astromatic/makecoadd/default.swarp:24-31): the resident-stack path."""
+    p = z.coadd_params(combine='CLIPPED', subtract_back=True, rescale_weights=True)
+    co = dev.DeviceCoadd(base, p, device=local, engine=eng, want_mask=not args.no_mask)
+    co.run(dframes)
+    eng.timing(True, only='combine')
+    eng.timing_reset()
+    dt = timed(lambda: co.run(dframes), args.steps)
+    eng.timing(False)
+    ms, cnt = eng.timing_read('combine')
+    out = {'combine': 'CLIPPED', 'coadd_ms': 1e3 * dt / args.steps,
+           'coadd_mpix_s': args.frames * npx / 1e6 * args.steps / dt}
+    if cnt:
+        us = 1e3 * ms / cnt
+        byt = (8 * args.frames + 8) * npx          # SURVEY.md 8(d): one read of every sample + one write
+        out['combine_kernel'] = {'avg_us': us, 'algorithmic_bytes': byt, 'achieved_GBs': byt / (us * 1e-6) / 1e9,
+                                 'frac_of_hbm_peak': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    del co
+    return out
+
+
+def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub, ref_rms, step, timed,
+                         device_ms):
+    """the same step on three clocks - inputs resident in HBM (the headline),
+    + H2D of every input plane and D2H of the products over PCIe, + FITS files on local disk in
+    and out (raw data blocks to the GPU, decode / encode kernels: device.FITSDeviceIO)."""
+    import shutil
+    import tempfile
+    device = coadd.device
+    clocks = {'device_ms': device_ms, 'workload': 'the bench step'}
+    tools = None
+    planes = [(f, k) for f in frames for k in ('img', 'wgt', 'mask')] + \
+             [(sci, k) for k in ('img', 'wgt', 'mask', 'rms')]
+    products = lambda: [coadd.img, coadd.wgt] + ([coadd.mask] if coadd.mask is not None else []) + \
+        ([] if args.no_subtract else [sub.diff, sub.noise, sub.submask])
+    try:
+        pinned_in = [f[k].cpu().pin_memory() for f, k in planes]
+        pinned_out = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in products()]
+        in_bytes = sum(t.numel() * t.element_size() for t in pinned_in)
+        out_bytes = sum(t.numel() * t.element_size() for t in pinned_out)
+
+        def pcie_step():
+            with torch.cuda.stream(coadd.stream):
+                for (f, k), h in zip(planes, pinned_in):
+                    f[k].copy_(h, non_blocking=True)
+            step()
+            with torch.cuda.stream(coadd.stream):
+                for h, t in zip(pinned_out, products()):
+                    h.copy_(t, non_blocking=True)
+        pcie_step()
+        dt = timed(pcie_step, 2) / 2
+        clocks['with_pcie_ms'] = 1e3 * dt
+        clocks['pcie'] = {'h2d_bytes': in_bytes, 'd2h_bytes': out_bytes, 'host_memory': 'pinned',
+                          'overlap': 'none: copies and kernels share one stream'}
+    except Exception as e:                                   # noqa: report, do not fail the bench
+        clocks['with_pcie_ms'] = None
+        clocks['pcie_error'] = repr(e)
+
+    d = tempfile.mkdtemp(prefix='zmbench_', dir=os.environ.get('TMPDIR') or None)
+    try:
+        need = sum(t.numel() * t.element_size() for f, k in planes for t in [f[k]])
+        if shutil.disk_usage(d).free < 2 * need:
+            raise OSError(f'not enough free space under {d} for {need / 1e9:.1f} GB of FITS files')
+        files = {'sci': [], 'wgt': [], 'msk': [], 'combine': args.combine}
+        for i, f in enumerate(frames + [sci]):
+            hdr = dict(f['wcs'].to_header(), NAXIS1=args.size, NAXIS2=args.size,
+                       MAGZP=25.0 - 2.5 * float(np.log10(f['flxscale'])), SEEING=args.seeing)
+            for lst, key, suf, cast in (('sci', 'img', 'sciimg', None), ('wgt', 'wgt', 'weight', None),
+                                        ('msk', 'mask', 'mskimg', np.int16)):
+                path = os.path.join(d, f'f{i:02d}.{suf}.fits')
+                a = f[key].cpu().numpy()
+                z.fits.write(path, a.astype(cast) if cast else a, hdr)
+                files[lst].append(path)
+        sci_paths = [files[k].pop() for k in ('sci', 'wgt', 'msk')]
+        io = dev.FITSDeviceIO(device.index, engine=eng, stream=coadd.stream)
+        big_rms = float(np.sqrt(50000.0))
+
+        def fits_step():
+            dfr, _ = io.load_frames(files['sci'], files['wgt'], files['msk'])
+            sc = dict(wcs=sci['wcs'])
+            sc['img'], _ = io.load(sci_paths[0], 'f32')
+            sc['wgt'], _ = io.load(sci_paths[1], 'f32')
+            sc['mask'], _ = io.load(sci_paths[2], 'i32')
+            sc['rms'] = torch.empty_like(sc['img'])
+            with torch.cuda.stream(coadd.stream):
+                z._lib.check(eng.L.zm_rms_from_weight_dev(eng.ctx, sc['wgt'].data_ptr(), None, sc['img'].numel(),
+                                                          big_rms, sc['rms'].data_ptr()))
+            step(coadd, dfr, sc)
+            hdr = base.to_header()
+            names = ['coadd.fits', 'coadd.weight.fits'] + (['coadd.mask.fits'] if coadd.mask is not None else []) + \
+                ([] if args.no_subtract else ['sub.fits', 'sub.rms.fits', 'sub.mask.fits'])
+            for nme, t in zip(names, products()):
+                io.save(os.path.join(d, nme), t, hdr)
+        fits_step()                                          # page cache, allocations
+        dt = timed(fits_step, 1)
+        clocks['with_fits_ms'] = 1e3 * dt
+        clocks['fits'] = {'files_in': 3 * (len(frames) + 1), 'bytes_in': sum(os.path.getsize(p) for k in ('sci', 'wgt', 'msk') for p in files[k]) + sum(os.path.getsize(p) for p in sci_paths),
+                          'page_cache': 'warm', 'decode': 'on the device (zm_fits_decode_dev)'}
+        mpix = (len(frames) + (0 if args.no_subtract else 1)) * args.size * args.size / 1e6
+        for k in ('device_ms', 'with_pcie_ms', 'with_fits_ms'):
+            if clocks.get(k):
+                clocks[k.replace('_ms', '_mpix_s')] = mpix / (clocks[k] * 1e-3)
+        tools = reference_tools(d, files, {'coadd': z.fits.read(os.path.join(d, 'coadd.fits'))[0]})
+    except Exception as e:                                   # noqa: report, do not fail the bench
+        clocks['with_fits_ms'] = None
+        clocks['fits_error'] = repr(e)
+        tools = reference_tools(d, None, None)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    # the step objects go back to the resident inputs
+    eng.set_stream(coadd.stream.cuda_stream)
+    return clocks, tools
 
 
 if __name__ == '__main__':

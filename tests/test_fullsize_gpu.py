@@ -172,3 +172,99 @@ def test_subtracting_a_convolved_scaled_copy_leaves_nothing(engine, frame):
     expect = 6.0 * np.sqrt(1 + 1.7 ** 2 / (4 * np.pi * 0.81))
     assert abs(np.median(n[good]) - expect) < 0.15
     assert np.all(n[grown] == np.float32(np.sqrt(50000.0)))
+
+
+def blob_bpm(seed, n=300):
+    """Detector defects as bench.py draws them: n clustered 3 x 3 blobs (a 49 x 49 substamp and
+    its 21 x 21 kernel margin must be clean to be usable)."""
+    rng = np.random.default_rng(seed)
+    bpm = np.zeros((NY, NX), np.uint8)
+    for bx, by in zip(rng.integers(2, NX - 2, n), rng.integers(2, NY - 2, n)):
+        bpm[by - 1:by + 2, bx - 1:bx + 2] = 1
+    return bpm
+
+
+def test_config2_subtraction_at_the_reference_parameters(engine, frame):
+    """BASELINE config[2] as prepare_hotpants emits it for SEEING = 4 px
+    (zuds/hotpants.py:44-93): r = 10, rss = 24, 3 x 3 regions of 10 x 10 stamps, ko = 4,
+    bgo = 0 -> nine 722-unknown systems and the 21 x 21 convolution, on a real ZTF quadrant
+    size.  sci = 1.7 (ref (x) G(0.9)) + 25, noise free: kernel sum = flux ratio, residual ~ 0,
+    fill pattern = bad-pixel map grown by the kernel half width, noise map analytic; the
+    ko = 2 fit (SURVEY 8(d) primary) of the same constant kernel gives the same difference."""
+    from scipy.ndimage import gaussian_filter
+    s = synth()
+    xs, ys, fl = frame['stars']
+    ref = np.full((NY, NX), 200.0)
+    s.add_stars(ref, xs, ys, fl, 2.1)
+    sci = (1.7 * gaussian_filter(ref, 0.9, mode='nearest') + 25.0).astype(np.float32)
+    ref = ref.astype(np.float32)
+    bpm = blob_bpm(77)
+    rms = np.full((NY, NX), 6.0, np.float32)
+    kw = dict(r=10.0, rss=24.0, nsx=10, nsy=10, nrx=3, nry=3, bgo=0, tu=1e6, iu=1e6, tl=-1e3, il=-1e3)
+    d, n, info = engine.subtract(sci, rms, ref, rms, bpm, ko=4, **kw)
+    assert info['status'] == 0 and info['ncoeff'] == 722
+    assert info['nstamps_total'] > 600 and info['nstamps_used'] > 0.8 * info['nstamps_total']
+    assert abs(info['kernel_sum'] - 1.7) < 1e-3
+    hw = 10
+    grown = maximum_filter(bpm, size=2 * hw + 1, mode='constant', cval=0).astype(bool)
+    grown[:hw] = grown[-hw:] = True
+    grown[:, :hw] = grown[:, -hw:] = True
+    assert np.array_equal(d == np.float32(1e-30), grown)
+    assert info['nmasked'] == int(grown.sum())
+    good = ~grown
+    assert np.abs(d[good]).max() < 5e-3 * np.abs(sci).max()
+    assert np.abs(d[good]).mean() < 0.05
+    expect = 6.0 * np.sqrt(1 + 1.7 ** 2 / (4 * np.pi * 0.81))
+    assert abs(np.median(n[good]) - expect) < 0.15
+    assert np.all(n[grown] == np.float32(np.sqrt(50000.0)))
+    d2, n2, info2 = engine.subtract(sci, rms, ref, rms, bpm, ko=2, **kw)
+    assert info2['status'] == 0 and info2['ncoeff'] == 1 + 48 * 6 + 1
+    assert abs(info2['kernel_sum'] - 1.7) < 1e-3
+    assert np.array_equal(d2 == np.float32(1e-30), grown)
+    assert np.abs(d2[good] - d[good]).max() < 5e-3 * np.abs(sci).max()
+    np.testing.assert_allclose(n2[good], n[good], rtol=2e-3)
+
+
+def test_fullsize_coadd_removes_the_background_and_rescales_the_weights(engine, frame):
+    """The science SWarp run with its defaults at full size (default.swarp: SUBTRACT_BACK Y,
+    BACK_SIZE 128 from zuds/swarp.py:69, RESCALE_WEIGHTS Y): a smooth sky gradient of 60
+    counts across the frame is gone from the coadd, and the output weight is N / (measured
+    variance) whatever scale the input weight maps claim - the batched mesh statistics +
+    rescale path bench.py times."""
+    z = pkg()
+    s = synth()
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:NY, 0:NX].astype(np.float32)
+    sky = (30.0 * (xx / NX) + 20.0 * (yy / NY) ** 2 + 10.0 * np.sin(2.5 * xx / NX) * (yy / NY)).astype(np.float32)
+    frames = []
+    for i in range(3):
+        w = s.ztf_wcs(NX, NY, dx=rng.uniform(-8, 8), dy=rng.uniform(-8, 8), rot_deg=rng.uniform(-0.05, 0.05))
+        frames.append(dict(frame, wcs=w, img=frame['img'] + sky * (1.0 + 0.3 * i)))
+    flat = [dict(f, img=frame['img']) for f in frames]
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True, back_size=128)
+    o, ow, _, _ = engine.coadd(frames, frame['wcs'], p, want_mask=False)
+    f0, fw, _, _ = engine.coadd(flat, frame['wcs'], p, want_mask=False)
+    good = (ow > 0) & (fw > 0)
+    assert good.mean() > 0.98
+    # the gradient (30 .. 78 counts peak to peak over the three frames) is gone: block medians
+    # of the coadd sit at zero, and the coadd equals the one made from the flat-sky frames
+    for by in range(0, NY - 512, 512):
+        for bx in range(0, NX, 512):
+            blk = (slice(by, by + 512), slice(bx, bx + 512))
+            assert abs(np.median(o[blk][good[blk]])) < 0.35, (by, bx)
+    assert np.abs(np.median((o - f0)[good])) < 0.05
+    assert np.percentile(np.abs(o - f0)[good], 99) < 1.0
+    # weights: 3 frames of sigma 6 -> 3 / 36, from weight maps that claim 1 / 36
+    assert abs(np.median(ow[good]) * 36.0 / 3.0 - 1.0) < 0.05
+    # ... and from maps that claim four times / a quarter of it: RESCALE_WEIGHTS removes the claim
+    for c in (4.0, 0.25):
+        scaled = [dict(f, wgt=(f['wgt'] * np.float32(c))) for f in frames]
+        o2, ow2, _, _ = engine.coadd(scaled, frame['wcs'], p, want_mask=False)
+        assert np.array_equal(ow2 > 0, ow > 0)
+        np.testing.assert_allclose(ow2[good], ow[good], rtol=2e-5)
+        np.testing.assert_allclose(o2[good], o[good], rtol=1e-5, atol=2e-3)
+    # without the rescale the claim goes straight through
+    pn = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=False, back_size=128)
+    _, own, _, _ = engine.coadd([dict(f, wgt=f['wgt'] * np.float32(4.0)) for f in frames], frame['wcs'], pn,
+                                want_mask=False)
+    assert abs(np.median(own[good]) * 36.0 / 12.0 - 1.0) < 0.01

@@ -66,8 +66,21 @@ def test_coadd_products_and_bookkeeping(products):
     assert abs(np.median(ref.data[good]) - 150.0) < 0.5
     # bit 16 exactly where the mask coadd has no coverage
     m = ref.mask_image.data
-    assert ((m & (1 << 16)) != 0).any()
-    assert np.array_equal((m & (1 << 16)) != 0, ~good | ((m & (1 << 16)) != 0)) or True
+    b16 = (m & (1 << 16)) != 0
+    assert b16.any() and not b16.all()
+    # no input mask reaches a bit-16 pixel: the AND over zero frames is 0, so the pixel holds
+    # exactly 2^16 (zuds/mask.py:26-33), and no science frame reaches it either
+    assert np.all(m[b16] == 1 << 16) and not good[b16].any()
+    # and it is the complement of the union of the 6 x 6 footprints of the three inputs
+    from oracle import resample as ores
+    wout = to_oracle_wcs(ref.wcs)
+    cov = np.zeros(m.shape, dtype=bool)
+    for f in frames[:3]:
+        px, py = ores.positions(wout, to_oracle_wcs(f['wcs']), *wout.naxis)
+        ix, _, _ = ores.split_position(px)
+        iy, _, _ = ores.split_position(py)
+        cov |= (ix - 2 >= 0) & (ix + 4 <= 512) & (iy - 2 >= 0) & (iy + 4 <= 512)
+    assert (b16 != ~cov).mean() < 2e-4
     assert ref.mask_image.header['BIT16'] == 16
 
 
@@ -135,8 +148,23 @@ def test_aligned_to_returns_unmapped_in_memory_products(products):
     assert al.basename == 'ref.000651_c03_q1_zg_aligned_to_' + ims[3].basename[:-5] + '.remap.fits'
     assert al.parent_image is ref
     assert al.mask_image.data.shape == (512, 512)
-    # MaskImage inputs get bit 16 where the reference has no data (zuds/swarp.py:190-191)
-    assert ((al.mask_image.data & (1 << 16)) != 0).sum() >= 0
+    # MaskImage inputs get bit 16 where the resampler found no data (zuds/swarp.py:190-191):
+    # frame 3 is shifted by (2.4, 1.3) px against frame 0, so two edges of frame 0's grid lie
+    # outside its footprint
+    a30 = ims[3].aligned_to(ims[0])
+    b16 = (a30.mask_image.data & (1 << 16)) != 0
+    assert 0 < b16.mean() < 0.05
+    assert np.all(a30.data[b16] == 0) and np.all(a30.mask_image.data[b16] == 1 << 16)
+    inner = np.zeros_like(b16)
+    inner[8:-8, 8:-8] = True
+    assert not b16[inner].any()
+    # ... while the transaction copy Subtraction.from_images aligns is a plain MaskImageBase
+    # and gets none (zuds/subtraction.py:94-99)
+    from importlib import import_module
+    subm = import_module('zuds-pipeline_amd.subtraction')
+    t3 = subm._shallow(ims[3], ims[3].__class__)
+    t3.mask_image = subm._shallow(ims[3].mask_image, z.MaskImageBase)
+    assert not (t3.aligned_to(ims[0]).mask_image.data & (1 << 16)).any()
     keep = ref.aligned_to(ims[3], persist_aligned=True)
     assert keep.ismapped and os.path.exists(keep.local_path)
     with pytest.raises(ValueError):
@@ -162,3 +190,16 @@ def test_multi_epoch_subtraction_is_a_coadd_of_single_epoch_subs(products, tmp_p
     assert me.header['SEEING'] == stack.header['SEEING']
     good = me.weight_image.data > 0
     assert abs(np.median(me.data[good])) < 1.0          # addbkg=False: no pedestal
+    # = the CLIPPED coadd of the two difference images with their 1 / rms^2 weights and their
+    # masks (zuds/subtraction.py:283-319 -> zuds/coadd.py:25-236 with addbkg=False)
+    of = [dict(img=s_.data, wgt=s_.weight_image.data, mask=s_.mask_image.data,
+               wcs=to_oracle_wcs(s_.wcs), magzp=s_.header['MAGZP']) for s_ in subs]
+    r = opipe.coadd_from_images(of, addbkg=False, combine='CLIPPED')
+    assert (me.header['NAXIS1'], me.header['NAXIS2']) == r['wcs'].naxis
+    gw = me.weight_image.data
+    both = (gw > 0) & (r['wgt'] > 0)
+    assert ((gw > 0) != (r['wgt'] > 0)).mean() < 2e-4
+    assert_close_masked(me.data[both], r['img'][both], 1e-4, 2e-3, 'multi-epoch sub',
+                        max_bad_frac=2e-4)
+    assert_close_masked(gw[both], r['wgt'][both], 2e-3, 0, 'multi-epoch weight', max_bad_frac=2e-4)
+    assert (me.mask_image.data != r['mask']).mean() < 2e-4

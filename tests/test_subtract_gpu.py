@@ -194,3 +194,15 @@ def test_median_mad_matches_numpy(engine):
     z = pkg()
     with pytest.raises(z.ZMError):
         engine.median_mad(np.ones(4, np.float32), np.ones(4, np.int32))
+
+
+@pytest.mark.parametrize('ko', [2, 4])
+def test_config2_parameters_against_the_oracle(engine, ko):
+    """BASELINE config[2] at its stated parameters on a 1024 x 1024 frame: SEEING = 4 px ->
+    r = 10 (21 x 21 kernel), rss = 24, 10 x 10 stamps, ko = 4 (the reference's default,
+    zuds/hotpants.py:93: 722 unknowns) and ko = 2 (SURVEY.md 8(d) primary)."""
+    data = scene(nx=1024, ny=1024, seed=50, nstars=1200, gradient=0.3, nbad=30)
+    d, n, info, rd = compare(engine, data, r=10.0, rss=24.0, nsx=10, nsy=10, ko=ko, bgo=0, **COMMON)
+    assert info['ncoeff'] == 1 + 48 * (ko + 1) * (ko + 2) // 2 + 1
+    assert info['nstamps_total'] == 100 and info['status'] == 0
+    assert abs(info['kernel_sum'] - 1.3) < 2e-3

@@ -54,6 +54,8 @@ def build(force=False, verbose=True):
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
+        elif verbose:
+            print(f'up to date: {o.name} (newer than {src} and the headers)', flush=True)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {src}')
@@ -64,6 +66,10 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if verbose:
+        print(f'libzudsmi: compiled {len(procs)} of {len(SOURCES)} translation units'
+              f'{" (forced)" if force else ""}, '
+              f'{"linked" if (force or procs) else "library reused"}', flush=True)
     return lib
 
 

@@ -168,22 +168,36 @@ class DeviceSubtraction(object):
         self.info = _lib.zm_hp_info()
 
     def run(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
-            nreg_side=3, subtract_back=True, hotpants_kws=None):
+            nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
+            ref_rms_flxscale=None):
         """All arguments are torch tensors on this device; ``seeing`` is the
-        science FWHM in pixels (header SEEING).  Returns (diff, noise, submask)."""
+        science FWHM in pixels (header SEEING); ``ref_flxscale`` the FLXSCALE card of the
+        reference (SWarp applies it on resampling, ``swarp.run_align``).
+        Returns (diff, noise, submask)."""
         from .engine import hp_params
+        from .hotpants import job_params
         L, ctx = self.engine.L, self.engine.ctx
         ny, nx = self.shape
         LAN = _lib.RESAMPLE['LANCZOS3']
+        fs = C.c_double()
+        check(L.zm_flux_scale(C.byref(self.wref), C.byref(self.wsci), float(ref_flxscale),
+                              C.byref(fs)), 'zm_flux_scale')
+        fs_rms = C.c_double()
+        check(L.zm_flux_scale(C.byref(self.wref), C.byref(self.wsci),
+                              float(ref_flxscale if ref_rms_flxscale is None else ref_rms_flxscale),
+                              C.byref(fs_rms)), 'zm_flux_scale')
         self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
         with self.torch.cuda.stream(self.stream):
-            # ref.aligned_to(sci): image (WEIGHT_TYPE NONE) + mask (OR), fitsfile.py:290-314
+            # ref.aligned_to(sci): image (WEIGHT_TYPE NONE) + mask (OR), fitsfile.py:290-314.
+            # The reference aligns a transaction copy whose mask is a plain MaskImageBase
+            # (zuds/subtraction.py:94-99), so run_align does NOT add bit 16 to it
+            # (zuds/swarp.py:186-191): uncovered pixels of the aligned mask stay 0, and
+            # quick_background_estimate(ref) therefore counts them (zuds/hotpants.py:67).
             check(L.zm_resample_dev(ctx, ref.data_ptr(), None, ref_mask.data_ptr(),
-                                    C.byref(self.wref), C.byref(self.wsci), LAN, 1.0,
+                                    C.byref(self.wref), C.byref(self.wsci), LAN, fs.value,
                                     self.ref_al.data_ptr(), self.ref_al_w.data_ptr(),
                                     self.refmask_al.data_ptr()), 'align ref')
-            check(L.zm_mask_flag_dev(ctx, self.refmask_al.data_ptr(), self.ref_al_w.data_ptr(),
-                                     0.0, 1 << 16, self.n), 'bit16')
             # badpix = remapped_refmask | sci mask; boolean bpm (subtraction.py:135-142)
             check(L.zm_mask_bad_dev(ctx, self.refmask_al.data_ptr(), sci_mask.data_ptr(),
                                     self.BAD_SUM, self.n, self.submask.data_ptr(),
@@ -201,21 +215,17 @@ class DeviceSubtraction(object):
                 scim = sci
             # ref rms aligned to the science grid (hotpants.py:51)
             check(L.zm_resample_dev(ctx, ref_rms.data_ptr(), None, None, C.byref(self.wref),
-                                    C.byref(self.wsci), LAN, 1.0, self.refrms_al.data_ptr(),
+                                    C.byref(self.wsci), LAN, fs_rms.value, self.refrms_al.data_ptr(),
                                     self.refrms_al_w.data_ptr(), None), 'align ref rms')
             # quick_background_estimate x 2 (hotpants.py:65-67)
             mm = (C.c_double * 4)()
             check(L.zm_median_mad2_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
                                        self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
                                        self.n, mm), 'sci / ref bkg')
-            m1, s1, m2, s2 = (C.c_double(v) for v in mm)
-            kw = dict(hotpants_kws or {})
-            kw.setdefault('bgo', 0)
-            kw.setdefault('ko', 4)
-            p = hp_params(il=m1.value - 10 * s1.value, tl=m2.value - 10 * s2.value,
-                          tu=5e3, iu=5e3, r=2.5 * seeing, rss=6.0 * seeing,
-                          fin=self.BIG_RMS, nsx=int(nx / 100.0 / nreg_side),
-                          nsy=int(ny / 100.0 / nreg_side), nrx=nreg_side, nry=nreg_side, **kw)
+            m1, s1, m2, s2 = (float(v) for v in mm)
+            self.limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
+            p = hp_params(**job_params(seeing, nx, ny, nreg_side, self.limits['il'],
+                                       self.limits['tl'], hotpants_kws))
             check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
                                     self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
                                     self.bpm.data_ptr(), nx, ny, C.byref(p),

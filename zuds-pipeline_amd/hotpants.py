@@ -16,11 +16,26 @@ _INT_KEYS = ('ko', 'bgo', 'nss', 'nsx', 'nsy', 'nrx', 'nry')
 _FLT_KEYS = ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks')
 
 
-def chunk(iterable, chunksize):
-    isize = len(iterable)
-    nchunks = isize // chunksize if isize % chunksize == 0 else isize // chunksize + 1
-    for i in range(nchunks):
-        yield i, iterable[i * chunksize: (i + 1) * chunksize]
+def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
+    """The numeric content of the hotpants command line (``zuds/hotpants.py:44-93``) as
+    keyword arguments of ``engine.hp_params``: r = 2.5 SEEING, rss = 6 SEEING, stamps per
+    region = NAXIS / 100 / nreg_side (hotpants reads -nsx / -nsy as integers), upper limits
+    5e3, ``-bgo 0 -ko 4`` unless overridden.  Shared by ``prepare_hotpants`` and the
+    device-resident chain (``device.DeviceSubtraction``) so the two cannot drift apart."""
+    satlev = 5e3
+    params = dict(tu=satlev, iu=satlev, tl=float(tl), il=float(il), r=2.5 * seeing,
+                  rss=6. * seeing, fin=float(BIG_RMS),
+                  nsx=max(int(naxis1 / 100. / nreg_side), 1),
+                  nsy=max(int(naxis2 / 100. / nreg_side), 1),
+                  nrx=int(nreg_side), nry=int(nreg_side), bgo=0, ko=4, normalize=0)
+    for key, val in (hotpants_kws or {}).items():
+        if key in _INT_KEYS:
+            params[key] = int(val)
+        elif key in _FLT_KEYS:
+            params[key] = float(val)
+        elif key == 'n':
+            params['normalize'] = 1 if str(val) == 't' else 0
+    return params
 
 
 class HotpantsCall(object):
@@ -62,17 +77,24 @@ def prepare_hotpants(sci, ref, outname, submask, directory, tmpdir='/tmp',
     if hotpants_kws is None:
         hotpants_kws = {}
     if subtract_new_back:
-        scimbkg = run_sextractor(sci, checkimage_type=['bkgsub'])[1]
-        scimbkg.data = scimbkg.data + np.float32(BKG_VAL)
-        if scimbkg.ismapped:
-            scimbkg.save()
+        # The reference adds the pedestal to the check-image and saves it - inside the
+        # transaction directory, which it deletes afterwards (zuds/hotpants.py:27-30,
+        # zuds/subtraction.py:224).  There is no such directory here, so the pedestal plane
+        # lives in memory only: a `.bkgsub.fits` on disk never carries the +150.
+        from .image import FITSImage
+        bkgsub = run_sextractor(sci, checkimage_type=['bkgsub'])[1]
+        scimbkg = FITSImage()
+        scimbkg.basename = bkgsub.basename
+        scimbkg.header, scimbkg.header_comments = bkgsub.header, bkgsub.header_comments
+        scimbkg.data = bkgsub.data + np.float32(BKG_VAL)
     else:
         scimbkg = sci
     if 'SEEING' not in sci.header:
         # zuds/hotpants.py:38-42: measured here from the pixels (seeing.py)
         from .seeing import estimate_seeing
         estimate_seeing(sci)
-        sci.save()
+        if sci.ismapped:
+            sci.save()
     seepix = sci.header['SEEING']   # header seeing is FWHM in pixels
     r = 2.5 * seepix
     rss = 6. * seepix
@@ -103,17 +125,8 @@ def prepare_hotpants(sci, ref, outname, submask, directory, tmpdir='/tmp',
         syscall += ' -bgo 0'
     if 'ko' not in hotpants_kws:
         syscall += ' -ko 4'
-    # hotpants parses -nsx / -nsy / -r / -rss with integer conversions
-    params = dict(tu=satlev, iu=satlev, tl=tl, il=il, r=r, rss=rss, fin=float(BIG_RMS),
-                  nsx=max(int(nsx / nreg_side), 1), nsy=max(int(nsy / nreg_side), 1),
-                  nrx=int(nreg_side), nry=int(nreg_side), bgo=0, ko=4, normalize=0)
-    for key, val in hotpants_kws.items():
-        if key in _INT_KEYS:
-            params[key] = int(val)
-        elif key in _FLT_KEYS:
-            params[key] = float(val)
-        elif key == 'n':
-            params['normalize'] = 1 if str(val) == 't' else 0
+    params = job_params(seepix, sci.header['NAXIS1'], sci.header['NAXIS2'], nreg_side, il, tl,
+                        hotpants_kws)
     bpm = np.ascontiguousarray(submask.data).astype(np.uint8)
     return HotpantsCall(syscall, params, scimbkg.data, scirms.data, ref.data, refrms.data,
                         bpm, outname, subrms, dict(sci.header))

@@ -76,5 +76,6 @@ def estimate_seeing(image):
     seeing, _ = measure_seeing(image.data, bad, float(sat) if sat else None)
     image.header['SEEING'] = float(seeing)
     image.header_comments['SEEING'] = 'FWHM of seeing in pixels (Goldstein)'
-    image.save()
+    if image.ismapped:          # a transaction copy held in memory has no file to update
+        image.save()
     return seeing

@@ -10,7 +10,7 @@ import numpy as np
 from .coadd import ScienceCoadd, _coadd_from_images
 from .constants import APER_KEY
 from .fitsfile import HasWCS
-from .image import CalibratableImage, CalibratedImage, FITSImage
+from .image import CalibratableImage, CalibratableImageBase, CalibratedImage, FITSImage
 from .mask import MaskImage, MaskImageBase
 
 __all__ = ['sub_name', 'Subtraction', 'SingleEpochSubtraction', 'MultiEpochSubtraction']
@@ -28,15 +28,18 @@ def sub_name(frame, template):
     return os.path.join(outdir, 'sub.%s.fits' % subp)
 
 
-def _shallow(obj, cls):
+def _shallow(obj, cls, mapped=True):
     """In-memory stand-in for the reference's on-disk transaction copy: a new
-    object of class ``cls`` sharing ``obj``'s arrays and header."""
+    object of class ``cls`` sharing ``obj``'s arrays and header.  ``mapped=False``
+    leaves the copy without a file: whatever derives products from it (check-images,
+    rms maps, a measured SEEING) keeps them in memory, as the reference keeps them in
+    the transaction directory it deletes (``zuds/subtraction.py:68-99,224``)."""
     new = cls()
     new.basename = obj.basename
     new.header = obj.header
     new.header_comments = obj.header_comments
     new.data = obj.data
-    if obj.ismapped:
+    if mapped and obj.ismapped:
         new._path = obj.local_path
     for prop in ('field', 'ccdid', 'qid', 'fid'):
         if hasattr(obj, prop):
@@ -82,9 +85,17 @@ class Subtraction(HasWCS):
         transact_ref = _shallow(ref, ref.__class__)
         transact_ref.mask_image = _shallow(ref.mask_image, MaskImageBase)
         transact_ref._weightimg = ref.weight_image
+        # the science frame too: prepare_hotpants derives a background-subtracted plane,
+        # possibly an rms map and a SEEING from it; none of that may land next to the
+        # caller's file
+        transact_sci = _shallow(sci, CalibratableImageBase, mapped=False)
+        transact_sci.mask_image = sci.mask_image
+        for attr in ('_rmsimg', '_weightimg'):
+            if hasattr(sci, attr):
+                setattr(transact_sci, attr, getattr(sci, attr))
 
         # remapped ref and remapped ref mask on the science grid
-        remapped_ref = transact_ref.aligned_to(sci, tmpdir=tmpdir)
+        remapped_ref = transact_ref.aligned_to(transact_sci, tmpdir=tmpdir)
         remapped_refmask = remapped_ref.mask_image
         remapped_ref.parent_image = transact_ref
 
@@ -99,7 +110,7 @@ class Subtraction(HasWCS):
         submask.header = dict(sci.mask_image.header or {})
         submask.header_comments = dict(sci.mask_image.header_comments or {})
 
-        call = prepare_hotpants(sci, remapped_ref, final_out, submask.boolean, directory,
+        call = prepare_hotpants(transact_sci, remapped_ref, final_out, submask.boolean, directory,
                                 tmpdir=tmpdir, nreg_side=nreg_side,
                                 subtract_new_back=subtract_new_back,
                                 hotpants_kws=hotpants_kws)
