@@ -174,7 +174,10 @@ def launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's JSON line goes to stdout; whatever else a child library wrote there (gloo prints
+    # its connection banner on stdout) goes to stderr
+    for line in out.decode().splitlines():
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -372,6 +375,14 @@ def main():
     step()
     sync()
     eng.timing(False)
+    names = ['resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
+             'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
+             'hp_solve', 'hp_apply']
+    kt = {}
+    for nme in names:
+        ms, cnt = eng.timing_read(nme)
+        if cnt:
+            kt[nme] = {'ms_per_step': ms, 'launches_per_step': cnt, 'avg_us': 1e3 * ms / cnt}
     if sub.info.status != 0 and not args.no_subtract:
         print(f'rank {rank}: subtraction status {sub.info.status}', file=sys.stderr)
         sys.exit(3)
@@ -408,14 +419,6 @@ def main():
                                                  ref_rms, step, timed, 1e3 * dt / args.steps)
 
     if rank == 0:
-        names = ['resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
-                 'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
-                 'hp_solve', 'hp_apply']
-        kt = {}
-        for nme in names:
-            ms, cnt = eng.timing_read(nme)
-            if cnt:
-                kt[nme] = {'ms_per_step': ms, 'launches_per_step': cnt, 'avg_us': 1e3 * ms / cnt}
         dom = max(kt, key=lambda k: kt[k]['ms_per_step']) if kt else None
         if rs_cnt:      # the roofline kernel: from the timed region itself
             kt['resample'] = {'ms_per_step': rs_ms / args.steps, 'launches_per_step': rs_cnt // args.steps,

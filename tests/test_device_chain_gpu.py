@@ -140,8 +140,9 @@ def test_median_mad2_dev_is_numpy_median_twice(env):
     for k, (x, m) in enumerate(((a, ma), (b, mb))):
         s = x[m == 0]
         med = np.median(s)
-        mad = 1.4826 * np.median(np.abs(s - med))
-        assert out[2 * k] == float(med) and out[2 * k + 1] == float(mad)
+        # the reference ran on numpy 1.x, where float32 scalar * python float is a float64 product
+        mad = 1.4826 * float(np.median(np.abs(s - med)))
+        assert out[2 * k] == float(med) and out[2 * k + 1] == pytest.approx(mad, rel=1e-12, abs=0)
 
 
 # ---- (b), (c) the chains ------------------------------------------------------------------
@@ -269,14 +270,17 @@ def test_aligned_reference_mask_has_no_bit16_and_uncovered_pixels_count(chain, d
     uncovered = ds.ref_al_w.cpu().numpy() == 0
     assert 0.05 < uncovered.mean() < 0.3                  # the two strips
     refmask_al = ds.refmask_al.cpu().numpy()
-    assert not (refmask_al & (1 << 16)).any()
+    # bit 16 may arrive from the reference's own mask (its union grid has corners no input
+    # reaches); the alignment itself adds none: where the resampler found no data the mask is 0
+    assert (refmask_al[uncovered] == 0).all()
     assert not (submask[uncovered] & (1 << 16)).any()
+    assert (refmask_al & (1 << 16)).any() == (chain['ref'].mask_image.data & (1 << 16)).any()
     # zuds/hotpants.py:67: quick_background_estimate(ref) over mask == 0, zeros included
     r = ds.ref_al.cpu().numpy()
     s = r[refmask_al == 0]
     med = np.median(s)
-    mad = 1.4826 * np.median(np.abs(s - med))
-    assert ds.limits['tl'] == float(med) - 10 * float(mad)
+    mad = 1.4826 * float(np.median(np.abs(s - med)))
+    assert ds.limits['tl'] == pytest.approx(float(med) - 10 * mad, rel=1e-12, abs=0)
     assert (s == 0).sum() >= uncovered.sum() * 0.9
 
 

@@ -18,6 +18,8 @@
 // footprint (bounding box of the 10 tile nodes + kernel support) is staged in
 // LDS with 16-byte loads and read back as 8-byte {value, variance} pairs.
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 #include "zm_internal.h"
 #include "wcs_math.h"
@@ -287,7 +289,100 @@ __host__ __device__ inline void zm_lanczos3(float d, float t[6]) {
     for (int k = 0; k < 6; ++k) t[k] = tt[k].x;
 }
 
-extern "C" void zm_debug_lanczos3(float d, float* out6) { zm_lanczos3(d, out6); }
+// ---------------------------------------------------------------------------
+// Tabulated taps.  The evaluation above costs ~60 packed VALU instructions per pixel (both
+// axes), a third of the resample kernel's vector work, and that kernel is bound by vector
+// issue (tools/valu_rate.hip: v_pk_fma_f32 5.1, v_fma_f32 3.4 cycles per instruction and SIMD
+// at 4 waves per SIMD).  The six unit-sum taps are smooth functions of d, so the kernel reads
+// them from a table in LDS instead: LZ_N + 1 nodes d_i = i / LZ_N, per node and tap the
+// quadratic through the three Chebyshev points of [d_i - h/2, d_i + h/2] (h = 1 / LZ_N),
+//   t_k(d) ~ c0 + (d - d_i) (c1 + (d - d_i) c2),
+// 2.4e-7 from the exact taps at LZ_N = 64 (the direct fp32 evaluation: 1e-7; the parity
+// tolerance of the resampled pixels is 2e-5).  Neighbouring lanes look at the same or the
+// next node (d moves by ~1e-3 per output pixel), so the five 16-byte LDS reads of a lookup
+// are broadcasts.  The coefficients of taps (k, k + 1) sit side by side: one packed FMA
+// updates two taps.  Entry layout (20 floats):
+//   {c0_0 c0_1 c1_0 c1_1} {c2_0 c2_1 c0_2 c0_3} {c1_2 c1_3 c2_2 c2_3} {c0_4 c0_5 c1_4 c1_5} {c2_4 c2_5 - -}
+#define LZ_N 64
+#define LZ_ENTRY 20
+#define LZ_FLOATS ((LZ_N + 1) * LZ_ENTRY)
+
+static void lz3_exact(double d, double t[6]) {
+    const double PI = 3.14159265358979323846;
+    double sum = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double x = d - (double)(k - 2);
+        t[k] = (x == 0.0) ? PI * PI / 3.0 : sin(PI * x) * sin(PI * x / 3.0) / (x * x);
+        sum += t[k];
+    }
+    for (int k = 0; k < 6; ++k) t[k] /= sum;
+}
+
+// [LZ_N + 1][LZ_ENTRY] floats
+void zm_lanczos_table(float* tab) {
+    const double h = 1.0 / LZ_N, a = 0.5 * h * 0.86602540378443864676;
+    for (int i = 0; i <= LZ_N; ++i) {
+        double f0[6], fp[6], fm[6];
+        lz3_exact(i * h, f0);
+        lz3_exact(i * h + a, fp);
+        lz3_exact(i * h - a, fm);
+        float c0[6], c1[6], c2[6];
+        for (int k = 0; k < 6; ++k) {
+            c0[k] = (float)f0[k];
+            c1[k] = (float)((fp[k] - fm[k]) / (2 * a));
+            c2[k] = (float)((fp[k] - 2 * f0[k] + fm[k]) / (2 * a * a));
+        }
+        float* e = tab + (size_t)i * LZ_ENTRY;
+        const float v[LZ_ENTRY] = {c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], c0[2], c0[3], c1[2], c1[3],
+                                   c2[2], c2[3], c0[4], c0[5], c1[4], c1[5], c2[4], c2[5], 0.f, 0.f};
+        for (int q = 0; q < LZ_ENTRY; ++q) e[q] = v[q];
+    }
+}
+
+// t[j] = {tap 2j, tap 2j + 1}; tab: the table (LDS on the device), d in [SNAP, 1 - SNAP]
+__host__ __device__ inline void zm_lz3_lookup(const float* tab, float d, zm_v2f t[3]) {
+    const float fi = __builtin_rintf(d * (float)LZ_N);
+    const float dl = __builtin_fmaf(fi, -1.0f / LZ_N, d);          // exact: fi / LZ_N is a dyadic rational
+    const float4* e = reinterpret_cast<const float4*>(tab) + 5 * (int)fi;
+    const float4 a = e[0], b = e[1], c = e[2], g = e[3], h = e[4];
+    const zm_v2f dd = (zm_v2f){dl, dl};
+    t[0] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){b.x, b.y}, (zm_v2f){a.z, a.w}),
+                                     (zm_v2f){a.x, a.y});
+    t[1] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){c.z, c.w}, (zm_v2f){c.x, c.y}),
+                                     (zm_v2f){b.z, b.w});
+    t[2] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){h.x, h.y}, (zm_v2f){g.z, g.w}),
+                                     (zm_v2f){g.x, g.y});
+}
+
+// the table in device memory (one per context, filled on first use)
+int zm_get_lanczos_table(zm_ctx* ctx, const float** out) {
+    float* dev = nullptr;
+    auto it = ctx->scratch.find("lz3_table");
+    if (it != ctx->scratch.end()) {
+        *out = (const float*)it->second.first;
+        return 0;
+    }
+    ZM_TRY(ctx->get("lz3_table", sizeof(float) * LZ_FLOATS, (void**)&dev));
+    std::vector<float> host(LZ_FLOATS);
+    zm_lanczos_table(host.data());
+    ZM_HIP(hipMemcpy(dev, host.data(), sizeof(float) * LZ_FLOATS, hipMemcpyHostToDevice));   // blocking, once
+    *out = dev;
+    return 0;
+}
+
+// what the kernels evaluate (table path), on the host: tests/test_abi.py pins it to the oracle
+extern "C" void zm_debug_lanczos3(float d, float* out6) {
+    static std::vector<float> tab;
+    if (tab.empty()) {
+        tab.resize(LZ_FLOATS);
+        zm_lanczos_table(tab.data());
+    }
+    zm_v2f t[3];
+    zm_lz3_lookup(tab.data(), d, t);
+    for (int k = 0; k < 6; ++k) out6[k] = (k & 1) ? t[k >> 1].y : t[k >> 1].x;
+}
+// the direct evaluation (the nearest / fallback paths and the record of what the table replaced)
+extern "C" void zm_debug_lanczos3_direct(float d, float* out6) { zm_lanczos3(d, out6); }
 
 // floor / fraction with the snap rule of oracle/resample.py::split_position
 __device__ inline void split_pos(float p, int* i, float* d, bool* delta) {
@@ -653,10 +748,13 @@ __global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
     const int32_t* __restrict__ mask, const uint16_t* __restrict__ mbox, int32_t* __restrict__ macc,
-    int mkind, int mfirst, int ntx, int ntiles) {
+    int mkind, int mfirst, int ntx, int ntiles, const float* __restrict__ taptab) {
     extern __shared__ float4 smem4[];
     rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
-    float2* tile = reinterpret_cast<float2*>(smem4) + HDR_FLOATS / 2;
+    // Lanczos-3: the tap table sits between the headers and the pixel tile
+    constexpr int TABF = (KIND == ZM_RESAMPLE_LANCZOS3) ? LZ_FLOATS : 0;
+    const float* ltab = reinterpret_cast<const float*>(smem4) + HDR_FLOATS;
+    float2* tile = reinterpret_cast<float2*>(smem4) + (HDR_FLOATS + TABF) / 2;
     constexpr int NT = taps_traits<KIND>::N;
     constexpr int OFF = taps_traits<KIND>::OFF;
     constexpr int CI = -OFF;                                       // tap index of a delta kernel
@@ -698,6 +796,10 @@ __global__ __launch_bounds__(256, 4) void k_resample(
 
     int t = blockIdx.x;
     if (t >= ntiles) return;
+    if (KIND == ZM_RESAMPLE_LANCZOS3) {
+        for (int e = tid; e < LZ_FLOATS / 4; e += 256)
+            smem4[HDR_FLOATS / 4 + e] = reinterpret_cast<const float4*>(taptab)[e];
+    }
     if (tid < 64) {
         rs_build_header<KIND>(lat, lnx, lny, t, ntx, nx, ny, lds_cap, &HR[0]);
         if (t + G < ntiles) rs_build_header<KIND>(lat, lnx, lny, t + G, ntx, nx, ny, lds_cap, &HR[1]);
@@ -788,9 +890,29 @@ __global__ __launch_bounds__(256, 4) void k_resample(
                         }
                     }
                 }
-                zm_v2f tw[NT];
-                make_taps2<KIND>(dx, dy, ddx, ddy, tw);
+                zm_v2f tw[NT];                     // tw[k] = {x tap k, y tap k}
                 float acc = 0.f, vacc = 0.f;
+                if (KIND == ZM_RESAMPLE_LANCZOS3) {
+                    // taps from the LDS table, two per register pair: txp[j] = {x tap 2j, x tap 2j + 1}
+                    zm_v2f txp[3], typ[3];
+                    zm_lz3_lookup(ltab, ddx ? 0.5f : dx, txp);
+                    zm_lz3_lookup(ltab, ddy ? 0.5f : dy, typ);
+                    // delta kernels are rare (aligned grids): patch them under a wave-uniform test
+                    if (__any(ddx || ddy)) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const zm_v2f dl = (zm_v2f){j == 1 ? 1.f : 0.f, 0.f};
+                            txp[j] = ddx ? dl : txp[j];
+                            typ[j] = ddy ? dl : typ[j];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        tw[k] = (zm_v2f){(k & 1) ? txp[k >> 1].y : txp[k >> 1].x,
+                                         (k & 1) ? typ[k >> 1].y : typ[k >> 1].x};
+                } else {
+                    make_taps2<KIND>(dx, dy, ddx, ddy, tw);
+                }
                 if (use_lds) {
                     const float2* p = tile + (iyr + OFF) * bw + (ixr + OFF);
                     zm_v2f av = (zm_v2f){0.f, 0.f};     // {value, variance} accumulators
@@ -909,18 +1031,23 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
         }
         ctx->box_ready_for = nullptr;
     }
+    const float* taptab = nullptr;
+    if (KIND == ZM_RESAMPLE_LANCZOS3) {
+        ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
+        shmem += sizeof(float) * LZ_FLOATS;
+    }
     zm_scope_timer t(ctx, "resample");
     // persistent grid: a few workgroups per CU, each walking ntiles / G tiles
     dim3 pgrd(std::min(ntiles, 256 * 4), 1, 1);
     if (mop == 0)
         hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
     else if (mop == 1)
         hipLaunchKernelGGL((k_resample<KIND, 1>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
     else
         hipLaunchKernelGGL((k_resample<KIND, 2>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
     ZM_HIP(hipGetLastError());
     return 0;
 }
