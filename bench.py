@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
 VALU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: max shader clock
-PMC_PROFILES = ['r02_pmc_resample.json', 'r01_pmc_resample.json']     # newest first
+PMC_PROFILES = ['r02_pmc_coadd_fused.json', 'r02_pmc_resample.json', 'r01_pmc_resample.json']     # newest first
 
 
 def parse():
@@ -89,16 +89,18 @@ def make_device_frames(synth, torch, n, size, seed0, device):
     return base, frames
 
 
-def pmc_profile(args):
-    """Counter figures per k_resample launch from the committed rocprofv3 --pmc passes
+def pmc_profile(args, kernel):
+    """Counter figures per launch of the roofline kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; SQ_INSTS_VALU); {} when
-    no committed profile matches this workload."""
+    no committed profile matches this kernel and workload."""
     for name in PMC_PROFILES:
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
         except (OSError, ValueError):
             continue
-        if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask):
+        if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask) and \
+                d.get('kernel', '').split('<')[0] == kernel.split('<')[0] and \
+                d.get('frames', args.frames) == args.frames:
             return d
     return {}
 
@@ -365,17 +367,21 @@ def main():
     # Timed region: only the roofline kernel carries HIP-event timers (two event records per
     # launch cost dispatch latency: 0.7 ms per step with every scope timed).  The per-kernel
     # table comes from one more, untimed-for-throughput step with every scope timed.
-    eng.timing(True, only='resample')
+    # WEIGHTED / AVERAGE stacks run the fused kernel (frames looped inside the output tile);
+    # CLIPPED / MEDIAN materialise the stack through k_resample
+    fused = sum_type and os.environ.get('ZM_COADD_FUSED', '1') != '0'
+    roof_scope = 'coadd_fused' if fused else 'resample'
+    eng.timing(True, only=roof_scope)
     eng.timing_reset()
     dt = timed(step, args.steps)
     eng.timing(False)
-    rs_ms, rs_cnt = eng.timing_read('resample')
+    rs_ms, rs_cnt = eng.timing_read(roof_scope)
     eng.timing_reset()
     eng.timing(True)
     step()
     sync()
     eng.timing(False)
-    names = ['resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
+    names = ['coadd_fused', 'resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
              'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
              'hp_solve', 'hp_apply']
     kt = {}
@@ -421,27 +427,39 @@ def main():
     if rank == 0:
         dom = max(kt, key=lambda k: kt[k]['ms_per_step']) if kt else None
         if rs_cnt:      # the roofline kernel: from the timed region itself
-            kt['resample'] = {'ms_per_step': rs_ms / args.steps, 'launches_per_step': rs_cnt // args.steps,
+            kt[roof_scope] = {'ms_per_step': rs_ms / args.steps, 'launches_per_step': rs_cnt // args.steps,
                               'avg_us': 1e3 * rs_ms / rs_cnt}
+            if not fused:
+                # (the 'resample' scope also holds the two align launches of the subtraction)
+                pass
         roofline = None
-        if 'resample' in kt:
-            avg_s = kt['resample']['avg_us'] * 1e-6
-            bpp = RESAMPLE_BYTES_PER_OUTPX + (0 if args.no_mask else MASK_BYTES_PER_OUTPX)
-            bytes_per_launch = bpp * args.size * args.size
+        if roof_scope in kt:
+            avg_s = kt[roof_scope]['avg_us'] * 1e-6
+            m = 0 if args.no_mask else 1
+            if fused:
+                # SURVEY.md 8(d), fused resample -> WEIGHTED coadd: 8 B per input pixel + 8 B per
+                # output pixel per stack; int32 masks riding along: + 4 B in per input pixel,
+                # + 4 B out per stack
+                bytes_per_launch = (args.frames * (8 + 4 * m) + (8 + 4 * m)) * npx
+                kname = 'k_coadd_fused<LANCZOS3' + (', mask coadd>' if m else '>')
+                units = f'{args.frames} frames x {args.size}^2 px per launch'
+            else:
+                bytes_per_launch = (RESAMPLE_BYTES_PER_OUTPX + MASK_BYTES_PER_OUTPX * m) * npx
+                kname = 'k_resample<LANCZOS3' + (', mask fused>' if m else '>')
+                units = f'1 frame x {args.size}^2 px per launch'
             ach = bytes_per_launch / avg_s / 1e9
-            pmc = pmc_profile(args)
-            roofline = {'bound': 'hbm',
-                        'kernel': 'k_resample<LANCZOS3, mask fused>' if not args.no_mask
-                        else 'k_resample<LANCZOS3>',
+            pmc = pmc_profile(args, kname)
+            roofline = {'bound': 'hbm', 'kernel': kname, 'units_per_launch': units,
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch'),
-                        'avg_launch_us': kt['resample']['avg_us'],
+                        'avg_launch_us': kt[roof_scope]['avg_us'],
+                        'us_per_frame': kt[roof_scope]['avg_us'] / (args.frames if fused else 1),
                         'algorithmic_bytes_per_launch': bytes_per_launch,
                         'dominant_by_time': dom}
             # the limit this kernel actually runs into is vector issue, not HBM: VALU
-            # instructions per launch from the committed SQ_INSTS_VALU pass x issue cycles
-            # (MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2
-            # cycles, packed fp32 for 4 - tools/valu_rate.hip) over the SIMD-cycles of the launch
+            # instructions per launch from the committed SQ_INSTS_VALU pass x measured issue
+            # cycles (tools/valu_rate.hip on MI355X at 4 waves per SIMD: v_pk_*_f32 5.1,
+            # other VALU 3.4 cycles per instruction and SIMD) over the SIMD-cycles of the launch
             if pmc.get('valu_cycles_per_launch'):
                 simd_cycles = avg_s * VALU_CLOCK_HZ * 256 * 4
                 roofline['valu_frac'] = pmc['valu_cycles_per_launch'] / simd_cycles

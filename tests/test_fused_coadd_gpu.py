@@ -1,0 +1,177 @@
+"""The fused resample -> WEIGHTED / AVERAGE coadd kernel (frames looped inside the output
+tile, running sums in registers: k_coadd_fused) against the materialised path it replaces
+(resampled stack in HBM + k_combine_sum, selected with ZM_COADD_FUSED=0): bit-identical
+coadd, weight, mask coadd and coverage - the sums run in the same order with the same
+operations - for full coadds and for the partial sums of a multi-GPU stack, on interior
+tiles (fast items), edge tiles, aligned grids (delta kernels), rotated / rescaled frames
+whose footprint exceeds the LDS tile, masks with bits above 15, frames without masks and
+frames that miss the grid altogether.  The materialised path itself is pinned to the oracle
+in test_coadd_gpu.py / test_resample_gpu.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from util import pkg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(engine, frames, wout, p, want_mask=True):
+    out = {}
+    for mode in ('0', '1'):
+        os.environ['ZM_COADD_FUSED'] = mode
+        try:
+            out[mode] = engine.coadd(frames, wout, p, want_mask=want_mask)
+        finally:
+            os.environ.pop('ZM_COADD_FUSED', None)
+    return out['0'], out['1']
+
+
+def assert_same(a, b):
+    for x, y, name in zip(a, b, ('img', 'wgt', 'mask', 'mask coverage')):
+        assert (x is None) == (y is None), name
+        if x is not None:
+            assert np.array_equal(x, y, equal_nan=True), \
+                f'{name}: {(x != y).sum()} of {x.size} pixels differ'
+
+
+def stack(n, nx, ny, seed, dither=8.0, rot=0.1, tpv=True, nbad=200, scale_jitter=0.0):
+    s = synth()
+    base = s.ztf_wcs(nx, ny, tpv=tpv)
+    rng = np.random.default_rng(seed)
+    xs, ys = rng.uniform(5, nx - 5, 60), rng.uniform(5, ny - 5, 60)
+    fl = np.exp(rng.uniform(np.log(2e3), np.log(5e4), 60))
+    ra, dec = base.all_pix2world(xs, ys, 0)
+    frames = []
+    for i in range(n):
+        w = s.ztf_wcs(nx, ny, dx=rng.uniform(-dither, dither), dy=rng.uniform(-dither, dither),
+                      rot_deg=rng.uniform(-rot, rot), tpv=tpv)
+        if scale_jitter:
+            w.cd = np.asarray(w.cd) * (1.0 + rng.uniform(-scale_jitter, scale_jitter))
+        frames.append(s.make_frame(nx, ny, seed + i, w, star_sky=(ra, dec, fl), sky=rng.uniform(100, 300),
+                                   magzp=rng.uniform(25.5, 26.5), nbad=nbad))
+    return frames, base
+
+
+@pytest.mark.parametrize('kind', ['WEIGHTED', 'AVERAGE'])
+@pytest.mark.parametrize('mask_kind', ['AND', 'OR'])
+def test_fused_equals_materialised_with_background_and_rescale(engine, kind, mask_kind):
+    z = pkg()
+    frames, wout = stack(6, 700, 650, 100)
+    p = z.coadd_params(combine=kind, mask_combine=mask_kind, subtract_back=True, rescale_weights=True,
+                       back_size=128)
+    a, b = run_both(engine, frames, wout, p)
+    assert_same(a, b)
+    assert (b[1] > 0).mean() > 0.9 and (b[3] == 0).any()
+    if mask_kind == 'OR':
+        assert (b[2] != 0).any()
+
+
+def test_union_grid_edge_tiles_and_frames_that_miss_tiles(engine):
+    z = pkg()
+    frames, _ = stack(5, 520, 480, 200, dither=60.0, rot=0.3)
+    wout = engine.autogrid([f['wcs'] for f in frames])
+    assert wout.naxis[0] > 560
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, wout, p)
+    assert_same(a, b)
+    # a frame entirely off the grid contributes nothing and breaks nothing
+    s = synth()
+    far = dict(frames[0], wcs=s.ztf_wcs(520, 480, dx=5000.0, dy=-4000.0))
+    a, b = run_both(engine, frames + [far], wout, p)
+    assert_same(a, b)
+
+
+def test_aligned_grids_take_the_delta_kernel_path(engine):
+    z = pkg()
+    s = synth()
+    frames, base = stack(3, 400, 380, 300, dither=0.0, rot=0.0)
+    frames[1]['wcs'] = s.ztf_wcs(400, 380, dx=-7.0, dy=3.0)           # integer shift
+    frames[2]['wcs'] = s.ztf_wcs(400, 380, dx=2.5, dy=0.0)            # delta in y only
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+    inner = (slice(12, -12), slice(12, -12))
+    assert (b[1][inner] > 0).mean() > 0.97
+
+
+def test_large_footprints_fall_back_to_the_global_gather(engine):
+    z = pkg()
+    frames, base = stack(3, 420, 400, 400, rot=0.2)
+    for f, k in zip(frames, (1.0, 2.6, 0.45)):                  # finer / coarser output sampling
+        f['wcs'].cd = np.asarray(f['wcs'].cd) * k
+    frames[1]['wcs'] = synth().ztf_wcs(420, 400, rot_deg=33.0)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+
+
+def test_high_mask_bits_missing_masks_and_no_masks(engine):
+    z = pkg()
+    frames, base = stack(4, 450, 430, 500)
+    frames[0]['mask'][100:140, 200:260] |= 1 << 16
+    frames[1]['mask'][300:310, 50:90] |= (1 << 17) | 0xffff
+    frames[2]['mask'][20:23, 400:403] = 0xffff
+    p = z.coadd_params(combine='WEIGHTED', mask_combine='OR', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+    assert (b[2] >> 16).any()
+    some = [dict(f) for f in frames]
+    some[1]['mask'] = None                                       # this frame does not enter the mask coadd
+    a, b = run_both(engine, some, base, p)
+    assert_same(a, b)
+    none = [dict(f, mask=None) for f in frames]
+    a, b = run_both(engine, none, base, p, want_mask=False)
+    assert_same(a, b)
+
+
+def test_partial_sums_and_single_frame(engine):
+    """zm_coadd_dev(partial = 1): S1, S0 and the mask with its -1 markers, as the multi-GPU
+    reduce consumes them; and a stack of one."""
+    import torch
+    z = pkg()
+    dmod = __import__('importlib').import_module('zuds-pipeline_amd.device')
+    frames, base = stack(4, 500, 470, 600)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True)
+    res = {}
+    for mode in ('0', '1'):
+        os.environ['ZM_COADD_FUSED'] = mode
+        try:
+            dc = dmod.DeviceCoadd(base, p, device=0, engine=engine, want_mask=True)
+            dfr = dmod.DeviceFrames(frames, dc.device)
+            dc.run(dfr, partial=True)
+            dc.stream.synchronize()
+            res[mode] = [t.cpu().numpy() for t in (dc.img, dc.wgt, dc.mask)]
+        finally:
+            os.environ.pop('ZM_COADD_FUSED', None)
+            engine.set_stream(0)
+    for x, y in zip(res['0'], res['1']):
+        assert np.array_equal(x, y)
+    assert (res['1'][2] == -1).any() and (res['1'][2] != -1).any()
+    a, b = run_both(engine, frames[:1], base, z.coadd_params(combine='AVERAGE', subtract_back=False,
+                                                             rescale_weights=False))
+    assert_same(a, b)
+
+
+def test_fullsize_stack_fused_equals_materialised(engine):
+    """BASELINE config[1] geometry at full size (3072 x 3072, TPV, +-15 px, +-0.1 deg), 4 frames."""
+    z = pkg()
+    s = synth()
+    nx = ny = 3072
+    rng = np.random.default_rng(7)
+    base = s.ztf_wcs(nx, ny, tpv=True)
+    frames = []
+    for i in range(4):
+        w = s.ztf_wcs(nx, ny, dx=rng.uniform(-15, 15), dy=rng.uniform(-15, 15), rot_deg=rng.uniform(-0.1, 0.1))
+        img = rng.normal(200.0, 6.0, (ny, nx)).astype(np.float32)
+        mask = np.zeros((ny, nx), np.int32)
+        bad = rng.integers(0, nx * ny, 9000)
+        mask.ravel()[bad] = rng.choice([1, 256, 2, 2048], bad.size)
+        wgt = np.where((mask & 198589) > 0, 0.0, 1.0 / 36.0).astype(np.float32)
+        frames.append(dict(img=img, wgt=wgt, mask=mask, wcs=w, flxscale=0.3 + 0.05 * i))
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+    assert (b[1] > 0).mean() > 0.98

@@ -3,6 +3,7 @@
 // runs the device flavour on the ctx stream and copies the products back.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "zm_internal.h"
 #include "wcs_math.h"
@@ -47,7 +48,7 @@ static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
             wmax = std::max(wmax, fabs(x1 - x0) + fabs(x2 - x0));
             hmax = std::max(hmax, fabs(y1 - y0) + fabs(y2 - y0));
         }
-    double w = ceil(wmax * 1.02) + ntaps + 6, h = ceil(hmax * 1.02) + ntaps + 5;
+    double w = ceil(wmax * 1.02) + ntaps + 9, h = ceil(hmax * 1.02) + ntaps + 5;   // + box alignment (4 px)
     double e = w * h;
     const int cap = 8000;   // 64,000 B + header < 64 KiB: no opt-in attribute needed
     if (!(e > 0) || e > cap) return cap;
@@ -56,6 +57,56 @@ static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
 
 static int ntaps_of(int kernel) {
     return kernel == ZM_RESAMPLE_LANCZOS3 ? 6 : kernel == ZM_RESAMPLE_BILINEAR ? 2 : 1;
+}
+
+struct bk_plan {
+    float* vs_all = nullptr;      // per frame: 4 floats, [0] = variance scale (RESCALE_WEIGHTS)
+    int nslot = 1;                // meshes of the largest frame: the scratch slot of every frame
+};
+
+static bool frame_has_bk(const zm_coadd_params* P, const zm_dframe* fr, int i) {
+    return P->subtract_back || (P->rescale_weights && fr[i].wgt);
+}
+static int frame_nmode(const zm_coadd_params* P, const zm_dframe* fr, int i) {
+    return (P->rescale_weights && fr[i].wgt) ? 2 : 1;
+}
+
+// Phase 1 of a stack: mesh statistics, filter and variance rescale of every frame, batched over
+// runs of equally sized frames (one launch each per run instead of one per frame: the
+// statistics grid of a single 3072^2 frame is 1152 workgroups against 1024 resident, and
+// every per-frame launch costs a ~10 us gap).
+// (Tried on MI355X and dropped: the filter / lattices on a second stream pipelined
+// against the neighbouring frames - foreign workgroups on its CUs stretch the statically
+// partitioned persistent resample kernel by a quarter.)
+static int frames_background(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_coadd_params* P, bk_plan* bp) {
+    const float wthresh = (float)P->weight_thresh;
+    ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&bp->vs_all));
+    int nslot = 1;
+    for (int i = 0; i < n; ++i)
+        nslot = std::max(nslot, ((fr[i].wcs.naxis[0] - 1) / std::max(P->back_size, 1) + 1) *
+                                    ((fr[i].wcs.naxis[1] - 1) / std::max(P->back_size, 1) + 1));
+    bp->nslot = nslot;
+    for (int i0 = 0; i0 < n;) {
+        if (!frame_has_bk(P, fr, i0)) { ++i0; continue; }
+        int i1 = i0 + 1;
+        while (i1 < n && frame_has_bk(P, fr, i1) && frame_nmode(P, fr, i1) == frame_nmode(P, fr, i0) &&
+               fr[i1].wcs.naxis[0] == fr[i0].wcs.naxis[0] && fr[i1].wcs.naxis[1] == fr[i0].wcs.naxis[1])
+            ++i1;
+        const int nf = i1 - i0, nx = fr[i0].wcs.naxis[0], ny = fr[i0].wcs.naxis[1], nmode = frame_nmode(P, fr, i0);
+        std::vector<const float*> imgs(nf), wgts(nf);
+        for (int f = 0; f < nf; ++f) { imgs[f] = fr[i0 + f].img; wgts[f] = fr[i0 + f].wgt; }
+        ZM_TRY(zm_batch_stats(ctx, nf, imgs.data(), wgts.data(), nx, ny, P->back_size, wthresh, 0, nmode,
+                              "cbk", i0, n, nslot));
+        ZM_TRY(zm_batch_filter(ctx, nf, nx, ny, P->back_size, P->back_filtersize, nmode, "cbk", i0, n, nslot));
+        if (nmode == 2) {
+            float *nodes = nullptr, *bstats = nullptr;
+            int nbx = 0, nby = 0;
+            ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i0, n, nslot, &nodes, &bstats, &nbx, &nby));
+            ZM_TRY(zm_batch_var_scale(ctx, nf, bstats, bp->vs_all + 4 * (size_t)i0));
+        }
+        i0 = i1;
+    }
+    return 0;
 }
 
 // Resample nframes device frames onto `wout` into `stack` (float2 [n][ony*onx]).
@@ -69,47 +120,19 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
 
     for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
 
-    // Phase 1: mesh statistics, filter and variance rescale of every frame, batched over runs
-    // of equally sized frames (one launch each per run instead of one per frame: the
-    // statistics grid of a single 3072^2 frame is 1152 workgroups against 1024 resident, and
-    // every per-frame launch costs a ~10 us gap).  Phase 2: prep + resample, frame by frame.
-    // (Tried on MI355X and dropped: the filter / lattices on a second stream pipelined
-    // against the neighbouring frames - foreign workgroups on its CUs stretch the statically
-    // partitioned persistent resample kernel by a quarter.)
+    // Phase 1: background statistics of every frame (batched).  Phase 2: prep + resample, frame by frame.
     // everything older on the main stream (the resamples of a previous call read the lattice
     // buffer): the lattices of this call may start once that has drained
     hipEvent_t* evs = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 5, &evs));
+    ZM_TRY(zm_get_sync_events(ctx, 6, &evs));
     ZM_HIP(hipEventRecord(evs[3], ctx->stream));
     const float wthresh = (float)P->weight_thresh;
-    float* vs_all = nullptr;
-    ZM_TRY(ctx->get("var_scale", sizeof(float) * 4 * (size_t)n, (void**)&vs_all));
-    auto has_bk = [&](int i) { return P->subtract_back || (P->rescale_weights && fr[i].wgt); };
-    auto nmode_of = [&](int i) { return (P->rescale_weights && fr[i].wgt) ? 2 : 1; };
-    int nslot = 1;                       // meshes of the largest frame: the scratch slot of every frame
-    for (int i = 0; i < n; ++i)
-        nslot = std::max(nslot, ((fr[i].wcs.naxis[0] - 1) / std::max(P->back_size, 1) + 1) *
-                                    ((fr[i].wcs.naxis[1] - 1) / std::max(P->back_size, 1) + 1));
-    for (int i0 = 0; i0 < n;) {
-        if (!has_bk(i0)) { ++i0; continue; }
-        int i1 = i0 + 1;
-        while (i1 < n && has_bk(i1) && nmode_of(i1) == nmode_of(i0) &&
-               fr[i1].wcs.naxis[0] == fr[i0].wcs.naxis[0] && fr[i1].wcs.naxis[1] == fr[i0].wcs.naxis[1])
-            ++i1;
-        const int nf = i1 - i0, nx = fr[i0].wcs.naxis[0], ny = fr[i0].wcs.naxis[1], nmode = nmode_of(i0);
-        std::vector<const float*> imgs(nf), wgts(nf);
-        for (int f = 0; f < nf; ++f) { imgs[f] = fr[i0 + f].img; wgts[f] = fr[i0 + f].wgt; }
-        ZM_TRY(zm_batch_stats(ctx, nf, imgs.data(), wgts.data(), nx, ny, P->back_size, wthresh, 0, nmode,
-                              "cbk", i0, n, nslot));
-        ZM_TRY(zm_batch_filter(ctx, nf, nx, ny, P->back_size, P->back_filtersize, nmode, "cbk", i0, n, nslot));
-        if (nmode == 2) {
-            float *nodes = nullptr, *bstats = nullptr;
-            int nbx = 0, nby = 0;
-            ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i0, n, nslot, &nodes, &bstats, &nbx, &nby));
-            ZM_TRY(zm_batch_var_scale(ctx, nf, bstats, vs_all + 4 * (size_t)i0));
-        }
-        i0 = i1;
-    }
+    bk_plan bp;
+    ZM_TRY(frames_background(ctx, n, fr, P, &bp));
+    float* vs_all = bp.vs_all;
+    const int nslot = bp.nslot;
+    auto has_bk = [&](int i) { return frame_has_bk(P, fr, i); };
+    auto nmode_of = [&](int i) { return frame_nmode(P, fr, i); };
     // The maps, flux scales and LDS plans are host work (fp64 TPV inversions): done here, while
     // the GPU runs phase 1, not before the first launch.
     std::vector<zm_map_params> mp_host(n);
@@ -153,6 +176,83 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     return 0;
 }
 
+
+// WEIGHTED / AVERAGE stacks with a Lanczos-3 kernel: every frame is prepped into its own plane
+// (N x 75 MB at 3072^2: the place the resampled stack took before), then ONE launch loops the
+// frames inside each output tile (k_coadd_fused, resample.hip).
+static bool fused_ok(const zm_coadd_params* P) {
+    // ZM_COADD_FUSED=0 takes the materialised path (resampled stack + k_combine_sum): the
+    // reference the fused kernel is tested against bit for bit (tests/test_coadd_gpu.py)
+    const char* e = getenv("ZM_COADD_FUSED");
+    const bool off = e && e[0] == '0';
+    return !off && P->resample == ZM_RESAMPLE_LANCZOS3 &&
+           (P->combine == ZM_COMBINE_WEIGHTED || P->combine == ZM_COMBINE_AVERAGE);
+}
+
+static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
+                       int partial, float* out_img, float* out_wgt, int32_t* out_mask, float* out_cov) {
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
+    for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
+    hipEvent_t* evs = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 6, &evs));
+    ZM_HIP(hipEventRecord(evs[3], ctx->stream));
+    const float wthresh = (float)P->weight_thresh;
+    bk_plan bp;
+    ZM_TRY(frames_background(ctx, n, fr, P, &bp));
+    std::vector<zm_map_params> mp_host(n);
+    std::vector<zm_ff> ff(n);
+    int lds = 0;
+    size_t prep_bytes = 0, box_bytes = 0;
+    std::vector<size_t> prep_off(n), box_off(n);
+    bool any_mask = false;
+    for (int i = 0; i < n; ++i) {
+        const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1], spitch = (nx + 1) & ~1;
+        zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
+        double fs = 1.0;
+        ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
+        lds = std::max(lds, plan_lds(&mp_host[i], onx, ony, 6));
+        prep_off[i] = prep_bytes;
+        prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
+        box_off[i] = box_bytes;
+        const bool with_mask = out_mask && fr[i].mask;
+        if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)nx * ny) + 255) & ~(size_t)255;
+        any_mask |= with_mask;
+        memset(&ff[i], 0, sizeof(zm_ff));
+        ff[i].nx = nx; ff[i].ny = ny; ff[i].spitch = spitch;
+        ff[i].fscale = (float)fs;
+        ff[i].fscale2 = (float)fs * (float)fs;
+        ff[i].mask = with_mask ? fr[i].mask : nullptr;
+    }
+    double2* lat = nullptr;
+    char *prep_all = nullptr, *box_all = nullptr;
+    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
+    ZM_TRY(ctx->get("prep_all", prep_bytes, (void**)&prep_all));
+    if (box_bytes) ZM_TRY(ctx->get("mask_box_all", box_bytes, (void**)&box_all));
+    ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat, evs[3]));
+    for (int i = 0; i < n; ++i) {
+        const int nx = ff[i].nx, ny = ff[i].ny;
+        float *bknodes = nullptr, *vscale = nullptr;
+        int nbx = 0, nby = 0;
+        if (frame_has_bk(P, fr, i)) {
+            float *nodes = nullptr, *bstats = nullptr;
+            ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i, n, bp.nslot, &nodes, &bstats, &nbx, &nby));
+            if (frame_nmode(P, fr, i) == 2) vscale = bp.vs_all + 4 * (size_t)i;
+            if (P->subtract_back) bknodes = nodes;
+        }
+        float2* src = (float2*)(prep_all + prep_off[i]);
+        uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
+        ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size, vscale,
+                              wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox));
+        ff[i].src = src;
+        ff[i].mbox = mbox;
+        ff[i].lat = lat + (size_t)i * lnx * lny;
+    }
+    return zm_launch_coadd_fused(ctx, ff.data(), n, lnx, lny, onx, ony, lds, P->combine, P->mask_combine,
+                                 out_img, out_wgt, (out_mask && any_mask) ? out_mask : nullptr, out_cov, partial,
+                                 out_mask && !any_mask ? out_mask : nullptr);
+}
+
 extern "C" int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
                                      const zm_wcs* wout, const zm_coadd_params* params,
                                      float* stack, int32_t* out_mask_partial) {
@@ -184,6 +284,8 @@ extern "C" int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
     ZM_HIP(hipSetDevice(ctx->device));
     ZM_TRY(check_wcs(wout, "output grid"));
     const int64_t opix = (int64_t)wout->naxis[0] * wout->naxis[1];
+    if (fused_ok(params))
+        return coadd_fused(ctx, nframes, frames, wout, params, partial, out_img, out_wgt, out_mask, out_mask_wgt);
     float2* stack = nullptr;
     ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix * nframes, (void**)&stack));
     ZM_TRY(resample_frames(ctx, nframes, frames, wout, params, stack, out_mask, -1,

@@ -19,6 +19,8 @@
 // LDS with 16-byte loads and read back as 8-byte {value, variance} pairs.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "zm_internal.h"
@@ -470,7 +472,15 @@ struct tile_hdr3 {
     int bx0, by0, bw, bh;
 };
 
-__device__ inline void build_tile_header3(const double2* __restrict__ lat, int lnx, int lny,
+__device__ inline double2 zm_lat_load(const double2* p) { return *p; }
+__device__ inline double2 zm_lat_load(const double2 __attribute__((address_space(1)))* p) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = *(const v2d __attribute__((address_space(1)))*)p;
+    return make_double2(v.x, v.y);
+}
+
+template <typename LatPtr>
+__device__ inline void build_tile_header3(LatPtr lat, int lnx, int lny,
                                           int cx0, int cy0, int support_lo, int support_hi,
                                           tile_hdr3* h) {
     // executed by the first wave; lanes 0..14 own one node each
@@ -480,7 +490,7 @@ __device__ inline void build_tile_header3(const double2* __restrict__ lat, int l
     double2 nd = make_double2(0.0, 0.0);
     double mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
     if (lane < 15) {
-        nd = lat[(size_t)ngy * lnx + ngx];
+        nd = zm_lat_load(lat + ((size_t)ngy * lnx + ngx));
         mnx = mxx = nd.x;
         mny = mxy = nd.y;
     }
@@ -493,11 +503,13 @@ __device__ inline void build_tile_header3(const double2* __restrict__ lat, int l
     }
     mnx = fmax(fmin(mnx, 1e8), -1e8); mxx = fmax(fmin(mxx, 1e8), -1e8);
     mny = fmax(fmin(mny, 1e8), -1e8); mxy = fmax(fmin(mxy, 1e8), -1e8);
-    int bx0 = ((int)floor(mnx) + support_lo - 1) & ~1;
+    // the box starts on a multiple of 4 pixels and is a multiple of 4 wide: rows of the prepped
+    // plane start 32-byte aligned, rows of the 16-bit box-OR plane 8-byte aligned
+    int bx0 = ((int)floor(mnx) + support_lo - 1) & ~3;
     int by0 = (int)floor(mny) + support_lo - 1;
     int bx1 = (int)floor(mxx) + support_hi + 2;
     int by1 = (int)floor(mxy) + support_hi + 2;
-    int bw = (bx1 - bx0 + 2) & ~1;
+    int bw = (bx1 - bx0 + 4) & ~3;
     int bh = by1 - by0 + 1;
     if (lane < 15) {
         h->nrel[lane / 5][lane % 5][0] = (float)(nd.x - bx0);
@@ -715,13 +727,14 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
 // "mask_box" scratch plane for the zm_launch_resample call that follows
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh, const float* var_scale_dev,
-                   float wthresh, float2* dst, int spitch, const int32_t* mask_for_box, int box_nt) {
+                   float wthresh, float2* dst, int spitch, const int32_t* mask_for_box, int box_nt,
+                   uint16_t* mbox_out) {
     const float invmesh = mesh > 0 ? 1.0f / mesh : 0.f;
     const int vec_ok = (nx % 4 == 0) && (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
     ctx->box_ready_for = nullptr;
     if (mask_for_box && (box_nt == 6 || box_nt == 2)) {
-        uint16_t* mbox = nullptr;
-        ZM_TRY(ctx->get("mask_box", sizeof(uint16_t) * (size_t)nx * ny, (void**)&mbox));
+        uint16_t* mbox = mbox_out;      // caller's plane (fused coadd: one per frame) or the ctx scratch
+        if (!mbox) ZM_TRY(ctx->get("mask_box", sizeof(uint16_t) * (size_t)nx * ny, (void**)&mbox));
         dim3 grd(zm_div_up(spitch, 64), zm_div_up(ny, 16), 1);
         zm_scope_timer t(ctx, "prep");
         if (box_nt == 6)
@@ -731,8 +744,10 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
             hipLaunchKernelGGL(k_prep_box<2>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
                                nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox);
         ZM_HIP(hipGetLastError());
-        ctx->box_ready_for = mask_for_box;
-        ctx->box_ready_nt = box_nt;
+        if (!mbox_out) {
+            ctx->box_ready_for = mask_for_box;
+            ctx->box_ready_nt = box_nt;
+        }
         return 0;
     }
     dim3 blk(256, 1, 1), grd(zm_div_up(zm_div_up(spitch, 4), 256), ny, 1);
@@ -1181,6 +1196,760 @@ int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny, co
         zm_set_error("zm_launch_resample_mask: unknown kernel %d", kernel);
         return 2;
     }
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ===========================================================================
+// Fused resample -> WEIGHTED / AVERAGE coadd (+ mask coadd): the frames of a stack are looped
+// INSIDE the output tile.  A workgroup owns a 64 x 32 output tile, walks the N frames of this
+// rank, resamples each one out of LDS exactly as k_resample does and keeps the running sums
+//   S1 = sum(w v), S0 = sum(w)   (and the AND / OR mask coadd)
+// of its 8 pixels per thread in registers; the coadd (or the partial sums of a multi-GPU
+// stack) is written once per tile.  This removes what SWarp does through `.resamp.fits` files
+// (zuds/coadd.py:126-140) and what the materialised path does through HBM: the N-deep
+// {value, weight} stack (2.4 GB at N = 32), its re-read by k_combine_sum and the per-frame
+// read-modify-write of the mask accumulator.  HBM traffic per frame and output pixel: the
+// prepped {value, variance} pair (8 B x tile halo) + the 16-bit box-OR entry, against
+// 8 + 8 + 8 + 2 + 4 + 4 B before.  The sums run in frame order with the operations of
+// k_combine_sum (fmaf(w, v, s1); s0 += w), so the result is bit-identical to the
+// materialised path.
+//
+// Per-pixel instruction diet (the kernel is bound by vector issue, tools/valu_rate.hip):
+//   * taps from the LDS table (zm_lz3_lookup);
+//   * the 8 pixels of a thread are unrolled, so the lattice cell row, the row fraction and the
+//     accumulator registers are compile-time;
+//   * tiles whose input footprint lies inside the frame and whose pixels are all inside the
+//     output grid ("fast" items, > 90 % of a dithered stack) skip every bounds test; the snap
+//     rule (delta kernels) and the 16-bit box-OR overflow are checked by one wave vote each and
+//     send the whole wave-row to the generic code, which is instantiated once, outside the
+//     unrolled loop.
+// Pointers that arrive through the descriptor array are generic to the compiler: it would
+// emit flat_load, which counts on lgkmcnt as well as vmcnt - every LDS wait of the tap rows
+// would then also wait for the prefetch of the next tile and for the mask gathers.  Casting
+// to the global address space gives global_load (vmcnt only).
+#define ZM_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ inline const T ZM_GLOBAL* zm_gptr(const T* p) { return (const T ZM_GLOBAL*)p; }
+// (HIP's float2 / float4 / double2 classes have no constructors from address-space qualified
+// references: loads through such pointers use the plain vector types)
+typedef float zm_v4f __attribute__((ext_vector_type(4)));
+typedef double zm_v2d __attribute__((ext_vector_type(2)));
+__device__ inline float2 zm_gload2(const float2 ZM_GLOBAL* p) {
+    const zm_v2f v = *(const zm_v2f ZM_GLOBAL*)p;
+    return make_float2(v.x, v.y);
+}
+__device__ inline float4 zm_gload4(const float2 ZM_GLOBAL* p) {
+    const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+#define FF_PF 7                      // pixel prefetch slots per thread (float4 = 2 pixels each)
+#define FF_PM 4                      // mask prefetch slots per thread (uint2 = 4 pixels each)
+
+struct ff_hdr {
+    tile_hdr3 h;
+    int use_lds, touches, fast, edge;
+};
+
+__device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int lnx, int lny, int t, int ntx,
+                                       int onx, int ony, int lds_cap, ff_hdr* H) {
+    constexpr int NT = 6, OFF = -2;
+    const int tyi = t / ntx, txi = t - tyi * ntx;
+    const zm_ff* F = fr + f;
+    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (RTH / LSTEP), OFF, OFF + NT - 1, &H->h);
+    if ((threadIdx.x & 63) == 0) {
+        const int nx = F->nx, ny = F->ny;
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
+        const int touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
+        const long long area = (long long)bw * bh;
+        // what k_coadd_fused's register staging can hold: FF_PF row slots of [256 / (bw / 2)] rows
+        // (and FF_PM slots of [256 / (bw / 4)] rows of the mask box)
+        const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bw <= 256 &&
+                            bh <= FF_PF * (256 / (bw >> 1)) && bh <= FF_PM * (256 / (bw >> 2));
+        H->touches = touches;
+        H->use_lds = use_lds;
+        H->fast = use_lds && bx0 >= 0 && by0 >= 0 && bx0 + bw <= nx && by0 + bh <= ny &&
+                  (txi + 1) * TW <= onx && (tyi + 1) * RTH <= ony;
+        // staged through LDS with bounds tests (the mask box in groups of 4 pixels: nx % 4 == 0)
+        H->edge = use_lds && !H->fast && (nx & 3) == 0;
+    }
+}
+
+// result of one generic pixel: {value, weight, mask bits, inb}
+struct ff_px {
+    float v, w;
+    int32_t m;
+    int inb;
+};
+
+// The general per-pixel code (k_resample's): bounds tests, delta kernels, global gather for
+// footprints that do not fit the LDS tile, raw-mask OR where the box-OR plane defers.
+// (not inlined: it runs for edge tiles and snapped positions only, and inlined into the item
+// loop its temporaries - on top of the 64 registers of prefetch and running sums - set the
+// register peak of the whole kernel)
+#ifndef FF_GENERIC_INLINE
+#define FF_GENERIC_INLINE 1
+#endif
+#if FF_GENERIC_INLINE
+#define FF_GENERIC_ATTR inline
+#else
+#define FF_GENERIC_ATTR __attribute__((noinline))
+#endif
+template <int MOP>
+__device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const float2* tile, const float* ltab,
+                                         bool use_lds, bool touches, int bx0, int by0, int bw, float px,
+                                         float py) {
+    constexpr int NT = 6, OFF = -2, CI = 2;
+    const int nx = F->nx, ny = F->ny, spitch = F->spitch;
+    int ixr, iyr;
+    float dx, dy;
+    bool ddx, ddy;
+    split_pos(px, &ixr, &dx, &ddx);
+    split_pos(py, &iyr, &dy, &ddy);
+    const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;
+    const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
+    ff_px r;
+    r.v = 0.f; r.w = 0.f; r.m = 0; r.inb = inb;
+    if (!inb) return r;
+    const bool with_mask = MOP && F->mask != nullptr;
+    int32_t mres = 0;
+    uint32_t m16 = 0;
+    if (with_mask) {
+        if (!(ddx || ddy)) {
+            m16 = zm_gptr(F->mbox)[(size_t)iy * nx + ix];
+        } else {
+            const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
+            const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
+#pragma unroll 1
+            for (int rr = r0; rr < r1; ++rr) {
+                const int32_t ZM_GLOBAL* mp = zm_gptr(F->mask) + (size_t)(iy + rr) * nx + ix;
+#pragma unroll 1
+                for (int c = c0; c < c1; ++c) mres |= mp[c];
+            }
+        }
+    }
+    zm_v2f txp[3], typ[3];
+    zm_lz3_lookup(ltab, ddx ? 0.5f : dx, txp);
+    zm_lz3_lookup(ltab, ddy ? 0.5f : dy, typ);
+    if (__any(ddx || ddy)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const zm_v2f dl = (zm_v2f){j == 1 ? 1.f : 0.f, 0.f};
+            txp[j] = ddx ? dl : txp[j];
+            typ[j] = ddy ? dl : typ[j];
+        }
+    }
+    float tx[NT], ty[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        tx[k] = (k & 1) ? txp[k >> 1].y : txp[k >> 1].x;
+        ty[k] = (k & 1) ? typ[k >> 1].y : typ[k >> 1].x;
+    }
+    float acc = 0.f, vacc = 0.f;
+    if (use_lds) {
+        const float2* p = tile + (iyr + OFF) * bw + (ixr + OFF);
+        zm_v2f av = (zm_v2f){0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < NT; ++rr) {
+            float2 s[NT];
+            lds_row<NT>::read(p, s);
+            zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                rv2 = __builtin_elementwise_fma((zm_v2f){tx[c], tx[c]}, (zm_v2f){s[c].x, s[c].y}, rv2);
+            av = __builtin_elementwise_fma((zm_v2f){ty[rr], ty[rr]}, rv2, av);
+            p += bw;
+        }
+        acc = av.x;
+        vacc = av.y;
+    } else {
+        const float2 ZM_GLOBAL* p = zm_gptr(F->src) + (size_t)iy * spitch + ix;
+#pragma unroll
+        for (int rr = 0; rr < NT; ++rr) {
+            float ra = 0.f, rv = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const float2 s = zm_gload2(p + c);
+                ra = fmaf(tx[c], s.x, ra);
+                rv = fmaf(tx[c], s.y, rv);
+            }
+            acc = fmaf(ty[rr], ra, acc);
+            vacc = fmaf(ty[rr], rv, vacc);
+            p += spitch;
+        }
+    }
+    if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
+        r.v = acc * F->fscale;
+        r.w = __builtin_amdgcn_rcpf(vacc * F->fscale2);
+    }
+    if (with_mask && !(ddx || ddy)) {
+        if (m16 != ZM_BOX_RAW) {
+            mres = (int32_t)m16;
+        } else {
+#pragma unroll 1
+            for (int rr = 0; rr < NT; ++rr) {
+                const int32_t ZM_GLOBAL* mp = zm_gptr(F->mask) + (size_t)(iy + rr) * nx + ix;
+#pragma unroll 1
+                for (int c = 0; c < NT; ++c) mres |= mp[c];
+            }
+        }
+    }
+    r.m = mres;
+    return r;
+}
+
+template <int MOP>
+__device__ inline int32_t ff_mask_fold(int32_t a, int32_t m) {
+    // -1 = "no frame covered the pixel yet" (k_mask_accum): -1 & m == m, so AND needs no test
+    if (MOP == 1) return a & m;
+    return a == -1 ? m : (a | m);
+}
+
+// ---- item headers, precomputed ------------------------------------------------------------
+// An item = (output tile, frame).  Its header (box of the input footprint, the 15 lattice
+// nodes relative to the box origin, the path flags) needs fp64 loads and a wave reduction:
+// built inside the persistent kernel by wave 0 it sits on that wave's critical path once per
+// item and every barrier of the workgroup waits for it.  A pre-pass builds all of them, one
+// wave per item; the persistent kernel fetches a header two items ahead with one 4-byte load
+// per lane.
+#define FF_HDR_WORDS 40              // ff_hdr padded to 160 bytes
+static_assert(sizeof(ff_hdr) <= FF_HDR_WORDS * 4, "ff_hdr does not fit its record");
+
+__global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr, int nfr, int lnx, int lny,
+                                                    int onx, int ony, int lds_cap, int ntx, int ntiles,
+                                                    int* __restrict__ out) {
+    __shared__ ff_hdr H[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + w;
+    const bool live = item < (long long)ntiles * nfr;
+    if (live) {
+        const int t = (int)(item / nfr), f = (int)(item - (long long)t * nfr);
+        ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, &H[w]);
+    }
+    __syncthreads();
+    if (live && lane < FF_HDR_WORDS)
+        out[item * FF_HDR_WORDS + lane] = lane < (int)(sizeof(ff_hdr) / 4) ? ((const int*)&H[w])[lane] : 0;
+}
+
+// LDS row reads, software-pipelined by hand: the six ds_read_b64 of tap row r + 1 are issued
+// before the packed FMAs of row r; `lds_wait` then waits until at most N reads are outstanding
+// (LDS returns in order) and carries the registers, so no consumer can be scheduled above it.
+struct lds_row6 {
+    unsigned long long r0, r1, r2, r3, r4, r5;
+};
+__device__ inline void lds_issue6(const float2* p, lds_row6& o) {
+    const unsigned a = (unsigned)(size_t)p;
+    asm volatile("ds_read_b64 %0, %6\n\t"
+                 "ds_read_b64 %1, %6 offset:8\n\t"
+                 "ds_read_b64 %2, %6 offset:16\n\t"
+                 "ds_read_b64 %3, %6 offset:24\n\t"
+                 "ds_read_b64 %4, %6 offset:32\n\t"
+                 "ds_read_b64 %5, %6 offset:40"
+                 : "=&v"(o.r0), "=&v"(o.r1), "=&v"(o.r2), "=&v"(o.r3), "=&v"(o.r4), "=&v"(o.r5)
+                 : "v"(a)
+                 : "memory");
+}
+template <int N>
+__device__ inline void lds_wait(lds_row6& o) {
+    if (N == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(o.r0), "+v"(o.r1), "+v"(o.r2), "+v"(o.r3), "+v"(o.r4), "+v"(o.r5)::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(6)"
+                     : "+v"(o.r0), "+v"(o.r1), "+v"(o.r2), "+v"(o.r3), "+v"(o.r4), "+v"(o.r5)::"memory");
+}
+__device__ inline zm_v2f lds_pair(unsigned long long r) {
+    return (zm_v2f){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
+}
+
+template <int N>
+__device__ inline void lds_wait_n(lds_row6& o) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt has four bits");
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(o.r0), "+v"(o.r1), "+v"(o.r2), "+v"(o.r3), "+v"(o.r4), "+v"(o.r5)
+                 : "n"(N)
+                 : "memory");
+}
+
+// one node of the tap table (zm_lz3_lookup's five reads), issued without waiting
+struct lz3_node {
+    zm_v4f a, b, c, g;
+    zm_v2f h;
+};
+__device__ inline void lz3_issue(const float* tab, float d, lz3_node& n, float& dl) {
+    const float fi = __builtin_rintf(d * (float)LZ_N);
+    dl = __builtin_fmaf(fi, -1.0f / LZ_N, d);
+    const unsigned a = (unsigned)(size_t)tab + (unsigned)((int)fi * (LZ_ENTRY * 4));
+    asm volatile("ds_read_b128 %0, %5\n\t"
+                 "ds_read_b128 %1, %5 offset:16\n\t"
+                 "ds_read_b128 %2, %5 offset:32\n\t"
+                 "ds_read_b128 %3, %5 offset:48\n\t"
+                 "ds_read_b64 %4, %5 offset:64"
+                 : "=&v"(n.a), "=&v"(n.b), "=&v"(n.c), "=&v"(n.g), "=&v"(n.h)
+                 : "v"(a)
+                 : "memory");
+}
+template <int N>
+__device__ inline void lz3_wait(lz3_node& n) {
+    asm volatile("s_waitcnt lgkmcnt(%5)"
+                 : "+v"(n.a), "+v"(n.b), "+v"(n.c), "+v"(n.g), "+v"(n.h)
+                 : "n"(N)
+                 : "memory");
+}
+// the arithmetic of zm_lz3_lookup on a node that has arrived
+__device__ inline void lz3_eval(const lz3_node& n, float dl, zm_v2f t[3]) {
+    const zm_v2f dd = (zm_v2f){dl, dl};
+    t[0] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){n.b.x, n.b.y}, (zm_v2f){n.a.z, n.a.w}),
+                                     (zm_v2f){n.a.x, n.a.y});
+    t[1] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){n.c.z, n.c.w}, (zm_v2f){n.c.x, n.c.y}),
+                                     (zm_v2f){n.b.z, n.b.w});
+    t[2] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){n.h.x, n.h.y}, (zm_v2f){n.g.z, n.g.w}),
+                                     (zm_v2f){n.g.x, n.g.y});
+}
+
+// WPS: waves per SIMD the register allocation aims at (3: 168 VGPRs)
+//
+// LDS: [3 headers][tap table][pixel tile: bw x bh {value, variance}][mask tile: bw x bh uint16].
+// Everything a pixel of a fast item touches is in LDS - also its box-OR mask entry: a per-pixel
+// global gather would be waited for with vmcnt(0), and vmcnt retires in order, so it would
+// drain the register prefetch of the next item at the first pixel.  In the fast path the
+// only vector-memory instructions between two barriers are that prefetch and the 4-byte
+// header fetch issued before it.
+template <int MOP, bool AVG, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_coadd_fused(
+    const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
+    const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
+    int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
+    const float* __restrict__ taptab) {
+    extern __shared__ float4 smem4[];
+    ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem4);                 // ring of 3 headers
+    const float* ltab = reinterpret_cast<const float*>(smem4) + HDR_FLOATS;
+    float2* tile = reinterpret_cast<float2*>(smem4) + (HDR_FLOATS + LZ_FLOATS) / 2;
+    uint16_t* mtile = reinterpret_cast<uint16_t*>(tile + lds_cap);  // lds_cap is a multiple of 4
+    int* rawflag = reinterpret_cast<int*>(smem4) + (HDR_FLOATS - 4); // one word per wave, behind the headers
+    constexpr int NT = 6, OFF = -2, NQ = RTH / 4;
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    static_assert(3 * sizeof(ff_hdr) <= (HDR_FLOATS - 4) * 4, "header ring does not fit");
+
+    // Staging of an item's box: thread (c, r0) of a [RP rows][bw / 2 float4 columns] arrangement
+    // loads rows r0, r0 + RP, ... - one address per thread, a uniform stride per slot.
+    float4 pf[FF_PF];
+    uint2 pm[FF_PM];
+    // (every path assigns every slot: a slot that kept its old value on some path would have to
+    // stay live - or be spilled and reloaded, with a vmcnt wait behind the loads just issued)
+    auto prefetch = [&](const ff_hdr* H, int f) {
+        const zm_ff* F = fr + f;
+        const float2 ZM_GLOBAL* src = zm_gptr(F->src);
+        const int ny = F->ny, spitch = F->spitch;
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bh = H->h.bh, bw2 = max(H->h.bw >> 1, 1);
+        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw2));
+        const int c = tid - r0 * bw2;
+        const int RP = 256 / bw2;                     // (uniform) rows per slot
+        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+#pragma unroll
+        for (int k = 0; k < FF_PM; ++k) pm[k] = make_uint2(0u, 0u);
+        if (H->fast) {
+            // The whole box lies on the frame: no tests, no fill.  A uniform base per slot (scalar
+            // registers) plus one 32-bit byte offset per thread: one address register for all slots.
+            const char ZM_GLOBAL* base = (const char ZM_GLOBAL*)(src + ((size_t)by0 * spitch + bx0));
+            const unsigned rowb = (unsigned)spitch * 8u;                     // bytes per row of the plane
+            const unsigned off = (unsigned)min(r0, RP - 1) * rowb + (unsigned)c * 16u;
+            const unsigned lastrow = (unsigned)(bh - 1) * rowb + (unsigned)c * 16u;
+            // (all slots load, unconditionally and back to back: one basic block, no waits in
+            // between; rows past the box re-read its last row and are never stored)
+#pragma unroll
+            for (int k = 0; k < FF_PF; ++k) {
+                const unsigned o = (r0 + k * RP < bh) ? off + (unsigned)(k * RP) * rowb : lastrow;
+                const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(base + o);
+                pf[k] = make_float4(v.x, v.y, v.z, v.w);
+            }
+            if (MOP && F->mask) {
+                // the box-OR entries of the same box: 4 pixels (8 bytes) per load
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const int nx = F->nx, bw4 = H->h.bw >> 2;
+                const char ZM_GLOBAL* mb = (const char ZM_GLOBAL*)(zm_gptr(F->mbox) + ((size_t)by0 * nx + bx0));
+                const int m0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
+                const int mc = tid - m0 * bw4;
+                const int RM = 256 / bw4;
+                const unsigned mrow = (unsigned)nx * 2u;
+#pragma unroll
+                for (int k = 0; k < FF_PM; ++k) {
+                    const unsigned row = (unsigned)min(min(m0, RM - 1) + k * RM, bh - 1);
+                    const v2u v = *(const v2u ZM_GLOBAL*)(mb + (row * mrow + (unsigned)mc * 8u));
+                    pm[k] = make_uint2(v.x, v.y);
+                }
+            }
+        } else if (H->use_lds) {
+            // an edge item: the box sticks out of the frame - bounds tests, {0, BIGVAR} outside (a tap
+            // on it drives the variance sum out of range: weight 0, as for a footprint that leaves
+            // the frame); its mask box is fetched when the item starts (store)
+#pragma unroll
+            for (int k = 0; k < FF_PF; ++k) {
+                const int gy = by0 + r0 + k * RP, gx = bx0 + 2 * c;
+                pf[k] = fill;
+                if (r0 + k * RP < bh && r0 < RP && gy >= 0 && gy < ny && gx >= 0 && gx < spitch)
+                    pf[k] = zm_gload4(src + (size_t)gy * spitch + gx);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < FF_PF; ++k) pf[k] = fill;
+        }
+    };
+    auto store = [&](const ff_hdr* H, int f) {
+        if (!H->use_lds) return;
+        const int bh = H->h.bh, bw2 = H->h.bw >> 1;
+        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw2));
+        const int c = tid - r0 * bw2;
+        const int RP = 256 / bw2;
+        if (r0 < RP) {
+#pragma unroll
+            for (int k = 0; k < FF_PF; ++k)
+                if (r0 + k * RP < bh) *reinterpret_cast<float4*>(tile + 2 * ((r0 + k * RP) * bw2 + c)) = pf[k];
+        }
+        if (MOP && (H->fast || H->edge) && fr[f].mask) {
+            const int bw4 = H->h.bw >> 2;
+            const int m0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
+            const int mc = tid - m0 * bw4;
+            const int RM = 256 / bw4;
+            // does any entry of the box defer to the raw mask (ZM_BOX_RAW: bits above 15)?  Decided
+            // here, once per item, so that the pixel loop carries no vote and no branch for it
+            bool raw = false;
+            if (H->fast) {
+                if (m0 < RM) {
+#pragma unroll
+                    for (int k = 0; k < FF_PM; ++k)
+                        if (m0 + k * RM < bh) {
+                            *reinterpret_cast<uint2*>(mtile + 4 * ((m0 + k * RM) * bw4 + mc)) = pm[k];
+                            const uint32_t a = pm[k].x, b = pm[k].y;
+                            raw |= (a & 0xffffu) == ZM_BOX_RAW || (a >> 16) == ZM_BOX_RAW ||
+                                   (b & 0xffffu) == ZM_BOX_RAW || (b >> 16) == ZM_BOX_RAW;
+                        }
+                }
+            } else {
+                // an edge item (one in twenty): its mask box is fetched here, with bounds tests,
+                // instead of riding in prefetch registers through the previous item
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const zm_ff* F = fr + f;
+                const uint16_t ZM_GLOBAL* mb = zm_gptr(F->mbox);
+                const int nx = F->nx, ny = F->ny, bx0 = H->h.bx0, by0 = H->h.by0;
+                if (m0 < RM) {
+#pragma unroll 1
+                    for (int k = 0; k < FF_PM; ++k) {
+                        const int gy = by0 + m0 + k * RM, gx = bx0 + 4 * mc;
+                        if (m0 + k * RM < bh) {
+                            v2u v = (v2u){0u, 0u};
+                            if (gy >= 0 && gy < ny && gx >= 0 && gx + 4 <= nx)
+                                v = *(const v2u ZM_GLOBAL*)(mb + ((size_t)gy * nx + gx));
+                            *reinterpret_cast<uint2*>(mtile + 4 * ((m0 + k * RM) * bw4 + mc)) = make_uint2(v.x, v.y);
+                            raw |= (v.x & 0xffffu) == ZM_BOX_RAW || (v.x >> 16) == ZM_BOX_RAW ||
+                                   (v.y & 0xffffu) == ZM_BOX_RAW || (v.y >> 16) == ZM_BOX_RAW;
+                        }
+                    }
+                }
+            }
+            const bool wraw = __any(raw);
+            if ((tid & 63) == 0) rawflag[tid >> 6] = wraw;
+        }
+    };
+    auto next_item = [&](int& tt, int& ff) {
+        if (++ff == nfr) { ff = 0; tt += G; }
+    };
+    auto hdr_word = [&](int tt, int ff) -> int {          // this lane's word of the header of item (tt, ff)
+        return tid < FF_HDR_WORDS ? ghdr[((size_t)tt * nfr + ff) * FF_HDR_WORDS + tid] : 0;
+    };
+    auto hdr_put = [&](int sl, int wv) {
+        if (tid < (int)(sizeof(ff_hdr) / 4)) reinterpret_cast<int*>(&HR[sl])[tid] = wv;
+    };
+
+    int t0 = blockIdx.x, f0 = 0;
+    if (t0 >= ntiles) return;
+    for (int e = tid; e < LZ_FLOATS / 4; e += 256)
+        smem4[HDR_FLOATS / 4 + e] = reinterpret_cast<const float4*>(taptab)[e];
+    int t1 = t0, f1 = f0;
+    next_item(t1, f1);
+    int t2 = t1, f2 = f1;
+    next_item(t2, f2);
+    hdr_put(0, hdr_word(t0, f0));
+    if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
+    __syncthreads();
+    prefetch(&HR[0], f0);
+
+    const int tx = tid & 63, tyb = tid >> 6;
+    const int cell = tx >> 4;
+    const float fx = (float)(tx & 15) * (1.f / LSTEP);
+    const float fyb = (float)tyb * (1.f / LSTEP);
+    float S1[NQ], S0[NQ], SW[NQ];
+    int32_t MK[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
+
+    int slot = 0;
+    for (;;) {
+        const ff_hdr* H = &HR[slot];
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        const int nnslot = nslot == 2 ? 0 : nslot + 1;
+        store(H, f0);
+        __syncthreads();
+        const zm_ff* F = fr + f0;
+        const bool use_lds = H->use_lds, touches = H->touches, fast = H->fast;
+        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw;
+        const int tyi = t0 / ntx, txi = t0 - tyi * ntx;
+        const int ox0 = txi * TW, oy0 = tyi * RTH;
+        const int ox = ox0 + tx;
+        // in this order: the header word is older than the prefetch, so storing it at the end of
+        // the item waits with vmcnt(prefetch loads), not vmcnt(0)
+        int hw2 = 0;
+        if (t2 < ntiles) hw2 = hdr_word(t2, f2);
+        // (unconditional: past the last item the current one is fetched again, into registers nobody reads)
+        prefetch(t1 < ntiles ? &HR[nslot] : H, t1 < ntiles ? f1 : f0);
+
+        if (touches) {
+            // x part of the bilinear lattice interpolation, once per item (same operations and
+            // order as k_resample / tile_position)
+            float xr[3], yr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float x0 = H->h.nrel[r][cell][0], x1 = H->h.nrel[r][cell + 1][0];
+                const float y0 = H->h.nrel[r][cell][1], y1 = H->h.nrel[r][cell + 1][1];
+                xr[r] = x0 + fx * (x1 - x0);
+                yr[r] = y0 + fx * (y1 - y0);
+            }
+            const bool with_mask = MOP && F->mask != nullptr;
+            // wave-uniform: pixels left to the generic code (items that do not go through LDS: all)
+            unsigned slow = (fast || H->edge) ? 0u : 0xffu;
+            const bool any_raw = MOP && with_mask && (fast || H->edge) &&
+                                 (rawflag[0] | rawflag[1] | rawflag[2] | rawflag[3]);
+            const float fscale = F->fscale, fscale2 = F->fscale2;
+            const float2* tbase = tile + (OFF * bw + OFF);
+            const uint16_t* mbase = mtile + (OFF * bw + OFF);
+            const int enx = F->nx, eny = F->ny;
+            // the eight pixels of a thread out of LDS; EDGE: the item's box sticks out of the frame
+            // or its tile out of the output grid (bounds tests for the mask fold)
+            auto pixels = [&](auto edge_tag) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int cr = q >> 2;
+                    // ((tyb + 4 q) & 15) / 16, exactly, from one per-thread constant: four precomputed
+                    // values would be spilled, and a scratch reload inside the pixel loop waits on
+                    // vmcnt - in order, i.e. for the whole prefetch of the next item
+                    float fy = fyb;
+                    // (an empty volatile asm stays behind the LDS reads of the previous pixel: without
+                    // it the positions, fractions and offsets of all eight pixels are computed up
+                    // front and kept live - 30 registers, spilled to scratch)
+                    asm volatile("" : "+v"(fy));
+                    fy += (float)(q & 3) * 0.25f;     // (after the asm: not hoisted out of the item loop)
+                    const float xa = xr[cr], xb = xr[cr + 1], ya = yr[cr], yb = yr[cr + 1];
+                    const float px = xa + fy * (xb - xa), py = ya + fy * (yb - ya);
+                    const float fxf = floorf(px), fyf = floorf(py);
+                    const float dx = px - fxf, dy = py - fyf;
+                    // snap rule: a fraction within 1e-5 of 0 or 1 on either axis -> generic code
+                    const float edge = fminf(fminf(dx, 1.f - dx), fminf(dy, 1.f - dy));
+                    if (__any(edge < ZM_SNAP)) {
+                        slow |= 1u << q;
+                        continue;
+                    }
+                    const int lo = (int)fyf * bw + (int)fxf;          // element offset in both tiles
+                    // edge items: is the footprint on the frame (decides the mask fold; the value
+                    // and weight follow from the {0, BIGVAR} fill), is the pixel on the output grid
+                    bool inb = true;
+                    if (EDGE) {
+                        const int ix = bx0 + OFF + (int)fxf, iy = by0 + OFF + (int)fyf;
+                        inb = ix >= 0 && ix + NT <= enx && iy >= 0 && iy + NT <= eny &&
+                              ox < onx && oy0 + tyb + 4 * q < ony;
+                    }
+                    const float2* p = tbase + lo;
+                    // tap row r + 1 is read while the packed FMAs of row r run: two row buffers (one
+                    // buffer with the wait behind every row: 10 % slower; three buffers and both
+                    // table nodes ahead: no faster, 30 registers more - spills in the mask variants)
+                    lds_row6 ra, rb;
+                    lds_issue6(p, ra);
+                    uint32_t m16 = 0;
+                    if (with_mask) m16 = mbase[lo];
+                    zm_v2f txp[3], typ[3];
+                    zm_lz3_lookup(ltab, dx, txp);
+                    zm_lz3_lookup(ltab, dy, typ);
+                    zm_v2f av = (zm_v2f){0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) {
+                        lds_row6& cur = (r & 1) ? rb : ra;
+                        lds_row6& nxt = (r & 1) ? ra : rb;
+                        if (r + 1 < NT) {
+                            lds_issue6(p + (r + 1) * bw, nxt);
+                            lds_wait_n<6>(cur);
+                        } else {
+                            lds_wait_n<0>(cur);
+                        }
+                        const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+                        zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) {
+                            const float tc = (c & 1) ? txp[c >> 1].y : txp[c >> 1].x;
+                            rv2 = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rv2);
+                        }
+                        const float tr = (r & 1) ? typ[r >> 1].y : typ[r >> 1].x;
+                        av = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, av);
+                    }
+                    const float acc = av.x, vacc = av.y;
+                    const bool ok = vacc > 0.f && vacc < ZM_BADVAR_TEST;
+                    const float v = ok ? acc * fscale : 0.f;
+                    const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
+                    const float ww = AVG ? (w > 0.f ? 1.f : 0.f) : w;
+                    S1[q] = fmaf(ww, v, S1[q]);
+                    S0[q] += ww;
+                    if (AVG) SW[q] += w;
+                    if (with_mask) {
+                        int32_t mres = (int32_t)m16;
+                        if (any_raw) {
+                            // bits above 15 somewhere in this box: OR the raw mask under such footprints
+                            if (m16 == ZM_BOX_RAW && inb) {
+                                mres = 0;
+                                const int nx = F->nx;
+                                const int32_t ZM_GLOBAL* mp0 =
+                                    zm_gptr(F->mask) + ((ptrdiff_t)(by0 + OFF + (int)fyf) * nx + (bx0 + OFF + (int)fxf));
+                                // (rolled on purpose: unrolled, its 36 loads claim registers in each of
+                                // the eight pixel bodies for a path that is almost never taken)
+#pragma unroll 1
+                                for (int r = 0; r < NT; ++r) {
+#pragma unroll 1
+                                    for (int c = 0; c < NT; ++c) mres |= mp0[(ptrdiff_t)r * nx + c];
+                                }
+                            }
+                        }
+                        MK[q] = (!EDGE || inb) ? ff_mask_fold<MOP>(MK[q], mres) : MK[q];
+                    }
+                }
+            };
+            if (fast) pixels(std::false_type{});
+            else if (H->edge) pixels(std::true_type{});
+            // the generic code, once: edge tiles, delta kernels, footprints beyond the LDS tile
+#pragma unroll 1
+            while (slow) {
+                const int q = __builtin_ctz(slow);
+                slow &= slow - 1;
+                const int ty = tyb + 4 * q;
+                const int oy = oy0 + ty;
+                if (ox >= onx || oy >= ony) continue;
+                const int cr = q >> 2;
+                const float fy = (float)(ty & 15) * (1.f / LSTEP);
+                const float xa = cr ? xr[1] : xr[0], xb = cr ? xr[2] : xr[1];
+                const float ya = cr ? yr[1] : yr[0], yb = cr ? yr[2] : yr[1];
+                const float px = xa + fy * (xb - xa), py = ya + fy * (yb - ya);
+                const ff_px r = ff_generic_pixel<MOP>(F, tile, ltab, use_lds, touches, bx0, by0, bw, px, py);
+                const float ww = AVG ? (r.w > 0.f ? 1.f : 0.f) : r.w;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) {
+                    const bool me = (k == q);
+                    S1[k] = me ? fmaf(ww, r.v, S1[k]) : S1[k];
+                    S0[k] = me ? S0[k] + ww : S0[k];
+                    if (AVG) SW[k] = me ? SW[k] + r.w : SW[k];
+                    if (MOP) MK[k] = (me && with_mask && r.inb) ? ff_mask_fold<MOP>(MK[k], r.m) : MK[k];
+                }
+            }
+        }
+
+        if (f0 == nfr - 1) {
+            // the tile is complete: coadd (or partial sums) and mask coadd, once
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int oy = oy0 + tyb + 4 * q;
+                if (ox < onx && oy < ony) {
+                    const size_t o = (size_t)oy * onx + ox;
+                    const float s1 = S1[q], s0 = S0[q];
+                    if (partial) {
+                        out_img[o] = s1;
+                        out_wgt[o] = s0;
+                    } else {
+                        out_img[o] = s0 > 0.f ? s1 / s0 : 0.f;
+                        out_wgt[o] = AVG ? SW[q] : s0;
+                    }
+                    if (MOP) {
+                        const int32_t a = MK[q];
+                        if (partial) {
+                            out_mask[o] = a;
+                        } else {
+                            out_mask[o] = a == -1 ? 0 : a;
+                            if (out_cov) out_cov[o] = a == -1 ? 0.f : 1.f;
+                        }
+                    }
+                }
+                S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1;
+            }
+        }
+        if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read two items ago
+        __syncthreads();          // everyone is done with the LDS tiles and with header `slot`
+        t0 = t1; f0 = f1;
+        t1 = t2; f1 = f2;
+        next_item(t2, f2);
+        slot = nslot;
+        if (t0 >= ntiles) break;
+    }
+}
+
+#define FF_WPS_DEFAULT 3
+// frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
+int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
+                          int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
+                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out) {
+    const int ntx = zm_div_up(onx, TW), ntiles = ntx * zm_div_up(ony, RTH);
+    if (unmasked_out) {
+        // a mask coadd was asked for but no frame carries a mask: "nothing covered" everywhere
+        const size_t opix = (size_t)onx * ony;
+        ZM_HIP(hipMemsetAsync(unmasked_out, partial ? 0xFF : 0, sizeof(int32_t) * opix, ctx->stream));
+        if (!partial && out_cov) ZM_HIP(hipMemsetAsync(out_cov, 0, sizeof(float) * opix, ctx->stream));
+    }
+    // what the prefetch registers can stage: FF_PF row slots of a [256 / (bw / 2)] x [bw / 2] arrangement
+    if (lds_elems > FF_PF * 256 * 2) lds_elems = FF_PF * 256 * 2;
+    lds_elems = (lds_elems + 3) & ~3;
+    const bool masks = out_mask != nullptr;
+    const size_t shmem = (size_t)(HDR_FLOATS + LZ_FLOATS) * 4 + (size_t)lds_elems * sizeof(float2) +
+                         (masks ? (size_t)lds_elems * sizeof(uint16_t) : 0);
+    const float* taptab = nullptr;
+    ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
+    // descriptors: pinned staging guarded by an event (a later call must not overwrite a copy in flight)
+    zm_ff *pin = nullptr, *dev = nullptr;
+    int* ghdr = nullptr;
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 6, &ev));
+    ZM_HIP(hipEventSynchronize(ev[5]));
+    ZM_TRY(ctx->get_pinned("ff_frames_h", sizeof(zm_ff) * (size_t)nfr, (void**)&pin));
+    ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
+    ZM_TRY(ctx->get("ff_headers", sizeof(int) * FF_HDR_WORDS * (size_t)ntiles * nfr, (void**)&ghdr));
+    memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
+    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, ctx->stream));
+    ZM_HIP(hipEventRecord(ev[5], ctx->stream));
+    // 3 waves per SIMD (168 registers): at 4 (128) the prefetch registers and the running sums spill
+    const int wps = FF_WPS_DEFAULT;
+    // persistent grid: `wps` workgroups per CU; trimmed so that every workgroup walks the same
+    // number of tiles (4608 tiles of a 3072^2 grid over 1024 workgroups would leave half of them
+    // idle during the fifth round)
+    int G = std::min(ntiles, 256 * wps);
+    const int rounds = zm_div_up(ntiles, G);
+    G = zm_div_up(ntiles, rounds);
+    const bool avg = combine == ZM_COMBINE_AVERAGE;
+    const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
+    if (shmem > 65536) {
+        // (dynamic LDS above 64 KiB needs the opt-in; not reached with RS_PFCAP-sized tiles)
+        zm_set_error("zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
+        return 2;
+    }
+    zm_scope_timer t(ctx, "coadd_fused");
+    {
+        const long long items = (long long)ntiles * nfr;
+        hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
+                           lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr);
+    }
+#define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV)                                                                    \
+    hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
+                       onx, ony, lds_elems, ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, \
+                       taptab)
+#define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3)
+    if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
+    else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true); else ZM_FF_LAUNCH(1, false); }
+    else { if (avg) ZM_FF_LAUNCH(2, true); else ZM_FF_LAUNCH(2, false); }
+#undef ZM_FF_LAUNCH
+#undef ZM_FF_LAUNCH1
     ZM_HIP(hipGetLastError());
     return 0;
 }

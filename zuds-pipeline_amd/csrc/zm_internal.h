@@ -104,7 +104,20 @@ int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, in
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh,
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch,
-                   const int32_t* mask_for_box = nullptr, int box_nt = 0);
+                   const int32_t* mask_for_box = nullptr, int box_nt = 0, uint16_t* mbox_out = nullptr);
+struct zm_ff {                       // one input frame of a fused coadd (device memory; read through the scalar cache)
+    const float2* src;               // prepped {value, variance} plane
+    const double2* lat;              // lattice of this frame
+    const int32_t* mask;             // raw mask or NULL
+    const uint16_t* mbox;            // box-OR plane of the mask
+    int nx, ny, spitch, pad0;
+    float fscale, fscale2;
+    int pad1, pad2;
+};
+int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
+                          int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
+                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out);
+int zm_get_lanczos_table(zm_ctx* ctx, const float** out);
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
                         float** nodes_dev, float** stats_dev, int* nbx_out, int* nby_out,
