@@ -253,7 +253,9 @@ def test_fullsize_coadd_removes_the_background_and_rescales_the_weights(engine, 
             blk = (slice(by, by + 512), slice(bx, bx + 512))
             assert abs(np.median(o[blk][good[blk]])) < 0.35, (by, bx)
     assert np.abs(np.median((o - f0)[good])) < 0.05
-    assert np.percentile(np.abs(o - f0)[good], 99) < 1.0
+    # (a 128-pixel mesh with a 3 x 3 median filter follows the curved part of this sky to ~1.5
+    # counts in the corners: 2 % of the 78-count gradient)
+    assert np.percentile(np.abs(o - f0)[good], 99) < 2.5
     # weights: 3 frames of sigma 6 -> 3 / 36, from weight maps that claim 1 / 36
     assert abs(np.median(ow[good]) * 36.0 / 3.0 - 1.0) < 0.05
     # ... and from maps that claim four times / a quarter of it: RESCALE_WEIGHTS removes the claim
