@@ -51,6 +51,8 @@ def parse():
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the CLIPPED secondary line')
     ap.add_argument('--no-clocks', action='store_true', help='skip the PCIe / FITS clocks')
+    ap.add_argument('--no-nightly', action='store_true', help='skip the concurrent-subtraction leg')
+    ap.add_argument('--nightly-jobs', type=int, default=16, help='subtractions of the concurrent leg')
     ap.add_argument('--cpu-frames', type=int, default=8,
                     help='full-size frames the CPU baseline resamples and coadds')
     return ap.parse_args()
@@ -361,6 +363,20 @@ def main():
             dt = float(t.item())
         return dt
 
+    if os.environ.get('ZM_BENCH_TRACE'):               # developer: per-step wall times from a cold start
+        for i in range(30):
+            sync()
+            t0 = time.perf_counter()
+            step()
+            sync()
+            print(f'step {i}: {1e3 * (time.perf_counter() - t0):.2f} ms', file=sys.stderr)
+    # Runtime spin-up, before the W warm-up steps the contract asks for: a fresh process stalls
+    # once, for ~40 ms, at its fourth step (HIP runtime state that is set up lazily - seen with
+    # ZM_BENCH_TRACE=1: 15, 11, 11, 53, 11, 11, ... ms); with a small W that stall would land in
+    # the timed region.  Untimed, like the allocation of the inputs above.
+    for _ in range(6):
+        step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -417,6 +433,9 @@ def main():
     secondary = None
     clocks = None
     tools = None
+    nightly = None
+    if world == 1 and rank == 0 and not args.no_subtract and not args.no_nightly:
+        nightly = nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local)
     if world == 1 and rank == 0:
         if sum_type and not args.no_secondary:
             secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx)
@@ -488,6 +507,8 @@ def main():
             'kernels': kt,      # one extra step with every scope timed ('resample': the timed region)
             'roofline': roofline,
         }
+        if nightly is not None:
+            out['nightly'] = nightly
         if secondary is not None:
             out['secondary'] = secondary
         if clocks is not None:
@@ -499,6 +520,58 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local):
+    """BASELINE config 5 in small: the epochs of the stack subtracted against its coadd, J at a
+    time on one GPU (nightly.SubtractionPool: J engines / streams / host threads; the reference
+    runs one process per job, nersc/controller.py:101), forced r = 3 px photometry at 500 fixed
+    sky positions on every difference image (scripts/dophot.py:94-156).  Same products for every J
+    (tests/test_nightly_gpu.py)."""
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    njobs = min(args.nightly_jobs, len(frames))
+    rng = np.random.default_rng(5)
+    ra, dec = base.all_pix2world(rng.uniform(50, args.size - 50, 500), rng.uniform(50, args.size - 50, 500), 0)
+    ref = dict(img=coadd.img, rms=ref_rms, mask=coadd.mask if coadd.mask is not None else no_ref_mask,
+               wcs=base, flxscale=1.0)
+    big = float(np.sqrt(50000.0))
+    jobs = []
+    g = torch.Generator(device='cpu')
+    for i, f in enumerate(frames[:njobs]):
+        # detector defects as on the science frame of the main step: 300 clustered 3 x 3 blobs
+        # (isolated bad pixels at 1e-3 would leave no clean 69 x 69 substamp box)
+        g.manual_seed(177 + i)
+        bx = torch.randint(2, args.size - 2, (300,), generator=g)
+        by = torch.randint(2, args.size - 2, (300,), generator=g)
+        m = torch.zeros((args.size, args.size), dtype=torch.int32)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                m[by + dy, bx + dx] = 256
+        m = m.to(f['img'].device)
+        wgt = torch.where(m != 0, 0.0, float(f['wgt'].max())).to(torch.float32)
+        rms = torch.where(wgt > 0, 1.0 / torch.sqrt(wgt.clamp_min(1e-20)), big).to(torch.float32)
+        sci = dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=args.seeing)
+        jobs.append(nm.SubtractionJob(sci, ref, radec=(ra, dec), nreg_side=3))
+    out = {'jobs': njobs, 'photometry_positions': 500, 'pools': {}}
+    for J in (1, 2, 3, 4, 5, 6):
+        if J > njobs:
+            continue
+        pool = nm.SubtractionPool(J, device=local)
+        try:
+            pool.map(jobs[:J], keep=False)                 # allocations, code objects
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = pool.map(jobs, keep=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            pool.close()
+        bad = [r['info']['status'] for r in res if r['info']['status'] != 0]
+        out['pools'][str(J)] = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
+                                'failed': len(bad)}
+    best = max(out['pools'].values(), key=lambda v: v['subtract_mpix_s'])
+    out['subtract_mpix_s'] = best['subtract_mpix_s']
+    return out
 
 
 def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx):

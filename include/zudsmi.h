@@ -59,6 +59,12 @@ int zm_ctx_destroy(zm_ctx* ctx);
 /* Use an external hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream);
 int zm_ctx_synchronize(zm_ctx* ctx);
+/* Several contexts (one host thread each) may subtract on one GPU at the same time - the
+ * reference runs 64 independent `hotpants` processes per node (nersc/controller.py:101,
+ * scripts/donightly.py:21-40).  The kernel-fit solver keeps every workgroup of a launch
+ * resident behind in-kernel barriers; declaring the number of concurrent contexts lets each
+ * size its launches to 1 / nctx of the GPU.  Results do not depend on the share. */
+int zm_ctx_set_share(zm_ctx* ctx, int nctx);
 const char* zm_last_error(void);
 const char* zm_version(void);
 

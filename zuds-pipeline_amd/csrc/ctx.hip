@@ -118,6 +118,13 @@ extern "C" int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream) {
     return 0;
 }
 
+extern "C" int zm_ctx_set_share(zm_ctx* ctx, int nctx) {
+    ZM_CHECK(ctx != nullptr, "zm_ctx_set_share: ctx is NULL");
+    ZM_CHECK(nctx >= 1 && nctx <= 13, "zm_ctx_set_share: %d contexts (1 .. 13: 3 x 3 regions need 18 workgroups each)", nctx);
+    ctx->share = nctx;
+    return 0;
+}
+
 int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out) {
     while ((int)ctx->sync_events.size() < n) {
         hipEvent_t e = nullptr;

@@ -2034,7 +2034,10 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     const size_t tvn = std::max((size_t)TH * TP, (size_t)P.nunk + 2 * (size_t)P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB + (size_t)2 * NB * P.nkp);
     size_t fl = 2 * tvn + (size_t)2 * NB * STEP * STEP;      // {T, V} tile (or the evaluation scratch) + {k, k^2} kernels
     size_t shmem = fl * sizeof(float) + (size_t)NB * P.nc * sizeof(double);
-    static size_t set_max = 65536;
+    // (remembered per context and kernel instance, not per process: contexts may sit on
+    // different devices)
+    size_t& set_max = ctx->hp_set_max[HWK];
+    if (set_max < 65536) set_max = 65536;
     if (shmem > set_max) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply<HWK>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -2119,11 +2122,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
         const size_t rsh = sizeof(int) * ((size_t)nx + 1);
         dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));
-        static bool rset = false;
-        if (!rset && rsh > 65536) {
+        if (!ctx->hp_rset && rsh > 65536) {
             ZM_HIP(hipFuncSetAttribute((const void*)k_hp_rowany, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(int) * (HP_ROWMAX + 1))));
-            rset = true;
+            ctx->hp_rset = true;
         }
         hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
         const bool col4 = (nx % 4 == 0) && (((uintptr_t)tmp8 | (uintptr_t)dirty | (uintptr_t)outbad) & 3) == 0;
@@ -2219,15 +2221,19 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 // One workgroup per CU: a second one on the same CU slows the serial chains of the
                 // look-ahead workgroup (measured: 806 us at 26 workgroups per region, 917 at 32).
                 // The occupancy API only bounds it (it can be one block per CU high; keep a margin).
-                static int wg_cap = 0;
-                if (!wg_cap) {
+                if (!ctx->hp_wg_cap) {
                     int occ = 0, ncu = 0;
                     ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
                     ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-                    wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
+                    ctx->hp_wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
                     if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
                 }
-                ZM_CHECK(2 * P.nreg <= wg_cap, "zm_subtract: %d regions exceed the %d resident workgroups", P.nreg, wg_cap);
+                // this context's share of the resident workgroups: `share` contexts subtract at the
+                // same time (zm_ctx_set_share), each keeps its launch fully resident
+                const int wg_cap = ctx->hp_wg_cap / std::max(ctx->share, 1);
+                ZM_CHECK(2 * P.nreg <= wg_cap,
+                         "zm_subtract: %d regions exceed the %d resident workgroups of this context's share (1 / %d)",
+                         P.nreg, wg_cap, ctx->share);
                 int W = std::max(2, std::min(68, wg_cap / P.nreg));
                 int nunk = P.nunk;
                 double* Aarg = A;
@@ -2257,11 +2263,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             {
                 const size_t bsh = sizeof(double) * (((size_t)P.nunk + 1) & ~(size_t)1) +
                                    sizeof(double) * CH_NB * (CH_NB + 1);
-                static bool bset = false;
-                if (!bset && bsh > 65536) {
+                if (!ctx->hp_bset && bsh > 65536) {
                     ZM_HIP(hipFuncSetAttribute((const void*)k_chol_back,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-                    bset = true;
+                    ctx->hp_bset = true;
                 }
                 ZM_CHECK(bsh <= 160 * 1024 - 64, "zm_subtract: %d unknowns exceed the solver's LDS", P.nunk);
                 if (P.nunk <= CBC_COLS)

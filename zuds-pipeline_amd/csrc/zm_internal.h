@@ -61,6 +61,15 @@ struct zm_ctx {
     // "mask_box"): zm_launch_resample then skips its own k_mask_box launch
     const void* box_ready_for = nullptr;
     int box_ready_nt = 0;
+    // How many contexts run subtractions on this GPU at the same time (zm_ctx_set_share): the
+    // fused Cholesky keeps every workgroup of a launch resident behind in-kernel barriers, so
+    // concurrent jobs split the CUs between them instead of each claiming all of them.
+    int share = 1;
+    // per-context launch plans of the subtraction kernels (function attributes, resident grid):
+    // per context, not per process - contexts may sit on different devices
+    int hp_wg_cap = 0;
+    bool hp_rset = false, hp_bset = false;
+    std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed
     std::map<std::string, zm_timer_slot> timers;

@@ -84,6 +84,11 @@ class Engine(object):
     def set_stream(self, stream_handle):
         check(self.L.zm_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)))
 
+    def set_share(self, nctx):
+        """Declare that ``nctx`` engines subtract on this GPU at the same time (one host thread
+        each): every engine then sizes its kernel-fit launches to 1 / nctx of the GPU."""
+        check(self.L.zm_ctx_set_share(self._ctx, int(nctx)), 'zm_ctx_set_share')
+
     # -- timing ----------------------------------------------------------------
     def timing(self, on=True, only=None):
         """HIP-event timers around the launches; ``only``: time just that scope."""

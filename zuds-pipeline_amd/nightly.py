@@ -1,0 +1,136 @@
+"""Many subtractions on one GPU at a time (BASELINE config 5: 64 epochs x 4 quadrants,
+32 subtractions per GPU, forced photometry on every difference image).
+
+The reference runs one process per subtraction job, 64 per node
+(``nersc/controller.py:101``; per job ``scripts/donightly.py:21-40`` ->
+``scripts/dosub.py:do_one`` -> ``SingleEpochSubtraction.from_images``, then
+``scripts/dophot.py:94-156`` -> ``raw_aperture_photometry``).  One device-resident
+subtraction is latency-bound - 13 launches of the kernel-fit solver with 23 serial block
+steps each - and leaves most of the GPU idle, so this module runs J of them concurrently:
+J engines (contexts, each with its own stream and scratch) driven by J host threads; the
+ctypes calls release the GIL.  ``Engine.set_share(J)`` makes every engine size the solver's
+resident grid to 1 / J of the CUs.  Results do not depend on J (tests/test_nightly_gpu.py).
+"""
+import ctypes as C
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .constants import APERTURE_RADIUS
+from .engine import Engine
+
+__all__ = ['SubtractionPool', 'SubtractionJob']
+
+
+class SubtractionJob(object):
+    """One science frame against one reference, all planes as torch tensors on the device.
+
+    sci / ref: dicts with ``img``, ``rms``, ``mask`` (int32), ``wcs``; sci also ``wgt`` (for the
+    mesh background, may be None) and ``seeing`` (FWHM in pixels); ref optionally ``flxscale``.
+    ``radec``: optional (ra, dec) arrays for forced photometry on the difference image."""
+
+    def __init__(self, sci, ref, radec=None, nreg_side=3, hotpants_kws=None, tag=None):
+        self.sci, self.ref, self.radec = sci, ref, radec
+        self.nreg_side, self.hotpants_kws, self.tag = nreg_side, hotpants_kws, tag
+
+
+class _Worker(object):
+    """An engine, its stream and the device planes of one subtraction chain."""
+
+    def __init__(self, device, share):
+        import torch
+        self.torch = torch
+        self.engine = Engine(device)
+        self.engine.set_share(share)
+        self.stream = torch.cuda.Stream(torch.device('cuda', device))
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.device = device
+        self.chain = None
+        self.key = None
+
+    def subtract(self, job, keep=True):
+        from .device import DeviceSubtraction
+        torch = self.torch
+        sci, ref = job.sci, job.ref
+        key = (tuple(sci['img'].shape), id(sci['wcs']), id(ref['wcs']))
+        if self.chain is None or self.key[0] != key[0]:
+            self.chain = None                           # frees the planes of another frame size first
+        if self.chain is None or self.key != key:
+            if self.chain is None:
+                self.chain = DeviceSubtraction(sci['wcs'], ref['wcs'], device=self.device,
+                                               engine=self.engine, stream=self.stream)
+            else:
+                self.chain.wsci = _lib.wcs_struct(sci['wcs'])
+                self.chain.wref = _lib.wcs_struct(ref['wcs'])
+            self.key = key
+        ch = self.chain
+        diff, noise, mask = ch.run(sci['img'], sci['rms'], sci['mask'], sci.get('wgt'), ref['img'],
+                                   ref['rms'], ref['mask'], seeing=float(sci['seeing']),
+                                   nreg_side=job.nreg_side, hotpants_kws=job.hotpants_kws,
+                                   ref_flxscale=float(ref.get('flxscale', 1.0)))
+        out = dict(tag=job.tag, info={k: getattr(ch.info, k) for k, _ in ch.info._fields_})
+        if job.radec is not None:
+            # forced photometry on the planes that are still in HBM (scripts/dophot.py:131-133)
+            ra, dec = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in job.radec)
+            x, y = sci['wcs'].all_world2pix(ra, dec, 0)
+            n = x.size
+            with torch.cuda.stream(self.stream):
+                pos = torch.from_numpy(np.ascontiguousarray(np.stack([x, y]))).to(ch.device, non_blocking=True)
+                res = torch.empty((2, n), dtype=torch.float64, device=ch.device)
+                flg = torch.empty(n, dtype=torch.int32, device=ch.device)
+                ny_, nx_ = ch.shape
+                check(self.engine.L.zm_aperture_photometry_dev(
+                    self.engine.ctx, diff.data_ptr(), noise.data_ptr(), mask.data_ptr(), nx_, ny_, n,
+                    pos[0].data_ptr(), pos[1].data_ptr(), float(APERTURE_RADIUS), res[0].data_ptr(),
+                    res[1].data_ptr(), flg.data_ptr()), 'zm_aperture_photometry_dev')
+                res_h, flg_h = res.cpu(), flg.cpu()
+            out['phot'] = dict(x=x, y=y, flux=res_h[0].numpy(), fluxerr=res_h[1].numpy(), flags=flg_h.numpy())
+        if keep:
+            with torch.cuda.stream(self.stream):
+                out['diff'], out['noise'], out['mask'] = diff.clone(), noise.clone(), mask.clone()
+        self.stream.synchronize()
+        return out
+
+
+class SubtractionPool(object):
+    """``njobs`` subtraction chains running side by side on one GPU."""
+
+    def __init__(self, njobs=8, device=0):
+        if not 1 <= njobs <= 13:
+            raise ValueError('njobs must be in 1 .. 13 (the solver needs 18 resident workgroups per job)')
+        self.njobs, self.device = int(njobs), int(device)
+        _lib.lib()                                   # loaded once, here, not by racing worker threads
+        self._local = threading.local()
+        self._workers = []
+        self._lock = threading.Lock()
+        self._pool = ThreadPoolExecutor(max_workers=self.njobs)
+
+    def _worker(self):
+        w = getattr(self._local, 'w', None)
+        if w is None:
+            import torch
+            torch.cuda.set_device(self.device)
+            w = self._local.w = _Worker(self.device, self.njobs)
+            with self._lock:
+                self._workers.append(w)
+        return w
+
+    def _run(self, job, keep):
+        return self._worker().subtract(job, keep=keep)
+
+    def map(self, jobs, keep=True):
+        """Run every job; results in job order.  ``keep``: clone diff / noise / mask of each job
+        out of the worker's planes (off for throughput runs that only want the photometry)."""
+        import torch
+        torch.cuda.synchronize(self.device)               # inputs produced on other streams are complete
+        return list(self._pool.map(lambda j: self._run(j, keep), jobs))
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for w in self._workers:
+            w.chain = None
+            w.engine.close()
+        self._workers = []
