@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Nightly subtractions + forced photometry: the job of the reference's
+``scripts/donightly.py`` (per image: ``dosub.do_one``) followed by ``scripts/dophot.py``
+(``raw_aperture_photometry`` at known sky positions), database-free, with J subtractions in
+flight on the GPU (``nightly.SubtractionPool``).
+
+usage: donightly.py images.txt ref.fits [positions.txt] [--jobs J] [--nreg-side N]
+
+* ``images.txt``: science image paths (``*sciimg.fits``; the mask is ``*mskimg.fits``; a
+  ``.weight.fits`` sibling is required: 1 / rms^2, 0 on bad pixels).  The list is sharded over
+  ranks as ``zuds.get_my_share_of_work`` does (RANK / WORLD_SIZE, one rank per GPU).
+* ``ref.fits`` with ``ref.mask.fits`` and ``ref.weight.fits`` next to it.
+* ``positions.txt``: ``ra dec`` per line (degrees); forced r = 3 px apertures are measured on
+  every difference image and written to ``<sub>.phot.txt``
+  (columns of the reference's photometry table: ra dec flux fluxerr flags zp obsjd).
+
+Products per image, with the reference's names: ``sub.<sci>_<ref>.fits``, ``.rms.fits``,
+``.mask.fits`` next to the science image.  An image whose subtraction exists is skipped
+(the reference's checkpoint by name, ``scripts/dosub.py:85-94``)."""
+import argparse
+import importlib
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zuds_amd as zuds
+
+zuds.init_db()
+
+
+def load_reference(io, refname):
+    """The reference planes in HBM: image, rms (1 / sqrt(w), BIG_RMS where bad: zuds/image.py:173-208)
+    and mask."""
+    import torch
+    img, hdr = io.load(refname, 'f32')
+    wgt, _ = io.load(refname.replace('.fits', '.weight.fits'), 'f32')
+    mask, _ = io.load(refname.replace('.fits', '.mask.fits'), 'i32')
+    eng = io.engine
+    rms = torch.empty_like(img)
+    bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
+    with torch.cuda.stream(io.stream):
+        zuds._lib.check(eng.L.zm_mask_bad_dev(eng.ctx, mask.data_ptr(), None, zuds.BAD_SUM, mask.numel(),
+                                              None, bad.data_ptr()))
+        zuds._lib.check(eng.L.zm_rms_from_weight_dev(eng.ctx, wgt.data_ptr(), bad.data_ptr(), wgt.numel(),
+                                                     float(zuds.BIG_RMS), rms.data_ptr()))
+    io.stream.synchronize()
+    return dict(img=img, rms=rms, mask=mask, wcs=zuds.WCS.from_header(hdr),
+                flxscale=float(hdr.get('FLXSCALE', 1.0)), header=hdr, path=refname)
+
+
+def load_science(io, fn):
+    import torch
+    img, hdr = io.load(fn, 'f32')
+    mask, _ = io.load(fn.replace('sciimg', 'mskimg'), 'i32')
+    wgt, _ = io.load(fn.replace('.fits', '.weight.fits'), 'f32')
+    eng = io.engine
+    rms = torch.empty_like(img)
+    bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
+    with torch.cuda.stream(io.stream):
+        zuds._lib.check(eng.L.zm_mask_bad_dev(eng.ctx, mask.data_ptr(), None, zuds.BAD_SUM, mask.numel(),
+                                              None, bad.data_ptr()))
+        zuds._lib.check(eng.L.zm_rms_from_weight_dev(eng.ctx, wgt.data_ptr(), bad.data_ptr(), wgt.numel(),
+                                                     float(zuds.BIG_RMS), rms.data_ptr()))
+        if 'SATURATE' in hdr:         # zuds/image.py:203-204
+            rms = torch.where(img >= 0.9 * float(hdr['SATURATE']), torch.full_like(rms, float(zuds.BIG_RMS)), rms)
+    io.stream.synchronize()
+    if 'SEEING' not in hdr:
+        raise RuntimeError(f'{fn}: no SEEING card (run estimate_seeing on the frame first)')
+    return dict(img=img, rms=rms, mask=mask, wgt=wgt, wcs=zuds.WCS.from_header(hdr),
+                seeing=float(hdr['SEEING']), header=hdr, path=fn)
+
+
+def write_products(io, sci, ref, res):
+    out = zuds.sub_name(sci['path'], ref['path'])
+    hdr = dict(sci['header'])
+    hdr['KSUM00'] = float(res['info']['kernel_sum'])
+    hdr['NSTAMPS'] = int(res['info']['nstamps_used'])
+    io.save(out, res['diff'], hdr)
+    io.save(out.replace('.fits', '.rms.fits'), res['noise'], hdr)
+    mh = dict(sci['header'])
+    mh['BIT17'] = 17
+    io.save(out.replace('.fits', '.mask.fits'), res['mask'], mh)
+    if 'phot' in res:
+        p = res['phot']
+        zp = float(hdr.get('MAGZP', 0.0)) + float(hdr.get(zuds.APER_KEY, 0.0))
+        jd = float(hdr.get('OBSJD', 0.0))
+        ra, dec = sci['radec']
+        np.savetxt(out.replace('.fits', '.phot.txt'),
+                   np.column_stack([ra, dec, p['flux'], p['fluxerr'], p['flags'],
+                                    np.full(ra.size, zp), np.full(ra.size, jd)]),
+                   header='ra dec flux fluxerr flags zp obsjd', fmt=['%.8f', '%.8f', '%.6e', '%.6e', '%d', '%.5f', '%.6f'])
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('infile')
+    ap.add_argument('refname')
+    ap.add_argument('positions', nargs='?')
+    ap.add_argument('--jobs', type=int, default=4, help='subtractions in flight on the GPU')
+    ap.add_argument('--nreg-side', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='science frames resident at a time')
+    args = ap.parse_args(argv)
+
+    nightly = importlib.import_module('zuds-pipeline_amd.nightly')
+    device = importlib.import_module('zuds-pipeline_amd.device')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    imgs = [str(f) for f in zuds.get_my_share_of_work(args.infile)]
+    radec = None
+    if args.positions:
+        t = np.atleast_2d(np.loadtxt(args.positions))
+        radec = (t[:, 0].copy(), t[:, 1].copy())
+
+    io = device.FITSDeviceIO(local, engine=zuds.Engine(local))
+    ref = load_reference(io, args.refname)
+    pool = nightly.SubtractionPool(args.jobs, device=local)
+    done = []
+    try:
+        for b0 in range(0, len(imgs), args.batch):
+            t0 = time.time()
+            scis, jobs = [], []
+            for fn in imgs[b0:b0 + args.batch]:
+                if os.path.exists(zuds.sub_name(fn, args.refname)):
+                    print(f'{os.path.basename(fn)}: subtraction exists, skipping', flush=True)
+                    continue
+                try:
+                    sci = load_science(io, fn)
+                except Exception:
+                    traceback.print_exception(*sys.exc_info())
+                    continue
+                sci['radec'] = radec
+                scis.append(sci)
+                jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=args.nreg_side, tag=fn))
+            results = pool.map(jobs)
+            for sci, res in zip(scis, results):
+                if res['info']['status'] != 0:
+                    print(f'{os.path.basename(sci["path"])}: subtraction failed (status '
+                          f'{res["info"]["status"]}, {res["info"]["nstamps_used"]} stamps)', flush=True)
+                    continue
+                done.append(write_products(io, sci, ref, res))
+            if jobs:
+                print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)
+    finally:
+        pool.close()
+    return done
+
+
+if __name__ == '__main__':
+    main()
