@@ -194,3 +194,81 @@ def test_band_bounds_follow_array_split():
             b = par.band_bounds(n, w)
             ref = np.cumsum([0] + [len(c) for c in np.array_split(np.arange(n), w)]).tolist()
             assert b == ref
+
+
+# ---- four ranks: the default mask schedule is the banded one, shards of 2 + 1 + 1 + 1 frames,
+# ---- one collective for both partial-sum planes
+
+class OneBufferBackend(OracleBackend):
+    """partial_sums as HipBackend returns them: the two planes of one (2, ny, nx) buffer."""
+
+    def partial_sums(self, frames):
+        s1, s0 = OracleBackend.partial_sums(self, frames)
+        both = torch.stack([s1, s0]).contiguous()
+        return both[0], both[1]
+
+
+def four_worker(rank, world, port, kind, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = __import__('importlib').import_module('zuds-pipeline_amd.parallel')
+    base, frames = make_frames()
+    mine = frames[:2] if rank == 0 else frames[rank + 1:rank + 2]
+    out = {}
+    if kind == 'MASK':
+        calls = []
+        orig = dist.all_gather
+        dist.all_gather = lambda *a, **k: (calls.append(tuple(a[1].shape)), orig(*a, **k))[1]
+        acc = torch.from_numpy(partial_mask(mine, base, 'AND'))
+        par.reduce_masks(acc, np_accum('AND'), np_finalize)          # banded by default at 4 ranks
+        dist.all_gather = orig
+        out = dict(mask=acc.numpy().copy(), gathered=calls)
+    else:
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+        sc = par.ShardedCoadd(OneBufferBackend(base, kind))
+        img, wgt = sc.weighted(mine) if kind == 'WEIGHTED' else sc.exact(mine)
+        dist.all_reduce = orig
+        out = dict(img=img.numpy().copy(), wgt=wgt.numpy().copy(), reduced=calls)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['WEIGHTED', 'CLIPPED', 'MASK'])
+def test_four_ranks(kind):
+    base, frames = make_frames()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=four_worker, args=(r, 4, port, kind, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ny, nx = base.naxis[1], base.naxis[0]
+    if kind == 'MASK':
+        ref = partial_mask(frames, base, 'AND')
+        ref[ref == -1] = 0
+        for rank, out in results:
+            assert np.array_equal(out['mask'], ref), f'rank {rank}'
+            # banded: what is gathered is one padded band (19 of 75 rows), not the whole plane
+            assert out['gathered'] == [(19, nx)]
+    else:
+        ob = OracleBackend(base, kind)
+        if kind == 'WEIGHTED':
+            ref_img, ref_wgt = ob.finalize(*ob.partial_sums(frames))
+        else:
+            ref_img, ref_wgt = ob.combine(ob.resample_stack(frames))
+        for rank, out in results:
+            if kind == 'WEIGHTED':
+                np.testing.assert_allclose(out['img'], ref_img.numpy(), rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(out['wgt'], ref_wgt.numpy(), rtol=1e-12)
+                assert out['reduced'] == [2 * ny * nx]          # both planes in one collective
+            else:
+                assert np.array_equal(out['img'], ref_img.numpy()), f'rank {rank}'
+                assert np.array_equal(out['wgt'], ref_wgt.numpy()), f'rank {rank}'

@@ -72,8 +72,9 @@ class DeviceCoadd(object):
         self.wout = wcs_struct(wout)
         onx, ony = self.wout.naxis[0], self.wout.naxis[1]
         self.shape = (ony, onx)
-        self.img = torch.empty(self.shape, dtype=torch.float32, device=self.device)
-        self.wgt = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        # the two planes of one buffer: the multi-GPU reduce of the partial sums is one collective
+        self._planes = torch.empty((2,) + self.shape, dtype=torch.float32, device=self.device)
+        self.img, self.wgt = self._planes[0], self._planes[1]
         self.mask = self.mask_wgt = None
         if want_mask:
             self.mask = torch.empty(self.shape, dtype=torch.int32, device=self.device)
@@ -109,8 +110,8 @@ class DeviceCoadd(object):
         self.run(dframes, partial=True)
         with self.torch.cuda.stream(self.stream):
             if dist.is_initialized() and dist.get_world_size(group) > 1:
-                dist.all_reduce(self.img, op=dist.ReduceOp.SUM, group=group)
-                dist.all_reduce(self.wgt, op=dist.ReduceOp.SUM, group=group)
+                from .parallel import all_reduce_planes
+                all_reduce_planes(self.img, self.wgt, group)
             check(L.zm_coadd_finalize_dev(ctx, self.img.data_ptr(), self.wgt.data_ptr(),
                                           self.img.numel()), 'zm_coadd_finalize_dev')
             if self.mask is not None:

@@ -2,8 +2,9 @@
 (SURVEY.md section 8(e)).
 
 * WEIGHTED / AVERAGE: every rank reduces its frames to the partial sums
-  S1 = sum(w v), S0 = sum(w) on the common grid; one all-reduce per plane
-  (RCCL over xGMI with the ``nccl`` backend), then S1 / S0.
+  S1 = sum(w v), S0 = sum(w) on the common grid - two planes of ONE buffer, one
+  all-reduce (RCCL over xGMI with the ``nccl`` backend: a reduce-scatter and an
+  all-gather over the 7 links of a GPU, 2 x 75.5 MB / 8 per link and phase), then S1 / S0.
 * CLIPPED / MEDIAN are not sums: the per-pixel median needs every sample, so the
   resampled stacks are transposed from frame-sharded to row-band-sharded with an
   all-to-all (rank g receives rows [b_g, b_{g+1}) of all N frames), each rank
@@ -40,11 +41,13 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
     every rank ends with the same mask whatever the order.  NCCL / RCCL have no bitwise
     reductions; two exact schedules:
 
-    * all-gather of the whole masks and a local fold: world x 4 B / px per rank (default: one
-      collective of the most travelled kind);
-    * ``banded`` (``banded=True`` or ZM_MASK_BANDED=1): a reduce-scatter by hand - rank g
-      receives row band g of every rank (grouped send / recv, as the CLIPPED exchange), folds
-      it, and the folded bands are all-gathered: 2 x 4 B / px per rank whatever the world size.
+    * all-gather of the whole masks and a local fold: world x 4 B / px per rank (one collective
+      of the most travelled kind; the default below 4 ranks);
+    * ``banded`` (the default from 4 ranks on; ``banded=`` or ZM_MASK_BANDED=0 / 1 override): a
+      reduce-scatter by hand - rank g receives row band g of every rank (grouped send / recv, as
+      the CLIPPED exchange; the bands are row ranges of a C-contiguous plane, sent in place), folds
+      it, and the folded bands are all-gathered: 2 x 4 B / px per rank whatever the world size
+      (8 ranks: 75 MB instead of 302 MB received per rank).
     """
     import torch
     import torch.distributed as dist
@@ -53,7 +56,8 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
     rank = dist.get_rank(group) if on else 0
     if banded is None:
         import os
-        banded = os.environ.get('ZM_MASK_BANDED', '0') not in ('', '0')
+        env = os.environ.get('ZM_MASK_BANDED', '')
+        banded = (world >= 4) if env == '' else env != '0'
     if world > 1 and not banded:
         parts = [torch.empty_like(acc) for _ in range(world)]
         dist.all_gather(parts, acc.contiguous(), group=group)
@@ -70,7 +74,7 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
         for g in range(world):
             if g == rank:
                 continue
-            band = acc[bounds[g]:bounds[g + 1]].contiguous()
+            band = acc[bounds[g]:bounds[g + 1]]          # rows of a contiguous plane: contiguous
             if band.numel():
                 ops.append(dist.P2POp(dist.isend, band, peer(g), group))
             if recv[g].numel():
@@ -92,6 +96,21 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
             acc[bounds[g]:bounds[g + 1]] = allp[g][:bounds[g + 1] - bounds[g]]
     finalize(acc)
     return acc
+
+
+def all_reduce_planes(s1, s0, group=None):
+    """Sum-reduce the two partial-sum planes across ranks with ONE collective when they are the
+    two halves of one buffer (``HipBackend.partial_sums``, ``DeviceCoadd``), else one each."""
+    import torch.distributed as dist
+    n = s1.numel()
+    if (s1.is_contiguous() and s0.is_contiguous() and s1.dtype == s0.dtype
+            and s1.untyped_storage().data_ptr() == s0.untyped_storage().data_ptr()
+            and s0.storage_offset() == s1.storage_offset() + n):
+        both = s1.new_empty(0).set_(s1.untyped_storage(), s1.storage_offset(), (2 * n,))
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=group)
 
 
 class HipBackend(object):
@@ -134,12 +153,14 @@ class HipBackend(object):
         torch = self.torch
         stack = stack.contiguous()
         n, rows, nx, _ = stack.shape
-        img = torch.empty((rows, nx), dtype=torch.float32, device=self.device)
-        wgt = torch.empty((rows, nx), dtype=torch.float32, device=self.device)
-        if rows * nx == 0:
-            return img, wgt
         self.engine.set_stream(self.stream.cuda_stream)
+        # whatever produced `stack` on the caller's stream is complete before the kernels here
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
+            img = torch.empty((rows, nx), dtype=torch.float32, device=self.device)
+            wgt = torch.empty((rows, nx), dtype=torch.float32, device=self.device)
+            if rows * nx == 0:
+                return img, wgt
             check(self.engine.L.zm_combine_stack_dev(self.engine.ctx, n, stack.data_ptr(),
                                                      rows * nx, rows * nx, C.byref(self.params),
                                                      img.data_ptr(), wgt.data_ptr()),
@@ -147,12 +168,14 @@ class HipBackend(object):
         return img, wgt
 
     def partial_sums(self, frames):
+        """(s1, s0): the two planes of one (2, ny, nx) buffer, so that a single collective reduces both."""
         torch = self.torch
         df = self.frames(frames)
-        s1 = torch.empty(self.shape, dtype=torch.float32, device=self.device)
-        s0 = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
+            both = torch.empty((2,) + tuple(self.shape), dtype=torch.float32, device=self.device)
+            s1, s0 = both[0], both[1]
             check(self.engine.L.zm_coadd_dev(self.engine.ctx, df.n, df.arr, C.byref(self.wout),
                                              C.byref(self.params), 1, s1.data_ptr(),
                                              s0.data_ptr(), None, None), 'zm_coadd_dev')
@@ -215,8 +238,7 @@ class ShardedCoadd(object):
         s1, s0 = self.backend.partial_sums(frames)
         with self.backend.scope():
             if world > 1:
-                dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_planes(s1, s0, self.group)
         return self.backend.finalize(s1, s0)
 
     def exact(self, frames, want_mask=False):
@@ -238,24 +260,31 @@ class ShardedCoadd(object):
             dist.all_gather(allc, counts, group=self.group)
             nfr = [int(c.item()) for c in allc]
             my_rows = bounds[rank + 1] - bounds[rank]
-            # band g of my stack goes to rank g; I receive my band of every rank's stack
-            send = [stack[:, bounds[g]:bounds[g + 1]].contiguous() for g in range(world)]
-            recv = [self.backend.empty((nfr[g], my_rows, nx, 2)) for g in range(world)]
-            # grouped point-to-point exchange (ncclSend / ncclRecv on RCCL; also
-            # available on gloo, which has no all-to-all)
-            recv[rank].copy_(send[rank])
+            # band g of my stack goes to rank g; I receive my band of every rank's stack.  Rows
+            # [b_g, b_g+1) of ONE frame are contiguous in the (n, ny, nx, 2) stack, so every frame
+            # is sent in place (no per-destination copy of the stack) and received straight into
+            # its slot of the (N, my_rows, nx, 2) band (no concatenation afterwards): the exchange
+            # holds the stack and the band, nothing else.  Grouped point-to-point operations
+            # (ncclSend / ncclRecv on RCCL; also available on gloo, which has no all-to-all).
+            first = [0]
+            for g in range(world):
+                first.append(first[-1] + nfr[g])
+            band = self.backend.empty((first[-1], my_rows, nx, 2))
+            if my_rows:
+                band[first[rank]:first[rank + 1]].copy_(stack[:, bounds[rank]:bounds[rank + 1]])
             ops = []
             for g in range(world):
                 if g == rank:
                     continue
-                if send[g].numel():
-                    ops.append(dist.P2POp(dist.isend, send[g], self._peer(g), self.group))
-                if recv[g].numel():
-                    ops.append(dist.P2POp(dist.irecv, recv[g], self._peer(g), self.group))
+                if bounds[g + 1] > bounds[g]:
+                    for i in range(n_local):
+                        ops.append(dist.P2POp(dist.isend, stack[i, bounds[g]:bounds[g + 1]], self._peer(g), self.group))
+                if my_rows:
+                    for i in range(nfr[g]):
+                        ops.append(dist.P2POp(dist.irecv, band[first[g] + i], self._peer(g), self.group))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            band = torch.cat(recv, dim=0)                    # (N, my_rows, nx, 2), rank order
         img_b, wgt_b = self.backend.combine(band)
         with self.backend.scope():
             # bands may differ by one row: gather through padded buffers
