@@ -32,12 +32,35 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= bound | {'zm_debug_lanczos3'}, set(names) - bound
 
 
-def test_struct_sizes_match_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every POD struct of include/zudsmi.h as a C compiler sees them,
+    against the ctypes mirrors the Python layer binds with (a probe compiled from the header
+    itself, not hand-written constants)."""
+    import os
+    import subprocess
     z = pkg()
-    assert C.sizeof(z._lib.zm_wcs) == 8 * (2 + 2 + 4 + 40 + 40) + 16
-    assert C.sizeof(z._lib.zm_coadd_params) == 8 * 4 + 3 * 8
-    assert C.sizeof(z._lib.zm_hp_params) == 8 * 8 + 8 * 4 + 2 * 8 + 8 * 4 + 4 * 8
-    assert C.sizeof(z._lib.zm_frame) == 3 * 8 + C.sizeof(z._lib.zm_wcs) + 8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {'zm_wcs': z._lib.zm_wcs, 'zm_frame': z._lib.zm_frame, 'zm_dframe': z._lib.zm_dframe,
+               'zm_coadd_params': z._lib.zm_coadd_params, 'zm_hp_params': z._lib.zm_hp_params,
+               'zm_hp_info': z._lib.zm_hp_info}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zudsmi.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} . %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'probe.c'
+    src.write_text('\n'.join(lines) + '\n')
+    exe = tmp_path / 'probe'
+    subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    seen = 0
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        name, field, value = line.split()
+        cls = structs[name]
+        want = C.sizeof(cls) if field == '.' else getattr(cls, field).offset
+        assert int(value) == want, (name, field, int(value), want)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
 
 
 def test_last_error_is_set_on_bad_arguments():

@@ -191,3 +191,22 @@ def test_coadd_argument_checks_do_not_need_a_gpu(tmp_path):
         z.MultiEpochSubtraction.from_images(im, im)
     with pytest.raises(ValueError, match='weight map or'):
         z.SingleEpochSubtraction.from_images(im, im)
+
+
+def test_job_params_follow_prepare_hotpants_and_clamp_large_seeing():
+    """zuds/hotpants.py:44-93: r = 2.5 SEEING, rss = 6 SEEING, NAXIS / 100 / nreg_side stamps
+    (integer), limits 5e3, -bgo 0 -ko 4 unless overridden; SEEING > 6.4 px is clamped to the
+    largest kernel libzudsmi instantiates, with a warning, instead of failing."""
+    import importlib
+    import warnings
+    hp = importlib.import_module('zuds-pipeline_amd.hotpants')
+    p = hp.job_params(4.0, 3072, 3080, 3, il=-12.5, tl=-40.0)
+    assert (p['r'], p['rss'], p['nsx'], p['nsy'], p['nrx'], p['nry']) == (10.0, 24.0, 10, 10, 3, 3)
+    assert (p['ko'], p['bgo'], p['tu'], p['iu'], p['il'], p['tl']) == (4, 0, 5e3, 5e3, -12.5, -40.0)
+    p = hp.job_params(2.0, 512, 512, 3, 0, 0, {'ko': '1', 'bgo': 2, 'n': 't', 'ks': '3.5', 'v': 0})
+    assert (p['nsx'], p['ko'], p['bgo'], p['normalize'], p['ks']) == (1, 1, 2, 1, 3.5) and 'v' not in p
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        p = hp.job_params(9.0, 3072, 3080, 3, 0, 0)
+    assert len(w) == 1 and 'clamped' in str(w[0].message)
+    assert int(p['r']) == 15 and int(p['rss']) == 48

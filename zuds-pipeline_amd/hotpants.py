@@ -12,6 +12,7 @@ from .utils import initialize_directory, quick_background_estimate
 
 __all__ = ['prepare_hotpants', 'HotpantsCall']
 
+MAX_R, MAX_RSS = 15, 48             # largest kernel / substamp half widths of zm_subtract
 _INT_KEYS = ('ko', 'bgo', 'nss', 'nsx', 'nsy', 'nrx', 'nry')
 _FLT_KEYS = ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks')
 
@@ -23,8 +24,18 @@ def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
     5e3, ``-bgo 0 -ko 4`` unless overridden.  Shared by ``prepare_hotpants`` and the
     device-resident chain (``device.DeviceSubtraction``) so the two cannot drift apart."""
     satlev = 5e3
-    params = dict(tu=satlev, iu=satlev, tl=float(tl), il=float(il), r=2.5 * seeing,
-                  rss=6. * seeing, fin=float(BIG_RMS),
+    r, rss = 2.5 * seeing, 6. * seeing
+    if int(r) > MAX_R or int(rss) > MAX_RSS:
+        # hotpants takes any half width; libzudsmi's convolution kernels are instantiated up to
+        # 15 (31 x 31 taps) and its substamps up to 48.  A frame with SEEING > 6.4 px is still
+        # subtracted, with the largest kernel available, instead of being dropped by the drivers'
+        # try / except (scripts/dosub.py:205-213)
+        import warnings
+        warnings.warn(f'SEEING {seeing:.2f} px asks for -r {r:.1f} -rss {rss:.1f}; clamped to '
+                      f'-r {min(r, MAX_R + 0.99):.2f} -rss {min(rss, MAX_RSS + 0.99):.2f}')
+        r, rss = min(r, MAX_R + 0.99), min(rss, MAX_RSS + 0.99)
+    params = dict(tu=satlev, iu=satlev, tl=float(tl), il=float(il), r=r,
+                  rss=rss, fin=float(BIG_RMS),
                   nsx=max(int(naxis1 / 100. / nreg_side), 1),
                   nsy=max(int(naxis2 / 100. / nreg_side), 1),
                   nrx=int(nreg_side), nry=int(nreg_side), bgo=0, ko=4, normalize=0)
