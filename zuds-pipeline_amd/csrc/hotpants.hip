@@ -901,6 +901,72 @@ __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail)
     if (bad && lane == 0 && fail) atomicAdd(fail, 1);
 }
 
+// The same factorisation in four panels of eight columns.  The register scheme above spends
+// most of its 7 us on the rank-1 updates: column j is broadcast lane by lane (2 readlanes + 1
+// FMA per remaining column, ~500 of each).  Here only the 8 columns of a panel are updated that
+// way; the rest of the block gets the panel's rank-8 update on the f64 matrix cores (two
+// v_mfma_f64_16x16x4 per 16 x 16 tile of the lower triangle, 10 in all), through LDS.  The 32
+// dependent reciprocal square roots remain.  One wave; LDS operations of a wave execute in
+// order, so the panel written by the lanes is what the matrix-core operands read back.
+__device__ inline void chol_diag_wave_panel(double (*D)[CH_NB + 1], int nb, int* fail) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, li = lane & 15, lk = lane >> 4;
+    int bad = 0;
+    double dinv = 1.0;                                   // 1 / L[row][row]
+#pragma unroll
+    for (int p = 0; p < CH_NB / 8; ++p) {
+        const int c0 = 8 * p, c1 = c0 + 8;
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = D[row][c0 + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double ajj = readlane_d(a[j], c0 + j);
+            if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
+            double ri = __builtin_amdgcn_rsq(ajj);
+            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+            const double dj = ajj * ri;
+            const double lj = (row == c0 + j) ? dj : a[j] * ri;   // L[row][c0 + j] (meaningful for row >= c0 + j)
+            if (row == c0 + j) dinv = ri;
+            a[j] = lj;
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) {
+                const double lc = readlane_d(lj, c0 + c);
+                a[c] -= lj * lc;
+            }
+        }
+        if (lane < CH_NB) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
+        }
+        if (c1 < CH_NB) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) {
+                    if (16 * (ti + 1) <= c1 || 16 * (tj + 1) <= c1) continue;     // tile above / left of the trailing part
+                    double4_t c4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c4[q] = D[16 * ti + lk + 4 * q][16 * tj + li];
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const double av = -D[16 * ti + li][c0 + 4 * kk + lk];
+                        const double bv = D[16 * tj + li][c0 + 4 * kk + lk];
+                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * ti + lk + 4 * q, jc = 16 * tj + li;
+                        if (i >= c1 && jc >= c1 && jc <= i) D[i][jc] = c4[q];
+                    }
+                }
+        }
+    }
+    if (lane < CH_NB) D[row][CH_NB] = dinv;
+    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
+}
+
 // ---- the whole factorisation in one launch ----------------------------------------
 // W workgroups per region walk the 32-column blocks together; a region-wide barrier (a
 // monotone counter in global memory, agent-scope release / acquire) separates the panel
@@ -986,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
     auto factor_and_publish = [&](int k0, int nb, int slot) {
         double* Dg = Dg2 + (size_t)slot * CH_NB * (CH_NB + 1);
         __syncthreads();
-        if (tid < 64) chol_diag_wave(D, nb, &fail[reg]);
+        if (tid < 64) chol_diag_wave_panel(D, nb, &fail[reg]);
         __syncthreads();
         for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) st_sh(&Dg[e], D[e / (CH_NB + 1)][e % (CH_NB + 1)]);
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
