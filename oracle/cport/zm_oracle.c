@@ -159,15 +159,20 @@ void zo_resample(const float* img, const float* wgt, const int32_t* mask, int nx
                 tx[0] = 1.0 - dx; tx[1] = dx; ty[0] = 1.0 - dy; ty[1] = dy;
             }
             long x0 = ix + off, y0 = iy + off;
-            int inb = x0 >= 0 && x0 + nt <= nx && y0 >= 0 && y0 + nt <= ny;
+            /* non-zero taps on the frame, per axis: the whole footprint, or the centre pixel of a
+             * delta kernel (oracle.resample.on_frame) */
+            int inbx = ddx ? (ix >= 0 && ix < nx) : (x0 >= 0 && x0 + nt <= nx);
+            int inby = ddy ? (iy >= 0 && iy < ny) : (y0 >= 0 && y0 + nt <= ny);
+            int inb = inbx && inby;
             double acc = 0, vacc = 0;
             int anybad = 0;
             int64_t macc = 0;
             if (inb)
                 for (int r = 0; r < nt; ++r)
                     for (int c = 0; c < nt; ++c) {
-                        size_t q = (size_t)(y0 + r) * nx + (x0 + c);
                         double wt = ty[r] * tx[c];
+                        if (wt == 0.0) continue;          /* (may lie off the frame next to a delta axis) */
+                        size_t q = (size_t)(y0 + r) * nx + (x0 + c);
                         double var = 1.0;
                         int bad = 0;
                         if (wgt) {

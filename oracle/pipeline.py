@@ -43,10 +43,8 @@ def coadd_from_images(frames, addbkg=True, combine='CLIPPED', mesh=128):
         vals.append(o)
         wgts.append(w)
         masks.append(m)
-        ix, _, _ = ores.split_position(px)
-        iy, _, _ = ores.split_position(py)
         nx, ny = f['wcs'].naxis
-        cov.append((ix - 2 >= 0) & (ix + 4 <= nx) & (iy - 2 >= 0) & (iy + 4 <= ny))
+        cov.append(ores.coverage(px, py, nx, ny))
     img, wgt, _ = ocombine.combine(np.array(vals), np.array(wgts), combine)
     msk, mcov = ocombine.combine_masks(np.array(masks), np.array(cov), 'AND')
     msk = msk + np.where(mcov == 0, 2 ** 16, 0)         # zuds/mask.py:26-33

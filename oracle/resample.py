@@ -15,8 +15,11 @@ Arithmetic (SWarp >= 2.38 ``interpolate.c`` as published; adopted conventions):
   is normalised to unit sum;
 * ``d < 1e-5`` (or ``d > 1 - 1e-5``: snapped to the next pixel) gives a delta;
 * the variance plane is interpolated with the same (unsquared) taps;
-* an output pixel is *bad* (value 0, weight 0) when its 6x6 footprint leaves the
-  input frame, when any tap with non-zero weight lands on a bad input pixel
+* an output pixel is *bad* (value 0, weight 0) when a tap with non-zero weight
+  falls outside the input frame - per axis: the 6-tap footprint, or for a delta
+  kernel (every other tap is exactly 0) its centre pixel only, so that identity /
+  integer-shift alignments keep their borders, as SWarp's edge-truncated kernels
+  do - when any tap with non-zero weight lands on a bad input pixel
   (weight <= WEIGHT_THRESH), or when the interpolated variance is <= 0;
 * flux: ``out = interp * fscale``, variance ``* fscale**2`` where ``fscale`` =
   FLXSCALE x (A_out / A_in) (fixed pixel-area ratio).
@@ -59,6 +62,22 @@ def split_position(p):
     delta = d < SNAP
     d = np.where(delta, 0.0, d)
     return i.astype(np.int64), d, delta
+
+
+def on_frame(i, delta, n, kind):
+    """Do the non-zero taps of one axis lie on the frame?  i: floor index, delta: snapped
+    (delta kernel: only the centre tap at i is non-zero), n: axis length."""
+    nt, off = (6, -2) if kind == LANCZOS3 else (2, 0)
+    full = (i + off >= 0) & (i + off + nt <= n)
+    centre = (i >= 0) & (i < n)
+    return np.where(delta, centre, full)
+
+
+def coverage(px, py, nx, ny, kind=LANCZOS3):
+    """Boolean map of the output pixels whose non-zero taps all lie on the nx x ny frame."""
+    ix, _, ddx = split_position(px)
+    iy, _, ddy = split_position(py)
+    return on_frame(ix, ddx, nx, kind) & on_frame(iy, ddy, ny, kind)
 
 
 def taps_for(d, delta, kind):
@@ -123,7 +142,7 @@ def resample(img, wgt, px, py, kind=LANCZOS3, fscale=1.0, mask=None,
         nt = tx.shape[-1]
         x0 = ix + off
         y0 = iy + off
-        inb = (x0 >= 0) & (x0 + nt <= nx) & (y0 >= 0) & (y0 + nt <= ny)
+        inb = on_frame(ix, ddx, nx, kind) & on_frame(iy, ddy, ny, kind)
         acc = np.zeros(ix.shape)
         vacc = np.zeros(ix.shape)
         anybad = np.zeros(ix.shape, dtype=bool)

@@ -31,12 +31,10 @@ def frame():
 def test_identity_resample_is_bit_exact(engine, frame):
     o, ow, om = engine.resample(frame['img'], frame['wcs'], frame['wcs'], wgt=frame['wgt'],
                                 mask=frame['mask'])
-    inner = (slice(2, -3), slice(2, -3))
-    good = frame['wgt'][inner] > 0
-    assert np.array_equal(o[inner][good], frame['img'][inner][good])
-    assert np.array_equal(ow[inner] > 0, good)
-    assert np.array_equal(om[inner], frame['mask'][inner])
-    assert not ow[:2].any() and not ow[:, -3:].any()
+    good = frame['wgt'] > 0
+    assert np.array_equal(o[good], frame['img'][good])
+    assert np.array_equal(ow > 0, good)                 # delta kernels: the border is kept
+    assert np.array_equal(om, frame['mask'])
 
 
 def test_integer_shift_is_bit_exact_through_tpv(engine, frame):

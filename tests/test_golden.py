@@ -201,3 +201,34 @@ def test_oracle_reproduces_photometry_golden():
     np.testing.assert_allclose(e, g['fluxerr'], rtol=1e-13, atol=1e-13)
     assert np.array_equal(fl, g['flags'])
     assert f[-1] == 0 and e[-1] == 0                      # aperture off the frame
+
+
+def test_footprint_rule_per_axis_delta_kernels_keep_their_border():
+    """oracle/resample.py::on_frame: an axis with six live taps needs its whole footprint on
+    the frame; a delta axis (identity / integer shift) only its centre pixel - SWarp truncates
+    kernels at the frame edge and keeps such pixels."""
+    from oracle import resample as ores
+    rng = np.random.default_rng(3)
+    img = rng.normal(100, 5, (40, 50))
+    yo, xo = np.mgrid[0:40, 0:50].astype(np.float64)
+    # identity: everything kept, exactly
+    o, w, _ = ores.resample(img, None, xo, yo)
+    assert np.array_equal(o, img) and (w > 0).all()
+    # integer shift: what maps onto the frame is kept up to its edge
+    o, w, _ = ores.resample(img, None, xo + 7, yo - 3)
+    assert np.array_equal(w > 0, (xo + 7 < 50) & (yo - 3 >= 0))
+    assert np.array_equal(o[3:, :43], img[:-3, 7:])
+    # half a pixel along x only: 2 / 3 columns lost, no row lost
+    o, w, _ = ores.resample(img, None, xo + 0.5, yo)
+    assert np.array_equal(w > 0, (xo - 2 >= 0) & (xo + 3 <= 49))
+    assert np.array_equal(ores.coverage(xo + 0.5, yo, 50, 40), w > 0)
+    # the C port follows
+    from oracle import cport
+    c = cport.load()
+    m = (rng.uniform(size=img.shape) < 0.05).astype(np.int32) * 4
+    for px, py in ((xo, yo), (xo + 7, yo - 3), (xo + 0.5, yo), (xo - 0.25, yo + 0.75)):
+        a = ores.resample(img.astype(np.float32), None, px, py, ores.LANCZOS3, 1.0, m)
+        b = c.resample(img.astype(np.float32), None, px, py, 3, 1.0, m)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
+        assert np.array_equal(b[2], a[2])

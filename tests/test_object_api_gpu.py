@@ -77,9 +77,7 @@ def test_coadd_products_and_bookkeeping(products):
     cov = np.zeros(m.shape, dtype=bool)
     for f in frames[:3]:
         px, py = ores.positions(wout, to_oracle_wcs(f['wcs']), *wout.naxis)
-        ix, _, _ = ores.split_position(px)
-        iy, _, _ = ores.split_position(py)
-        cov |= (ix - 2 >= 0) & (ix + 4 <= 512) & (iy - 2 >= 0) & (iy + 4 <= 512)
+        cov |= ores.coverage(px, py, 512, 512)
     assert (b16 != ~cov).mean() < 2e-4
     assert ref.mask_image.header['BIT16'] == 16
 

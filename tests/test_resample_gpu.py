@@ -43,19 +43,29 @@ def check(engine, img, wgt, mask, win, wout, kernel='LANCZOS3', fscale=1.0,
     return g_img, g_wgt, g_msk
 
 
-def test_identity_is_exact_away_from_border(engine):
+def test_identity_is_exact_up_to_the_border(engine):
+    """Delta kernels have one non-zero tap per axis: an identity alignment keeps every pixel,
+    border included (the 6 x 6 footprint rule only applies to axes with six live taps)."""
     s = synth()
     f = s.make_frame(200, 150, 7, s.tan_wcs(200, 150), nbad=40)
     g_img, g_wgt, g_msk = engine.resample(f['img'], f['wcs'], f['wcs'],
                                           wgt=f['wgt'], mask=f['mask'])
-    inner = (slice(2, -3), slice(2, -3))
-    good = f['wgt'][inner] > 0
-    assert np.array_equal(g_img[inner][good], f['img'][inner][good])
-    assert np.array_equal(g_wgt[inner] > 0, good)      # delta taps: bad stays a single pixel
-    assert np.array_equal(g_msk[inner], f['mask'][inner])
-    # footprint rule: 2 px low side, 3 px high side carry no data
-    assert np.all(g_wgt[:2] == 0) and np.all(g_wgt[-3:] == 0)
-    assert np.all(g_wgt[:, :2] == 0) and np.all(g_wgt[:, -3:] == 0)
+    good = f['wgt'] > 0
+    assert np.array_equal(g_img[good], f['img'][good])
+    assert np.array_equal(g_wgt > 0, good)              # delta taps: bad stays a single pixel
+    assert np.array_equal(g_msk, f['mask'])
+    assert g_wgt[0, 0] > 0 and g_wgt[-1, -1] > 0
+
+
+def test_half_pixel_shift_along_one_axis_keeps_the_border_of_the_other(engine):
+    """dx = 0.5, dy = 0: six live taps along x (2 / 3 columns lost), a delta along y (no row lost)."""
+    s = synth()
+    f = s.make_frame(160, 120, 9, s.tan_wcs(160, 120), nbad=0)
+    wout = s.tan_wcs(160, 120, dx=0.5)                  # out (x, y) = in (x - 0.5, y)
+    g_img, g_wgt, _ = engine.resample(f['img'], f['wcs'], wout, wgt=f['wgt'])
+    cols = np.nonzero((g_wgt > 0).any(axis=0))[0]
+    assert (g_wgt > 0)[:, cols[0]:cols[-1] + 1].all()   # every row of the covered columns
+    assert cols[0] == 3 and cols[-1] == 160 - 3         # floor(x - 0.5) - 2 >= 0, floor(x - 0.5) + 3 <= 159
 
 
 def test_integer_shift_is_exact(engine):

@@ -93,11 +93,9 @@ def partial_mask(frames, base, kind):
     for f in frames:
         px, py = oresample.positions(to_oracle_wcs(base), to_oracle_wcs(f['wcs']), onx, ony)
         _, _, m = oresample.resample(f['img'], f['wgt'], px, py, oresample.LANCZOS3, 1.0, f['mask'])
-        ix, _, _ = oresample.split_position(px)
-        iy, _, _ = oresample.split_position(py)
         nx, ny = f['wcs'].naxis
         masks.append(m)
-        cov.append((ix - 2 >= 0) & (ix + 4 <= nx) & (iy - 2 >= 0) & (iy + 4 <= ny))
+        cov.append(oresample.coverage(px, py, nx, ny))
     m, c = ocombine.combine_masks(np.array(masks), np.array(cov), kind)
     return np.where(c > 0, m, -1).astype(np.int32)
 

@@ -883,7 +883,11 @@ __global__ __launch_bounds__(256, 4) void k_resample(
             split_pos(px, &ixr, &dx, &ddx);
             split_pos(py, &iyr, &dy, &ddy);
             const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;   // first tap, absolute
-            const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
+            // the non-zero taps must lie on the frame: per axis the whole footprint, or only the
+            // centre pixel of a delta kernel (oracle/resample.py::on_frame)
+            const bool inbx = ddx ? (ix + CI >= 0 && ix + CI < nx) : (ix >= 0 && ix + NT <= nx);
+            const bool inby = ddy ? (iy + CI >= 0 && iy + CI < ny) : (iy >= 0 && iy + NT <= ny);
+            const bool inb = touches && inbx && inby;
             float2 res = make_float2(0.f, 0.f);
             int32_t mres = 0;
             uint32_t m16 = 0;                     // box-OR entry of a non-delta footprint
@@ -950,11 +954,16 @@ __global__ __launch_bounds__(256, 4) void k_resample(
 #pragma unroll
                     for (int r = 0; r < NT; ++r) {
                         float ra = 0.f, rv = 0.f;
+                        // (zero taps of a delta axis may lie off the frame: not read)
+                        if (tw[r].y != 0.f) {
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) {
-                            float2 s = p[c];
-                            ra = fmaf(tw[c].x, s.x, ra);
-                            rv = fmaf(tw[c].x, s.y, rv);
+                            for (int c = 0; c < NT; ++c) {
+                                if (tw[c].x != 0.f) {
+                                    float2 s = p[c];
+                                    ra = fmaf(tw[c].x, s.x, ra);
+                                    rv = fmaf(tw[c].x, s.y, rv);
+                                }
+                            }
                         }
                         acc = fmaf(tw[r].y, ra, acc);
                         vacc = fmaf(tw[r].y, rv, vacc);
@@ -1136,7 +1145,9 @@ __global__ __launch_bounds__(256) void k_resample_mask(const int32_t* __restrict
         split_pos(py, &iyr, &dy, &ddy);
         const int ix = hdr.bx0 + ixr + OFF, iy = hdr.by0 + iyr + OFF;
         int32_t m = fill;
-        if (ix >= 0 && ix + NT <= nx && iy >= 0 && iy + NT <= ny) {
+        const bool inbx = ddx ? (ix - OFF >= 0 && ix - OFF < nx) : (ix >= 0 && ix + NT <= nx);
+        const bool inby = ddy ? (iy - OFF >= 0 && iy - OFF < ny) : (iy >= 0 && iy + NT <= ny);
+        if (inbx && inby) {
             m = 0;
             // delta kernels only touch the centre tap (index -OFF)
             int c0 = ddx ? -OFF : 0, c1 = ddx ? -OFF + 1 : NT;
@@ -1307,7 +1318,9 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
     split_pos(px, &ixr, &dx, &ddx);
     split_pos(py, &iyr, &dy, &ddy);
     const int ix = bx0 + ixr + OFF, iy = by0 + iyr + OFF;
-    const bool inb = touches && (ix >= 0) && (ix + NT <= nx) && (iy >= 0) && (iy + NT <= ny);
+    const bool inbx = ddx ? (ix + CI >= 0 && ix + CI < nx) : (ix >= 0 && ix + NT <= nx);
+    const bool inby = ddy ? (iy + CI >= 0 && iy + CI < ny) : (iy >= 0 && iy + NT <= ny);
+    const bool inb = touches && inbx && inby;
     ff_px r;
     r.v = 0.f; r.w = 0.f; r.m = 0; r.inb = inb;
     if (!inb) return r;
@@ -1367,11 +1380,15 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
 #pragma unroll
         for (int rr = 0; rr < NT; ++rr) {
             float ra = 0.f, rv = 0.f;
+            if (ty[rr] != 0.f) {                // (zero taps of a delta axis may lie off the frame: not read)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                const float2 s = zm_gload2(p + c);
-                ra = fmaf(tx[c], s.x, ra);
-                rv = fmaf(tx[c], s.y, rv);
+                for (int c = 0; c < NT; ++c) {
+                    if (tx[c] != 0.f) {
+                        const float2 s = zm_gload2(p + c);
+                        ra = fmaf(tx[c], s.x, ra);
+                        rv = fmaf(tx[c], s.y, rv);
+                    }
+                }
             }
             acc = fmaf(ty[rr], ra, acc);
             vacc = fmaf(ty[rr], rv, vacc);
