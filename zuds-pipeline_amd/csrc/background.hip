@@ -264,119 +264,12 @@ struct bk_batch {
     const float* wgt[BK_BATCH];
 };
 
-__global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_batch B, int nmode,
-                                                                 int nx, int ny, int mesh, int nbx,
-                                                                 int nby, float wthresh, int mode0,
-                                                                 int vec_ok, int dbg,
-                                                                 mesh_dump* __restrict__ dump) {
-    extern __shared__ char smem_raw[];
-    meshf_lds* S = reinterpret_cast<meshf_lds*>(smem_raw);
-    const int frame = blockIdx.z / nmode;
-    const int mode = mode0 + (blockIdx.z - frame * nmode);
-    const float* __restrict__ img = B.img[frame];
-    const float* __restrict__ wgt = B.wgt[frame];
-    const int mi = blockIdx.x, mj = blockIdx.y;
-    const int x0 = mi * mesh, y0 = mj * mesh;
-    const int w = min(mesh, nx - x0), h = min(mesh, ny - y0);
-    const int area = w * h;
+// The statistic of one mesh from its 32 px per thread (NaN = not a sample): pivot, two moment passes,
+// histogram, prefix arrays -> *D.  Every branch is uniform over the workgroup.
+__device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area, meshf_lds* S,
+                                             mesh_dump* __restrict__ D, const int dbg) {
     const int tid = threadIdx.x;
     const float qnan = __builtin_nanf("");
-
-    // ---- load: BKF_PX / 4 passes of BKF_ROWS rows x 128 columns, 4 px per thread per pass
-    float v[BKF_PX];
-    const int c4 = (tid & 31) * 4, r32 = tid >> 5;
-#pragma unroll
-    for (int k = 0; k < BKF_PX / 4; ++k) {
-        const int row = BKF_ROWS * k + r32;
-        float pv[4] = {qnan, qnan, qnan, qnan};
-        float pw[4] = {1.f, 1.f, 1.f, 1.f};
-        if (row < h && c4 < w) {
-            const size_t idx = (size_t)(y0 + row) * nx + x0 + c4;
-            if (vec_ok && c4 + 3 < w) {
-                if (mode == 0) {
-                    float4 a = *reinterpret_cast<const float4*>(img + idx);
-                    pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
-                }
-                if (wgt) {
-                    float4 b = *reinterpret_cast<const float4*>(wgt + idx);
-                    pw[0] = b.x; pw[1] = b.y; pw[2] = b.z; pw[3] = b.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c4 + j < w) {
-                        if (mode == 0) pv[j] = img[idx + j];
-                        if (wgt) pw[j] = wgt[idx + j];
-                    }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bool good = (row < h) && (c4 + j < w);
-            if (wgt) good = good && pw[j] > wthresh;
-            float val = pv[j];
-            if (mode == 1) val = good ? pw[j] : qnan;            // inverted below, unless the mesh is flat
-            good = good && (val > -BK_BIG) && (val == val);
-            v[4 * k + j] = good ? val : qnan;
-        }
-    }
-    if (dbg == 1) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < BKF_PX; ++k) a += v[k];
-        if (a == 12345.f) dump[0].valid = 7;
-        return;
-    }
-    if (mode == 1) {
-        // Variance statistic: most weight maps are flat inside a mesh.  Then every 1 / w is the
-        // same float, the clipped mean is that value exactly and sigma is 0 - the result of the
-        // general path below - and a min / max / count of the weights (three fp32 operations per
-        // pixel) replaces the divisions and the two fp64 moment passes.
-        float wmn = __builtin_inff(), wmx = -__builtin_inff();
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < BKF_PX; ++k) {
-            const float x = v[k];
-            const bool in = (x == x);
-            wmn = in ? fminf(wmn, x) : wmn;
-            wmx = in ? fmaxf(wmx, x) : wmx;
-            cnt += in ? 1 : 0;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            wmn = fminf(wmn, __shfl_xor(wmn, o));
-            wmx = fmaxf(wmx, __shfl_xor(wmx, o));
-            cnt += __shfl_xor(cnt, o);
-        }
-        __syncthreads();
-        if ((tid & 63) == 0) { S->red3[0][tid >> 6] = wmn; S->red3[1][tid >> 6] = wmx; S->red3[2][tid >> 6] = cnt; }
-        __syncthreads();
-        double bmn = S->red3[0][0], bmx = S->red3[1][0], bc = 0.0;
-#pragma unroll
-        for (int w8 = 0; w8 < BKF_WAVES; ++w8) {
-            bmn = fmin(bmn, S->red3[0][w8]);
-            bmx = fmax(bmx, S->red3[1][w8]);
-            bc += S->red3[2][w8];
-        }
-        const float inv = 1.0f / (float)bmn;
-        if (bc >= 1.0 && bc >= area * 0.5 && bmn == bmx && inv > -BK_BIG && inv == inv) {
-            if (tid == 0) {
-                mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
-                D->q = make_quant((double)inv, 0.0, bc);
-                D->mean0 = (double)inv;
-                D->valid = 2;
-            }
-            return;
-        }
-        __syncthreads();                                   // red3 is reused below
-#pragma unroll
-        for (int k = 0; k < BKF_PX; ++k) {
-            const float x = v[k];
-            float val = 1.0f / x;
-            const bool ok = (x == x) && (val > -BK_BIG) && (val == val);
-            v[k] = ok ? val : qnan;
-        }
-    }
     // ---- pivot: some valid pixel of the mesh.  Moments are accumulated about it, in fp64:
     // (x - K) is exact, a constant mesh gives exactly zero variance (as numpy's two-pass var
     // in the oracle does) and a nearly flat map loses nothing to cancellation, in one sweep
@@ -397,7 +290,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
         kf = (float)kd;
     }
     if (!(kf == kf)) {                                       // no valid pixel at all
-        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        if (tid == 0) D->valid = 0;
         return;
     }
     const double K = (double)kf;
@@ -420,7 +313,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
     }
     blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
-        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        if (tid == 0) D->valid = 0;
         return;
     }
     double dm = s1 / s0;                                     // mean - K
@@ -449,7 +342,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
     }
     blockf_sum3(s0, s1, s2, S->red3);
     if (s0 < 1.0) {
-        if (tid == 0) dump[((size_t)blockIdx.z * nby + mj) * nbx + mi].valid = 0;
+        if (tid == 0) D->valid = 0;
         return;
     }
     dm = s1 / s0;
@@ -457,14 +350,13 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
     var = s2 / s0 - dm * dm;
     sig = var > 0 ? sqrt(var) : 0.0;
     const bk_quant q = make_quant(mean, sig, s0);
-    if (dbg == 2) { if (sig == 12345.0) dump[0].valid = 7; return; }
+    if (dbg == 2) { if (sig == 12345.0) D->valid = 7; return; }
     if (sig == 0.0) {
         // a constant mesh (flat variance maps, most of the time): qscale = 1 and every pixel
         // falls into bin 0, so backguess returns exactly qzero = (float)mean and sigma 0 -
         // no histogram, no prefix arrays, no dump
         if (tid == 0) {
-            mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
-            D->q = q;
+                        D->q = q;
             D->mean0 = (double)(float)mean;
             D->valid = 2;
         }
@@ -505,7 +397,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
         if (cur >= 0) atomicAdd(&S->histo[cur], run);
     }
     __syncthreads();
-    if (dbg == 3) { if (S->histo[tid] == -5) dump[0].valid = 7; return; }
+    if (dbg == 3) { if (S->histo[tid] == -5) D->valid = 7; return; }
     // ---- prefix: the first 256 threads own 16 bins each; the prefix arrays and the
     // quantisation go to global memory, the clip iterations run in k_mesh_guess
     // (one wave per mesh, every mesh of the frame in flight at once)
@@ -535,8 +427,7 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
         if (tid < BK_THREADS) {
             long long o0 = 0, o1 = 0, o2 = 0;
             for (int ww = 0; ww < wave; ++ww) { o0 += S->wsum[0][ww]; o1 += S->wsum[1][ww]; o2 += S->wsum[2][ww]; }
-            mesh_dump* D = dump + ((size_t)blockIdx.z * nby + mj) * nbx + mi;
-            D->b1[tid] = o1 + e1 - a1;
+                        D->b1[tid] = o1 + e1 - a1;
             D->b2[tid] = o2 + e2 - a2;
             int run = (int)(o0 + e0 - a0);
             int4* dst = reinterpret_cast<int4*>(D->p0 + tid * BK_PER);      // 8 prefixes of 16 bits per int4
@@ -555,6 +446,138 @@ __global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_bat
             if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
         }
     }
+}
+
+// SEL 0: image statistic; 1: variance statistic (1 / weight); 2: both from one read of the two planes
+// (blockIdx.z = frame; the dumps of a frame are consecutive: image, then variance).  Most weight
+// maps are flat inside a mesh: then every 1 / w is the same float, the clipped mean is that value
+// exactly and sigma is 0 - the result of the general path - and a min / max / count of the weights,
+// taken while the pixels are loaded, replaces the divisions and the moment passes; only a mesh
+// whose weights vary reads them again (SEL 2) and takes the general path a second time.
+template <int SEL>
+__global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_batch B, int nx, int ny, int mesh,
+                                                                 int nbx, int nby, float wthresh, int vec_ok,
+                                                                 int dbg, mesh_dump* __restrict__ dump) {
+    extern __shared__ char smem_raw[];
+    meshf_lds* S = reinterpret_cast<meshf_lds*>(smem_raw);
+    constexpr int NM = SEL == 2 ? 2 : 1;
+    const int frame = blockIdx.z;
+    const float* __restrict__ img = B.img[frame];
+    const float* __restrict__ wgt = B.wgt[frame];
+    const int mi = blockIdx.x, mj = blockIdx.y;
+    const int x0 = mi * mesh, y0 = mj * mesh;
+    const int w = min(mesh, nx - x0), h = min(mesh, ny - y0);
+    const int area = w * h;
+    const int tid = threadIdx.x;
+    const float qnan = __builtin_nanf("");
+    mesh_dump* D0 = dump + ((size_t)(frame * NM) * nby + mj) * nbx + mi;
+    mesh_dump* D1 = D0 + (size_t)(NM - 1) * nby * nbx;              // variance statistic
+
+    // ---- load: BKF_PX / 4 passes of BKF_ROWS rows x 128 columns, 4 px per thread per pass
+    float v[BKF_PX];
+    float wmn = __builtin_inff(), wmx = -__builtin_inff();
+    int wcnt = 0;
+    const int c4 = (tid & 31) * 4, r32 = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < BKF_PX / 4; ++k) {
+        const int row = BKF_ROWS * k + r32;
+        float pv[4] = {qnan, qnan, qnan, qnan};
+        float pw[4] = {1.f, 1.f, 1.f, 1.f};
+        if (row < h && c4 < w) {
+            const size_t idx = (size_t)(y0 + row) * nx + x0 + c4;
+            if (vec_ok && c4 + 3 < w) {
+                if (SEL != 1) {
+                    float4 a = *reinterpret_cast<const float4*>(img + idx);
+                    pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+                }
+                if (wgt) {
+                    float4 b = *reinterpret_cast<const float4*>(wgt + idx);
+                    pw[0] = b.x; pw[1] = b.y; pw[2] = b.z; pw[3] = b.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c4 + j < w) {
+                        if (SEL != 1) pv[j] = img[idx + j];
+                        if (wgt) pw[j] = wgt[idx + j];
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool good = (row < h) && (c4 + j < w);
+            if (wgt) good = good && pw[j] > wthresh;
+            if (SEL != 0) {
+                const float x = pw[j];
+                const bool in = good && (x > -BK_BIG) && (x == x);
+                wmn = in ? fminf(wmn, x) : wmn;
+                wmx = in ? fmaxf(wmx, x) : wmx;
+                wcnt += in ? 1 : 0;
+                if (SEL == 1) v[4 * k + j] = in ? x : qnan;          // inverted below, unless the mesh is flat
+            }
+            if (SEL != 1) {
+                const float val = pv[j];
+                v[4 * k + j] = (good && (val > -BK_BIG) && (val == val)) ? val : qnan;
+            }
+        }
+    }
+    if (dbg == 1) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < BKF_PX; ++k) a += v[k];
+        if (a == 12345.f) dump[0].valid = 7;
+        return;
+    }
+    bool flat = false;
+    if (SEL != 0) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            wmn = fminf(wmn, __shfl_xor(wmn, o));
+            wmx = fmaxf(wmx, __shfl_xor(wmx, o));
+            wcnt += __shfl_xor(wcnt, o);
+        }
+        if ((tid & 63) == 0) { S->red3[0][tid >> 6] = wmn; S->red3[1][tid >> 6] = wmx; S->red3[2][tid >> 6] = wcnt; }
+        __syncthreads();
+        double bmn = S->red3[0][0], bmx = S->red3[1][0], bc = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < BKF_WAVES; ++w8) {
+            bmn = fmin(bmn, S->red3[0][w8]);
+            bmx = fmax(bmx, S->red3[1][w8]);
+            bc += S->red3[2][w8];
+        }
+        const float inv = 1.0f / (float)bmn;
+        flat = bc >= 1.0 && bc >= area * 0.5 && bmn == bmx && inv > -BK_BIG && inv == inv;
+        if (flat && tid == 0) {
+            D1->q = make_quant((double)inv, 0.0, bc);
+            D1->mean0 = (double)inv;
+            D1->valid = 2;
+        }
+        __syncthreads();                                   // red3 is reused below
+    }
+    if (SEL != 1) mesh_general(v, area, S, D0, dbg);
+    if (SEL == 0 || flat) return;
+    if (SEL == 2) {
+        // the weights of this mesh vary: read them again (the registers held the image)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BKF_PX / 4; ++k) {
+            const int row = BKF_ROWS * k + r32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = qnan;
+                if (row < h && c4 + j < w) x = wgt[(size_t)(y0 + row) * nx + x0 + c4 + j];
+                v[4 * k + j] = (x > wthresh && x > -BK_BIG) ? x : qnan;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BKF_PX; ++k) {
+        const float x = v[k];
+        const float val = 1.0f / x;
+        const bool ok = (x == x) && (val > -BK_BIG) && (val == val);
+        v[k] = ok ? val : qnan;
+    }
+    mesh_general(v, area, S, D1, dbg);
 }
 
 // One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
@@ -1024,11 +1047,10 @@ int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* c
     ZM_TRY(frame_slots(ctx, nx, ny, mesh, slot, index0, count, nslot, &nbx, &nby, &raw, &nodes, &stats));
     const int n = nbx * nby;
     if (nslot < n) nslot = n;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->bk_stats_set) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_stats, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(mesh_lds)));
-        attr_set = true;
+        ctx->bk_stats_set = true;
     }
     zm_scope_timer t(ctx, "mesh_stats");
     if (mesh <= 128) {
@@ -1046,9 +1068,16 @@ int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* c
             mesh_dump* dump = nullptr;
             ZM_TRY(ctx->get((std::string(slot) + "_dump").c_str(),
                             sizeof(mesh_dump) * 2 * (size_t)n * std::min(nf, BK_BATCH), (void**)&dump));
-            hipLaunchKernelGGL(k_mesh_stats_fast, dim3(nbx, nby, nmode * nb), dim3(BKF_THREADS, 1, 1),
-                               sizeof(meshf_lds), ctx->stream, B, nmode, nx, ny, mesh, nbx, nby,
-                               wthresh, mode0, vec_ok, dbg, dump);
+            const dim3 grid(nbx, nby, nb), block(BKF_THREADS, 1, 1);
+            if (nmode == 2)
+                hipLaunchKernelGGL(k_mesh_stats_fast<2>, grid, block, sizeof(meshf_lds), ctx->stream, B, nx, ny, mesh,
+                                   nbx, nby, wthresh, vec_ok, dbg, dump);
+            else if (mode0 == 0)
+                hipLaunchKernelGGL(k_mesh_stats_fast<0>, grid, block, sizeof(meshf_lds), ctx->stream, B, nx, ny, mesh,
+                                   nbx, nby, wthresh, vec_ok, dbg, dump);
+            else
+                hipLaunchKernelGGL(k_mesh_stats_fast<1>, grid, block, sizeof(meshf_lds), ctx->stream, B, nx, ny, mesh,
+                                   nbx, nby, wthresh, vec_ok, dbg, dump);
             hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode * nb, 1), dim3(64, 1, 1), 0, ctx->stream,
                                dump, n, nmode, nslot, raw + (size_t)f0 * 4 * nslot);
         }
@@ -1073,13 +1102,12 @@ int zm_batch_filter(zm_ctx* ctx, int nf, int nx, int ny, int mesh, int fsize, in
     const bool fast = n <= 1024;
     // FAST: 4 n maps + 4 n spline scratch + max(8 n planes, 2 x 1024 sort buffer)
     const size_t fsh = sizeof(float) * (fast ? (size_t)8 * n + std::max(8 * n, 2048) : (size_t)9 * n);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->bk_filter_set) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter<false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         ZM_HIP(hipFuncSetAttribute((const void*)k_mesh_filter<true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
+        ctx->bk_filter_set = true;
     }
     zm_scope_timer t(ctx, "mesh_filter");
     if (fast)
