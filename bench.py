@@ -251,9 +251,14 @@ def main():
     local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    # ZM_BENCH_FORCE_DIST=1 (developer): a process group of ONE rank with every collective of the
+    # multi-GPU step still made - the RCCL calls of an 8-GPU run, rehearsed on a one-GPU box
+    multi = world > 1 or bool(os.environ.get('ZM_BENCH_FORCE_DIST'))
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend, rank=rank, world_size=world)
+        importlib.import_module('zuds-pipeline_amd.parallel').FORCE_COLLECTIVES = world == 1
     if args.gpus != world and rank == 0 and world > 1:
         print(f'warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
 
@@ -293,7 +298,7 @@ def main():
 
     sum_type = args.combine.upper() in ('WEIGHTED', 'AVERAGE')
     sharded = None
-    if world > 1 and not sum_type:
+    if multi and not sum_type:
         # exact CLIPPED / MEDIAN of the 32 N deep stack: row-band exchange (BASELINE config 4)
         par = importlib.import_module('zuds-pipeline_amd.parallel')
         sharded = par.ShardedCoadd(par.HipBackend(base, params, device=local, engine=eng))
@@ -313,7 +318,7 @@ def main():
                     m = sharded.backend.reduce_mask(cov=co.mask_wgt)
                     co.stream.wait_stream(sharded.backend.stream)
                     co.mask.copy_(m)
-        elif world > 1:
+        elif multi:
             co.run_sharded_weighted(dfr)
         else:
             co.run(dfr)
@@ -346,7 +351,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local]) if backend == 'nccl' else dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -357,7 +362,7 @@ def main():
             fn()
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -500,7 +505,7 @@ def main():
                        'combine': args.combine, 'subtract': not args.no_subtract,
                        'hotpants': None if args.no_subtract else
                        {k: getattr(sub.info, k) for k, _ in sub.info._fields_}},
-            'world': {'backend': backend if world > 1 else None, 'world_size': world,
+            'world': {'backend': backend if multi else None, 'world_size': world,
                       'launcher': os.environ.get('ZM_BENCH_LAUNCHER', 'external' if world > 1 else 'none'),
                       'ranks': ranks},
             'legs': legs,
@@ -518,7 +523,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(synth, args.size, args.combine, args.cpu_frames)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -109,9 +109,9 @@ class DeviceCoadd(object):
         L, ctx = self.engine.L, self.engine.ctx
         self.run(dframes, partial=True)
         with self.torch.cuda.stream(self.stream):
-            if dist.is_initialized() and dist.get_world_size(group) > 1:
-                from .parallel import all_reduce_planes
-                all_reduce_planes(self.img, self.wgt, group)
+            from . import parallel
+            if dist.is_initialized() and (dist.get_world_size(group) > 1 or parallel.FORCE_COLLECTIVES):
+                parallel.all_reduce_planes(self.img, self.wgt, group)
             check(L.zm_coadd_finalize_dev(ctx, self.img.data_ptr(), self.wgt.data_ptr(),
                                           self.img.numel()), 'zm_coadd_finalize_dev')
             if self.mask is not None:

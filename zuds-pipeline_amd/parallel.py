@@ -22,6 +22,11 @@ from . import _lib
 from ._lib import check, wcs_struct
 
 
+# Tests set this to run every collective even in a process group of one rank (RCCL accepts a
+# communicator of one): the one-GPU box then exercises the same calls an 8-GPU node makes.
+FORCE_COLLECTIVES = False
+
+
 def band_bounds(nrows, world):
     """Row-band boundaries, ``np.array_split`` semantics (as ``zuds/mpi.py:52-60``
     splits job lists)."""
@@ -58,12 +63,13 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
         import os
         env = os.environ.get('ZM_MASK_BANDED', '')
         banded = (world >= 4) if env == '' else env != '0'
-    if world > 1 and not banded:
+    multi = world > 1 or (on and FORCE_COLLECTIVES)
+    if multi and not banded:
         parts = [torch.empty_like(acc) for _ in range(world)]
         dist.all_gather(parts, acc.contiguous(), group=group)
         for r, m in enumerate(parts):
             accum(acc, m, r == 0)
-    elif world > 1:
+    elif multi:
         ny = acc.shape[0]
         bounds = band_bounds(ny, world)
         peer = (lambda g: g) if group is None else (lambda g: dist.get_global_rank(group, g))
@@ -237,7 +243,7 @@ class ShardedCoadd(object):
         rank, world = self._world()
         s1, s0 = self.backend.partial_sums(frames)
         with self.backend.scope():
-            if world > 1:
+            if world > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
                 all_reduce_planes(s1, s0, self.group)
         return self.backend.finalize(s1, s0)
 
@@ -251,7 +257,7 @@ class ShardedCoadd(object):
         stack = (self.backend.resample_stack(frames, want_mask=True) if want_mask
                  else self.backend.resample_stack(frames))   # (n_local, ny, nx, 2)
         n_local, ny, nx, _ = stack.shape
-        if world == 1:
+        if world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
             return self.backend.combine(stack)
         bounds = band_bounds(ny, world)
         with self.backend.scope():
