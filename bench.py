@@ -32,7 +32,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
-VALU_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: max shader clock
 PMC_PROFILES = ['r02_pmc_coadd_fused.json', 'r02_pmc_resample.json', 'r01_pmc_resample.json']     # newest first
 
 
@@ -480,13 +479,14 @@ def main():
                         'us_per_frame': kt[roof_scope]['avg_us'] / (args.frames if fused else 1),
                         'algorithmic_bytes_per_launch': bytes_per_launch,
                         'dominant_by_time': dom}
-            # the limit this kernel actually runs into is vector issue, not HBM: VALU
-            # instructions per launch from the committed SQ_INSTS_VALU pass x measured issue
-            # cycles (tools/valu_rate.hip on MI355X at 4 waves per SIMD: v_pk_*_f32 5.1,
-            # other VALU 3.4 cycles per instruction and SIMD) over the SIMD-cycles of the launch
-            if pmc.get('valu_cycles_per_launch'):
-                simd_cycles = avg_s * VALU_CLOCK_HZ * 256 * 4
-                roofline['valu_frac'] = pmc['valu_cycles_per_launch'] / simd_cycles
+            # what this kernel runs into is not HBM: its waves alternate between LDS tap reads
+            # and the packed FMAs that consume them
+            if pmc.get('valu_simd_seconds_per_launch'):
+                # vector-issue time of the launch's instruction mix (measured ns per wave-instruction,
+                # profiles/r02_valu_rate.txt) over the 1024 SIMDs, and the LDS pipe time per CU
+                roofline['valu_frac'] = pmc['valu_simd_seconds_per_launch'] / (256 * 4) / avg_s
+                if pmc.get('lds_pipe'):
+                    roofline['lds_frac'] = pmc['lds_pipe']['seconds_per_cu_per_launch'] / avg_s
                 roofline['valu_insts_per_px'] = pmc.get('valu_insts_per_px')
         out = {
             'metric': 'Mpix/s resample->coadd->subtract, 3072x3072 frames',

@@ -1537,8 +1537,11 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab) {
+    const float* __restrict__ taptab, long long* __restrict__ clk) {
     extern __shared__ float4 smem4[];
+    // developer probe (ZM_FF_CLOCK=1): shader-clock and 100 MHz wall-clock stamps of workgroup 0 at
+    // its first and last instruction - the clock the chip holds while this kernel runs
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64(); clk[1] = wall_clock64(); }
     ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem4);                 // ring of 3 headers
     const float* ltab = reinterpret_cast<const float*>(smem4) + HDR_FLOATS;
     float2* tile = reinterpret_cast<float2*>(smem4) + (HDR_FLOATS + LZ_FLOATS) / 2;
@@ -1902,6 +1905,7 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         slot = nslot;
         if (t0 >= ntiles) break;
     }
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = clock64(); clk[3] = wall_clock64(); }
 }
 
 #define FF_WPS_DEFAULT 3
@@ -1951,6 +1955,9 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         zm_set_error("zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
         return 2;
     }
+    long long* clk = nullptr;
+    const bool want_clk = getenv("ZM_FF_CLOCK") != nullptr;
+    if (want_clk) ZM_TRY(ctx->get("ff_clk", sizeof(long long) * 4, (void**)&clk));
     zm_scope_timer t(ctx, "coadd_fused");
     {
         const long long items = (long long)ntiles * nfr;
@@ -1960,7 +1967,7 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
 #define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV)                                                                    \
     hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
                        onx, ony, lds_elems, ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, \
-                       taptab)
+                       taptab, clk)
 #define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3)
     if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
     else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true); else ZM_FF_LAUNCH(1, false); }
@@ -1968,5 +1975,13 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
 #undef ZM_FF_LAUNCH
 #undef ZM_FF_LAUNCH1
     ZM_HIP(hipGetLastError());
+    if (want_clk) {
+        long long h[4];
+        ZM_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ZM_HIP(hipStreamSynchronize(ctx->stream));
+        const double us = (double)(h[3] - h[1]) * 0.01;
+        fprintf(stderr, "k_coadd_fused: workgroup 0 ran %.1f us, %lld shader clocks: %.3f GHz\n", us, h[2] - h[0],
+                (double)(h[2] - h[0]) / us * 1e-3);
+    }
     return 0;
 }
