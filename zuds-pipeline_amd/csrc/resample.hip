@@ -1434,8 +1434,9 @@ static_assert(sizeof(ff_hdr) <= FF_HDR_WORDS * 4, "ff_hdr does not fit its recor
 
 __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr, int nfr, int lnx, int lny,
                                                     int onx, int ony, int lds_cap, int ntx, int ntiles,
-                                                    int* __restrict__ out) {
+                                                    int* __restrict__ out, int* __restrict__ tilectr, int ctr0) {
     __shared__ ff_hdr H[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tilectr = ctr0;     // k_coadd_fused's tile queue starts behind its first wave of tiles
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + w;
     const bool live = item < (long long)ntiles * nfr;
@@ -1537,20 +1538,33 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab, long long* __restrict__ clk) {
+    const float* __restrict__ taptab, int* __restrict__ tilectr, long long* __restrict__ clk) {
     extern __shared__ float4 smem4[];
     // developer probe (ZM_FF_CLOCK=1): shader-clock and 100 MHz wall-clock stamps of workgroup 0 at
     // its first and last instruction - the clock the chip holds while this kernel runs
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64(); clk[1] = wall_clock64(); }
+    if (clk && threadIdx.x == 0) {
+        if (blockIdx.x == 0) { clk[0] = clock64(); clk[1] = wall_clock64(); }
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        clk[4 + 3 * blockIdx.x] = wall_clock64();
+        clk[4 + 3 * blockIdx.x + 2] = ((long long)(xcc & 0xf) << 32) | hw;
+    }
     ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem4);                 // ring of 3 headers
     const float* ltab = reinterpret_cast<const float*>(smem4) + HDR_FLOATS;
     float2* tile = reinterpret_cast<float2*>(smem4) + (HDR_FLOATS + LZ_FLOATS) / 2;
     uint16_t* mtile = reinterpret_cast<uint16_t*>(tile + lds_cap);  // lds_cap is a multiple of 4
     int* rawflag = reinterpret_cast<int*>(smem4) + (HDR_FLOATS - 4); // one word per wave, behind the headers
+    // Tile queue.  Workgroups do not own a fixed share of the tiles: the SIMDs favour the oldest waves, so
+    // of the three workgroups of a CU the first dispatched runs 40 % faster than the third and a static
+    // split leaves the CUs a third full for the last fifth of the launch.  A workgroup takes its next
+    // tile from a global counter, two items before it runs out (header and box of an item are fetched
+    // that far ahead); the tiles it holds sit in a ring of four LDS words indexed by their ordinal.
+    int* tring = reinterpret_cast<int*>(smem4) + (HDR_FLOATS - 8);
     constexpr int NT = 6, OFF = -2, NQ = RTH / 4;
     const int tid = threadIdx.x;
     const int G = gridDim.x;
-    static_assert(3 * sizeof(ff_hdr) <= (HDR_FLOATS - 4) * 4, "header ring does not fit");
+    static_assert(3 * sizeof(ff_hdr) <= (HDR_FLOATS - 8) * 4, "header ring does not fit");
 
     // Staging of an item's box: thread (c, r0) of a [RP rows][bw / 2 float4 columns] arrangement
     // loads rows r0, r0 + RP, ... - one address per thread, a uniform stride per slot.
@@ -1672,8 +1686,15 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
             if ((tid & 63) == 0) rawflag[tid >> 6] = wraw;
         }
     };
-    auto next_item = [&](int& tt, int& ff) {
-        if (++ff == nfr) { ff = 0; tt += G; }
+    const int nty = ntiles / ntx;
+    // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
+    auto tile_of = [&](int s) -> int {
+        if (s >= ntiles) return s;
+        const int r = s / ntx, c = s - r * ntx;
+        return (r == 0 ? 0 : r == 1 ? nty - 1 : r - 1) * ntx + c;
+    };
+    auto next_item = [&](int& tt, int& ff, int& kk) {
+        if (++ff == nfr) { ff = 0; ++kk; tt = tring[kk & 3]; }
     };
     auto hdr_word = [&](int tt, int ff) -> int {          // this lane's word of the header of item (tt, ff)
         return tid < FF_HDR_WORDS ? ghdr[((size_t)tt * nfr + ff) * FF_HDR_WORDS + tid] : 0;
@@ -1682,14 +1703,21 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         if (tid < (int)(sizeof(ff_hdr) / 4)) reinterpret_cast<int*>(&HR[sl])[tid] = wv;
     };
 
-    int t0 = blockIdx.x, f0 = 0;
-    if (t0 >= ntiles) return;
+    if ((int)blockIdx.x >= ntiles) return;
+    int t0 = tile_of(blockIdx.x), f0 = 0, k2 = 0;
     for (int e = tid; e < LZ_FLOATS / 4; e += 256)
         smem4[HDR_FLOATS / 4 + e] = reinterpret_cast<const float4*>(taptab)[e];
+    if (tid == 0) {
+        // stacks of one or two frames look two items = up to two tiles ahead
+        tring[0] = t0;
+        if (nfr <= 2) tring[1] = tile_of(atomicAdd(tilectr, 1));
+        if (nfr == 1) tring[2] = tile_of(atomicAdd(tilectr, 1));
+    }
+    __syncthreads();
     int t1 = t0, f1 = f0;
-    next_item(t1, f1);
+    next_item(t1, f1, k2);
     int t2 = t1, f2 = f1;
-    next_item(t2, f2);
+    next_item(t2, f2, k2);
     hdr_put(0, hdr_word(t0, f0));
     if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
     __syncthreads();
@@ -1721,6 +1749,11 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         // the item waits with vmcnt(prefetch loads), not vmcnt(0)
         int hw2 = 0;
         if (t2 < ntiles) hw2 = hdr_word(t2, f2);
+        // the item two ahead is the last of its tile: take the tile after it from the queue (older
+        // than the prefetch below, as the header word is; its ring slot, ordinal k2 + 1, is not in use)
+        const bool grab = f2 == nfr - 1;
+        int gnext = 0;
+        if (grab && tid == 0) gnext = atomicAdd(tilectr, 1);
         // (unconditional: past the last item the current one is fetched again, into registers nobody reads)
         prefetch(t1 < ntiles ? &HR[nslot] : H, t1 < ntiles ? f1 : f0);
 
@@ -1898,14 +1931,18 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
             }
         }
         if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read two items ago
+        if (grab && tid == 0) tring[(k2 + 1) & 3] = tile_of(gnext);
         __syncthreads();          // everyone is done with the LDS tiles and with header `slot`
         t0 = t1; f0 = f1;
         t1 = t2; f1 = f2;
-        next_item(t2, f2);
+        next_item(t2, f2, k2);
         slot = nslot;
         if (t0 >= ntiles) break;
     }
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = clock64(); clk[3] = wall_clock64(); }
+    if (clk && threadIdx.x == 0) {
+        if (blockIdx.x == 0) { clk[2] = clock64(); clk[3] = wall_clock64(); }
+        clk[4 + 3 * blockIdx.x + 1] = wall_clock64();
+    }
 }
 
 #define FF_WPS_DEFAULT 3
@@ -1936,18 +1973,16 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     ZM_HIP(hipEventSynchronize(ev[5]));
     ZM_TRY(ctx->get_pinned("ff_frames_h", sizeof(zm_ff) * (size_t)nfr, (void**)&pin));
     ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
-    ZM_TRY(ctx->get("ff_headers", sizeof(int) * FF_HDR_WORDS * (size_t)ntiles * nfr, (void**)&ghdr));
+    ZM_TRY(ctx->get("ff_headers", sizeof(int) * (FF_HDR_WORDS * (size_t)ntiles * nfr + 16), (void**)&ghdr));
+    int* tilectr = ghdr + FF_HDR_WORDS * (size_t)ntiles * nfr;
     memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
     ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, ctx->stream));
     ZM_HIP(hipEventRecord(ev[5], ctx->stream));
     // 3 waves per SIMD (168 registers): at 4 (128) the prefetch registers and the running sums spill
     const int wps = FF_WPS_DEFAULT;
-    // persistent grid: `wps` workgroups per CU; trimmed so that every workgroup walks the same
-    // number of tiles (4608 tiles of a 3072^2 grid over 1024 workgroups would leave half of them
-    // idle during the fifth round)
-    int G = std::min(ntiles, 256 * wps);
-    const int rounds = zm_div_up(ntiles, G);
-    G = zm_div_up(ntiles, rounds);
+    // persistent grid: `wps` workgroups per CU, each starting on the tile of its index and taking
+    // further tiles from a queue (a counter behind the item headers, set to G by k_ff_headers)
+    const int G = std::min(ntiles, 256 * wps);
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
     if (shmem > 65536) {
@@ -1957,17 +1992,17 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     }
     long long* clk = nullptr;
     const bool want_clk = getenv("ZM_FF_CLOCK") != nullptr;
-    if (want_clk) ZM_TRY(ctx->get("ff_clk", sizeof(long long) * 4, (void**)&clk));
+    if (want_clk) ZM_TRY(ctx->get("ff_clk", sizeof(long long) * (4 + 3 * 256 * FF_WPS_DEFAULT), (void**)&clk));
     zm_scope_timer t(ctx, "coadd_fused");
     {
         const long long items = (long long)ntiles * nfr;
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
-                           lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr);
+                           lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr, tilectr, G);
     }
 #define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV)                                                                    \
     hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
                        onx, ony, lds_elems, ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, \
-                       taptab, clk)
+                       taptab, tilectr, clk)
 #define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3)
     if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
     else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true); else ZM_FF_LAUNCH(1, false); }
@@ -1976,12 +2011,50 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
 #undef ZM_FF_LAUNCH1
     ZM_HIP(hipGetLastError());
     if (want_clk) {
-        long long h[4];
-        ZM_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<long long> h(4 + 3 * (size_t)G);
+        ZM_HIP(hipMemcpyAsync(h.data(), clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         ZM_HIP(hipStreamSynchronize(ctx->stream));
         const double us = (double)(h[3] - h[1]) * 0.01;
         fprintf(stderr, "k_coadd_fused: workgroup 0 ran %.1f us, %lld shader clocks: %.3f GHz\n", us, h[2] - h[0],
                 (double)(h[2] - h[0]) / us * 1e-3);
+        // per-workgroup run times and placement (XCC, SE, CU from HW_ID)
+        long long t0 = h[4], t1 = h[5];
+        for (int g = 0; g < G; ++g) { t0 = std::min(t0, h[4 + 3 * g]); t1 = std::max(t1, h[4 + 3 * g + 1]); }
+        std::vector<double> dur(G);
+        std::map<int, int> percu;
+        std::map<int, std::pair<double, int>> perxcc;
+        for (int g = 0; g < G; ++g) {
+            dur[g] = (double)(h[4 + 3 * g + 1] - h[4 + 3 * g]) * 0.01;
+            const unsigned hw = (unsigned)h[4 + 3 * g + 2], xcc = (unsigned)(h[4 + 3 * g + 2] >> 32);
+            const int cu = (int)((hw >> 8) & 0xf), se = (int)((hw >> 13) & 0x7);
+            percu[(int)(xcc * 1024 + se * 16 + cu)]++;
+            perxcc[(int)xcc].first += dur[g];
+            perxcc[(int)xcc].second++;
+        }
+        std::vector<double> sd = dur;
+        std::sort(sd.begin(), sd.end());
+        std::map<int, int> hist;
+        for (auto& kv : percu) hist[kv.second]++;
+        fprintf(stderr, "  %d workgroups over %.1f us: run time min %.1f / median %.1f / max %.1f us; last start %.1f us; CUs used %zu:",
+                G, (double)(t1 - t0) * 0.01, sd.front(), sd[G / 2], sd.back(),
+                [&] { long long m = t0; for (int g = 0; g < G; ++g) m = std::max(m, h[4 + 3 * g]); return (double)(m - t0) * 0.01; }(),
+                percu.size());
+        for (auto& kv : hist) fprintf(stderr, " %d CUs x %d workgroups", kv.second, kv.first);
+        fprintf(stderr, "\n  mean run time by first tile column (of %d):", ntx);
+        for (int c = 0; c < ntx && c < G; ++c) {
+            double a = 0; int n = 0;
+            for (int g = c; g < G; g += ntx) { a += dur[g]; ++n; }
+            fprintf(stderr, " %.0f", a / n);
+        }
+        fprintf(stderr, "\n  mean run time by first tile row:");
+        for (int r = 0; r * ntx < G; ++r) {
+            double a = 0; int n = 0;
+            for (int g = r * ntx; g < std::min(G, (r + 1) * ntx); ++g) { a += dur[g]; ++n; }
+            fprintf(stderr, " %.0f", a / n);
+        }
+        fprintf(stderr, "\n  mean run time per XCC:");
+        for (auto& kv : perxcc) fprintf(stderr, " [%d] %.0f us (%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
+        fprintf(stderr, "\n");
     }
     return 0;
 }
