@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# one hardware queue per stream for the many-subtractions leg (see zuds-pipeline_amd/__init__.py);
+# read by the HIP runtime at its first call
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along

@@ -102,6 +102,9 @@ class SubtractionPool(object):
         if not 1 <= njobs <= 13:
             raise ValueError('njobs must be in 1 .. 13 (the solver needs 18 resident workgroups per job)')
         self.njobs, self.device = int(njobs), int(device)
+        # the solver's resident grid per job: 1 / share of the CUs (ZM_POOL_SHARE overrides: developer)
+        import os
+        self.share = min(max(int(os.environ.get('ZM_POOL_SHARE', self.njobs)), self.njobs), 13)
         _lib.lib()                                   # loaded once, here, not by racing worker threads
         self._local = threading.local()
         self._workers = []
@@ -113,7 +116,7 @@ class SubtractionPool(object):
         if w is None:
             import torch
             torch.cuda.set_device(self.device)
-            w = self._local.w = _Worker(self.device, self.njobs)
+            w = self._local.w = _Worker(self.device, self.share)
             with self._lock:
                 self._workers.append(w)
         return w
