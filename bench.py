@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true', help='skip the CLIPPED secondary line')
     ap.add_argument('--no-clocks', action='store_true', help='skip the PCIe / FITS clocks')
     ap.add_argument('--no-nightly', action='store_true', help='skip the concurrent-subtraction leg')
+    ap.add_argument('--no-pipelined', action='store_true', help='skip the software-pipelined rate')
     ap.add_argument('--nightly-jobs', type=int, default=16, help='subtractions of the concurrent leg')
     ap.add_argument('--cpu-frames', type=int, default=8,
                     help='full-size frames the CPU baseline resamples and coadds')
@@ -441,6 +442,9 @@ def main():
     secondary = None
     clocks = None
     tools = None
+    pipelined = None
+    if world == 1 and rank == 0 and not args.no_subtract and not args.no_pipelined and sum_type:
+        pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local)
     nightly = None
     if world == 1 and rank == 0 and not args.no_subtract and not args.no_nightly:
         nightly = nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local)
@@ -518,6 +522,8 @@ def main():
         }
         if nightly is not None:
             out['nightly'] = nightly
+        if pipelined is not None:
+            out['pipelined'] = pipelined
         if secondary is not None:
             out['secondary'] = secondary
         if clocks is not None:
@@ -529,6 +535,81 @@ def main():
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
+
+
+def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local):
+    """The same step with consecutive steps software-pipelined, reported beside `value`, never as
+    it: the subtraction of step k (its own context and stream) runs while the coadd of step k + 1
+    is computed - step k + 1's coadd does not depend on step k's subtraction (another field, another
+    quadrant: BASELINE config 5).  Every step still makes one full coadd and one full subtraction
+    against THAT coadd (its products are snapshotted into one of two buffer sets; events order the
+    streams).  What it buys: the coadd kernels fill the CUs that the latency-bound kernel fit of
+    the subtraction leaves idle."""
+    check = z._lib.check
+    eng_s = z.Engine(local)
+    L = eng.L
+    big = float(np.sqrt(50000.0))
+    A = coadd.stream
+    try:
+        sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng_s)
+        B = sub.stream
+        snap = [dict(img=torch.empty_like(coadd.img), rms=torch.empty_like(coadd.img),
+                     mask=torch.empty((args.size, args.size), dtype=torch.int32, device=coadd.img.device))
+                for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [None, None]
+
+        def enqueue_coadd(k):
+            s = snap[k & 1]
+            if freed[k & 1] is not None:
+                A.wait_event(freed[k & 1])           # the subtraction that read this buffer set is done
+            coadd.run(dframes)
+            with torch.cuda.stream(A):
+                if coadd.mask is not None:
+                    check(L.zm_mask_flag_dev(eng.ctx, coadd.mask.data_ptr(), coadd.mask_wgt.data_ptr(), 0.0, 1 << 16, npx))
+                    s['mask'].copy_(coadd.mask)
+                else:
+                    s['mask'].copy_(no_ref_mask)
+                check(L.zm_add_scalar_dev(eng.ctx, coadd.img.data_ptr(), 150.0, npx))
+                check(L.zm_rms_from_weight_dev(eng.ctx, coadd.wgt.data_ptr(), None, npx, big, s['rms'].data_ptr()))
+                s['img'].copy_(coadd.img)
+                ready[k & 1].record(A)
+
+        def subtract(k):
+            s = snap[k & 1]
+            B.wait_event(ready[k & 1])
+            sub.run(sci['img'], sci['rms'], sci['mask'], sci['wgt'], s['img'], s['rms'], s['mask'],
+                    seeing=args.seeing, nreg_side=3)
+            ev = torch.cuda.Event()
+            ev.record(B)
+            freed[k & 1] = ev
+
+        state = {'k': 0}
+        enqueue_coadd(0)
+
+        def pstep():
+            k = state['k']
+            enqueue_coadd(k + 1)
+            subtract(k)
+            state['k'] = k + 1
+
+        for _ in range(4):
+            pstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pstep()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = sub.info.status == 0
+        del sub
+    finally:
+        eng.set_stream(A.cuda_stream)
+        eng_s.close()
+    return {'ms_per_step': 1e3 * dt / args.steps,
+            'mpix_s': (args.frames + 1) * npx / 1e6 * args.steps / dt, 'steps': args.steps, 'status_ok': ok,
+            'what': 'steps software-pipelined: subtraction of step k beside the coadd of step k + 1 (two streams, '
+                    'two sets of coadd products); one full coadd and one full subtraction against it per step'}
 
 
 def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local):
