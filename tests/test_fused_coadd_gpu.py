@@ -155,6 +155,19 @@ def test_partial_sums_and_single_frame(engine):
     assert_same(a, b)
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 5])
+def test_tile_queue_with_short_stacks_and_many_tiles(engine, n):
+    """The persistent kernel takes tiles from a queue two items ahead: with one or two frames per
+    tile that is one or two tiles ahead (ring of tile ordinals), on a grid with more tiles than
+    resident workgroups (1600 x 1600: 1250 tiles against 768)."""
+    z = pkg()
+    frames, base = stack(n, 1600, 1600, 700 + n, nbad=2000)
+    p = z.coadd_params(combine='WEIGHTED', mask_combine='OR', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+    assert (b[1] > 0).mean() > 0.95
+
+
 def test_fullsize_stack_fused_equals_materialised(engine):
     """BASELINE config[1] geometry at full size (3072 x 3072, TPV, +-15 px, +-0.1 deg), 4 frames."""
     z = pkg()
