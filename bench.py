@@ -683,6 +683,33 @@ def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx):
         out['combine_kernel'] = {'avg_us': us, 'algorithmic_bytes': byt, 'achieved_GBs': byt / (us * 1e-6) / 1e9,
                                  'frac_of_hbm_peak': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     del co
+    # BASELINE configs[3]: what each of 8 ranks combines after the row-band exchange of a 256-frame stack -
+    # all 256 samples of its 384 rows (k_combine_wide<4>); synthetic samples, 2 % of them without weight
+    import ctypes as C
+    import torch
+    depth, rows = 8 * args.frames, args.size // 8
+    if depth <= 512 and rows >= 1:
+        g = torch.Generator(device='cuda')
+        g.manual_seed(9)
+        device = torch.device('cuda', local)
+        stack = torch.empty((depth, rows, args.size, 2), dtype=torch.float32, device=device)
+        stack[..., 0] = torch.randn((depth, rows, args.size), generator=g, device=device) * 5 + 100
+        stack[..., 1] = torch.where(torch.rand((depth, rows, args.size), generator=g, device=device) < 0.02, 0.0, 0.04)
+        o1 = torch.empty((rows, args.size), dtype=torch.float32, device=device)
+        o2 = torch.empty_like(o1)
+        bpx = rows * args.size
+
+        def band():
+            z._lib.check(eng.L.zm_combine_stack_dev(eng.ctx, depth, stack.data_ptr(), bpx, bpx, C.byref(p),
+                                                    o1.data_ptr(), o2.data_ptr()))
+        band()
+        dtb = timed(band, args.steps)
+        byt = (8 * depth + 8) * bpx
+        out['band_combine'] = {'depth': depth, 'rows': rows, 'ms': 1e3 * dtb / args.steps,
+                               'achieved_GBs': byt * args.steps / dtb / 1e9,
+                               'frac_of_hbm_peak': byt * args.steps / dtb / 1e9 / HBM_PEAK_GBS,
+                               'what': 'CLIPPED combine of one rank\'s row band of an 8-rank stack (every frame of the stack)'}
+        del stack
     return out
 
 

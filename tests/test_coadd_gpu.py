@@ -132,9 +132,10 @@ def test_single_frame_clipped_is_identity_of_resample(engine):
     np.testing.assert_allclose(g_wgt, r_wgt, rtol=1e-6)
 
 
-@pytest.mark.parametrize('n', [3, 9, 20, 40, 70, 256])
+@pytest.mark.parametrize('n', [3, 9, 20, 40, 64, 65, 70, 128, 129, 200, 256, 257, 400, 512])
 def test_stack_depths_use_every_kernel_variant(engine, n):
-    # register networks (4..64) and the deep LDS path (> 64)
+    # register networks: one lane per pixel (4 .. 64 samples), 2 / 4 / 8 lanes per pixel (<= 128 / 256 / 512:
+    # k_combine_wide, the row bands of a multi-GPU CLIPPED stack); nx = 50: ragged last wave
     z = pkg()
     rng = np.random.default_rng(n)
     ny, nx = 40, 50
@@ -150,6 +151,13 @@ def test_stack_depths_use_every_kernel_variant(engine, n):
         assert_close_masked(g_img, r_img, 2e-6, 1e-4, f'{kind} n={n}', max_bad_frac=1e-3)
         assert_close_masked(g_wgt, r_wgt, 1e-5, 0, f'{kind} n={n} weight', max_bad_frac=1e-3)
         assert g_img[0, 0] == 0 and g_wgt[0, 0] == 0
+
+
+def test_too_deep_a_stack_is_refused(engine):
+    z = pkg()
+    vals = np.ones((513, 4, 8), np.float32)
+    with pytest.raises(z.ZMError, match='512'):
+        engine.combine_stack(vals, vals, z.coadd_params(combine='MEDIAN'))
 
 
 def test_background_and_weight_rescale_in_the_coadd(engine):

@@ -10,7 +10,7 @@
 // output pixel, the n samples of a pixel live in registers (n <= 64) and the
 // median comes from a fully unrolled bitonic network; lanes read consecutive
 // pixels of one frame, so every load is a coalesced 512-B wave transaction.
-// Deeper stacks use one LDS column per lane (k_combine_deep).
+// Deeper stacks (<= 512) spread a pixel over 2, 4 or 8 lanes (k_combine_wide).
 #include "zm_internal.h"
 
 template <int N>
@@ -110,64 +110,121 @@ __global__ __launch_bounds__(256) void k_combine(const float2* __restrict__ stac
     out_wgt[p] = s0;
 }
 
-// Deep stacks (n > 64): each lane owns an LDS column of n keys (stride 64 words,
-// bank = lane, conflict free) and Shell-sorts it in place.
-__global__ __launch_bounds__(64) void k_combine_deep(const float2* __restrict__ stack,
-                                                     int64_t fstride, int n, int64_t npix,
-                                                     int kind, float clip_sigma,
-                                                     float clip_ampfrac,
-                                                     float* __restrict__ out_img,
-                                                     float* __restrict__ out_wgt) {
-    extern __shared__ float col[];   // [n][64]
-    const int lane = threadIdx.x;
-    int64_t p = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = p < npix;
+// The bitonic network over the 64 LPP keys of a pixel held by LPP lanes (element index of register r
+// of lane `sub`: e = 64 sub + r), expanded at compile time level by level (K) and step by step (J).
+template <int LPP, int K, int J>
+__device__ __forceinline__ void wide_step(float (&key)[64], const int sub) {
+    constexpr int NL = 64, PPW = 64 / LPP;
+    if constexpr (J >= NL) {
+        // the partner lives in the lane J / 64 subs away
+        const bool up = ((sub * NL) & K) == 0, lower = ((sub * NL) & J) == 0;
+        const bool keepmin = lower == up;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            const float other = __shfl_xor(key[r], (J / NL) * PPW);
+            key[r] = keepmin ? fminf(key[r], other) : fmaxf(key[r], other);
+        }
+    } else {
+        const bool upl = ((sub * NL) & K) == 0;                 // the lane's part of the direction (K >= 64)
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            if ((r ^ J) > r) {
+                const bool up = K >= NL ? upl : ((r & K) == 0);
+                const float lo = fminf(key[r], key[r ^ J]), hi = fmaxf(key[r], key[r ^ J]);
+                key[r] = up ? lo : hi;
+                key[r ^ J] = up ? hi : lo;
+            }
+        }
+    }
+    if constexpr (J > 1) wide_step<LPP, K, J / 2>(key, sub);
+}
+template <int LPP, int K>
+__device__ __forceinline__ void wide_level(float (&key)[64], const int sub) {
+    wide_step<LPP, K, K / 2>(key, sub);
+    if constexpr (K < 64 * LPP) wide_level<LPP, 2 * K>(key, sub);
+}
+
+// Deep stacks (64 < n <= 512: the row bands of a multi-GPU CLIPPED / MEDIAN stack hold every frame of
+// the stack, 256 at BASELINE config 4): LPP = 2, 4 or 8 lanes share a pixel, each with 64 of its
+// samples in registers - lane (sub, px) of a wave holds frames sub, sub + LPP, ... of pixel px, so
+// a load instruction still reads whole 128-B lines (64 / LPP consecutive pixels of LPP frames).  The
+// bitonic network runs over the 64 LPP keys of a pixel: steps with a partner distance below 64 are
+// compare-exchanges between registers of a lane, the others exchange registers with the lane that
+// holds the partner (one cross-lane read each).  (Its predecessor kept a column of n keys per lane
+// in LDS and Shell-sorted it: 64 KB of LDS per wave at n = 256, two waves per CU, 29.6 ms for the
+// 256 x 384 x 3072 band of an 8-GPU stack against 0.7 ms for the same samples at n = 32.)
+template <int LPP>
+__global__ __launch_bounds__(256) void k_combine_wide(const float2* __restrict__ stack, int64_t fstride, int n,
+                                                      int64_t npix, int kind, float clip_sigma,
+                                                      float clip_ampfrac, float* __restrict__ out_img,
+                                                      float* __restrict__ out_wgt) {
+    constexpr int NL = 64, PPW = 64 / LPP, N = NL * LPP;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int px = lane % PPW, sub = lane / PPW;
+    const int64_t p = wave * PPW + px;
+    const bool live = p < npix;                         // (no early exit: every lane takes part in the exchanges)
+    float v[NL], w[NL];
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int f = r * LPP + sub;
+        float2 s = make_float2(0.f, 0.f);
+        if (live && f < n) s = stack[(int64_t)f * fstride + p];
+        v[r] = s.x;
+        w[r] = s.y > 0.f ? s.y : 0.f;
+    }
+    float key[NL];
     int nv = 0;
     float sw = 0.f;
-    for (int i = 0; i < n; ++i) {
-        float2 s = live ? stack[(int64_t)i * fstride + p] : make_float2(0.f, 0.f);
-        bool ok = s.y > 0.f;
-        col[i * 64 + lane] = ok ? s.x : __builtin_inff();
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const bool ok = w[r] > 0.f;
+        key[r] = ok ? v[r] : __builtin_inff();
         nv += ok ? 1 : 0;
-        sw += ok ? s.y : 0.f;
+        sw += w[r];
     }
-    // Shell sort (Ciura gaps), per lane, no cross-lane traffic
-    const int gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
-    for (int g = 0; g < 8; ++g) {
-        const int gap = gaps[g];
-        if (gap >= n) continue;
-        for (int i = gap; i < n; ++i) {
-            float t = col[i * 64 + lane];
-            int j = i;
-            while (j >= gap && col[(j - gap) * 64 + lane] > t) {
-                col[j * 64 + lane] = col[(j - gap) * 64 + lane];
-                j -= gap;
-            }
-            col[j * 64 + lane] = t;
-        }
+#pragma unroll
+    for (int o = PPW; o < 64; o <<= 1) {                 // over the lanes of the pixel, fixed order
+        nv += __shfl_xor(nv, o);
+        sw += __shfl_xor(sw, o);
     }
-    if (!live) return;
+    wide_level<LPP, 2>(key, sub);
     float med = 0.f;
-    if (nv > 0) med = 0.5f * (col[((nv - 1) >> 1) * 64 + lane] + col[(nv >> 1) * 64 + lane]);
+    {
+        const int e1 = nv > 0 ? (nv - 1) >> 1 : 0, e2 = nv >> 1 < N ? nv >> 1 : N - 1;
+        const float c1 = pick<NL>(key, e1 & (NL - 1)), c2 = pick<NL>(key, e2 & (NL - 1));
+        const float m1 = __shfl(c1, (e1 >> 6) * PPW + px), m2 = __shfl(c2, (e2 >> 6) * PPW + px);
+        if (nv > 0) med = 0.5f * (m1 + m2);
+    }
     if (kind == ZM_COMBINE_MEDIAN) {
-        out_img[p] = med;
-        out_wgt[p] = sw;
+        if (live && sub == 0) {
+            out_img[p] = med;
+            out_wgt[p] = sw;
+        }
         return;
     }
+    // CLIPPED
     const float amp = clip_ampfrac * fabsf(med);
     float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < n; ++i) {
-        float2 s = stack[(int64_t)i * fstride + p];
-        if (s.y > 0.f) {
-            float sig = rsqrtf(s.y);
-            if (fabsf(s.x - med) <= clip_sigma * sig + amp) {
-                s1 = fmaf(s.y, s.x, s1);
-                s0 += s.y;
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        if (w[r] > 0.f) {
+            const float sig = rsqrtf(w[r]);
+            if (fabsf(v[r] - med) <= clip_sigma * sig + amp) {
+                s1 = fmaf(w[r], v[r], s1);
+                s0 += w[r];
             }
         }
     }
-    out_img[p] = s0 > 0.f ? s1 / s0 : 0.f;
-    out_wgt[p] = s0;
+#pragma unroll
+    for (int o = PPW; o < 64; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s0 += __shfl_xor(s0, o);
+    }
+    if (live && sub == 0) {
+        out_img[p] = s0 > 0.f ? s1 / s0 : 0.f;
+        out_wgt[p] = s0;
+    }
 }
 
 // WEIGHTED / AVERAGE for any depth: running sums, no sample storage
@@ -222,13 +279,15 @@ int zm_launch_combine(zm_ctx* ctx, int n, const float2* stack, int64_t frame_str
     else if (n <= 64) ZM_COMBINE_CASE(64);
     else {
         ZM_CHECK(n <= 512, "combine: stack depth %d > 512 not supported", n);
-        dim3 b2(64, 1, 1), g2((unsigned)((npix + 63) / 64), 1, 1);
-        size_t shmem = (size_t)n * 64 * sizeof(float);
-        if (shmem > 65536)
-            ZM_HIP(hipFuncSetAttribute((const void*)k_combine_deep,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_combine_deep, g2, b2, shmem, ctx->stream, stack, frame_stride, n,
-                           npix, kind, clip_sigma, clip_ampfrac, out_img, out_wgt);
+        const int lpp = n <= 128 ? 2 : n <= 256 ? 4 : 8;
+        const int64_t waves = (npix + 64 / lpp - 1) / (64 / lpp);
+        dim3 g2((unsigned)((waves + 3) / 4), 1, 1);
+#define ZM_WIDE_CASE(L) hipLaunchKernelGGL(k_combine_wide<L>, g2, blk, 0, ctx->stream, stack, frame_stride, n, \
+                                           npix, kind, clip_sigma, clip_ampfrac, out_img, out_wgt)
+        if (lpp == 2) ZM_WIDE_CASE(2);
+        else if (lpp == 4) ZM_WIDE_CASE(4);
+        else ZM_WIDE_CASE(8);
+#undef ZM_WIDE_CASE
     }
 #undef ZM_COMBINE_CASE
     ZM_HIP(hipGetLastError());
