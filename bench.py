@@ -29,9 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# one hardware queue per stream for the many-subtractions leg (see zuds-pipeline_amd/__init__.py);
-# read by the HIP runtime at its first call
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# hardware queues for the many-subtractions leg (one process on the GPU: zuds-pipeline_amd/nightly.py);
+# read by the HIP runtime at its first call.  Not for N > 1 (no such leg) nor for the rehearsal
+# with several ranks on one card, where more queues per process only oversubscribe the hardware.
+if int(os.environ.get('WORLD_SIZE', '1')) == 1:
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write

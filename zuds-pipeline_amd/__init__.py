@@ -5,14 +5,6 @@ The directory name is not a Python identifier; import it with
 ``importlib.import_module('zuds-pipeline_amd')`` or through the ``zuds_amd``
 shim at the repository root (``import zuds_amd as zuds``).
 """
-import os as _os
-
-# Streams share the HIP runtime's pool of hardware queues (4 by default): with more streams than
-# queues, kernels of different streams queue up behind each other instead of running side by side
-# (measured: two subtraction workers never overlapped; nightly.SubtractionPool).  The runtime reads
-# this when it initialises, i.e. at the first HIP call of the process - import this package first.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
-
 from . import _lib
 from ._lib import ZMError
 from .wcs import WCS

@@ -12,6 +12,7 @@ ctypes calls release the GIL.  ``Engine.set_share(J)`` makes every engine size t
 resident grid to 1 / J of the CUs.  Results do not depend on J (tests/test_nightly_gpu.py).
 """
 import ctypes as C
+import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -23,6 +24,14 @@ from .constants import APERTURE_RADIUS
 from .engine import Engine
 
 __all__ = ['SubtractionPool', 'SubtractionJob']
+
+# Streams share the HIP runtime's pool of hardware queues (4 by default): with more streams than
+# queues, kernels of different streams queue up behind each other instead of running side by side
+# (measured: two workers never overlapped).  The runtime reads this at the first HIP call of the
+# process, so import this module before anything touches the GPU.  8, not more, and only for the
+# one-process-per-GPU pattern of this module: with several processes on a card the hardware queues
+# are oversubscribed and time-sliced (two processes with 16 each: 6 x slower).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 class SubtractionJob(object):
@@ -103,7 +112,6 @@ class SubtractionPool(object):
             raise ValueError('njobs must be in 1 .. 13 (the solver needs 18 resident workgroups per job)')
         self.njobs, self.device = int(njobs), int(device)
         # the solver's resident grid per job: 1 / share of the CUs (ZM_POOL_SHARE overrides: developer)
-        import os
         self.share = min(max(int(os.environ.get('ZM_POOL_SHARE', self.njobs)), self.njobs), 13)
         _lib.lib()                                   # loaded once, here, not by racing worker threads
         self._local = threading.local()
