@@ -645,22 +645,25 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
         sci = dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=args.seeing)
         jobs.append(nm.SubtractionJob(sci, ref, radec=(ra, dec), nreg_side=3))
     out = {'jobs': njobs, 'photometry_positions': 500, 'pools': {}}
-    for J in (1, 2, 3, 4, 5, 6):
+    for J in (1, 2, 3, 4):
         if J > njobs:
             continue
         pool = nm.SubtractionPool(J, device=local)
         try:
             pool.map(jobs[:J], keep=False)                 # allocations, code objects
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            res = pool.map(jobs, keep=False)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            reps = []
+            for _ in range(2):                             # (host threads: the faster of two passes)
+                t0 = time.perf_counter()
+                res = pool.map(jobs, keep=False)
+                torch.cuda.synchronize()
+                reps.append(time.perf_counter() - t0)
+            dt = min(reps)
         finally:
             pool.close()
         bad = [r['info']['status'] for r in res if r['info']['status'] != 0]
         out['pools'][str(J)] = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
-                                'failed': len(bad)}
+                                'passes_ms': [1e3 * t / njobs for t in reps], 'failed': len(bad)}
     best = max(out['pools'].values(), key=lambda v: v['subtract_mpix_s'])
     out['subtract_mpix_s'] = best['subtract_mpix_s']
     return out
