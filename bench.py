@@ -515,7 +515,7 @@ def main():
                        'combine': args.combine, 'subtract': not args.no_subtract,
                        'hotpants': None if args.no_subtract else
                        {k: getattr(sub.info, k) for k, _ in sub.info._fields_}},
-            'world': {'backend': backend if multi else None, 'world_size': world,
+            'world': {'backend': backend if multi else None, 'native_rccl': os.environ.get('ZM_NATIVE_RCCL') == '1', 'world_size': world,
                       'launcher': os.environ.get('ZM_BENCH_LAUNCHER', 'external' if world > 1 else 'none'),
                       'ranks': ranks},
             'legs': legs,

@@ -240,6 +240,23 @@ int zm_coadd_finalize_dev(zm_ctx* ctx, float* s1_to_img, const float* s0,
 int zm_mask_accum_dev(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix,
                       int kind, int first);
 int zm_mask_finalize_dev(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
+/* ---- multi-GPU: the exchange step of a frame-sharded coadd on RCCL (one process per GPU) ----
+ * The reference has no collective: it shards by job (zuds/mpi.py:36-64, nersc/controller.py:101);
+ * BASELINE config 4 shards the FRAMES of one stack, and these calls are the reduce that adds.
+ * librccl is opened on first use.  zm_comm_unique_id on rank 0, the 128 bytes handed to every rank
+ * by the launcher (MPI broadcast, torch.distributed, a file), zm_comm_init on every rank.
+ * zm_coadd_reduce_dev: sum-reduce of S1 / S0, the two planes of ONE buffer of 2 npix floats as
+ * zm_coadd_dev(partial = 1) fills them when out_wgt == out_img + npix; then zm_coadd_finalize_dev.
+ * zm_mask_reduce_dev: the partial masks (-1 marker) of all ranks folded with AND / OR by row
+ * bands, every rank ends with the finalised mask (cov may be NULL).  All enqueue on the stream. */
+#define ZM_COMM_ID_BYTES 128
+typedef struct zm_comm zm_comm;
+int zm_comm_unique_id(void* id128);
+int zm_comm_init(zm_ctx* ctx, int nranks, int rank, const void* id128, zm_comm** out);
+int zm_comm_destroy(zm_comm* comm);
+int zm_coadd_reduce_dev(zm_ctx* ctx, zm_comm* comm, float* s1s0, int64_t npix);
+int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int nx, int ny, int kind,
+                       float* cov);
 /* Resample the frames to `wout` into a resident stack [nframes][ony][onx][2]
  * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it).
  * out_mask_partial (may be NULL): the mask coadd of these frames with the -1 marker

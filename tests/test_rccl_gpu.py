@@ -89,3 +89,37 @@ def test_sharded_coadd_classes_on_rccl(engine, rccl_group, kind):
         engine.set_stream(0)
     assert np.array_equal(img.cpu().numpy(), want[0], equal_nan=True)
     assert np.array_equal(wgt.cpu().numpy(), want[1], equal_nan=True)
+
+
+def test_native_rccl_layer_of_libzudsmi(engine):
+    """zm_comm_* (csrc/comm.hip): librccl opened from inside libzudsmi, a communicator of one rank,
+    the all-reduce over the two partial-sum planes and the mask reduce on the engine's stream; the
+    coadd equals the single-call coadd bit for bit (ZM_NATIVE_RCCL=1 in run_sharded_weighted)."""
+    z = pkg()
+    dmod = importlib.import_module('zuds-pipeline_amd.device')
+    par = importlib.import_module('zuds-pipeline_amd.parallel')
+    frames, base = stack(4, 640, 600)
+    p = z.coadd_params(combine='WEIGHTED', mask_combine='OR', subtract_back=True, rescale_weights=True)
+    want = engine.coadd(frames, base, p, want_mask=True)
+    os.environ['ZM_NATIVE_RCCL'] = '1'
+    try:
+        dc = dmod.DeviceCoadd(base, p, device=0, engine=engine, want_mask=True)
+        dfr = dmod.DeviceFrames(frames, dc.device)
+        dc.run_sharded_weighted(dfr)
+        dc.stream.synchronize()
+        assert isinstance(dc._native, par.NativeComm) and dc._native.world == 1
+        got = [t.cpu().numpy() for t in (dc.img, dc.wgt, dc.mask, dc.mask_wgt)]
+        dc._native.close()
+    finally:
+        os.environ.pop('ZM_NATIVE_RCCL', None)
+        engine.set_stream(0)
+    for a, b, name in zip(got, want, ('img', 'wgt', 'mask', 'mask coverage')):
+        assert np.array_equal(a, b, equal_nan=True), name
+    # an all-reduce that really runs: twice the planes in, the same planes out of a world of one
+    import torch
+    nc = par.NativeComm(engine)
+    both = torch.arange(2 * 1000, dtype=torch.float32, device='cuda').reshape(2, 1000)
+    nc.all_reduce_planes(both[0], both[1])
+    engine.synchronize()
+    assert torch.equal(both.cpu().ravel(), torch.arange(2000, dtype=torch.float32))
+    nc.close()

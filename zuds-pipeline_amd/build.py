@@ -15,7 +15,7 @@ LIBDIR = HERE / 'lib'
 LIBNAME = 'libzudsmi.so'
 
 SOURCES = ['ctx.hip', 'wcs_host.hip', 'resample.hip', 'combine.hip',
-           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip', 'detect.hip']
+           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip', 'detect.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']
 EXTRA_FLAGS = {}     # per-source additions, e.g. {'x.hip': ['-mllvm', '...']}
@@ -62,7 +62,7 @@ def build(force=False, verbose=True):
     lib = LIBDIR / LIBNAME
     if force or procs or _stale(lib, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o',
-               str(lib)] + [str(o) for o in objs]
+               str(lib)] + [str(o) for o in objs] + ['-ldl']          # (dlopen of librccl: comm.hip)
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -108,8 +108,20 @@ class DeviceCoadd(object):
         from .parallel import reduce_masks
         L, ctx = self.engine.L, self.engine.ctx
         self.run(dframes, partial=True)
+        import os
+        from . import parallel
+        if os.environ.get('ZM_NATIVE_RCCL') == '1':
+            # the same reductions called from inside libzudsmi (csrc/comm.hip) on the engine's stream
+            if getattr(self, '_native', None) is None:
+                self._native = parallel.NativeComm(self.engine, group)
+            self.engine.set_stream(self.stream.cuda_stream)
+            self._native.all_reduce_planes(self.img, self.wgt)
+            check(L.zm_coadd_finalize_dev(ctx, self.img.data_ptr(), self.wgt.data_ptr(), self.img.numel()),
+                  'zm_coadd_finalize_dev')
+            if self.mask is not None:
+                self._native.reduce_mask(self.mask, self.params.mask_combine, self.mask_wgt)
+            return self.img, self.wgt
         with self.torch.cuda.stream(self.stream):
-            from . import parallel
             if dist.is_initialized() and (dist.get_world_size(group) > 1 or parallel.FORCE_COLLECTIVES):
                 parallel.all_reduce_planes(self.img, self.wgt, group)
             check(L.zm_coadd_finalize_dev(ctx, self.img.data_ptr(), self.wgt.data_ptr(),

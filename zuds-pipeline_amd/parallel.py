@@ -119,6 +119,56 @@ def all_reduce_planes(s1, s0, group=None):
         dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=group)
 
 
+class NativeComm(object):
+    """The reductions of the frame-sharded WEIGHTED coadd on RCCL called from inside libzudsmi
+    (``zm_comm_*``, csrc/comm.hip) instead of through torch.distributed: the same call pattern -
+    one all-reduce over the two partial-sum planes, the banded exchange of the partial masks -
+    enqueued on the engine's stream.  torch.distributed (any backend) only carries the 128-byte
+    RCCL id from rank 0 to the others; a world of one needs no process group at all.
+    ``ZM_NATIVE_RCCL=1`` makes ``DeviceCoadd.run_sharded_weighted`` use it."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.engine = engine
+        L = engine.L
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(L.zm_comm_unique_id(ident), 'zm_comm_unique_id')
+        if self.world > 1:
+            box = [ident.raw]
+            src = 0 if group is None else dist.get_global_rank(group, 0)
+            dist.broadcast_object_list(box, src=src, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        self._comm = C.c_void_p()
+        check(L.zm_comm_init(engine.ctx, self.world, self.rank, ident, C.byref(self._comm)), 'zm_comm_init')
+
+    def all_reduce_planes(self, s1, s0):
+        """s1, s0: the two planes of one buffer (``DeviceCoadd``, ``HipBackend.partial_sums``)."""
+        n = s1.numel()
+        if not (s1.is_contiguous() and s0.is_contiguous() and s0.data_ptr() == s1.data_ptr() + 4 * n):
+            raise ValueError('the partial sums must be the two planes of one float32 buffer')
+        check(self.engine.L.zm_coadd_reduce_dev(self.engine.ctx, self._comm, s1.data_ptr(), n), 'zm_coadd_reduce_dev')
+
+    def reduce_mask(self, mask, kind, cov=None):
+        ny, nx = mask.shape
+        check(self.engine.L.zm_mask_reduce_dev(self.engine.ctx, self._comm, mask.data_ptr(), nx, ny, int(kind),
+                                               cov.data_ptr() if cov is not None else None), 'zm_mask_reduce_dev')
+
+    def close(self):
+        if self._comm:
+            self.engine.L.zm_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipBackend(object):
     """libzudsmi on this rank's GPU; tensors are CUDA (HIP) tensors."""
 
