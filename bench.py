@@ -395,8 +395,9 @@ def main():
     # launch cost dispatch latency: 0.7 ms per step with every scope timed).  The per-kernel
     # table comes from one more, untimed-for-throughput step with every scope timed.
     # WEIGHTED / AVERAGE stacks run the fused kernel (frames looped inside the output tile);
-    # CLIPPED / MEDIAN materialise the stack through k_resample
-    fused = sum_type and os.environ.get('ZM_COADD_FUSED', '1') != '0'
+    # CLIPPED / MEDIAN materialise the stack through the same kernel in STACK mode (ZM_COADD_FUSED=0:
+    # k_resample frame by frame)
+    fused = os.environ.get('ZM_COADD_FUSED', '1') != '0'
     roof_scope = 'coadd_fused' if fused else 'resample'
     eng.timing(True, only=roof_scope)
     eng.timing_reset()
@@ -469,12 +470,18 @@ def main():
         if roof_scope in kt:
             avg_s = kt[roof_scope]['avg_us'] * 1e-6
             m = 0 if args.no_mask else 1
-            if fused:
+            if fused and sum_type:
                 # SURVEY.md 8(d), fused resample -> WEIGHTED coadd: 8 B per input pixel + 8 B per
                 # output pixel per stack; int32 masks riding along: + 4 B in per input pixel,
                 # + 4 B out per stack
                 bytes_per_launch = (args.frames * (8 + 4 * m) + (8 + 4 * m)) * npx
                 kname = 'k_coadd_fused<LANCZOS3' + (', mask coadd>' if m else '>')
+                units = f'{args.frames} frames x {args.size}^2 px per launch'
+            elif fused:
+                # the materialised stack out of the same kernel (STACK mode): SURVEY.md 8(d) resample,
+                # 16 B per output pixel and frame (+ 4 B mask in per input pixel, + 4 B out per stack)
+                bytes_per_launch = (args.frames * (16 + 4 * m) + 4 * m) * npx
+                kname = 'k_coadd_fused<LANCZOS3, stack' + (', mask coadd>' if m else '>')
                 units = f'{args.frames} frames x {args.size}^2 px per launch'
             else:
                 bytes_per_launch = (RESAMPLE_BYTES_PER_OUTPX + MASK_BYTES_PER_OUTPX * m) * npx

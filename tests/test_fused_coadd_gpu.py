@@ -188,3 +188,49 @@ def test_fullsize_stack_fused_equals_materialised(engine):
     a, b = run_both(engine, frames, base, p)
     assert_same(a, b)
     assert (b[1] > 0).mean() > 0.98
+
+
+@pytest.mark.parametrize('kind', ['CLIPPED', 'MEDIAN'])
+def test_stack_mode_feeds_the_clipped_and_median_coadds(engine, kind):
+    """CLIPPED / MEDIAN stacks are resampled by the same kernel in STACK mode (samples stored instead of
+    summed, the mask coadd still folded in registers): the coadd, its weight, the mask coadd and the
+    coverage equal those of the k_resample path (ZM_COADD_FUSED=0) bit for bit - interior, edge and
+    off-grid tiles, a frame without mask, a frame that misses the grid."""
+    z = pkg()
+    s = synth()
+    frames, _ = stack(6, 520, 480, 900, dither=40.0, rot=0.3)
+    frames[2]['mask'] = None
+    frames.append(dict(frames[0], wcs=s.ztf_wcs(520, 480, dx=5000.0, dy=-4000.0)))
+    wout = engine.autogrid([f['wcs'] for f in frames[:6]])
+    p = z.coadd_params(combine=kind, mask_combine='AND', subtract_back=True, rescale_weights=True, back_size=64)
+    a, b = run_both(engine, frames, wout, p)
+    assert_same(a, b)
+    assert (b[1] > 0).mean() > 0.5 and (b[3] == 0).any()
+
+
+def test_stack_mode_stack_and_partial_mask_equal_k_resample(engine):
+    """zm_resample_stack_dev: every sample of the resident stack and the partial mask coadd (-1 markers),
+    aligned grids (delta kernels) and a rotated frame whose footprint exceeds the LDS tile included."""
+    import importlib
+    z = pkg()
+    s = synth()
+    par = importlib.import_module('zuds-pipeline_amd.parallel')
+    frames, base = stack(4, 450, 430, 950)
+    frames[1]['wcs'] = s.ztf_wcs(450, 430, dx=-7.0, dy=3.0)            # integer shift: delta kernels
+    frames[3]['wcs'] = s.ztf_wcs(450, 430, rot_deg=25.0)
+    frames[0]['mask'][100:140, 200:260] |= 1 << 16
+    p = z.coadd_params(combine='CLIPPED', mask_combine='OR', subtract_back=False, rescale_weights=False)
+    res = {}
+    for mode in ('0', '1'):
+        os.environ['ZM_COADD_FUSED'] = mode
+        try:
+            be = par.HipBackend(base, p, device=0, engine=engine)
+            st = be.resample_stack(frames, want_mask=True)
+            be.stream.synchronize()
+            res[mode] = (st.cpu().numpy(), be.partial_mask.cpu().numpy())
+        finally:
+            os.environ.pop('ZM_COADD_FUSED', None)
+            engine.set_stream(0)
+    assert np.array_equal(res['0'][0], res['1'][0])
+    assert np.array_equal(res['0'][1], res['1'][1])
+    assert (res['1'][1] == -1).any() and (res['1'][0][..., 1] > 0).mean() > 0.5

@@ -111,9 +111,14 @@ static int frames_background(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_c
 
 // Resample nframes device frames onto `wout` into `stack` (float2 [n][ony*onx]).
 // Also accumulates the mask coadd when acc_mask != NULL.
+static int resample_frames_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
+                                 const zm_coadd_params* P, float2* stack, int32_t* acc_mask);
+static bool fused_stack_ok(const zm_coadd_params* P);
 static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
                            const zm_coadd_params* P, float2* stack, int32_t* acc_mask,
                            int32_t mask_fill, int mask_kind) {
+    if (fused_stack_ok(P) && mask_fill == -1 && mask_kind == P->mask_combine)
+        return resample_frames_fused(ctx, n, fr, wout, P, stack, acc_mask);
     const int onx = wout->naxis[0], ony = wout->naxis[1];
     const int64_t opix = (int64_t)onx * ony;
     const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
@@ -189,10 +194,19 @@ static bool fused_ok(const zm_coadd_params* P) {
            (P->combine == ZM_COMBINE_WEIGHTED || P->combine == ZM_COMBINE_AVERAGE);
 }
 
-static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
-                       int partial, float* out_img, float* out_wgt, int32_t* out_mask, float* out_cov) {
+// Everything in front of the fused launch: backgrounds, lattices, every frame prepped into its own
+// plane (+ its box-OR mask plane when a mask coadd is wanted), the frame descriptors.
+struct fused_stage {
+    std::vector<zm_ff> ff;
+    int lds = 0, lnx = 0, lny = 0;
+    bool any_mask = false;
+};
+static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
+                         bool want_mask, fused_stage* S) {
     const int onx = wout->naxis[0], ony = wout->naxis[1];
     const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
+    S->lnx = lnx;
+    S->lny = lny;
     for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
     hipEvent_t* evs = nullptr;
     ZM_TRY(zm_get_sync_events(ctx, 6, &evs));
@@ -201,7 +215,8 @@ static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wo
     bk_plan bp;
     ZM_TRY(frames_background(ctx, n, fr, P, &bp));
     std::vector<zm_map_params> mp_host(n);
-    std::vector<zm_ff> ff(n);
+    std::vector<zm_ff>& ff = S->ff;
+    ff.resize(n);
     int lds = 0;
     size_t prep_bytes = 0, box_bytes = 0;
     std::vector<size_t> prep_off(n), box_off(n);
@@ -215,7 +230,7 @@ static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wo
         prep_off[i] = prep_bytes;
         prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
         box_off[i] = box_bytes;
-        const bool with_mask = out_mask && fr[i].mask;
+        const bool with_mask = want_mask && fr[i].mask;
         if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)nx * ny) + 255) & ~(size_t)255;
         any_mask |= with_mask;
         memset(&ff[i], 0, sizeof(zm_ff));
@@ -248,9 +263,39 @@ static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wo
         ff[i].mbox = mbox;
         ff[i].lat = lat + (size_t)i * lnx * lny;
     }
-    return zm_launch_coadd_fused(ctx, ff.data(), n, lnx, lny, onx, ony, lds, P->combine, P->mask_combine,
-                                 out_img, out_wgt, (out_mask && any_mask) ? out_mask : nullptr, out_cov, partial,
-                                 out_mask && !any_mask ? out_mask : nullptr);
+    S->lds = lds;
+    S->any_mask = any_mask;
+    return 0;
+}
+
+static bool fused_stack_ok(const zm_coadd_params* P) {
+    // the stack of any Lanczos-3 coadd; ZM_COADD_FUSED=0: k_resample frame by frame (the reference
+    // the fused machinery is tested against)
+    const char* e = getenv("ZM_COADD_FUSED");
+    return !(e && e[0] == '0') && P->resample == ZM_RESAMPLE_LANCZOS3;
+}
+
+static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
+                       int partial, float* out_img, float* out_wgt, int32_t* out_mask, float* out_cov) {
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    fused_stage S;
+    ZM_TRY(fused_prepare(ctx, n, fr, wout, P, out_mask != nullptr, &S));
+    return zm_launch_coadd_fused(ctx, S.ff.data(), n, S.lnx, S.lny, onx, ony, S.lds, P->combine, P->mask_combine,
+                                 out_img, out_wgt, (out_mask && S.any_mask) ? out_mask : nullptr, out_cov, partial,
+                                 out_mask && !S.any_mask ? out_mask : nullptr);
+}
+
+// The resampled stack of a CLIPPED / MEDIAN coadd through the same kernel (STACK mode: samples stored,
+// not summed; the mask coadd with its -1 markers left in, as resample_frames leaves it).
+static int resample_frames_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
+                                 const zm_coadd_params* P, float2* stack, int32_t* acc_mask) {
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    const int64_t opix = (int64_t)onx * ony;
+    fused_stage S;
+    ZM_TRY(fused_prepare(ctx, n, fr, wout, P, acc_mask != nullptr, &S));
+    return zm_launch_coadd_fused(ctx, S.ff.data(), n, S.lnx, S.lny, onx, ony, S.lds, ZM_COMBINE_WEIGHTED,
+                                 P->mask_combine, nullptr, nullptr, (acc_mask && S.any_mask) ? acc_mask : nullptr,
+                                 nullptr, 1, acc_mask && !S.any_mask ? acc_mask : nullptr, stack, opix);
 }
 
 extern "C" int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,

@@ -1533,12 +1533,18 @@ __device__ inline void lz3_eval(const lz3_node& n, float dl, zm_v2f t[3]) {
 // drain the register prefetch of the next item at the first pixel.  In the fast path the
 // only vector-memory instructions between two barriers are that prefetch and the 4-byte
 // header fetch issued before it.
-template <int MOP, bool AVG, int WPS>
+// STACK: the same machinery as a resampler - nothing is summed, every item's samples {value, weight}
+// go to its frame's plane of a resident stack (the CLIPPED / MEDIAN path), the mask coadd still
+// accumulates in registers.  An item's samples wait in the sum registers and are stored when the
+// next item starts, ahead of its prefetch: stores issued behind the prefetch would sit in front of
+// it in the (in-order) vmcnt queue of the wait that ends the item.
+template <int MOP, bool AVG, int WPS, bool STACK>
 __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab, int* __restrict__ tilectr, long long* __restrict__ clk) {
+    const float* __restrict__ taptab, int* __restrict__ tilectr, long long* __restrict__ clk,
+    float2* __restrict__ stack, long long fstride) {
     extern __shared__ float4 smem4[];
     // developer probe (ZM_FF_CLOCK=1): shader-clock and 100 MHz wall-clock stamps of workgroup 0 at
     // its first and last instruction - the clock the chip holds while this kernel runs
@@ -1732,6 +1738,19 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
 
+    // STACK: the samples of item (pt, pfr), held in S1 / S0, to plane pfr of the stack
+    int pt = -1, pfr = 0;
+    auto flush = [&]() {
+        if (pt < 0) return;
+        const int ptyi = pt / ntx, ptxi = pt - ptyi * ntx;
+        const int pox = ptxi * TW + tx, poy0 = ptyi * RTH + tyb;
+        float2* plane = stack + (size_t)pfr * (size_t)fstride;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int oy = poy0 + 4 * q;
+            if (pox < onx && oy < ony) plane[(size_t)oy * onx + pox] = make_float2(S1[q], S0[q]);
+        }
+    };
     int slot = 0;
     for (;;) {
         const ff_hdr* H = &HR[slot];
@@ -1747,6 +1766,13 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         const int ox = ox0 + tx;
         // in this order: the header word is older than the prefetch, so storing it at the end of
         // the item waits with vmcnt(prefetch loads), not vmcnt(0)
+        if (STACK) {
+            flush();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { S1[q] = 0.f; S0[q] = 0.f; }
+            pt = t0;
+            pfr = f0;
+        }
         int hw2 = 0;
         if (t2 < ntiles) hw2 = hdr_word(t2, f2);
         // the item two ahead is the last of its tile: take the tile after it from the queue (older
@@ -1849,8 +1875,13 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                     const float v = ok ? acc * fscale : 0.f;
                     const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
                     const float ww = AVG ? (w > 0.f ? 1.f : 0.f) : w;
-                    S1[q] = fmaf(ww, v, S1[q]);
-                    S0[q] += ww;
+                    if (STACK) {
+                        S1[q] = v;
+                        S0[q] = w;
+                    } else {
+                        S1[q] = fmaf(ww, v, S1[q]);
+                        S0[q] += ww;
+                    }
                     if (AVG) SW[q] += w;
                     if (with_mask) {
                         int32_t mres = (int32_t)m16;
@@ -1894,8 +1925,8 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) {
                     const bool me = (k == q);
-                    S1[k] = me ? fmaf(ww, r.v, S1[k]) : S1[k];
-                    S0[k] = me ? S0[k] + ww : S0[k];
+                    S1[k] = me ? (STACK ? r.v : fmaf(ww, r.v, S1[k])) : S1[k];
+                    S0[k] = me ? (STACK ? r.w : S0[k] + ww) : S0[k];
                     if (AVG) SW[k] = me ? SW[k] + r.w : SW[k];
                     if (MOP) MK[k] = (me && with_mask && r.inb) ? ff_mask_fold<MOP>(MK[k], r.m) : MK[k];
                 }
@@ -1910,7 +1941,9 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                 if (ox < onx && oy < ony) {
                     const size_t o = (size_t)oy * onx + ox;
                     const float s1 = S1[q], s0 = S0[q];
-                    if (partial) {
+                    if (STACK) {
+                        // (the samples of this item are flushed with the others)
+                    } else if (partial) {
                         out_img[o] = s1;
                         out_wgt[o] = s0;
                     } else {
@@ -1927,7 +1960,8 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                         }
                     }
                 }
-                S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1;
+                if (!STACK) { S1[q] = 0.f; S0[q] = 0.f; }
+                SW[q] = 0.f; MK[q] = -1;
             }
         }
         if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read two items ago
@@ -1939,6 +1973,7 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         slot = nslot;
         if (t0 >= ntiles) break;
     }
+    if (STACK) flush();
     if (clk && threadIdx.x == 0) {
         if (blockIdx.x == 0) { clk[2] = clock64(); clk[3] = wall_clock64(); }
         clk[4 + 3 * blockIdx.x + 1] = wall_clock64();
@@ -1949,7 +1984,8 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
-                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out) {
+                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
+                          float2* stack, int64_t fstride) {
     const int ntx = zm_div_up(onx, TW), ntiles = ntx * zm_div_up(ony, RTH);
     if (unmasked_out) {
         // a mask coadd was asked for but no frame carries a mask: "nothing covered" everywhere
@@ -1999,12 +2035,17 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
                            lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr, tilectr, G);
     }
-#define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV)                                                                    \
-    hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
+#define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV, STACKV)                                                            \
+    hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV, STACKV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
                        onx, ony, lds_elems, ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, \
-                       taptab, tilectr, clk)
-#define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3)
-    if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
+                       taptab, tilectr, clk, stack, (long long)fstride)
+#define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3, false)
+    if (stack) {
+        if (mop == 0) ZM_FF_LAUNCH1(0, false, 3, true);
+        else if (mop == 1) ZM_FF_LAUNCH1(1, false, 3, true);
+        else ZM_FF_LAUNCH1(2, false, 3, true);
+    }
+    else if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
     else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true); else ZM_FF_LAUNCH(1, false); }
     else { if (avg) ZM_FF_LAUNCH(2, true); else ZM_FF_LAUNCH(2, false); }
 #undef ZM_FF_LAUNCH

@@ -126,7 +126,8 @@ struct zm_ff {                       // one input frame of a fused coadd (device
 };
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
-                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out);
+                          int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
+                          float2* stack = nullptr, int64_t fstride = 0);
 int zm_get_lanczos_table(zm_ctx* ctx, const float** out);
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
