@@ -108,6 +108,7 @@ def pmc_profile(args, kernel):
             continue
         if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask) and \
                 d.get('kernel', '').split('<')[0] == kernel.split('<')[0] and \
+                ('stack' in d.get('kernel', '')) == ('stack' in kernel) and \
                 d.get('frames', args.frames) == args.frames:
             return d
     return {}
