@@ -234,3 +234,22 @@ def test_stack_mode_stack_and_partial_mask_equal_k_resample(engine):
     assert np.array_equal(res['0'][0], res['1'][0])
     assert np.array_equal(res['0'][1], res['1'][1])
     assert (res['1'][1] == -1).any() and (res['1'][0][..., 1] > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize('kind', ['WEIGHTED', 'CLIPPED'])
+def test_ragged_stack_with_odd_widths(engine, kind):
+    """Frames of different sizes in one stack, widths that are not multiples of 4 (no vector staging of the
+    mask box: such frames' edge items go through the generic code), one frame without weights."""
+    z = pkg()
+    s = synth()
+    rng = np.random.default_rng(77)
+    base = s.ztf_wcs(420, 400, tpv=True)
+    frames = []
+    for i, (nx, ny) in enumerate([(333, 290), (400, 410), (257, 300), (420, 400), (391, 377)]):
+        w = s.ztf_wcs(nx, ny, dx=rng.uniform(-20, 20), dy=rng.uniform(-20, 20), rot_deg=rng.uniform(-0.3, 0.3), tpv=True)
+        frames.append(s.make_frame(nx, ny, 1300 + i, w, nstars=30, nbad=200))
+    frames[3]['wgt'] = None
+    p = z.coadd_params(combine=kind, mask_combine='OR', subtract_back=True, rescale_weights=True, back_size=64)
+    a, b = run_both(engine, frames, base, p)
+    assert_same(a, b)
+    assert (b[1] > 0).mean() > 0.6
