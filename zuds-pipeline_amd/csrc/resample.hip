@@ -692,9 +692,10 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
         if (y < ny && x < spitch) {
             float4 o[2];
             prep_quad(img, wgt, nx, bk, nbx, nby, invmesh, var_scale, wthresh, vec_ok, x, y, o);
-            float4* d4 = reinterpret_cast<float4*>(dst + (size_t)y * spitch + x);
-            d4[0] = o[0];
-            if (x + 2 < spitch) d4[1] = o[1];
+            typedef float zm_nt4 __attribute__((ext_vector_type(4)));
+            zm_nt4* d4 = reinterpret_cast<zm_nt4*>(dst + (size_t)y * spitch + x);
+            __builtin_nontemporal_store((zm_nt4){o[0].x, o[0].y, o[0].z, o[0].w}, &d4[0]);
+            if (x + 2 < spitch) __builtin_nontemporal_store((zm_nt4){o[1].x, o[1].y, o[1].z, o[1].w}, &d4[1]);
         }
     }
 #pragma unroll
@@ -1748,7 +1749,9 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int oy = poy0 + 4 * q;
-            if (pox < onx && oy < ony) plane[(size_t)oy * onx + pox] = make_float2(S1[q], S0[q]);
+            // (read back by the combine kernel, 2.4 GB later: non-temporal)
+            if (pox < onx && oy < ony)
+                __builtin_nontemporal_store((zm_v2f){S1[q], S0[q]}, reinterpret_cast<zm_v2f*>(plane + (size_t)oy * onx + pox));
         }
     };
     int slot = 0;
