@@ -1,7 +1,7 @@
 """Developer tool: time of the CLIPPED / MEDIAN combine kernels against the stack depth (same number of samples)."""
 import importlib, sys, time, ctypes as C
 sys.path.insert(0, '/root/repo')
-import numpy as np, torch
+import torch
 z = importlib.import_module('zuds-pipeline_amd')
 eng = z.Engine(0)
 L = eng.L

@@ -11,7 +11,6 @@ J engines (contexts, each with its own stream and scratch) driven by J host thre
 ctypes calls release the GIL.  ``Engine.set_share(J)`` makes every engine size the solver's
 resident grid to 1 / J of the CUs.  Results do not depend on J (tests/test_nightly_gpu.py).
 """
-import ctypes as C
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor

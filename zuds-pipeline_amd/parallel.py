@@ -16,9 +16,6 @@ backend is :class:`HipBackend` (libzudsmi on torch-allocated HBM).
 """
 import ctypes as C
 
-import numpy as np
-
-from . import _lib
 from ._lib import check, wcs_struct
 
 
