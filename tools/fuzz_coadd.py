@@ -12,12 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(ncases, seed, eng=None, verbose=True):
+    """Number of cases whose products differ between the two paths."""
     z = importlib.import_module('zuds-pipeline_amd')
     s = importlib.import_module('zuds-pipeline_amd.synth')
-    eng = z.Engine(0)
+    eng = eng or z.Engine(0)
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(ncases):
@@ -59,8 +58,15 @@ def main():
             diffs = [None if x is None else int((x != y).sum()) for x, y in zip(out['0'], out['1'])]
             print(f'case {case}: MISMATCH n={n} grid={onx}x{ony} tpv={tpv} big_rot={big_rot} {kind} {mk} back={back} '
                   f'sizes={[f["img"].shape for f in frames]} differing pixels {diffs}', flush=True)
-        elif case % 25 == 0:
+        elif verbose and case % 25 == 0:
             print(f'case {case}: ok (n={n}, {onx}x{ony}, {kind}, {mk})', flush=True)
+    return bad
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = run(ncases, seed)
     print(f'{ncases} cases, {bad} mismatches', flush=True)
     sys.exit(1 if bad else 0)
 
