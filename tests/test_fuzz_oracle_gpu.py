@@ -77,3 +77,35 @@ def test_random_subtractions_match_the_oracle(engine, seed):
         kw['ko'] -= 1
     d, n, info, rd = compare(engine, data, **kw)
     assert info['status'] == 0
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('ZM_FUZZ_SEEDS', '8'))))
+def test_random_backgrounds_match_the_oracle(engine, seed):
+    """Random frame sizes (ragged against the mesh), mesh sizes, sky gradients, masked blocks (whole meshes
+    among them) and weight maps that vary inside a mesh, through zm_background and the SExtractor
+    restatement, at the tolerances of test_background_gpu.py."""
+    from oracle import background as oback
+    s = synth()
+    rng = np.random.default_rng(9100 + seed)
+    mesh = int(rng.choice([16, 32, 64, 128]))
+    nx, ny = int(rng.integers(2 * mesh + 3, 5 * mesh + 40)), int(rng.integers(2 * mesh + 3, 5 * mesh + 40))
+    f = s.make_frame(nx, ny, 9100 + seed, s.tan_wcs(nx, ny), sky=float(rng.uniform(50, 400)), noise=float(rng.uniform(2, 9)),
+                     nstars=int(nx * ny / 4000) + 3, nbad=int(rng.integers(0, 300)))
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    img = (f['img'] + rng.uniform(-0.05, 0.05) * xx + rng.uniform(-0.05, 0.05) * yy
+           + rng.uniform(0, 6) * np.sin(xx / rng.uniform(40, 200))).astype(np.float32)
+    wgt = f['wgt'].copy()
+    for _ in range(int(rng.integers(0, 4))):
+        x0, y0 = int(rng.integers(0, nx - 8)), int(rng.integers(0, ny - 8))
+        wgt[y0:y0 + int(rng.integers(4, 2 * mesh)), x0:x0 + int(rng.integers(4, 2 * mesh))] = 0
+    if seed % 3 == 0:
+        wgt = (wgt * (1.0 + 0.3 * np.sin(xx / 37.0) * np.cos(yy / 23.0))).astype(np.float32)
+    if seed % 4 == 3:
+        wgt = None
+    bkg, rms, sub, stats = engine.background(img, wgt, mesh=mesh)
+    r_bkg, r_rms, r_mean, r_sig, _, _ = oback.background(img.astype(np.float64),
+                                                         None if wgt is None else wgt.astype(np.float64), mesh)
+    assert_close_masked(bkg, r_bkg, 2e-5, 1e-3, 'background')
+    assert_close_masked(rms, r_rms, 1e-4, 1e-4, 'background rms')
+    np.testing.assert_allclose(sub, img - bkg, atol=1e-4)
+    assert abs(stats[0] - r_mean) < 2e-3 and abs(stats[1] - r_sig) < 1e-3
