@@ -109,3 +109,37 @@ def test_random_backgrounds_match_the_oracle(engine, seed):
     assert_close_masked(rms, r_rms, 1e-4, 1e-4, 'background rms')
     np.testing.assert_allclose(sub, img - bkg, atol=1e-4)
     assert abs(stats[0] - r_mean) < 2e-3 and abs(stats[1] - r_sig) < 1e-3
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('ZM_FUZZ_SEEDS', '12'))))
+def test_random_median_mad_is_numpy(engine, seed):
+    """quick_background_estimate (zuds/utils.py:32-53) on random sizes and value distributions - heavy
+    ties, negative values, denormals, huge dynamic range, one or two unmasked pixels - equals np.median
+    of the float32 values exactly (radix select on the bit patterns)."""
+    rng = np.random.default_rng(5300 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 4097, 100003, 640 * 611]))
+    kind = seed % 6
+    if kind == 0:
+        a = rng.normal(150, 8, n)
+    elif kind == 1:
+        a = rng.integers(-3, 4, n).astype(np.float64)                 # ties
+    elif kind == 2:
+        a = np.exp(rng.uniform(-80, 80, n)) * rng.choice([-1, 1], n)    # dynamic range, both signs
+    elif kind == 3:
+        a = rng.normal(0, 1e-41, n)                                   # denormals
+    elif kind == 4:
+        a = np.full(n, 42.5)
+    else:
+        a = rng.standard_cauchy(n)
+    a = a.astype(np.float32)
+    mask = (rng.random(n) < rng.uniform(0, 0.6)).astype(np.int32) * 256
+    if mask.all():
+        mask[int(rng.integers(0, n))] = 0
+    med, mad = engine.median_mad(a, mask)
+    pix = a[mask == 0]                      # float32, as image.data of the reference: numpy's median stays in float32
+    with np.errstate(over='ignore', invalid='ignore'):
+        rmed = np.median(pix)
+        rmad = 1.4826 * np.median(np.abs(pix - rmed))
+    assert med == float(rmed), (n, kind, med, rmed)
+    if np.isfinite(rmad):
+        assert abs(mad - rmad) <= 1e-6 * max(abs(rmad), 1e-30), (n, kind, mad, rmad)
