@@ -273,10 +273,6 @@ int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms,
                     const float* ref, const float* ref_rms, const uint8_t* bpm,
                     int nx, int ny, const zm_hp_params* params, float* out_diff,
                     float* out_rms, zm_hp_info* out_info_host);
-/* zm_subtract_dev with out_info_host == NULL only enqueues (the rejection rounds still wait for
- * their flags, the convolution and everything behind it does not); zm_subtract_info synchronises
- * the stream and returns the summary of the context's last subtraction. */
-int zm_subtract_info(zm_ctx* ctx, zm_hp_info* out_info_host);
 int zm_background_dev(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                       int ny, int mesh, int filtersize, float* out_bkg,
                       float* out_rms, float* out_sub, double* out_stats_host);

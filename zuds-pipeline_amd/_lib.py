@@ -125,7 +125,6 @@ _SIGS = {
     'zm_fits_encode_dev': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'zm_mask_accum_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int]),
     'zm_mask_finalize_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
-    'zm_subtract_info': (C.c_int, [_P, _P]),
     'zm_comm_unique_id': (C.c_int, [_P]),
     'zm_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_void_p)]),
     'zm_comm_destroy': (C.c_int, [_P]),

@@ -52,14 +52,6 @@ struct hp_plan {
     int tf0[HP_MAXF1], tfn[HP_MAXF1];           // terms whose x filter is f: tf0[f] .. tf0[f] + tfn[f] - 1 (consecutive)
 };
 
-// fit summary of a subtraction in pinned memory (zm_subtract_info)
-struct hp_summary {
-    int ints[3 * HP_MAXREG + 4];      // nrej | ntotal | fail | nmasked (the device-side ibuf)
-    double stats[2 * HP_MAXREG];      // per region: chi2, stamps used
-    double x0[HP_MAXREG];             // per region: first unknown (the kernel sum)
-    int nreg, nunk, rounds;
-};
-
 // ---------------------------------------------------------------------------
 __global__ void k_hp_valid(const float* __restrict__ sci, const float* __restrict__ ref,
                            const uint8_t* __restrict__ bpm, int64_t n, float il, float iu,
@@ -1750,8 +1742,7 @@ template <int HWK> struct apply_cfg {
 };
 
 template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, const double* __restrict__ rstats,
-                                                  const int* __restrict__ rfail,
+__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long long solved_mask,
                                                   const float* __restrict__ sci,
                                                   const float* __restrict__ ref,
                                                   const float* __restrict__ srms,
@@ -1764,9 +1755,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, const double*
                                                   int* __restrict__ nmasked) {
     // every region in one launch: blockIdx.z = region (the grid covers the largest one)
     const int reg = blockIdx.z;
-    // a region is solved when it fitted at least one stamp and the factorisation held (decided here,
-    // from the device-side fit summary: no host round trip between the last round and this launch)
-    const int solved = rstats[2 * reg + 1] >= 1.0 && rfail[reg] == 0 && isfinite(xsol[(size_t)reg * P.nunk]);
+    const int solved = (int)((solved_mask >> reg) & 1ull);
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
     constexpr int TW = C::TW;                 // tile width
@@ -2121,7 +2110,7 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
 }
 
 template <int HWK>
-static int launch_apply(zm_ctx* ctx, const hp_plan& P, const double* rstats, const int* rfail, const float* sci,
+static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved_mask, const float* sci,
                         const float* ref, const float* srms, const float* trms, const uint8_t* outbad,
                         const double* filt, const double* xsol, float* diff, float* noise,
                         int* nmasked) {
@@ -2146,7 +2135,7 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, const double* rstats, con
         H = std::max(H, P.ry1[reg] - P.ry0[reg]);
     }
     dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
-    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, rstats, rfail, sci, ref, srms,
+    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
                        trms, outbad, filt, xsol, diff, noise, nmasked);
     ZM_HIP(hipGetLastError());
     return 0;
@@ -2254,6 +2243,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                  sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
 
+    int h_int[3 * HP_MAXREG + 4];
     const int nblk = (P.nunk + CH_NB - 1) / CH_NB;
     // Rejection rounds without a host round trip on the critical path: round r + 1 is enqueued
     // before the host learns whether round r rejected anything.  k_hp_reject of round r adds its
@@ -2391,67 +2381,52 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         rounds = r;
         if (h_rflags[r] == 0) break;
     }
+    // a region is solved when it fitted at least one stamp and the factorisation held
+    std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
+    ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipStreamSynchronize(st));
     {
         zm_scope_timer t(ctx, "hp_apply");
-#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, stats, fail, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
-        switch (P.hwk) {
-            HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
-            HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
-            HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
-            default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-        }
+        unsigned long long solved_mask = 0;
+        for (int reg = 0; reg < P.nreg; ++reg)
+            if (h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
+                std::isfinite(h_x[(size_t)reg * P.nunk]))
+                solved_mask |= 1ull << reg;
+        {
+#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
+            switch (P.hwk) {
+                HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
+                HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
+                HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
+                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+            }
 #undef HP_APPLY_CASE
-    }
-    // the fit summary travels to pinned memory behind the apply launch; it is read (after a stream
-    // synchronisation) only when somebody asks for it: here if `info` is given, else in zm_subtract_info
-    {
-        hp_summary* hs = nullptr;
-        ZM_TRY(ctx->get_pinned("hp_summary", sizeof(hp_summary), (void**)&hs));
-        ZM_HIP(hipMemcpyAsync(hs->ints, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipMemcpyAsync(hs->stats, stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipMemcpy2DAsync(hs->x0, sizeof(double), rhs, sizeof(double) * P.nunk, sizeof(double), P.nreg,
-                                hipMemcpyDeviceToHost, st));
-        hs->nreg = P.nreg;
-        hs->nunk = P.nunk;
-        hs->rounds = rounds;
-        hipEvent_t* sev = nullptr;
-        ZM_TRY(zm_get_sync_events(ctx, 9, &sev));
-        ZM_HIP(hipEventRecord(sev[8], st));           // (an event, not the stream: the context may be on another one by then)
-        ctx->hp_summary_ready = true;
-    }
-    if (info) ZM_TRY(zm_subtract_info(ctx, info));
-    return 0;
-}
-
-// The summary of the context's last zm_subtract_dev (its `info` argument may be NULL, in which case
-// nothing waits for the subtraction): waits for that subtraction to finish.
-extern "C" int zm_subtract_info(zm_ctx* ctx, zm_hp_info* info) {
-    ZM_CHECK(ctx && info, "zm_subtract_info: null argument");
-    ZM_CHECK(ctx->hp_summary_ready, "zm_subtract_info: no subtraction has run in this context");
-    ZM_HIP(hipSetDevice(ctx->device));
-    hp_summary* hs = nullptr;
-    ZM_TRY(ctx->get_pinned("hp_summary", sizeof(hp_summary), (void**)&hs));
-    hipEvent_t* sev = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 9, &sev));
-    ZM_HIP(hipEventSynchronize(sev[8]));
-    memset(info, 0, sizeof(*info));
-    double ks = 0, chi = 0;
-    int nsolved = 0;
-    for (int r = 0; r < hs->nreg; ++r) {
-        info->nstamps_total += hs->ints[HP_MAXREG + r];
-        info->nstamps_used += (int)hs->stats[2 * r + 1];
-        if (hs->stats[2 * r + 1] >= 1.0 && hs->ints[2 * HP_MAXREG + r] == 0) {
-            ks += hs->x0[r];
-            chi += hs->stats[2 * r];
-            ++nsolved;
         }
     }
-    info->niter = hs->rounds;
-    info->ncoeff = hs->nunk;
-    info->kernel_sum = nsolved ? ks / nsolved : 0.0;
-    info->chi2 = nsolved ? chi / nsolved : 0.0;
-    info->nmasked = hs->ints[3 * HP_MAXREG];
-    info->status = nsolved == hs->nreg ? 0 : 1;
+    if (info) {
+        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipStreamSynchronize(st));
+        memset(info, 0, sizeof(*info));
+        double ks = 0, chi = 0;
+        int nsolved = 0;
+        for (int r = 0; r < P.nreg; ++r) {
+            info->nstamps_total += h_int[HP_MAXREG + r];
+            info->nstamps_used += (int)h_stats[2 * r + 1];
+            if (h_stats[2 * r + 1] >= 1.0 && h_int[2 * HP_MAXREG + r] == 0) {
+                ks += h_x[(size_t)r * P.nunk];
+                chi += h_stats[2 * r];
+                ++nsolved;
+            }
+        }
+        info->niter = rounds;
+        info->ncoeff = P.nunk;
+        info->kernel_sum = nsolved ? ks / nsolved : 0.0;
+        info->chi2 = nsolved ? chi / nsolved : 0.0;
+        info->nmasked = h_int[3 * HP_MAXREG];
+        info->status = nsolved == P.nreg ? 0 : 1;
+    }
     return 0;
 }
 

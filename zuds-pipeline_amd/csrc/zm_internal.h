@@ -71,7 +71,6 @@ struct zm_ctx {
     bool hp_rset = false, hp_bset = false;
     std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
-    bool hp_summary_ready = false;             // the pinned fit summary of the last zm_subtract_dev is in flight / there
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed
     std::map<std::string, zm_timer_slot> timers;

@@ -150,14 +150,6 @@ class DeviceSubtraction(object):
     ref_* live on the reference grid ``wref``; sci_* on the science grid ``wsci``.
     """
 
-    @property
-    def info(self):
-        """The fit summary (zm_hp_info) of the last ``run``; the first read after a run waits for it."""
-        if not self._info_fresh:
-            check(self.engine.L.zm_subtract_info(self.engine.ctx, C.byref(self._info)), 'zm_subtract_info')
-            self._info_fresh = True
-        return self._info
-
     def __init__(self, wsci, wref, device=0, engine=None, stream=None):
         from .constants import BAD_SUM, BIG_RMS, BKG_VAL
         torch = _torch()
@@ -186,8 +178,7 @@ class DeviceSubtraction(object):
         self.diff = torch.empty(self.shape, **f32)
         self.noise = torch.empty(self.shape, **f32)
         self.BAD_SUM, self.BIG_RMS, self.BKG_VAL = BAD_SUM, float(BIG_RMS), float(BKG_VAL)
-        self._info = _lib.zm_hp_info()
-        self._info_fresh = True
+        self.info = _lib.zm_hp_info()
 
     def run(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
             nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
@@ -248,13 +239,11 @@ class DeviceSubtraction(object):
             self.limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
             p = hp_params(**job_params(seeing, nx, ny, nreg_side, self.limits['il'],
                                        self.limits['tl'], hotpants_kws))
-            # (no info argument: nothing waits for the convolution; `self.info` fetches the fit
-            # summary - and synchronises - when somebody reads it)
             check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
                                     self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
                                     self.bpm.data_ptr(), nx, ny, C.byref(p),
-                                    self.diff.data_ptr(), self.noise.data_ptr(), None), 'zm_subtract_dev')
-            self._info_fresh = False
+                                    self.diff.data_ptr(), self.noise.data_ptr(),
+                                    C.byref(self.info)), 'zm_subtract_dev')
             # bit 17 where hotpants masked (subtraction.py:167-177)
             check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
                                      1 << 17, self.n), 'bit17')

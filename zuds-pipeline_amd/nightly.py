@@ -79,7 +79,7 @@ class _Worker(object):
                                    ref['rms'], ref['mask'], seeing=float(sci['seeing']),
                                    nreg_side=job.nreg_side, hotpants_kws=job.hotpants_kws,
                                    ref_flxscale=float(ref.get('flxscale', 1.0)))
-        out = dict(tag=job.tag)
+        out = dict(tag=job.tag, info={k: getattr(ch.info, k) for k, _ in ch.info._fields_})
         if job.radec is not None:
             # forced photometry on the planes that are still in HBM (scripts/dophot.py:131-133)
             ra, dec = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in job.radec)
@@ -99,8 +99,6 @@ class _Worker(object):
         if keep:
             with torch.cuda.stream(self.stream):
                 out['diff'], out['noise'], out['mask'] = diff.clone(), noise.clone(), mask.clone()
-        # (the fit summary last: reading it waits for the subtraction, everything above is enqueued behind it)
-        out['info'] = {k: getattr(ch.info, k) for k, _ in ch.info._fields_}
         self.stream.synchronize()
         return out
 
