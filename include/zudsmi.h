@@ -168,8 +168,17 @@ typedef struct zm_hp_info {
     double kernel_sum;        /* mean kernel sum over regions */
     double chi2;              /* mean figure of merit of the used stamps */
     int32_t nmasked;          /* output pixels filled with `fi` */
-    int32_t status;
+    int32_t status;           /* 0, or ZM_HP_* bits */
+    int32_t nunsolved;        /* regions without a usable fit (filled with `fi`) */
+    int32_t retries;          /* fits repeated after a solver barrier timed out (see below) */
 } zm_hp_info;
+/* status bits.  The reference sees a failed hotpants as a non-zero exit (CalledProcessError,
+ * zuds/subtraction.py:162); here: ZM_HP_UNSOLVED = a region of the fit had no usable stamps or a
+ * normal matrix that is not positive definite - a property of the data, the call still returns 0
+ * and the region carries the fill value; ZM_HP_TIMEOUT = the solver did not make progress even
+ * after its retry on the safe path - the call returns non-zero. */
+#define ZM_HP_UNSOLVED 1
+#define ZM_HP_TIMEOUT 2
 
 /* Replaces the hotpants run of Subtraction.from_images
  * (zuds/subtraction.py:144-162; flags zuds/hotpants.py:77-93): convolve the

@@ -77,8 +77,7 @@ def load_science(io, fn):
 def write_products(io, sci, ref, res):
     out = zuds.sub_name(sci['path'], ref['path'])
     hdr = dict(sci['header'])
-    hdr['KSUM00'] = float(res['info']['kernel_sum'])
-    hdr['NSTAMPS'] = int(res['info']['nstamps_used'])
+    hdr.update(zuds.hotpants.info_cards(res['info']))    # KSUM00, NSTAMPS, ZMSTATUS, ZMUNSOLV, ZMRETRY
     io.save(out, res['diff'], hdr)
     io.save(out.replace('.fits', '.rms.fits'), res['noise'], hdr)
     mh = dict(sci['header'])
@@ -140,10 +139,17 @@ def main(argv=None):
                 jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=args.nreg_side, tag=fn))
             results = pool.map(jobs)
             for sci, res in zip(scis, results):
-                if res['info']['status'] != 0:
-                    print(f'{os.path.basename(sci["path"])}: subtraction failed (status '
-                          f'{res["info"]["status"]}, {res["info"]["nstamps_used"]} stamps)', flush=True)
+                if 'error' in res:
+                    # the job raised (the reference's drivers: try / except per image,
+                    # scripts/dosub.py:205-213): no products, the night goes on
+                    print(f'{os.path.basename(sci["path"])}: subtraction failed: {res["error"]}', flush=True)
                     continue
+                if res['info']['status'] != 0:
+                    # some regions of the fit have no solution: their pixels carry the fill value and
+                    # bit 17; the products are written with ZMSTATUS / ZMUNSOLV in their headers
+                    print(f'{os.path.basename(sci["path"])}: {res["info"]["nunsolved"]} region(s) of the '
+                          f'kernel fit unsolved (status {res["info"]["status"]}, '
+                          f'{res["info"]["nstamps_used"]} stamps)', flush=True)
                 done.append(write_products(io, sci, ref, res))
             if jobs:
                 print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)

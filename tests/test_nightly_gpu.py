@@ -87,6 +87,41 @@ def test_pool_at_the_reference_parameters(engine):
             assert torch.equal(x[k], y[k]), k
 
 
+def test_fresh_wcs_objects_per_batch(engine):
+    """scripts/donightly.py builds new sci dicts and WCS objects per batch and drops the old ones, so
+    CPython hands the addresses of dead WCS objects to new ones (the worker once cached the
+    WCS structs under id()).  Two batches of the same frame size and different geometry through ONE
+    worker, the first batch garbage-collected in between: the second equals a fresh pool's result."""
+    import gc
+    import torch
+    z, s = pkg(), synth()
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    pool = nm.SubtractionPool(1)
+    first = make_jobs(torch, z, s, 2, 640, 600, 1, {'ko': 1, 'bgo': 0}, seed=1300)
+    ids = {id(j.sci['wcs']) for j in first}
+    pool.map(first, keep=False)
+    del first
+    gc.collect()
+    second = reused = None
+    for attempt in range(20):                            # until an address really is handed out again
+        second = make_jobs(torch, z, s, 2, 640, 600, 1, {'ko': 1, 'bgo': 0}, seed=1400 + attempt)
+        reused = ids & {id(j.sci['wcs']) for j in second}
+        if reused:
+            break
+        ids |= {id(j.sci['wcs']) for j in second}
+        gc.collect()
+    got = pool.map(second)
+    pool.close()
+    fresh = nm.SubtractionPool(1)
+    want = fresh.map(second)
+    fresh.close()
+    for x, y in zip(got, want):
+        assert x['info'] == y['info'] and x['info']['status'] == 0
+        for k in ('diff', 'noise', 'mask'):
+            assert torch.equal(x[k], y[k]), k
+        assert np.array_equal(x['phot']['flux'], y['phot']['flux'], equal_nan=True)
+
+
 def test_share_limits(engine):
     z = pkg()
     nm = importlib.import_module('zuds-pipeline_amd.nightly')

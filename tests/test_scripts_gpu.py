@@ -92,3 +92,138 @@ def test_donightly_products_equal_the_object_api(tmp_path, engine):
         assert np.array_equal(sub.rms_image.data, got[out][1])
         assert np.array_equal(sub.mask_image.data, got[out][2])
         assert sub.hotpants_info['ncoeff'] == 722 and sub.hotpants_info['status'] == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# dostack.py / dosub.py / makeref.py: the reference's other drivers on the hot path
+# (scripts/dostack.py:59, scripts/dosub.py:97, scripts/makeref.py:85).  Each is run on job files
+# and its products are compared with the object API called directly.
+def _scene(z, s, d, nx, ny, n, seed, prefix, fwhm=2.2, extra=None):
+    """n dithered frames of one star field as IPAC-style files (sciimg + mskimg); -> (objects, paths)"""
+    base = s.ztf_wcs(nx, ny, tpv=True)
+    rng = np.random.default_rng(seed)
+    nst = int(nx * ny / 2500)
+    xs, ys = rng.uniform(-20, nx + 20, nst), rng.uniform(-20, ny + 20, nst)
+    fl = np.exp(rng.uniform(np.log(3e3), np.log(8e4), nst))
+    ra, dec = base.all_pix2world(xs, ys, 0)
+    ims, paths = [], []
+    for i in range(n):
+        w = s.ztf_wcs(nx, ny, dx=rng.uniform(-5, 5), dy=rng.uniform(-5, 5), rot_deg=rng.uniform(-0.05, 0.05))
+        f = s.make_frame(nx, ny, seed + 1 + i, w, star_sky=(ra, dec, fl), fwhm=fwhm, sky=150.0 + 7 * i,
+                         noise=4.0, bad_block=(60 + 37 * i, 90 + 23 * i, 4))
+        hdr = f['header']
+        hdr['OBSJD'] = 2458000.5 + hdr['OBSMJD'] - 58000.0 + i
+        hdr.update(extra(i) if extra else {})
+        path = os.path.join(d, f'ztf_{prefix}{i:02d}_000651_zg_c03_o_q1_sciimg.fits')
+        z.fits.write(path, f['img'], hdr)
+        z.fits.write(path.replace('sciimg', 'mskimg'), f['mask'].astype(np.int16), hdr)
+        im = z.ScienceImage.from_file(path)
+        im.mask_image = z.MaskImage.from_file(path.replace('sciimg', 'mskimg'))
+        ims.append(im)
+        paths.append(path)
+    return ims, paths
+
+
+def _products(z, path):
+    return [z.fits.read(path.replace('.fits', sfx))[0] for sfx in ('.fits', '.weight.fits', '.mask.fits')]
+
+
+def test_dostack_products_equal_from_images(tmp_path, engine):
+    """scripts/dostack.py on a two-job file: names, skip-if-exists and pixels."""
+    import pandas as pd
+    z, s = pkg(), synth()
+    d = str(tmp_path)
+    _, p1 = _scene(z, s, d, 640, 600, 3, 4100, '202001')
+    _, p2 = _scene(z, s, d, 640, 600, 4, 4200, '202002')
+    pd.DataFrame({'target': [';'.join(p1), ';'.join(p2)], 'left': ['20200101', '20200201'],
+                  'right': ['20200108', '20200208']}).to_csv(os.path.join(d, 'jobs.csv'), index=False)
+    script = load_script('dostack')
+    assert script.main([os.path.join(d, 'jobs.csv'), '--tmpdir', d]) == 0
+    names = [os.path.join(d, f'000651_c03_q1_zg_{a}_{b}.coadd.fits')
+             for a, b in (('20200101', '20200108'), ('20200201', '20200208'))]
+    got = []
+    for nm in names:
+        assert os.path.exists(nm) and os.path.exists(nm.replace('.fits', '.mask.fits')), nm
+        got.append(_products(z, nm))
+    stamp = [os.path.getmtime(nm) for nm in names]
+    assert script.main([os.path.join(d, 'jobs.csv'), '--tmpdir', d]) == 0       # resumes: nothing redone
+    assert [os.path.getmtime(nm) for nm in names] == stamp
+    for nm, paths, g in zip(names, (p1, p2), got):
+        ims = script.load_inputs(';'.join(paths))
+        want = z.ScienceCoadd.from_images(ims, outfile_name=nm.replace('.coadd.', '.direct.'), tmpdir=d)
+        w = _products(z, want.local_path)
+        for a, b, what in zip(g, w, ('coadd', 'weight', 'mask')):
+            assert np.array_equal(a, b), (nm, what)
+        hdr = z.fits.read(nm)[1]
+        assert hdr['MAGZP'] == 25.0 and 'SEEING' in hdr        # calculate_seeing=True ran offline
+
+
+def test_dosub_products_equal_from_images(tmp_path, engine):
+    """scripts/dosub.py do_one: the mesh-rms branch (no weight / rms sibling, dosub.py:42-44), the
+    checkpoint by name, and products equal to SingleEpochSubtraction.from_images."""
+    z, s = pkg(), synth()
+    d = str(tmp_path)
+    refims, _ = _scene(z, s, d, 640, 600, 3, 4300, '201912', fwhm=2.0)
+    refname = os.path.join(d, 'ref.000651_c03_q1_zg.fits')
+    z.ReferenceImage.from_images(refims, refname, sci_swarp_kws={'COMBINE_TYPE': 'WEIGHTED'})
+    _, spaths = _scene(z, s, d, 640, 600, 2, 4400, '202003', fwhm=2.6)
+    script = load_script('dosub')
+    subs = [script.do_one(p, z.ScienceImage, z.SingleEpochSubtraction, refname, tmpdir=d) for p in spaths]
+    with pytest.raises(script.PredecessorError):
+        script.do_one(spaths[0], z.ScienceImage, z.SingleEpochSubtraction, refname, tmpdir=d)
+    for p, sub in zip(spaths, subs):
+        out = z.sub_name(p, refname)
+        assert sub.local_path == out and os.path.exists(out.replace('.fits', '.rms.fits'))
+        got = [z.fits.read(out.replace('.fits', sfx))[0] for sfx in ('.fits', '.rms.fits', '.mask.fits')]
+        hdr = z.fits.read(out)[1]
+        assert hdr['ZMSTATUS'] == 0 and hdr['ZMUNSOLV'] == 0 and hdr['ZMRETRY'] == 0 and 'KSUM00' in hdr
+        for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+            os.remove(out.replace('.fits', sfx))
+        sci = z.ScienceImage.from_file(p)
+        sci.mask_image = z.MaskImage.from_file(p.replace('sciimg', 'mskimg'))
+        _ = sci.rms_image
+        ref = z.ReferenceImage.from_file(refname, load_others=False)
+        ref.mask_image = z.MaskImage.from_file(refname.replace('.fits', '.mask.fits'))
+        ref._weightimg = z.FITSImage.from_file(refname.replace('.fits', '.weight.fits'))
+        want = z.SingleEpochSubtraction.from_images(sci, ref, tmpdir=d)
+        assert np.array_equal(want.data, got[0])
+        assert np.array_equal(want.rms_image.data, got[1])
+        assert np.array_equal(want.mask_image.data, got[2])
+
+
+def test_makeref_selects_like_the_reference_and_coadds(tmp_path, engine):
+    """scripts/makeref.py: the header cuts of scripts/makeref.py:57-78 (date window, seeing, limiting
+    magnitude, infobits, the deepest MAX_FRAMES, at least MIN_FRAMES), the product name, and pixels
+    equal to ReferenceImage.from_images of the selected frames."""
+    import pandas as pd
+    z, s = pkg(), synth()
+    d = str(tmp_path / 'field')
+    os.makedirs(d)
+    maglim = [20.5, 20.9, 20.1, 20.7, 19.0, 20.8, 20.6, 20.4]
+
+    def cards(i):
+        return {'MAGLIM': maglim[i], 'INFOBITS': 1 if i == 1 else 0, 'SEEING': 2.9 if i == 2 else 2.1}
+    ims, paths = _scene(z, s, d, 512, 480, 8, 4500, '202001', extra=cards)
+    # frame 7 falls out of the date window, 1 has infobits, 2 bad seeing, 4 too shallow
+    jd = [float(im.header['OBSJD']) for im in ims]
+    lo = pd.to_datetime(jd[0] - 0.5, unit='D', origin='julian')
+    hi = pd.to_datetime(jd[6] + 0.5, unit='D', origin='julian')
+    with open(os.path.join(str(tmp_path), 'dirs.txt'), 'w') as fh:
+        fh.write(d + '\n')
+    script = load_script('makeref')
+    top = script.select(d, lo, hi)
+    assert [os.path.basename(t.local_path) for t in top] == [os.path.basename(paths[i]) for i in (5, 3, 6, 0)]
+    args = [os.path.join(str(tmp_path), 'dirs.txt'), str(lo), str(hi), 'v9']
+    assert script.main(args) == []                         # 4 < 14 frames: skipped, like the reference
+    script.MIN_FRAMES = 3
+    script.MAX_FRAMES = 3                                  # "the very best images"
+    made = script.main(args)
+    want_name = os.path.join(d, 'ref.000651_c03_q1_zg.v9.fits')
+    assert made == [want_name]
+    assert script.main(args) == []                         # exists: skipped
+    got = _products(z, want_name)
+    sel = script.select(d, lo, hi)
+    assert len(sel) == 3
+    direct = z.ReferenceImage.from_images(sel, os.path.join(d, 'direct.fits'), data_product=True, tmpdir=str(tmp_path))
+    for a, b, what in zip(got, _products(z, direct.local_path), ('coadd', 'weight', 'mask')):
+        assert np.array_equal(a, b), what

@@ -206,3 +206,42 @@ def test_config2_parameters_against_the_oracle(engine, ko):
     assert info['ncoeff'] == 1 + 48 * (ko + 1) * (ko + 2) // 2 + 1
     assert info['nstamps_total'] == 100 and info['status'] == 0
     assert abs(info['kernel_sum'] - 1.3) < 2e-3
+
+
+def test_barrier_timeout_is_retried_on_the_safe_path_and_reported(engine, monkeypatch, tmp_path):
+    """a barrier of the fused factorisation that gives up (its workgroups were
+    not all resident) used to look like a singular fit.  Now the time-outs are counted apart from bad
+    pivots, the whole fit is repeated on the one-workgroup form (which waits for nobody) and the
+    summary says so.  ZM_CHOL_SPIN_LIMIT=0 makes every barrier of the first attempt give up at its
+    first unsuccessful poll; the retry must give the bits of an undisturbed run."""
+    z = pkg()
+    data = scene(nx=640, ny=600, seed=21, nstars=400)
+    kw = dict(r=5.0, rss=12.0, nsx=5, nsy=5, nrx=2, nry=2, ko=2, bgo=0, **COMMON)
+    d0, n0, i0 = engine.subtract(*data, **kw)
+    assert i0['status'] == 0 and i0['retries'] == 0 and i0['nunsolved'] == 0
+    monkeypatch.setenv('ZM_CHOL_SPIN_LIMIT', '0')
+    d1, n1, i1 = engine.subtract(*data, **kw)
+    monkeypatch.delenv('ZM_CHOL_SPIN_LIMIT')
+    assert i1['retries'] == 1 and i1['status'] == 0 and i1['nunsolved'] == 0
+    assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
+    for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
+        assert i0[k] == i1[k], k
+    # the summary lands in the product header (hotpants -hki writes its kernel information there)
+    cards = z.hotpants.info_cards(i1)
+    assert cards['ZMSTATUS'] == 0 and cards['ZMRETRY'] == 1 and cards['ZMUNSOLV'] == 0
+
+
+def test_unsolved_region_warns_and_is_flagged(engine):
+    """A region whose stamps are all unusable: status bit ZM_HP_UNSOLVED, nunsolved counts it, its
+    pixels carry the fill value, the object layer warns (hotpants.warn_unsolved)."""
+    z = pkg()
+    sci, srms, ref, rrms, bpm = scene(nx=640, ny=600, seed=22, nstars=400)
+    bpm = bpm.copy()
+    bpm[:300, :320] = 1                                   # region (0, 0) of a 2 x 2 layout: all bad
+    d, n, info = engine.subtract(sci, srms, ref, rrms, bpm, r=5.0, rss=12.0, nsx=4, nsy=4, nrx=2, nry=2,
+                                 ko=1, bgo=0, **COMMON)
+    assert info['status'] == z._lib.HP_UNSOLVED and info['nunsolved'] == 1 and info['retries'] == 0
+    assert np.all(d[:300, :320] == np.float32(1e-30))
+    assert (d[300:, 320:] != np.float32(1e-30)).mean() > 0.9
+    with pytest.warns(RuntimeWarning, match='1 region'):
+        z.hotpants.warn_unsolved(info, 'test')

@@ -65,7 +65,11 @@ class zm_hp_info(C.Structure):
     _fields_ = [('nstamps_total', C.c_int32), ('nstamps_used', C.c_int32),
                 ('niter', C.c_int32), ('ncoeff', C.c_int32),
                 ('kernel_sum', C.c_double), ('chi2', C.c_double),
-                ('nmasked', C.c_int32), ('status', C.c_int32)]
+                ('nmasked', C.c_int32), ('status', C.c_int32),
+                ('nunsolved', C.c_int32), ('retries', C.c_int32)]
+
+
+HP_UNSOLVED, HP_TIMEOUT = 1, 2          # zm_hp_info.status bits (include/zudsmi.h)
 
 
 _P = C.c_void_p

@@ -77,7 +77,25 @@ int rccl_load() {
 struct zm_comm {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    bool broken = false;   // a call failed inside a group: peers hold unmatched calls, nothing more may be queued
 };
+
+// Inside ncclGroupStart / ncclGroupEnd a plain `return` would leave this thread's group open: every
+// later collective on the communicator is then queued and never launched.  Close the group, mark
+// the communicator unusable, then report.
+#define ZM_NCCL_IN_GROUP(comm_, call)                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            (void)R.GroupEnd();                                                                \
+            (comm_)->broken = true;                                                            \
+            zm_set_error("%s failed inside a group: %s (%s:%d); communicator unusable", #call, \
+                         R.GetErrorString(r_), __FILE__, __LINE__);                            \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+#define ZM_COMM_USABLE(comm_, who) \
+    ZM_CHECK(!(comm_)->broken, who ": communicator marked unusable by an earlier failure; zm_comm_destroy it")
 
 extern "C" int zm_comm_unique_id(void* id128) {
     ZM_CHECK(id128 != nullptr, "zm_comm_unique_id: null argument");
@@ -118,6 +136,7 @@ extern "C" int zm_comm_destroy(zm_comm* comm) {
 
 extern "C" int zm_coadd_reduce_dev(zm_ctx* ctx, zm_comm* comm, float* s1s0, int64_t npix) {
     ZM_CHECK(ctx && comm && s1s0 && npix > 0, "zm_coadd_reduce_dev: bad argument");
+    ZM_COMM_USABLE(comm, "zm_coadd_reduce_dev");
     ZM_HIP(hipSetDevice(ctx->device));
     zm_scope_timer t(ctx, "rccl_planes");
     ZM_NCCL(R.AllReduce(s1s0, s1s0, (size_t)(2 * npix), ncclFloat, ncclSum, comm->comm, ctx->stream));
@@ -135,6 +154,7 @@ extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int
                                   float* cov) {
     ZM_CHECK(ctx && comm && mask && nx > 0 && ny > 0, "zm_mask_reduce_dev: bad argument");
     ZM_CHECK(kind == ZM_MASK_AND || kind == ZM_MASK_OR, "zm_mask_reduce_dev: unknown mask combine %d", kind);
+    ZM_COMM_USABLE(comm, "zm_mask_reduce_dev");
     ZM_HIP(hipSetDevice(ctx->device));
     const int world = comm->nranks, rank = comm->rank;
     const int64_t npix = (int64_t)nx * ny;
@@ -155,10 +175,18 @@ extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int
     for (int g = 0; g < world; ++g) {
         if (g == rank) continue;
         const size_t sendpx = (size_t)(b[g + 1] - b[g]) * nx;
-        if (sendpx) ZM_NCCL(R.Send(mask + (size_t)b[g] * nx, sendpx, ncclInt32, g, comm->comm, st));
-        if (myrows) ZM_NCCL(R.Recv(recv + (size_t)g * bandpx, (size_t)myrows * nx, ncclInt32, g, comm->comm, st));
+        if (sendpx) ZM_NCCL_IN_GROUP(comm, R.Send(mask + (size_t)b[g] * nx, sendpx, ncclInt32, g, comm->comm, st));
+        if (myrows)
+            ZM_NCCL_IN_GROUP(comm, R.Recv(recv + (size_t)g * bandpx, (size_t)myrows * nx, ncclInt32, g, comm->comm, st));
     }
-    ZM_NCCL(R.GroupEnd());
+    {
+        ncclResult_t r_ = R.GroupEnd();
+        if (r_ != ncclSuccess) {
+            comm->broken = true;
+            zm_set_error("ncclGroupEnd failed: %s; communicator unusable", R.GetErrorString(r_));
+            return 1;
+        }
+    }
     if (myrows) {
         ZM_HIP(hipMemcpyAsync(recv + (size_t)rank * bandpx, mask + (size_t)b[rank] * nx,
                               sizeof(int32_t) * (size_t)myrows * nx, hipMemcpyDeviceToDevice, st));

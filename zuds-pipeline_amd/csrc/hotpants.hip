@@ -989,7 +989,7 @@ __device__ inline void st_sh(double* p, double v) {
 // sized to be fully resident, so this only happens when something else holds the GPU).
 // The wait is bounded: no hang, the factorisation is reported as failed instead.
 #define CF_SPIN_LIMIT (1 << 16)
-__device__ inline bool region_barrier(unsigned* ctr, unsigned target) {
+__device__ inline bool region_barrier(unsigned* ctr, unsigned target, int spin_limit) {
     __shared__ int dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are done
     __syncthreads();
@@ -998,7 +998,7 @@ __device__ inline bool region_barrier(unsigned* ctr, unsigned target) {
         int spins = 0, d = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > CF_SPIN_LIMIT || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (++spins > spin_limit || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 d = 1;
                 break;
@@ -1030,8 +1030,12 @@ __device__ inline void region_arrive(unsigned* ctr) {
 //         without the corner that workgroup 0 holds)                           | barrier b2
 // so the 32 x 32 factorisation - the longest serial piece - overlaps the panel barrier and the
 // trailing update instead of following them.
+// fail[reg]: pivots that had to be clamped (the matrix is not positive definite: a property of the
+// fit); tmo[reg]: a barrier gave up waiting (a property of the launch: not every workgroup was
+// resident - the host repeats the fit on the one-workgroup form, which waits for nobody)
 __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
-                                                    unsigned* bar, long long* prof, const int* __restrict__ guard) {
+                                                    int* tmo, int spin_limit, unsigned* bar, long long* prof,
+                                                    const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ double Li[64][CH_NB + 2];        // pitch 34: conflict-free ds_read_b64 of MFMA operands
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         factor_and_publish(0, nb0, 0);
     }
     gen2 += W;
-    bool dead = region_barrier(ctr2, gen2);
+    bool dead = region_barrier(ctr2, gen2, spin_limit);
     const int wave = tid >> 6, lane = tid & 63;
     for (int kb = 0; kb < nblk && !dead; ++kb) {
         const int k0 = kb * CH_NB;
@@ -1081,7 +1085,8 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         const int r0n = min(CH_NB, below);
         const int per = (W > 1) ? (below - r0n + W - 2) / (W - 1) : 0;
         const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
-        const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
+        // (a lone workgroup - the safe form the host falls back to - solves every panel row itself)
+        const int pend = (w == 0) ? (W == 1 ? below : r0n) : min(r0n + w * per, below);
         // workgroup 0: the unfactored next diagonal block, fetched ahead of its use
         // (in the accumulator layout of the f64 matrix cores: wave = 16 x 16 quadrant (ti, tj) of
         // the block, column = lane & 15, row = (lane >> 4) + 4 reg)
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             CF_TICK(4);
         } else {
             gen1 += W;
-            dead = region_barrier(ctr1, gen1);
+            dead = region_barrier(ctr1, gen1, spin_limit);
             CF_TICK(3);
             if (dead) break;
             // (c) trailing update A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle; the
@@ -1311,10 +1316,10 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             CF_TICK(4);
         }
         gen2 += W;
-        dead = region_barrier(ctr2, gen2);
+        dead = region_barrier(ctr2, gen2, spin_limit);
         CF_TICK(5);
     }
-    if (dead && tid == 0) atomicAdd(&fail[reg], 1);
+    if (dead && tid == 0) atomicAdd(&tmo[reg], 1);
     if (prof && tid == 0)
         for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
 #undef CF_TICK
@@ -2170,8 +2175,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
     int* chg = nullptr;                  // cells whose substamp the last rejection changed
     ZM_TRY(ctx->get("hp_chg", sizeof(int) * (2 * (size_t)P.ncell + P.nreg), (void**)&chg));   // flags + per-region lists
-    ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * (3 * HP_MAXREG + 4), (void**)&ibuf));
+    constexpr int HP_NIBUF = 4 * HP_MAXREG + 4;
+    ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * HP_NIBUF, (void**)&ibuf));
     int *nrej = ibuf, *ntotal = ibuf + HP_MAXREG, *fail = ibuf + 2 * HP_MAXREG, *nmasked = ibuf + 3 * HP_MAXREG;
+    int* tmo = ibuf + 3 * HP_MAXREG + 4;  // barrier time-outs of k_chol_fused per region
     unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
     ZM_TRY(ctx->get("hp_cbar", sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG, (void**)&cbar));
     double* cdg = nullptr;               // published diagonal factors of k_chol_fused
@@ -2198,7 +2205,6 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_HIP(hipStreamSynchronize(st));   // the previous call may still be reading the staging area
     memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
     ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
-    ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * (3 * HP_MAXREG + 4), st));
 
     const dim3 b256(256);
     {
@@ -2223,6 +2229,19 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
         ZM_HIP(hipGetLastError());
     }
+    // The fit (stamp search ... rejection rounds) is one repeatable attempt: when a barrier of the
+    // fused factorisation timed out - its workgroups were not all resident, something else held
+    // the GPU - every later round worked on a garbage solution, so the whole fit is run again on
+    // the one-workgroup form of the factorisation (W = 1: it waits for nobody; slower, same bits).
+    // ZM_CHOL_SPIN_LIMIT (developer / tests): spins before a barrier gives up in the FIRST attempt.
+    int h_int[HP_NIBUF];
+    std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
+    int rounds = 0, retries = 0, ntimeouts = 0;
+    const char* spin_env = getenv("ZM_CHOL_SPIN_LIMIT");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool safe = attempt > 0;
+    const int spin_limit = (!safe && spin_env) ? atoi(spin_env) : CF_SPIN_LIMIT;
+    ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * HP_NIBUF, st));
     {
         zm_scope_timer t(ctx, "hp_cells");
         {
@@ -2243,8 +2262,6 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                  sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
 
-    int h_int[3 * HP_MAXREG + 4];
-    const int nblk = (P.nunk + CH_NB - 1) / CH_NB;
     // Rejection rounds without a host round trip on the critical path: round r + 1 is enqueued
     // before the host learns whether round r rejected anything.  k_hp_reject of round r adds its
     // rejections to rflags[r]; every kernel of round r + 1 starts with `if (rflags[r] == 0)
@@ -2320,7 +2337,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 ZM_CHECK(2 * P.nreg <= wg_cap,
                          "zm_subtract: %d regions exceed the %d resident workgroups of this context's share (1 / %d)",
                          P.nreg, wg_cap, ctx->share);
-                int W = std::max(2, std::min(68, wg_cap / P.nreg));
+                int W = safe ? 1 : std::max(2, std::min(68, wg_cap / P.nreg));
                 int nunk = P.nunk;
                 double* Aarg = A;
                 int* farg = fail;
@@ -2332,7 +2349,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
                 // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
                 // order against the following launches of the stream on its first use)
-                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, barg, parg, guard);
+                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
+                                   spin_limit, barg, parg, guard);
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
                     std::vector<long long> hp((size_t)6 * P.nreg * W);
@@ -2373,7 +2391,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         ZM_HIP(hipEventRecord(evs[1 + (rounds & 1)], st));
         return 0;
     };
-    int rounds = 0;
+    rounds = 0;
     ZM_TRY(enqueue_round(1));
     for (int r = 1; r <= 8; ++r) {
         if (r < 8) ZM_TRY(enqueue_round(r + 1));          // void if round r rejects nothing
@@ -2381,19 +2399,30 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         rounds = r;
         if (h_rflags[r] == 0) break;
     }
-    // a region is solved when it fitted at least one stamp and the factorisation held
-    std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
-    ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+    ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * HP_NIBUF, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipStreamSynchronize(st));
+    ntimeouts = 0;
+    for (int reg = 0; reg < P.nreg; ++reg) ntimeouts += h_int[3 * HP_MAXREG + 4 + reg];
+    if (ntimeouts == 0) break;
+    if (!safe) {
+        ++retries;
+        if (getenv("ZM_VERBOSE"))
+            fprintf(stderr, "zm_subtract: %d barrier time-out(s) in the fused factorisation; repeating the fit on the "
+                            "one-workgroup form\n", ntimeouts);
+    }
+    }   // attempts
+    // a region is solved when it fitted at least one stamp and the factorisation held
+    auto reg_solved = [&](int reg) {
+        return h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
+               h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x[(size_t)reg * P.nunk]);
+    };
     {
         zm_scope_timer t(ctx, "hp_apply");
         unsigned long long solved_mask = 0;
         for (int reg = 0; reg < P.nreg; ++reg)
-            if (h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
-                std::isfinite(h_x[(size_t)reg * P.nunk]))
-                solved_mask |= 1ull << reg;
+            if (reg_solved(reg)) solved_mask |= 1ull << reg;
         {
 #define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
             switch (P.hwk) {
@@ -2406,7 +2435,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         }
     }
     if (info) {
-        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * (3 * HP_MAXREG + 4), hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * HP_NIBUF, hipMemcpyDeviceToHost, st));
         ZM_HIP(hipStreamSynchronize(st));
         memset(info, 0, sizeof(*info));
         double ks = 0, chi = 0;
@@ -2414,7 +2443,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         for (int r = 0; r < P.nreg; ++r) {
             info->nstamps_total += h_int[HP_MAXREG + r];
             info->nstamps_used += (int)h_stats[2 * r + 1];
-            if (h_stats[2 * r + 1] >= 1.0 && h_int[2 * HP_MAXREG + r] == 0) {
+            if (reg_solved(r)) {
                 ks += h_x[(size_t)r * P.nunk];
                 chi += h_stats[2 * r];
                 ++nsolved;
@@ -2425,7 +2454,17 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         info->kernel_sum = nsolved ? ks / nsolved : 0.0;
         info->chi2 = nsolved ? chi / nsolved : 0.0;
         info->nmasked = h_int[3 * HP_MAXREG];
-        info->status = nsolved == P.nreg ? 0 : 1;
+        // status bits: ZM_HP_UNSOLVED - a region without a usable fit (no stamps left / normal matrix
+        // not positive definite: its pixels carry the fill value); ZM_HP_TIMEOUT - the solver's
+        // barriers timed out in the safe form as well (the device is not making progress)
+        info->status = (nsolved == P.nreg ? 0 : ZM_HP_UNSOLVED) | (ntimeouts ? ZM_HP_TIMEOUT : 0);
+        info->nunsolved = P.nreg - nsolved;
+        info->retries = retries;
+    }
+    if (ntimeouts) {
+        zm_set_error("zm_subtract: the kernel-fit solver timed out at its barriers %d time(s), also in the "
+                     "one-workgroup form after %d retry; the difference image is not valid", ntimeouts, retries);
+        return 3;
     }
     return 0;
 }

@@ -1280,8 +1280,10 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
                             bh <= FF_PF * (256 / (bw >> 1)) && bh <= FF_PM * (256 / (bw >> 2));
         H->touches = touches;
         H->use_lds = use_lds;
+        // (the fast path fetches the box-OR entries 4 pixels = 8 bytes per load from row starts at
+        // multiples of nx: aligned only when nx % 4 == 0 - other widths take the generic mask code)
         H->fast = use_lds && bx0 >= 0 && by0 >= 0 && bx0 + bw <= nx && by0 + bh <= ny &&
-                  (txi + 1) * TW <= onx && (tyi + 1) * RTH <= ony;
+                  (txi + 1) * TW <= onx && (tyi + 1) * RTH <= ony && ((nx & 3) == 0 || F->mask == nullptr);
         // staged through LDS with bounds tests (the mask box in groups of 4 pixels: nx % 4 == 0)
         H->edge = use_lds && !H->fast && (nx & 3) == 0;
     }

@@ -49,6 +49,27 @@ def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
     return params
 
 
+def info_cards(info):
+    """The fit summary as header cards of the difference image (hotpants ``-hki`` writes its
+    kernel information there too): KSUM00, NSTAMPS, and the solver status - ZMSTATUS (0 = every
+    region solved; bit 0 = ZMUNSOLV regions carry the fill value), ZMRETRY (fits repeated on the
+    safe solver path after a barrier time-out)."""
+    return {'KSUM00': float(info['kernel_sum']), 'NSTAMPS': int(info['nstamps_used']),
+            'ZMSTATUS': int(info['status']), 'ZMUNSOLV': int(info.get('nunsolved', 0)),
+            'ZMRETRY': int(info.get('retries', 0))}
+
+
+def warn_unsolved(info, what=''):
+    """hotpants exits non-zero when it cannot fit at all (CalledProcessError at
+    ``zuds/subtraction.py:162``); a fit that lost some of its regions is reported, never silent.
+    (A solver that made no progress even on its safe path raises in ``_lib.check``.)"""
+    if int(info['status']) & 1:
+        import warnings
+        warnings.warn(f'subtraction {what}: {info.get("nunsolved", "?")} region(s) of the kernel fit '
+                      f'have no usable solution (too few stamps or a singular normal matrix) and '
+                      f'carry the fill value 1e-30 / mask bit 17', RuntimeWarning)
+
+
 class HotpantsCall(object):
 
     def __init__(self, command, params, sci, scirms, ref, refrms, bpm, outname, subrms, header):
@@ -70,8 +91,8 @@ class HotpantsCall(object):
                                                   self.refrms, self.bpm, params=p)
         self.info = info
         hdr = dict(self.header)
-        hdr['KSUM00'] = float(info['kernel_sum'])        # -hki: kernel info in the header
-        hdr['NSTAMPS'] = int(info['nstamps_used'])
+        hdr.update(info_cards(info))
+        warn_unsolved(info, self.outname)
         _fits.write(self.outname, diff, hdr)
         _fits.write(self.subrms, noise, hdr)
         return diff, noise

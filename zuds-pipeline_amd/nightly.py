@@ -63,17 +63,20 @@ class _Worker(object):
         from .device import DeviceSubtraction
         torch = self.torch
         sci, ref = job.sci, job.ref
-        key = (tuple(sci['img'].shape), id(sci['wcs']), id(ref['wcs']))
-        if self.chain is None or self.key[0] != key[0]:
+        # The device planes are reused between jobs of one frame size; the WCS structs are
+        # rebuilt for EVERY job (a few hundred bytes of host work).  They were once cached under
+        # id(wcs): ids are only unique among live objects, and a driver that builds fresh WCS
+        # objects per batch gets the same addresses back for different frames.
+        shape = tuple(sci['img'].shape)
+        if self.chain is not None and self.key != shape:
             self.chain = None                           # frees the planes of another frame size first
-        if self.chain is None or self.key != key:
-            if self.chain is None:
-                self.chain = DeviceSubtraction(sci['wcs'], ref['wcs'], device=self.device,
-                                               engine=self.engine, stream=self.stream)
-            else:
-                self.chain.wsci = _lib.wcs_struct(sci['wcs'])
-                self.chain.wref = _lib.wcs_struct(ref['wcs'])
-            self.key = key
+        if self.chain is None:
+            self.chain = DeviceSubtraction(sci['wcs'], ref['wcs'], device=self.device,
+                                           engine=self.engine, stream=self.stream)
+            self.key = shape
+        else:
+            self.chain.wsci = _lib.wcs_struct(sci['wcs'])
+            self.chain.wref = _lib.wcs_struct(ref['wcs'])
         ch = self.chain
         diff, noise, mask = ch.run(sci['img'], sci['rms'], sci['mask'], sci.get('wgt'), ref['img'],
                                    ref['rms'], ref['mask'], seeing=float(sci['seeing']),
@@ -129,7 +132,12 @@ class SubtractionPool(object):
         return w
 
     def _run(self, job, keep):
-        return self._worker().subtract(job, keep=keep)
+        # one failed job must not end the batch (the reference's drivers wrap every image in
+        # try / except, scripts/dosub.py:205-213): the result carries the error instead of products
+        try:
+            return self._worker().subtract(job, keep=keep)
+        except _lib.ZMError as exc:
+            return dict(tag=job.tag, error=str(exc))
 
     def map(self, jobs, keep=True):
         """Run every job; results in job order.  ``keep``: clone diff / noise / mask of each job

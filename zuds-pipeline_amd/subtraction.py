@@ -30,14 +30,16 @@ def sub_name(frame, template):
 
 def _shallow(obj, cls, mapped=True):
     """In-memory stand-in for the reference's on-disk transaction copy: a new
-    object of class ``cls`` sharing ``obj``'s arrays and header.  ``mapped=False``
+    object of class ``cls`` sharing ``obj``'s arrays, with its OWN header dicts (the
+    reference reloads the copy from disk: a SEEING measured on it never reaches the
+    caller's object).  ``mapped=False``
     leaves the copy without a file: whatever derives products from it (check-images,
     rms maps, a measured SEEING) keeps them in memory, as the reference keeps them in
     the transaction directory it deletes (``zuds/subtraction.py:68-99,224``)."""
     new = cls()
     new.basename = obj.basename
-    new.header = obj.header
-    new.header_comments = obj.header_comments
+    new.header = dict(obj.header or {})
+    new.header_comments = dict(obj.header_comments or {})
     new.data = obj.data
     if mapped and obj.ismapped:
         new._path = obj.local_path
@@ -143,8 +145,12 @@ class Subtraction(HasWCS):
         sub.reference_image = ref
         sub.target_image = sci
         sub.hotpants_info = call.info
-        sub.header['SEEING'] = sci.header['SEEING']
-        sub.header_comments['SEEING'] = (sci.header_comments or {}).get('SEEING', '')
+        # zuds/subtraction.py:208-209 reads the caller's header; a frame without the card got
+        # its SEEING measured on the transaction copy (prepare_hotpants), which is what the
+        # difference image was made with
+        sub.header['SEEING'] = sci.header.get('SEEING', transact_sci.header['SEEING'])
+        sub.header_comments['SEEING'] = (sci.header_comments or {}).get(
+            'SEEING', transact_sci.header_comments.get('SEEING', ''))
         if isinstance(sub, CalibratedImage):
             for key in ('MAGZP', APER_KEY):
                 if key in sci.header:
