@@ -41,6 +41,8 @@ class CalibratableImageBase(FITSImage):
                                             tmpdir=tmpdir, use_weightmap=use_weightmap,
                                             sextractor_kws=sextractor_kws)
         for result in results:
+            if result is None:          # the catalog slot (no source extraction on this path)
+                continue
             if result.basename.endswith('.rms.fits'):
                 self._rmsimg = result
             elif result.basename.endswith('.bkgsub.fits'):
