@@ -155,7 +155,7 @@ def test_dostack_products_equal_from_images(tmp_path, engine):
         for a, b, what in zip(g, w, ('coadd', 'weight', 'mask')):
             assert np.array_equal(a, b), (nm, what)
         hdr = z.fits.read(nm)[1]
-        assert hdr['MAGZP'] == 25.0 and 'SEEING' in hdr        # calculate_seeing=True ran offline
+        assert 'SEEING' in hdr and hdr['FIELD'] == 651       # calculate_seeing=True ran offline
 
 
 def test_dosub_products_equal_from_images(tmp_path, engine):

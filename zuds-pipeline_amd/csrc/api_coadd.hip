@@ -33,25 +33,27 @@ static int check_wcs(const zm_wcs* w, const char* what) {
     return 0;
 }
 
-// LDS elements (float2) a 64 x 32 output tile of k_resample needs: bound the footprint from the
-// map's Jacobian sampled over the output grid.
-static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps) {
+// LDS elements (float2) a tw x th output tile needs: bound the footprint from the map's Jacobian
+// sampled over the output grid.  k_resample: 64 x 32 tiles, at most 8000 elements (64 KB without
+// the opt-in); the fused coadd: 64 x 64 tiles made of two k_resample boxes (their union: one more
+// alignment step), `cap` elements - a larger plan means the frame's footprints exceed the LDS tile.
+static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw = 64, int th = 32, int cap = 8000) {
     double wmax = 0, hmax = 0;
     for (int sy = 0; sy < 3; ++sy)
         for (int sx = 0; sx < 3; ++sx) {
             double x = 1.0 + sx * 0.5 * (onx - 1), y = 1.0 + sy * 0.5 * (ony - 1);
             double x0, y0, x1, y1, x2, y2;
             zm_map_point(mp, x, y, &x0, &y0);
-            zm_map_point(mp, x + 64, y, &x1, &y1);
-            zm_map_point(mp, x, y + 32, &x2, &y2);
+            zm_map_point(mp, x + tw, y, &x1, &y1);
+            zm_map_point(mp, x, y + th, &x2, &y2);
             if (!std::isfinite(x0 + y0 + x1 + y1 + x2 + y2)) continue;
             wmax = std::max(wmax, fabs(x1 - x0) + fabs(x2 - x0));
             hmax = std::max(hmax, fabs(y1 - y0) + fabs(y2 - y0));
         }
-    double w = ceil(wmax * 1.02) + ntaps + 9, h = ceil(hmax * 1.02) + ntaps + 5;   // + box alignment (4 px)
+    const int extra = th > 32 ? 4 : 0;
+    double w = ceil(wmax * 1.02) + ntaps + 9 + extra, h = ceil(hmax * 1.02) + ntaps + 5 + extra / 2;   // + box alignment (4 px)
     double e = w * h;
-    const int cap = 8000;   // 64,000 B + header < 64 KiB: no opt-in attribute needed
-    if (!(e > 0) || e > cap) return cap;
+    if (!(e > 0) || e > cap) return cap + 1;
     return (int)e;
 }
 
@@ -146,7 +148,7 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
     for (int i = 0; i < n; ++i) {
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fscale[i]));
-        lds[i] = plan_lds(&mp_host[i], onx, ony, ntaps_of(P->resample));
+        lds[i] = std::min(plan_lds(&mp_host[i], onx, ony, ntaps_of(P->resample)), 8000);
     }
     double2* lat = nullptr;
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
@@ -194,8 +196,11 @@ static bool fused_ok(const zm_coadd_params* P) {
            (P->combine == ZM_COMBINE_WEIGHTED || P->combine == ZM_COMBINE_AVERAGE);
 }
 
-// Everything in front of the fused launch: backgrounds, lattices, every frame prepped into its own
-// plane (+ its box-OR mask plane when a mask coadd is wanted), the frame descriptors.
+// Everything in front of the fused launch: backgrounds, lattices, the y part of every frame's
+// background spline (k_bk_rows), the box-OR planes of the masks, the frame descriptors.  Frames
+// are read RAW by the fused kernel; a prepped plane is only written for a frame that cannot be
+// staged that way (see zm_ff.src).
+#define ZM_FF_LDS_CAP 7800           // = FF_LDS_CAP of resample.hip
 struct fused_stage {
     std::vector<zm_ff> ff;
     int lds = 0, lnx = 0, lny = 0;
@@ -209,26 +214,32 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     S->lny = lny;
     for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
     hipEvent_t* evs = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 6, &evs));
+    ZM_TRY(zm_get_sync_events(ctx, 7, &evs));
     ZM_HIP(hipEventRecord(evs[3], ctx->stream));
     const float wthresh = (float)P->weight_thresh;
     bk_plan bp;
     ZM_TRY(frames_background(ctx, n, fr, P, &bp));
+    const char* e = getenv("ZM_FF_RAW");
+    const bool raw_ok = !(e && e[0] == '0') && (P->back_size % 8 == 0 || !P->subtract_back);
     std::vector<zm_map_params> mp_host(n);
     std::vector<zm_ff>& ff = S->ff;
     ff.resize(n);
-    int lds = 0;
-    size_t prep_bytes = 0, box_bytes = 0;
-    std::vector<size_t> prep_off(n), box_off(n);
+    int lds = 64;
+    size_t prep_bytes = 0, box_bytes = 0, yt_bytes = 0;
+    std::vector<size_t> prep_off(n), box_off(n), yt_off(n);
+    std::vector<char> need_src(n, 0);
     bool any_mask = false;
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1], spitch = (nx + 1) & ~1;
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         double fs = 1.0;
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
-        lds = std::max(lds, plan_lds(&mp_host[i], onx, ony, 6));
+        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, 64, ZM_FF_LDS_CAP);
+        // a footprint beyond the LDS tile is gathered from global memory: from a prepped plane
+        need_src[i] = !raw_ok || plan > ZM_FF_LDS_CAP;
+        lds = std::max(lds, std::min(plan, ZM_FF_LDS_CAP));
         prep_off[i] = prep_bytes;
-        prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
+        if (need_src[i]) prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
         box_off[i] = box_bytes;
         const bool with_mask = want_mask && fr[i].mask;
         if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)nx * ny) + 255) & ~(size_t)255;
@@ -238,31 +249,67 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         ff[i].fscale = (float)fs;
         ff[i].fscale2 = (float)fs * (float)fs;
         ff[i].mask = with_mask ? fr[i].mask : nullptr;
+        ff[i].img = fr[i].img;
+        ff[i].wgt = fr[i].wgt;
+        ff[i].wthresh = wthresh;
+        ff[i].vec_ok = (nx % 4 == 0) && (((uintptr_t)fr[i].img & 15) == 0) && (((uintptr_t)fr[i].wgt & 15) == 0);
     }
     double2* lat = nullptr;
-    char *prep_all = nullptr, *box_all = nullptr;
+    char *prep_all = nullptr, *box_all = nullptr, *yt_all = nullptr;
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
-    ZM_TRY(ctx->get("prep_all", prep_bytes, (void**)&prep_all));
+    if (prep_bytes) ZM_TRY(ctx->get("prep_all", prep_bytes, (void**)&prep_all));
     if (box_bytes) ZM_TRY(ctx->get("mask_box_all", box_bytes, (void**)&box_all));
     ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat, evs[3]));
+    std::vector<zm_bkrows> rows;
+    std::vector<zm_boxjob> boxes;
+    struct bkinfo { float* nodes; float* vscale; int nbx, nby; };
+    std::vector<bkinfo> bki(n, bkinfo{nullptr, nullptr, 0, 0});
     for (int i = 0; i < n; ++i) {
         const int nx = ff[i].nx, ny = ff[i].ny;
-        float *bknodes = nullptr, *vscale = nullptr;
-        int nbx = 0, nby = 0;
         if (frame_has_bk(P, fr, i)) {
             float *nodes = nullptr, *bstats = nullptr;
+            int nbx = 0, nby = 0;
             ZM_TRY(zm_frame_products(ctx, nx, ny, P->back_size, "cbk", i, n, bp.nslot, &nodes, &bstats, &nbx, &nby));
-            if (frame_nmode(P, fr, i) == 2) vscale = bp.vs_all + 4 * (size_t)i;
-            if (P->subtract_back) bknodes = nodes;
+            if (frame_nmode(P, fr, i) == 2) bki[i].vscale = bp.vs_all + 4 * (size_t)i;
+            if (P->subtract_back) { bki[i].nodes = nodes; bki[i].nbx = nbx; bki[i].nby = nby; }
         }
-        float2* src = (float2*)(prep_all + prep_off[i]);
+        yt_off[i] = yt_bytes;
+        if (!need_src[i] && bki[i].nodes) {
+            ff[i].ytp = std::max(bki[i].nbx - 1, 1);
+            yt_bytes += ((sizeof(float4) * (size_t)ny * ff[i].ytp) + 255) & ~(size_t)255;
+        }
+    }
+    if (yt_bytes) ZM_TRY(ctx->get("bk_rows_all", yt_bytes, (void**)&yt_all));
+    for (int i = 0; i < n; ++i) {
+        const int nx = ff[i].nx, ny = ff[i].ny;
         uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
-        ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size, vscale,
-                              wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox));
-        ff[i].src = src;
         ff[i].mbox = mbox;
         ff[i].lat = lat + (size_t)i * lnx * lny;
+        ff[i].vscale = bki[i].vscale;
+        if (need_src[i]) {
+            // the frame prepped into its own plane (k_prep_box also fills the box-OR plane)
+            float2* src = (float2*)(prep_all + prep_off[i]);
+            ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bki[i].nodes, bki[i].nbx, bki[i].nby, P->back_size,
+                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox));
+            ff[i].src = src;
+            continue;
+        }
+        if (bki[i].nodes) {
+            ff[i].bk = bki[i].nodes;
+            ff[i].nbx = bki[i].nbx;
+            ff[i].nby = bki[i].nby;
+            ff[i].invmesh = 1.0f / (float)P->back_size;
+            ff[i].ytab = (const float4*)(yt_all + yt_off[i]);
+            zm_bkrows r;
+            memset(&r, 0, sizeof(r));
+            r.bk = bki[i].nodes; r.out = (float4*)(yt_all + yt_off[i]);
+            r.nbx = bki[i].nbx; r.nby = bki[i].nby; r.ny = ny; r.ytp = ff[i].ytp;
+            r.invmesh = ff[i].invmesh;
+            rows.push_back(r);
+        }
+        if (mbox) boxes.push_back(zm_boxjob{ff[i].mask, mbox, nx, ny});
     }
+    ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size(), boxes.data(), (int)boxes.size()));
     S->lds = lds;
     S->any_mask = any_mask;
     return 0;
@@ -377,7 +424,7 @@ extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
     const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
     zm_map_params mp_host;
     zm_make_map(wout, win, &mp_host);
-    int lds = plan_lds(&mp_host, onx, ony, ntaps_of(kernel));
+    int lds = std::min(plan_lds(&mp_host, onx, ony, ntaps_of(kernel)), 8000);
     double2* lat = nullptr;
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny, (void**)&lat));
     ZM_TRY(zm_launch_lattice(ctx, &mp_host, lnx, lny, lat));

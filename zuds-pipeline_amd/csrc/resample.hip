@@ -106,81 +106,91 @@ int zm_launch_lattice(zm_ctx* ctx, const zm_map_params* mp, int lnx, int lny, do
 // value V, d2/dy2 / 6 (DY), d2/dx2 / 6 of V (A), d2/dx2 / 6 of DY (B); the
 // tensor-product natural spline is then a 16-term combination (equivalent to
 // SExtractor's "spline along y per node column, then along x per line").
-__device__ inline float bk_eval(const float* __restrict__ bk, int nbx, int nby, float invmesh,
-                                int x, int y) {
-    size_t pl = (size_t)nbx * nby;
-    float ty = (y + 0.5f) * invmesh - 0.5f;
-    float tx = (x + 0.5f) * invmesh - 0.5f;
-    int j0 = 0, i0 = 0;
-    float dy = 0.f, dx = 0.f;
-    if (nby > 1) {
-        j0 = min(max((int)floorf(ty), 0), nby - 2);
-        dy = ty - j0;
-    }
-    if (nbx > 1) {
-        i0 = min(max((int)floorf(tx), 0), nbx - 2);
-        dx = tx - i0;
-    }
-    int j1 = nby > 1 ? j0 + 1 : j0, i1 = nbx > 1 ? i0 + 1 : i0;
-    float dy1 = 1.f - dy, dx1 = 1.f - dx;
-    float cdy = dy * dy * dy - dy, cdy1 = dy1 * dy1 * dy1 - dy1;
-    float cdx = dx * dx * dx - dx, cdx1 = dx1 * dx1 * dx1 - dx1;
-    const float* V = bk;
-    const float* DY = bk + pl;
-    const float* A = bk + 2 * pl;
-    const float* B = bk + 3 * pl;
-    int a00 = j0 * nbx + i0, a01 = j0 * nbx + i1, a10 = j1 * nbx + i0, a11 = j1 * nbx + i1;
-    float r0 = dy1 * V[a00] + dy * V[a10] + cdy1 * DY[a00] + cdy * DY[a10];
-    float r1 = dy1 * V[a01] + dy * V[a11] + cdy1 * DY[a01] + cdy * DY[a11];
-    float e0 = dy1 * A[a00] + dy * A[a10] + cdy1 * B[a00] + cdy * B[a10];
-    float e1 = dy1 * A[a01] + dy * A[a11] + cdy1 * B[a01] + cdy * B[a11];
-    return dx1 * r0 + dx * r1 + cdx1 * e0 + cdx * e1;
+//
+// The arithmetic is PINNED (explicit fused multiply-adds, contraction off): three kernels evaluate
+// it - k_prep (the prepped plane k_resample reads), k_bk_rows (the y part, once per frame row and
+// mesh column) and the staging of k_coadd_fused (the x part, per staged pixel) - and the fused
+// coadd must equal the k_resample path bit for bit (tests/test_fused_coadd_gpu.py).
+//   y part of (y, mesh column i0): {r0, r1, e0, e1} - the spline along y through the node columns
+//   i0 and i0 + 1 and through their d2/dx2 columns;  x part: dx1 r0 + dx r1 + cdx1 e0 + cdx e1.
+#pragma clang fp contract(off)
+__device__ inline int bk_col(int nbx, float invmesh, int x) {
+    if (nbx <= 1) return 0;
+    const float tx = __builtin_fmaf((float)x + 0.5f, invmesh, -0.5f);
+    return min(max((int)floorf(tx), 0), nbx - 2);
 }
-
-// Background of four consecutive pixels of a row (x a multiple of 4).  The y part of the
-// tensor-product spline (4 x 4 node loads, 16 FMAs) is shared when the four pixels lie in one
-// mesh column, which they always do when BACK_SIZE is a multiple of 8.
-__device__ inline void bk_eval4(const float* __restrict__ bk, int nbx, int nby, float invmesh, int x,
-                                int y, float out[4]) {
-    const float tx0 = (x + 0.5f) * invmesh - 0.5f, tx3 = (x + 3.5f) * invmesh - 0.5f;
-    int i0 = 0, i3 = 0;
-    if (nbx > 1) {
-        i0 = min(max((int)floorf(tx0), 0), nbx - 2);
-        i3 = min(max((int)floorf(tx3), 0), nbx - 2);
-    }
-    if (i0 != i3) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = bk_eval(bk, nbx, nby, invmesh, x + k, y);
-        return;
-    }
+__device__ inline float bk_dx(int nbx, float invmesh, int x, int i0) {
+    if (nbx <= 1) return 0.f;
+    return __builtin_fmaf((float)x + 0.5f, invmesh, -0.5f) - (float)i0;
+}
+__device__ inline float4 bk_ypart(const float* __restrict__ bk, int nbx, int nby, float invmesh, int y, int i0) {
     const size_t pl = (size_t)nbx * nby;
-    const float ty = (y + 0.5f) * invmesh - 0.5f;
     int j0 = 0;
     float dy = 0.f;
     if (nby > 1) {
+        const float ty = __builtin_fmaf((float)y + 0.5f, invmesh, -0.5f);
         j0 = min(max((int)floorf(ty), 0), nby - 2);
-        dy = ty - j0;
+        dy = ty - (float)j0;
     }
     const int j1 = nby > 1 ? j0 + 1 : j0, i1 = nbx > 1 ? i0 + 1 : i0;
     const float dy1 = 1.f - dy;
-    const float cdy = dy * dy * dy - dy, cdy1 = dy1 * dy1 * dy1 - dy1;
+    const float cdy = __builtin_fmaf(dy * dy, dy, -dy), cdy1 = __builtin_fmaf(dy1 * dy1, dy1, -dy1);
     const float* V = bk;
     const float* DY = bk + pl;
     const float* A = bk + 2 * pl;
     const float* B = bk + 3 * pl;
     const int a00 = j0 * nbx + i0, a01 = j0 * nbx + i1, a10 = j1 * nbx + i0, a11 = j1 * nbx + i1;
-    const float r0 = dy1 * V[a00] + dy * V[a10] + cdy1 * DY[a00] + cdy * DY[a10];
-    const float r1 = dy1 * V[a01] + dy * V[a11] + cdy1 * DY[a01] + cdy * DY[a11];
-    const float e0 = dy1 * A[a00] + dy * A[a10] + cdy1 * B[a00] + cdy * B[a10];
-    const float e1 = dy1 * A[a01] + dy * A[a11] + cdy1 * B[a01] + cdy * B[a11];
+    // (all sixteen node loads first: a load inside an expression is waited for on the spot)
+    const float v00 = V[a00], v10 = V[a10], d00 = DY[a00], d10 = DY[a10];
+    const float v01 = V[a01], v11 = V[a11], d01 = DY[a01], d11 = DY[a11];
+    const float p00 = A[a00], p10 = A[a10], q00 = B[a00], q10 = B[a10];
+    const float p01 = A[a01], p11 = A[a11], q01 = B[a01], q11 = B[a11];
+    float4 r;
+    r.x = __builtin_fmaf(cdy, d10, __builtin_fmaf(cdy1, d00, __builtin_fmaf(dy, v10, dy1 * v00)));
+    r.y = __builtin_fmaf(cdy, d11, __builtin_fmaf(cdy1, d01, __builtin_fmaf(dy, v11, dy1 * v01)));
+    r.z = __builtin_fmaf(cdy, q10, __builtin_fmaf(cdy1, q00, __builtin_fmaf(dy, p10, dy1 * p00)));
+    r.w = __builtin_fmaf(cdy, q11, __builtin_fmaf(cdy1, q01, __builtin_fmaf(dy, p11, dy1 * p01)));
+    return r;
+}
+// the four x weights of a pixel column: {dx1, dx, cdx1, cdx}
+__device__ inline float4 bk_xweights(float dx) {
+    const float dx1 = 1.f - dx;
+    return make_float4(dx1, dx, __builtin_fmaf(dx1 * dx1, dx1, -dx1), __builtin_fmaf(dx * dx, dx, -dx));
+}
+__device__ inline float bk_xpart(float4 yp, float4 xw) {
+    return __builtin_fmaf(xw.w, yp.w, __builtin_fmaf(xw.z, yp.z, __builtin_fmaf(xw.y, yp.y, xw.x * yp.x)));
+}
+__device__ inline float bk_eval(const float* __restrict__ bk, int nbx, int nby, float invmesh,
+                                int x, int y) {
+    const int i0 = bk_col(nbx, invmesh, x);
+    return bk_xpart(bk_ypart(bk, nbx, nby, invmesh, y, i0), bk_xweights(bk_dx(nbx, invmesh, x, i0)));
+}
+
+// Background of four consecutive pixels of a row (x a multiple of 4).  The y part is shared when
+// the four pixels lie in one mesh column, which they always do when BACK_SIZE is a multiple of 8.
+__device__ inline void bk_eval4(const float* __restrict__ bk, int nbx, int nby, float invmesh, int x,
+                                int y, float out[4]) {
+    const int i0 = bk_col(nbx, invmesh, x), i3 = bk_col(nbx, invmesh, x + 3);
+    if (i0 != i3) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float dx = 0.f;
-        if (nbx > 1) dx = ((x + k) + 0.5f) * invmesh - 0.5f - i0;
-        const float dx1 = 1.f - dx;
-        const float cdx = dx * dx * dx - dx, cdx1 = dx1 * dx1 * dx1 - dx1;
-        out[k] = dx1 * r0 + dx * r1 + cdx1 * e0 + cdx * e1;
+        for (int k = 0; k < 4; ++k) out[k] = bk_eval(bk, nbx, nby, invmesh, x + k, y);
+        return;
     }
+    const float4 yp = bk_ypart(bk, nbx, nby, invmesh, y, i0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = bk_xpart(yp, bk_xweights(bk_dx(nbx, invmesh, x + k, i0)));
+}
+
+// One prepped pixel {value, variance}: background off, variance = var_scale / weight (a weight at
+// or below the threshold, a NaN pixel: bad = {., BIGVAR}).  The quotient is a reciprocal estimate
+// and a multiply (1 ulp; the parity tolerance of a resampled weight is 5e-5): the staging of the
+// fused coadd evaluates this once per staged pixel.
+__device__ inline float2 prep_pixel(float v, float w, bool has_w, float bg, float var_scale, float wthresh) {
+    float val = v - bg;
+    float var = var_scale;
+    if (has_w) var = (w > wthresh) ? var_scale * __builtin_amdgcn_rcpf(w) : ZM_BIGVAR;
+    const bool nan = !(val == val);                       // NaN pixels are bad
+    return make_float2(nan ? 0.f : val, nan ? ZM_BIGVAR : var);
 }
 
 // four prepped pixels (x a multiple of 4): two float4 {value, variance, value, variance}
@@ -209,19 +219,15 @@ __device__ inline void prep_quad(const float* __restrict__ img, const float* __r
     float r[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float val = 0.f, var = ZM_BIGVAR;
-        if (x + k < nx) {
-            val = v[k] - bg[k];
-            var = var_scale;
-            if (wgt) var = (w[k] > wthresh) ? var_scale / w[k] : ZM_BIGVAR;
-            if (!(val == val)) { val = 0.f; var = ZM_BIGVAR; }   // NaN pixels are bad
-        }
-        r[2 * k] = val;
-        r[2 * k + 1] = var;
+        float2 p = make_float2(0.f, ZM_BIGVAR);
+        if (x + k < nx) p = prep_pixel(v[k], w[k], wgt != nullptr, bg[k], var_scale, wthresh);
+        r[2 * k] = p.x;
+        r[2 * k + 1] = p.y;
     }
     o[0] = make_float4(r[0], r[1], r[2], r[3]);
     o[1] = make_float4(r[4], r[5], r[6], r[7]);
 }
+#pragma clang fp contract(fast)
 
 __global__ __launch_bounds__(256) void k_prep(const float* __restrict__ img,
                                               const float* __restrict__ wgt, int nx, int ny,
@@ -1213,29 +1219,42 @@ int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny, co
 }
 
 // ===========================================================================
-// Fused resample -> WEIGHTED / AVERAGE coadd (+ mask coadd): the frames of a stack are looped
-// INSIDE the output tile.  A workgroup owns a 64 x 32 output tile, walks the N frames of this
-// rank, resamples each one out of LDS exactly as k_resample does and keeps the running sums
-//   S1 = sum(w v), S0 = sum(w)   (and the AND / OR mask coadd)
-// of its 8 pixels per thread in registers; the coadd (or the partial sums of a multi-GPU
-// stack) is written once per tile.  This removes what SWarp does through `.resamp.fits` files
-// (zuds/coadd.py:126-140) and what the materialised path does through HBM: the N-deep
-// {value, weight} stack (2.4 GB at N = 32), its re-read by k_combine_sum and the per-frame
-// read-modify-write of the mask accumulator.  HBM traffic per frame and output pixel: the
-// prepped {value, variance} pair (8 B x tile halo) + the 16-bit box-OR entry, against
-// 8 + 8 + 8 + 2 + 4 + 4 B before.  The sums run in frame order with the operations of
-// k_combine_sum (fmaf(w, v, s1); s0 += w), so the result is bit-identical to the
-// materialised path.
+// Fused resample -> coadd (+ mask coadd): the frames of a stack are looped INSIDE the output
+// tile, and the frames are read RAW - background, variance and the weight threshold are applied
+// while a tile is staged, so no prepped plane is ever written (round 3; SURVEY.md section 7
+// step 5 / 8(d): "background fused into the resample read, 0 extra").
 //
-// Per-pixel instruction diet (the kernel is bound by vector issue, tools/valu_rate.hip):
-//   * taps from the LDS table (zm_lz3_lookup);
-//   * the 8 pixels of a thread are unrolled, so the lattice cell row, the row fraction and the
-//     accumulator registers are compile-time;
-//   * tiles whose input footprint lies inside the frame and whose pixels are all inside the
-//     output grid ("fast" items, > 90 % of a dithered stack) skip every bounds test; the snap
-//     rule (delta kernels) and the 16-bit box-OR overflow are checked by one wave vote each and
-//     send the whole wave-row to the generic code, which is instantiated once, outside the
-//     unrolled loop.
+// A workgroup (512 threads, one per CU: 2 waves per SIMD, 256 registers per lane) owns a
+// 64 x 64 output tile, walks the N frames of this rank, resamples each one out of LDS exactly as
+// k_resample does and keeps the running sums
+//   S1 = sum(w v), S0 = sum(w)   (and the AND / OR mask coadd)
+// of its 8 pixels per thread in registers; the coadd (or the partial sums of a multi-GPU stack)
+// is written once per tile.  This removes what SWarp does through `.resamp.fits` files
+// (zuds/coadd.py:126-140) and what the materialised path does through HBM: the prepped plane
+// (8 B / px written and read back), the N-deep {value, weight} stack, its re-read by
+// k_combine_sum and the per-frame read-modify-write of the mask accumulator.  HBM traffic per
+// frame and output pixel: img + wgt (8 B x tile halo 1.35) + the 16-bit box-OR entry.  The sums
+// run in frame order with the operations of k_combine_sum (fmaf(w, v, s1); s0 += w), and every
+// sample is the one k_resample computes, so the result is bit-identical to the materialised path.
+//
+// Why bit-identical although the tile is twice k_resample's: a fused tile is two STACKED
+// k_resample tiles (64 x 32), each with its own header - lattice nodes relative to its own box
+// origin - so a pixel's position is computed with k_resample's very operands; the two boxes are
+// staged as one (their union), the sub-box offsets enter as integers.  A wave (64 columns x 8
+// rows) lies in one sub-tile and one lattice cell row: sub-tile, node rows and row fractions are
+// wave-uniform.
+//
+// LDS diet (round 2 measured the LDS pipe as the first bound: 36 ds_read_b64 per pixel): a thread
+// owns 4 vertically ADJACENT pixels twice.  At near-unit scale their 6 x 6 windows are rows
+// iy .. iy + 8 of the same six columns: 9 x 6 reads serve 4 pixels (13.5 per pixel), each row
+// read once and used by up to four pixels with their own taps - the arithmetic per pixel is
+// unchanged.  A wave whose lanes do not all have that shape (rotations of degrees, scale
+// changes, a floor boundary between the rows) takes the generic per-pixel code.
+//
+// The staging is double-buffered in LDS (one workgroup per CU leaves 160 KB): the raw planes of
+// item i + 1 are requested into registers before the pixels of item i are computed, prepped and
+// written to the other buffer after them - one barrier per item.
+//
 // Pointers that arrive through the descriptor array are generic to the compiler: it would
 // emit flat_load, which counts on lgkmcnt as well as vmcnt - every LDS wait of the tap rows
 // would then also wait for the prefetch of the next tile and for the mask gathers.  Casting
@@ -1246,47 +1265,89 @@ template <typename T> __device__ inline const T ZM_GLOBAL* zm_gptr(const T* p) {
 // references: loads through such pointers use the plain vector types)
 typedef float zm_v4f __attribute__((ext_vector_type(4)));
 typedef double zm_v2d __attribute__((ext_vector_type(2)));
+typedef unsigned zm_v2u __attribute__((ext_vector_type(2)));
 __device__ inline float2 zm_gload2(const float2 ZM_GLOBAL* p) {
     const zm_v2f v = *(const zm_v2f ZM_GLOBAL*)p;
     return make_float2(v.x, v.y);
 }
-__device__ inline float4 zm_gload4(const float2 ZM_GLOBAL* p) {
+__device__ inline float4 zm_gload4f(const float ZM_GLOBAL* p) {
     const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)p;
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-#define FF_PF 7                      // pixel prefetch slots per thread (float4 = 2 pixels each)
-#define FF_PM 4                      // mask prefetch slots per thread (uint2 = 4 pixels each)
+// compile-time loop: the index is a constant in the front end, so register arrays indexed by it are
+// scalarised at once (with `#pragma unroll` the staging arrays of k_coadd_fused went to scratch)
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void zm_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        zm_static_for<I + 1, N>(fn);
+    }
+}
+
+#define FT_H 64                      // output rows of a fused tile: two stacked k_resample tiles
+#define FF_THREADS 512
+#define FF_NSLOT 4                   // staging slots per thread; a slot = 4 consecutive pixels of one box row
+#define FF_NPX 8                     // output pixels per thread: rows 8 wave .. 8 wave + 7 of column (tid & 63)
+#define FF_HDR_WORDS 80
+#define FF_LDS_HDR 1152              // bytes: 3 headers, tile ring, raw-mask flags
+#define FF_LDS_TAB ((LZ_FLOATS * 4 + 127) & ~127)
+#define FF_LDS_CAP 7800              // staged pixels per buffer: 2 x (8 + 2) B x 7800 + table + headers < 160 KB
 
 struct ff_hdr {
-    tile_hdr3 h;
+    tile_hdr3 sub[2];                // the headers k_resample would build for the two half-tiles
+    int bx0, by0, bw, bh;            // the staged box: union of the two sub-boxes
     int use_lds, touches, fast, edge;
+    int sdx[2], sdy[2];              // sub-box origin minus union origin
 };
+static_assert(sizeof(ff_hdr) == FF_HDR_WORDS * 4, "ff_hdr is not its record");
+static_assert(3 * sizeof(ff_hdr) + 4 * 4 + 2 * 8 * 4 <= FF_LDS_HDR, "LDS header area too small");
 
 __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int lnx, int lny, int t, int ntx,
                                        int onx, int ony, int lds_cap, ff_hdr* H) {
     constexpr int NT = 6, OFF = -2;
     const int tyi = t / ntx, txi = t - tyi * ntx;
     const zm_ff* F = fr + f;
-    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (RTH / LSTEP), OFF, OFF + NT - 1, &H->h);
+    // (a last tile row whose lower half lies off the grid: the upper header twice)
+    const int two = (tyi * FT_H + RTH < ony) ? 1 : 0;
+    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (FT_H / LSTEP), OFF, OFF + NT - 1,
+                       &H->sub[0]);
+    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (FT_H / LSTEP) + two * (RTH / LSTEP), OFF,
+                       OFF + NT - 1, &H->sub[1]);
     if ((threadIdx.x & 63) == 0) {
         const int nx = F->nx, ny = F->ny;
-        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw, bh = H->h.bh;
-        const int touches = (bx0 < nx) && (bx0 + bw > 0) && (by0 < ny) && (by0 + bh > 0);
+        const tile_hdr3 &a = H->sub[0], &b = H->sub[1];
+        const int bx0 = min(a.bx0, b.bx0), by0 = min(a.by0, b.by0);
+        const int bx1 = max(a.bx0 + a.bw, b.bx0 + b.bw), by1 = max(a.by0 + a.bh, b.by0 + b.bh);
+        const int bw = bx1 - bx0, bh = by1 - by0;              // bw: a multiple of 4, like its parts
+        const int touches = (bx0 < nx) && (bx1 > 0) && (by0 < ny) && (by1 > 0);
         const long long area = (long long)bw * bh;
-        // what k_coadd_fused's register staging can hold: FF_PF row slots of [256 / (bw / 2)] rows
-        // (and FF_PM slots of [256 / (bw / 4)] rows of the mask box)
-        const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bw <= 256 &&
-                            bh <= FF_PF * (256 / (bw >> 1)) && bh <= FF_PM * (256 / (bw >> 2));
+        // what the staging registers hold: FF_NSLOT rows per thread of a [512 / (bw / 4)] x [bw / 4] arrangement
+        const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bw <= 256 && bh >= 1 &&
+                            bh <= FF_NSLOT * (FF_THREADS / (bw >> 2));
+        const int inside = bx0 >= 0 && by0 >= 0 && bx1 <= nx && by1 <= ny && (txi + 1) * TW <= onx &&
+                           (tyi + 1) * FT_H <= ony;
+        H->bx0 = bx0; H->by0 = by0; H->bw = bw; H->bh = bh;
         H->touches = touches;
         H->use_lds = use_lds;
-        // (the fast path fetches the box-OR entries 4 pixels = 8 bytes per load from row starts at
-        // multiples of nx: aligned only when nx % 4 == 0 - other widths take the generic mask code)
-        H->fast = use_lds && bx0 >= 0 && by0 >= 0 && bx0 + bw <= nx && by0 + bh <= ny &&
-                  (txi + 1) * TW <= onx && (tyi + 1) * RTH <= ony && ((nx & 3) == 0 || F->mask == nullptr);
-        // staged through LDS with bounds tests (the mask box in groups of 4 pixels: nx % 4 == 0)
-        H->edge = use_lds && !H->fast && (nx & 3) == 0;
+        // fast: the box lies on the frame and the tile on the grid - no bounds test anywhere (vector
+        // loads: rows of the frame 16-byte aligned).  edge: staged with bounds tests, {0, BIGVAR} outside.
+        H->fast = use_lds && inside && F->vec_ok;
+        H->edge = use_lds && !H->fast;
+        H->sdx[0] = a.bx0 - bx0; H->sdx[1] = b.bx0 - bx0;
+        H->sdy[0] = a.by0 - by0; H->sdy[1] = b.by0 - by0;
     }
+}
+
+// One prepped pixel straight from the raw planes (frames staged raw keep no prepped plane): the
+// global-gather path of a footprint that exceeds the LDS tile - rare, slow, correct.
+__device__ inline float2 ff_raw_pixel(const zm_ff* __restrict__ F, int x, int y) {
+    const size_t idx = (size_t)y * F->nx + x;
+    const float v = zm_gptr(F->img)[idx];
+    const float w = F->wgt ? zm_gptr(F->wgt)[idx] : 1.f;
+    const float bg = F->bk ? bk_eval(F->bk, F->nbx, F->nby, F->invmesh, x, y) : 0.f;
+    const float vs = F->vscale ? *F->vscale : 1.f;
+    return prep_pixel(v, w, F->wgt != nullptr, bg, vs, F->wthresh);
 }
 
 // result of one generic pixel: {value, weight, mask bits, inb}
@@ -1298,19 +1359,9 @@ struct ff_px {
 
 // The general per-pixel code (k_resample's): bounds tests, delta kernels, global gather for
 // footprints that do not fit the LDS tile, raw-mask OR where the box-OR plane defers.
-// (not inlined: it runs for edge tiles and snapped positions only, and inlined into the item
-// loop its temporaries - on top of the 64 registers of prefetch and running sums - set the
-// register peak of the whole kernel)
-#ifndef FF_GENERIC_INLINE
-#define FF_GENERIC_INLINE 1
-#endif
-#if FF_GENERIC_INLINE
-#define FF_GENERIC_ATTR inline
-#else
-#define FF_GENERIC_ATTR __attribute__((noinline))
-#endif
+// tile: the staged box shifted to the sub-box origin; bx0 / by0: the sub-box origin; bw: the pitch.
 template <int MOP>
-__device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const float2* tile, const float* ltab,
+__device__ inline ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const float2* tile, const float* ltab,
                                          bool use_lds, bool touches, int bx0, int by0, int bw, float px,
                                          float py) {
     constexpr int NT = 6, OFF = -2, CI = 2;
@@ -1379,7 +1430,7 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
         acc = av.x;
         vacc = av.y;
     } else {
-        const float2 ZM_GLOBAL* p = zm_gptr(F->src) + (size_t)iy * spitch + ix;
+        const float2 ZM_GLOBAL* p = F->src ? zm_gptr(F->src) + (size_t)iy * spitch + ix : nullptr;
 #pragma unroll
         for (int rr = 0; rr < NT; ++rr) {
             float ra = 0.f, rv = 0.f;
@@ -1387,7 +1438,7 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
 #pragma unroll
                 for (int c = 0; c < NT; ++c) {
                     if (tx[c] != 0.f) {
-                        const float2 s = zm_gload2(p + c);
+                        const float2 s = p ? zm_gload2(p + c) : ff_raw_pixel(F, ix + c, iy + rr);
                         ra = fmaf(tx[c], s.x, ra);
                         rv = fmaf(tx[c], s.y, rv);
                     }
@@ -1395,7 +1446,7 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
             }
             acc = fmaf(ty[rr], ra, acc);
             vacc = fmaf(ty[rr], rv, vacc);
-            p += spitch;
+            if (p) p += spitch;
         }
     }
     if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
@@ -1418,23 +1469,27 @@ __device__ FF_GENERIC_ATTR ff_px ff_generic_pixel(const zm_ff* __restrict__ F, c
     return r;
 }
 
+// Mask coadd of a pixel in registers: one AND per sample for both kinds.  AND: the accumulator
+// starts at -1 ("no frame covered the pixel yet", k_mask_accum's marker) and -1 & m == m.
+// OR: by De Morgan on the complement - the accumulator holds ~(OR so far) in bits 0 .. 30 and
+// "never covered" in bit 31 (masks carry their flags in bits 0 .. 30): it starts at -1, a sample
+// ANDs in m ^ 0x7fffffff (bit 31 clear, the other bits complemented).  (k_mask_accum's literal
+// `a == -1 ? m : a | m` in the unrolled pixel loop made the compiler spill 250 registers.)
 template <int MOP>
-__device__ inline int32_t ff_mask_fold(int32_t a, int32_t m) {
-    // -1 = "no frame covered the pixel yet" (k_mask_accum): -1 & m == m, so AND needs no test
-    if (MOP == 1) return a & m;
-    return a == -1 ? m : (a | m);
+__device__ inline int32_t ff_mask_term(int32_t m) { return MOP == 1 ? m : (m ^ 0x7fffffff); }
+template <int MOP>
+__device__ inline int32_t ff_mask_fold(int32_t a, int32_t m) { return a & ff_mask_term<MOP>(m); }
+template <int MOP>
+__device__ inline int32_t ff_mask_result(int32_t a) {       // k_mask_accum's convention: -1 = never covered
+    if (MOP == 1) return a;
+    return a < 0 ? -1 : (a ^ 0x7fffffff);
 }
 
 // ---- item headers, precomputed ------------------------------------------------------------
-// An item = (output tile, frame).  Its header (box of the input footprint, the 15 lattice
-// nodes relative to the box origin, the path flags) needs fp64 loads and a wave reduction:
-// built inside the persistent kernel by wave 0 it sits on that wave's critical path once per
-// item and every barrier of the workgroup waits for it.  A pre-pass builds all of them, one
-// wave per item; the persistent kernel fetches a header two items ahead with one 4-byte load
-// per lane.
-#define FF_HDR_WORDS 40              // ff_hdr padded to 160 bytes
-static_assert(sizeof(ff_hdr) <= FF_HDR_WORDS * 4, "ff_hdr does not fit its record");
-
+// An item = (output tile, frame).  Its header (the two sub-tile headers: box of the input
+// footprint, 15 lattice nodes relative to the box origin; the union box; the path flags) needs
+// fp64 loads and wave reductions: a pre-pass builds all of them, one wave per item; the
+// persistent kernel fetches a header two items ahead with one 4-byte load per lane.
 __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr, int nfr, int lnx, int lny,
                                                     int onx, int ony, int lds_cap, int ntx, int ntiles,
                                                     int* __restrict__ out, int* __restrict__ tilectr, int ctr0) {
@@ -1448,8 +1503,100 @@ __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr
         ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, &H[w]);
     }
     __syncthreads();
-    if (live && lane < FF_HDR_WORDS)
-        out[item * FF_HDR_WORDS + lane] = lane < (int)(sizeof(ff_hdr) / 4) ? ((const int*)&H[w])[lane] : 0;
+    if (live) {
+        out[item * FF_HDR_WORDS + lane] = ((const int*)&H[w])[lane];
+        if (lane + 64 < FF_HDR_WORDS) out[item * FF_HDR_WORDS + 64 + lane] = ((const int*)&H[w])[64 + lane];
+    }
+}
+
+// ---- the y part of the background spline, once per frame row and mesh column ---------------
+// T[y][i0] = {r0, r1, e0, e1} (bk_ypart): what the staging of k_coadd_fused combines with a
+// pixel's four x weights.  1.1 MB per 3072^2 frame against the 75 MB of a prepped plane.
+__global__ __launch_bounds__(256) void k_bk_rows(const zm_bkrows* __restrict__ jobs) {
+    const zm_bkrows J = jobs[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= J.ny * J.ytp) return;
+    const int y = e / J.ytp, i0 = e - y * J.ytp;
+    J.out[e] = bk_ypart(J.bk, J.nbx, J.nby, J.invmesh, y, i0);
+}
+
+// box-OR planes of all masks of a stack in one launch (k_mask_box per frame: 32 launches)
+template <int NT>
+__global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restrict__ jobs) {
+    constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
+    __shared__ int32_t t0[IH * IP];
+    __shared__ int32_t h[IH * TWB];
+    const zm_boxjob J = jobs[blockIdx.z];
+    const int nx = J.nx, ny = J.ny;
+    const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
+    if (x0 >= nx || y0 >= ny) return;                        // (the grid covers the largest frame)
+    const int32_t* __restrict__ m = J.m;
+    constexpr int NLD = (IH * IW + 255) / 256;          // loads first, LDS stores after: one latency
+    int32_t mm[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
+        const int r = e / IW, c = e - r * IW;
+        const int x = x0 + c, y = y0 + r;
+        mm[q] = (e < IH * IW && x < nx && y < ny) ? m[(size_t)y * nx + x] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
+        if (e < IH * IW) t0[(e / IW) * IP + (e % IW)] = mm[q];
+    }
+    __syncthreads();
+    for (int e = tid; e < IH * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        int32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) o |= t0[r * IP + c + k];
+        h[e] = o;
+    }
+    __syncthreads();
+    for (int e = tid; e < THB * TWB; e += 256) {
+        const int r = e / TWB, c = e - r * TWB;
+        const int x = x0 + c, y = y0 + r;
+        if (x + NT <= nx && y + NT <= ny) {
+            int32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
+            J.B[(size_t)y * nx + x] = box_entry(o);
+        }
+    }
+}
+
+// jobs: host arrays (staged through pinned memory behind an event, like the frame descriptors)
+int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows, const zm_boxjob* boxes, int nboxes) {
+    if (nrows == 0 && nboxes == 0) return 0;
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 7, &ev));
+    ZM_HIP(hipEventSynchronize(ev[6]));
+    const size_t rb = sizeof(zm_bkrows) * (size_t)std::max(nrows, 1), bb = sizeof(zm_boxjob) * (size_t)std::max(nboxes, 1);
+    char *pin = nullptr, *dev = nullptr;
+    ZM_TRY(ctx->get_pinned("ff_pre_h", rb + bb, (void**)&pin));
+    ZM_TRY(ctx->get("ff_pre", rb + bb, (void**)&dev));
+    if (nrows) memcpy(pin, rows, sizeof(zm_bkrows) * (size_t)nrows);
+    if (nboxes) memcpy(pin + rb, boxes, sizeof(zm_boxjob) * (size_t)nboxes);
+    ZM_HIP(hipMemcpyAsync(dev, pin, rb + bb, hipMemcpyHostToDevice, ctx->stream));
+    ZM_HIP(hipEventRecord(ev[6], ctx->stream));
+    if (nrows) {
+        int most = 1;
+        for (int i = 0; i < nrows; ++i) most = std::max(most, rows[i].ny * rows[i].ytp);
+        zm_scope_timer t(ctx, "bk_rows");
+        hipLaunchKernelGGL(k_bk_rows, dim3(zm_div_up(most, 256), nrows), dim3(256), 0, ctx->stream,
+                           (const zm_bkrows*)dev);
+        ZM_HIP(hipGetLastError());
+    }
+    if (nboxes) {
+        int mx = 1, my = 1;
+        for (int i = 0; i < nboxes; ++i) { mx = std::max(mx, boxes[i].nx); my = std::max(my, boxes[i].ny); }
+        zm_scope_timer t(ctx, "mask_box");
+        hipLaunchKernelGGL(k_mask_box_batch<6>, dim3(zm_div_up(mx, 64), zm_div_up(my, 16), nboxes), dim3(256), 0,
+                           ctx->stream, (const zm_boxjob*)(dev + rb));
+        ZM_HIP(hipGetLastError());
+    }
+    return 0;
 }
 
 // LDS row reads, software-pipelined by hand: the six ds_read_b64 of tap row r + 1 are issued
@@ -1470,19 +1617,9 @@ __device__ inline void lds_issue6(const float2* p, lds_row6& o) {
                  : "v"(a)
                  : "memory");
 }
-template <int N>
-__device__ inline void lds_wait(lds_row6& o) {
-    if (N == 0)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(o.r0), "+v"(o.r1), "+v"(o.r2), "+v"(o.r3), "+v"(o.r4), "+v"(o.r5)::"memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(6)"
-                     : "+v"(o.r0), "+v"(o.r1), "+v"(o.r2), "+v"(o.r3), "+v"(o.r4), "+v"(o.r5)::"memory");
-}
 __device__ inline zm_v2f lds_pair(unsigned long long r) {
     return (zm_v2f){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
 }
-
 template <int N>
 __device__ inline void lds_wait_n(lds_row6& o) {
     static_assert(N >= 0 && N <= 15, "lgkmcnt has four bits");
@@ -1527,172 +1664,199 @@ __device__ inline void lz3_eval(const lz3_node& n, float dl, zm_v2f t[3]) {
     t[2] = __builtin_elementwise_fma(dd, __builtin_elementwise_fma(dd, (zm_v2f){n.h.x, n.h.y}, (zm_v2f){n.g.z, n.g.w}),
                                      (zm_v2f){n.g.x, n.g.y});
 }
+__device__ inline void lds_issue_u16(const uint16_t* p, uint32_t& o) {
+    asm volatile("ds_read_u16 %0, %1" : "=v"(o) : "v"((unsigned)(size_t)p) : "memory");
+}
 
-// WPS: waves per SIMD the register allocation aims at (3: 168 VGPRs)
-//
-// LDS: [3 headers][tap table][pixel tile: bw x bh {value, variance}][mask tile: bw x bh uint16].
-// Everything a pixel of a fast item touches is in LDS - also its box-OR mask entry: a per-pixel
+// LDS: [3 headers, tile ring, raw flags][tap table][pixel tile x 2][mask tile x 2].
+// Everything a pixel of a staged item touches is in LDS - also its box-OR mask entry: a per-pixel
 // global gather would be waited for with vmcnt(0), and vmcnt retires in order, so it would
-// drain the register prefetch of the next item at the first pixel.  In the fast path the
-// only vector-memory instructions between two barriers are that prefetch and the 4-byte
-// header fetch issued before it.
+// drain the register prefetch of the next item at the first pixel.  In the fast path the only
+// vector-memory instructions between two barriers are that prefetch, the 4-byte header fetch and
+// the tile-queue atomic issued before it, and the stores of a finished tile behind it.
 // STACK: the same machinery as a resampler - nothing is summed, every item's samples {value, weight}
 // go to its frame's plane of a resident stack (the CLIPPED / MEDIAN path), the mask coadd still
 // accumulates in registers.  An item's samples wait in the sum registers and are stored when the
 // next item starts, ahead of its prefetch: stores issued behind the prefetch would sit in front of
 // it in the (in-order) vmcnt queue of the wait that ends the item.
-template <int MOP, bool AVG, int WPS, bool STACK>
-__global__ __launch_bounds__(256, WPS) void k_coadd_fused(
+template <int MOP, bool AVG, bool STACK>
+__global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab, int* __restrict__ tilectr, long long* __restrict__ clk,
-    float2* __restrict__ stack, long long fstride) {
+    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride) {
     extern __shared__ float4 smem4[];
-    // developer probe (ZM_FF_CLOCK=1): shader-clock and 100 MHz wall-clock stamps of workgroup 0 at
-    // its first and last instruction - the clock the chip holds while this kernel runs
-    if (clk && threadIdx.x == 0) {
-        if (blockIdx.x == 0) { clk[0] = clock64(); clk[1] = wall_clock64(); }
-        unsigned xcc, hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        clk[4 + 3 * blockIdx.x] = wall_clock64();
-        clk[4 + 3 * blockIdx.x + 2] = ((long long)(xcc & 0xf) << 32) | hw;
-    }
-    ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem4);                 // ring of 3 headers
-    const float* ltab = reinterpret_cast<const float*>(smem4) + HDR_FLOATS;
-    float2* tile = reinterpret_cast<float2*>(smem4) + (HDR_FLOATS + LZ_FLOATS) / 2;
-    uint16_t* mtile = reinterpret_cast<uint16_t*>(tile + lds_cap);  // lds_cap is a multiple of 4
-    int* rawflag = reinterpret_cast<int*>(smem4) + (HDR_FLOATS - 4); // one word per wave, behind the headers
-    // Tile queue.  Workgroups do not own a fixed share of the tiles: the SIMDs favour the oldest waves, so
-    // of the three workgroups of a CU the first dispatched runs 40 % faster than the third and a static
-    // split leaves the CUs a third full for the last fifth of the launch.  A workgroup takes its next
-    // tile from a global counter, two items before it runs out (header and box of an item are fetched
-    // that far ahead); the tiles it holds sit in a ring of four LDS words indexed by their ordinal.
-    int* tring = reinterpret_cast<int*>(smem4) + (HDR_FLOATS - 8);
-    constexpr int NT = 6, OFF = -2, NQ = RTH / 4;
+    char* smem = reinterpret_cast<char*>(smem4);
+    ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem);                  // ring of 3 headers
+    int* tring = reinterpret_cast<int*>(smem + 3 * sizeof(ff_hdr));   // tiles held, by ordinal & 3
+    int* rawflag = tring + 4;                                       // [buffer][wave]
+    const float* ltab = reinterpret_cast<const float*>(smem + FF_LDS_HDR);
+    float2* tile0 = reinterpret_cast<float2*>(smem + FF_LDS_HDR + FF_LDS_TAB);
+    uint16_t* mtile0 = reinterpret_cast<uint16_t*>(tile0 + 2 * (size_t)lds_cap);   // lds_cap is a multiple of 8
+    constexpr int NT = 6, OFF = -2;
     const int tid = threadIdx.x;
-    const int G = gridDim.x;
-    static_assert(3 * sizeof(ff_hdr) <= (HDR_FLOATS - 8) * 4, "header ring does not fit");
 
-    // Staging of an item's box: thread (c, r0) of a [RP rows][bw / 2 float4 columns] arrangement
-    // loads rows r0, r0 + RP, ... - one address per thread, a uniform stride per slot.
-    float4 pf[FF_PF];
-    uint2 pm[FF_PM];
-    // (every path assigns every slot: a slot that kept its old value on some path would have to
-    // stay live - or be spilled and reloaded, with a vmcnt wait behind the loads just issued)
+    // ---- staging: thread (r0, c) of a [RP rows][bw / 4 quads] arrangement holds the quad c of rows
+    // r0, r0 + RP, ... - one column position per thread, a uniform row stride per slot.
+    float4 pi[FF_NSLOT], pw[FF_NSLOT], py4[FF_NSLOT];     // raw image / weight quads (or two prepped pairs), y part
+    uint2 pm[FF_NSLOT];                                   // box-OR entries
     auto prefetch = [&](const ff_hdr* H, int f) {
         const zm_ff* F = fr + f;
-        const float2 ZM_GLOBAL* src = zm_gptr(F->src);
-        const int ny = F->ny, spitch = F->spitch;
-        const int bx0 = H->h.bx0, by0 = H->h.by0, bh = H->h.bh, bw2 = max(H->h.bw >> 1, 1);
-        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw2));
-        const int c = tid - r0 * bw2;
-        const int RP = 256 / bw2;                     // (uniform) rows per slot
-        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
-#pragma unroll
-        for (int k = 0; k < FF_PM; ++k) pm[k] = make_uint2(0u, 0u);
+        const int nx = F->nx, ny = F->ny;
+        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, bw4 = max(H->bw >> 2, 1);
+        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
+        const int c = tid - r0 * bw4;
+        const int RP = FF_THREADS / bw4;                  // (uniform) rows per slot
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool prepped = F->src != nullptr;
+        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr, has_m = MOP && F->mask != nullptr;
+        const int gx = bx0 + 4 * c;
+        const int i0 = has_y ? bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1)) : 0;
+        zm_static_for<0, FF_NSLOT>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            pi[k] = z4; pw[k] = z4; py4[k] = z4; pm[k] = make_uint2(0u, 0u);
+        });
+        if (!H->use_lds) return;
         if (H->fast) {
-            // The whole box lies on the frame: no tests, no fill.  A uniform base per slot (scalar
-            // registers) plus one 32-bit byte offset per thread: one address register for all slots.
-            const char ZM_GLOBAL* base = (const char ZM_GLOBAL*)(src + ((size_t)by0 * spitch + bx0));
-            const unsigned rowb = (unsigned)spitch * 8u;                     // bytes per row of the plane
-            const unsigned off = (unsigned)min(r0, RP - 1) * rowb + (unsigned)c * 16u;
-            const unsigned lastrow = (unsigned)(bh - 1) * rowb + (unsigned)c * 16u;
-            // (all slots load, unconditionally and back to back: one basic block, no waits in
-            // between; rows past the box re-read its last row and are never stored)
-#pragma unroll
-            for (int k = 0; k < FF_PF; ++k) {
-                const unsigned o = (r0 + k * RP < bh) ? off + (unsigned)(k * RP) * rowb : lastrow;
-                const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(base + o);
-                pf[k] = make_float4(v.x, v.y, v.z, v.w);
-            }
-            if (MOP && F->mask) {
-                // the box-OR entries of the same box: 4 pixels (8 bytes) per load
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                const int nx = F->nx, bw4 = H->h.bw >> 2;
-                const char ZM_GLOBAL* mb = (const char ZM_GLOBAL*)(zm_gptr(F->mbox) + ((size_t)by0 * nx + bx0));
-                const int m0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
-                const int mc = tid - m0 * bw4;
-                const int RM = 256 / bw4;
-                const unsigned mrow = (unsigned)nx * 2u;
-#pragma unroll
-                for (int k = 0; k < FF_PM; ++k) {
-                    const unsigned row = (unsigned)min(min(m0, RM - 1) + k * RM, bh - 1);
-                    const v2u v = *(const v2u ZM_GLOBAL*)(mb + (row * mrow + (unsigned)mc * 8u));
+            // The whole box lies on the frame: no tests, no fill; rows past the box re-read its last
+            // row and are never stored.  (all loads back to back: one basic block, no waits in between)
+            zm_static_for<0, FF_NSLOT>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const int row = min(min(r0, RP - 1) + k * RP, bh - 1);
+                const size_t o = (size_t)(by0 + row) * nx + gx;
+                // (one pair of loads for both kinds of frame: two branches storing into different
+                // register arrays are merged by the compiler into one store through a pointer - to scratch)
+                const float ZM_GLOBAL* sp = (const float ZM_GLOBAL*)zm_gptr(F->src) + ((size_t)(by0 + row) * F->spitch + gx) * 2;
+                const float ZM_GLOBAL* pa = prepped ? sp : zm_gptr(F->img) + o;
+                const float ZM_GLOBAL* pb = prepped ? sp + 4 : zm_gptr(F->wgt) + o;
+                pi[k] = zm_gload4f(pa);
+                if (prepped || has_w) pw[k] = zm_gload4f(pb);
+                if (has_y && !prepped) {
+                    const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(zm_gptr(F->ytab) + ((size_t)(by0 + row) * F->ytp + i0));
+                    py4[k] = make_float4(v.x, v.y, v.z, v.w);
+                }
+                if (has_m) {
+                    const zm_v2u v = *(const zm_v2u ZM_GLOBAL*)(zm_gptr(F->mbox) + o);
                     pm[k] = make_uint2(v.x, v.y);
                 }
-            }
-        } else if (H->use_lds) {
-            // an edge item: the box sticks out of the frame - bounds tests, {0, BIGVAR} outside (a tap
-            // on it drives the variance sum out of range: weight 0, as for a footprint that leaves
-            // the frame); its mask box is fetched when the item starts (store)
-#pragma unroll
-            for (int k = 0; k < FF_PF; ++k) {
-                const int gy = by0 + r0 + k * RP, gx = bx0 + 2 * c;
-                pf[k] = fill;
-                if (r0 + k * RP < bh && r0 < RP && gy >= 0 && gy < ny && gx >= 0 && gx < spitch)
-                    pf[k] = zm_gload4(src + (size_t)gy * spitch + gx);
-            }
+            });
         } else {
+            // an edge item: the box sticks out of the frame (or the frame has no 16-byte rows) - bounds
+            // tests; what lies off the frame is filled at the store
+            const bool vec = F->vec_ok && gx >= 0 && gx + 4 <= nx;
+            zm_static_for<0, FF_NSLOT>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const int row = r0 + k * RP, gy = by0 + row;
+                if (!(r0 < RP && row < bh && gy >= 0 && gy < ny)) return;
+                const size_t o = (size_t)gy * nx + gx;
+                const int sp = F->spitch;
+                const float ZM_GLOBAL* ps = (const float ZM_GLOBAL*)zm_gptr(F->src) + ((ptrdiff_t)gy * sp + gx) * 2;
+                // (the prepped plane carries {0, BIGVAR} from nx to its even pitch; gx + 2 >= 0 when gx >= 0)
+                const bool la = prepped ? (gx >= 0 && gx < sp) : vec;
+                const bool lb = prepped ? (gx >= 0 && gx + 2 < sp) : (vec && has_w);
+                const float ZM_GLOBAL* pa = prepped ? ps : zm_gptr(F->img) + o;
+                const float ZM_GLOBAL* pb = prepped ? ps + 4 : zm_gptr(F->wgt) + o;
+                const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+                float4 va = prepped ? fill : z4, vb = prepped ? fill : z4;
+                if (la) va = zm_gload4f(pa);
+                if (lb) vb = zm_gload4f(pb);
+                if (!prepped && !vec) {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < FF_PF; ++k) pf[k] = fill;
-        }
-    };
-    auto store = [&](const ff_hdr* H, int f) {
-        if (!H->use_lds) return;
-        const int bh = H->h.bh, bw2 = H->h.bw >> 1;
-        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw2));
-        const int c = tid - r0 * bw2;
-        const int RP = 256 / bw2;
-        if (r0 < RP) {
-#pragma unroll
-            for (int k = 0; k < FF_PF; ++k)
-                if (r0 + k * RP < bh) *reinterpret_cast<float4*>(tile + 2 * ((r0 + k * RP) * bw2 + c)) = pf[k];
-        }
-        if (MOP && (H->fast || H->edge) && fr[f].mask) {
-            const int bw4 = H->h.bw >> 2;
-            const int m0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
-            const int mc = tid - m0 * bw4;
-            const int RM = 256 / bw4;
-            // does any entry of the box defer to the raw mask (ZM_BOX_RAW: bits above 15)?  Decided
-            // here, once per item, so that the pixel loop carries no vote and no branch for it
-            bool raw = false;
-            if (H->fast) {
-                if (m0 < RM) {
-#pragma unroll
-                    for (int k = 0; k < FF_PM; ++k)
-                        if (m0 + k * RM < bh) {
-                            *reinterpret_cast<uint2*>(mtile + 4 * ((m0 + k * RM) * bw4 + mc)) = pm[k];
-                            const uint32_t a = pm[k].x, b = pm[k].y;
-                            raw |= (a & 0xffffu) == ZM_BOX_RAW || (a >> 16) == ZM_BOX_RAW ||
-                                   (b & 0xffffu) == ZM_BOX_RAW || (b >> 16) == ZM_BOX_RAW;
+                    for (int e = 0; e < 4; ++e)
+                        if (gx + e >= 0 && gx + e < nx) {
+                            v[e] = zm_gptr(F->img)[(ptrdiff_t)o + e];
+                            if (has_w) w[e] = zm_gptr(F->wgt)[(ptrdiff_t)o + e];
                         }
+                    va = make_float4(v[0], v[1], v[2], v[3]);
+                    vb = make_float4(w[0], w[1], w[2], w[3]);
                 }
-            } else {
-                // an edge item (one in twenty): its mask box is fetched here, with bounds tests,
-                // instead of riding in prefetch registers through the previous item
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                const zm_ff* F = fr + f;
-                const uint16_t ZM_GLOBAL* mb = zm_gptr(F->mbox);
-                const int nx = F->nx, ny = F->ny, bx0 = H->h.bx0, by0 = H->h.by0;
-                if (m0 < RM) {
-#pragma unroll 1
-                    for (int k = 0; k < FF_PM; ++k) {
-                        const int gy = by0 + m0 + k * RM, gx = bx0 + 4 * mc;
-                        if (m0 + k * RM < bh) {
-                            v2u v = (v2u){0u, 0u};
-                            if (gy >= 0 && gy < ny && gx >= 0 && gx + 4 <= nx)
-                                v = *(const v2u ZM_GLOBAL*)(mb + ((size_t)gy * nx + gx));
-                            *reinterpret_cast<uint2*>(mtile + 4 * ((m0 + k * RM) * bw4 + mc)) = make_uint2(v.x, v.y);
-                            raw |= (v.x & 0xffffu) == ZM_BOX_RAW || (v.x >> 16) == ZM_BOX_RAW ||
-                                   (v.y & 0xffffu) == ZM_BOX_RAW || (v.y >> 16) == ZM_BOX_RAW;
-                        }
+                pi[k] = va;
+                pw[k] = vb;
+                if (has_y && !prepped) {
+                    const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(zm_gptr(F->ytab) + ((size_t)gy * F->ytp + i0));
+                    py4[k] = make_float4(v.x, v.y, v.z, v.w);
+                }
+                if (has_m) {
+                    if (vec) {
+                        const zm_v2u v = *(const zm_v2u ZM_GLOBAL*)(zm_gptr(F->mbox) + o);
+                        pm[k] = make_uint2(v.x, v.y);
+                    } else {
+                        // (entries whose 6 x 6 footprint leaves the frame are never written by the box
+                        // pre-pass and never folded: the pixel loop tests the footprint)
+                        unsigned e4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gx + e >= 0 && gx + e < nx) e4[e] = zm_gptr(F->mbox)[(ptrdiff_t)o + e];
+                        pm[k] = make_uint2(e4[0] | (e4[1] << 16), e4[2] | (e4[3] << 16));
                     }
                 }
-            }
+            });
+        }
+    };
+    // prep the staged quads (background off, variance, bad pixels) and write them to LDS buffer `b`
+    auto store = [&](const ff_hdr* H, int f, int b) {
+        if (!H->use_lds) return;
+        const zm_ff* F = fr + f;
+        const int nx = F->nx, ny = F->ny;
+        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, bw = H->bw, bw4 = bw >> 2;
+        const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
+        const int c = tid - r0 * bw4;
+        const int RP = FF_THREADS / bw4;
+        float2* tile = tile0 + (size_t)b * lds_cap;
+        uint16_t* mtile = mtile0 + (size_t)b * lds_cap;
+        const bool prepped = F->src != nullptr, fast = H->fast;
+        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr, has_m = MOP && F->mask != nullptr;
+        const int gx = bx0 + 4 * c;
+        const float vs = F->vscale ? *F->vscale : 1.f, wth = F->wthresh;
+        // the four x weights of this thread's four columns: once per item
+        float4 xw[4];
+        if (has_y && !prepped) {
+            const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xw[e] = bk_xweights(bk_dx(F->nbx, F->invmesh, gx + e, i0));
+        }
+        bool raw = false;
+        if (r0 < RP) {
+            zm_static_for<0, FF_NSLOT>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const int row = r0 + k * RP;
+                if (row >= bh) return;
+                float4 o0, o1;
+                if (prepped) {
+                    o0 = pi[k];
+                    o1 = pw[k];
+                    if (!fast && !((unsigned)(by0 + row) < (unsigned)ny)) o0 = o1 = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+                } else {
+                    const float v[4] = {pi[k].x, pi[k].y, pi[k].z, pi[k].w};
+                    const float w[4] = {pw[k].x, pw[k].y, pw[k].z, pw[k].w};
+                    float2 p[4];
+                    const bool rowok = fast || (unsigned)(by0 + row) < (unsigned)ny;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bg = has_y ? bk_xpart(py4[k], xw[e]) : 0.f;
+                        p[e] = prep_pixel(v[e], w[e], has_w, bg, vs, wth);
+                        if (!fast && !(rowok && (unsigned)(gx + e) < (unsigned)nx)) p[e] = make_float2(0.f, ZM_BIGVAR);
+                    }
+                    o0 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+                    o1 = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
+                }
+                float4* d = reinterpret_cast<float4*>(tile + (size_t)row * bw + 4 * c);
+                d[0] = o0;
+                d[1] = o1;
+                if (has_m) {
+                    *reinterpret_cast<uint2*>(mtile + (size_t)row * bw + 4 * c) = pm[k];
+                    const uint32_t a = pm[k].x, bb = pm[k].y;
+                    raw |= (a & 0xffffu) == ZM_BOX_RAW || (a >> 16) == ZM_BOX_RAW ||
+                           (bb & 0xffffu) == ZM_BOX_RAW || (bb >> 16) == ZM_BOX_RAW;
+                }
+            });
+        }
+        if (MOP) {
+            // does any entry of the box defer to the raw mask (ZM_BOX_RAW: bits above 15)?  Decided
+            // here, once per item, so that the pixel loop carries no vote and no branch for it
             const bool wraw = __any(raw);
-            if ((tid & 63) == 0) rawflag[tid >> 6] = wraw;
+            if ((tid & 63) == 0) rawflag[b * 8 + (tid >> 6)] = wraw;
         }
     };
     const int nty = ntiles / ntx;
@@ -1705,17 +1869,17 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
     auto next_item = [&](int& tt, int& ff, int& kk) {
         if (++ff == nfr) { ff = 0; ++kk; tt = tring[kk & 3]; }
     };
-    auto hdr_word = [&](int tt, int ff) -> int {          // this lane's word of the header of item (tt, ff)
+    auto hdr_word = [&](int tt, int ff) -> int {          // this thread's word of the header of item (tt, ff)
         return tid < FF_HDR_WORDS ? ghdr[((size_t)tt * nfr + ff) * FF_HDR_WORDS + tid] : 0;
     };
     auto hdr_put = [&](int sl, int wv) {
-        if (tid < (int)(sizeof(ff_hdr) / 4)) reinterpret_cast<int*>(&HR[sl])[tid] = wv;
+        if (tid < FF_HDR_WORDS) reinterpret_cast<int*>(&HR[sl])[tid] = wv;
     };
 
     if ((int)blockIdx.x >= ntiles) return;
     int t0 = tile_of(blockIdx.x), f0 = 0, k2 = 0;
-    for (int e = tid; e < LZ_FLOATS / 4; e += 256)
-        smem4[HDR_FLOATS / 4 + e] = reinterpret_cast<const float4*>(taptab)[e];
+    for (int e = tid; e < LZ_FLOATS / 4; e += FF_THREADS)
+        reinterpret_cast<float4*>(smem + FF_LDS_HDR)[e] = reinterpret_cast<const float4*>(taptab)[e];
     if (tid == 0) {
         // stacks of one or two frames look two items = up to two tiles ahead
         tring[0] = t0;
@@ -1731,151 +1895,203 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
     if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
     __syncthreads();
     prefetch(&HR[0], f0);
+    store(&HR[0], f0, 0);
+    __syncthreads();
 
-    const int tx = tid & 63, tyb = tid >> 6;
+    // ---- this thread's pixels: column tx, rows 8 wv .. 8 wv + 7 of the tile.  The wave lies in
+    // sub-tile `sub` (k_resample's tile), lattice cell row `cr` of it; all wave-uniform.
+    const int tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wv >> 2, cr = (wv & 3) >> 1;
     const int cell = tx >> 4;
     const float fx = (float)(tx & 15) * (1.f / LSTEP);
-    const float fyb = (float)tyb * (1.f / LSTEP);
-    float S1[NQ], S0[NQ], SW[NQ];
-    int32_t MK[NQ];
+    const float fyb = (float)((wv & 1) * 8) * (1.f / LSTEP);
+    float S1[FF_NPX], S0[FF_NPX], SW[FF_NPX];
+    int32_t MK[FF_NPX];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
+    for (int q = 0; q < FF_NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
 
     // STACK: the samples of item (pt, pfr), held in S1 / S0, to plane pfr of the stack
     int pt = -1, pfr = 0;
     auto flush = [&]() {
         if (pt < 0) return;
         const int ptyi = pt / ntx, ptxi = pt - ptyi * ntx;
-        const int pox = ptxi * TW + tx, poy0 = ptyi * RTH + tyb;
+        const int pox = ptxi * TW + tx, poy0 = ptyi * FT_H + wv * FF_NPX;
         float2* plane = stack + (size_t)pfr * (size_t)fstride;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int oy = poy0 + 4 * q;
+        for (int q = 0; q < FF_NPX; ++q) {
+            const int oy = poy0 + q;
             // (read back by the combine kernel, 2.4 GB later: non-temporal)
             if (pox < onx && oy < ony)
                 __builtin_nontemporal_store((zm_v2f){S1[q], S0[q]}, reinterpret_cast<zm_v2f*>(plane + (size_t)oy * onx + pox));
         }
     };
-    int slot = 0;
+    int slot = 0, buf = 0;
     for (;;) {
         const ff_hdr* H = &HR[slot];
         const int nslot = slot == 2 ? 0 : slot + 1;
         const int nnslot = nslot == 2 ? 0 : nslot + 1;
-        store(H, f0);
-        __syncthreads();
         const zm_ff* F = fr + f0;
         const bool use_lds = H->use_lds, touches = H->touches, fast = H->fast;
-        const int bx0 = H->h.bx0, by0 = H->h.by0, bw = H->h.bw;
+        const tile_hdr3* SH = &H->sub[sub];
+        const int bw = H->bw;
+        const int sbx0 = SH->bx0, sby0 = SH->by0;                 // the sub-box origin (k_resample's box)
+        const int soff = H->sdy[sub] * bw + H->sdx[sub];          // ... inside the staged box
+        const float2* tile = tile0 + (size_t)buf * lds_cap;
+        const uint16_t* mtile = mtile0 + (size_t)buf * lds_cap;
         const int tyi = t0 / ntx, txi = t0 - tyi * ntx;
-        const int ox0 = txi * TW, oy0 = tyi * RTH;
+        const int ox0 = txi * TW, oy0 = tyi * FT_H + wv * FF_NPX;
         const int ox = ox0 + tx;
-        // in this order: the header word is older than the prefetch, so storing it at the end of
-        // the item waits with vmcnt(prefetch loads), not vmcnt(0)
+        // in this order: the header word and the queue atomic are older than the prefetch, so using
+        // them at the end of the item waits with vmcnt(prefetch loads), not vmcnt(0)
         if (STACK) {
             flush();
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { S1[q] = 0.f; S0[q] = 0.f; }
+            for (int q = 0; q < FF_NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; }
             pt = t0;
             pfr = f0;
         }
         int hw2 = 0;
         if (t2 < ntiles) hw2 = hdr_word(t2, f2);
-        // the item two ahead is the last of its tile: take the tile after it from the queue (older
-        // than the prefetch below, as the header word is; its ring slot, ordinal k2 + 1, is not in use)
+        // the item two ahead is the last of its tile: take the tile after it from the queue (its ring
+        // slot, ordinal k2 + 1, is not in use)
         const bool grab = f2 == nfr - 1;
         int gnext = 0;
         if (grab && tid == 0) gnext = atomicAdd(tilectr, 1);
-        // (unconditional: past the last item the current one is fetched again, into registers nobody reads)
-        prefetch(t1 < ntiles ? &HR[nslot] : H, t1 < ntiles ? f1 : f0);
+        // (unconditional: past the last item the current one is fetched again, into registers nobody stores)
+        const bool more = t1 < ntiles;
+        prefetch(more ? &HR[nslot] : H, more ? f1 : f0);
 
         if (touches) {
-            // x part of the bilinear lattice interpolation, once per item (same operations and
-            // order as k_resample / tile_position)
-            float xr[3], yr[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float x0 = H->h.nrel[r][cell][0], x1 = H->h.nrel[r][cell + 1][0];
-                const float y0 = H->h.nrel[r][cell][1], y1 = H->h.nrel[r][cell + 1][1];
-                xr[r] = x0 + fx * (x1 - x0);
-                yr[r] = y0 + fx * (y1 - y0);
-            }
+            // x part of the bilinear lattice interpolation, once per item (k_resample's operations)
+            const float x0a = SH->nrel[cr][cell][0], x1a = SH->nrel[cr][cell + 1][0];
+            const float y0a = SH->nrel[cr][cell][1], y1a = SH->nrel[cr][cell + 1][1];
+            const float x0b = SH->nrel[cr + 1][cell][0], x1b = SH->nrel[cr + 1][cell + 1][0];
+            const float y0b = SH->nrel[cr + 1][cell][1], y1b = SH->nrel[cr + 1][cell + 1][1];
+            const float xa = __builtin_fmaf(fx, x1a - x0a, x0a), ya = __builtin_fmaf(fx, y1a - y0a, y0a);
+            const float xb = __builtin_fmaf(fx, x1b - x0b, x0b), yb = __builtin_fmaf(fx, y1b - y0b, y0b);
+            const float xd = xb - xa, yd = yb - ya;
             const bool with_mask = MOP && F->mask != nullptr;
+            const bool staged = fast || H->edge;
             // wave-uniform: pixels left to the generic code (items that do not go through LDS: all)
-            unsigned slow = (fast || H->edge) ? 0u : 0xffu;
-            const bool any_raw = MOP && with_mask && (fast || H->edge) &&
-                                 (rawflag[0] | rawflag[1] | rawflag[2] | rawflag[3]);
+            unsigned slow = staged ? 0u : 0xffu;
+            bool any_raw = false;
+            if (MOP && with_mask && staged) {
+                const int* rf = rawflag + buf * 8;
+                any_raw = (rf[0] | rf[1] | rf[2] | rf[3] | rf[4] | rf[5] | rf[6] | rf[7]) != 0;
+            }
             const float fscale = F->fscale, fscale2 = F->fscale2;
-            const float2* tbase = tile + (OFF * bw + OFF);
-            const uint16_t* mbase = mtile + (OFF * bw + OFF);
+            const float2* tbase = tile + (soff + OFF * bw + OFF);
+            const uint16_t* mbase = mtile + (soff + OFF * bw + OFF);
             const int enx = F->nx, eny = F->ny;
-            // the eight pixels of a thread out of LDS; EDGE: the item's box sticks out of the frame
-            // or its tile out of the output grid (bounds tests for the mask fold)
-            auto pixels = [&](auto edge_tag) {
+            // four vertically adjacent pixels (rows 4 g .. 4 g + 3 of the thread) out of one 9 x 6 window
+            auto group = [&](auto edge_tag, auto g_tag) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
+                constexpr int G = decltype(g_tag)::value;
+                float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
+                bool shape = true;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int cr = q >> 2;
-                    // ((tyb + 4 q) & 15) / 16, exactly, from one per-thread constant: four precomputed
-                    // values would be spilled, and a scratch reload inside the pixel loop waits on
-                    // vmcnt - in order, i.e. for the whole prefetch of the next item
+                for (int j = 0; j < 4; ++j) {
                     float fy = fyb;
-                    // (an empty volatile asm stays behind the LDS reads of the previous pixel: without
-                    // it the positions, fractions and offsets of all eight pixels are computed up
-                    // front and kept live - 30 registers, spilled to scratch)
+                    // (an empty volatile asm keeps the row fraction from being hoisted out of the item
+                    // loop as eight live constants)
                     asm volatile("" : "+v"(fy));
-                    fy += (float)(q & 3) * 0.25f;     // (after the asm: not hoisted out of the item loop)
-                    const float xa = xr[cr], xb = xr[cr + 1], ya = yr[cr], yb = yr[cr + 1];
-                    const float px = xa + fy * (xb - xa), py = ya + fy * (yb - ya);
+                    fy += (float)(4 * G + j) * (1.f / LSTEP);
+                    const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
                     const float fxf = floorf(px), fyf = floorf(py);
                     const float dx = px - fxf, dy = py - fyf;
-                    // snap rule: a fraction within 1e-5 of 0 or 1 on either axis -> generic code
+                    dxs[j] = dx;
+                    dys[j] = dy;
+                    if (j == 0) { fxf0 = fxf; fyf0 = fyf; }
+                    // snap rule: a fraction within 1e-5 of 0 or 1 on either axis -> generic code;
+                    // window shape: the same six columns, rows one apart
                     const float edge = fminf(fminf(dx, 1.f - dx), fminf(dy, 1.f - dy));
-                    if (__any(edge < ZM_SNAP)) {
-                        slow |= 1u << q;
-                        continue;
-                    }
-                    const int lo = (int)fyf * bw + (int)fxf;          // element offset in both tiles
-                    // edge items: is the footprint on the frame (decides the mask fold; the value
-                    // and weight follow from the {0, BIGVAR} fill), is the pixel on the output grid
-                    bool inb = true;
-                    if (EDGE) {
-                        const int ix = bx0 + OFF + (int)fxf, iy = by0 + OFF + (int)fyf;
-                        inb = ix >= 0 && ix + NT <= enx && iy >= 0 && iy + NT <= eny &&
-                              ox < onx && oy0 + tyb + 4 * q < ony;
-                    }
-                    const float2* p = tbase + lo;
-                    // tap row r + 1 is read while the packed FMAs of row r run: two row buffers (one
-                    // buffer with the wait behind every row: 10 % slower; three buffers and both
-                    // table nodes ahead: no faster, 30 registers more - spills in the mask variants)
-                    lds_row6 ra, rb;
-                    lds_issue6(p, ra);
-                    uint32_t m16 = 0;
-                    if (with_mask) m16 = mbase[lo];
-                    zm_v2f txp[3], typ[3];
-                    zm_lz3_lookup(ltab, dx, txp);
-                    zm_lz3_lookup(ltab, dy, typ);
-                    zm_v2f av = (zm_v2f){0.f, 0.f};
+                    shape = shape && !(edge < ZM_SNAP) && fxf == fxf0 && fyf == fyf0 + (float)j;
+                }
+                if (!__all(shape)) {
+                    slow |= 0xfu << (4 * G);
+                    return;
+                }
+                const int ix0 = (int)fxf0, iy0 = (int)fyf0;
+                const int lo = iy0 * bw + ix0;                       // element offset in both tiles
+                const float2* p = tbase + lo;
+                // edge items: is the footprint on the frame (decides the mask fold; value and weight
+                // follow from the {0, BIGVAR} fill), is the pixel on the output grid.  (Decided here,
+                // as four bits: computed after the row pipeline these tests cost 300 spilled registers)
+                unsigned inbm = 0xfu;
+                if (EDGE && MOP) {
+                    const int ix = sbx0 + OFF + ix0, iy = sby0 + OFF + iy0;
+                    const bool xin = ix >= 0 && ix + NT <= enx && ox < onx;
+                    inbm = 0u;
 #pragma unroll
-                    for (int r = 0; r < NT; ++r) {
-                        lds_row6& cur = (r & 1) ? rb : ra;
-                        lds_row6& nxt = (r & 1) ? ra : rb;
-                        if (r + 1 < NT) {
-                            lds_issue6(p + (r + 1) * bw, nxt);
-                            lds_wait_n<6>(cur);
-                        } else {
-                            lds_wait_n<0>(cur);
+                    for (int j = 0; j < 4; ++j)
+                        inbm |= (xin && iy + j >= 0 && iy + j + NT <= eny && oy0 + 4 * G + j < ony) ? (1u << j) : 0u;
+                }
+                // The mask term of each pixel, as plain data flow: what the accumulator is ANDed with
+                // (-1: nothing to fold - no mask, footprint off the frame).  Conditional code in the
+                // epilogue below is cloned per pixel by the compiler and costs 250 spilled registers.
+                int32_t mterm[4] = {-1, -1, -1, -1};
+                if (MOP) {
+                    uint32_t m16[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m16[j] = mbase[lo + j * bw];          // (the tile exists, mask or not)
+                    // bits above 15 somewhere in this box (a reference mask with bit 16): a footprint whose
+                    // box-OR entry defers to the raw mask is left to the generic code, which ORs it
+                    if (any_raw) {
+                        bool defer = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) defer |= m16[j] == ZM_BOX_RAW && ((inbm >> j) & 1u);
+                        if (__any(defer)) {
+                            slow |= 0xfu << (4 * G);
+                            return;
                         }
-                        const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t t = ff_mask_term<MOP>((int32_t)m16[j]);
+                        mterm[j] = (with_mask && ((inbm >> j) & 1u)) ? t : -1;
+                    }
+                }
+                zm_v2f txp[4][3], typ[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    zm_lz3_lookup(ltab, dxs[j], txp[j]);
+                    zm_lz3_lookup(ltab, dys[j], typ[j]);
+                }
+                // rows 0 .. 8 of the window; row rho is tap row rho - j of pixel j.  Row rho + 1 is read
+                // while the packed FMAs of row rho run (two row buffers).
+                zm_v2f av[4];
+                lds_row6 ra, rb;
+                lds_issue6(p, ra);
+#pragma unroll
+                for (int rho = 0; rho < NT + 3; ++rho) {
+                    lds_row6& cur = (rho & 1) ? rb : ra;
+                    lds_row6& nxt = (rho & 1) ? ra : rb;
+                    if (rho + 1 < NT + 3) {
+                        lds_issue6(p + (rho + 1) * bw, nxt);
+                        lds_wait_n<6>(cur);
+                    } else {
+                        lds_wait_n<0>(cur);
+                    }
+                    const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rho - j;
+                        if (r < 0 || r >= NT) continue;
                         zm_v2f rv2 = (zm_v2f){0.f, 0.f};
 #pragma unroll
                         for (int c = 0; c < NT; ++c) {
-                            const float tc = (c & 1) ? txp[c >> 1].y : txp[c >> 1].x;
+                            const float tc = (c & 1) ? txp[j][c >> 1].y : txp[j][c >> 1].x;
                             rv2 = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rv2);
                         }
-                        const float tr = (r & 1) ? typ[r >> 1].y : typ[r >> 1].x;
-                        av = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, av);
+                        const float tr = (r & 1) ? typ[j][r >> 1].y : typ[j][r >> 1].x;
+                        av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
                     }
-                    const float acc = av.x, vacc = av.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    constexpr int Q0 = 4 * G;
+                    const int q = Q0 + j;
+                    const float acc = av[j].x, vacc = av[j].y;
                     const bool ok = vacc > 0.f && vacc < ZM_BADVAR_TEST;
                     const float v = ok ? acc * fscale : 0.f;
                     const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
@@ -1888,47 +2104,29 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                         S0[q] += ww;
                     }
                     if (AVG) SW[q] += w;
-                    if (with_mask) {
-                        int32_t mres = (int32_t)m16;
-                        if (any_raw) {
-                            // bits above 15 somewhere in this box: OR the raw mask under such footprints
-                            if (m16 == ZM_BOX_RAW && inb) {
-                                mres = 0;
-                                const int nx = F->nx;
-                                const int32_t ZM_GLOBAL* mp0 =
-                                    zm_gptr(F->mask) + ((ptrdiff_t)(by0 + OFF + (int)fyf) * nx + (bx0 + OFF + (int)fxf));
-                                // (rolled on purpose: unrolled, its 36 loads claim registers in each of
-                                // the eight pixel bodies for a path that is almost never taken)
-#pragma unroll 1
-                                for (int r = 0; r < NT; ++r) {
-#pragma unroll 1
-                                    for (int c = 0; c < NT; ++c) mres |= mp0[(ptrdiff_t)r * nx + c];
-                                }
-                            }
-                        }
-                        MK[q] = (!EDGE || inb) ? ff_mask_fold<MOP>(MK[q], mres) : MK[q];
-                    }
+                    if (MOP) MK[q] &= mterm[j];
                 }
             };
-            if (fast) pixels(std::false_type{});
-            else if (H->edge) pixels(std::true_type{});
-            // the generic code, once: edge tiles, delta kernels, footprints beyond the LDS tile
+            if (fast) {
+                group(std::false_type{}, std::integral_constant<int, 0>{});
+                group(std::false_type{}, std::integral_constant<int, 1>{});
+            } else if (H->edge) {
+                group(std::true_type{}, std::integral_constant<int, 0>{});
+                group(std::true_type{}, std::integral_constant<int, 1>{});
+            }
+            // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
 #pragma unroll 1
             while (slow) {
                 const int q = __builtin_ctz(slow);
                 slow &= slow - 1;
-                const int ty = tyb + 4 * q;
-                const int oy = oy0 + ty;
+                const int oy = oy0 + q;
                 if (ox >= onx || oy >= ony) continue;
-                const int cr = q >> 2;
-                const float fy = (float)(ty & 15) * (1.f / LSTEP);
-                const float xa = cr ? xr[1] : xr[0], xb = cr ? xr[2] : xr[1];
-                const float ya = cr ? yr[1] : yr[0], yb = cr ? yr[2] : yr[1];
-                const float px = xa + fy * (xb - xa), py = ya + fy * (yb - ya);
-                const ff_px r = ff_generic_pixel<MOP>(F, tile, ltab, use_lds, touches, bx0, by0, bw, px, py);
+                const float fy = fyb + (float)q * (1.f / LSTEP);
+                const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
+                const ff_px r = ff_generic_pixel<MOP>(F, tile + soff, ltab, use_lds, touches, sbx0, sby0, bw, px, py);
                 const float ww = AVG ? (r.w > 0.f ? 1.f : 0.f) : r.w;
 #pragma unroll
-                for (int k = 0; k < NQ; ++k) {
+                for (int k = 0; k < FF_NPX; ++k) {
                     const bool me = (k == q);
                     S1[k] = me ? (STACK ? r.v : fmaf(ww, r.v, S1[k])) : S1[k];
                     S0[k] = me ? (STACK ? r.w : S0[k] + ww) : S0[k];
@@ -1941,8 +2139,8 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
         if (f0 == nfr - 1) {
             // the tile is complete: coadd (or partial sums) and mask coadd, once
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int oy = oy0 + tyb + 4 * q;
+            for (int q = 0; q < FF_NPX; ++q) {
+                const int oy = oy0 + q;
                 if (ox < onx && oy < ony) {
                     const size_t o = (size_t)oy * onx + ox;
                     const float s1 = S1[q], s0 = S0[q];
@@ -1956,7 +2154,7 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                         out_wgt[o] = AVG ? SW[q] : s0;
                     }
                     if (MOP) {
-                        const int32_t a = MK[q];
+                        const int32_t a = ff_mask_result<MOP>(MK[q]);
                         if (partial) {
                             out_mask[o] = a;
                         } else {
@@ -1969,48 +2167,45 @@ __global__ __launch_bounds__(256, WPS) void k_coadd_fused(
                 SW[q] = 0.f; MK[q] = -1;
             }
         }
-        if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read two items ago
+        // the next item: prepped into the other LDS buffer (the one the pixels of the item before
+        // this one were read from - every wave is past that since the last barrier)
+        if (more) store(&HR[nslot], f1, buf ^ 1);
+        if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read an item ago
         if (grab && tid == 0) tring[(k2 + 1) & 3] = tile_of(gnext);
-        __syncthreads();          // everyone is done with the LDS tiles and with header `slot`
+        __syncthreads();
         t0 = t1; f0 = f1;
         t1 = t2; f1 = f2;
         next_item(t2, f2, k2);
         slot = nslot;
+        buf ^= 1;
         if (t0 >= ntiles) break;
     }
     if (STACK) flush();
-    if (clk && threadIdx.x == 0) {
-        if (blockIdx.x == 0) { clk[2] = clock64(); clk[3] = wall_clock64(); }
-        clk[4 + 3 * blockIdx.x + 1] = wall_clock64();
-    }
 }
 
-#define FF_WPS_DEFAULT 3
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
                           float2* stack, int64_t fstride) {
-    const int ntx = zm_div_up(onx, TW), ntiles = ntx * zm_div_up(ony, RTH);
+    const int ntx = zm_div_up(onx, TW), ntiles = ntx * zm_div_up(ony, FT_H);
     if (unmasked_out) {
         // a mask coadd was asked for but no frame carries a mask: "nothing covered" everywhere
         const size_t opix = (size_t)onx * ony;
         ZM_HIP(hipMemsetAsync(unmasked_out, partial ? 0xFF : 0, sizeof(int32_t) * opix, ctx->stream));
         if (!partial && out_cov) ZM_HIP(hipMemsetAsync(out_cov, 0, sizeof(float) * opix, ctx->stream));
     }
-    // what the prefetch registers can stage: FF_PF row slots of a [256 / (bw / 2)] x [bw / 2] arrangement
-    if (lds_elems > FF_PF * 256 * 2) lds_elems = FF_PF * 256 * 2;
-    lds_elems = (lds_elems + 3) & ~3;
-    const bool masks = out_mask != nullptr;
-    const size_t shmem = (size_t)(HDR_FLOATS + LZ_FLOATS) * 4 + (size_t)lds_elems * sizeof(float2) +
-                         (masks ? (size_t)lds_elems * sizeof(uint16_t) : 0);
+    lds_elems = std::min(std::max(lds_elems, 64), FF_LDS_CAP);
+    lds_elems = (lds_elems + 7) & ~7;
+    const size_t shmem = (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)lds_elems * (sizeof(float2) + sizeof(uint16_t));
+    ZM_CHECK(shmem <= 160 * 1024, "zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
     const float* taptab = nullptr;
     ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
     // descriptors: pinned staging guarded by an event (a later call must not overwrite a copy in flight)
     zm_ff *pin = nullptr, *dev = nullptr;
     int* ghdr = nullptr;
     hipEvent_t* ev = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 6, &ev));
+    ZM_TRY(zm_get_sync_events(ctx, 7, &ev));
     ZM_HIP(hipEventSynchronize(ev[5]));
     ZM_TRY(ctx->get_pinned("ff_frames_h", sizeof(zm_ff) * (size_t)nfr, (void**)&pin));
     ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
@@ -2019,88 +2214,41 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
     ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, ctx->stream));
     ZM_HIP(hipEventRecord(ev[5], ctx->stream));
-    // 3 waves per SIMD (168 registers): at 4 (128) the prefetch registers and the running sums spill
-    const int wps = FF_WPS_DEFAULT;
-    // persistent grid: `wps` workgroups per CU, each starting on the tile of its index and taking
-    // further tiles from a queue (a counter behind the item headers, set to G by k_ff_headers)
-    const int G = std::min(ntiles, 256 * wps);
+    // persistent grid: one workgroup per CU (its LDS tile leaves room for no second), each starting
+    // on the tile of its index and taking further tiles from a queue (a counter behind the item
+    // headers, set to G by k_ff_headers)
+    int ncu = 256;
+    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int G = std::min(ntiles, std::max(ncu, 1));
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
-    if (shmem > 65536) {
-        // (dynamic LDS above 64 KiB needs the opt-in; not reached with RS_PFCAP-sized tiles)
-        zm_set_error("zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
-        return 2;
-    }
-    long long* clk = nullptr;
-    const bool want_clk = getenv("ZM_FF_CLOCK") != nullptr;
-    if (want_clk) ZM_TRY(ctx->get("ff_clk", sizeof(long long) * (4 + 3 * 256 * FF_WPS_DEFAULT), (void**)&clk));
     zm_scope_timer t(ctx, "coadd_fused");
     {
         const long long items = (long long)ntiles * nfr;
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
                            lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr, tilectr, G);
     }
-#define ZM_FF_LAUNCH1(MOPV, AVGV, WPSV, STACKV)                                                            \
-    hipLaunchKernelGGL((k_coadd_fused<MOPV, AVGV, WPSV, STACKV>), dim3(G), dim3(256), shmem, ctx->stream, dev, nfr, \
-                       onx, ony, lds_elems, ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, \
-                       taptab, tilectr, clk, stack, (long long)fstride)
-#define ZM_FF_LAUNCH(MOPV, AVGV) ZM_FF_LAUNCH1(MOPV, AVGV, 3, false)
+#define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
+    do {                                                                                                       \
+        auto kfn = k_coadd_fused<MOPV, AVGV, STACKV>;                                                          \
+        static bool attr_set[64] = {};                                                                         \
+        if (!attr_set[ctx->device & 63]) {                                                                     \
+            ZM_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set[ctx->device & 63] = true;                                                                 \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kfn, dim3(G), dim3(FF_THREADS), shmem, ctx->stream, dev, nfr, onx, ony, lds_elems,  \
+                           ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, taptab, tilectr,   \
+                           stack, (long long)fstride);                                                         \
+    } while (0)
     if (stack) {
-        if (mop == 0) ZM_FF_LAUNCH1(0, false, 3, true);
-        else if (mop == 1) ZM_FF_LAUNCH1(1, false, 3, true);
-        else ZM_FF_LAUNCH1(2, false, 3, true);
+        if (mop == 0) ZM_FF_LAUNCH(0, false, true);
+        else if (mop == 1) ZM_FF_LAUNCH(1, false, true);
+        else ZM_FF_LAUNCH(2, false, true);
     }
-    else if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true); else ZM_FF_LAUNCH(0, false); }
-    else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true); else ZM_FF_LAUNCH(1, false); }
-    else { if (avg) ZM_FF_LAUNCH(2, true); else ZM_FF_LAUNCH(2, false); }
+    else if (mop == 0) { if (avg) ZM_FF_LAUNCH(0, true, false); else ZM_FF_LAUNCH(0, false, false); }
+    else if (mop == 1) { if (avg) ZM_FF_LAUNCH(1, true, false); else ZM_FF_LAUNCH(1, false, false); }
+    else { if (avg) ZM_FF_LAUNCH(2, true, false); else ZM_FF_LAUNCH(2, false, false); }
 #undef ZM_FF_LAUNCH
-#undef ZM_FF_LAUNCH1
     ZM_HIP(hipGetLastError());
-    if (want_clk) {
-        std::vector<long long> h(4 + 3 * (size_t)G);
-        ZM_HIP(hipMemcpyAsync(h.data(), clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
-        ZM_HIP(hipStreamSynchronize(ctx->stream));
-        const double us = (double)(h[3] - h[1]) * 0.01;
-        fprintf(stderr, "k_coadd_fused: workgroup 0 ran %.1f us, %lld shader clocks: %.3f GHz\n", us, h[2] - h[0],
-                (double)(h[2] - h[0]) / us * 1e-3);
-        // per-workgroup run times and placement (XCC, SE, CU from HW_ID)
-        long long t0 = h[4], t1 = h[5];
-        for (int g = 0; g < G; ++g) { t0 = std::min(t0, h[4 + 3 * g]); t1 = std::max(t1, h[4 + 3 * g + 1]); }
-        std::vector<double> dur(G);
-        std::map<int, int> percu;
-        std::map<int, std::pair<double, int>> perxcc;
-        for (int g = 0; g < G; ++g) {
-            dur[g] = (double)(h[4 + 3 * g + 1] - h[4 + 3 * g]) * 0.01;
-            const unsigned hw = (unsigned)h[4 + 3 * g + 2], xcc = (unsigned)(h[4 + 3 * g + 2] >> 32);
-            const int cu = (int)((hw >> 8) & 0xf), se = (int)((hw >> 13) & 0x7);
-            percu[(int)(xcc * 1024 + se * 16 + cu)]++;
-            perxcc[(int)xcc].first += dur[g];
-            perxcc[(int)xcc].second++;
-        }
-        std::vector<double> sd = dur;
-        std::sort(sd.begin(), sd.end());
-        std::map<int, int> hist;
-        for (auto& kv : percu) hist[kv.second]++;
-        fprintf(stderr, "  %d workgroups over %.1f us: run time min %.1f / median %.1f / max %.1f us; last start %.1f us; CUs used %zu:",
-                G, (double)(t1 - t0) * 0.01, sd.front(), sd[G / 2], sd.back(),
-                [&] { long long m = t0; for (int g = 0; g < G; ++g) m = std::max(m, h[4 + 3 * g]); return (double)(m - t0) * 0.01; }(),
-                percu.size());
-        for (auto& kv : hist) fprintf(stderr, " %d CUs x %d workgroups", kv.second, kv.first);
-        fprintf(stderr, "\n  mean run time by first tile column (of %d):", ntx);
-        for (int c = 0; c < ntx && c < G; ++c) {
-            double a = 0; int n = 0;
-            for (int g = c; g < G; g += ntx) { a += dur[g]; ++n; }
-            fprintf(stderr, " %.0f", a / n);
-        }
-        fprintf(stderr, "\n  mean run time by first tile row:");
-        for (int r = 0; r * ntx < G; ++r) {
-            double a = 0; int n = 0;
-            for (int g = r * ntx; g < std::min(G, (r + 1) * ntx); ++g) { a += dur[g]; ++n; }
-            fprintf(stderr, " %.0f", a / n);
-        }
-        fprintf(stderr, "\n  mean run time per XCC:");
-        for (auto& kv : perxcc) fprintf(stderr, " [%d] %.0f us (%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
-        fprintf(stderr, "\n");
-    }
     return 0;
 }

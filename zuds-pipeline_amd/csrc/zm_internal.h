@@ -116,14 +116,34 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch,
                    const int32_t* mask_for_box = nullptr, int box_nt = 0, uint16_t* mbox_out = nullptr);
 struct zm_ff {                       // one input frame of a fused coadd (device memory; read through the scalar cache)
-    const float2* src;               // prepped {value, variance} plane
+    const float* img;                // raw planes: staged with background, variance and threshold applied on the way
+    const float* wgt;                // ... or NULL (unit weights)
+    const float4* ytab;              // y part of the background spline per (row, mesh column) (k_bk_rows), or NULL
+    const float* vscale;             // device scalar: variance scale (RESCALE_WEIGHTS), or NULL
+    const float2* src;               // prepped {value, variance} plane: frames that cannot be staged raw (footprints
+                                     // beyond the LDS tile, BACK_SIZE not a multiple of 8, ZM_FF_RAW=0), else NULL
     const double2* lat;              // lattice of this frame
     const int32_t* mask;             // raw mask or NULL
     const uint16_t* mbox;            // box-OR plane of the mask
-    int nx, ny, spitch, pad0;
-    float fscale, fscale2;
-    int pad1, pad2;
+    const float* bk;                 // spline nodes (4 planes [nby][nbx]) or NULL: the per-tap path of the generic code
+    int nx, ny, spitch, nbx, nby, ytp;
+    float invmesh, wthresh, fscale, fscale2;
+    int vec_ok, pad0;
 };
+// jobs of the pre-pass of a fused coadd (resample.hip: k_bk_rows, k_mask_box_batch)
+struct zm_bkrows {
+    const float* bk;                 // spline nodes of the frame (4 planes [nby][nbx])
+    float4* out;                     // [ny][ytp]
+    int nbx, nby, ny, ytp;
+    float invmesh;
+    int pad[3];
+};
+struct zm_boxjob {
+    const int32_t* m;
+    uint16_t* B;
+    int nx, ny;
+};
+int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows, const zm_boxjob* boxes, int nboxes);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
