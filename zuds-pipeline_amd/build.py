@@ -19,6 +19,8 @@ SOURCES = ['ctx.hip', 'wcs_host.hip', 'resample.hip', 'combine.hip',
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']
 EXTRA_FLAGS = {}     # per-source additions, e.g. {'x.hip': ['-mllvm', '...']}
+# developer: ZM_HIPCC_FLAGS='-DFF_TALL=1' adds flags to every translation unit (use with --force)
+FLAGS += os.environ.get('ZM_HIPCC_FLAGS', '').split()
 
 
 def _hipcc():

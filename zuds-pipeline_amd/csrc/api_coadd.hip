@@ -200,7 +200,6 @@ static bool fused_ok(const zm_coadd_params* P) {
 // background spline (k_bk_rows), the box-OR planes of the masks, the frame descriptors.  Frames
 // are read RAW by the fused kernel; a prepped plane is only written for a frame that cannot be
 // staged that way (see zm_ff.src).
-#define ZM_FF_LDS_CAP 7800           // = FF_LDS_CAP of resample.hip
 struct fused_stage {
     std::vector<zm_ff> ff;
     int lds = 0, lnx = 0, lny = 0;
@@ -219,6 +218,8 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     const float wthresh = (float)P->weight_thresh;
     bk_plan bp;
     ZM_TRY(frames_background(ctx, n, fr, P, &bp));
+    int ff_th = 32, ff_cap = 3700;
+    zm_fused_geometry(&ff_th, &ff_cap);
     const char* e = getenv("ZM_FF_RAW");
     const bool raw_ok = !(e && e[0] == '0') && (P->back_size % 8 == 0 || !P->subtract_back);
     std::vector<zm_map_params> mp_host(n);
@@ -234,15 +235,18 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         double fs = 1.0;
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
-        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, 64, ZM_FF_LDS_CAP);
+        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, ff_th, ff_cap);
         // a footprint beyond the LDS tile is gathered from global memory: from a prepped plane
-        need_src[i] = !raw_ok || plan > ZM_FF_LDS_CAP;
-        lds = std::max(lds, std::min(plan, ZM_FF_LDS_CAP));
+        // (a frame without 16-byte rows is prepped into a plane, which has them)
+        const int vec_ok = (nx % 4 == 0) && (((uintptr_t)fr[i].img & 15) == 0) && (((uintptr_t)fr[i].wgt & 15) == 0);
+        need_src[i] = (!raw_ok || !vec_ok || plan > ff_cap) ? 1 : 0;
+        lds = std::max(lds, std::min(plan, ff_cap));
         prep_off[i] = prep_bytes;
         if (need_src[i]) prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
         box_off[i] = box_bytes;
         const bool with_mask = want_mask && fr[i].mask;
-        if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)nx * ny) + 255) & ~(size_t)255;
+        const int mpitch = (nx + 3) & ~3;
+        if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)mpitch * ny) + 255) & ~(size_t)255;
         any_mask |= with_mask;
         memset(&ff[i], 0, sizeof(zm_ff));
         ff[i].nx = nx; ff[i].ny = ny; ff[i].spitch = spitch;
@@ -252,7 +256,8 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         ff[i].img = fr[i].img;
         ff[i].wgt = fr[i].wgt;
         ff[i].wthresh = wthresh;
-        ff[i].vec_ok = (nx % 4 == 0) && (((uintptr_t)fr[i].img & 15) == 0) && (((uintptr_t)fr[i].wgt & 15) == 0);
+        ff[i].vec_ok = vec_ok;
+        ff[i].mpitch = mpitch;
     }
     double2* lat = nullptr;
     char *prep_all = nullptr, *box_all = nullptr, *yt_all = nullptr;
@@ -290,7 +295,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             // the frame prepped into its own plane (k_prep_box also fills the box-OR plane)
             float2* src = (float2*)(prep_all + prep_off[i]);
             ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bki[i].nodes, bki[i].nbx, bki[i].nby, P->back_size,
-                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox));
+                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox, ff[i].mpitch));
             ff[i].src = src;
             continue;
         }
@@ -307,7 +312,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             r.invmesh = ff[i].invmesh;
             rows.push_back(r);
         }
-        if (mbox) boxes.push_back(zm_boxjob{ff[i].mask, mbox, nx, ny});
+        if (mbox) boxes.push_back(zm_boxjob{ff[i].mask, mbox, nx, ny, ff[i].mpitch, 0});
     }
     ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size(), boxes.data(), (int)boxes.size()));
     S->lds = lds;

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
                                                   float invmesh, const float* __restrict__ var_scale_dev,
                                                   float wthresh, int vec_ok, float2* __restrict__ dst,
                                                   int spitch, const int32_t* __restrict__ m,
-                                                  uint16_t* __restrict__ B) {
+                                                  uint16_t* __restrict__ B, int bpitch) {
     constexpr int TWB = 64, THB = 16, IW = TWB + NT - 1, IH = THB + NT - 1, IP = IW + 1;
     __shared__ int32_t t0[IH * IP];
     __shared__ int32_t h[IH * TWB];
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
             int32_t o = 0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
-            B[(size_t)y * nx + x] = box_entry(o);
+            B[(size_t)y * bpitch + x] = box_entry(o);
         }
     }
 }
@@ -735,7 +735,8 @@ __global__ __launch_bounds__(256) void k_prep_box(const float* __restrict__ img,
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh, const float* var_scale_dev,
                    float wthresh, float2* dst, int spitch, const int32_t* mask_for_box, int box_nt,
-                   uint16_t* mbox_out) {
+                   uint16_t* mbox_out, int mbox_pitch) {
+    if (mbox_pitch <= 0) mbox_pitch = nx;
     const float invmesh = mesh > 0 ? 1.0f / mesh : 0.f;
     const int vec_ok = (nx % 4 == 0) && (((uintptr_t)img & 15) == 0) && (((uintptr_t)wgt & 15) == 0);
     ctx->box_ready_for = nullptr;
@@ -746,10 +747,10 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
         zm_scope_timer t(ctx, "prep");
         if (box_nt == 6)
             hipLaunchKernelGGL(k_prep_box<6>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
-                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox);
+                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox, mbox_pitch);
         else
             hipLaunchKernelGGL(k_prep_box<2>, grd, dim3(256), 0, ctx->stream, img, wgt, nx, ny, bknodes, nbx,
-                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox);
+                               nby, invmesh, var_scale_dev, wthresh, vec_ok, dst, spitch, mask_for_box, mbox, mbox_pitch);
         ZM_HIP(hipGetLastError());
         if (!mbox_out) {
             ctx->box_ready_for = mask_for_box;
@@ -1285,20 +1286,31 @@ __device__ __forceinline__ void zm_static_for(Fn&& fn) {
     }
 }
 
-#define FT_H 64                      // output rows of a fused tile: two stacked k_resample tiles
-#define FF_THREADS 512
+// Two shapes (FF_TALL): 1 = 64 x 64 tiles, one workgroup of 512 threads per CU (halo 1.35, every wave of a
+// CU in the same phase); 0 = 64 x 32 tiles, two workgroups of 256 threads per CU (halo 1.52; while one
+// stages and waits at its barrier the other computes).  Two waves per SIMD either way.
+#ifndef FF_TALL
+#define FF_TALL 0
+#endif
+#define FF_NSUB (FF_TALL ? 2 : 1)    // k_resample tiles (64 x 32) stacked in a fused tile
+#define FT_H (RTH * FF_NSUB)         // output rows of a fused tile
+#define FF_THREADS (256 * FF_NSUB)
+#define FF_WG_PER_CU (FF_TALL ? 1 : 2)
 #define FF_NSLOT 4                   // staging slots per thread; a slot = 4 consecutive pixels of one box row
 #define FF_NPX 8                     // output pixels per thread: rows 8 wave .. 8 wave + 7 of column (tid & 63)
-#define FF_HDR_WORDS 80
+#define FF_HDR_WORDS (FF_TALL ? 80 : 48)
 #define FF_LDS_HDR 1152              // bytes: 3 headers, tile ring, raw-mask flags
 #define FF_LDS_TAB ((LZ_FLOATS * 4 + 127) & ~127)
-#define FF_LDS_CAP 7800              // staged pixels per buffer: 2 x (8 + 2) B x 7800 + table + headers < 160 KB
+// staged pixels per buffer: 2 x (8 + 2) B x cap + table + headers < 160 KB / workgroups per CU
+#define FF_LDS_CAP (FF_TALL ? 7800 : 3700)
 
 struct ff_hdr {
-    tile_hdr3 sub[2];                // the headers k_resample would build for the two half-tiles
+    tile_hdr3 sub[FF_NSUB];          // the headers k_resample would build for the stacked tiles
     int bx0, by0, bw, bh;            // the staged box: union of the two sub-boxes
-    int use_lds, touches, fast, edge;
-    int sdx[2], sdy[2];              // sub-box origin minus union origin
+    int use_lds, touches, fast;      // (edge item = use_lds && !fast)
+    float vscale;                    // the frame's variance scale (a device scalar: fetched here, by the pre-pass)
+    int sdx[FF_NSUB], sdy[FF_NSUB];  // sub-box origin minus union origin
+    int pad[FF_HDR_WORDS - 34 * FF_NSUB - 8 - 2 * FF_NSUB];
 };
 static_assert(sizeof(ff_hdr) == FF_HDR_WORDS * 4, "ff_hdr is not its record");
 static_assert(3 * sizeof(ff_hdr) + 4 * 4 + 2 * 8 * 4 <= FF_LDS_HDR, "LDS header area too small");
@@ -1308,17 +1320,24 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
     constexpr int NT = 6, OFF = -2;
     const int tyi = t / ntx, txi = t - tyi * ntx;
     const zm_ff* F = fr + f;
-    // (a last tile row whose lower half lies off the grid: the upper header twice)
-    const int two = (tyi * FT_H + RTH < ony) ? 1 : 0;
-    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (FT_H / LSTEP), OFF, OFF + NT - 1,
-                       &H->sub[0]);
-    build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (FT_H / LSTEP) + two * (RTH / LSTEP), OFF,
-                       OFF + NT - 1, &H->sub[1]);
+    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+#pragma unroll
+    for (int u = 0; u < FF_NSUB; ++u) {
+        // (a last tile row whose lower half lies off the grid: the upper header twice)
+        const int live = (u == 0 || tyi * FT_H + u * RTH < ony) ? u : 0;
+        build_tile_header3(zm_gptr(F->lat), lnx, lny, txi * (TW / LSTEP), tyi * (FT_H / LSTEP) + live * (RTH / LSTEP), OFF,
+                           OFF + NT - 1, &H->sub[u]);
+    }
     if ((threadIdx.x & 63) == 0) {
         const int nx = F->nx, ny = F->ny;
-        const tile_hdr3 &a = H->sub[0], &b = H->sub[1];
-        const int bx0 = min(a.bx0, b.bx0), by0 = min(a.by0, b.by0);
-        const int bx1 = max(a.bx0 + a.bw, b.bx0 + b.bw), by1 = max(a.by0 + a.bh, b.by0 + b.bh);
+#pragma unroll
+        for (int u = 0; u < FF_NSUB; ++u) {
+            const tile_hdr3& a = H->sub[u];
+            bx0 = u ? min(bx0, a.bx0) : a.bx0;
+            by0 = u ? min(by0, a.by0) : a.by0;
+            bx1 = u ? max(bx1, a.bx0 + a.bw) : a.bx0 + a.bw;
+            by1 = u ? max(by1, a.by0 + a.bh) : a.by0 + a.bh;
+        }
         const int bw = bx1 - bx0, bh = by1 - by0;              // bw: a multiple of 4, like its parts
         const int touches = (bx0 < nx) && (bx1 > 0) && (by0 < ny) && (by1 > 0);
         const long long area = (long long)bw * bh;
@@ -1330,12 +1349,15 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         H->bx0 = bx0; H->by0 = by0; H->bw = bw; H->bh = bh;
         H->touches = touches;
         H->use_lds = use_lds;
-        // fast: the box lies on the frame and the tile on the grid - no bounds test anywhere (vector
-        // loads: rows of the frame 16-byte aligned).  edge: staged with bounds tests, {0, BIGVAR} outside.
-        H->fast = use_lds && inside && F->vec_ok;
-        H->edge = use_lds && !H->fast;
-        H->sdx[0] = a.bx0 - bx0; H->sdx[1] = b.bx0 - bx0;
-        H->sdy[0] = a.by0 - by0; H->sdy[1] = b.by0 - by0;
+        // fast: the box lies on the frame and the tile on the grid - no bounds test anywhere.  edge (staged,
+        // not fast): what lies off the frame becomes {0, BIGVAR} at the store.
+        H->fast = use_lds && inside;
+        H->vscale = F->vscale ? *F->vscale : 1.f;
+#pragma unroll
+        for (int u = 0; u < FF_NSUB; ++u) {
+            H->sdx[u] = H->sub[u].bx0 - bx0;
+            H->sdy[u] = H->sub[u].by0 - by0;
+        }
     }
 }
 
@@ -1383,7 +1405,7 @@ __device__ inline ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const floa
     uint32_t m16 = 0;
     if (with_mask) {
         if (!(ddx || ddy)) {
-            m16 = zm_gptr(F->mbox)[(size_t)iy * nx + ix];
+            m16 = zm_gptr(F->mbox)[(size_t)iy * F->mpitch + ix];
         } else {
             const int c0 = ddx ? CI : 0, c1 = ddx ? CI + 1 : NT;
             const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
@@ -1504,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr
     }
     __syncthreads();
     if (live) {
-        out[item * FF_HDR_WORDS + lane] = ((const int*)&H[w])[lane];
+        if (lane < FF_HDR_WORDS) out[item * FF_HDR_WORDS + lane] = ((const int*)&H[w])[lane];
         if (lane + 64 < FF_HDR_WORDS) out[item * FF_HDR_WORDS + 64 + lane] = ((const int*)&H[w])[64 + lane];
     }
 }
@@ -1561,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restr
             int32_t o = 0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
-            J.B[(size_t)y * nx + x] = box_entry(o);
+            J.B[(size_t)y * J.pitch + x] = box_entry(o);
         }
     }
 }
@@ -1680,11 +1702,12 @@ __device__ inline void lds_issue_u16(const uint16_t* p, uint32_t& o) {
 // next item starts, ahead of its prefetch: stores issued behind the prefetch would sit in front of
 // it in the (in-order) vmcnt queue of the wait that ends the item.
 template <int MOP, bool AVG, bool STACK>
-__global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
+__global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride) {
+    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride,
+    int dbg, long long* __restrict__ prof) {
     extern __shared__ float4 smem4[];
     char* smem = reinterpret_cast<char*>(smem4);
     ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem);                  // ring of 3 headers
@@ -1700,118 +1723,77 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
     // r0, r0 + RP, ... - one column position per thread, a uniform row stride per slot.
     float4 pi[FF_NSLOT], pw[FF_NSLOT], py4[FF_NSLOT];     // raw image / weight quads (or two prepped pairs), y part
     uint2 pm[FF_NSLOT];                                   // box-OR entries
-    auto prefetch = [&](const ff_hdr* H, int f) {
+    // One straight-line sequence of loads for every kind of item and frame, from addresses clamped
+    // onto the frame; what a quad is worth is decided at the store.  (Branches here - fast / edge,
+    // with / without weights - end in a join where the compiler copies the loaded registers: a use,
+    // i.e. a vmcnt(0) wait that drains the prefetch right after it was issued.  Measured: the
+    // staging loads and the pixel work did not overlap at all.)  Frames staged raw have 16-byte rows
+    // (vec_ok: the host preps the others into a plane); the prepped plane has an even pitch; the
+    // box-OR plane a pitch that is a multiple of 4.
+    auto prefetch = [&](const ff_hdr* H, int f, auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+        constexpr int KLO = decltype(lo_tag)::value, KHI = decltype(hi_tag)::value;
+        if (dbg & 4) return;
         const zm_ff* F = fr + f;
         const int nx = F->nx, ny = F->ny;
-        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, bw4 = max(H->bw >> 2, 1);
+        const int bx0 = H->bx0, by0 = H->by0, bh = max(H->bh, 1), bw4 = max(H->bw >> 2, 1);
         const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
         const int c = tid - r0 * bw4;
         const int RP = FF_THREADS / bw4;                  // (uniform) rows per slot
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool prepped = F->src != nullptr;
-        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr, has_m = MOP && F->mask != nullptr;
         const int gx = bx0 + 4 * c;
-        const int i0 = has_y ? bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1)) : 0;
-        zm_static_for<0, FF_NSLOT>([&](auto K) {
+        // raw: one quad of image, one of weights, the y part of its mesh column.  prepped: the two pairs.
+        const int sp = F->spitch;
+        const int xa = prepped ? min(max(gx, 0), sp - 2) : min(max(gx, 0), nx - 4);
+        const int xb = prepped ? min(max(gx + 2, 0), sp - 2) : xa;
+        const int xm = min(max(gx, 0), F->mpitch - 4);
+        const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1));
+        const float ZM_GLOBAL* pa0 = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) + 2 * (size_t)xa : zm_gptr(F->img) + xa;
+        const float ZM_GLOBAL* pb0 = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) + 2 * (size_t)xb
+                                             : (F->wgt ? zm_gptr(F->wgt) : zm_gptr(F->img)) + xb;
+        const size_t rowf = prepped ? 2 * (size_t)sp : (size_t)nx;       // floats per row of that plane
+        // (frames without a background / a mask: a harmless load of image pixels, ignored at the store)
+        const bool has_y = F->ytab != nullptr && !prepped, has_m = MOP && F->mask != nullptr;
+        const char ZM_GLOBAL* py0 = has_y ? (const char ZM_GLOBAL*)(zm_gptr(F->ytab) + i0) : (const char ZM_GLOBAL*)pa0;
+        const size_t rowy = has_y ? sizeof(float4) * (size_t)F->ytp : sizeof(float) * rowf;
+        const char ZM_GLOBAL* pm0 = has_m ? (const char ZM_GLOBAL*)(zm_gptr(F->mbox) + xm) : (const char ZM_GLOBAL*)pa0;
+        const size_t rowm = has_m ? sizeof(uint16_t) * (size_t)F->mpitch : sizeof(float) * rowf;
+        zm_static_for<KLO, KHI>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            pi[k] = z4; pw[k] = z4; py4[k] = z4; pm[k] = make_uint2(0u, 0u);
+            const int row = min(min(r0, RP - 1) + k * RP, bh - 1);
+            const size_t gy = (size_t)min(max(by0 + row, 0), ny - 1);
+            pi[k] = zm_gload4f(pa0 + gy * rowf);
+            pw[k] = zm_gload4f(pb0 + gy * rowf);
+            const zm_v4f vy = *(const zm_v4f ZM_GLOBAL*)(py0 + gy * rowy);
+            py4[k] = make_float4(vy.x, vy.y, vy.z, vy.w);
+            const zm_v2u vm = *(const zm_v2u ZM_GLOBAL*)(pm0 + gy * rowm);
+            pm[k] = make_uint2(vm.x, vm.y);
         });
-        if (!H->use_lds) return;
-        if (H->fast) {
-            // The whole box lies on the frame: no tests, no fill; rows past the box re-read its last
-            // row and are never stored.  (all loads back to back: one basic block, no waits in between)
-            zm_static_for<0, FF_NSLOT>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const int row = min(min(r0, RP - 1) + k * RP, bh - 1);
-                const size_t o = (size_t)(by0 + row) * nx + gx;
-                // (one pair of loads for both kinds of frame: two branches storing into different
-                // register arrays are merged by the compiler into one store through a pointer - to scratch)
-                const float ZM_GLOBAL* sp = (const float ZM_GLOBAL*)zm_gptr(F->src) + ((size_t)(by0 + row) * F->spitch + gx) * 2;
-                const float ZM_GLOBAL* pa = prepped ? sp : zm_gptr(F->img) + o;
-                const float ZM_GLOBAL* pb = prepped ? sp + 4 : zm_gptr(F->wgt) + o;
-                pi[k] = zm_gload4f(pa);
-                if (prepped || has_w) pw[k] = zm_gload4f(pb);
-                if (has_y && !prepped) {
-                    const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(zm_gptr(F->ytab) + ((size_t)(by0 + row) * F->ytp + i0));
-                    py4[k] = make_float4(v.x, v.y, v.z, v.w);
-                }
-                if (has_m) {
-                    const zm_v2u v = *(const zm_v2u ZM_GLOBAL*)(zm_gptr(F->mbox) + o);
-                    pm[k] = make_uint2(v.x, v.y);
-                }
-            });
-        } else {
-            // an edge item: the box sticks out of the frame (or the frame has no 16-byte rows) - bounds
-            // tests; what lies off the frame is filled at the store
-            const bool vec = F->vec_ok && gx >= 0 && gx + 4 <= nx;
-            zm_static_for<0, FF_NSLOT>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const int row = r0 + k * RP, gy = by0 + row;
-                if (!(r0 < RP && row < bh && gy >= 0 && gy < ny)) return;
-                const size_t o = (size_t)gy * nx + gx;
-                const int sp = F->spitch;
-                const float ZM_GLOBAL* ps = (const float ZM_GLOBAL*)zm_gptr(F->src) + ((ptrdiff_t)gy * sp + gx) * 2;
-                // (the prepped plane carries {0, BIGVAR} from nx to its even pitch; gx + 2 >= 0 when gx >= 0)
-                const bool la = prepped ? (gx >= 0 && gx < sp) : vec;
-                const bool lb = prepped ? (gx >= 0 && gx + 2 < sp) : (vec && has_w);
-                const float ZM_GLOBAL* pa = prepped ? ps : zm_gptr(F->img) + o;
-                const float ZM_GLOBAL* pb = prepped ? ps + 4 : zm_gptr(F->wgt) + o;
-                const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
-                float4 va = prepped ? fill : z4, vb = prepped ? fill : z4;
-                if (la) va = zm_gload4f(pa);
-                if (lb) vb = zm_gload4f(pb);
-                if (!prepped && !vec) {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (gx + e >= 0 && gx + e < nx) {
-                            v[e] = zm_gptr(F->img)[(ptrdiff_t)o + e];
-                            if (has_w) w[e] = zm_gptr(F->wgt)[(ptrdiff_t)o + e];
-                        }
-                    va = make_float4(v[0], v[1], v[2], v[3]);
-                    vb = make_float4(w[0], w[1], w[2], w[3]);
-                }
-                pi[k] = va;
-                pw[k] = vb;
-                if (has_y && !prepped) {
-                    const zm_v4f v = *(const zm_v4f ZM_GLOBAL*)(zm_gptr(F->ytab) + ((size_t)gy * F->ytp + i0));
-                    py4[k] = make_float4(v.x, v.y, v.z, v.w);
-                }
-                if (has_m) {
-                    if (vec) {
-                        const zm_v2u v = *(const zm_v2u ZM_GLOBAL*)(zm_gptr(F->mbox) + o);
-                        pm[k] = make_uint2(v.x, v.y);
-                    } else {
-                        // (entries whose 6 x 6 footprint leaves the frame are never written by the box
-                        // pre-pass and never folded: the pixel loop tests the footprint)
-                        unsigned e4[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (gx + e >= 0 && gx + e < nx) e4[e] = zm_gptr(F->mbox)[(ptrdiff_t)o + e];
-                        pm[k] = make_uint2(e4[0] | (e4[1] << 16), e4[2] | (e4[3] << 16));
-                    }
-                }
-            });
-        }
     };
     // prep the staged quads (background off, variance, bad pixels) and write them to LDS buffer `b`
-    auto store = [&](const ff_hdr* H, int f, int b) {
-        if (!H->use_lds) return;
+    // (two instantiations: `fast` items - nine in ten - carry no bounds test; written as one body with run-time
+    // tests the compiler built a branch per staged pixel around the fill)
+    auto store_impl = [&](const ff_hdr* H, int f, int b, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const zm_ff* F = fr + f;
-        const int nx = F->nx, ny = F->ny;
+        const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, bw = H->bw, bw4 = bw >> 2;
         const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)bw4));
         const int c = tid - r0 * bw4;
         const int RP = FF_THREADS / bw4;
         float2* tile = tile0 + (size_t)b * lds_cap;
         uint16_t* mtile = mtile0 + (size_t)b * lds_cap;
-        const bool prepped = F->src != nullptr, fast = H->fast;
-        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr, has_m = MOP && F->mask != nullptr;
+        const bool prepped = F->src != nullptr;
+        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr && !prepped, has_m = MOP && F->mask != nullptr;
         const int gx = bx0 + 4 * c;
-        const float vs = F->vscale ? *F->vscale : 1.f, wth = F->wthresh;
+        const float vs = H->vscale, wth = F->wthresh;
+        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+        // columns of this thread that lie on the frame (the loads came from clamped addresses)
+        const bool cok = FAST || (gx >= 0 && gx + 4 <= nx);                         // raw quad (nx % 4 == 0)
+        const bool cpa = FAST || (gx >= 0 && gx <= sp - 2), cpb = FAST || (gx + 2 >= 0 && gx + 2 <= sp - 2);
+        const bool cm = FAST || (gx >= 0 && gx + 4 <= F->mpitch);
         // the four x weights of this thread's four columns: once per item
         float4 xw[4];
-        if (has_y && !prepped) {
+        if (has_y) {
             const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1));
 #pragma unroll
             for (int e = 0; e < 4; ++e) xw[e] = bk_xweights(bk_dx(F->nbx, F->invmesh, gx + e, i0));
@@ -1822,21 +1804,24 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                 constexpr int k = decltype(K)::value;
                 const int row = r0 + k * RP;
                 if (row >= bh) return;
+                const bool rowok = FAST || (unsigned)(by0 + row) < (unsigned)ny;
                 float4 o0, o1;
                 if (prepped) {
-                    o0 = pi[k];
-                    o1 = pw[k];
-                    if (!fast && !((unsigned)(by0 + row) < (unsigned)ny)) o0 = o1 = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+                    o0 = (rowok && cpa) ? pi[k] : fill;
+                    o1 = (rowok && cpb) ? pw[k] : fill;
                 } else {
                     const float v[4] = {pi[k].x, pi[k].y, pi[k].z, pi[k].w};
                     const float w[4] = {pw[k].x, pw[k].y, pw[k].z, pw[k].w};
                     float2 p[4];
-                    const bool rowok = fast || (unsigned)(by0 + row) < (unsigned)ny;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float bg = has_y ? bk_xpart(py4[k], xw[e]) : 0.f;
                         p[e] = prep_pixel(v[e], w[e], has_w, bg, vs, wth);
-                        if (!fast && !(rowok && (unsigned)(gx + e) < (unsigned)nx)) p[e] = make_float2(0.f, ZM_BIGVAR);
+                        if (!FAST) {
+                            const bool ok = rowok && cok;
+                            p[e].x = ok ? p[e].x : 0.f;
+                            p[e].y = ok ? p[e].y : ZM_BIGVAR;
+                        }
                     }
                     o0 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
                     o1 = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
@@ -1844,9 +1829,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                 float4* d = reinterpret_cast<float4*>(tile + (size_t)row * bw + 4 * c);
                 d[0] = o0;
                 d[1] = o1;
-                if (has_m) {
-                    *reinterpret_cast<uint2*>(mtile + (size_t)row * bw + 4 * c) = pm[k];
-                    const uint32_t a = pm[k].x, bb = pm[k].y;
+                if (MOP) {
+                    // (entries whose 6 x 6 footprint leaves the frame are never written by the box
+                    // pre-pass and never folded: the pixel loop tests the footprint)
+                    uint2 mv = pm[k];
+                    if (!(has_m && rowok && cm)) mv = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(mtile + (size_t)row * bw + 4 * c) = mv;
+                    const uint32_t a = mv.x, bb = mv.y;
                     raw |= (a & 0xffffu) == ZM_BOX_RAW || (a >> 16) == ZM_BOX_RAW ||
                            (bb & 0xffffu) == ZM_BOX_RAW || (bb >> 16) == ZM_BOX_RAW;
                 }
@@ -1856,8 +1845,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
             // does any entry of the box defer to the raw mask (ZM_BOX_RAW: bits above 15)?  Decided
             // here, once per item, so that the pixel loop carries no vote and no branch for it
             const bool wraw = __any(raw);
-            if ((tid & 63) == 0) rawflag[b * 8 + (tid >> 6)] = wraw;
+            if ((tid & 63) == 0) rawflag[b * (FF_THREADS / 64) + (tid >> 6)] = wraw;
         }
+    };
+    auto store = [&](const ff_hdr* H, int f, int b) __attribute__((always_inline)) {
+        if (!H->use_lds || (dbg & 2)) return;
+        if (H->fast) store_impl(H, f, b, std::true_type{});
+        else store_impl(H, f, b, std::false_type{});
     };
     const int nty = ntiles / ntx;
     // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
@@ -1894,14 +1888,14 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
     hdr_put(0, hdr_word(t0, f0));
     if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
     __syncthreads();
-    prefetch(&HR[0], f0);
+    prefetch(&HR[0], f0, std::integral_constant<int, 0>{}, std::integral_constant<int, FF_NSLOT>{});
     store(&HR[0], f0, 0);
     __syncthreads();
 
     // ---- this thread's pixels: column tx, rows 8 wv .. 8 wv + 7 of the tile.  The wave lies in
     // sub-tile `sub` (k_resample's tile), lattice cell row `cr` of it; all wave-uniform.
     const int tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wv >> 2, cr = (wv & 3) >> 1;
+    const int sub = (FF_NSUB > 1) ? wv >> 2 : 0, cr = (wv & 3) >> 1;
     const int cell = tx >> 4;
     const float fx = (float)(tx & 15) * (1.f / LSTEP);
     const float fyb = (float)((wv & 1) * 8) * (1.f / LSTEP);
@@ -1925,6 +1919,10 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                 __builtin_nontemporal_store((zm_v2f){S1[q], S0[q]}, reinterpret_cast<zm_v2f*>(plane + (size_t)oy * onx + pox));
         }
     };
+    // developer (ZM_FF_PROF=1): shader-clock sums per phase of this wave
+    long long ptk[5] = {0, 0, 0, 0, 0}, tc = 0;
+#define FF_TICK(k) do { if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
+    if (prof) tc = __builtin_amdgcn_s_memtime();
     int slot = 0, buf = 0;
     for (;;) {
         const ff_hdr* H = &HR[slot];
@@ -1959,9 +1957,15 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
         if (grab && tid == 0) gnext = atomicAdd(tilectr, 1);
         // (unconditional: past the last item the current one is fetched again, into registers nobody stores)
         const bool more = t1 < ntiles;
-        prefetch(more ? &HR[nslot] : H, more ? f1 : f0);
+        // The staging loads of the next item go out in two bursts, one ahead of each pixel group: sixteen
+        // loads per thread at once back up the vector-memory pipe (3 700 cycles per item spent issuing them)
+        const ff_hdr* HN = more ? &HR[nslot] : H;
+        const int fn = more ? f1 : f0;
+        prefetch(HN, fn, std::integral_constant<int, 0>{}, std::integral_constant<int, FF_NSLOT / 2>{});
+        FF_TICK(0);
 
-        if (touches) {
+        const bool do_px = touches && !(dbg & 1);
+        {
             // x part of the bilinear lattice interpolation, once per item (k_resample's operations)
             const float x0a = SH->nrel[cr][cell][0], x1a = SH->nrel[cr][cell + 1][0];
             const float y0a = SH->nrel[cr][cell][1], y1a = SH->nrel[cr][cell + 1][1];
@@ -1971,20 +1975,23 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
             const float xb = __builtin_fmaf(fx, x1b - x0b, x0b), yb = __builtin_fmaf(fx, y1b - y0b, y0b);
             const float xd = xb - xa, yd = yb - ya;
             const bool with_mask = MOP && F->mask != nullptr;
-            const bool staged = fast || H->edge;
+            const bool staged = use_lds;
             // wave-uniform: pixels left to the generic code (items that do not go through LDS: all)
-            unsigned slow = staged ? 0u : 0xffu;
+            unsigned slow = !do_px ? 0u : staged ? 0u : 0xffu;
             bool any_raw = false;
             if (MOP && with_mask && staged) {
-                const int* rf = rawflag + buf * 8;
-                any_raw = (rf[0] | rf[1] | rf[2] | rf[3] | rf[4] | rf[5] | rf[6] | rf[7]) != 0;
+                const int* rf = rawflag + buf * (FF_THREADS / 64);
+                int any = 0;
+#pragma unroll
+                for (int u = 0; u < FF_THREADS / 64; ++u) any |= rf[u];
+                any_raw = any != 0;
             }
             const float fscale = F->fscale, fscale2 = F->fscale2;
             const float2* tbase = tile + (soff + OFF * bw + OFF);
             const uint16_t* mbase = mtile + (soff + OFF * bw + OFF);
             const int enx = F->nx, eny = F->ny;
             // four vertically adjacent pixels (rows 4 g .. 4 g + 3 of the thread) out of one 9 x 6 window
-            auto group = [&](auto edge_tag, auto g_tag) {
+            auto group = [&](auto edge_tag, auto g_tag) __attribute__((always_inline)) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
                 constexpr int G = decltype(g_tag)::value;
                 float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
@@ -2060,14 +2067,18 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                 // rows 0 .. 8 of the window; row rho is tap row rho - j of pixel j.  Row rho + 1 is read
                 // while the packed FMAs of row rho run (two row buffers).
                 zm_v2f av[4];
-                lds_row6 ra, rb;
-                lds_issue6(p, ra);
+                // three row buffers: rows rho + 1 and rho + 2 are in flight while row rho is applied (two
+                // waves per SIMD do not cover an LDS round trip with the 24 packed FMAs of one row)
+                lds_row6 rbuf[3];
+                lds_issue6(p, rbuf[0]);
+                lds_issue6(p + bw, rbuf[1]);
 #pragma unroll
                 for (int rho = 0; rho < NT + 3; ++rho) {
-                    lds_row6& cur = (rho & 1) ? rb : ra;
-                    lds_row6& nxt = (rho & 1) ? ra : rb;
-                    if (rho + 1 < NT + 3) {
-                        lds_issue6(p + (rho + 1) * bw, nxt);
+                    lds_row6& cur = rbuf[rho % 3];
+                    if (rho + 2 < NT + 3) {
+                        lds_issue6(p + (rho + 2) * bw, rbuf[(rho + 2) % 3]);
+                        lds_wait_n<12>(cur);
+                    } else if (rho + 1 < NT + 3) {
                         lds_wait_n<6>(cur);
                     } else {
                         lds_wait_n<0>(cur);
@@ -2107,12 +2118,14 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                     if (MOP) MK[q] &= mterm[j];
                 }
             };
-            if (fast) {
-                group(std::false_type{}, std::integral_constant<int, 0>{});
-                group(std::false_type{}, std::integral_constant<int, 1>{});
-            } else if (H->edge) {
-                group(std::true_type{}, std::integral_constant<int, 0>{});
-                group(std::true_type{}, std::integral_constant<int, 1>{});
+            if (do_px) {
+                if (fast) group(std::false_type{}, std::integral_constant<int, 0>{});
+                else if (use_lds) group(std::true_type{}, std::integral_constant<int, 0>{});
+            }
+            prefetch(HN, fn, std::integral_constant<int, FF_NSLOT / 2>{}, std::integral_constant<int, FF_NSLOT>{});
+            if (do_px) {
+                if (fast) group(std::false_type{}, std::integral_constant<int, 1>{});
+                else if (use_lds) group(std::true_type{}, std::integral_constant<int, 1>{});
             }
             // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
 #pragma unroll 1
@@ -2167,12 +2180,16 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
                 SW[q] = 0.f; MK[q] = -1;
             }
         }
+        FF_TICK(1);
+        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FF_TICK(2); }
         // the next item: prepped into the other LDS buffer (the one the pixels of the item before
         // this one were read from - every wave is past that since the last barrier)
         if (more) store(&HR[nslot], f1, buf ^ 1);
+        FF_TICK(3);
         if (t2 < ntiles) hdr_put(nnslot, hw2);       // slot nnslot was last read an item ago
         if (grab && tid == 0) tring[(k2 + 1) & 3] = tile_of(gnext);
         __syncthreads();
+        FF_TICK(4);
         t0 = t1; f0 = f1;
         t1 = t2; f1 = f2;
         next_item(t2, f2, k2);
@@ -2181,6 +2198,14 @@ __global__ __launch_bounds__(FF_THREADS) void k_coadd_fused(
         if (t0 >= ntiles) break;
     }
     if (STACK) flush();
+    if (prof && (tid & 63) == 0)
+        for (int k = 0; k < 5; ++k) prof[((size_t)blockIdx.x * (FF_THREADS / 64) + (tid >> 6)) * 5 + k] = ptk[k];
+#undef FF_TICK
+}
+
+void zm_fused_geometry(int* tile_h, int* lds_cap) {
+    *tile_h = FT_H;
+    *lds_cap = FF_LDS_CAP;
 }
 
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
@@ -2198,7 +2223,7 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     lds_elems = std::min(std::max(lds_elems, 64), FF_LDS_CAP);
     lds_elems = (lds_elems + 7) & ~7;
     const size_t shmem = (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)lds_elems * (sizeof(float2) + sizeof(uint16_t));
-    ZM_CHECK(shmem <= 160 * 1024, "zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
+    ZM_CHECK(shmem <= 160 * 1024 / FF_WG_PER_CU, "zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
     const float* taptab = nullptr;
     ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
     // descriptors: pinned staging guarded by an event (a later call must not overwrite a copy in flight)
@@ -2214,14 +2239,20 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
     ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, ctx->stream));
     ZM_HIP(hipEventRecord(ev[5], ctx->stream));
-    // persistent grid: one workgroup per CU (its LDS tile leaves room for no second), each starting
+    // persistent grid: FF_WG_PER_CU workgroups per CU (what their LDS tiles leave room for), each starting
     // on the tile of its index and taking further tiles from a queue (a counter behind the item
     // headers, set to G by k_ff_headers)
     int ncu = 256;
     ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int G = std::min(ntiles, std::max(ncu, 1));
+    const int G = std::min(ntiles, std::max(ncu, 1) * FF_WG_PER_CU);
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
+    // ZM_FF_DBG (developer, tools/ff_probe.py): 1 no pixel work, 2 no prep / LDS store, 4 no staging loads
+    const int dbg = getenv("ZM_FF_DBG") ? atoi(getenv("ZM_FF_DBG")) : 0;
+    long long* prof = nullptr;
+    const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
+    const int nwv = FF_THREADS / 64;
+    if (want_prof) ZM_TRY(ctx->get("ff_prof", sizeof(long long) * 5 * nwv * (size_t)G, (void**)&prof));
     zm_scope_timer t(ctx, "coadd_fused");
     {
         const long long items = (long long)ntiles * nfr;
@@ -2238,7 +2269,7 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         }                                                                                                      \
         hipLaunchKernelGGL(kfn, dim3(G), dim3(FF_THREADS), shmem, ctx->stream, dev, nfr, onx, ony, lds_elems,  \
                            ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, taptab, tilectr,   \
-                           stack, (long long)fstride);                                                         \
+                           stack, (long long)fstride, dbg, prof);                                                         \
     } while (0)
     if (stack) {
         if (mop == 0) ZM_FF_LAUNCH(0, false, true);
@@ -2250,5 +2281,17 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     else { if (avg) ZM_FF_LAUNCH(2, true, false); else ZM_FF_LAUNCH(2, false, false); }
 #undef ZM_FF_LAUNCH
     ZM_HIP(hipGetLastError());
+    if (want_prof) {
+        std::vector<long long> h((size_t)5 * nwv * G);
+        ZM_HIP(hipMemcpyAsync(h.data(), prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        ZM_HIP(hipStreamSynchronize(ctx->stream));
+        static const char* nm[5] = {"issue", "pixels", "loadwait", "store", "barrier"};
+        double sum[5] = {0, 0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)nwv * G; ++w)
+            for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 5 + k];
+        fprintf(stderr, "k_coadd_fused phases, mean per wave (s_memtime ticks of 10 ns):");
+        for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f us", nm[k], sum[k] / ((double)nwv * G) * 0.01);
+        fprintf(stderr, "\n");
+    }
     return 0;
 }

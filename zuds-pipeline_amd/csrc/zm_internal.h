@@ -114,7 +114,8 @@ int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, in
 int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                    const float* bknodes, int nbx, int nby, int mesh,
                    const float* var_scale_dev, float wthresh, float2* dst, int spitch,
-                   const int32_t* mask_for_box = nullptr, int box_nt = 0, uint16_t* mbox_out = nullptr);
+                   const int32_t* mask_for_box = nullptr, int box_nt = 0, uint16_t* mbox_out = nullptr,
+                   int mbox_pitch = 0);
 struct zm_ff {                       // one input frame of a fused coadd (device memory; read through the scalar cache)
     const float* img;                // raw planes: staged with background, variance and threshold applied on the way
     const float* wgt;                // ... or NULL (unit weights)
@@ -128,7 +129,7 @@ struct zm_ff {                       // one input frame of a fused coadd (device
     const float* bk;                 // spline nodes (4 planes [nby][nbx]) or NULL: the per-tap path of the generic code
     int nx, ny, spitch, nbx, nby, ytp;
     float invmesh, wthresh, fscale, fscale2;
-    int vec_ok, pad0;
+    int vec_ok, mpitch;              // mpitch: pixels per row of the box-OR plane (a multiple of 4)
 };
 // jobs of the pre-pass of a fused coadd (resample.hip: k_bk_rows, k_mask_box_batch)
 struct zm_bkrows {
@@ -141,8 +142,10 @@ struct zm_bkrows {
 struct zm_boxjob {
     const int32_t* m;
     uint16_t* B;
-    int nx, ny;
+    int nx, ny, pitch, pad;
 };
+// the fused coadd's tile rows and LDS capacity in staged pixels (resample.hip: FT_H, FF_LDS_CAP)
+void zm_fused_geometry(int* tile_h, int* lds_cap);
 int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows, const zm_boxjob* boxes, int nboxes);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
