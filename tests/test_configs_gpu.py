@@ -1,0 +1,150 @@
+"""BASELINE.json configs at their stated shapes on one GPU.
+
+configs[1]: 32 frames 3072 x 3072, Lanczos-3 + weighted coadd - the fused kernel against the
+materialised k_resample path, bit for bit, at the depth the metric is quoted on.
+
+configs[4]: full-quadrant nightly - per CCD quadrant one N = 16 reference stack
+(``scripts/makeref.py:85`` -> ``ReferenceImage.from_images``), then the epochs subtracted against it
+(``scripts/donightly.py:30-49`` -> ``dosub.do_one``) with forced r = 3 px photometry at 500 positions
+on every difference image (``scripts/dophot.py:94-156``).  4 quadrants x (16 + 8) frames of
+3072 x 3072 through ``DeviceCoadd`` and ``nightly.SubtractionPool``: products independent of the
+number of jobs in flight, every region solved, fill pattern == bit 17, photometry equal to the host
+entry point ``raw_aperture_photometry`` uses.  (The 8-GPU run shards these jobs 32 per GPU with no
+collective; one GPU runs a quarter of the epochs.)"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import pkg, synth
+
+pytestmark = pytest.mark.gpu
+N = 3072
+
+
+def device_frames(torch, s, eng, n, seed0, stars=None, base=None, dither=15.0, rot=0.1, nbad_frac=1e-3):
+    """n config-2 style frames generated on the device (sky + Poisson-like noise, bad pixels; the star
+    field `stars` - an image on the `base` grid - resampled onto each frame's own WCS)."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    frames = []
+    for i in range(n):
+        r = np.random.default_rng(seed0 + i)
+        w = s.ztf_wcs(N, N, dx=r.uniform(-dither, dither), dy=r.uniform(-dither, dither),
+                      rot_deg=r.uniform(-rot, rot), tpv=True)
+        sky = r.uniform(100, 300)
+        magzp = r.uniform(25.8, 26.6)
+        g.manual_seed(seed0 + i)
+        img = sky + torch.randn((N, N), generator=g, device=dev) * float(np.sqrt(sky / 6.2))
+        if stars is not None:
+            st, _, _ = eng.resample(stars, base, w)
+            img += torch.from_numpy(st * 10 ** (0.4 * (magzp - 25.0))).to(dev)
+        bad = torch.rand((N, N), generator=g, device=dev) < nbad_frac
+        frames.append(dict(img=img.float(), wgt=torch.where(bad, 0.0, 6.2 / sky).float(),
+                           mask=torch.where(bad, 256, 0).to(torch.int32), wcs=w, sky=sky,
+                           flxscale=10 ** (-0.4 * (magzp - 25.0))))
+    return frames
+
+
+def test_config1_depth_32_fused_equals_materialised(engine):
+    import torch
+    z, s = pkg(), synth()
+    dv = importlib.import_module('zuds-pipeline_amd.device')
+    base = s.ztf_wcs(N, N, tpv=True)
+    frames = device_frames(torch, s, engine, 32, 2000)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True)
+    dfr = dv.DeviceFrames(frames, torch.device('cuda', 0))
+    out = {}
+    for mode in ('0', '1'):
+        os.environ['ZM_COADD_FUSED'] = mode
+        try:
+            co = dv.DeviceCoadd(base, p, device=0, engine=engine, want_mask=True)
+            co.run(dfr)
+            co.stream.synchronize()
+            out[mode] = [t.clone() for t in (co.img, co.wgt, co.mask, co.mask_wgt)]
+        finally:
+            os.environ.pop('ZM_COADD_FUSED', None)
+            engine.set_stream(0)
+    for a, b, what in zip(out['0'], out['1'], ('coadd', 'weight', 'mask', 'coverage')):
+        assert torch.equal(a, b), what
+    img, wgt = out['1'][0], out['1'][1]
+    assert float((wgt > 0).float().mean()) > 0.98
+    # background removed, 32 frames deep: the coadd's scatter is that of a 32-frame mean
+    core = img[200:-200, 200:-200][wgt[200:-200, 200:-200] > 0]
+    assert abs(float(core.mean())) < 0.05 and 0.2 < float(core.std()) < 0.6
+
+
+def test_config4_full_quadrant_nightly(engine):
+    import torch
+    z, s = pkg(), synth()
+    dv = importlib.import_module('zuds-pipeline_amd.device')
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    dev = torch.device('cuda', 0)
+    base = s.ztf_wcs(N, N, tpv=True)
+    NREF, NEPOCH, NPOS = 16, 8, 500
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True)
+    one, four = nm.SubtractionPool(1), nm.SubtractionPool(4)
+    try:
+        for quad in range(4):
+            rng = np.random.default_rng(5000 + quad)
+            stars = np.zeros((N, N))
+            xs, ys = rng.uniform(10, N - 10, 2500), rng.uniform(10, N - 10, 2500)
+            s.add_stars(stars, xs, ys, np.exp(rng.uniform(np.log(2e3), np.log(6e4), 2500)), 2.2)
+            stars = stars.astype(np.float32)
+            # the reference of this quadrant: N = 16 stack on the quadrant's grid, mask coadd, bit 16, rms map
+            ref_frames = device_frames(torch, s, engine, NREF, 6000 + 100 * quad, stars, base)
+            co = dv.DeviceCoadd(base, p, device=0, engine=engine, want_mask=True)
+            co.run(dv.DeviceFrames(ref_frames, dev))
+            L = engine.L
+            with torch.cuda.stream(co.stream):
+                z._lib.check(L.zm_mask_flag_dev(engine.ctx, co.mask.data_ptr(), co.mask_wgt.data_ptr(), 0.0, 1 << 16, N * N))
+                z._lib.check(L.zm_add_scalar_dev(engine.ctx, co.img.data_ptr(), 150.0, N * N))
+                ref_rms = torch.empty_like(co.wgt)
+                z._lib.check(L.zm_rms_from_weight_dev(engine.ctx, co.wgt.data_ptr(), None, N * N,
+                                                      float(np.sqrt(50000.0)), ref_rms.data_ptr()))
+            co.stream.synchronize()
+            del ref_frames
+            assert float((co.wgt > 0).float().mean()) > 0.97
+            ref = dict(img=co.img, rms=ref_rms, mask=co.mask, wcs=base, flxscale=1.0)
+            # the epochs of the night, forced photometry at 500 fixed sky positions of the quadrant
+            pra, pdec = base.all_pix2world(rng.uniform(30, N - 30, NPOS), rng.uniform(30, N - 30, NPOS), 0)
+            jobs = []
+            for f in device_frames(torch, s, engine, NEPOCH, 7000 + 100 * quad, stars, base, dither=8.0, rot=0.05, nbad_frac=2e-4):
+                rms = torch.where(f['wgt'] > 0, 1.0 / torch.sqrt(f['wgt'].clamp_min(1e-20)), float(np.sqrt(50000.0))).float()
+                sci = dict(img=f['img'], rms=rms, mask=f['mask'], wgt=f['wgt'], wcs=f['wcs'], seeing=2.2)
+                jobs.append(nm.SubtractionJob(sci, ref, radec=(pra, pdec), nreg_side=3, tag=len(jobs)))
+            a = one.map(jobs)
+            b = four.map(jobs)
+            for x, y in zip(a, b):
+                assert 'error' not in x and 'error' not in y
+                assert x['info'] == y['info'], (quad, x['tag'])
+                assert x['info']['status'] == 0 and x['info']['nunsolved'] == 0 and x['info']['retries'] == 0
+                assert x['info']['ncoeff'] == 722                      # the reference's -ko 4 -bgo 0
+                for k in ('diff', 'noise', 'mask'):
+                    assert torch.equal(x[k], y[k]), (quad, x['tag'], k)
+                for k in ('flux', 'fluxerr', 'flags'):
+                    assert np.array_equal(x['phot'][k], y['phot'][k], equal_nan=True), (quad, x['tag'], k)
+                # hotpants' fill value <-> bit 17 (zuds/subtraction.py:170-171)
+                fill = x['diff'] == 1e-30
+                assert torch.equal(fill, (x['mask'] & (1 << 17)) != 0)
+                assert 0.0 < float(fill.float().mean()) < 0.1
+                assert len(x['phot']['flux']) == NPOS
+            assert len({float(r['info']['kernel_sum']) for r in a}) == NEPOCH
+            # the difference images are noise: the science frame's, less what the deep reference removes
+            r0 = a[0]
+            good = ~(r0['diff'] == 1e-30)
+            d = r0['diff'][good]
+            sig = 1.4826 * float((d - d.median()).abs().median())           # robust: bright-star residuals aside
+            assert 0.7 * float(jobs[0].sci['rms'].median()) < sig < 1.4 * float(jobs[0].sci['rms'].median())
+            # photometry of the pool == the host entry point raw_aperture_photometry calls, on the same planes
+            flux, err, flags = engine.aperture_photometry(r0['diff'].cpu().numpy(), r0['phot']['x'], r0['phot']['y'],
+                                                          rms=r0['noise'].cpu().numpy(), mask=r0['mask'].cpu().numpy())
+            assert np.array_equal(flux, r0['phot']['flux'], equal_nan=True)
+            assert np.array_equal(err, r0['phot']['fluxerr'], equal_nan=True)
+            assert np.array_equal(flags, r0['phot']['flags'])
+            del a, b, jobs, ref, co
+            torch.cuda.empty_cache()
+    finally:
+        one.close()
+        four.close()
