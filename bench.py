@@ -59,6 +59,11 @@ def parse():
     ap.add_argument('--no-nightly', action='store_true', help='skip the concurrent-subtraction leg')
     ap.add_argument('--no-pipelined', action='store_true', help='skip the software-pipelined rate')
     ap.add_argument('--nightly-jobs', type=int, default=16, help='subtractions of the concurrent leg')
+    ap.add_argument('--dump-coadd', default=None,
+                    help='developer / tests: rank 0 saves the coadd planes [img, wgt] (.npy) after the run')
+    ap.add_argument('--emulate-ranks', type=int, default=1,
+                    help='developer / tests: ONE process coadds the frames N ranks would hold (their seeds), '
+                         'the reference a multi-rank run is compared with')
     ap.add_argument('--cpu-frames', type=int, default=8,
                     help='full-size frames the CPU baseline resamples and coadds')
     return ap.parse_args()
@@ -278,6 +283,8 @@ def main():
     base, frames = make_device_frames(synth, torch, args.frames + 1, args.size,
                                       2000 + 1000 * rank, device)
     sci = frames.pop()            # the science epoch of configs[2]
+    for r in range(1, args.emulate_ranks if world == 1 else 1):
+        frames += make_device_frames(synth, torch, args.frames + 1, args.size, 2000 + 1000 * r, device)[1][:-1]
     # detector defects of the science frame: 300 clustered 3x3 blobs instead of
     # isolated pixels (a 69 x 69 substamp box must be clean to be usable)
     g = torch.Generator(device='cpu')
@@ -459,6 +466,9 @@ def main():
             clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
                                                  ref_rms, step, timed, 1e3 * dt / args.steps)
 
+    if rank == 0 and args.dump_coadd:
+        torch.cuda.synchronize(device)
+        np.save(args.dump_coadd, torch.stack([coadd.img, coadd.wgt]).cpu().numpy())
     if rank == 0:
         dom = max(kt, key=lambda k: kt[k]['ms_per_step']) if kt else None
         if rs_cnt:      # the roofline kernel: from the timed region itself
