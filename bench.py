@@ -38,7 +38,7 @@ if int(os.environ.get('WORLD_SIZE', '1')) == 1:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
-PMC_PROFILES = ['r02_pmc_coadd_fused.json', 'r02_pmc_resample.json', 'r01_pmc_resample.json']     # newest first
+PMC_PROFILES = ['r03_pmc_coadd_fused.json']     # newest first; each stamped with the hash of the kernel sources it measured
 
 
 def parse():
@@ -102,15 +102,33 @@ def make_device_frames(synth, torch, n, size, seed0, device):
     return base, frames
 
 
+def kernel_sources_sha16():
+    """Hash of the kernel sources of this tree (the function of tools/make_pmc_json.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'zuds-pipeline_amd', 'csrc')
+    for f in sorted(f for f in os.listdir(d) if f.endswith(('.hip', '.h'))):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'zudsmi.h'), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_profile(args, kernel):
     """Counter figures per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; SQ_INSTS_VALU); {} when
-    no committed profile matches this kernel and workload."""
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; SQ_INSTS_VALU).  Counters cannot be
+    collected inside a bench run (separate --pmc passes), so they are quoted - but only from a profile
+    that was measured on THESE kernel sources (`kernel_sources_sha16`); otherwise {'stale': ...} and the
+    line carries null for traffic / valu_frac / lds_frac."""
+    sha = kernel_sources_sha16()
     for name in PMC_PROFILES:
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
         except (OSError, ValueError):
             continue
+        if d.get('kernel_sources_sha16') != sha:
+            return {'stale': f'profiles/{name} was measured on kernel sources {d.get("kernel_sources_sha16")}, '
+                             f'this tree is {sha}: counter figures not quoted'}
         if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask) and \
                 d.get('kernel', '').split('<')[0] == kernel.split('<')[0] and \
                 ('stack' in d.get('kernel', '')) == ('stack' in kernel) and \
@@ -506,7 +524,8 @@ def main():
                         'avg_launch_us': kt[roof_scope]['avg_us'],
                         'us_per_frame': kt[roof_scope]['avg_us'] / (args.frames if fused else 1),
                         'algorithmic_bytes_per_launch': bytes_per_launch,
-                        'dominant_by_time': dom}
+                        'dominant_by_time': dom,
+                        'counters_from': pmc.get('stale') or (f'profiles/{PMC_PROFILES[0]} (kernel sources {pmc.get("kernel_sources_sha16")})' if pmc else None)}
             # what this kernel runs into is not HBM: its waves alternate between LDS tap reads
             # and the packed FMAs that consume them
             if pmc.get('valu_simd_seconds_per_launch'):

@@ -27,4 +27,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $out/pmc_SQ -o pmc --output-format csv -- python3 $B > $out/pmc_SQ.log 2>&1 || { tail -20 $out/pmc_SQ.log; exit 1; }
 python3 tools/pmc_summary.py $(find $out/pmc_* -name '*counter_collection.csv') > $out/pmc_summary.txt
-grep -E "k_coadd_fused|k_prep_box|k_mesh_stats|k_chol_fused|k_hp_apply" $out/pmc_summary.txt
+grep -E "k_coadd_fused|k_mask_box|k_mesh_stats|k_chol|k_hp_apply" $out/pmc_summary.txt
+# the counter profile bench.py quotes, stamped with the hash of these kernel sources (copy it to profiles/)
+python3 tools/make_pmc_json.py $out $out/pmc_coadd_fused.json
