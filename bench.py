@@ -64,7 +64,7 @@ def parse():
     ap.add_argument('--emulate-ranks', type=int, default=1,
                     help='developer / tests: ONE process coadds the frames N ranks would hold (their seeds), '
                          'the reference a multi-rank run is compared with')
-    ap.add_argument('--cpu-frames', type=int, default=8,
+    ap.add_argument('--cpu-frames', type=int, default=2,
                     help='full-size frames the CPU baseline resamples and coadds')
     return ap.parse_args()
 
@@ -137,18 +137,26 @@ def pmc_profile(args, kernel):
     return {}
 
 
-def cpu_baseline(synth, size, combine, nframes=8, sub_size=640):
-    """CPU restatement timed on this box's host cores (a port, NOT SWarp / hotpants, which
-    are not installed): the C / OpenMP port of the oracle (oracle/cport, all cores) on the
-    resample -> coadd leg of `nframes` config-2 frames of the full size, plus - reported in
-    the sample text only - the numpy hotpants restatement on one small frame."""
+def cpu_baseline(synth, size, combine, nframes=8, steps_frames=32, nreg_side=3):
+    """The whole metric on this box's host cores, by a CPU restatement (a port, NOT SWarp / hotpants /
+    SExtractor, which are not installed): per frame the mesh background of the image and of its variance
+    map (SUBTRACT_BACK Y, RESCALE_WEIGHTS Y), background off, per-pixel TPV inverse map, Lanczos-3 resample
+    of image / variance / mask, then the combine - all in the C / OpenMP port of the oracle
+    (oracle/cport, every core) on `nframes` full-size frames; and the hotpants restatement
+    (oracle/hotpants.py: numpy + scipy correlate2d + LAPACK, the arithmetic inside compiled code) on ONE of
+    the 3 x 3 regions of a full-size subtraction at the bench's parameters (r = 10, rss = 24, 10 x 10
+    stamps, ko = 4: 722 unknowns).  `value` composes the stage times into the bench step - `steps_frames`
+    frames resampled and coadded + one full-size subtraction (nine regions) - with the metric's pixel
+    accounting; the C stages are also timed on one thread (SWarp's NTHREADS 1,
+    zuds/astromatic/makecoadd/default.swarp:115)."""
     from oracle import cport
+    from oracle import hotpants as ohp
     from oracle.wcs import WCS as OWCS
 
     def ow(w):
         return OWCS(w.crpix, w.crval, w.cd, w.pv1, w.pv2, w.naxis)
     c = cport.load(native=True)
-    c.set_threads(int(os.environ.get('ZM_CPU_THREADS', 0)) or cport.host_cores())
+    ncores = int(os.environ.get('ZM_CPU_THREADS', 0)) or cport.host_cores()
     base = synth.ztf_wcs(size, size, tpv=True)
     frames = []
     for i in range(nframes):
@@ -156,37 +164,73 @@ def cpu_baseline(synth, size, combine, nframes=8, sub_size=640):
         w = synth.ztf_wcs(size, size, dx=r.uniform(-15, 15), dy=r.uniform(-15, 15),
                           rot_deg=r.uniform(-0.1, 0.1), tpv=True)
         frames.append(synth.make_frame(size, size, 2000 + i, w, nstars=100, nbad=size))
-    t0 = time.perf_counter()
-    vals, wgts = [], []
-    for f in frames:
-        px, py = c.positions(ow(base), ow(f['wcs']), size, size)
-        o, w_, _ = c.resample(f['img'], f['wgt'], px, py, 3, f['flxscale'], f['mask'])
-        vals.append(o)
-        wgts.append(w_)
-    ref, refw = c.combine(np.array(vals), np.array(wgts), combine)
-    t1 = time.perf_counter()
-    mpix = nframes * size * size / 1e6
-    # one subtraction against a small coadd (numpy hotpants restatement, one core)
-    from oracle import hotpants as ohp
-    from oracle import resample as oresample
-    ss = sub_size
-    sbase = synth.ztf_wcs(ss, ss, tpv=True)
-    sf = synth.make_frame(ss, ss, 2100, synth.ztf_wcs(ss, ss, dx=2.0, dy=-3.0, tpv=True), nstars=100, nbad=ss)
-    spx, spy = oresample.positions(ow(sbase), ow(sf['wcs']), ss, ss)
-    sv, sw, _ = oresample.resample(sf['img'], sf['wgt'], spx, spy, oresample.LANCZOS3, 1.0)
-    srms = np.where(sw > 0, 1.0 / np.sqrt(np.where(sw > 0, sw, 1)), np.sqrt(50000.0))
+
+    def coadd_leg(fr):
+        t0 = time.perf_counter()
+        vals, wgts = [], []
+        for f in fr:
+            img, wgt = f['img'].astype(np.float64), f['wgt']
+            bkg, _, _, bsig, _, _ = c.background(img, wgt, 128, 3)
+            with np.errstate(divide='ignore'):
+                var = np.where(wgt > 1e-30, 1.0 / np.where(wgt > 0, wgt, 1), 0.0)
+            _, _, level, _, _, _ = c.background(var, wgt, 128, 3, want_images=False)
+            scale = bsig * bsig / level if (level > 0 and bsig > 0) else 1.0
+            px, py = c.positions(ow(base), ow(f['wcs']), size, size)
+            o, w_, _ = c.resample((img - bkg).astype(np.float32), (wgt / scale).astype(np.float32), px, py, 3,
+                                  f['flxscale'], f['mask'])
+            vals.append(o)
+            wgts.append(w_)
+        t1 = time.perf_counter()
+        c.combine(np.array(vals), np.array(wgts), combine)
+        return t1 - t0, time.perf_counter() - t1
+    c.set_threads(ncores)
+    t_fr, t_cb = coadd_leg(frames)
+    c.set_threads(1)
+    t_fr1, t_cb1 = coadd_leg(frames[:1])
+    c.set_threads(ncores)
+    # one region of the subtraction: a (size / nreg_side)^2 frame with the stamps, kernel and orders of the step
+    rs = size // nreg_side
+    rng = np.random.default_rng(3000)
+    ref = np.full((rs, rs), 150.0)
+    ns_ = max(int(3000 * (rs / 3072.0) ** 2), 50)
+    synth.add_stars(ref, rng.uniform(10, rs - 10, ns_), rng.uniform(10, rs - 10, ns_),
+                    np.exp(rng.uniform(np.log(3e3), np.log(8e4), ns_)), 4.0)
+    from scipy.ndimage import gaussian_filter
+    sci = 1.2 * gaussian_filter(ref, 1.0) + 20.0 + rng.normal(0, 3.0, ref.shape)
+    ref = ref + rng.normal(0, 0.5, ref.shape)
+    nst = max(int(size / 100.0 / nreg_side), 1)
     t2 = time.perf_counter()
-    ohp.subtract(sv + 150.0, sv + 150.0, srms, srms, (sw <= 0).astype(np.uint8),
-                 r=5.0, rss=12.0, nsx=max(ss // 100, 1), nsy=max(ss // 100, 1), ko=2, bgo=0,
-                 tu=5e3, iu=5e3, tl=-100.0, il=-100.0)
-    t3 = time.perf_counter()
-    return {'value': mpix / (t1 - t0), 'unit': 'Mpix/s', 'cores': c.threads(), 'kind': 'port',
-            'sample': f'{nframes} frames {size}x{size}: per-pixel TPV inverse map + Lanczos-3 resample '
-                      f'(image, variance, mask) + {combine} combine in {t1 - t0:.1f} s, C / OpenMP port of '
-                      f'the oracle on {c.threads()} threads ({os.cpu_count()} host CPUs visible; gcc -O3 '
-                      f'-march=native); separately the numpy hotpants restatement, one core, one '
-                      f'{ss}x{ss} subtraction r=5 ko=2: {t3 - t2:.1f} s = {ss * ss / 1e6 / (t3 - t2):.2f} Mpix/s. '
-                      f'CPU restatement, not SWarp / hotpants (not installed)'}
+    _, _, hinfo = ohp.subtract(sci, ref, np.full(ref.shape, 3.0), np.full(ref.shape, 0.5), np.zeros(ref.shape, np.uint8),
+                               r=10.0, rss=24.0, nsx=nst, nsy=nst, nrx=1, nry=1, ko=4, bgo=0, tu=5e3, iu=5e3,
+                               tl=-100.0, il=-100.0)
+    t_reg = time.perf_counter() - t2
+    npx = size * size / 1e6
+    per_frame, per_frame1 = t_fr / nframes, t_fr1 / 1
+    comb = t_cb * steps_frames / nframes                       # one read of every sample: linear in the depth
+    comb1 = t_cb1 * steps_frames / 1
+    t_sub = t_reg * nreg_side * nreg_side
+    t_step = steps_frames * per_frame + comb + t_sub
+    t_step1 = steps_frames * per_frame1 + comb1 + t_sub
+    mpix_step = (steps_frames + 1) * npx
+    return {'value': mpix_step / t_step, 'unit': 'Mpix/s', 'cores': ncores, 'kind': 'port',
+            'value_one_thread': mpix_step / t_step1,
+            'stages': {'background_rescale_resample_s_per_frame': per_frame, 'same_on_one_thread': per_frame1,
+                       f'combine_{combine}_s_per_{steps_frames}_frames': comb,
+                       'hotpants_s_per_region': t_reg, 'hotpants_s_per_subtraction': t_sub,
+                       'coadd_leg_mpix_s': steps_frames * npx / (steps_frames * per_frame + comb),
+                       'subtract_leg_mpix_s': npx / t_sub,
+                       'hotpants_region': {'size': rs, 'stamps_used': hinfo['regions'][0]['nstamps_used'],
+                                           'rounds': hinfo['regions'][0]['niter'], 'unknowns': hinfo['regions'][0]['ncoeff']}},
+            'sample': f'all three stages of the metric on {size}x{size} frames: {nframes} frames through mesh background '
+                      f'(image + variance map) + weight rescale + per-pixel TPV inverse map + Lanczos-3 resample '
+                      f'(image, variance, mask) in {t_fr:.1f} s and their {combine} combine in {t_cb:.1f} s (C / OpenMP port '
+                      f'of the oracle, {ncores} threads; gcc -O3 -march=native; {os.cpu_count()} host CPUs visible); '
+                      f'one of the {nreg_side * nreg_side} regions ({rs}x{rs}) of a subtraction with r=10 rss=24 '
+                      f'{nst}x{nst} stamps ko=4 (722 unknowns) in {t_reg:.1f} s (oracle/hotpants.py: numpy / scipy / LAPACK, '
+                      f'one process). value = ({steps_frames} + 1) frames x {npx:.2f} Mpix / ({steps_frames} x per-frame '
+                      f'time + combine scaled to {steps_frames} frames + {nreg_side * nreg_side} x region time) = the bench '
+                      f'step; value_one_thread: the C stages on 1 thread (SWarp NTHREADS 1). CPU restatement, not '
+                      f'SWarp / hotpants / SExtractor (not installed)'}
 
 
 def launch(args):
@@ -570,7 +614,7 @@ def main():
         if tools is not None:
             out['reference_tools'] = tools
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(synth, args.size, args.combine, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(synth, args.size, args.combine, args.cpu_frames, args.frames)
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()

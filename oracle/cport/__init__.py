@@ -58,6 +58,7 @@ class CPort(object):
         self.L.zo_resample.argtypes = [P, P, P, C.c_int, C.c_int, P, P, C.c_int, C.c_int, C.c_int,
                                        C.c_double, P, P, P]
         self.L.zo_combine.argtypes = [P, P, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double, P, P]
+        self.L.zo_background.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P]
 
     def threads(self):
         return int(self.L.zo_threads())
@@ -88,6 +89,21 @@ class CPort(object):
                            py.ctypes.data, onx, ony, int(kind), float(fscale), out.ctypes.data,
                            outw.ctypes.data, None if outm is None else outm.ctypes.data)
         return out, outw, outm
+
+    def background(self, img, wgt=None, mesh=128, fsize=3, want_images=True):
+        """oracle.background.background: (bkg, rms, backmean, backsig, nodes_b, nodes_s)."""
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        wgt = None if wgt is None else np.ascontiguousarray(wgt, dtype=np.float32)
+        ny, nx = img.shape
+        nbx, nby = (nx - 1) // mesh + 1, (ny - 1) // mesh + 1
+        bkg = np.empty((ny, nx)) if want_images else None
+        rms = np.empty((ny, nx)) if want_images else None
+        stats = np.empty(2)
+        nb, ns = np.empty((nby, nbx)), np.empty((nby, nbx))
+        self.L.zo_background(img.ctypes.data, None if wgt is None else wgt.ctypes.data, nx, ny, int(mesh), int(fsize),
+                             None if bkg is None else bkg.ctypes.data, None if rms is None else rms.ctypes.data,
+                             stats.ctypes.data, nb.ctypes.data, ns.ctypes.data)
+        return bkg, rms, float(stats[0]), float(stats[1]), nb, ns
 
     def combine(self, vals, wgts, kind='CLIPPED', clip_sigma=4.0, clip_ampfrac=0.3):
         vals = np.ascontiguousarray(vals, dtype=np.float64)

@@ -256,3 +256,234 @@ int zo_threads(void) {
     return 1;
 #endif
 }
+
+/* ---- mesh background (oracle/background.py, line by line) ------------------------------------
+ * SWarp SUBTRACT_BACK Y / BACK_SIZE 128 / BACK_FILTERSIZE 3 (zuds/swarp.py:69,
+ * zuds/astromatic/makecoadd/default.swarp:77-88) and SExtractor's -BACKGROUND / BACKGROUND_RMS
+ * check-images (zuds/sextractor.py:21-26): per mesh 2-sigma pre-clip, quantised histogram over
+ * +-5 sigma, iterated +-3 sigma clipping around the histogram median, mode; bad meshes filled
+ * from the nearest good ones; fsize x fsize median; natural bicubic spline to full resolution. */
+#define ZB_BIG 1e30
+#define ZB_NMAXLEVELS 4096
+
+static double zb_median_walk(const int64_t* histo, int nlevels, int lcut, int hcut) {
+    int64_t lowsum = 0, highsum = 0;
+    int lo = lcut, hi = hcut;
+    for (int k = lcut; k <= hcut; ++k) {
+        if (lowsum < highsum) lowsum += histo[lo++];
+        else highsum += histo[hi--];
+    }
+    if (hi < 0) return 0.0;
+    int64_t a = lo < nlevels ? histo[lo] : 0, b = histo[hi];
+    double den = 2.0 * (double)(a > b ? a : b);
+    double frac = den > 0 ? (double)(highsum - lowsum) / den : 0.0;
+    return hi + 0.5 + frac;
+}
+
+/* one mesh: pix = its valid pixels (n of them); returns 0 when the mesh has no estimate */
+static int zb_mesh(const double* pix, int n, int64_t* histo, double* mode, double* sigma) {
+    if (n == 0) return 0;
+    double s = 0, s2 = 0;
+    for (int i = 0; i < n; ++i) s += pix[i];
+    double mean = s / n;
+    for (int i = 0; i < n; ++i) s2 += (pix[i] - mean) * (pix[i] - mean);
+    double var = s2 / n, sig = var > 0 ? sqrt(var) : 0.0;
+    double lcut = mean - 2.0 * sig, hcut = mean + 2.0 * sig;
+    int npix = 0;
+    s = 0;
+    for (int i = 0; i < n; ++i) if (pix[i] >= lcut && pix[i] <= hcut) { s += pix[i]; ++npix; }
+    if (npix == 0) return 0;
+    mean = s / npix;
+    s2 = 0;
+    for (int i = 0; i < n; ++i) if (pix[i] >= lcut && pix[i] <= hcut) s2 += (pix[i] - mean) * (pix[i] - mean);
+    var = s2 / npix;
+    sig = var > 0 ? sqrt(var) : 0.0;
+    double step = sqrt(2.0 / 3.14159265358979323846) * 5 / 4;
+    int nlevels = (int)(step * npix + 1);
+    if (nlevels > ZB_NMAXLEVELS) nlevels = ZB_NMAXLEVELS;
+    float mean32 = (float)mean, sig32 = (float)sig;
+    float qscale = sig32 > 0 ? (float)(2.0 * 5 * (double)sig32 / nlevels) : 1.0f;
+    float qzero = (float)((double)mean32 - 5 * (double)sig32);
+    float cste = (float)(0.499999 - (double)(qzero / qscale));
+    memset(histo, 0, sizeof(int64_t) * (size_t)nlevels);
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        float q = (float)pix[i] / qscale + cste;
+        double t = trunc((double)q);
+        if (t >= 0 && t < nlevels) { histo[(int)t]++; ++total; }
+    }
+    if (total == 0) return 0;
+    /* backguess */
+    int nlm1 = nlevels - 1, lc = 0, hc = nlm1;
+    double sg = 10.0 * nlm1, sg1 = 1.0, mea = mean32, med = mean32;
+    for (int it = 100; it > 0 && sg >= 0.1 && fabs(sg / sg1 - 1.0) > 1e-4; --it) {
+        sg1 = sg;
+        double hs = 0, hm = 0, hq = 0;
+        for (int k = lc; k <= hc; ++k) { double h = (double)histo[k]; hs += h; hm += h * k; hq += h * k * (double)k; }
+        mea = hm;
+        sg = hq;
+        med = zb_median_walk(histo, nlevels, lc, hc);
+        if (hs > 0) { mea /= hs; sg = sg / hs - mea * mea; }
+        sg = sg > 0 ? sqrt(sg) : 0.0;
+        double ft = med - 3.0 * sg;
+        lc = ft > 0 ? (int)(ft + 0.5) : 0;
+        ft = med + 3.0 * sg;
+        hc = ft < nlm1 ? (ft > 0 ? (int)(ft + 0.5) : (int)(ft - 0.5)) : nlm1;
+    }
+    double qz = qzero, qs = qscale;
+    if (sg > 0) *mode = fabs((mea - med) / sg) < 0.3 ? qz + (2.5 * med - 1.5 * mea) * qs : qz + med * qs;
+    else *mode = qz + mea * qs;
+    *sigma = sg * qs;
+    return 1;
+}
+
+static double zb_fqmedian(double* v, int n) {
+    if (n == 0) return 0.0;
+    qsort(v, (size_t)n, sizeof(double), cmp_d);
+    return (n & 1) ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+}
+
+/* natural cubic spline second derivatives / 6 of `n` values with stride `st` */
+static void zb_derivs(const double* a, int n, int st, double* d) {
+    for (int i = 0; i < n; ++i) d[i] = 0.0;
+    if (n < 3) return;
+    double* u = (double*)calloc((size_t)n, sizeof(double));
+    for (int y = 1; y < n - 1; ++y) {
+        double temp = -1.0 / (d[y - 1] + 4.0);
+        d[y] = temp;
+        u[y] = temp * (u[y - 1] - 6.0 * (a[(size_t)(y + 1) * st] + a[(size_t)(y - 1) * st] - 2.0 * a[(size_t)y * st]));
+    }
+    d[n - 1] = 0.0;
+    for (int y = n - 2; y > 0; --y) d[y] = d[y] * d[y + 1] + u[y];
+    d[0] = 0.0;
+    for (int i = 0; i < n; ++i) d[i] /= 6.0;
+    free(u);
+}
+
+static void zb_expand(const double* nodes, int nbx, int nby, int nx, int ny, int mesh, double* out) {
+    /* spline along y per node column -> rows [ny][nbx]; then along x per image row */
+    double* rows = (double*)malloc(sizeof(double) * (size_t)ny * nbx);
+    double* d = (double*)malloc(sizeof(double) * (size_t)(nby > nbx ? nby : nbx));
+    for (int i = 0; i < nbx; ++i) {
+        zb_derivs(nodes + i, nby, nbx, d);
+        for (int y = 0; y < ny; ++y) {
+            if (nby < 2) { rows[(size_t)y * nbx + i] = nodes[i]; continue; }
+            double t = (y + 0.5) / mesh - 0.5;
+            int j0 = (int)floor(t);
+            if (j0 < 0) j0 = 0;
+            if (j0 > nby - 2) j0 = nby - 2;
+            double dy = t - j0, dy1 = 1.0 - dy, cdy = dy * dy * dy - dy, cdy1 = dy1 * dy1 * dy1 - dy1;
+            rows[(size_t)y * nbx + i] = dy1 * nodes[(size_t)j0 * nbx + i] + dy * nodes[(size_t)(j0 + 1) * nbx + i] +
+                                        cdy1 * d[j0] + cdy * d[j0 + 1];
+        }
+    }
+    free(d);
+#pragma omp parallel
+    {
+        double* dx = (double*)malloc(sizeof(double) * (size_t)nbx);
+#pragma omp for schedule(static)
+        for (int y = 0; y < ny; ++y) {
+            const double* r = rows + (size_t)y * nbx;
+            zb_derivs(r, nbx, 1, dx);
+            for (int x = 0; x < nx; ++x) {
+                if (nbx < 2) { out[(size_t)y * nx + x] = r[0]; continue; }
+                double t = (x + 0.5) / mesh - 0.5;
+                int i0 = (int)floor(t);
+                if (i0 < 0) i0 = 0;
+                if (i0 > nbx - 2) i0 = nbx - 2;
+                double ddx = t - i0, dx1 = 1.0 - ddx, cdx = ddx * ddx * ddx - ddx, cdx1 = dx1 * dx1 * dx1 - dx1;
+                out[(size_t)y * nx + x] = dx1 * r[i0] + ddx * r[i0 + 1] + cdx1 * dx[i0] + cdx * dx[i0 + 1];
+            }
+        }
+        free(dx);
+    }
+    free(rows);
+}
+
+/* oracle.background.background: bkg / rms [ny][nx] float64 (either may be NULL), stats = {backmean,
+ * backsig}, nodes_b / nodes_s [nby][nbx] (may be NULL).  img float64 [ny][nx]; wgt float32 or NULL. */
+void zo_background(const double* img, const float* wgt, int nx, int ny, int mesh, int fsize, double* bkg,
+                   double* rms, double* stats, double* nodes_b, double* nodes_s) {
+    const int nbx = (nx - 1) / mesh + 1, nby = (ny - 1) / mesh + 1, nm = nbx * nby;
+    double* back = (double*)malloc(sizeof(double) * (size_t)nm);
+    double* sigm = (double*)malloc(sizeof(double) * (size_t)nm);
+#pragma omp parallel
+    {
+        double* pix = (double*)malloc(sizeof(double) * (size_t)mesh * mesh);
+        int64_t* histo = (int64_t*)malloc(sizeof(int64_t) * ZB_NMAXLEVELS);
+#pragma omp for schedule(dynamic)
+        for (int m = 0; m < nm; ++m) {
+            const int j = m / nbx, i = m - j * nbx;
+            const int y0 = j * mesh, y1 = (j + 1) * mesh < ny ? (j + 1) * mesh : ny;
+            const int x0 = i * mesh, x1 = (i + 1) * mesh < nx ? (i + 1) * mesh : nx;
+            int n = 0;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const double p = img[(size_t)y * nx + x];
+                    if (p > -ZB_BIG && (!wgt || wgt[(size_t)y * nx + x] > (float)WEIGHT_THRESH)) pix[n++] = p;
+                }
+            back[m] = sigm[m] = -ZB_BIG;
+            if (n < (y1 - y0) * (x1 - x0) * 0.5) continue;
+            double mo, sg;
+            if (zb_mesh(pix, n, histo, &mo, &sg)) { back[m] = mo; sigm[m] = sg; }
+        }
+        free(pix);
+        free(histo);
+    }
+    /* fill bad meshes from the nearest good ones */
+    double* b2 = (double*)malloc(sizeof(double) * (size_t)nm);
+    double* s2 = (double*)malloc(sizeof(double) * (size_t)nm);
+    int ngood = 0;
+    for (int m = 0; m < nm; ++m) ngood += back[m] > -ZB_BIG;
+    for (int j = 0; j < nby; ++j)
+        for (int i = 0; i < nbx; ++i) {
+            const int m = j * nbx + i;
+            b2[m] = back[m];
+            s2[m] = sigm[m];
+            if (back[m] > -ZB_BIG) continue;
+            if (!ngood) { b2[m] = 0.0; s2[m] = 1.0; continue; }
+            long best = -1;
+            for (int q = 0; q < nm; ++q)
+                if (back[q] > -ZB_BIG) {
+                    long dd = (long)(q % nbx - i) * (q % nbx - i) + (long)(q / nbx - j) * (q / nbx - j);
+                    if (best < 0 || dd < best) best = dd;
+                }
+            double sb = 0, ss = 0;
+            int cnt = 0;
+            for (int q = 0; q < nm; ++q)
+                if (back[q] > -ZB_BIG) {
+                    long dd = (long)(q % nbx - i) * (q % nbx - i) + (long)(q / nbx - j) * (q / nbx - j);
+                    if (dd == best) { sb += back[q]; ss += sigm[q]; ++cnt; }
+                }
+            b2[m] = sb / cnt;
+            s2[m] = ss / cnt;
+        }
+    /* fsize x fsize median */
+    double* bo = (double*)malloc(sizeof(double) * (size_t)nm);
+    double* so = (double*)malloc(sizeof(double) * (size_t)nm);
+    const int hb = fsize / 2;
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)(fsize * fsize > nm ? fsize * fsize : nm));
+    for (int j = 0; j < nby; ++j)
+        for (int i = 0; i < nbx; ++i) {
+            if (fsize <= 1) { bo[j * nbx + i] = b2[j * nbx + i]; so[j * nbx + i] = s2[j * nbx + i]; continue; }
+            int n = 0;
+            for (int y = (j - hb > 0 ? j - hb : 0); y <= (j + hb < nby - 1 ? j + hb : nby - 1); ++y)
+                for (int x = (i - hb > 0 ? i - hb : 0); x <= (i + hb < nbx - 1 ? i + hb : nbx - 1); ++x) tmp[n++] = b2[y * nbx + x];
+            bo[j * nbx + i] = zb_fqmedian(tmp, n);
+            n = 0;
+            for (int y = (j - hb > 0 ? j - hb : 0); y <= (j + hb < nby - 1 ? j + hb : nby - 1); ++y)
+                for (int x = (i - hb > 0 ? i - hb : 0); x <= (i + hb < nbx - 1 ? i + hb : nbx - 1); ++x) tmp[n++] = s2[y * nbx + x];
+            so[j * nbx + i] = zb_fqmedian(tmp, n);
+        }
+    if (bkg) zb_expand(bo, nbx, nby, nx, ny, mesh, bkg);
+    if (rms) zb_expand(so, nbx, nby, nx, ny, mesh, rms);
+    if (nodes_b) memcpy(nodes_b, bo, sizeof(double) * (size_t)nm);
+    if (nodes_s) memcpy(nodes_s, so, sizeof(double) * (size_t)nm);
+    if (stats) {
+        memcpy(tmp, bo, sizeof(double) * (size_t)nm);
+        stats[0] = zb_fqmedian(tmp, nm);
+        memcpy(tmp, so, sizeof(double) * (size_t)nm);
+        stats[1] = zb_fqmedian(tmp, nm);
+    }
+    free(tmp); free(bo); free(so); free(b2); free(s2); free(back); free(sigm);
+}

@@ -59,3 +59,26 @@ def test_combine_matches_numpy(c, kind):
         ro, rw, _ = ocombine.combine(vals, wgts, kind)
         np.testing.assert_allclose(o, ro, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(w, rw, rtol=1e-12, atol=0)
+
+
+def test_background_matches_numpy(c):
+    """Mesh background / RMS maps of the C port against oracle.background (what bench.py's
+    cpu_baseline times for SWarp's SUBTRACT_BACK and the variance rescale): ragged frame, a
+    star field, a masked region that empties some meshes, flat weights (the variance map)."""
+    from oracle import background as obk
+    s = synth()
+    rng = np.random.default_rng(12)
+    ny, nx = 300, 410
+    img = rng.normal(180.0, 5.0, (ny, nx)) + 0.02 * np.arange(nx)[None, :]
+    s.add_stars(img, rng.uniform(0, nx, 40), rng.uniform(0, ny, 40), np.exp(rng.uniform(7, 10, 40)), 2.2)
+    wgt = np.full((ny, nx), 1 / 25.0, np.float32)
+    wgt[rng.uniform(size=wgt.shape) < 0.01] = 0
+    wgt[:70, 130:260] = 0                                   # a whole mesh without pixels
+    for im, wg, mesh in ((img, wgt, 64), (img, None, 128), (1.0 / np.maximum(wgt, 1e-3).astype(np.float64), wgt, 64)):
+        b, r, bm, bs, nb, ns = c.background(im, wg, mesh=mesh, fsize=3)
+        rb, rr, rbm, rbs, rnb, rns = obk.background(im, wg, mesh=mesh, fsize=3)
+        np.testing.assert_allclose(nb, rnb, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ns, rns, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(b, rb, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r, rr, rtol=1e-9, atol=1e-9)
+        assert abs(bm - rbm) < 1e-9 * max(1, abs(rbm)) and abs(bs - rbs) < 1e-9 * max(1, abs(rbs))
