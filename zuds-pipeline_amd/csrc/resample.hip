@@ -1757,6 +1757,8 @@ __global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
         const size_t rowy = has_y ? sizeof(float4) * (size_t)F->ytp : sizeof(float) * rowf;
         const char ZM_GLOBAL* pm0 = has_m ? (const char ZM_GLOBAL*)(zm_gptr(F->mbox) + xm) : (const char ZM_GLOBAL*)pa0;
         const size_t rowm = has_m ? sizeof(uint16_t) * (size_t)F->mpitch : sizeof(float) * rowf;
+        // (measured and dropped: not loading a slot none of this wave's lanes needs - the last one, for
+        // most waves - by a wave-uniform branch: 2.38 -> 2.46 ms)
         zm_static_for<KLO, KHI>([&](auto K) {
             constexpr int k = decltype(K)::value;
             const int row = min(min(r0, RP - 1) + k * RP, bh - 1);
@@ -2058,11 +2060,29 @@ __global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
                         mterm[j] = (with_mask && ((inbm >> j) & 1u)) ? t : -1;
                     }
                 }
+                // the eight tap-table nodes (x and y of four pixels), two in flight: the node of lookup i + 1 is
+                // requested before lookup i is evaluated (left to the compiler, every lookup waits for its own
+                // five reads right after issuing them: eight exposed LDS round trips per group)
                 zm_v2f txp[4][3], typ[4][3];
+                {
+                    lz3_node na, nb;
+                    float dla, dlb;
+                    lz3_issue(ltab, dxs[0], na, dla);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    zm_lz3_lookup(ltab, dxs[j], txp[j]);
-                    zm_lz3_lookup(ltab, dys[j], typ[j]);
+                    for (int i = 0; i < 8; ++i) {
+                        lz3_node& cur = (i & 1) ? nb : na;
+                        lz3_node& nxt = (i & 1) ? na : nb;
+                        float& dlc = (i & 1) ? dlb : dla;
+                        float& dln = (i & 1) ? dla : dlb;
+                        if (i + 1 < 8) {
+                            lz3_issue(ltab, ((i + 1) & 1) ? dys[(i + 1) >> 1] : dxs[(i + 1) >> 1], nxt, dln);
+                            lz3_wait<5>(cur);
+                        } else {
+                            lz3_wait<0>(cur);
+                        }
+                        if (i & 1) lz3_eval(cur, dlc, typ[i >> 1]);
+                        else lz3_eval(cur, dlc, txp[i >> 1]);
+                    }
                 }
                 // rows 0 .. 8 of the window; row rho is tap row rho - j of pixel j.  Row rho + 1 is read
                 // while the packed FMAs of row rho run (two row buffers).
