@@ -37,7 +37,8 @@ static int check_wcs(const zm_wcs* w, const char* what) {
 // sampled over the output grid.  k_resample: 64 x 32 tiles, at most 8000 elements (64 KB without
 // the opt-in); the fused coadd: 64 x 64 tiles made of two k_resample boxes (their union: one more
 // alignment step), `cap` elements - a larger plan means the frame's footprints exceed the LDS tile.
-static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw = 64, int th = 32, int cap = 8000) {
+static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw = 64, int th = 32, int cap = 8000,
+                    bool exact = false) {
     double wmax = 0, hmax = 0;
     for (int sy = 0; sy < 3; ++sy)
         for (int sx = 0; sx < 3; ++sx) {
@@ -52,6 +53,12 @@ static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw
         }
     const int extra = th > 32 ? 4 : 0;
     double w = ceil(wmax * 1.02) + ntaps + 9 + extra, h = ceil(hmax * 1.02) + ntaps + 5 + extra / 2;   // + box alignment (4 px)
+    if (exact) {
+        // the bound build_tile_header3 obeys: bw = (bx1 - bx0 + 4) & ~3 <= extent + 16, bh <= extent + 10.
+        // (No safety factor: an item that exceeds the plan is found by its header and takes the generic code.)
+        w = (double)(((long long)(ceil(wmax) + ntaps + 10)) & ~3LL);
+        h = ceil(hmax) + ntaps + 4;
+    }
     double e = w * h;
     if (!(e > 0) || e > cap) return cap + 1;
     return (int)e;
@@ -221,7 +228,8 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     int ff_th = 32, ff_cap = 3700;
     zm_fused_geometry(&ff_th, &ff_cap);
     const char* e = getenv("ZM_FF_RAW");
-    const bool raw_ok = !(e && e[0] == '0') && (P->back_size % 8 == 0 || !P->subtract_back);
+    // (raw staging: a quad in one mesh column, a box - at most 96 columns - under at most two of them)
+    const bool raw_ok = !(e && e[0] == '0') && ((P->back_size % 8 == 0 && P->back_size >= 96) || !P->subtract_back);
     std::vector<zm_map_params> mp_host(n);
     std::vector<zm_ff>& ff = S->ff;
     ff.resize(n);
@@ -235,7 +243,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         double fs = 1.0;
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
-        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, ff_th, ff_cap);
+        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, ff_th, ff_cap, true);
         // a footprint beyond the LDS tile is gathered from global memory: from a prepped plane
         // (a frame without 16-byte rows is prepped into a plane, which has them)
         const int vec_ok = (nx % 4 == 0) && (((uintptr_t)fr[i].img & 15) == 0) && (((uintptr_t)fr[i].wgt & 15) == 0);
@@ -245,7 +253,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         if (need_src[i]) prep_bytes += ((sizeof(float2) * (size_t)spitch * ny) + 255) & ~(size_t)255;
         box_off[i] = box_bytes;
         const bool with_mask = want_mask && fr[i].mask;
-        const int mpitch = (nx + 3) & ~3;
+        const int mpitch = (nx + 7) & ~7;          // 16-byte pieces of the box-OR plane for the LDS-DMA
         if (with_mask) box_bytes += ((sizeof(uint16_t) * (size_t)mpitch * ny) + 255) & ~(size_t)255;
         any_mask |= with_mask;
         memset(&ff[i], 0, sizeof(zm_ff));
@@ -285,6 +293,9 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         }
     }
     if (yt_bytes) ZM_TRY(ctx->get("bk_rows_all", yt_bytes, (void**)&yt_all));
+    int* boxflags = nullptr;           // per frame: its box-OR plane holds entries that defer to the raw mask
+    ZM_TRY(ctx->get("mask_box_flags", sizeof(int) * (size_t)n, (void**)&boxflags));
+    ZM_HIP(hipMemsetAsync(boxflags, 0, sizeof(int) * (size_t)n, ctx->stream));
     for (int i = 0; i < n; ++i) {
         const int nx = ff[i].nx, ny = ff[i].ny;
         uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
@@ -312,7 +323,10 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             r.invmesh = ff[i].invmesh;
             rows.push_back(r);
         }
-        if (mbox) boxes.push_back(zm_boxjob{ff[i].mask, mbox, nx, ny, ff[i].mpitch, 0});
+        if (mbox) {
+            boxes.push_back(zm_boxjob{ff[i].mask, mbox, boxflags + i, nx, ny, ff[i].mpitch, 0});
+            ff[i].mboxflag = boxflags + i;
+        }
     }
     ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size(), boxes.data(), (int)boxes.size()));
     S->lds = lds;

@@ -1303,6 +1303,13 @@ __device__ __forceinline__ void zm_static_for(Fn&& fn) {
 #define FF_LDS_TAB ((LZ_FLOATS * 4 + 127) & ~127)
 // staged pixels per buffer: 2 x (8 + 2) B x cap + table + headers < 160 KB / workgroups per CU
 #define FF_LDS_CAP (FF_TALL ? 7800 : 3700)
+// the DMA-staged kernel (k_coadd_fused_dma below)
+#define FD_THREADS 512
+#define FD_YROWS 64                  // box rows the y table holds
+#define FD_YCOLS 2                   // mesh columns a box may span (BACK_SIZE >= FD_XCOLS)
+#define FD_XCOLS 96                  // box columns the x-weight table holds
+#define FD_XQ (FD_XCOLS / 4)          // ... as [pixel of the quad][quad column]: conflict-free b128 reads
+#define FD_LDS_CAP 3480              // staged pixels (a 64 x 32 tile at unit scale stages at most 80 x 43)
 
 struct ff_hdr {
     tile_hdr3 sub[FF_NSUB];          // the headers k_resample would build for the stacked tiles
@@ -1310,13 +1317,14 @@ struct ff_hdr {
     int use_lds, touches, fast;      // (edge item = use_lds && !fast)
     float vscale;                    // the frame's variance scale (a device scalar: fetched here, by the pre-pass)
     int sdx[FF_NSUB], sdy[FF_NSUB];  // sub-box origin minus union origin
-    int pad[FF_HDR_WORDS - 34 * FF_NSUB - 8 - 2 * FF_NSUB];
+    int frame_raw;                   // the frame's box-OR plane has entries that defer to the raw mask (pre-pass flag)
+    int pad[FF_HDR_WORDS - 34 * FF_NSUB - 9 - 2 * FF_NSUB];
 };
 static_assert(sizeof(ff_hdr) == FF_HDR_WORDS * 4, "ff_hdr is not its record");
 static_assert(3 * sizeof(ff_hdr) + 4 * 4 + 2 * 8 * 4 <= FF_LDS_HDR, "LDS header area too small");
 
 __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int lnx, int lny, int t, int ntx,
-                                       int onx, int ony, int lds_cap, ff_hdr* H) {
+                                       int onx, int ony, int lds_cap, int dma, ff_hdr* H) {
     constexpr int NT = 6, OFF = -2;
     const int tyi = t / ntx, txi = t - tyi * ntx;
     const zm_ff* F = fr + f;
@@ -1342,8 +1350,9 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         const int touches = (bx0 < nx) && (bx1 > 0) && (by0 < ny) && (by1 > 0);
         const long long area = (long long)bw * bh;
         // what the staging registers hold: FF_NSLOT rows per thread of a [512 / (bw / 4)] x [bw / 4] arrangement
-        const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bw <= 256 && bh >= 1 &&
-                            bh <= FF_NSLOT * (FF_THREADS / (bw >> 2));
+        // (the DMA-staged kernel: rows of the y table, columns of the x-weight table)
+        const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bh >= 1 &&
+                            (dma ? (bw <= FD_XCOLS && bh <= FD_YROWS) : (bw <= 256 && bh <= FF_NSLOT * (FF_THREADS / (bw >> 2))));
         const int inside = bx0 >= 0 && by0 >= 0 && bx1 <= nx && by1 <= ny && (txi + 1) * TW <= onx &&
                            (tyi + 1) * FT_H <= ony;
         H->bx0 = bx0; H->by0 = by0; H->bw = bw; H->bh = bh;
@@ -1353,6 +1362,7 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         // not fast): what lies off the frame becomes {0, BIGVAR} at the store.
         H->fast = use_lds && inside;
         H->vscale = F->vscale ? *F->vscale : 1.f;
+        H->frame_raw = F->mboxflag ? *F->mboxflag : 1;
 #pragma unroll
         for (int u = 0; u < FF_NSUB; ++u) {
             H->sdx[u] = H->sub[u].bx0 - bx0;
@@ -1513,7 +1523,7 @@ __device__ inline int32_t ff_mask_result(int32_t a) {       // k_mask_accum's co
 // fp64 loads and wave reductions: a pre-pass builds all of them, one wave per item; the
 // persistent kernel fetches a header two items ahead with one 4-byte load per lane.
 __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr, int nfr, int lnx, int lny,
-                                                    int onx, int ony, int lds_cap, int ntx, int ntiles,
+                                                    int onx, int ony, int lds_cap, int dma, int ntx, int ntiles,
                                                     int* __restrict__ out, int* __restrict__ tilectr, int ctr0) {
     __shared__ ff_hdr H[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) *tilectr = ctr0;     // k_coadd_fused's tile queue starts behind its first wave of tiles
@@ -1522,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr
     const bool live = item < (long long)ntiles * nfr;
     if (live) {
         const int t = (int)(item / nfr), f = (int)(item - (long long)t * nfr);
-        ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, &H[w]);
+        ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, dma, &H[w]);
     }
     __syncthreads();
     if (live) {
@@ -1583,7 +1593,9 @@ __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restr
             int32_t o = 0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) o |= h[(r + k) * TWB + c];
-            J.B[(size_t)y * J.pitch + x] = box_entry(o);
+            const uint16_t en = box_entry(o);
+            J.B[(size_t)y * J.pitch + x] = en;
+            if (en == ZM_BOX_RAW && J.rawflag) atomicOr(J.rawflag, 1);
         }
     }
 }
@@ -2223,9 +2235,520 @@ __global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
 #undef FF_TICK
 }
 
+// ===========================================================================
+// The same fused coadd with the staging done by the LDS-DMA engine (global_load_lds): the raw
+// planes of the next item go from HBM straight into LDS - no staging registers - and are prepped
+// LDS -> LDS behind the pixel phase.  Without the 56 staging registers and with four output
+// pixels per thread (one vertical group) a wave needs <= 128 registers: two workgroups of 512
+// threads per CU = FOUR waves per SIMD instead of two.  (The register-staged kernel above was
+// measured bound by vector issue at ~50 % utilisation: two waves per SIMD do not cover each
+// other's staging, barrier and LDS phases.)
+//
+// LDS per workgroup (80 KB): [headers][tap table][x weights of the box columns][y table: the y part of
+// the background per box row and mesh column][raw image quads][raw weight quads][box-OR tile x 2]
+// [prepped tile].  The DMA writes lane-linear (wave-uniform base + lane x 16 B), so the raw tiles
+// are the box in row-major quads; the per-lane SOURCE address carries the row / column split.
+// Per item: DMA of item i + 1 issued -> pixels of item i -> wait for the DMA, barrier -> prep
+// pass raw -> prepped tile (item i + 1) -> barrier.  Results: bit-identical to the register-staged
+// kernel and to k_resample (the same prep_pixel / bk_* functions, the same pixel group code).
+#define FD_OFF_XW (FF_LDS_HDR + FF_LDS_TAB)
+#define FD_OFF_YT (FD_OFF_XW + FD_XCOLS * 16)
+#define FD_OFF_RAW (FD_OFF_YT + FD_YCOLS * FD_YROWS * 16)
+static_assert(FD_OFF_RAW + 20 * FD_LDS_CAP + 4 * 8 * FD_YROWS <= 80 * 1024, "DMA-staged kernel: LDS budget of half a CU");
+
+__device__ inline void ff_glds16(const void ZM_GLOBAL* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int MOP, bool AVG, bool STACK>
+__global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
+    const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
+    const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
+    int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
+    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride,
+    int dbg, long long* __restrict__ prof) {
+    extern __shared__ float4 smem4[];
+    char* smem = reinterpret_cast<char*>(smem4);
+    ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem);                  // ring of 3 headers
+    int* tring = reinterpret_cast<int*>(smem + 3 * sizeof(ff_hdr));   // tiles held, by ordinal & 3
+    const float* ltab = reinterpret_cast<const float*>(smem + FF_LDS_HDR);
+    float4* XW = reinterpret_cast<float4*>(smem + FD_OFF_XW);       // per box column: {dx1, dx, cdx1, cdx}
+    float4* YT = reinterpret_cast<float4*>(smem + FD_OFF_YT);       // [mesh column][box row]
+    const int mcap = lds_cap + 8 * FD_YROWS;                        // box-OR tile: rows padded to 8 pixels
+    char* RAWI = smem + FD_OFF_RAW;
+    char* RAWW = RAWI + 4 * (size_t)lds_cap;
+    uint16_t* MSK0 = reinterpret_cast<uint16_t*>(RAWW + 4 * (size_t)lds_cap);
+    float2* PREP = reinterpret_cast<float2*>(reinterpret_cast<char*>(MSK0) + 4 * (size_t)mcap);
+    constexpr int NT = 6, OFF = -2, NW = FD_THREADS / 64, NPX = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- staging, part 1: the DMA of an item's raw planes (every wave takes chunks of 64 pieces of 16 B)
+    auto dma = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
+        if (!H->use_lds || (dbg & 4)) return;
+        const zm_ff* F = fr + f;
+        const int nx = F->nx, ny = F->ny, sp = F->spitch;
+        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        const int nq = bw4 * bh;
+        const bool prepped = F->src != nullptr;
+        const float ZM_GLOBAL* gI = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : zm_gptr(F->img);
+        const float ZM_GLOBAL* gW = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : (F->wgt ? zm_gptr(F->wgt) : zm_gptr(F->img));
+        const float inv4 = 1.0f / (float)bw4;
+#pragma unroll 1
+        for (int chunk = wv; chunk * 64 < nq; chunk += NW) {
+            const int p = chunk * 64 + lane;
+            if (p < nq) {
+                const int row = (int)(((float)p + 0.5f) * inv4), c = p - row * bw4;
+                const size_t gy = (size_t)min(max(by0 + row, 0), ny - 1);
+                const int gx = bx0 + 4 * c;
+                size_t oa, ob;
+                if (prepped) {
+                    oa = (gy * sp + min(max(gx, 0), sp - 2)) * 2;
+                    ob = (gy * sp + min(max(gx + 2, 0), sp - 2)) * 2;
+                } else {
+                    oa = ob = gy * nx + min(max(gx, 0), nx - 4);
+                }
+                ff_glds16(gI + oa, RAWI + (size_t)chunk * 1024);
+                ff_glds16(gW + ob, RAWW + (size_t)chunk * 1024);
+            }
+        }
+        if (MOP && F->mask) {
+            // the box-OR tile starts on a multiple of 8 pixels (16-byte pieces of a plane with such a pitch)
+            const int mx0 = bx0 & ~7, bwm8 = ((bx0 + bw - mx0) + 7) >> 3, nm = bwm8 * bh;
+            const float inv8 = 1.0f / (float)bwm8;
+            char* M = reinterpret_cast<char*>(MSK0) + (size_t)mb * 2 * mcap;
+#pragma unroll 1
+            for (int chunk = wv; chunk * 64 < nm; chunk += NW) {
+                const int p = chunk * 64 + lane;
+                if (p < nm) {
+                    const int row = (int)(((float)p + 0.5f) * inv8), c8 = p - row * bwm8;
+                    const size_t gy = (size_t)min(max(by0 + row, 0), ny - 1);
+                    const int gxm = min(max(mx0 + 8 * c8, 0), F->mpitch - 8);
+                    ff_glds16(zm_gptr(F->mbox) + (gy * F->mpitch + gxm), M + (size_t)chunk * 1024);
+                }
+            }
+        }
+        if (F->ytab && !prepped) {
+            // the y part of the background for the box rows, one table column per mesh column under the box
+            const int ia = bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1));
+            const int ib = bk_col(F->nbx, F->invmesh, min(max(bx0 + bw - 1, 0), nx - 1));
+            if (wv <= ib - ia && wv < FD_YCOLS && lane < bh) {
+                const size_t gy = (size_t)min(max(by0 + lane, 0), ny - 1);
+                ff_glds16(zm_gptr(F->ytab) + (gy * F->ytp + min(ia + wv, F->ytp - 1)),
+                          reinterpret_cast<char*>(YT) + (size_t)wv * FD_YROWS * 16);
+            }
+        }
+    };
+    // the x weights of the box columns of an item (threads 0 .. bw - 1), read by its prep pass
+    auto xweights = [&](const ff_hdr* H, int f) __attribute__((always_inline)) {
+        const zm_ff* F = fr + f;
+        if (!H->use_lds || !F->ytab || F->src) return;
+        if (tid < H->bw) {
+            const int gx = H->bx0 + tid;
+            const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), F->nx - 1));
+            XW[(tid & 3) * FD_XQ + (tid >> 2)] = bk_xweights(bk_dx(F->nbx, F->invmesh, gx, i0));
+        }
+    };
+    // ---- staging, part 2: raw quads -> prepped tile (background off, variance, bad pixels, fill)
+    auto prep_impl = [&](const ff_hdr* H, int f, int mb, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const zm_ff* F = fr + f;
+        const int nx = F->nx, ny = F->ny, sp = F->spitch;
+        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        const int nq = bw4 * bh;
+        const bool prepped = F->src != nullptr;
+        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr && !prepped;
+        const float vs = H->vscale, wth = F->wthresh;
+        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+        const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;   // (q + 0.5) / bw4 floors right for q < 2^12
+        const int ia = has_y ? bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1)) : 0;
+        // (straight-line: the LDS reads of both quads of a thread first, then the arithmetic; a lane without a
+        // second quad works on the last one again and does not store - a branch per quad serialises the round trips)
+        int qs[2], rows[2], cs[2];
+        float4 ra[2], rb[2], ry[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            qs[k] = min(tid + FD_THREADS * k, nq - 1);
+            rows[k] = (int)(((float)qs[k] + 0.5f) * inv4);
+            cs[k] = qs[k] - rows[k] * bw4;
+            ra[k] = reinterpret_cast<const float4*>(RAWI)[qs[k]];
+            rb[k] = reinterpret_cast<const float4*>(RAWW)[qs[k]];
+            if (has_y) {
+                const int gx = bx0 + 4 * cs[k];
+                const int yc = bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1)) - ia;
+                ry[k] = YT[min(max(yc, 0), FD_YCOLS - 1) * FD_YROWS + rows[k]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = rows[k], c = cs[k];
+            const int gx = bx0 + 4 * c;
+            const float4 a = ra[k], b = rb[k];
+            const bool rowok = FAST || (unsigned)(by0 + row) < (unsigned)ny;
+            float4 o0, o1;
+            if (prepped) {
+                const bool cpa = FAST || (gx >= 0 && gx <= sp - 2), cpb = FAST || (gx + 2 >= 0 && gx + 2 <= sp - 2);
+                o0 = (rowok && cpa) ? a : fill;
+                o1 = (rowok && cpb) ? b : fill;
+            } else {
+                const bool cok = FAST || (gx >= 0 && gx + 4 <= nx);
+                const float v[4] = {a.x, a.y, a.z, a.w}, w[4] = {b.x, b.y, b.z, b.w};
+                float2 p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bg = has_y ? bk_xpart(ry[k], XW[e * FD_XQ + c]) : 0.f;
+                    p[e] = prep_pixel(v[e], w[e], has_w, bg, vs, wth);
+                    if (!FAST) {
+                        const bool ok = rowok && cok;
+                        p[e].x = ok ? p[e].x : 0.f;
+                        p[e].y = ok ? p[e].y : ZM_BIGVAR;
+                    }
+                }
+                o0 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+                o1 = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
+            }
+            if (tid + FD_THREADS * k < nq) {
+                float4* d = reinterpret_cast<float4*>(PREP + (size_t)row * bw + 4 * c);
+                d[0] = o0;
+                d[1] = o1;
+            }
+        }
+    };
+    auto prep = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
+        if (!H->use_lds || (dbg & 2)) return;
+        if (H->fast) prep_impl(H, f, mb, std::true_type{});
+        else prep_impl(H, f, mb, std::false_type{});
+    };
+    const int nty = ntiles / ntx;
+    // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
+    auto tile_of = [&](int s) -> int {
+        if (s >= ntiles) return s;
+        const int r = s / ntx, c = s - r * ntx;
+        return (r == 0 ? 0 : r == 1 ? nty - 1 : r - 1) * ntx + c;
+    };
+    auto next_item = [&](int& tt, int& ff, int& kk) {
+        if (++ff == nfr) { ff = 0; ++kk; tt = tring[kk & 3]; }
+    };
+    auto hdr_word = [&](int tt, int ff) -> int {          // this thread's word of the header of item (tt, ff)
+        return tid < FF_HDR_WORDS ? ghdr[((size_t)tt * nfr + ff) * FF_HDR_WORDS + tid] : 0;
+    };
+    auto hdr_put = [&](int sl, int wd) {
+        if (tid < FF_HDR_WORDS) reinterpret_cast<int*>(&HR[sl])[tid] = wd;
+    };
+
+    if ((int)blockIdx.x >= ntiles) return;
+    int t0 = tile_of(blockIdx.x), f0 = 0, k2 = 0;
+    for (int e = tid; e < LZ_FLOATS / 4; e += FD_THREADS)
+        reinterpret_cast<float4*>(smem + FF_LDS_HDR)[e] = reinterpret_cast<const float4*>(taptab)[e];
+    if (tid == 0) {
+        // stacks of one or two frames look two items = up to two tiles ahead
+        tring[0] = t0;
+        if (nfr <= 2) tring[1] = tile_of(atomicAdd(tilectr, 1));
+        if (nfr == 1) tring[2] = tile_of(atomicAdd(tilectr, 1));
+    }
+    __syncthreads();
+    int t1 = t0, f1 = f0;
+    next_item(t1, f1, k2);
+    int t2 = t1, f2 = f1;
+    next_item(t2, f2, k2);
+    hdr_put(0, hdr_word(t0, f0));
+    if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
+    __syncthreads();
+    dma(&HR[0], f0, 0);
+    xweights(&HR[0], f0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    prep(&HR[0], f0, 0);
+    __syncthreads();
+
+    // ---- this thread's pixels: column tx, rows 4 wv .. 4 wv + 3 of the 64 x 32 tile (one group)
+    const int tx = lane;
+    const int cr = wv >> 2;
+    const int cell = tx >> 4;
+    const float fx = (float)(tx & 15) * (1.f / LSTEP);
+    const float fyb = (float)((4 * wv) & 15) * (1.f / LSTEP);
+    float S1[NPX], S0[NPX], SW[NPX];
+    int32_t MK[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
+
+    // STACK: the samples of item (pt, pfr), held in S1 / S0, to plane pfr of the stack
+    int pt = -1, pfr = 0;
+    auto flush = [&]() {
+        if (pt < 0) return;
+        const int ptyi = pt / ntx, ptxi = pt - ptyi * ntx;
+        const int pox = ptxi * TW + tx, poy0 = ptyi * RTH + wv * NPX;
+        float2* plane = stack + (size_t)pfr * (size_t)fstride;
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            const int oy = poy0 + q;
+            if (pox < onx && oy < ony)
+                __builtin_nontemporal_store((zm_v2f){S1[q], S0[q]}, reinterpret_cast<zm_v2f*>(plane + (size_t)oy * onx + pox));
+        }
+    };
+    long long ptk[5] = {0, 0, 0, 0, 0}, tc = 0;      // developer (ZM_FF_PROF=1): shader-clock sums per phase of this wave
+#define FD_TICK(k) do { if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
+    if (prof) tc = __builtin_amdgcn_s_memtime();
+    int slot = 0, buf = 0;
+    for (;;) {
+        const ff_hdr* H = &HR[slot];
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        const int nnslot = nslot == 2 ? 0 : nslot + 1;
+        const zm_ff* F = fr + f0;
+        const bool use_lds = H->use_lds, touches = H->touches, fast = H->fast;
+        const tile_hdr3* SH = &H->sub[0];
+        const int bw = H->bw;
+        const int sbx0 = SH->bx0, sby0 = SH->by0;
+        const int mx0 = sbx0 & ~7, bwm = (((sbx0 + bw - mx0) + 7) >> 3) << 3;      // box-OR tile: origin, pitch
+        const uint16_t* mtile = MSK0 + (size_t)buf * mcap;
+        const int tyi = t0 / ntx, txi = t0 - tyi * ntx;
+        const int ox0 = txi * TW, oy0 = tyi * RTH + wv * NPX;
+        const int ox = ox0 + tx;
+        if (STACK) {
+            flush();
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; }
+            pt = t0;
+            pfr = f0;
+        }
+        int hw2 = 0;
+        if (t2 < ntiles) hw2 = hdr_word(t2, f2);
+        const bool grab = f2 == nfr - 1;
+        int gnext = 0;
+        if (grab && tid == 0) gnext = atomicAdd(tilectr, 1);
+        const bool more = t1 < ntiles;
+        // the raw planes of the next item: DMA into the raw tiles (free since the last barrier), its
+        // box-OR tile into the other mask buffer; its x weights
+        if (more) {
+            dma(&HR[nslot], f1, buf ^ 1);
+            xweights(&HR[nslot], f1);
+        }
+        FD_TICK(0);
+
+        const bool do_px = touches && !(dbg & 1);
+        {
+            // x part of the bilinear lattice interpolation, once per item (k_resample's operations)
+            const float x0a = SH->nrel[cr][cell][0], x1a = SH->nrel[cr][cell + 1][0];
+            const float y0a = SH->nrel[cr][cell][1], y1a = SH->nrel[cr][cell + 1][1];
+            const float x0b = SH->nrel[cr + 1][cell][0], x1b = SH->nrel[cr + 1][cell + 1][0];
+            const float y0b = SH->nrel[cr + 1][cell][1], y1b = SH->nrel[cr + 1][cell + 1][1];
+            const float xa = __builtin_fmaf(fx, x1a - x0a, x0a), ya = __builtin_fmaf(fx, y1a - y0a, y0a);
+            const float xb = __builtin_fmaf(fx, x1b - x0b, x0b), yb = __builtin_fmaf(fx, y1b - y0b, y0b);
+            const float xd = xb - xa, yd = yb - ya;
+            const bool with_mask = MOP && F->mask != nullptr;
+            unsigned slow = !do_px ? 0u : use_lds ? 0u : 0xfu;
+            // (does the frame's box-OR plane hold entries that defer to the raw mask - bits above 15?  A flag of
+            // the box pre-pass, carried by the header: science masks never do, the pixel loop then has no vote)
+            const bool any_raw = MOP && with_mask && use_lds && H->frame_raw != 0;
+            const float fscale = F->fscale, fscale2 = F->fscale2;
+            const float2* tbase = PREP + (OFF * bw + OFF);
+            const uint16_t* mbase = mtile + (OFF * bwm + OFF + (sbx0 - mx0));
+            const int enx = F->nx, eny = F->ny;
+            // the four vertically adjacent pixels of this thread out of one 9 x 6 window
+            auto group = [&](auto edge_tag) __attribute__((always_inline)) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
+                float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
+                bool shape = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float fy = fyb;
+                    asm volatile("" : "+v"(fy));
+                    fy += (float)j * (1.f / LSTEP);
+                    const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
+                    const float fxf = floorf(px), fyf = floorf(py);
+                    const float dx = px - fxf, dy = py - fyf;
+                    dxs[j] = dx;
+                    dys[j] = dy;
+                    if (j == 0) { fxf0 = fxf; fyf0 = fyf; }
+                    const float edge = fminf(fminf(dx, 1.f - dx), fminf(dy, 1.f - dy));
+                    shape = shape && !(edge < ZM_SNAP) && fxf == fxf0 && fyf == fyf0 + (float)j;
+                }
+                if (!__all(shape)) {
+                    slow |= 0xfu;
+                    return;
+                }
+                const int ix0 = (int)fxf0, iy0 = (int)fyf0;
+                const int lo = iy0 * bw + ix0;
+                const float2* p = tbase + lo;
+                unsigned inbm = 0xfu;
+                if (EDGE && MOP) {
+                    const int ix = sbx0 + OFF + ix0, iy = sby0 + OFF + iy0;
+                    const bool xin = ix >= 0 && ix + NT <= enx && ox < onx;
+                    inbm = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        inbm |= (xin && iy + j >= 0 && iy + j + NT <= eny && oy0 + j < ony) ? (1u << j) : 0u;
+                }
+                int32_t mterm[4] = {-1, -1, -1, -1};
+                if (MOP) {
+                    const int lom = iy0 * bwm + ix0;
+                    uint32_t m16[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m16[j] = mbase[lom + j * bwm];
+                    if (any_raw) {
+                        bool defer = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) defer |= m16[j] == ZM_BOX_RAW && ((inbm >> j) & 1u);
+                        if (__any(defer)) {
+                            slow |= 0xfu;
+                            return;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t t = ff_mask_term<MOP>((int32_t)m16[j]);
+                        mterm[j] = (with_mask && ((inbm >> j) & 1u)) ? t : -1;
+                    }
+                }
+                zm_v2f txp[4][3], typ[4][3];
+                {
+                    // (one tap-table node in flight: four waves per SIMD cover the round trip, and a second
+                    // node buffer would not fit the 128 registers)
+                    lz3_node nd;
+                    float dl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        lz3_issue(ltab, (i & 1) ? dys[i >> 1] : dxs[i >> 1], nd, dl);
+                        lz3_wait<0>(nd);
+                        if (i & 1) lz3_eval(nd, dl, typ[i >> 1]);
+                        else lz3_eval(nd, dl, txp[i >> 1]);
+                    }
+                }
+                zm_v2f av[4];
+                lds_row6 ra, rb;
+                lds_issue6(p, ra);
+#pragma unroll
+                for (int rho = 0; rho < NT + 3; ++rho) {
+                    lds_row6& cur = (rho & 1) ? rb : ra;
+                    lds_row6& nxt = (rho & 1) ? ra : rb;
+                    if (rho + 1 < NT + 3) {
+                        lds_issue6(p + (rho + 1) * bw, nxt);
+                        lds_wait_n<6>(cur);
+                    } else {
+                        lds_wait_n<0>(cur);
+                    }
+                    const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rho - j;
+                        if (r < 0 || r >= NT) continue;
+                        zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) {
+                            const float tc = (c & 1) ? txp[j][c >> 1].y : txp[j][c >> 1].x;
+                            rv2 = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rv2);
+                        }
+                        const float tr = (r & 1) ? typ[j][r >> 1].y : typ[j][r >> 1].x;
+                        av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float acc = av[j].x, vacc = av[j].y;
+                    const bool ok = vacc > 0.f && vacc < ZM_BADVAR_TEST;
+                    const float v = ok ? acc * fscale : 0.f;
+                    const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
+                    const float ww = AVG ? (w > 0.f ? 1.f : 0.f) : w;
+                    if (STACK) {
+                        S1[j] = v;
+                        S0[j] = w;
+                    } else {
+                        S1[j] = fmaf(ww, v, S1[j]);
+                        S0[j] += ww;
+                    }
+                    if (AVG) SW[j] += w;
+                    if (MOP) MK[j] &= mterm[j];
+                }
+            };
+            if (do_px) {
+                if (fast) group(std::false_type{});
+                else if (use_lds) group(std::true_type{});
+            }
+            // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
+#pragma unroll 1
+            while (slow) {
+                const int q = __builtin_ctz(slow);
+                slow &= slow - 1;
+                const int oy = oy0 + q;
+                if (ox >= onx || oy >= ony) continue;
+                const float fy = fyb + (float)q * (1.f / LSTEP);
+                const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
+                const ff_px r = ff_generic_pixel<MOP>(F, PREP, ltab, use_lds, touches, sbx0, sby0, bw, px, py);
+                const float ww = AVG ? (r.w > 0.f ? 1.f : 0.f) : r.w;
+#pragma unroll
+                for (int k = 0; k < NPX; ++k) {
+                    const bool me = (k == q);
+                    S1[k] = me ? (STACK ? r.v : fmaf(ww, r.v, S1[k])) : S1[k];
+                    S0[k] = me ? (STACK ? r.w : S0[k] + ww) : S0[k];
+                    if (AVG) SW[k] = me ? SW[k] + r.w : SW[k];
+                    if (MOP) MK[k] = (me && with_mask && r.inb) ? ff_mask_fold<MOP>(MK[k], r.m) : MK[k];
+                }
+            }
+        }
+
+        if (f0 == nfr - 1) {
+            // the tile is complete: coadd (or partial sums) and mask coadd, once
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) {
+                const int oy = oy0 + q;
+                if (ox < onx && oy < ony) {
+                    const size_t o = (size_t)oy * onx + ox;
+                    const float s1 = S1[q], s0 = S0[q];
+                    if (STACK) {
+                    } else if (partial) {
+                        out_img[o] = s1;
+                        out_wgt[o] = s0;
+                    } else {
+                        out_img[o] = s0 > 0.f ? s1 / s0 : 0.f;
+                        out_wgt[o] = AVG ? SW[q] : s0;
+                    }
+                    if (MOP) {
+                        const int32_t a = ff_mask_result<MOP>(MK[q]);
+                        if (partial) {
+                            out_mask[o] = a;
+                        } else {
+                            out_mask[o] = a == -1 ? 0 : a;
+                            if (out_cov) out_cov[o] = a == -1 ? 0.f : 1.f;
+                        }
+                    }
+                }
+                if (!STACK) { S1[q] = 0.f; S0[q] = 0.f; }
+                SW[q] = 0.f; MK[q] = -1;
+            }
+        }
+        FD_TICK(1);
+        // every wave is through with the prepped tile, and every DMA of the next item has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FD_TICK(2);
+        __syncthreads();
+        FD_TICK(3);
+        if (more) prep(&HR[nslot], f1, buf ^ 1);
+        if (t2 < ntiles) hdr_put(nnslot, hw2);
+        if (grab && tid == 0) tring[(k2 + 1) & 3] = tile_of(gnext);
+        FD_TICK(4);
+        __syncthreads();
+        if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[3] += t_ - tc; tc = t_; }
+        t0 = t1; f0 = f1;
+        t1 = t2; f1 = f2;
+        next_item(t2, f2, k2);
+        slot = nslot;
+        buf ^= 1;
+        if (t0 >= ntiles) break;
+    }
+    if (STACK) flush();
+    if (prof && lane == 0)
+        for (int k = 0; k < 5; ++k) prof[((size_t)blockIdx.x * NW + wv) * 5 + k] = ptk[k];
+#undef FD_TICK
+}
+
+// ZM_FF_DMA=0: the register-staged kernel (developer: A / B); default: the DMA-staged one
+static bool ff_use_dma() {
+    const char* e = getenv("ZM_FF_DMA");
+    return !(e && e[0] == '0') && FF_TALL == 0;
+}
 void zm_fused_geometry(int* tile_h, int* lds_cap) {
     *tile_h = FT_H;
-    *lds_cap = FF_LDS_CAP;
+    *lds_cap = ff_use_dma() ? FD_LDS_CAP : FF_LDS_CAP;
 }
 
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
@@ -2240,9 +2763,11 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         ZM_HIP(hipMemsetAsync(unmasked_out, partial ? 0xFF : 0, sizeof(int32_t) * opix, ctx->stream));
         if (!partial && out_cov) ZM_HIP(hipMemsetAsync(out_cov, 0, sizeof(float) * opix, ctx->stream));
     }
-    lds_elems = std::min(std::max(lds_elems, 64), FF_LDS_CAP);
+    const bool use_dma = ff_use_dma();
+    lds_elems = std::min(std::max(lds_elems, 64), use_dma ? FD_LDS_CAP : FF_LDS_CAP);
     lds_elems = (lds_elems + 7) & ~7;
-    const size_t shmem = (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)lds_elems * (sizeof(float2) + sizeof(uint16_t));
+    const size_t shmem = use_dma ? (size_t)FD_OFF_RAW + 20 * (size_t)lds_elems + 4 * 8 * FD_YROWS
+                                 : (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)lds_elems * (sizeof(float2) + sizeof(uint16_t));
     ZM_CHECK(shmem <= 160 * 1024 / FF_WG_PER_CU, "zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
     const float* taptab = nullptr;
     ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
@@ -2271,16 +2796,28 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     const int dbg = getenv("ZM_FF_DBG") ? atoi(getenv("ZM_FF_DBG")) : 0;
     long long* prof = nullptr;
     const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
-    const int nwv = FF_THREADS / 64;
+    const int nwv = (use_dma ? FD_THREADS : FF_THREADS) / 64;
     if (want_prof) ZM_TRY(ctx->get("ff_prof", sizeof(long long) * 5 * nwv * (size_t)G, (void**)&prof));
     zm_scope_timer t(ctx, "coadd_fused");
     {
         const long long items = (long long)ntiles * nfr;
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
-                           lnx, lny, onx, ony, lds_elems, ntx, ntiles, ghdr, tilectr, G);
+                           lnx, lny, onx, ony, lds_elems, use_dma ? 1 : 0, ntx, ntiles, ghdr, tilectr, G);
     }
 #define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
     do {                                                                                                       \
+        if (use_dma) {                                                                                         \
+            auto kd = k_coadd_fused_dma<MOPV, AVGV, STACKV>;                                                   \
+            static bool dattr[64] = {};                                                                        \
+            if (!dattr[ctx->device & 63]) {                                                                    \
+                ZM_HIP(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+                dattr[ctx->device & 63] = true;                                                                \
+            }                                                                                                  \
+            hipLaunchKernelGGL(kd, dim3(G), dim3(FD_THREADS), shmem, ctx->stream, dev, nfr, onx, ony, lds_elems, \
+                               ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, taptab, tilectr, \
+                               stack, (long long)fstride, dbg, prof);                                          \
+            break;                                                                                             \
+        }                                                                                                      \
         auto kfn = k_coadd_fused<MOPV, AVGV, STACKV>;                                                          \
         static bool attr_set[64] = {};                                                                         \
         if (!attr_set[ctx->device & 63]) {                                                                     \
@@ -2305,12 +2842,14 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         std::vector<long long> h((size_t)5 * nwv * G);
         ZM_HIP(hipMemcpyAsync(h.data(), prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         ZM_HIP(hipStreamSynchronize(ctx->stream));
-        static const char* nm[5] = {"issue", "pixels", "loadwait", "store", "barrier"};
+        static const char* nm0[5] = {"issue", "pixels", "loadwait", "store", "barrier"};
+        static const char* nm1[5] = {"dma issue", "pixels", "dma wait", "barriers", "prep"};
+        const char** nm = use_dma ? nm1 : nm0;
         double sum[5] = {0, 0, 0, 0, 0};
         for (size_t w = 0; w < (size_t)nwv * G; ++w)
             for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 5 + k];
-        fprintf(stderr, "k_coadd_fused phases, mean per wave (s_memtime ticks of 10 ns):");
-        for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f us", nm[k], sum[k] / ((double)nwv * G) * 0.01);
+        fprintf(stderr, "k_coadd_fused phases, mean per wave (kilo-cycles of the shader clock):");
+        for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f", nm[k], sum[k] / ((double)nwv * G) * 1e-3);
         fprintf(stderr, "\n");
     }
     return 0;

@@ -127,6 +127,7 @@ struct zm_ff {                       // one input frame of a fused coadd (device
     const int32_t* mask;             // raw mask or NULL
     const uint16_t* mbox;            // box-OR plane of the mask
     const float* bk;                 // spline nodes (4 planes [nby][nbx]) or NULL: the per-tap path of the generic code
+    const int* mboxflag;             // device word: != 0 when the box-OR plane holds ZM_BOX_RAW entries (NULL: assume so)
     int nx, ny, spitch, nbx, nby, ytp;
     float invmesh, wthresh, fscale, fscale2;
     int vec_ok, mpitch;              // mpitch: pixels per row of the box-OR plane (a multiple of 4)
@@ -142,6 +143,7 @@ struct zm_bkrows {
 struct zm_boxjob {
     const int32_t* m;
     uint16_t* B;
+    int* rawflag;                    // set when an entry defers to the raw mask (or NULL)
     int nx, ny, pitch, pad;
 };
 // the fused coadd's tile rows and LDS capacity in staged pixels (resample.hip: FT_H, FF_LDS_CAP)
