@@ -2364,10 +2364,13 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         const int ia = has_y ? bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1)) : 0;
         // (straight-line: the LDS reads of both quads of a thread first, then the arithmetic; a lane without a
         // second quad works on the last one again and does not store - a branch per quad serialises the round trips)
+        // (the second quad exists for the first waves only: a wave-uniform count)
+        const int nk = (FD_THREADS + 64 * wv < nq) ? 2 : 1;
         int qs[2], rows[2], cs[2];
         float4 ra[2], rb[2], ry[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if (k >= nk) break;
             qs[k] = min(tid + FD_THREADS * k, nq - 1);
             rows[k] = (int)(((float)qs[k] + 0.5f) * inv4);
             cs[k] = qs[k] - rows[k] * bw4;
@@ -2381,6 +2384,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if (k >= nk) break;
             const int row = rows[k], c = cs[k];
             const int gx = bx0 + 4 * c;
             const float4 a = ra[k], b = rb[k];
@@ -2545,8 +2549,9 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
             const uint16_t* mbase = mtile + (OFF * bwm + OFF + (sbx0 - mx0));
             const int enx = F->nx, eny = F->ny;
             // the four vertically adjacent pixels of this thread out of one 9 x 6 window
-            auto group = [&](auto edge_tag) __attribute__((always_inline)) {
-                constexpr bool EDGE = decltype(edge_tag)::value;
+            // (one instantiation: two - fast / edge - end in a join where every accumulator is copied)
+            const bool EDGE = !fast;
+            auto group = [&]() __attribute__((always_inline)) {
                 float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
                 bool shape = true;
 #pragma unroll
@@ -2660,10 +2665,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                     if (MOP) MK[j] &= mterm[j];
                 }
             };
-            if (do_px) {
-                if (fast) group(std::false_type{});
-                else if (use_lds) group(std::true_type{});
-            }
+            if (do_px && use_lds) group();
             // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
 #pragma unroll 1
             while (slow) {
