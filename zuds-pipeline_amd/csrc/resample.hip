@@ -1671,7 +1671,8 @@ struct lz3_node {
 __device__ inline void lz3_issue(const float* tab, float d, lz3_node& n, float& dl) {
     const float fi = __builtin_rintf(d * (float)LZ_N);
     dl = __builtin_fmaf(fi, -1.0f / LZ_N, d);
-    const unsigned a = (unsigned)(size_t)tab + (unsigned)((int)fi * (LZ_ENTRY * 4));
+    // (a 24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate)
+    const unsigned a = (unsigned)(size_t)tab + (unsigned)__mul24((int)fi, LZ_ENTRY * 4);
     asm volatile("ds_read_b128 %0, %5\n\t"
                  "ds_read_b128 %1, %5 offset:16\n\t"
                  "ds_read_b128 %2, %5 offset:32\n\t"
@@ -2293,7 +2294,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         const bool prepped = F->src != nullptr;
         const float ZM_GLOBAL* gI = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : zm_gptr(F->img);
         const float ZM_GLOBAL* gW = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : (F->wgt ? zm_gptr(F->wgt) : zm_gptr(F->img));
-        const float inv4 = 1.0f / (float)bw4;
+        const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;   // (p + 0.5) / bw4 floors right for p < 2^12
 #pragma unroll 1
         for (int chunk = wv; chunk * 64 < nq; chunk += NW) {
             const int p = chunk * 64 + lane;
@@ -2315,7 +2316,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         if (MOP && F->mask) {
             // the box-OR tile starts on a multiple of 8 pixels (16-byte pieces of a plane with such a pitch)
             const int mx0 = bx0 & ~7, bwm8 = ((bx0 + bw - mx0) + 7) >> 3, nm = bwm8 * bh;
-            const float inv8 = 1.0f / (float)bwm8;
+            const float inv8 = __builtin_amdgcn_rcpf((float)bwm8) * 1.0000002f;
             char* M = reinterpret_cast<char*>(MSK0) + (size_t)mb * 2 * mcap;
 #pragma unroll 1
             for (int chunk = wv; chunk * 64 < nm; chunk += NW) {
@@ -2573,7 +2574,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                     return;
                 }
                 const int ix0 = (int)fxf0, iy0 = (int)fyf0;
-                const int lo = iy0 * bw + ix0;
+                const int lo = __mul24(iy0, bw) + ix0;
                 const float2* p = tbase + lo;
                 unsigned inbm = 0xfu;
                 if (EDGE && MOP) {
@@ -2586,7 +2587,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                 }
                 int32_t mterm[4] = {-1, -1, -1, -1};
                 if (MOP) {
-                    const int lom = iy0 * bwm + ix0;
+                    const int lom = __mul24(iy0, bwm) + ix0;
                     uint32_t m16[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m16[j] = mbase[lom + j * bwm];
