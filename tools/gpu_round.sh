@@ -8,7 +8,7 @@ tag=${1:-round}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="bench.py --steps 5 --warmup 2 --no-clocks --no-cpu-baseline --no-secondary --no-nightly"
+B="bench.py --steps 20 --warmup 2 --no-clocks --no-cpu-baseline --no-secondary --no-nightly --no-pipelined"
 if [ "${2:-tests}" = tests ]; then
     timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
     tail -2 $out/tests.log

@@ -36,11 +36,12 @@ def main(src, out):
         m = re.match(r'(k_coadd_fused\S*)\s+(\S+)\s+mean\s+([0-9.]+)', line)
         if m:
             pm[m.group(2)] = float(m.group(3))
-    avg_us = None
+    avg_us = med_us = None
     with open(os.path.join(src, 'kernel_stats.csv')) as f:
         for r in csv.DictReader(f):
             if 'k_coadd_fused' in r['Name']:
                 avg_us = float(r['AverageNs']) / 1e3
+                med_us = float(r.get('MedianNs') or 0) / 1e3
                 break
     bench = json.loads([l for l in open(os.path.join(src, 'bench.json')) if l.startswith('{')][-1])
     size, frames = bench['config']['size'], bench['config']['frames_per_gpu']
@@ -65,7 +66,7 @@ def main(src, out):
                  'MI355X_MICROARCH.md HBM section); WRITE_SIZE as is',
         'size': size, 'frames': frames, 'mask': True,
         'kernel': 'k_coadd_fused<LANCZOS3, mask coadd>',
-        'avg_duration_us_kernel_trace': avg_us,
+        'avg_duration_us_kernel_trace': avg_us, 'median_duration_us_kernel_trace': med_us,
         'FETCH_SIZE_KiB': pm['FETCH_SIZE'], 'WRITE_SIZE_KiB': pm['WRITE_SIZE'],
         'hbm_bytes_per_launch': int(fetch + write),
         'algorithmic_bytes_per_launch': (frames * 12 + 12) * npx,
