@@ -58,7 +58,10 @@ def parse():
     ap.add_argument('--no-clocks', action='store_true', help='skip the PCIe / FITS clocks')
     ap.add_argument('--no-nightly', action='store_true', help='skip the concurrent-subtraction leg')
     ap.add_argument('--no-pipelined', action='store_true', help='skip the software-pipelined rate')
-    ap.add_argument('--nightly-jobs', type=int, default=16, help='subtractions of the concurrent leg')
+    ap.add_argument('--pipelined-share', type=int, default=1, help='developer: zm_ctx_set_share of the subtraction contexts')
+    ap.add_argument('--pipelined-depth', type=int, default=4, help='subtractions in flight in the pipelined leg')
+    ap.add_argument('--nightly-jobs', type=int, default=24, help='subtractions of the concurrent leg')
+    ap.add_argument('--nightly-pools', default='1,2,3,4,8,12', help='jobs in flight to time in the concurrent leg')
     ap.add_argument('--dump-coadd', default=None,
                     help='developer / tests: rank 0 saves the coadd planes [img, wgt] (.npy) after the run')
     ap.add_argument('--emulate-ranks', type=int, default=1,
@@ -622,30 +625,39 @@ def main():
 
 def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local):
     """The same step with consecutive steps software-pipelined, reported beside `value`, never as
-    it: the subtraction of step k (its own context and stream) runs while the coadd of step k + 1
-    is computed - step k + 1's coadd does not depend on step k's subtraction (another field, another
-    quadrant: BASELINE config 5).  Every step still makes one full coadd and one full subtraction
-    against THAT coadd (its products are snapshotted into one of two buffer sets; events order the
-    streams).  What it buys: the coadd kernels fill the CUs that the latency-bound kernel fit of
-    the subtraction leaves idle."""
+    it: the subtractions of steps k, k - 1, ... (D contexts, each with its own stream and host
+    thread) run while the coadd of step k + 1 is computed - step k + 1's coadd does not depend on
+    step k's subtraction (another field, another quadrant: BASELINE config 5).  Every step still
+    makes one full coadd and one full subtraction against THAT coadd (its products are snapshotted
+    into one of D + 1 buffer sets; events order the streams).  With D >= 2 the subtraction contexts
+    use the one-workgroup-per-region form of the kernel fit's factorisation (zm_ctx_set_share), which
+    leaves the CUs to the coadd kernels; D = 1 keeps the many-workgroup form."""
+    from concurrent.futures import ThreadPoolExecutor
     check = z._lib.check
-    eng_s = z.Engine(local)
+    D = max(1, args.pipelined_depth)
     L = eng.L
     big = float(np.sqrt(50000.0))
     A = coadd.stream
+    engs, subs = [], []
+    pool = ThreadPoolExecutor(max_workers=D)
     try:
-        sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng_s)
-        B = sub.stream
+        for _ in range(D):
+            e = z.Engine(local)
+            e.set_share(max(args.pipelined_share, D))
+            engs.append(e)
+            subs.append(dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=e))
+        nset = D + 1
         snap = [dict(img=torch.empty_like(coadd.img), rms=torch.empty_like(coadd.img),
                      mask=torch.empty((args.size, args.size), dtype=torch.int32, device=coadd.img.device))
-                for _ in range(2)]
-        ready = [torch.cuda.Event() for _ in range(2)]
-        freed = [None, None]
+                for _ in range(nset)]
+        ready = [torch.cuda.Event() for _ in range(nset)]
+        freed = [None] * nset
+        futs = {}
 
         def enqueue_coadd(k):
-            s = snap[k & 1]
-            if freed[k & 1] is not None:
-                A.wait_event(freed[k & 1])           # the subtraction that read this buffer set is done
+            s = snap[k % nset]
+            if freed[k % nset] is not None:
+                A.wait_event(freed[k % nset])        # the subtraction that read this buffer set is done
             coadd.run(dframes)
             with torch.cuda.stream(A):
                 if coadd.mask is not None:
@@ -656,43 +668,56 @@ def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_ma
                 check(L.zm_add_scalar_dev(eng.ctx, coadd.img.data_ptr(), 150.0, npx))
                 check(L.zm_rms_from_weight_dev(eng.ctx, coadd.wgt.data_ptr(), None, npx, big, s['rms'].data_ptr()))
                 s['img'].copy_(coadd.img)
-                ready[k & 1].record(A)
+                ready[k % nset].record(A)
 
         def subtract(k):
-            s = snap[k & 1]
-            B.wait_event(ready[k & 1])
+            torch.cuda.set_device(local)
+            s, sub = snap[k % nset], subs[k % D]
+            sub.stream.wait_event(ready[k % nset])
             sub.run(sci['img'], sci['rms'], sci['mask'], sci['wgt'], s['img'], s['rms'], s['mask'],
                     seeing=args.seeing, nreg_side=3)
             ev = torch.cuda.Event()
-            ev.record(B)
-            freed[k & 1] = ev
+            ev.record(sub.stream)
+            freed[k % nset] = ev
+            return sub.info.status
 
-        state = {'k': 0}
+        state = {'k': 0, 'bad': 0}
         enqueue_coadd(0)
 
         def pstep():
             k = state['k']
+            if k - D in futs:                         # context k % D is free again
+                state['bad'] += futs.pop(k - D).result() != 0
             enqueue_coadd(k + 1)
-            subtract(k)
+            futs[k] = pool.submit(subtract, k)
             state['k'] = k + 1
 
-        for _ in range(4):
+        def drain():
+            for k in sorted(futs):
+                state['bad'] += futs.pop(k).result() != 0
+            torch.cuda.synchronize()
+
+        for _ in range(3 + D):
             pstep()
-        torch.cuda.synchronize()
+        drain()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pstep()
-        torch.cuda.synchronize()
+        drain()
         dt = time.perf_counter() - t0
-        ok = sub.info.status == 0
-        del sub
+        ok = state['bad'] == 0
+        subs.clear()
     finally:
+        pool.shutdown(wait=True)
         eng.set_stream(A.cuda_stream)
-        eng_s.close()
+        for e in engs:
+            e.close()
     return {'ms_per_step': 1e3 * dt / args.steps,
             'mpix_s': (args.frames + 1) * npx / 1e6 * args.steps / dt, 'steps': args.steps, 'status_ok': ok,
-            'what': 'steps software-pipelined: subtraction of step k beside the coadd of step k + 1 (two streams, '
-                    'two sets of coadd products); one full coadd and one full subtraction against it per step'}
+            'subtractions_in_flight': D,
+            'what': 'steps software-pipelined: the subtractions of steps k, k - 1, ... beside the coadd of step k + 1 '
+                    '(one stream, context and host thread per subtraction in flight, D + 1 sets of coadd products); '
+                    'one full coadd and one full subtraction against it per step'}
 
 
 def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local):
@@ -726,7 +751,7 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
         sci = dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=args.seeing)
         jobs.append(nm.SubtractionJob(sci, ref, radec=(ra, dec), nreg_side=3))
     out = {'jobs': njobs, 'photometry_positions': 500, 'pools': {}}
-    for J in (1, 2, 3, 4):
+    for J in [int(v) for v in args.nightly_pools.split(',')]:
         if J > njobs:
             continue
         pool = nm.SubtractionPool(J, device=local)

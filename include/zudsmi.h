@@ -61,9 +61,10 @@ int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream);
 int zm_ctx_synchronize(zm_ctx* ctx);
 /* Several contexts (one host thread each) may subtract on one GPU at the same time - the
  * reference runs 64 independent `hotpants` processes per node (nersc/controller.py:101,
- * scripts/donightly.py:21-40).  The kernel-fit solver keeps every workgroup of a launch
- * resident behind in-kernel barriers; declaring the number of concurrent contexts lets each
- * size its launches to 1 / nctx of the GPU.  Results do not depend on the share. */
+ * scripts/donightly.py:21-40).  The kernel-fit solver of a context that has the GPU to itself
+ * (nctx = 1, the default) keeps ~230 workgroups resident behind in-kernel barriers - the short
+ * form; declaring nctx >= 2 (1 .. 64) switches the context to the one-workgroup-per-region
+ * form, which claims nothing (k_chol_tp).  Results do not depend on the share: same bits. */
 int zm_ctx_set_share(zm_ctx* ctx, int nctx);
 const char* zm_last_error(void);
 const char* zm_version(void);

@@ -67,8 +67,8 @@ def test_pool_of_four_equals_one_at_a_time(engine):
 
 
 def test_pool_at_the_reference_parameters(engine):
-    """3 x 3 regions, ko = 4 (722 unknowns per region): the configuration whose solver launch
-    shares the CUs between the concurrent jobs."""
+    """3 x 3 regions, ko = 4 (722 unknowns per region).  A lone job factors on the many-workgroup form
+    of the solver, the jobs of a pool on the one-workgroup-per-region form: same bits."""
     import torch
     z, s = pkg(), synth()
     nm = importlib.import_module('zuds-pipeline_amd.nightly')
@@ -128,9 +128,11 @@ def test_share_limits(engine):
     with pytest.raises(ValueError):
         nm.SubtractionPool(0)
     with pytest.raises(ValueError):
-        nm.SubtractionPool(14)
+        nm.SubtractionPool(65)
     with pytest.raises(z.ZMError):
         engine.set_share(0)
+    with pytest.raises(z.ZMError):
+        engine.set_share(65)
     engine.set_share(1)
 
 

@@ -245,3 +245,28 @@ def test_unsolved_region_warns_and_is_flagged(engine):
     assert (d[300:, 320:] != np.float32(1e-30)).mean() > 0.9
     with pytest.warns(RuntimeWarning, match='1 region'):
         z.hotpants.warn_unsolved(info, 'test')
+
+
+@pytest.mark.parametrize('case', [
+    dict(nx=384, ny=352, seed=1, nstars=120, kw=dict(r=5.0, rss=12.0, nsx=4, nsy=4, ko=0, bgo=0)),               # 50 unknowns
+    dict(nx=540, ny=510, seed=3, nstars=400, kw=dict(r=4.0, rss=9.0, nsx=3, nsy=3, nrx=3, nry=3, ko=1, bgo=0)),   # 146, 9 regions
+    dict(nx=448, ny=416, seed=5, nstars=220, kw=dict(r=6.0, rss=11.0, nsx=5, nsy=5, ko=2, bgo=1)),               # 292
+    dict(nx=1024, ny=1024, seed=50, nstars=1200, kw=dict(r=10.0, rss=24.0, nsx=10, nsy=10, nrx=3, nry=3, ko=4, bgo=0)),  # 722, 9 regions
+    dict(nx=448, ny=416, seed=14, nstars=400, kw=dict(r=3.0, rss=7.0, nsx=8, nsy=8, ko=5, bgo=0)),               # 1010
+])
+def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkeypatch, case):
+    """The kernel fit's factorisation has two forms: k_chol_fused (many workgroups per region, region
+    barriers: short) and k_chol_tp (one workgroup per region: cheap in CU-time; what a context uses when
+    zm_ctx_set_share >= 2 and what a fit is repeated on after a barrier time-out).  Same arithmetic,
+    operation for operation: every product of the subtraction is bit-identical."""
+    data = scene(nx=case['nx'], ny=case['ny'], seed=case['seed'], nstars=case['nstars'], gradient=0.3)
+    kw = dict(case['kw'], **COMMON)
+    monkeypatch.setenv('ZM_CHOL_FORM', 'lat')
+    d0, n0, i0 = engine.subtract(*data, **kw)
+    monkeypatch.setenv('ZM_CHOL_FORM', 'tp')
+    d1, n1, i1 = engine.subtract(*data, **kw)
+    monkeypatch.delenv('ZM_CHOL_FORM')
+    assert i0['status'] == 0 and i1['status'] == 0 and i0['retries'] == 0 and i1['retries'] == 0
+    assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
+    for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
+        assert i0[k] == i1[k], k

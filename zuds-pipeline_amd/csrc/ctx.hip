@@ -120,7 +120,7 @@ extern "C" int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream) {
 
 extern "C" int zm_ctx_set_share(zm_ctx* ctx, int nctx) {
     ZM_CHECK(ctx != nullptr, "zm_ctx_set_share: ctx is NULL");
-    ZM_CHECK(nctx >= 1 && nctx <= 13, "zm_ctx_set_share: %d contexts (1 .. 13: 3 x 3 regions need 18 workgroups each)", nctx);
+    ZM_CHECK(nctx >= 1 && nctx <= 64, "zm_ctx_set_share: %d contexts (1 .. 64)", nctx);
     ctx->share = nctx;
     return 0;
 }

@@ -908,7 +908,8 @@ __device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail)
 // v_mfma_f64_16x16x4 per 16 x 16 tile of the lower triangle, 10 in all), through LDS.  The 32
 // dependent reciprocal square roots remain.  One wave; LDS operations of a wave execute in
 // order, so the panel written by the lanes is what the matrix-core operands read back.
-__device__ inline void chol_diag_wave_panel(double (*D)[CH_NB + 1], int nb, int* fail) {
+template <int TAG>
+__device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, int* fail) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, li = lane & 15, lk = lane >> 4;
     int bad = 0;
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
     auto factor_and_publish = [&](int k0, int nb, int slot) {
         double* Dg = Dg2 + (size_t)slot * CH_NB * (CH_NB + 1);
         __syncthreads();
-        if (tid < 64) chol_diag_wave_panel(D, nb, &fail[reg]);
+        if (tid < 64) chol_diag_wave_panel_t<0>(D, nb, &fail[reg]);
         __syncthreads();
         for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) st_sh(&Dg[e], D[e / (CH_NB + 1)][e % (CH_NB + 1)]);
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
@@ -1323,6 +1324,243 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
     if (prof && tid == 0)
         for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
 #undef CF_TICK
+}
+
+// ---- the same factorisation, cheap in CU-time instead of short --------------------------
+// One workgroup of 512 threads per region and nothing shared between workgroups: no region
+// barrier, nothing that has to be resident together, 9 CUs instead of 234.  Built for the case
+// where many subtractions are in flight on one GPU (zm_ctx_set_share >= 2) and as the form a
+// fit is repeated on after a barrier time-out of k_chol_fused.
+// Left-looking: block column kb is   C = A[k0:, k0:k0+32] - L[k0:, 0:k0] L[k0:k0+32, 0:k0]^T
+// on the f64 matrix cores, 16-row strips dealt to the waves (three per wave and pass, the
+// accumulators stay in registers), the block row L[k0:k0+32, 0:k0] staged through LDS in
+// 32-column chunks (double-buffered, one barrier per chunk), the strips' own rows read from
+// global memory in the operand layout (a lane's eight loads of a chunk fall into two lines
+// that stay in the vector L1).  Then wave 0 factors the diagonal block (chol_diag_wave_panel,
+// the code k_chol_fused runs) and every wave solves its strips X L^T = C in place, in the
+// accumulator layout: step m broadcasts column m inside each row of 16 lanes (DPP
+// row_newbcast) and every lane subtracts u_m c[col][m].
+// The arithmetic is that of k_chol_fused, operation for operation: an entry receives the
+// products of the earlier block columns through the same v_mfma_f64_16x16x4 (negated row
+// operand, chunks of four columns in ascending order - k_chol_fused applies them right-looking,
+// one block step at a time, which is the same sequence per entry), the panel solve is the
+// same chain (u_m unscaled, c = -(L[i][m] / L[m][m]), 1 / L[i][i] at the end).  Same bits:
+// tests/test_subtract_gpu.py compares the two forms.
+#define CT_THREADS 512
+#define CT_WAVES (CT_THREADS / 64)
+#define CT_NQ 3                          // strips per wave and pass
+#define CT_NS (CH_NB * CH_NB / CT_THREADS)   // chunk entries staged per thread
+
+template <int SRC>
+__device__ __forceinline__ double row16_bcast_d(double v) {
+    // lane SRC of every row of 16 lanes to all lanes of that row (row_newbcast: 0x150 + SRC)
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + SRC, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + SRC, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void hp_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        hp_static_for<I + 1, N>(fn);
+    }
+}
+
+// (one out-of-line copy for the four instances of ct_pass; k_chol_fused keeps its inlined one)
+__device__ __noinline__ void chol_diag_wave_panel_call(double (*D)[CH_NB + 1], int nb, int* fail) {
+    chol_diag_wave_panel_t<1>(D, nb, fail);
+}
+
+struct ct_lds {
+    double D[CH_NB][CH_NB + 1];
+    double Lb[2][CH_NB][CH_NB + 2];           // block-row chunk; pitch 34: conflict-free operand reads
+    double2 Cf[CH_NB][16];                    // Cf[m][li] = {c[li][m], c[li + 16][m]}
+    double Rd[CH_NB];                         // 1 / L[i][i]
+};
+
+// One pass of block column kb for a wave that owns NQ strips in it (NQ is wave-uniform: the
+// instances differ in the work between the barriers, not in the barriers).
+template <int NQ>
+__device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, const int lda, const int kb, const int pass,
+                                        ct_lds* __restrict__ S, int* fail) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int sr = tid >> 5, sm = tid & 31;               // staging role: rows sr + 16 e, column sm of a 32 x 32 chunk
+    const int nrows = n + 1;
+    const int k0 = kb * CH_NB;
+    const int nb = min(CH_NB, n - k0);
+    const int k1 = k0 + nb;
+    // (offsets into the region's matrix fit 32 bits: one base, unsigned offsets)
+    bool bok[CT_NS];
+    unsigned brow[CT_NS];
+#pragma unroll
+    for (int e = 0; e < CT_NS; ++e) {
+        const int r = sr + (CH_NB / CT_NS) * e;
+        bok[e] = k0 + r < n;
+        brow[e] = (unsigned)(min(k0 + r, n - 1) * lda + sm);
+    }
+    constexpr int NA = NQ > 0 ? NQ : 1;
+    int row0[NA];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) row0[q] = k0 + 16 * (CT_NQ * CT_WAVES * pass + wave + CT_WAVES * q);
+    double4_t acc[NA][2];
+    // C = A (entries beyond the matrix: 0); clamped addresses, selected afterwards
+    {
+        double t[NA][2][4];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = row0[q] + lk + 4 * rg, j = k0 + 16 * c + li;
+                    t[q][c][rg] = A[(unsigned)(min(i, nrows - 1) * lda + min(j, n - 1))];
+                }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = row0[q] + lk + 4 * rg, j = k0 + 16 * c + li;
+                    acc[q][c][rg] = (i < nrows && j < n) ? t[q][c][rg] : 0.0;
+                }
+    }
+    if (kb > 0) {
+        {
+            double b0[CT_NS];
+#pragma unroll
+            for (int e = 0; e < CT_NS; ++e) b0[e] = A[brow[e]];
+#pragma unroll
+            for (int e = 0; e < CT_NS; ++e) S->Lb[0][sr + (CH_NB / CT_NS) * e][sm] = bok[e] ? b0[e] : 0.0;
+        }
+        unsigned ap[NA];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ap[q] = (unsigned)(min(row0[q] + li, nrows - 1) * lda + lk);
+        double av[NA][8];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) av[q][kk] = A[ap[q] + 4 * kk];
+        __syncthreads();
+        for (int kc = 0; kc < kb; ++kc) {
+            // the next chunk is requested before the matrix cores run on this one (the last
+            // iteration requests the last chunk again: no branch around the loads)
+            const int kn = min(kc + 1, kb - 1) * CH_NB;
+            double bnext[CT_NS], avn[NA][8];
+#pragma unroll
+            for (int e = 0; e < CT_NS; ++e) bnext[e] = A[brow[e] + kn];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) avn[q][kk] = A[ap[q] + kn + 4 * kk];
+            const double (*B)[CH_NB + 2] = S->Lb[kc & 1];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const double b0 = B[li][4 * kk + lk], b1 = B[16 + li][4 * kk + lk];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const double a = -av[q][kk];
+                    acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[q][0], 0, 0, 0);
+                    acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[q][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CT_NS; ++e)
+                S->Lb[(kc + 1) & 1][sr + (CH_NB / CT_NS) * e][sm] = bok[e] ? bnext[e] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) av[q][kk] = avn[q][kk];
+            __syncthreads();
+        }
+    }
+    if (pass == 0) {
+        // the diagonal block (strips 0 and 1: waves 0 and 1) -> D, identity outside nb
+        for (int e = tid; e < CH_NB * (CH_NB + 1); e += CT_THREADS) {
+            const int i = e / (CH_NB + 1), j = e - i * (CH_NB + 1);
+            S->D[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if constexpr (NQ > 0) {
+            if (wave < 2) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int i = 16 * wave + lk + 4 * rg, j = 16 * c + li;
+                        if (i < nb && j <= i) S->D[i][j] = acc[0][c][rg];
+                    }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) chol_diag_wave_panel_call(S->D, nb, fail);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < CT_NS; ++e) {
+            const int m = sr + (CH_NB / CT_NS) * e, i = sm;               // column m of row i
+            const double cv = -(S->D[i][m] * S->D[m][CH_NB]);
+            reinterpret_cast<double*>(&S->Cf[m][i & 15])[i >> 4] = (i > m) ? cv : 0.0;
+            if (i < nb && m <= i) A[(unsigned)((k0 + i) * lda + k0 + m)] = S->D[i][m];
+        }
+        if (tid < CH_NB) S->Rd[tid] = S->D[tid][CH_NB];
+        __syncthreads();
+    }
+    if constexpr (NQ > 0) {
+        // panel rows X L^T = C in the accumulator layout (rows of the diagonal block ride along, unstored)
+        hp_static_for<0, CH_NB - 1>([&](auto M) __attribute__((always_inline)) {
+            constexpr int m = decltype(M)::value;
+            constexpr int tm = m >> 4, sl = m & 15;
+            const double2 cf = S->Cf[m][li];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const double u = row16_bcast_d<sl>(acc[q][tm][rg]);
+                    if (m < 15) acc[q][0][rg] = fma(cf.x, u, acc[q][0][rg]);
+                    acc[q][1][rg] = fma(cf.y, u, acc[q][1][rg]);
+                }
+        });
+        const double r0 = S->Rd[li], r1 = S->Rd[16 + li];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int i = row0[q] + lk + 4 * rg;
+                const double x0 = acc[q][0][rg] * r0, x1 = acc[q][1][rg] * r1;
+                if (i >= k1 && i < nrows) {
+                    if (li < nb) A[(unsigned)(i * lda + k0 + li)] = x0;
+                    if (16 + li < nb) A[(unsigned)(i * lda + k0 + 16 + li)] = x1;
+                }
+            }
+    }
+    __syncthreads();          // the stored rows are the next column's operands; Lb / D / Cf are reused
+}
+
+__global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, double* Aall, int* fail,
+                                                        const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
+    __shared__ ct_lds S;
+    const int reg = blockIdx.x;
+    double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
+    const int wave = threadIdx.x >> 6;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int ns = (n + 1 - kb * CH_NB + 15) >> 4;       // 16-row strips from row k0 down
+        const int npass = (ns + CT_NQ * CT_WAVES - 1) / (CT_NQ * CT_WAVES);
+        for (int pass = 0; pass < npass; ++pass) {
+            // strips of this wave: first + wave + CT_WAVES q, q < nq
+            const int left = ns - CT_NQ * CT_WAVES * pass - wave;
+            const int nq = left <= 0 ? 0 : min(CT_NQ, (left + CT_WAVES - 1) / CT_WAVES);
+            switch (nq) {
+                case 0: ct_pass<0>(A, n, lda, kb, pass, &S, &fail[reg]); break;
+                case 1: ct_pass<1>(A, n, lda, kb, pass, &S, &fail[reg]); break;
+                case 2: ct_pass<2>(A, n, lda, kb, pass, &S, &fail[reg]); break;
+                default: ct_pass<3>(A, n, lda, kb, pass, &S, &fail[reg]); break;
+            }
+        }
+    }
 }
 
 // Back substitution L^T x = y (y = row n of the factored storage), one workgroup
@@ -2331,13 +2569,26 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     ctx->hp_wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
                     if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
                 }
-                // this context's share of the resident workgroups: `share` contexts subtract at the
-                // same time (zm_ctx_set_share), each keeps its launch fully resident
+                // Which form: the latency form (W workgroups per region, all resident, one per CU) for a
+                // context that has the GPU to itself; the throughput form (one workgroup per region,
+                // nothing shared) when `share` contexts subtract at the same time (zm_ctx_set_share)
+                // and for the repeat after a barrier time-out.  Same bits either way.  ZM_CHOL_FORM=tp /
+                // lat overrides (tests, A / B timing).
+                const char* form_env = getenv("ZM_CHOL_FORM");
+                bool tp = safe || ctx->share >= 2;
+                if (form_env && !strcmp(form_env, "tp")) tp = true;
+                if (form_env && !strcmp(form_env, "lat") && !safe) tp = false;
+                if (tp) {
+                    hipLaunchKernelGGL(k_chol_tp, dim3(P.nreg), dim3(CT_THREADS), 0, st, P.nunk, lda, A, fail, guard);
+                    ZM_HIP(hipGetLastError());
+                } else {
+                // this context's share of the resident workgroups: each of `share` contexts keeps its
+                // launch fully resident
                 const int wg_cap = ctx->hp_wg_cap / std::max(ctx->share, 1);
                 ZM_CHECK(2 * P.nreg <= wg_cap,
                          "zm_subtract: %d regions exceed the %d resident workgroups of this context's share (1 / %d)",
                          P.nreg, wg_cap, ctx->share);
-                int W = safe ? 1 : std::max(2, std::min(68, wg_cap / P.nreg));
+                int W = std::max(2, std::min(68, wg_cap / P.nreg));
                 int nunk = P.nunk;
                 double* Aarg = A;
                 int* farg = fail;
@@ -2363,6 +2614,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                         fprintf(stderr, "\n");
                     }
                 }
+                }   // latency form
             }
             {
                 const size_t bsh = sizeof(double) * (((size_t)P.nunk + 1) & ~(size_t)1) +

@@ -110,11 +110,13 @@ class SubtractionPool(object):
     """``njobs`` subtraction chains running side by side on one GPU."""
 
     def __init__(self, njobs=8, device=0):
-        if not 1 <= njobs <= 13:
-            raise ValueError('njobs must be in 1 .. 13 (the solver needs 18 resident workgroups per job)')
+        if not 1 <= njobs <= 64:
+            raise ValueError('njobs must be in 1 .. 64')
         self.njobs, self.device = int(njobs), int(device)
-        # the solver's resident grid per job: 1 / share of the CUs (ZM_POOL_SHARE overrides: developer)
-        self.share = min(max(int(os.environ.get('ZM_POOL_SHARE', self.njobs)), self.njobs), 13)
+        # share >= 2 selects the one-workgroup-per-region form of the kernel fit's factorisation, which
+        # claims nothing for itself (a lone job keeps the many-workgroup form); ZM_POOL_SHARE overrides
+        # (developer: with ZM_CHOL_FORM=lat it is the fraction of the CUs each job's resident grid gets)
+        self.share = min(max(int(os.environ.get('ZM_POOL_SHARE', self.njobs)), self.njobs), 64)
         _lib.lib()                                   # loaded once, here, not by racing worker threads
         self._local = threading.local()
         self._workers = []
