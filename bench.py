@@ -60,8 +60,8 @@ def parse():
     ap.add_argument('--no-pipelined', action='store_true', help='skip the software-pipelined rate')
     ap.add_argument('--pipelined-share', type=int, default=1, help='developer: zm_ctx_set_share of the subtraction contexts')
     ap.add_argument('--pipelined-depth', type=int, default=4, help='subtractions in flight in the pipelined leg')
-    ap.add_argument('--nightly-jobs', type=int, default=24, help='subtractions of the concurrent leg')
-    ap.add_argument('--nightly-pools', default='1,2,3,4,8,12', help='jobs in flight to time in the concurrent leg')
+    ap.add_argument('--nightly-jobs', type=int, default=32, help='subtractions of the concurrent leg')
+    ap.add_argument('--nightly-pools', default='1,2,4,8,16', help='jobs in flight to time in the concurrent leg')
     ap.add_argument('--dump-coadd', default=None,
                     help='developer / tests: rank 0 saves the coadd planes [img, wgt] (.npy) after the run')
     ap.add_argument('--emulate-ranks', type=int, default=1,

@@ -1033,7 +1033,7 @@ __device__ inline void region_arrive(unsigned* ctr) {
 // trailing update instead of following them.
 // fail[reg]: pivots that had to be clamped (the matrix is not positive definite: a property of the
 // fit); tmo[reg]: a barrier gave up waiting (a property of the launch: not every workgroup was
-// resident - the host repeats the fit on the one-workgroup form, which waits for nobody)
+// resident - the host repeats the fit on k_chol_tp, which has no region barrier and waits for nobody)
 __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
                                                     int* tmo, int spin_limit, unsigned* bar, long long* prof,
                                                     const int* __restrict__ guard) {
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         const int r0n = min(CH_NB, below);
         const int per = (W > 1) ? (below - r0n + W - 2) / (W - 1) : 0;
         const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
-        // (a lone workgroup - the safe form the host falls back to - solves every panel row itself)
+        // (a lone workgroup, W = 1 - kept for experiments; the host's fallback is k_chol_tp - solves every panel row itself)
         const int pend = (w == 0) ? (W == 1 ? below : r0n) : min(r0n + w * per, below);
         // workgroup 0: the unfactored next diagonal block, fetched ahead of its use
         // (in the accumulator layout of the f64 matrix cores: wave = 16 x 16 quadrant (ti, tj) of
@@ -1383,8 +1383,12 @@ struct ct_lds {
 // One pass of block column kb for a wave that owns NQ strips in it (NQ is wave-uniform: the
 // instances differ in the work between the barriers, not in the barriers).
 template <int NQ>
-__device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, const int lda, const int kb, const int pass,
-                                        ct_lds* __restrict__ S, int* fail) {
+__device__ __forceinline__ void ct_pass(double* __restrict__ A, double* __restrict__ AT, const int n, const int lda,
+                                        const int ldt, const int kb, const int pass, ct_lds* __restrict__ S, int* fail,
+                                        long long* pt) {
+    // phase clocks (100 MHz) when pt != NULL: 0 C = A, 1 products, 2 diagonal block, 3 its factor, 4 panel solve + store
+    long long tc = pt ? wall_clock64() : 0;
+#define CT_TICK(k) do { if (pt) { long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int sr = tid >> 5, sm = tid & 31;               // staging role: rows sr + 16 e, column sm of a 32 x 32 chunk
     const int nrows = n + 1;
@@ -1427,6 +1431,7 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
                     acc[q][c][rg] = (i < nrows && j < n) ? t[q][c][rg] : 0.0;
                 }
     }
+    CT_TICK(0);
     if (kb > 0) {
         {
             double b0[CT_NS];
@@ -1435,14 +1440,16 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
 #pragma unroll
             for (int e = 0; e < CT_NS; ++e) S->Lb[0][sr + (CH_NB / CT_NS) * e][sm] = bok[e] ? b0[e] : 0.0;
         }
+        // the strips' own rows come from the column-major copy AT (16 consecutive lanes = 16 consecutive rows
+        // = one 128-B line; from the row-major matrix every lane of a load would touch a line of its own)
         unsigned ap[NA];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) ap[q] = (unsigned)(min(row0[q] + li, nrows - 1) * lda + lk);
+        for (int q = 0; q < NQ; ++q) ap[q] = (unsigned)(lk * ldt + row0[q] + li);
         double av[NA][8];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) av[q][kk] = A[ap[q] + 4 * kk];
+            for (int kk = 0; kk < 8; ++kk) av[q][kk] = AT[ap[q] + 4 * kk * ldt];
         __syncthreads();
         for (int kc = 0; kc < kb; ++kc) {
             // the next chunk is requested before the matrix cores run on this one (the last
@@ -1454,7 +1461,7 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) avn[q][kk] = A[ap[q] + kn + 4 * kk];
+                for (int kk = 0; kk < 8; ++kk) avn[q][kk] = AT[ap[q] + (kn + 4 * kk) * ldt];
             const double (*B)[CH_NB + 2] = S->Lb[kc & 1];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
@@ -1476,6 +1483,7 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
             __syncthreads();
         }
     }
+    CT_TICK(1);
     if (pass == 0) {
         // the diagonal block (strips 0 and 1: waves 0 and 1) -> D, identity outside nb
         for (int e = tid; e < CH_NB * (CH_NB + 1); e += CT_THREADS) {
@@ -1495,8 +1503,10 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
             }
         }
         __syncthreads();
+        CT_TICK(2);
         if (wave == 0) chol_diag_wave_panel_call(S->D, nb, fail);
         __syncthreads();
+        CT_TICK(3);
 #pragma unroll
         for (int e = 0; e < CT_NS; ++e) {
             const int m = sr + (CH_NB / CT_NS) * e, i = sm;               // column m of row i
@@ -1523,29 +1533,53 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, const int n, con
                 }
         });
         const double r0 = S->Rd[li], r1 = S->Rd[16 + li];
+        // (the chunk buffers are idle here: 16 x 17 doubles of them per wave turn a tile for the column-major copy)
+        double (*T)[17] = reinterpret_cast<double (*)[17]>(&S->Lb[0][0][0] + wave * (16 * 17));
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q) {
+            double x[2][4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int i = row0[q] + lk + 4 * rg;
-                const double x0 = acc[q][0][rg] * r0, x1 = acc[q][1][rg] * r1;
+                x[0][rg] = acc[q][0][rg] * r0;
+                x[1][rg] = acc[q][1][rg] * r1;
                 if (i >= k1 && i < nrows) {
-                    if (li < nb) A[(unsigned)(i * lda + k0 + li)] = x0;
-                    if (16 + li < nb) A[(unsigned)(i * lda + k0 + 16 + li)] = x1;
+                    if (li < nb) A[(unsigned)(i * lda + k0 + li)] = x[0][rg];
+                    if (16 + li < nb) A[(unsigned)(i * lda + k0 + 16 + li)] = x[1][rg];
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) T[li][lk + 4 * rg] = x[c][rg];
+                double tv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tv[j] = T[lk + 4 * j][li];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 16 * c + lk + 4 * j, i = row0[q] + li;
+                    if (i >= k1 && i < nrows && col < nb) AT[(unsigned)((k0 + col) * ldt + i)] = tv[j];
+                }
+            }
+        }
     }
     __syncthreads();          // the stored rows are the next column's operands; Lb / D / Cf are reused
+    CT_TICK(4);
+#undef CT_TICK
 }
 
-__global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, double* Aall, int* fail,
-                                                        const int* __restrict__ guard) {
+// AT: [reg][n][ldt] scratch, ldt = n + 1 rounded up to 16: the panels of L once more, column by column
+__global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, int ldt, double* Aall, double* ATall, int* fail,
+                                                        long long* prof, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ ct_lds S;
     const int reg = blockIdx.x;
     double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
+    double* AT = ATall + (size_t)reg * (size_t)n * ldt;
     const int wave = threadIdx.x >> 6;
     const int nblk = (n + CH_NB - 1) / CH_NB;
+    long long ptv[5] = {0, 0, 0, 0, 0};
+    long long* pt = prof ? ptv : nullptr;
     for (int kb = 0; kb < nblk; ++kb) {
         const int ns = (n + 1 - kb * CH_NB + 15) >> 4;       // 16-row strips from row k0 down
         const int npass = (ns + CT_NQ * CT_WAVES - 1) / (CT_NQ * CT_WAVES);
@@ -1554,13 +1588,15 @@ __global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, double* 
             const int left = ns - CT_NQ * CT_WAVES * pass - wave;
             const int nq = left <= 0 ? 0 : min(CT_NQ, (left + CT_WAVES - 1) / CT_WAVES);
             switch (nq) {
-                case 0: ct_pass<0>(A, n, lda, kb, pass, &S, &fail[reg]); break;
-                case 1: ct_pass<1>(A, n, lda, kb, pass, &S, &fail[reg]); break;
-                case 2: ct_pass<2>(A, n, lda, kb, pass, &S, &fail[reg]); break;
-                default: ct_pass<3>(A, n, lda, kb, pass, &S, &fail[reg]); break;
+                case 0: ct_pass<0>(A, AT, n, lda, ldt, kb, pass, &S, &fail[reg], pt); break;
+                case 1: ct_pass<1>(A, AT, n, lda, ldt, kb, pass, &S, &fail[reg], pt); break;
+                case 2: ct_pass<2>(A, AT, n, lda, ldt, kb, pass, &S, &fail[reg], pt); break;
+                default: ct_pass<3>(A, AT, n, lda, ldt, kb, pass, &S, &fail[reg], pt); break;
             }
         }
     }
+    if (prof && threadIdx.x == 0)
+        for (int k = 0; k < 5; ++k) prof[blockIdx.x * 5 + k] = ptv[k];
 }
 
 // Back substitution L^T x = y (y = row n of the factored storage), one workgroup
@@ -2470,7 +2506,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     // The fit (stamp search ... rejection rounds) is one repeatable attempt: when a barrier of the
     // fused factorisation timed out - its workgroups were not all resident, something else held
     // the GPU - every later round worked on a garbage solution, so the whole fit is run again on
-    // the one-workgroup form of the factorisation (W = 1: it waits for nobody; slower, same bits).
+    // the one-workgroup-per-region form of the factorisation (k_chol_tp: it waits for nobody; slower, same bits).
     // ZM_CHOL_SPIN_LIMIT (developer / tests): spins before a barrier gives up in the FIRST attempt.
     int h_int[HP_NIBUF];
     std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
@@ -2579,8 +2615,23 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (form_env && !strcmp(form_env, "tp")) tp = true;
                 if (form_env && !strcmp(form_env, "lat") && !safe) tp = false;
                 if (tp) {
-                    hipLaunchKernelGGL(k_chol_tp, dim3(P.nreg), dim3(CT_THREADS), 0, st, P.nunk, lda, A, fail, guard);
+                    static const bool tp_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
+                    long long* parg = nullptr;
+                    if (tp_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 5 * P.nreg, (void**)&parg));
+                    const int ldt = (P.nunk + 1 + 15) & ~15;
+                    double* AT = nullptr;
+                    ZM_TRY(ctx->get("hp_chol_at", sizeof(double) * (size_t)P.nreg * P.nunk * ldt, (void**)&AT));
+                    hipLaunchKernelGGL(k_chol_tp, dim3(P.nreg), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, A, AT, fail, parg, guard);
                     ZM_HIP(hipGetLastError());
+                    if (tp_prof) {
+                        std::vector<long long> hp((size_t)5 * P.nreg);
+                        ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
+                        ZM_HIP(hipStreamSynchronize(st));
+                        static const char* nm[5] = {"init", "products", "diag", "factor", "solve"};
+                        fprintf(stderr, "chol_tp wg 0:");
+                        for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f us", nm[k], hp[k] * 0.01);
+                        fprintf(stderr, "\n");
+                    }
                 } else {
                 // this context's share of the resident workgroups: each of `share` contexts keeps its
                 // launch fully resident
