@@ -220,11 +220,8 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     S->lny = lny;
     for (int i = 0; i < n; ++i) ZM_TRY(check_wcs(&fr[i].wcs, "frame"));
     hipEvent_t* evs = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 7, &evs));
-    ZM_HIP(hipEventRecord(evs[3], ctx->stream));
+    ZM_TRY(zm_get_sync_events(ctx, 9, &evs));
     const float wthresh = (float)P->weight_thresh;
-    bk_plan bp;
-    ZM_TRY(frames_background(ctx, n, fr, P, &bp));
     int ff_th = 32, ff_cap = 3700;
     zm_fused_geometry(&ff_th, &ff_cap);
     const char* e = getenv("ZM_FF_RAW");
@@ -272,9 +269,27 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny * n, (void**)&lat));
     if (prep_bytes) ZM_TRY(ctx->get("prep_all", prep_bytes, (void**)&prep_all));
     if (box_bytes) ZM_TRY(ctx->get("mask_box_all", box_bytes, (void**)&box_all));
+    int* boxflags = nullptr;           // per frame: its box-OR plane holds entries that defer to the raw mask
+    ZM_TRY(ctx->get("mask_box_flags", sizeof(int) * (size_t)n, (void**)&boxflags));
+    ZM_HIP(hipMemsetAsync(boxflags, 0, sizeof(int) * (size_t)n, ctx->stream));
+    ZM_HIP(hipEventRecord(evs[3], ctx->stream));
+    // the box-OR planes of the frames that are read raw: they need the masks only, so they go out first, on the
+    // second stream, beside the mesh statistics
+    std::vector<zm_boxjob> boxes;
+    for (int i = 0; i < n; ++i) {
+        uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
+        ff[i].mbox = mbox;
+        if (mbox && !need_src[i]) {
+            boxes.push_back(zm_boxjob{ff[i].mask, mbox, boxflags + i, ff[i].nx, ff[i].ny, ff[i].mpitch, 0});
+            ff[i].mboxflag = boxflags + i;
+        }
+    }
+    hipEvent_t boxes_done = nullptr;
+    ZM_TRY(zm_launch_mask_boxes(ctx, boxes.data(), (int)boxes.size(), evs[3], &boxes_done));
+    bk_plan bp;
+    ZM_TRY(frames_background(ctx, n, fr, P, &bp));
     ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat, evs[3]));
     std::vector<zm_bkrows> rows;
-    std::vector<zm_boxjob> boxes;
     struct bkinfo { float* nodes; float* vscale; int nbx, nby; };
     std::vector<bkinfo> bki(n, bkinfo{nullptr, nullptr, 0, 0});
     for (int i = 0; i < n; ++i) {
@@ -293,20 +308,15 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         }
     }
     if (yt_bytes) ZM_TRY(ctx->get("bk_rows_all", yt_bytes, (void**)&yt_all));
-    int* boxflags = nullptr;           // per frame: its box-OR plane holds entries that defer to the raw mask
-    ZM_TRY(ctx->get("mask_box_flags", sizeof(int) * (size_t)n, (void**)&boxflags));
-    ZM_HIP(hipMemsetAsync(boxflags, 0, sizeof(int) * (size_t)n, ctx->stream));
     for (int i = 0; i < n; ++i) {
         const int nx = ff[i].nx, ny = ff[i].ny;
-        uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
-        ff[i].mbox = mbox;
         ff[i].lat = lat + (size_t)i * lnx * lny;
         ff[i].vscale = bki[i].vscale;
         if (need_src[i]) {
             // the frame prepped into its own plane (k_prep_box also fills the box-OR plane)
             float2* src = (float2*)(prep_all + prep_off[i]);
             ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bki[i].nodes, bki[i].nbx, bki[i].nby, P->back_size,
-                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, mbox, ff[i].mpitch));
+                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, (uint16_t*)ff[i].mbox, ff[i].mpitch));
             ff[i].src = src;
             continue;
         }
@@ -323,12 +333,9 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             r.invmesh = ff[i].invmesh;
             rows.push_back(r);
         }
-        if (mbox) {
-            boxes.push_back(zm_boxjob{ff[i].mask, mbox, boxflags + i, nx, ny, ff[i].mpitch, 0});
-            ff[i].mboxflag = boxflags + i;
-        }
     }
-    ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size(), boxes.data(), (int)boxes.size()));
+    ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size()));
+    if (boxes_done) ZM_HIP(hipStreamWaitEvent(ctx->stream, boxes_done, 0));
     S->lds = lds;
     S->any_mask = any_mask;
     return 0;

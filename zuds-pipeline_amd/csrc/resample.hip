@@ -1601,34 +1601,61 @@ __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restr
 }
 
 // jobs: host arrays (staged through pinned memory behind an event, like the frame descriptors)
-int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows, const zm_boxjob* boxes, int nboxes) {
-    if (nrows == 0 && nboxes == 0) return 0;
+int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows) {
+    if (nrows == 0) return 0;
     hipEvent_t* ev = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 7, &ev));
+    ZM_TRY(zm_get_sync_events(ctx, 9, &ev));
     ZM_HIP(hipEventSynchronize(ev[6]));
-    const size_t rb = sizeof(zm_bkrows) * (size_t)std::max(nrows, 1), bb = sizeof(zm_boxjob) * (size_t)std::max(nboxes, 1);
+    const size_t rb = sizeof(zm_bkrows) * (size_t)nrows;
     char *pin = nullptr, *dev = nullptr;
-    ZM_TRY(ctx->get_pinned("ff_pre_h", rb + bb, (void**)&pin));
-    ZM_TRY(ctx->get("ff_pre", rb + bb, (void**)&dev));
-    if (nrows) memcpy(pin, rows, sizeof(zm_bkrows) * (size_t)nrows);
-    if (nboxes) memcpy(pin + rb, boxes, sizeof(zm_boxjob) * (size_t)nboxes);
-    ZM_HIP(hipMemcpyAsync(dev, pin, rb + bb, hipMemcpyHostToDevice, ctx->stream));
+    ZM_TRY(ctx->get_pinned("ff_pre_h", rb, (void**)&pin));
+    ZM_TRY(ctx->get("ff_pre", rb, (void**)&dev));
+    memcpy(pin, rows, rb);
+    ZM_HIP(hipMemcpyAsync(dev, pin, rb, hipMemcpyHostToDevice, ctx->stream));
     ZM_HIP(hipEventRecord(ev[6], ctx->stream));
-    if (nrows) {
-        int most = 1;
-        for (int i = 0; i < nrows; ++i) most = std::max(most, rows[i].ny * rows[i].ytp);
-        zm_scope_timer t(ctx, "bk_rows");
-        hipLaunchKernelGGL(k_bk_rows, dim3(zm_div_up(most, 256), nrows), dim3(256), 0, ctx->stream,
-                           (const zm_bkrows*)dev);
-        ZM_HIP(hipGetLastError());
-    }
-    if (nboxes) {
-        int mx = 1, my = 1;
-        for (int i = 0; i < nboxes; ++i) { mx = std::max(mx, boxes[i].nx); my = std::max(my, boxes[i].ny); }
+    int most = 1;
+    for (int i = 0; i < nrows; ++i) most = std::max(most, rows[i].ny * rows[i].ytp);
+    zm_scope_timer t(ctx, "bk_rows");
+    hipLaunchKernelGGL(k_bk_rows, dim3(zm_div_up(most, 256), nrows), dim3(256), 0, ctx->stream, (const zm_bkrows*)dev);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+// The box-OR planes depend on the masks only.  after != NULL: the launch goes to the second stream, ordered
+// after `after` (an event recorded on the main stream before the caller enqueues the mesh statistics: nothing
+// older may still read the planes), and runs BESIDE those statistics - they are bound by their own moment /
+// histogram work at 2.5 TB/s, this kernel streams.  *joined receives the event the main stream has to wait
+// for before the planes are read (NULL: same stream, nothing to wait for).
+int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined) {
+    if (joined) *joined = nullptr;
+    if (nboxes == 0) return 0;
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 9, &ev));
+    ZM_HIP(hipEventSynchronize(ev[7]));
+    const size_t bb = sizeof(zm_boxjob) * (size_t)nboxes;
+    char *pin = nullptr, *dev = nullptr;
+    ZM_TRY(ctx->get_pinned("ff_box_h", bb, (void**)&pin));
+    ZM_TRY(ctx->get("ff_box", bb, (void**)&dev));
+    memcpy(pin, boxes, bb);
+    // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
+    const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "mask_box");
+    static const bool fork_off = getenv("ZM_FF_FORK") && getenv("ZM_FF_FORK")[0] == '0';
+    const bool side = after != nullptr && joined != nullptr && ctx->aux != nullptr && !timed && !fork_off;
+    hipStream_t s = side ? ctx->aux : ctx->stream;
+    if (side) ZM_HIP(hipStreamWaitEvent(s, after, 0));
+    ZM_HIP(hipMemcpyAsync(dev, pin, bb, hipMemcpyHostToDevice, s));
+    ZM_HIP(hipEventRecord(ev[7], s));
+    int mx = 1, my = 1;
+    for (int i = 0; i < nboxes; ++i) { mx = std::max(mx, boxes[i].nx); my = std::max(my, boxes[i].ny); }
+    {
         zm_scope_timer t(ctx, "mask_box");
-        hipLaunchKernelGGL(k_mask_box_batch<6>, dim3(zm_div_up(mx, 64), zm_div_up(my, 16), nboxes), dim3(256), 0,
-                           ctx->stream, (const zm_boxjob*)(dev + rb));
-        ZM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_mask_box_batch<6>, dim3(zm_div_up(mx, 64), zm_div_up(my, 16), nboxes), dim3(256), 0, s,
+                           (const zm_boxjob*)dev);
+    }
+    ZM_HIP(hipGetLastError());
+    if (side) {
+        ZM_HIP(hipEventRecord(ev[8], s));
+        *joined = ev[8];
     }
     return 0;
 }

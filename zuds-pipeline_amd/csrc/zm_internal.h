@@ -148,7 +148,8 @@ struct zm_boxjob {
 };
 // the fused coadd's tile rows and LDS capacity in staged pixels (resample.hip: FT_H, FF_LDS_CAP)
 void zm_fused_geometry(int* tile_h, int* lds_cap);
-int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows, const zm_boxjob* boxes, int nboxes);
+int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows);
+int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
