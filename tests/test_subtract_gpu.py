@@ -270,3 +270,34 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
     assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
     for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
         assert i0[k] == i1[k], k
+
+
+def test_two_engines_side_by_side_without_a_pool(engine):
+    """two contexts that subtract at the same time without having declared it
+    (zm_ctx_set_share) used to size the many-workgroup factorisation to the whole GPU each.  A context
+    that finds another one fitting on its device now takes the one-workgroup-per-region form by itself;
+    whatever the interleaving (a collision of the first launches ends in a counted retry), the products
+    are those of a lone run."""
+    from concurrent.futures import ThreadPoolExecutor
+    z = pkg()
+    data = scene(nx=640, ny=600, seed=23, nstars=400, gradient=0.2)
+    kw = dict(r=5.0, rss=12.0, nsx=5, nsy=5, nrx=2, nry=2, ko=2, bgo=0, **COMMON)
+    d0, n0, i0 = engine.subtract(*data, **kw)
+    assert i0['status'] == 0 and i0['retries'] == 0
+    engines = [z.Engine(0), z.Engine(0)]
+
+    def work(e):
+        return [e.subtract(*data, **kw) for _ in range(6)]
+
+    try:
+        with ThreadPoolExecutor(2) as ex:
+            res = list(ex.map(work, engines))
+    finally:
+        for e in engines:
+            e.close()
+    for runs in res:
+        for d, n, info in runs:
+            assert info['status'] == 0 and info['nunsolved'] == 0
+            assert np.array_equal(d, d0) and np.array_equal(n, n0)
+            for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2'):
+                assert info[k] == i0[k], k

@@ -22,6 +22,7 @@
 //   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
 //                   fp32 convolution of template and template variance
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "zm_internal.h"
@@ -2420,6 +2421,8 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     return 0;
 }
 
+static std::atomic<int> g_hp_fitting[64];    // per device: contexts inside the kernel fit
+
 extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms, const float* ref,
                                const float* ref_rms, const uint8_t* bpm, int nx, int ny,
                                const zm_hp_params* hp, float* out_diff, float* out_rms,
@@ -2512,6 +2515,17 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
     int rounds = 0, retries = 0, ntimeouts = 0;
     const char* spin_env = getenv("ZM_CHOL_SPIN_LIMIT");
+    // Contexts of this process that are fitting on this device right now: the many-workgroup form of the
+    // factorisation wants the GPU to itself, so a context that finds another one at work takes the
+    // one-workgroup-per-region form without having been told (zm_ctx_set_share) - two engines used side by
+    // side without a pool are safe by default.  Other processes on the card are not seen: there
+    // the barrier time-out and the repeat below bound the damage.
+    struct fit_guard {
+        std::atomic<int>* c;
+        int others;
+        explicit fit_guard(std::atomic<int>* cc) : c(cc), others(cc->fetch_add(1)) {}
+        ~fit_guard() { c->fetch_sub(1); }
+    } fitting(&g_hp_fitting[ctx->device & 63]);
     for (int attempt = 0; attempt < 2; ++attempt) {
     const bool safe = attempt > 0;
     const int spin_limit = (!safe && spin_env) ? atoi(spin_env) : CF_SPIN_LIMIT;
@@ -2611,7 +2625,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 // and for the repeat after a barrier time-out.  Same bits either way.  ZM_CHOL_FORM=tp /
                 // lat overrides (tests, A / B timing).
                 const char* form_env = getenv("ZM_CHOL_FORM");
-                bool tp = safe || ctx->share >= 2;
+                bool tp = safe || ctx->share >= 2 || fitting.others > 0;
                 if (form_env && !strcmp(form_env, "tp")) tp = true;
                 if (form_env && !strcmp(form_env, "lat") && !safe) tp = false;
                 if (tp) {
