@@ -267,3 +267,24 @@ def test_differential_fuzz_against_the_k_resample_path(engine):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(80, 2026, eng=engine, verbose=False) == 0
+
+
+@pytest.mark.parametrize('variant', [{'ZM_FF_DMA': '0'}, {'ZM_FF_RAW': '0'}, {'ZM_FF_DMA': '0', 'ZM_FF_RAW': '0'},
+                                     {'ZM_FF_FORK': '0'}])
+def test_kernel_variants_behind_the_switches(engine, monkeypatch, variant):
+    """The library ships two fused kernels (LDS-DMA staging, the default, and the register-staged one:
+    ZM_FF_DMA=0) and two ways to feed them (raw planes prepped in the kernel, the default, and planes
+    prepped ahead: ZM_FF_RAW=0, also what frames without 16-byte rows or with large footprints take).
+    Every combination gives the bits of the materialised path, on interior and edge tiles."""
+    z = pkg()
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    frames, wout = stack(5, 700, 650, 310)
+    p = z.coadd_params(combine='WEIGHTED', mask_combine='OR', subtract_back=True, rescale_weights=True, back_size=128)
+    a, b = run_both(engine, frames, wout, p)
+    assert_same(a, b)
+    frames, _ = stack(4, 520, 480, 320, dither=50.0, rot=0.3)
+    wout = engine.autogrid([f['wcs'] for f in frames])
+    p = z.coadd_params(combine='AVERAGE', mask_combine='AND', subtract_back=False, rescale_weights=False)
+    a, b = run_both(engine, frames, wout, p)
+    assert_same(a, b)
