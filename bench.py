@@ -267,18 +267,50 @@ def launch(args):
     return 0
 
 
+def hotpants_command(paths, r, rss, nsx, nsy, nreg_side, big_rms, tu, tl):
+    """The command line zuds/hotpants.py:77-93 composes (flag for flag), on the files in `paths`."""
+    return (f'hotpants -inim {paths["sci"]} -hki -n i -c t -tmplim {paths["ref"]} -outim {paths["out"]} '
+            f'-tu {tu} -iu {tu} -tl {tl} -il {tl} -r {r} -rss {rss} -tni {paths["ref_rms"]} '
+            f'-ini {paths["sci_rms"]} -imi {paths["mask"]} -v 0 -oni {paths["out_rms"]} '
+            f'-fin {big_rms} -nsx {nsx / nreg_side} -nsy {nsy / nreg_side} -nrx {nreg_side} -nry {nreg_side} '
+            f'-bgo 0 -ko 4')
+
+
+def sextractor_command(paths):
+    """zuds/sextractor.py:67-98 with the keys of zuds/astromatic/sextractor.conf that reach the
+    background maps spelled out as flags (BACK_SIZE 128 = BKG_BOX_SIZE, BACK_FILTERSIZE 3, MAP_WEIGHT,
+    WEIGHT_THRESH 1e-30); no catalogue, no detection filter file."""
+    return (f'sex {paths["img"]} -CHECKIMAGE_TYPE BACKGROUND,BACKGROUND_RMS '
+            f'-CHECKIMAGE_NAME {paths["bkg"]},{paths["rms"]} -CATALOG_TYPE NONE -PARAMETERS_NAME {paths["param"]} '
+            f'-FILTER N -BACK_SIZE 128 -BACK_FILTERSIZE 3 -WEIGHT_IMAGE {paths["wgt"]} -WEIGHT_TYPE MAP_WEIGHT '
+            f'-WEIGHT_THRESH 1e-30 -VERBOSE_TYPE QUIET')
+
+
+def rel_diff(ref, mine, good, floor):
+    rel = np.abs(ref[good].astype(np.float64) - mine[good]) / np.maximum(np.abs(ref[good]), floor)
+    return {'median_rel_diff': float(np.median(rel)), 'p99_rel_diff': float(np.percentile(rel, 99)),
+            'pixels': int(good.sum())}
+
+
 def reference_tools(workdir, files, hip_products):
     """when the reference's own binaries exist on this box, run the commands the
-    reference would run (zuds/swarp.py:68-78, zuds/hotpants.py:77-93) on the same FITS files,
-    time them and report the pixel disagreement with the HIP products.  None of them is
+    reference would run (zuds/swarp.py:68-78, zuds/hotpants.py:77-93, zuds/sextractor.py:67-98) on
+    FITS files, time them and report the pixel disagreement with the HIP products: `swarp` on the
+    bench's own frames against the coadd, `hotpants` on an aligned synthetic 1024 x 1024 pair against
+    zm_subtract at the same parameters, `sex` on one frame against zm_background.  None of them is
     installed on the pool images seen so far; the probe result is part of the line either way."""
     import shutil
     import subprocess
     found = {t: shutil.which(t) for t in ('swarp', 'hotpants', 'sex')}
     rep = {'found': {k: v for k, v in found.items() if v}, 'probed': sorted(found)}
+    z = importlib.import_module('zuds-pipeline_amd')
+    if found['hotpants'] or found['sex']:
+        try:
+            rep.update(tool_probes_small(workdir, found, z, subprocess))
+        except Exception as e:                               # noqa: a probe must not fail the bench
+            rep['probe_error'] = repr(e)
     if not found['swarp'] or files is None:
         return rep
-    z = importlib.import_module('zuds-pipeline_amd')
     try:
         inlist, wlist = os.path.join(workdir, 'images.in'), os.path.join(workdir, 'weight.in')
         open(inlist, 'w').write('\n'.join(files['sci']) + '\n')
@@ -301,12 +333,75 @@ def reference_tools(workdir, files, hip_products):
         rep['swarp'] = {'seconds': dt, 'mpix_s': len(files['sci']) * mine.size / 1e6 / dt, 'nthreads': 1,
                         'shape': list(ref.shape), 'hip_shape': list(mine.shape)}
         if ref.shape == mine.shape:
-            good = (ref != 0) & (mine != 0)
-            rel = np.abs(ref[good] - mine[good]) / np.maximum(np.abs(ref[good]), 1e-3)
-            rep['swarp']['median_rel_diff'] = float(np.median(rel))
-            rep['swarp']['p99_rel_diff'] = float(np.percentile(rel, 99))
+            rep['swarp'].update(rel_diff(ref, mine, (ref != 0) & (mine != 0), 1e-3))
     except Exception as e:                                   # noqa: a probe must not fail the bench
         rep['swarp_error'] = repr(e)
+    return rep
+
+
+def tool_probes_small(workdir, found, z, subprocess):
+    """hotpants / sex, if installed, on a synthetic 1024 x 1024 scene against the HIP path at the same settings."""
+    from scipy.ndimage import gaussian_filter
+    synth = importlib.import_module('zuds-pipeline_amd.synth')
+    rep = {}
+    n = 1024
+    rng = np.random.default_rng(77)
+    ref = np.full((n, n), 150.0)
+    nst = 1200
+    synth.add_stars(ref, rng.uniform(10, n - 10, nst), rng.uniform(10, n - 10, nst),
+                    np.exp(rng.uniform(np.log(3e3), np.log(8e4), nst)), 2.0)
+    sci = 1.3 * gaussian_filter(ref, 0.9, mode='nearest') + 20.0 + rng.normal(0, 3.0, ref.shape)
+    ref = ref + rng.normal(0, 0.5, ref.shape)
+    bpm = np.zeros((n, n), np.int16)
+    for _ in range(30):
+        bx, by = rng.integers(20, n - 20, 2)
+        bpm[by:by + 3, bx:bx + 3] = 1
+    sci, ref = sci.astype(np.float32), ref.astype(np.float32)
+    srms, rrms = np.full((n, n), 3.0, np.float32), np.full((n, n), 0.5, np.float32)
+    wcs_hdr = synth.ztf_wcs(n, n, tpv=False).to_header()
+    pth = {k: os.path.join(workdir, f'probe.{k}.fits') for k in
+           ('sci', 'ref', 'sci_rms', 'ref_rms', 'mask', 'out', 'out_rms', 'img', 'wgt', 'bkg', 'rms')}
+    for k, a in (('sci', sci), ('ref', ref), ('sci_rms', srms), ('ref_rms', rrms), ('mask', bpm)):
+        z.fits.write(pth[k], a, dict(wcs_hdr, NAXIS1=n, NAXIS2=n))
+    eng = z.Engine(0)
+    try:
+        if found['hotpants']:
+            big = float(np.sqrt(50000.0))
+            kw = dict(r=10.0, rss=24.0, nsx=10, nsy=10, nrx=1, nry=1, ko=4, bgo=0, tu=1e6, iu=1e6, tl=-1e3, il=-1e3)
+            cmd = hotpants_command(pth, kw['r'], kw['rss'], kw['nsx'], kw['nsy'], 1, big, kw['tu'], kw['tl'])
+            t0 = time.perf_counter()
+            subprocess.check_call(cmd.split())
+            dt = time.perf_counter() - t0
+            d, _, info = eng.subtract(sci, srms, ref, rrms, (bpm != 0).astype(np.uint8), **kw)
+            hp = z.fits.read(pth['out'])[0]
+            fill = np.float32(1e-30)
+            good = (hp != fill) & (d != fill)
+            rep['hotpants'] = {'seconds': dt, 'mpix_s': n * n / 1e6 / dt, 'command': cmd,
+                               'fill_pixels_agree': float(np.mean((hp == fill) == (d == fill))),
+                               'hip_kernel_sum': info['kernel_sum'], 'hip_stamps_used': info['nstamps_used']}
+            # (relative to the magnitudes that enter the difference: |I| + |I - D|, tests/test_subtract_gpu.py)
+            scale = np.abs(sci.astype(np.float64)) + np.abs(sci.astype(np.float64) - hp)
+            err = np.abs(hp.astype(np.float64) - d)[good] / scale[good]
+            rep['hotpants'].update({'median_rel_diff': float(np.median(err)), 'p99_rel_diff': float(np.percentile(err, 99)),
+                                    'pixels': int(good.sum())})
+        if found['sex']:
+            wgt = np.where(bpm != 0, 0.0, 1.0 / 9.0).astype(np.float32)
+            z.fits.write(pth['img'], sci, dict(wcs_hdr, NAXIS1=n, NAXIS2=n))
+            z.fits.write(pth['wgt'], wgt, dict(wcs_hdr, NAXIS1=n, NAXIS2=n))
+            pth['param'] = os.path.join(workdir, 'probe.param')
+            open(pth['param'], 'w').write('NUMBER\n')
+            cmd = sextractor_command(pth)
+            t0 = time.perf_counter()
+            subprocess.check_call(cmd.split())
+            dt = time.perf_counter() - t0
+            bk = eng.background(sci, wgt, mesh=128, filtersize=3, want=('bkg', 'rms'))
+            sb, sr = z.fits.read(pth['bkg'])[0], z.fits.read(pth['rms'])[0]
+            allpx = np.ones(sb.shape, bool)
+            rep['sex'] = {'seconds': dt, 'mpix_s': n * n / 1e6 / dt, 'command': cmd,
+                          'background': rel_diff(sb, np.asarray(bk[0]), allpx, 1e-3),
+                          'rms': rel_diff(sr, np.asarray(bk[1]), allpx, 1e-3)}
+    finally:
+        eng.close()
     return rep
 
 
