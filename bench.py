@@ -736,6 +736,8 @@ def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_ma
     engs, subs = [], []
     pool = ThreadPoolExecutor(max_workers=D)
     try:
+        if D >= 2:
+            eng.set_share(D + 1)                     # the coadd context too: its fused kernel yields CU slots
         for _ in range(D):
             e = z.Engine(local)
             e.set_share(max(args.pipelined_share, D))
@@ -804,6 +806,7 @@ def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_ma
         subs.clear()
     finally:
         pool.shutdown(wait=True)
+        eng.set_share(1)
         eng.set_stream(A.cuda_stream)
         for e in engs:
             e.close()

@@ -2521,6 +2521,8 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     long long ptk[5] = {0, 0, 0, 0, 0}, tc = 0;      // developer (ZM_FF_PROF=1): shader-clock sums per phase of this wave
 #define FD_TICK(k) do { if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
     if (prof) tc = __builtin_amdgcn_s_memtime();
+    const int budget = dbg >> 8;
+    int ngrab = 0;
     int slot = 0, buf = 0;
     for (;;) {
         const ff_hdr* H = &HR[slot];
@@ -2547,7 +2549,13 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         if (t2 < ntiles) hw2 = hdr_word(t2, f2);
         const bool grab = f2 == nfr - 1;
         int gnext = 0;
-        if (grab && tid == 0) gnext = atomicAdd(tilectr, 1);
+        if (grab) {
+            // a tile budget (yield mode: the workgroup retires after `budget` tiles and leaves its CU slot to
+            // whatever else is queued on the GPU; later workgroups of the launch carry on)
+            const bool allowed = budget == 0 || ngrab + 1 < budget;
+            if (tid == 0) gnext = allowed ? atomicAdd(tilectr, 1) : ntiles;
+            ++ngrab;
+        }
         const bool more = t1 < ntiles;
         // the raw planes of the next item: DMA into the raw tiles (free since the last barrier), its
         // box-OR tile into the other mask buffer; its x weights
@@ -2819,11 +2827,21 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     // headers, set to G by k_ff_headers)
     int ncu = 256;
     ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int G = std::min(ntiles, std::max(ncu, 1) * FF_WG_PER_CU);
+    int G = std::min(ntiles, std::max(ncu, 1) * FF_WG_PER_CU);
+    // yield mode (a context that shares the GPU: zm_ctx_set_share >= 2, or ZM_FF_YIELD = tiles per workgroup):
+    // more workgroups than fit, each retiring after a few tiles, so that the kernels of other streams get CU
+    // slots while this launch runs (the persistent form holds every slot for its whole 2.4 ms)
+    int budget = 0;
+    if (use_dma) {
+        const char* ye = getenv("ZM_FF_YIELD");
+        budget = ye ? atoi(ye) : (ctx->share >= 2 ? 2 : 0);
+        if (budget > 0 && (ntiles + budget - 1) / budget > G) G = (ntiles + budget - 1) / budget;
+        else budget = 0;
+    }
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
     // ZM_FF_DBG (developer, tools/ff_probe.py): 1 no pixel work, 2 no prep / LDS store, 4 no staging loads
-    const int dbg = getenv("ZM_FF_DBG") ? atoi(getenv("ZM_FF_DBG")) : 0;
+    const int dbg = (getenv("ZM_FF_DBG") ? (atoi(getenv("ZM_FF_DBG")) & 255) : 0) | (budget << 8);
     long long* prof = nullptr;
     const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
     const int nwv = (use_dma ? FD_THREADS : FF_THREADS) / 64;
