@@ -36,6 +36,7 @@ if int(os.environ.get('WORLD_SIZE', '1')) == 1:
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (packed FMA), spec
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
 PMC_PROFILES = ['r03_pmc_coadd_fused.json']     # newest first; each stamped with the hash of the kernel sources it measured
@@ -265,6 +266,29 @@ def launch(args):
         print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
         return 1
     return 0
+
+
+def copy_ceiling(z, eng, torch, stream, device):
+    """the rate a plain float4 copy kernel reaches on this GPU (read + write), the
+    practical ceiling beside the nominal 8 TB/s.  1 GiB each way, 10 launches between two events on the
+    engine's stream."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    src.zero_()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            z._lib.check(eng.L.zm_copy_probe_dev(eng.ctx, src.data_ptr(), dst.data_ptr(), n))
+        a.record(stream)
+        for _ in range(10):
+            z._lib.check(eng.L.zm_copy_probe_dev(eng.ctx, src.data_ptr(), dst.data_ptr(), n))
+        b.record(stream)
+    b.synchronize()
+    ms = a.elapsed_time(b) / 10
+    del src, dst
+    return {'kernel': 'k_copy4 (float4, grid-stride, 8 workgroups per CU)', 'bytes_each_way': n,
+            'avg_us': 1e3 * ms, 'GBs_read_plus_write': 2 * n / (ms * 1e-3) / 1e9}
 
 
 def hotpants_command(paths, r, rss, nsx, nsy, nreg_side, big_rms, tu, tl):
@@ -677,6 +701,27 @@ def main():
                 if pmc.get('lds_pipe'):
                     roofline['lds_frac'] = pmc['lds_pipe']['seconds_per_cu_per_launch'] / avg_s
                 roofline['valu_insts_per_px'] = pmc.get('valu_insts_per_px')
+            if world == 1:
+                try:
+                    cc = copy_ceiling(z, eng, torch, coadd.stream, device)
+                    roofline['copy_ceiling'] = cc
+                    roofline['frac_of_copy_ceiling'] = ach / cc['GBs_read_plus_write']
+                except Exception as e:                       # noqa: a probe must not fail the bench
+                    roofline['copy_ceiling_error'] = repr(e)
+        # SURVEY.md 8(d), the exception to the HBM bound: the convolution of the subtraction (25 B and
+        # 2 * 2 * (2r + 1)^2 flop per pixel) against both the HBM peak and the fp32 vector peak
+        apply_roof = None
+        if 'hp_apply' in kt and not args.no_subtract:
+            us = kt['hp_apply']['avg_us']
+            hw = int(2.5 * args.seeing)
+            flop = 4.0 * (2 * hw + 1) ** 2 * npx
+            apply_roof = {'kernel': f'k_hp_apply<{hw}>', 'avg_us': us, 'algorithmic_bytes': 25 * npx,
+                          'achieved_GBs': 25 * npx / (us * 1e-6) / 1e9, 'hbm_frac': 25 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          'flop': flop, 'achieved_TFLOPs': flop / (us * 1e-6) / 1e12,
+                          'valu_frac': flop / (us * 1e-6) / 1e12 / VALU_F32_PEAK_TFLOPS,
+                          'valu_peak_TFLOPs': VALU_F32_PEAK_TFLOPS,
+                          'what': 'template and template variance convolved with the spatially varying kernel, '
+                                  '(2r+1)^2 taps each; bound by fp32 vector issue, not HBM (SURVEY 8(d))'}
         out = {
             'metric': 'Mpix/s resample->coadd->subtract, 3072x3072 frames',
             'value': value, 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
@@ -698,6 +743,7 @@ def main():
                       'launcher': os.environ.get('ZM_BENCH_LAUNCHER', 'external' if world > 1 else 'none'),
                       'ranks': ranks},
             'legs': legs,
+            'apply_roofline': apply_roof,
             'kernels': kt,      # one extra step with every scope timed ('resample': the timed region)
             'roofline': roofline,
         }

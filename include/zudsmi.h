@@ -308,6 +308,10 @@ int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, float value,
                      int32_t bit, int64_t n);
 /* img += v: the 150-count pedestal (zuds/coadd.py:205-206, zuds/hotpants.py:29). */
 int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n);
+/* Measurement aid ("an achieved-copy ceiling with a float4 copy kernel"): dst = src,
+ * nbytes a multiple of 16, 16-byte aligned device pointers, on the context's stream.  bench.py times it
+ * and reports the roofline kernel against the rate it reaches as well as against the nominal 8 TB/s. */
+int zm_copy_probe_dev(zm_ctx* ctx, const void* src, void* dst, int64_t nbytes);
 
 /* ---- seeing estimate and detection cuts from pixels -------------------------- */
 /* Pixel-only stand-ins for the parts of estimate_seeing (zuds/seeing.py:10-118) and

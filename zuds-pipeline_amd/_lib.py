@@ -140,6 +140,7 @@ _SIGS = {
     'zm_mask_bad_dev': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     'zm_mask_flag_dev': (C.c_int, [_P, _P, _P, C.c_float, C.c_int32, C.c_int64]),
     'zm_add_scalar_dev': (C.c_int, [_P, _P, C.c_float, C.c_int64]),
+    'zm_copy_probe_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
     'zm_aperture_photometry': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P,
                                          C.c_double, _P, _P, _P]),
     'zm_aperture_photometry_dev': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P,

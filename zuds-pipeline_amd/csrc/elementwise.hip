@@ -1,6 +1,7 @@
 // Per-pixel bookkeeping kernels of the device-resident pipelines: weight <-> rms
 // maps, mask algebra, pedestal.  They restate numpy one-liners of the reference
 // (cited per entry point) so that a coadd -> subtract chain never leaves HBM.
+#include <algorithm>
 #include "zm_internal.h"
 
 #define EW_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream
@@ -87,6 +88,26 @@ extern "C" int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, fl
     ZM_CHECK(ctx && mask && img && n > 0, "zm_mask_flag_dev: bad argument");
     ZM_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_mask_flag, EW_GRID(n), mask, img, value, bit, n);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+// float4 copy, grid-stride over a launch sized to the chip (8 workgroups per CU): the rate a plain
+// streaming kernel reaches on this GPU, read + write
+__global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n4; p += stride) dst[p] = src[p];
+}
+
+extern "C" int zm_copy_probe_dev(zm_ctx* ctx, const void* src, void* dst, int64_t nbytes) {
+    ZM_CHECK(ctx && src && dst && nbytes > 0 && nbytes % 16 == 0 && ((uintptr_t)src & 15) == 0 &&
+             ((uintptr_t)dst & 15) == 0, "zm_copy_probe_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    int ncu = 256;
+    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int64_t n4 = nbytes / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)ncu * 8);
+    hipLaunchKernelGGL(k_copy4, dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
     ZM_HIP(hipGetLastError());
     return 0;
 }
