@@ -365,36 +365,32 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
     // ---- histogram.  bin = (int)(x / qscale + cste) with a correctly rounded quotient:
     // y = RN(1 / qscale), q0 = RN(x y), r = RN(x - q0 qscale), q = RN(q0 + r y) is the
     // correctly rounded x / qscale (Markstein) unless the significand of qscale is all
-    // ones; three instructions instead of the ten of a division.  Consecutive pixels of a
-    // thread that fall into one bin (flat variance maps: all of them) are added at once.
+    // ones; three instructions instead of the ten of a division.
     for (int k = tid; k < BK_NLEVELS; k += BKF_THREADS) S->histo[k] = 0;
     __syncthreads();
     {
+        // one exec-masked LDS add per valid pixel, nothing else in the loop's control flow (a version that
+        // merged runs of equal bins paid four branches per pixel for a case - flat maps - that no longer
+        // comes here); the division that does not take the three-instruction form is a loop of its own
         const float qinv = 1.0f / q.qscale;
         const bool slow_div = (__float_as_uint(q.qscale) & 0x7fffffu) == 0x7fffffu;
-        int cur = -1, run = 0;
+        if (!slow_div) {
 #pragma unroll
-        for (int k = 0; k < BKF_PX; ++k) {
-            const float x = v[k];
-            int b = -1;
-            if (x == x) {
-                float qq;
-                if (slow_div) qq = x / q.qscale;
-                else {
-                    const float q0 = x * qinv;
-                    qq = fmaf(fmaf(-q0, q.qscale, x), qinv, q0);
-                }
-                b = (int)(qq + q.cste);
+            for (int k = 0; k < BKF_PX; ++k) {
+                const float x = v[k];
+                const float q0 = x * qinv;
+                const float qq = fmaf(fmaf(-q0, q.qscale, x), qinv, q0);
+                const int b = (int)(qq + q.cste);
+                if ((x == x) && b >= 0 && b < q.nlevels) atomicAdd(&S->histo[b], 1);
             }
-            if (!(b >= 0 && b < q.nlevels)) b = -1;
-            if (b != cur) {
-                if (cur >= 0) atomicAdd(&S->histo[cur], run);
-                cur = b;
-                run = 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < BKF_PX; ++k) {
+                const float x = v[k];
+                const int b = (int)(x / q.qscale + q.cste);
+                if ((x == x) && b >= 0 && b < q.nlevels) atomicAdd(&S->histo[b], 1);
             }
-            ++run;
         }
-        if (cur >= 0) atomicAdd(&S->histo[cur], run);
     }
     __syncthreads();
     if (dbg == 3) { if (S->histo[tid] == -5) D->valid = 7; return; }
@@ -454,8 +450,11 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
 // exactly and sigma is 0 - the result of the general path - and a min / max / count of the weights,
 // taken while the pixels are loaded, replaces the divisions and the moment passes; only a mesh
 // whose weights vary reads them again (SEL 2) and takes the general path a second time.
+#ifndef BKF_WPS
+#define BKF_WPS 4                     // waves per SIMD the register budget is set for (4: two workgroups per CU)
+#endif
 template <int SEL>
-__global__ __launch_bounds__(BKF_THREADS, 4) void k_mesh_stats_fast(const bk_batch B, int nx, int ny, int mesh,
+__global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const bk_batch B, int nx, int ny, int mesh,
                                                                  int nbx, int nby, float wthresh, int vec_ok,
                                                                  int dbg, mesh_dump* __restrict__ dump) {
     extern __shared__ char smem_raw[];
