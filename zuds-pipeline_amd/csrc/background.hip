@@ -473,15 +473,21 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
     mesh_dump* D1 = D0 + (size_t)(NM - 1) * nby * nbx;              // variance statistic
 
     // ---- load: BKF_PX / 4 passes of BKF_ROWS rows x 128 columns, 4 px per thread per pass
+    // A pixel outside the mesh or the frame gets the weight -inf, a frame without weights the weight 1 and
+    // the threshold -inf: the classification below is then two comparisons per pixel, with no terms for
+    // the mesh edge or the missing plane (as separate conditions they were carried as 64-bit masks per pixel,
+    // spilled to lanes of a VGPR at this kernel's register budget)
     float v[BKF_PX];
     float wmn = __builtin_inff(), wmx = -__builtin_inff();
     int wcnt = 0;
+    const float pinf = __builtin_inff();
+    const float thr = wgt ? wthresh : -pinf;
     const int c4 = (tid & 31) * 4, r32 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < BKF_PX / 4; ++k) {
         const int row = BKF_ROWS * k + r32;
         float pv[4] = {qnan, qnan, qnan, qnan};
-        float pw[4] = {1.f, 1.f, 1.f, 1.f};
+        float pw[4] = {-pinf, -pinf, -pinf, -pinf};
         if (row < h && c4 < w) {
             const size_t idx = (size_t)(y0 + row) * nx + x0 + c4;
             if (vec_ok && c4 + 3 < w) {
@@ -492,31 +498,32 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
                 if (wgt) {
                     float4 b = *reinterpret_cast<const float4*>(wgt + idx);
                     pw[0] = b.x; pw[1] = b.y; pw[2] = b.z; pw[3] = b.w;
+                } else {
+                    pw[0] = pw[1] = pw[2] = pw[3] = 1.f;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (c4 + j < w) {
                         if (SEL != 1) pv[j] = img[idx + j];
-                        if (wgt) pw[j] = wgt[idx + j];
+                        pw[j] = wgt ? wgt[idx + j] : 1.f;
                     }
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bool good = (row < h) && (c4 + j < w);
-            if (wgt) good = good && pw[j] > wthresh;
+            const float x = pw[j];
+            const bool good = x > thr;                                  // (false for NaN)
             if (SEL != 0) {
-                const float x = pw[j];
-                const bool in = good && (x > -BK_BIG) && (x == x);
-                wmn = in ? fminf(wmn, x) : wmn;
-                wmx = in ? fmaxf(wmx, x) : wmx;
+                const bool in = good && (x > -BK_BIG);
+                wmn = fminf(wmn, in ? x : pinf);
+                wmx = fmaxf(wmx, in ? x : -pinf);
                 wcnt += in ? 1 : 0;
                 if (SEL == 1) v[4 * k + j] = in ? x : qnan;          // inverted below, unless the mesh is flat
             }
             if (SEL != 1) {
                 const float val = pv[j];
-                v[4 * k + j] = (good && (val > -BK_BIG) && (val == val)) ? val : qnan;
+                v[4 * k + j] = (good && (val > -BK_BIG)) ? val : qnan;
             }
         }
     }
