@@ -211,11 +211,11 @@ struct meshf_lds {
     long long wsum[3][4];
 };
 
-// per-mesh hand-off from k_mesh_stats_fast to k_mesh_guess (global memory)
+// per-mesh hand-off from k_mesh_stats_fast to k_mesh_guess (global memory): the histogram itself; its
+// prefix arrays are built by k_mesh_guess (one wave per mesh, every mesh of the batch in flight), not at
+// the tail of the statistics workgroup, where half its waves idled and the CU slot was held meanwhile
 struct mesh_dump {
-    unsigned short p0[BK_NLEVELS];   // inclusive prefix of the counts (a fast-path mesh has at most 16384 pixels)
-    long long b1[BK_THREADS];        // exclusive block sums of h i
-    long long b2[BK_THREADS];        // exclusive block sums of h i i
+    unsigned short h[BK_NLEVELS];    // counts (a fast-path mesh has at most 16384 pixels)
     bk_quant q;
     double mean0;
     int valid;
@@ -394,53 +394,19 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
     }
     __syncthreads();
     if (dbg == 3) { if (S->histo[tid] == -5) D->valid = 7; return; }
-    // ---- prefix: the first 256 threads own 16 bins each; the prefix arrays and the
-    // quantisation go to global memory, the clip iterations run in k_mesh_guess
-    // (one wave per mesh, every mesh of the frame in flight at once)
+    // ---- the histogram goes out as 16-bit counts, 8 bins = one 16-byte store per thread; the prefix
+    // arrays and the clip iterations are k_mesh_guess's
     {
-        long long a0 = 0, a1 = 0, a2 = 0, e0 = 0, e1 = 0, e2 = 0;
-        int hloc[BK_PER];
-        const int lane = tid & 63, wave = tid >> 6;
-        if (tid < BK_THREADS) {
-#pragma unroll
-            for (int k = 0; k < BK_PER; ++k) {
-                const int i = tid * BK_PER + k;
-                const int hh = S->histo[i];
-                hloc[k] = hh;
-                a0 += hh;
-                a1 += (long long)hh * i;
-                a2 += (long long)hh * i * i;
-            }
-            e0 = a0; e1 = a1; e2 = a2;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                long long t0 = __shfl_up(e0, o), t1 = __shfl_up(e1, o), t2 = __shfl_up(e2, o);
-                if (lane >= o) { e0 += t0; e1 += t1; e2 += t2; }
-            }
-            if (lane == 63) { S->wsum[0][wave] = e0; S->wsum[1][wave] = e1; S->wsum[2][wave] = e2; }
-        }
-        __syncthreads();
-        if (tid < BK_THREADS) {
-            long long o0 = 0, o1 = 0, o2 = 0;
-            for (int ww = 0; ww < wave; ++ww) { o0 += S->wsum[0][ww]; o1 += S->wsum[1][ww]; o2 += S->wsum[2][ww]; }
-                        D->b1[tid] = o1 + e1 - a1;
-            D->b2[tid] = o2 + e2 - a2;
-            int run = (int)(o0 + e0 - a0);
-            int4* dst = reinterpret_cast<int4*>(D->p0 + tid * BK_PER);      // 8 prefixes of 16 bits per int4
-#pragma unroll
-            for (int k = 0; k < BK_PER; k += 8) {
-                unsigned w[4];
-#pragma unroll
-                for (int h2 = 0; h2 < 4; ++h2) {
-                    run += hloc[k + 2 * h2];
-                    const unsigned lo = (unsigned)run;
-                    run += hloc[k + 2 * h2 + 1];
-                    w[h2] = lo | ((unsigned)run << 16);
-                }
-                dst[k / 8] = make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]);
-            }
-            if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
-        }
+        static_assert(BK_NLEVELS == 8 * BKF_THREADS, "one 16-byte piece of the histogram per thread");
+        const int4 lo = *reinterpret_cast<const int4*>(&S->histo[8 * tid]);
+        const int4 hi = *reinterpret_cast<const int4*>(&S->histo[8 * tid + 4]);
+        int4 o;
+        o.x = (int)((unsigned)lo.x | ((unsigned)lo.y << 16));
+        o.y = (int)((unsigned)lo.z | ((unsigned)lo.w << 16));
+        o.z = (int)((unsigned)hi.x | ((unsigned)hi.y << 16));
+        o.w = (int)((unsigned)hi.z | ((unsigned)hi.w << 16));
+        reinterpret_cast<int4*>(D->h)[tid] = o;
+        if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
     }
 }
 
@@ -589,7 +555,7 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
 // One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
 __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__ dump, int n, int nmode,
                                                    int nslot, float* __restrict__ raw) {
-    __shared__ unsigned short P0[BK_NLEVELS];      // 16-bit as handed over: 16 KB of LDS per mesh, not 24
+    __shared__ __attribute__((aligned(16))) unsigned short P0[BK_NLEVELS];      // 16-bit: 8 KB of LDS per mesh
     __shared__ long long B1[BK_THREADS];
     __shared__ long long B2[BK_THREADS];
     const int m = blockIdx.x, z = blockIdx.y, lane = threadIdx.x;
@@ -605,14 +571,52 @@ __global__ __launch_bounds__(64) void k_mesh_guess(const mesh_dump* __restrict__
         if (lane == 0) { *ob = D->q.qzero; *os = 0.f; }
         return;
     }
-    const int4* src = reinterpret_cast<const int4*>(D->p0);          // 8 prefixes of 16 bits per int4
-    int4* dst = reinterpret_cast<int4*>(P0);
+    // prefix arrays of the histogram, 512 bins per pass: lane l holds bins 512 k + 8 l .. + 7 (one 16-byte
+    // piece, read coalesced), sums them locally, the wave scans the lane sums.  P0: inclusive prefix of the
+    // counts; B1 / B2: exclusive sums of h i and h i i per block of 16 bins (two lanes), as backguess_wave reads them
+    const int4* src = reinterpret_cast<const int4*>(D->h);
+    int4 piece[BK_NLEVELS / 8 / 64];
 #pragma unroll
-    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) piece[k] = src[k * 64 + lane];
+    unsigned run0 = 0;
+    long long run1 = 0, run2 = 0;
 #pragma unroll
-    for (int k = 0; k < BK_THREADS / 64; ++k) {
-        B1[k * 64 + lane] = D->b1[k * 64 + lane];
-        B2[k * 64 + lane] = D->b2[k * 64 + lane];
+    for (int k = 0; k < BK_NLEVELS / 8 / 64; ++k) {
+        const unsigned wv[4] = {(unsigned)piece[k].x, (unsigned)piece[k].y, (unsigned)piece[k].z, (unsigned)piece[k].w};
+        unsigned c[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[2 * j] = wv[j] & 0xffffu; c[2 * j + 1] = wv[j] >> 16; }
+        unsigned s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 += c[j]; s1 += c[j] * (unsigned)j; s2 += c[j] * (unsigned)(j * j); }
+        const long long base = (long long)(512 * k + 8 * lane);
+        const long long a1 = base * s0 + s1, a2 = base * base * s0 + 2 * base * s1 + s2;
+        unsigned e0 = s0;
+        long long e1 = a1, e2 = a2;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t0 = __shfl_up(e0, o);
+            const long long t1 = __shfl_up(e1, o), t2 = __shfl_up(e2, o);
+            if (lane >= o) { e0 += t0; e1 += t1; e2 += t2; }
+        }
+        // inclusive prefixes of this lane's 8 bins
+        unsigned p = run0 + e0 - s0;
+        unsigned w16[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p += c[2 * j];
+            const unsigned lo16 = p;
+            p += c[2 * j + 1];
+            w16[j] = lo16 | (p << 16);
+        }
+        reinterpret_cast<int4*>(P0)[k * 64 + lane] = make_int4((int)w16[0], (int)w16[1], (int)w16[2], (int)w16[3]);
+        if ((lane & 1) == 0) {                              // first lane of a 16-bin block: sums of everything before it
+            B1[32 * k + (lane >> 1)] = run1 + e1 - a1;
+            B2[32 * k + (lane >> 1)] = run2 + e2 - a2;
+        }
+        run0 += __shfl(e0, 63);
+        run1 += __shfl(e1, 63);
+        run2 += __shfl(e2, 63);
     }
     __syncthreads();
     backguess_wave(P0, B1, B2, D->q, D->mean0, ob, os);
