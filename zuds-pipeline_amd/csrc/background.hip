@@ -199,9 +199,11 @@ __device__ inline void histo_prefix(mesh_lds* S) {
 // registers (four 16-byte loads per plane), so HBM is read once and a mesh's
 // latency chain is short.  blockIdx.z selects the statistic: mode0 + z, mode 0 =
 // image, mode 1 = 1 / weight (variance level).
+#ifndef BKF_THREADS
 #define BKF_THREADS 512
+#endif
 #define BKF_WAVES (BKF_THREADS / 64)
-#define BKF_PX 32
+#define BKF_PX (16384 / BKF_THREADS)   // pixels of a 128 x 128 mesh per thread
 #define BKF_ROWS (BKF_THREADS / 32)   // mesh rows covered per load pass
 
 struct meshf_lds {
@@ -397,15 +399,23 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
     // ---- the histogram goes out as 16-bit counts, 8 bins = one 16-byte store per thread; the prefix
     // arrays and the clip iterations are k_mesh_guess's
     {
-        static_assert(BK_NLEVELS == 8 * BKF_THREADS, "one 16-byte piece of the histogram per thread");
-        const int4 lo = *reinterpret_cast<const int4*>(&S->histo[8 * tid]);
-        const int4 hi = *reinterpret_cast<const int4*>(&S->histo[8 * tid + 4]);
-        int4 o;
-        o.x = (int)((unsigned)lo.x | ((unsigned)lo.y << 16));
-        o.y = (int)((unsigned)lo.z | ((unsigned)lo.w << 16));
-        o.z = (int)((unsigned)hi.x | ((unsigned)hi.y << 16));
-        o.w = (int)((unsigned)hi.z | ((unsigned)hi.w << 16));
-        reinterpret_cast<int4*>(D->h)[tid] = o;
+        constexpr int NB = BK_NLEVELS / BKF_THREADS;       // bins per thread: 8 (one 16-byte store) or 4
+        static_assert(NB == 8 || NB == 4, "the histogram hand-over packs 8 or 4 bins per thread");
+        const int4 lo = *reinterpret_cast<const int4*>(&S->histo[NB * tid]);
+        if (NB == 8) {
+            const int4 hi = *reinterpret_cast<const int4*>(&S->histo[NB * tid + 4]);
+            int4 o;
+            o.x = (int)((unsigned)lo.x | ((unsigned)lo.y << 16));
+            o.y = (int)((unsigned)lo.z | ((unsigned)lo.w << 16));
+            o.z = (int)((unsigned)hi.x | ((unsigned)hi.y << 16));
+            o.w = (int)((unsigned)hi.z | ((unsigned)hi.w << 16));
+            reinterpret_cast<int4*>(D->h)[tid] = o;
+        } else {
+            int2 o;
+            o.x = (int)((unsigned)lo.x | ((unsigned)lo.y << 16));
+            o.y = (int)((unsigned)lo.z | ((unsigned)lo.w << 16));
+            reinterpret_cast<int2*>(D->h)[tid] = o;
+        }
         if (tid == 0) { D->q = q; D->mean0 = (double)(float)mean; D->valid = 1; }
     }
 }
