@@ -1123,14 +1123,15 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         auto tile_fetch_acc = [&](int t) {
             int i0, j0;
             tile_of(t, i0, j0);
-            const bool skip_corner = (t == 0) && (W > 1);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    // (entries outside the matrix, above the diagonal or in workgroup 0's corner are never
+                    // stored: they are fetched from a clamped address instead of being masked - sixteen 64-bit
+                    // predicates held across the loads overflowed the scalar registers into VGPR lanes)
                     const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                    const bool corner = skip_corner && i < k1 + nbn;           // j <= i: in the block
-                    accn[c][rg] = (i < nrows && j < n && j <= i && !corner) ? ld_sh(&A[(size_t)i * lda + j]) : 0.0;
+                    accn[c][rg] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
                 }
         };
         auto tile_fetch_panels = [&](int t) {
@@ -1141,8 +1142,9 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
                 const int e = tid + 256 * q, r = e >> 5, m = e & 31;
                 // (negated when it is written to LDS: arithmetic here would make every one of these
                 // loads wait for itself)
-                pa[q] = (i0 + r < nrows) ? ld_sh(&A[(size_t)(i0 + r) * lda + k0 + m]) : 0.0;
-                pb[q] = (j0 + r < n) ? ld_sh(&A[(size_t)(j0 + r) * lda + k0 + m]) : 0.0;
+                // (rows beyond the matrix feed tile rows / columns that are never stored: clamped, not masked)
+                pa[q] = ld_sh(&A[(size_t)min(i0 + r, nrows - 1) * lda + k0 + m]);
+                pb[q] = ld_sh(&A[(size_t)min(j0 + r, nrows - 1) * lda + k0 + m]);
             }
         };
         if ((w != 0 || W == 1) && nb == CH_NB && wu < ntile) tile_fetch_acc(wu);
