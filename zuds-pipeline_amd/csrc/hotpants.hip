@@ -1096,8 +1096,9 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         if (w == 0 && nb == CH_NB)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                // (entries outside the block or above its diagonal are replaced when D is formed: clamped, not masked)
                 const int i = 16 * (wave >> 1) + (lane >> 4) + 4 * q, j = 16 * (wave & 1) + (lane & 15);
-                if (i < nbn && j <= i) cpre[q] = ld_sh(&A[(size_t)(k1 + i) * lda + k1 + j]);
+                cpre[q] = ld_sh(&A[(size_t)min(k1 + i, nrows - 1) * lda + min(k1 + j, n - 1)]);
             }
         // trailing update: 64 x 64 tiles of the lower triangle dealt to workgroups 1 .. W - 1.
         // The loop over a workgroup's tiles is software-pipelined (the next tile is requested
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
                 const int e = tid + 256 * q;
-                dv[q] = e < CH_NB * (CH_NB + 1) ? ld_sh(&Dg[e]) : 0.0;
+                dv[q] = ld_sh(&Dg[min(e, CH_NB * (CH_NB + 1) - 1)]);
             }
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
