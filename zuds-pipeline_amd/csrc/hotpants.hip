@@ -1209,13 +1209,24 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             // four row pairs at a time: their loads go out together (one memory latency) and
             // the four register chains interleave
             while (pp0 < pend) {
+                // only the row pairs this wave really has (late steps leave a wave one or two of the four):
+                // the chains of absent pairs are not run
+                const int nq = min(4, (pend - pp0 + 7) >> 3);
+                auto chains = [&](auto NQ) __attribute__((always_inline)) {
 #pragma unroll
-                for (int m = 0; m < CH_NB; ++m) {
+                    for (int m = 0; m < CH_NB; ++m) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double ua = readlane_d(bj[q], m), ub = readlane_d(bj[q], 32 + m);
-                        bj[q] = fma(lrow[m], half ? ub : ua, bj[q]);
+                        for (int q = 0; q < decltype(NQ)::value; ++q) {
+                            const double ua = readlane_d(bj[q], m), ub = readlane_d(bj[q], 32 + m);
+                            bj[q] = fma(lrow[m], half ? ub : ua, bj[q]);
+                        }
                     }
+                };
+                switch (nq) {
+                    case 1: chains(std::integral_constant<int, 1>{}); break;
+                    case 2: chains(std::integral_constant<int, 2>{}); break;
+                    case 3: chains(std::integral_constant<int, 3>{}); break;
+                    default: chains(std::integral_constant<int, 4>{}); break;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bj[q] *= rdl;
