@@ -2314,7 +2314,10 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     // ---- staging, part 1: the DMA of an item's raw planes (every wave takes chunks of 64 pieces of 16 B)
     auto dma = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
         if (!H->use_lds || (dbg & 4)) return;
-        const zm_ff* F = fr + f;
+        // the frame descriptor BY VALUE: its scalar loads go out together, ahead of the branches below (read field
+        // by field where it is used, every section began with a scalar-cache round trip of its own)
+        const zm_ff Fv = fr[f];
+        const zm_ff* F = &Fv;
         const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
         const int nq = bw4 * bh;
@@ -2327,14 +2330,15 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
             const int p = chunk * 64 + lane;
             if (p < nq) {
                 const int row = (int)(((float)p + 0.5f) * inv4), c = p - row * bw4;
-                const size_t gy = (size_t)min(max(by0 + row, 0), ny - 1);
+                // (element offsets of a plane fit 32 bits: one uniform base + an unsigned lane offset per load)
+                const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
                 const int gx = bx0 + 4 * c;
-                size_t oa, ob;
+                unsigned oa, ob;
                 if (prepped) {
-                    oa = (gy * sp + min(max(gx, 0), sp - 2)) * 2;
-                    ob = (gy * sp + min(max(gx + 2, 0), sp - 2)) * 2;
+                    oa = (gy * (unsigned)sp + (unsigned)min(max(gx, 0), sp - 2)) * 2u;
+                    ob = (gy * (unsigned)sp + (unsigned)min(max(gx + 2, 0), sp - 2)) * 2u;
                 } else {
-                    oa = ob = gy * nx + min(max(gx, 0), nx - 4);
+                    oa = ob = gy * (unsigned)nx + (unsigned)min(max(gx, 0), nx - 4);
                 }
                 ff_glds16(gI + oa, RAWI + (size_t)chunk * 1024);
                 ff_glds16(gW + ob, RAWW + (size_t)chunk * 1024);
@@ -2350,9 +2354,9 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                 const int p = chunk * 64 + lane;
                 if (p < nm) {
                     const int row = (int)(((float)p + 0.5f) * inv8), c8 = p - row * bwm8;
-                    const size_t gy = (size_t)min(max(by0 + row, 0), ny - 1);
+                    const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
                     const int gxm = min(max(mx0 + 8 * c8, 0), F->mpitch - 8);
-                    ff_glds16(zm_gptr(F->mbox) + (gy * F->mpitch + gxm), M + (size_t)chunk * 1024);
+                    ff_glds16(zm_gptr(F->mbox) + (gy * (unsigned)F->mpitch + (unsigned)gxm), M + (size_t)chunk * 1024);
                 }
             }
         }
@@ -2361,15 +2365,16 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
             const int ia = bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1));
             const int ib = bk_col(F->nbx, F->invmesh, min(max(bx0 + bw - 1, 0), nx - 1));
             if (wv <= ib - ia && wv < FD_YCOLS && lane < bh) {
-                const size_t gy = (size_t)min(max(by0 + lane, 0), ny - 1);
-                ff_glds16(zm_gptr(F->ytab) + (gy * F->ytp + min(ia + wv, F->ytp - 1)),
+                const unsigned gy = (unsigned)min(max(by0 + lane, 0), ny - 1);
+                ff_glds16(zm_gptr(F->ytab) + (gy * (unsigned)F->ytp + (unsigned)min(ia + wv, F->ytp - 1)),
                           reinterpret_cast<char*>(YT) + (size_t)wv * FD_YROWS * 16);
             }
         }
     };
     // the x weights of the box columns of an item (threads 0 .. bw - 1), read by its prep pass
     auto xweights = [&](const ff_hdr* H, int f) __attribute__((always_inline)) {
-        const zm_ff* F = fr + f;
+        const zm_ff Fv = fr[f];
+        const zm_ff* F = &Fv;
         if (!H->use_lds || !F->ytab || F->src) return;
         if (tid < H->bw) {
             const int gx = H->bx0 + tid;
@@ -2380,7 +2385,8 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     // ---- staging, part 2: raw quads -> prepped tile (background off, variance, bad pixels, fill)
     auto prep_impl = [&](const ff_hdr* H, int f, int mb, auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        const zm_ff* F = fr + f;
+        const zm_ff Fv = fr[f];
+        const zm_ff* F = &Fv;
         const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
         const int nq = bw4 * bh;
