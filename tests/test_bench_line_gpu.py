@@ -1,0 +1,42 @@
+"""The one JSON line of bench.py (the driver's contract): every key the contract names, the roofline and
+cpu_baseline objects with their fields, the bookkeeping consistent (value = Mpix of the steps / time).
+Run at a reduced size so that it takes seconds - the numbers are not looked at, the shape of the line is."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '2048', '--frames', '4', '--steps', '2', '--warmup', '1',
+           '--no-clocks', '--no-nightly', '--no-secondary', '--no-pipelined', '--cpu-frames', '1']
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'Mpix/s' and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    mpix = (4 + 1) * 2048 * 2048 / 1e6
+    assert d['value'] == pytest.approx(mpix / (d['ms_per_step'] * 1e-3), rel=1e-6)
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'copy_ceiling', 'frac_of_copy_ceiling'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'])
+    # counters are quoted only for the workload and the sources they were taken on: not at this size
+    assert r['traffic'] is None
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
+    assert d['apply_roofline']['valu_frac'] > 0
