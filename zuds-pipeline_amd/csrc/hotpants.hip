@@ -969,6 +969,23 @@ __device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, in
     if (bad && lane == 0 && fail) atomicAdd(fail, 1);
 }
 
+template <int SRC>
+__device__ __forceinline__ double row16_bcast_d(double v) {
+    // lane SRC of every row of 16 lanes to all lanes of that row (row_newbcast: 0x150 + SRC)
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + SRC, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + SRC, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void hp_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        hp_static_for<I + 1, N>(fn);
+    }
+}
+
 // ---- the whole factorisation in one launch ----------------------------------------
 // W workgroups per region walk the 32-column blocks together; a region-wide barrier (a
 // monotone counter in global memory, agent-scope release / acquire) separates the panel
@@ -1042,6 +1059,10 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ double Li[64][CH_NB + 2];        // pitch 34: conflict-free ds_read_b64 of MFMA operands
     __shared__ double Lj[64][CH_NB + 2];
+    // coefficients of the panel chains from the current factor: Cf[m][li] = {c[li][m], c[li + 16][m]},
+    // c[i][m] = -(L[i][m] / L[m][m]) for i > m, else 0; Rd[i] = 1 / L[i][i] (what is published per block)
+    __shared__ double2 Cf[CH_NB][16];
+    __shared__ double Rd[CH_NB];
     const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
     double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
     double* Dg2 = Dgall + (size_t)reg * 2 * CH_NB * (CH_NB + 1);
@@ -1060,10 +1081,18 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
         __syncthreads();
         if (tid < 64) chol_diag_wave_panel_t<0>(D, nb, &fail[reg]);
         __syncthreads();
-        for (int e = tid; e < CH_NB * (CH_NB + 1); e += 256) st_sh(&Dg[e], D[e / (CH_NB + 1)][e % (CH_NB + 1)]);
+        // published: the chain coefficients and reciprocal diagonals (what every workgroup's panel solve
+        // reads; this workgroup keeps them in Cf / Rd for its own rows); L itself goes to A
         for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int i = e >> 5, j = e & 31;
-            if (i < nb && j <= i) st_sh(&A[(size_t)(k0 + i) * lda + k0 + j], D[i][j]);
+            const int m = e >> 5, i = e & 31;                      // column m of row i
+            const double cv = (i > m) ? -(D[i][m] * D[m][CH_NB]) : 0.0;
+            reinterpret_cast<double*>(&Cf[m][i & 15])[i >> 4] = cv;
+            st_sh(&Dg[2 * (m * 16 + (i & 15)) + (i >> 4)], cv);
+            if (i < nb && m <= i) st_sh(&A[(size_t)(k0 + i) * lda + k0 + m], D[i][m]);
+        }
+        if (tid < CH_NB) {
+            Rd[tid] = D[tid][CH_NB];
+            st_sh(&Dg[CH_NB * CH_NB + tid], D[tid][CH_NB]);
         }
     };
     if (w == 0) {
@@ -1149,95 +1178,83 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
             }
         };
         if ((w != 0 || W == 1) && nb == CH_NB && wu < ntile) tile_fetch_acc(wu);
-        // the first panel rows of this step are requested before anything waits: they were
-        // final at the last barrier, so their latency overlaps that of the published factor
-        const int half = lane >> 5, pli = lane & 31;
-        double bj[4];
-        bool act[4];
-        auto panel_fetch = [&](int pp0) {
+        // (b) panel rows X L^T = B.  A wave takes 16-row strips of its workgroup's slice in the accumulator layout
+        // of the matrix cores (row = lk + 4 rg, column = li + 16 c: loads and stores along rows) and runs the
+        // chain on them in place: step m broadcasts column m inside each row of 16 lanes (DPP row_newbcast) and
+        // every lane subtracts u_m c[col][m] - the unscaled chain of the first form of this kernel (lane = column,
+        // two rows per wave, readlanes), operation for operation, at a third of its instructions per row; the
+        // form k_chol_tp runs.  The first strip is requested before anything waits: it was final at the last
+        // barrier, so its latency overlaps that of the published coefficients.  Rows beyond the slice come from
+        // clamped addresses and are not stored.
+        const int nslice = max(pend - pbeg, 0);
+        // (a wave takes HALF a strip - rows lk + 4 rg for two of the four rg - so that the 27 rows a workgroup has
+        // at 26 workgroups per region keep all four waves busy: the chain is as long, its steps half as wide)
+        const int ntask = 2 * ((nslice + 15) >> 4);
+        double xb[2][2];
+        auto panel_fetch = [&](int t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = pp0 + 8 * q + half;
-                act[q] = p < pend && pli < nb;
-                bj[q] = act[q] ? ld_sh(&A[(size_t)(k1 + p) * lda + k0 + pli]) : 0.0;
-            }
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = k1 + pbeg + 16 * (t >> 1) + lk + 4 * (2 * (t & 1) + h);
+                    xb[c][h] = ld_sh(&A[(size_t)min(prow, nrows - 1) * lda + min(k0 + 16 * c + li, n - 1)]);
+                }
         };
-        int pp0 = pbeg + 2 * wave;
-        if (pp0 < pend) panel_fetch(pp0);
-        // (a) the published factor of block kb; workgroup 0 factored it itself and still has it in D
-        __syncthreads();                                         // D of the previous step is consumed
+        if (wave < ntask) panel_fetch(wave);
+        // (a) the published coefficients of block kb; workgroup 0 computed them itself and still has them
+        __syncthreads();                                         // Cf / Rd of the previous step are consumed
         if (w != 0) {
-            // all five loads of a thread first, then the LDS stores: one latency, not five
+            // all loads of a thread first, then the LDS stores: one latency
             const double* Dg = Dg2 + (size_t)(kb & 1) * CH_NB * (CH_NB + 1);
             constexpr int ND = (CH_NB * (CH_NB + 1) + 255) / 256;
             double dv[ND];
 #pragma unroll
-            for (int q = 0; q < ND; ++q) {
-                const int e = tid + 256 * q;
-                dv[q] = ld_sh(&Dg[min(e, CH_NB * (CH_NB + 1) - 1)]);
-            }
+            for (int q = 0; q < ND; ++q) dv[q] = ld_sh(&Dg[min(tid + 256 * q, CH_NB * (CH_NB + 1) - 1)]);
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
                 const int e = tid + 256 * q;
-                if (e < CH_NB * (CH_NB + 1)) D[e / (CH_NB + 1)][e % (CH_NB + 1)] = dv[q];
+                if (e < CH_NB * CH_NB) reinterpret_cast<double*>(&Cf[0][0])[e] = dv[q];
+                else if (e < CH_NB * (CH_NB + 1)) Rd[e - CH_NB * CH_NB] = dv[q];
             }
         }
         __syncthreads();
         CF_TICK(0);
-        // (b) panel rows X L^T = B, two rows per wave (one per half): lane i of a half keeps row i
-        // of L in registers; step m broadcasts the finished x_m with a readlane and every lane
-        // i > m subtracts L[i][m] x_m - a 32-step register chain per row pair instead of 496
-        // dependent LDS reads per row.  Workgroup 0 also keeps its rows in LDS (Li) for the
-        // look-ahead.
-        {
-            // u_m = b_m - sum_{k<m} x_k L[m][k] is carried unscaled: lane i subtracts
-            // u_m (L[i][m] / L[m][m]) for m < i and multiplies by 1 / L[i][i] once at the end, so a
-            // step is the broadcast of u_m (readlanes, one per half) and one FMA per row
-            // (all LDS reads first, unconditionally: reads inside a condition are waited for one by one)
-            double lrow[CH_NB];
-            {
-                double lr[CH_NB], rr[CH_NB];
+        for (int t = wave; t < ntask; t += 4) {
+            // columns of a partial (last) block beyond nb count as zero, as the masked loads of the first form did
+            if (nb < CH_NB) {
 #pragma unroll
-                for (int m = 0; m < CH_NB; ++m) { lr[m] = D[pli][m]; rr[m] = D[m][CH_NB]; }
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int m = 0; m < CH_NB; ++m) {
-                    const double t = -(lr[m] * rr[m]);
-                    lrow[m] = (pli > m) ? t : 0.0;
-                }
+                    for (int h = 0; h < 2; ++h) xb[c][h] = (16 * c + li < nb) ? xb[c][h] : 0.0;
             }
-            const double rdl = D[pli][CH_NB];                    // 1 / L[i][i]
-            // four row pairs at a time: their loads go out together (one memory latency) and
-            // the four register chains interleave
-            while (pp0 < pend) {
-                // only the row pairs this wave really has (late steps leave a wave one or two of the four):
-                // the chains of absent pairs are not run
-                const int nq = min(4, (pend - pp0 + 7) >> 3);
-                auto chains = [&](auto NQ) __attribute__((always_inline)) {
+            hp_static_for<0, CH_NB - 1>([&](auto M) __attribute__((always_inline)) {
+                constexpr int m = decltype(M)::value;
+                constexpr int tm = m >> 4, sl = m & 15;
+                const double2 cf = Cf[m][li];
 #pragma unroll
-                    for (int m = 0; m < CH_NB; ++m) {
-#pragma unroll
-                        for (int q = 0; q < decltype(NQ)::value; ++q) {
-                            const double ua = readlane_d(bj[q], m), ub = readlane_d(bj[q], 32 + m);
-                            bj[q] = fma(lrow[m], half ? ub : ua, bj[q]);
-                        }
-                    }
-                };
-                switch (nq) {
-                    case 1: chains(std::integral_constant<int, 1>{}); break;
-                    case 2: chains(std::integral_constant<int, 2>{}); break;
-                    case 3: chains(std::integral_constant<int, 3>{}); break;
-                    default: chains(std::integral_constant<int, 4>{}); break;
+                for (int h = 0; h < 2; ++h) {
+                    const double u = row16_bcast_d<sl>(xb[tm][h]);
+                    if (m < 15) xb[0][h] = fma(cf.x, u, xb[0][h]);
+                    xb[1][h] = fma(cf.y, u, xb[1][h]);
                 }
+            });
+            const double r0 = Rd[li], r1 = Rd[16 + li];
+            double x0[2], x1[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bj[q] *= rdl;
+            for (int h = 0; h < 2; ++h) { x0[h] = xb[0][h] * r0; x1[h] = xb[1][h] * r1; }
+            const int tcur = t;
+            if (t + 4 < ntask) panel_fetch(t + 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = pp0 + 8 * q + half;
-                    if (act[q]) st_sh(&A[(size_t)(k1 + p) * lda + k0 + pli], bj[q]);
-                    if (w == 0 && p < CH_NB) Li[p][pli] = (p < pend) ? bj[q] : 0.0;
+            for (int h = 0; h < 2; ++h) {
+                const int pr = 16 * (tcur >> 1) + lk + 4 * (2 * (tcur & 1) + h), p = pbeg + pr;
+                if (pr < nslice) {
+                    if (li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + li], x0[h]);
+                    if (16 + li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + 16 + li], x1[h]);
                 }
-                pp0 += 32;
-                if (pp0 < pend) panel_fetch(pp0);
+                if (w == 0 && p < CH_NB) {
+                    Li[p][li] = (pr < nslice) ? x0[h] : 0.0;
+                    Li[p][16 + li] = (pr < nslice) ? x1[h] : 0.0;
+                }
             }
         }
         if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
@@ -1365,23 +1382,6 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #define CT_WAVES (CT_THREADS / 64)
 #define CT_NQ 3                          // strips per wave and pass
 #define CT_NS (CH_NB * CH_NB / CT_THREADS)   // chunk entries staged per thread
-
-template <int SRC>
-__device__ __forceinline__ double row16_bcast_d(double v) {
-    // lane SRC of every row of 16 lanes to all lanes of that row (row_newbcast: 0x150 + SRC)
-    const unsigned long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + SRC, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + SRC, 0xf, 0xf, false);
-    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-template <int I, int N, typename Fn>
-__device__ __forceinline__ void hp_static_for(Fn&& fn) {
-    if constexpr (I < N) {
-        fn(std::integral_constant<int, I>{});
-        hp_static_for<I + 1, N>(fn);
-    }
-}
 
 // (one out-of-line copy for the four instances of ct_pass; k_chol_fused keeps its inlined one)
 __device__ __noinline__ void chol_diag_wave_panel_call(double (*D)[CH_NB + 1], int nb, int* fail) {
