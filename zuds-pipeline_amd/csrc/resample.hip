@@ -2313,13 +2313,15 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
 
     // ---- staging, part 1: the DMA of an item's raw planes (every wave takes chunks of 64 pieces of 16 B)
     auto dma = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
-        if (!H->use_lds || (dbg & 4)) return;
-        // the frame descriptor BY VALUE: its scalar loads go out together, ahead of the branches below (read field
-        // by field where it is used, every section began with a scalar-cache round trip of its own)
+        // the frame descriptor BY VALUE and the header fields, all requested before the first branch: their
+        // scalar loads and LDS reads go out together (read where they are used, every section began with a
+        // round trip of its own)
         const zm_ff Fv = fr[f];
         const zm_ff* F = &Fv;
-        const int nx = F->nx, ny = F->ny, sp = F->spitch;
+        const int use_lds = H->use_lds;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        if (!use_lds || (dbg & 4)) return;
+        const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int nq = bw4 * bh;
         const bool prepped = F->src != nullptr;
         const float ZM_GLOBAL* gI = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : zm_gptr(F->img);
@@ -2375,9 +2377,10 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     auto xweights = [&](const ff_hdr* H, int f) __attribute__((always_inline)) {
         const zm_ff Fv = fr[f];
         const zm_ff* F = &Fv;
-        if (!H->use_lds || !F->ytab || F->src) return;
-        if (tid < H->bw) {
-            const int gx = H->bx0 + tid;
+        const int use_lds = H->use_lds, hbw = H->bw, hbx0 = H->bx0;     // (requested before the first branch)
+        if (!use_lds || !F->ytab || F->src) return;
+        if (tid < hbw) {
+            const int gx = hbx0 + tid;
             const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), F->nx - 1));
             XW[(tid & 3) * FD_XQ + (tid >> 2)] = bk_xweights(bk_dx(F->nbx, F->invmesh, gx, i0));
         }
@@ -2387,12 +2390,13 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         constexpr bool FAST = decltype(fast_tag)::value;
         const zm_ff Fv = fr[f];
         const zm_ff* F = &Fv;
-        const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        const float hvs = H->vscale;
+        const int nx = F->nx, ny = F->ny, sp = F->spitch;
         const int nq = bw4 * bh;
         const bool prepped = F->src != nullptr;
         const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr && !prepped;
-        const float vs = H->vscale, wth = F->wthresh;
+        const float vs = hvs, wth = F->wthresh;
         const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
         const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;   // (q + 0.5) / bw4 floors right for q < 2^12
         const int ia = has_y ? bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1)) : 0;
@@ -2453,8 +2457,9 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         }
     };
     auto prep = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
-        if (!H->use_lds || (dbg & 2)) return;
-        if (H->fast) prep_impl(H, f, mb, std::true_type{});
+        const int use_lds = H->use_lds, fast = H->fast;                  // (both requested before the first branch)
+        if (!use_lds || (dbg & 2)) return;
+        if (fast) prep_impl(H, f, mb, std::true_type{});
         else prep_impl(H, f, mb, std::false_type{});
     };
     const int nty = ntiles / ntx;
