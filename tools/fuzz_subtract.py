@@ -1,7 +1,7 @@
-"""Developer tool: differential fuzzing of the subtraction across solver layouts - the same random scene
-and parameters through one context that owns the GPU (W = 26 workgroups per region of the fused Cholesky)
-and through contexts declared to share it 3 and 9 ways (W = 8, 2): difference image, noise image and the
-fit summary must agree bit for bit (the solver's arithmetic does not depend on who computes which tile).
+"""Developer tool: differential fuzzing of the subtraction across the two forms of the solver - the same random
+scene and parameters through one context that owns the GPU (k_chol_fused: 26 workgroups per region) and
+through contexts declared to share it 3 and 9 ways (k_chol_tp: one workgroup per region): difference image,
+noise image and the fit summary must agree bit for bit (the two forms run the same arithmetic).
 usage: fuzz_subtract.py [ncases] [seed]"""
 import importlib
 import os
