@@ -267,6 +267,23 @@ int zm_comm_destroy(zm_comm* comm);
 int zm_coadd_reduce_dev(zm_ctx* ctx, zm_comm* comm, float* s1s0, int64_t npix);
 int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int nx, int ny, int kind,
                        float* cov);
+/* Host arithmetic of the banded schedule, callable without a GPU (tests replay it for every rank):
+ * zm_comm_band_bounds: rows [bounds[g], bounds[g + 1]) belong to rank g, g < world - the split of
+ * np.array_split / zuds/mpi.py:36-64 (bounds: world + 1 entries).
+ * zm_comm_mask_plan: what zm_mask_reduce_dev sends / receives / gathers for one rank, in elements. */
+#define ZM_COMM_MAX_RANKS 64
+typedef struct {
+    int32_t world, rank;
+    int64_t band_px;                          /* slot size: rows of the largest band x nx */
+    int64_t my_px;                            /* this rank's band */
+    int64_t send_off[ZM_COMM_MAX_RANKS];      /* band g of this rank's plane (offset, count) -> rank g */
+    int64_t send_cnt[ZM_COMM_MAX_RANKS];
+    int64_t recv_off[ZM_COMM_MAX_RANKS];      /* slot of rank g in the receive buffer, my_px elements each */
+    int64_t recv_cnt[ZM_COMM_MAX_RANKS];
+    int64_t gather_off[ZM_COMM_MAX_RANKS];    /* folded band of rank g in the all-gather buffer */
+} zm_mask_plan;
+int zm_comm_band_bounds(int nrows, int world, int32_t* bounds);
+int zm_comm_mask_plan(int nx, int ny, int world, int rank, zm_mask_plan* plan);
 /* Resample the frames to `wout` into a resident stack [nframes][ony][onx][2]
  * of (value, weight) pairs (the CLIPPED multi-GPU exchange operates on it).
  * out_mask_partial (may be NULL): the mask coadd of these frames with the -1 marker

@@ -210,3 +210,68 @@ def test_job_params_follow_prepare_hotpants_and_clamp_large_seeing():
         p = hp.job_params(9.0, 3072, 3080, 3, 0, 0)
     assert len(w) == 1 and 'clamped' in str(w[0].message)
     assert int(p['r']) == 15 and int(p['rss']) == 48
+
+
+def test_swarp_keyword_classes_raise_ignore_or_warn():
+    """zuds/swarp.py:76-78,100-102 forward every keyword to SWarp.  Here: keys the
+    engine implements are translated; keys that change the operator and are not implemented raise
+    unless they carry the value the engine works with; bookkeeping keys are ignored; the rest warns."""
+    import importlib
+    import warnings
+    sw = importlib.import_module('zuds-pipeline_amd.swarp')
+    base = dict(sw._SCI_DEFAULTS)
+    # implemented
+    p = sw._params_from_kws(base, {'weight_thresh': '1e-3', 'back_filtersize': 5, 'RESAMPLING_TYPE': 'bilinear'})
+    assert (p['weight_thresh'], p['back_filtersize'], p['resample']) == (1e-3, 5, 'BILINEAR')
+    # operator keys at the engine's value: accepted; at another value: ValueError
+    assert sw._params_from_kws(base, {'PROJECTION_TYPE': 'TPV', 'CENTER_TYPE': 'ALL', 'OVERSAMPLING': 0,
+                                      'pixelscale_type': 'median', 'PROJECTION_ERR': 0.01}) == base
+    for bad in ({'PROJECTION_TYPE': 'ZEA'}, {'CENTER_TYPE': 'MANUAL'}, {'CENTER': '10:00:00, +20:00:00'},
+                {'PIXEL_SCALE': 0.5}, {'oversampling': 2}, {'INTERPOLATE': 'Y'}, {'FSCALASTRO_TYPE': 'NONE'},
+                {'BACK_TYPE': 'MANUAL'}, {'BACK_DEFAULT': 100.0}, {'IMAGE_SIZE': '1000,1000'},
+                {'CELESTIAL_TYPE': 'GALACTIC'}, {'WEIGHT_TYPE': 'MAP_RMS'}, {'BLANK_BADPIXELS': 'Y'}):
+        with pytest.raises(ValueError, match='SWarp keyword'):
+            sw._params_from_kws(base, bad)
+    # bookkeeping: silently dropped
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert sw._params_from_kws(base, {'NTHREADS': 8, 'VMEM_DIR': '/x', 'MEM_MAX': 1024, 'verbose_type': 'QUIET',
+                                          'REFINED': True, 'DELETE_TMPFILES': 'N', 'COMBINE_BUFSIZE': 64}) == base
+    # anything else: one warning per key
+    sw._warned_keys.discard('SOME_FUTURE_KEY')
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert sw._params_from_kws(base, {'SOME_FUTURE_KEY': 1}) == base
+        sw._params_from_kws(base, {'SOME_FUTURE_KEY': 2})
+    assert len(w) == 1 and 'SOME_FUTURE_KEY' in str(w[0].message)
+    # an unknown COMBINE_TYPE still fails where the parameters are built (engine.coadd_params)
+    z = pkg()
+    with pytest.raises(ValueError):
+        z.coadd_params(**sw._params_from_kws(base, {'COMBINE_TYPE': 'CHI-MEAN'}))
+
+
+def test_hotpants_keyword_classes_raise_ignore_or_warn():
+    """zuds/hotpants.py:86-87: every -key value goes to hotpants.  Implemented keys are translated
+    (incl. the Gaussian basis -ng); -c only as the reference's own `-c t`; -v / -hki ignored; extra
+    products warn once; every other switch changes the operator and raises."""
+    import importlib
+    import warnings
+    hp = importlib.import_module('zuds-pipeline_amd.hotpants')
+    p = hp.job_params(2.0, 512, 512, 1, 0, 0, {'ng': '2 4 0.9 2 2.1', 'c': 't', 'n': 'i', 'fi': 1e-20})
+    assert p['deg'] == [4, 2] and p['sigma'] == [0.9, 2.1] and p['normalize'] == 0 and p['fi'] == 1e-20
+    hpp = pkg().hp_params(**p)
+    assert hpp.ngauss == 2 and list(hpp.deg)[:2] == [4, 2] and list(hpp.sigma)[:2] == [0.9, 2.1]
+    for bad in ({'ng': '3 6 0.7 4'}, {'ng': '5 1 1 1 1 1 1 1 1 1 1'}, {'c': 'i'}, {'n': 'u'}, {'ssig': 3.0},
+                {'kfm': 0.9}, {'sconv': ''}, {'fom': 'h'}, {'convvar': ''}, {'afssc': 0}, {'tg': 1.5},
+                {'pca': 'x'}, {'rkf': 3.0}):
+        with pytest.raises(ValueError, match='hotpants -'):
+            hp.job_params(2.0, 512, 512, 1, 0, 0, bad)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        hp.job_params(2.0, 512, 512, 1, 0, 0, {'v': 2, 'hki': '', 'nc': 'x'})
+    hp._warned_keys.discard('oci')
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        hp.job_params(2.0, 512, 512, 1, 0, 0, {'oci': 'conv.fits'})
+        hp.job_params(2.0, 512, 512, 1, 0, 0, {'oci': 'conv.fits'})
+    assert len(w) == 1 and 'oci' in str(w[0].message)

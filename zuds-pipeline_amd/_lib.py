@@ -69,6 +69,16 @@ class zm_hp_info(C.Structure):
                 ('nunsolved', C.c_int32), ('retries', C.c_int32)]
 
 
+COMM_MAX_RANKS = 64
+
+
+class zm_mask_plan(C.Structure):
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('band_px', C.c_int64), ('my_px', C.c_int64),
+                ('send_off', C.c_int64 * COMM_MAX_RANKS), ('send_cnt', C.c_int64 * COMM_MAX_RANKS),
+                ('recv_off', C.c_int64 * COMM_MAX_RANKS), ('recv_cnt', C.c_int64 * COMM_MAX_RANKS),
+                ('gather_off', C.c_int64 * COMM_MAX_RANKS)]
+
+
 HP_UNSOLVED, HP_TIMEOUT = 1, 2          # zm_hp_info.status bits (include/zudsmi.h)
 
 
@@ -134,6 +144,8 @@ _SIGS = {
     'zm_comm_destroy': (C.c_int, [_P]),
     'zm_coadd_reduce_dev': (C.c_int, [_P, _P, _P, C.c_int64]),
     'zm_mask_reduce_dev': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    'zm_comm_band_bounds': (C.c_int, [C.c_int, C.c_int, _P]),
+    'zm_comm_mask_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(zm_mask_plan)]),
     'zm_median_mad2_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_double)]),
     'zm_rms_from_weight_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     'zm_weight_from_rms_dev': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P]),

@@ -150,6 +150,39 @@ static void band_bounds(int nrows, int world, std::vector<int>* b) {
     for (int r = 0; r < world; ++r) b->push_back(b->back() + base + (r < extra ? 1 : 0));
 }
 
+extern "C" int zm_comm_band_bounds(int nrows, int world, int32_t* bounds) {
+    ZM_CHECK(bounds && nrows >= 0 && world >= 1, "zm_comm_band_bounds: bad argument");
+    std::vector<int> b;
+    band_bounds(nrows, world, &b);
+    for (int g = 0; g <= world; ++g) bounds[g] = b[g];
+    return 0;
+}
+
+// The banded schedule of zm_mask_reduce_dev for one rank, as element offsets / counts (host arithmetic only;
+// the send / recv / gather calls below are issued from exactly these numbers, and tests replay the plans of
+// all ranks on the CPU: what rank r sends to g is what g expects from r, slots do not overlap).
+extern "C" int zm_comm_mask_plan(int nx, int ny, int world, int rank, zm_mask_plan* plan) {
+    ZM_CHECK(plan && nx > 0 && ny > 0 && world >= 1 && world <= ZM_COMM_MAX_RANKS && rank >= 0 && rank < world,
+             "zm_comm_mask_plan: bad argument (rank %d of %d, at most %d ranks)", rank, world, ZM_COMM_MAX_RANKS);
+    std::vector<int> b;
+    band_bounds(ny, world, &b);
+    int maxr = 0;
+    for (int g = 0; g < world; ++g) maxr = std::max(maxr, b[g + 1] - b[g]);
+    memset(plan, 0, sizeof(*plan));
+    plan->world = world;
+    plan->rank = rank;
+    plan->band_px = (int64_t)maxr * nx;
+    plan->my_px = (int64_t)(b[rank + 1] - b[rank]) * nx;
+    for (int g = 0; g < world; ++g) {
+        plan->send_off[g] = (int64_t)b[g] * nx;                   // into this rank's mask plane
+        plan->send_cnt[g] = (int64_t)(b[g + 1] - b[g]) * nx;       // (g == rank: the local copy)
+        plan->recv_off[g] = (int64_t)g * plan->band_px;            // into the receive buffer: slot of rank g
+        plan->recv_cnt[g] = plan->my_px;
+        plan->gather_off[g] = (int64_t)g * plan->band_px;          // folded band of rank g in the gather buffer
+    }
+    return 0;
+}
+
 extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int nx, int ny, int kind,
                                   float* cov) {
     ZM_CHECK(ctx && comm && mask && nx > 0 && ny > 0, "zm_mask_reduce_dev: bad argument");
@@ -159,12 +192,9 @@ extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int
     const int world = comm->nranks, rank = comm->rank;
     const int64_t npix = (int64_t)nx * ny;
     if (world == 1) return zm_launch_mask_finalize(ctx, mask, cov, npix);
-    std::vector<int> b;
-    band_bounds(ny, world, &b);
-    int maxr = 0;
-    for (int g = 0; g < world; ++g) maxr = std::max(maxr, b[g + 1] - b[g]);
-    const int myrows = b[rank + 1] - b[rank];
-    const size_t bandpx = (size_t)maxr * nx;
+    zm_mask_plan P;
+    ZM_TRY(zm_comm_mask_plan(nx, ny, world, rank, &P));
+    const size_t bandpx = (size_t)P.band_px;
     int32_t *recv = nullptr, *folded = nullptr, *gathered = nullptr;
     ZM_TRY(ctx->get("comm_recv", sizeof(int32_t) * bandpx * world, (void**)&recv));
     ZM_TRY(ctx->get("comm_fold", sizeof(int32_t) * bandpx, (void**)&folded));
@@ -174,10 +204,10 @@ extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int
     ZM_NCCL(R.GroupStart());
     for (int g = 0; g < world; ++g) {
         if (g == rank) continue;
-        const size_t sendpx = (size_t)(b[g + 1] - b[g]) * nx;
-        if (sendpx) ZM_NCCL_IN_GROUP(comm, R.Send(mask + (size_t)b[g] * nx, sendpx, ncclInt32, g, comm->comm, st));
-        if (myrows)
-            ZM_NCCL_IN_GROUP(comm, R.Recv(recv + (size_t)g * bandpx, (size_t)myrows * nx, ncclInt32, g, comm->comm, st));
+        if (P.send_cnt[g])
+            ZM_NCCL_IN_GROUP(comm, R.Send(mask + P.send_off[g], (size_t)P.send_cnt[g], ncclInt32, g, comm->comm, st));
+        if (P.my_px)
+            ZM_NCCL_IN_GROUP(comm, R.Recv(recv + P.recv_off[g], (size_t)P.recv_cnt[g], ncclInt32, g, comm->comm, st));
     }
     {
         ncclResult_t r_ = R.GroupEnd();
@@ -187,18 +217,17 @@ extern "C" int zm_mask_reduce_dev(zm_ctx* ctx, zm_comm* comm, int32_t* mask, int
             return 1;
         }
     }
-    if (myrows) {
-        ZM_HIP(hipMemcpyAsync(recv + (size_t)rank * bandpx, mask + (size_t)b[rank] * nx,
-                              sizeof(int32_t) * (size_t)myrows * nx, hipMemcpyDeviceToDevice, st));
+    if (P.my_px) {
+        ZM_HIP(hipMemcpyAsync(recv + P.recv_off[rank], mask + P.send_off[rank], sizeof(int32_t) * (size_t)P.my_px,
+                              hipMemcpyDeviceToDevice, st));
         for (int g = 0; g < world; ++g)
-            ZM_TRY(zm_launch_mask_accum(ctx, folded, recv + (size_t)g * bandpx, (int64_t)myrows * nx, kind, g == 0));
+            ZM_TRY(zm_launch_mask_accum(ctx, folded, recv + P.recv_off[g], P.my_px, kind, g == 0));
     }
     // bands may differ by one row: gathered through slots of the largest
     ZM_NCCL(R.AllGather(folded, gathered, bandpx, ncclInt32, comm->comm, st));
     for (int g = 0; g < world; ++g) {
-        const size_t px = (size_t)(b[g + 1] - b[g]) * nx;
-        if (px)
-            ZM_HIP(hipMemcpyAsync(mask + (size_t)b[g] * nx, gathered + (size_t)g * bandpx, sizeof(int32_t) * px,
+        if (P.send_cnt[g])
+            ZM_HIP(hipMemcpyAsync(mask + P.send_off[g], gathered + P.gather_off[g], sizeof(int32_t) * (size_t)P.send_cnt[g],
                                   hipMemcpyDeviceToDevice, st));
     }
     return zm_launch_mask_finalize(ctx, mask, cov, npix);

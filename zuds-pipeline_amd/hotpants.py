@@ -15,6 +15,14 @@ __all__ = ['prepare_hotpants', 'HotpantsCall']
 MAX_R, MAX_RSS = 15, 48             # largest kernel / substamp half widths of zm_subtract
 _INT_KEYS = ('ko', 'bgo', 'nss', 'nsx', 'nsy', 'nrx', 'nry')
 _FLT_KEYS = ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks')
+# The `-key value` pass-through (zuds/hotpants.py:86-87) reaches hotpants itself.  Beyond the keys above
+# (VERDICT r3 item 7): switches the command line of the reference hardwires are accepted with that value
+# only; verbosity / header bookkeeping is ignored; extra output products warn once; the rest raises.
+MAX_NGAUSS = 4
+_FIXED_KEYS = {'c': ('t',)}
+_IGNORED_KEYS = ('v', 'hki', 'nc')
+_EXTRA_PRODUCT_KEYS = ('oki', 'oci', 'cim', 'nim', 'ndm', 'omi', 'ond', 'allm', 'savexy')
+_warned_keys = set()
 
 
 def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
@@ -45,7 +53,34 @@ def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
         elif key in _FLT_KEYS:
             params[key] = float(val)
         elif key == 'n':
+            if str(val) not in ('t', 'i'):
+                raise ValueError(f'hotpants -n {val}: libzudsmi normalises to the template (t) or '
+                                 f'the image (i) only')
             params['normalize'] = 1 if str(val) == 't' else 0
+        elif key == 'ng':
+            # -ng ngauss degree0 sigma0 .. degreeN sigmaN: the Gaussian basis (hotpants defaults 3 6 0.7 4 1.5 2 3.0)
+            tok = str(val).replace(',', ' ').split() if not isinstance(val, (list, tuple)) else list(val)
+            n = int(tok[0])
+            if len(tok) != 1 + 2 * n or not 1 <= n <= MAX_NGAUSS:
+                raise ValueError(f'hotpants -ng {val}: expected "n deg_1 sigma_1 .. deg_n sigma_n" with '
+                                 f'n <= {MAX_NGAUSS}')
+            params['deg'] = [int(t) for t in tok[1::2]]
+            params['sigma'] = [float(t) for t in tok[2::2]]
+        elif key in _FIXED_KEYS:
+            if str(val) not in _FIXED_KEYS[key]:
+                raise ValueError(f'hotpants -{key} {val}: libzudsmi implements -{key} '
+                                 f'{" / ".join(_FIXED_KEYS[key])} only (zuds/hotpants.py:77)')
+        elif key in _IGNORED_KEYS:
+            continue
+        elif key in _EXTRA_PRODUCT_KEYS:
+            if key not in _warned_keys:
+                import warnings
+                _warned_keys.add(key)
+                warnings.warn(f'hotpants -{key} {val}: this extra product is not written by libzudsmi')
+        else:
+            # every other hotpants switch changes the operator (basis, convolution direction, noise
+            # model, figure of merit ...): the default operator must not be returned in its place
+            raise ValueError(f'hotpants -{key} {val} is not implemented by libzudsmi')
     return params
 
 

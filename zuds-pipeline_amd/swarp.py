@@ -29,11 +29,40 @@ def _yn(v):
     return str(v).strip().upper() in ('Y', 'YES', 'TRUE', '1')
 
 
-def _params_from_kws(base, swarp_kws):
+# The `-KEY value` pass-through of the reference (``zuds/swarp.py:76-78,100-102``) reaches SWarp
+# itself, so every SWarp keyword is a legal override.  Three classes here:
+#   * implemented - mapped onto zm_coadd_params below;
+#   * keys that CHANGE THE OPERATOR and that libzudsmi does not implement: accepted when the value
+#     is the one the engine works with (the value of default.swarp / mask.swarp), ``ValueError``
+#     otherwise - a caller who overrides the projection or the centre must not get the default
+#     operator without a word;
+#   * bookkeeping keys (threads, scratch directories, logs ...): ignored;
+# anything else warns once per key.
+_SWARP_FIXED = {            # key -> values the engine's operator corresponds to
+    'PROJECTION_TYPE': ('TPV', 'TAN'), 'PROJECTION_ERR': None,      # (the lattice is exact at its nodes)
+    'CELESTIAL_TYPE': ('NATIVE',), 'CENTER_TYPE': ('ALL',), 'PIXELSCALE_TYPE': ('MEDIAN',),
+    'PIXEL_SCALE': ('0', '0.0'), 'IMAGE_SIZE': ('0',), 'OVERSAMPLING': ('0',),
+    'INTERPOLATE': ('N',), 'FSCALASTRO_TYPE': ('FIXED',), 'FSCALE_KEYWORD': ('FLXSCALE',),
+    'FSCALE_DEFAULT': ('1', '1.0'), 'BACK_TYPE': ('AUTO',), 'BACK_FILTTHRESH': ('0', '0.0'),
+    'BLANK_BADPIXELS': ('N',), 'COMBINE': ('Y',), 'RESAMPLE': ('Y',), 'HEADER_ONLY': ('N',),
+    'GAIN_DEFAULT': ('0', '0.0'), 'WEIGHT_TYPE': ('MAP_WEIGHT', 'NONE'),
+}
+_SWARP_UNSUPPORTED = ('CENTER', 'BACK_DEFAULT', 'WEIGHT_IMAGE', 'WEIGHT_SUFFIX', 'IMAGEOUT_NAME',
+                      'WEIGHTOUT_NAME', 'HEADER_SUFFIX', 'GAIN_KEYWORD', 'SATLEV_KEYWORD',
+                      'SATLEV_DEFAULT', 'COPY_KEYWORDS')
+_SWARP_IGNORED = ('NTHREADS', 'VMEM_DIR', 'VMEM_MAX', 'MEM_MAX', 'COMBINE_BUFSIZE', 'RESAMPLE_DIR',
+                  'RESAMPLE_SUFFIX', 'DELETE_TMPFILES', 'VERBOSE_TYPE', 'WRITE_XML', 'XML_NAME',
+                  'XSL_URL', 'WRITE_FILEINFO', 'NNODES', 'NODE_INDEX', 'CLIP_WRITELOG',
+                  'CLIP_LOGNAME', 'NOPENFILES_MAX', 'TILE_COMPRESS',
+                  # not SWarp keys: keyword arguments MultiEpochSubtraction.from_images forwards
+                  # as swarp_kws (zuds/subtraction.py:308-310)
+                  'REFINED', 'FORCE_MAP_SUBS', 'TMPDIR')
+_warned_keys = set()
+
+
+def _params_from_kws(base, swarp_kws, kind='sci'):
     """Overlay the ``-KEY value`` pass-through of the reference
-    (``zuds/swarp.py:76-78``) on the config-file defaults.  Keys libzudsmi has
-    no use for (``REFINED``, ``FORCE_MAP_SUBS``, ``NTHREADS`` ...; see
-    ``zuds/subtraction.py:308-310``) are dropped silently."""
+    (``zuds/swarp.py:76-78``) on the config-file defaults; see the key classes above."""
     p = dict(base)
     for k, v in (swarp_kws or {}).items():
         ku = str(k).upper()
@@ -55,6 +84,20 @@ def _params_from_kws(base, swarp_kws):
             p['rescale_weights'] = _yn(v)
         elif ku == 'WEIGHT_THRESH':
             p['weight_thresh'] = float(v)
+        elif ku in _SWARP_FIXED:
+            ok = _SWARP_FIXED[ku]
+            if ok is not None and str(v).strip().upper() not in ok:
+                raise ValueError(f'SWarp keyword -{ku} {v}: libzudsmi implements {" / ".join(ok)} only '
+                                 f'(the {kind} operator of default.swarp / mask.swarp)')
+        elif ku in _SWARP_UNSUPPORTED:
+            raise ValueError(f'SWarp keyword -{ku} {v} changes the {kind} coadd and is not implemented '
+                             f'by libzudsmi')
+        elif ku in _SWARP_IGNORED:
+            continue
+        elif ku not in _warned_keys:
+            import warnings
+            _warned_keys.add(ku)
+            warnings.warn(f'SWarp keyword -{ku} {v} has no equivalent in libzudsmi and is ignored')
     return p
 
 
@@ -203,7 +246,7 @@ def prepare_swarp_mask(masks, outname, mskoutweightname, directory, swarp_kws=No
             syscall += f'-{kw.upper()} {swarp_kws[kw]} '
     base = dict(_SCI_DEFAULTS, combine='CLIPPED', mask_combine='AND', subtract_back=False,
                 rescale_weights=False)
-    params = _params_from_kws(base, swarp_kws)
+    params = _params_from_kws(base, swarp_kws, kind='mask')
     mc = str((swarp_kws or {}).get('COMBINE_TYPE', (swarp_kws or {}).get('combine_type', 'AND'))).upper()
     params['mask_combine'] = mc if mc in ('AND', 'OR') else 'AND'
     params['combine'] = 'WEIGHTED'
