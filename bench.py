@@ -911,9 +911,13 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
             dt = min(reps)
         finally:
             pool.close()
-        bad = [r['info']['status'] for r in res if r['info']['status'] != 0]
+        # (a job that raised comes back as {'tag', 'error'} without 'info': nightly.SubtractionPool._run)
+        bad = [r for r in res if 'error' in r or r['info']['status'] != 0]
         out['pools'][str(J)] = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
                                 'passes_ms': [1e3 * t / njobs for t in reps], 'failed': len(bad)}
+        errs = [r['error'] for r in bad if 'error' in r]
+        if errs:
+            out['pools'][str(J)]['first_error'] = str(errs[0])[:200]
     best = max(out['pools'].values(), key=lambda v: v['subtract_mpix_s'])
     out['subtract_mpix_s'] = best['subtract_mpix_s']
     return out

@@ -176,8 +176,9 @@ typedef struct zm_hp_info {
 /* status bits.  The reference sees a failed hotpants as a non-zero exit (CalledProcessError,
  * zuds/subtraction.py:162); here: ZM_HP_UNSOLVED = a region of the fit had no usable stamps or a
  * normal matrix that is not positive definite - a property of the data, the call still returns 0
- * and the region carries the fill value; ZM_HP_TIMEOUT = the solver did not make progress even
- * after its retry on the safe path - the call returns non-zero. */
+ * and the region carries the fill value.  ZM_HP_TIMEOUT is reserved (never set): a barrier of the
+ * many-workgroup factorisation that times out makes the fit repeat on the one-workgroup form, which
+ * has no barrier that could time out - `retries` counts such repeats. */
 #define ZM_HP_UNSOLVED 1
 #define ZM_HP_TIMEOUT 2
 

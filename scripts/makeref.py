@@ -37,12 +37,17 @@ def select(directory, min_date, max_date):
     """The frames of ``directory`` that may go into a reference, deepest first."""
     ok = []
     for fn in sorted(Path(directory).glob('ztf*sciimg.fits')):
+        # each file is read once to see that it is whole, then dropped again and re-mapped, as the
+        # reference does (scripts/makeref.py:45-63): a directory of several hundred candidates must not
+        # sit in host memory until the 50 deepest are chosen - from_images loads those when it runs
         try:
             sci = zuds.ScienceImage.from_file(f'{fn}')
             sci.load()
         except Exception:
             print(f'bad: File {fn.name} is corrupted, skipping...', flush=True)
             continue
+        sci.clear()
+        sci.map_to_local_file(f'{fn}')
         maskname = f'{fn}'.replace('sciimg', 'mskimg')
         try:
             sci.mask_image = zuds.MaskImage.from_file(maskname)
@@ -50,6 +55,8 @@ def select(directory, min_date, max_date):
         except Exception:
             print(f'bad: File {os.path.basename(maskname)} is corrupted, skipping...', flush=True)
             continue
+        sci.mask_image.clear()
+        sci.mask_image.map_to_local_file(maskname)
         h = sci.header
         try:
             c1 = min_date <= obsdate(sci) <= max_date

@@ -65,7 +65,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(f'J = {J}: {1e3 * dt / njobs:.2f} ms per subtraction ({njobs} jobs, '
-                  f'{sum(r["info"]["status"] != 0 for r in res)} failed)', flush=True)
+                  f'{sum(("error" in r) or r["info"]["status"] != 0 for r in res)} failed)', flush=True)
     finally:
         pool.close()
 
