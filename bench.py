@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-subtract', action='store_true')
     ap.add_argument('--no-mask', action='store_true', help='skip the mask coadd (dev only)')
+    ap.add_argument('--mask-dtype', default='int16', choices=['int16', 'int32'],
+                    help='input masks in HBM: int16 = a ZTF mask as its BITPIX 16 file holds it (zm_dframe.mask_type), '
+                         'int32 = the widened copy of rounds 1 - 3')
     ap.add_argument('--seeing', type=float, default=4.0,
                     help='science FWHM in pixels: r = 2.5 seeing, rss = 6 seeing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the CLIPPED secondary line')
@@ -73,7 +76,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_device_frames(synth, torch, n, size, seed0, device):
+def make_device_frames(synth, torch, n, size, seed0, device, mask_dtype='int16'):
     """Config-2 frames: star fields rendered on the host once, sky + noise added
     on the device (keeps set-up to seconds; the values follow synth.config2)."""
     base = synth.ztf_wcs(size, size, tpv=True)
@@ -99,7 +102,7 @@ def make_device_frames(synth, torch, n, size, seed0, device):
         img = torch.from_numpy(stars.astype(np.float32)).to(device)
         img += sky + torch.randn((size, size), generator=g, device=device) * float(np.sqrt(sky / 6.2))
         bad = torch.rand((size, size), generator=g, device=device) < 1e-3
-        mask = torch.where(bad, 256, 0).to(torch.int32)
+        mask = torch.where(bad, 256, 0).to(getattr(torch, mask_dtype))
         wgt = torch.where(bad, 0.0, 6.2 / sky).to(torch.float32)
         frames.append(dict(img=img, wgt=wgt, mask=mask, wcs=w,
                            flxscale=10 ** (-0.4 * (magzp - 25.0))))
@@ -465,17 +468,18 @@ def main():
 
     eng = z.Engine(local)
     base, frames = make_device_frames(synth, torch, args.frames + 1, args.size,
-                                      2000 + 1000 * rank, device)
+                                      2000 + 1000 * rank, device, args.mask_dtype)
     sci = frames.pop()            # the science epoch of configs[2]
     for r in range(1, args.emulate_ranks if world == 1 else 1):
-        frames += make_device_frames(synth, torch, args.frames + 1, args.size, 2000 + 1000 * r, device)[1][:-1]
+        frames += make_device_frames(synth, torch, args.frames + 1, args.size, 2000 + 1000 * r, device,
+                                     args.mask_dtype)[1][:-1]
     # detector defects of the science frame: 300 clustered 3x3 blobs instead of
     # isolated pixels (a 69 x 69 substamp box must be clean to be usable)
     g = torch.Generator(device='cpu')
     g.manual_seed(77 + rank)
     bx = torch.randint(2, args.size - 2, (300,), generator=g)
     by = torch.randint(2, args.size - 2, (300,), generator=g)
-    smask = torch.zeros((args.size, args.size), dtype=torch.int32)
+    smask = torch.zeros((args.size, args.size), dtype=getattr(torch, args.mask_dtype))
     for dx in (-1, 0, 1):
         for dy in (-1, 0, 1):
             smask[by + dy, bx + dx] = 256
@@ -986,6 +990,7 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
              [(sci, k) for k in ('img', 'wgt', 'mask', 'rms')]
     products = lambda: [coadd.img, coadd.wgt] + ([coadd.mask] if coadd.mask is not None else []) + \
         ([] if args.no_subtract else [sub.diff, sub.noise, sub.submask])
+    native16 = sci['mask'].dtype == torch.int16              # int16 masks in HBM: no widening behind the copy
     try:
         # Host side: every input plane in pinned memory, masks as int16 (what a ZTF mask file holds:
         # half the bytes of the int32 the kernels read; widened on the device behind the copy).
@@ -1022,7 +1027,7 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
                 if S['free'] is not None:
                     cs.wait_event(S['free'])
                 for (f, k), h in zip(S['planes'], pinned_in):
-                    (S['m16'][id(f)] if k == 'mask' else f[k]).copy_(h, non_blocking=True)
+                    (S['m16'][id(f)] if (k == 'mask' and not native16) else f[k]).copy_(h, non_blocking=True)
                 S['arrived'] = cs.record_event()
 
         def pcie_step():
@@ -1033,8 +1038,9 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
             enqueue_copies(sets[state['k'] % 2])
             with torch.cuda.stream(coadd.stream):
                 coadd.stream.wait_event(S['arrived'])
-                for f in S['frames'] + [S['sci']]:
-                    f['mask'].copy_(S['m16'][id(f)])             # int16 -> int32 on the device
+                if not native16:
+                    for f in S['frames'] + [S['sci']]:
+                        f['mask'].copy_(S['m16'][id(f)])         # int16 -> int32 on the device
                 if state['d2h'] is not None:
                     coadd.stream.wait_event(state['d2h'])        # the products of the previous step have left
             step(coadd, S['dfr'], S['sci'])
@@ -1049,7 +1055,7 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
         def copies_only():
             with torch.cuda.stream(cs):
                 for (f, k), h in zip(sets[1]['planes'], pinned_in):
-                    (sets[1]['m16'][id(f)] if k == 'mask' else f[k]).copy_(h, non_blocking=True)
+                    (sets[1]['m16'][id(f)] if (k == 'mask' and not native16) else f[k]).copy_(h, non_blocking=True)
         enqueue_copies(sets[0])
         pcie_step()
         pcie_step()
@@ -1060,7 +1066,7 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
         clocks['with_pcie_ms'] = 1e3 * dt
         clocks['pcie'] = {'h2d_bytes': in_bytes, 'd2h_bytes': out_bytes, 'host_memory': 'pinned',
                           'h2d_copy_alone_ms': 1e3 * dt_copy, 'h2d_GBs': in_bytes / dt_copy / 1e9,
-                          'masks_over_pcie': 'int16, widened on the device',
+                          'masks_over_pcie': 'int16, read as int16 by the kernels' if native16 else 'int16, widened on the device',
                           'overlap': 'H2D of step k + 1 (copy stream, second set of input planes) under the kernels '
                                      'of step k; D2H of the products of step k - 1 on a third stream; events '
                                      'between the three',
@@ -1096,7 +1102,7 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
             sc = dict(wcs=sci['wcs'])
             sc['img'], _ = io.load(sci_paths[0], 'f32')
             sc['wgt'], _ = io.load(sci_paths[1], 'f32')
-            sc['mask'], _ = io.load(sci_paths[2], 'i32')
+            sc['mask'], _ = io.load(sci_paths[2], 'mask' if native16 else 'i32')
             sc['rms'] = torch.empty_like(sc['img'])
             with torch.cuda.stream(coadd.stream):
                 z._lib.check(eng.L.zm_rms_from_weight_dev(eng.ctx, sc['wgt'].data_ptr(), None, sc['img'].numel(),

@@ -106,12 +106,20 @@ int zm_background(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                   float* out_rms, float* out_sub, double* out_stats);
 
 /* ---- coadd ---------------------------------------------------------------- */
+/* Mask planes are integer bit masks (zuds/mask.py:26-72).  ZTF mask files are BITPIX 16: such a plane is
+ * handed over as it is (mask_type = ZM_MASKTYPE_I16, `mask` points at int16_t) and is read as int16 by the
+ * kernels - half the bytes over PCIe and from HBM; its values mean what numpy's astype(int32) would make
+ * of them (sign extension).  mask_type = 0 (a zero-initialised struct): int32_t, as before. */
+#define ZM_MASKTYPE_I32 0
+#define ZM_MASKTYPE_I16 1
 typedef struct zm_frame {
     const float* img;       /* [ny][nx] */
     const float* wgt;       /* inverse variance, NULL = WEIGHT_TYPE NONE */
-    const int32_t* mask;    /* NULL = no mask */
+    const void* mask;       /* int32_t (or int16_t, see mask_type) [ny][nx]; NULL = no mask */
     zm_wcs wcs;
     double flxscale;        /* FLXSCALE = 10^(-0.4 (MAGZP - 25)), zuds/swarp.py:31 */
+    int32_t mask_type;      /* ZM_MASKTYPE_* */
+    int32_t pad_;
 } zm_frame;
 
 typedef struct zm_coadd_params {
@@ -227,9 +235,11 @@ int zm_aperture_photometry_dev(zm_ctx* ctx, const float* img, const float* rms,
 typedef struct zm_dframe {
     const float* img;       /* device */
     const float* wgt;       /* device or NULL */
-    const int32_t* mask;    /* device or NULL */
+    const void* mask;       /* device int32_t / int16_t plane (mask_type) or NULL */
     zm_wcs wcs;
     double flxscale;
+    int32_t mask_type;      /* ZM_MASKTYPE_* */
+    int32_t pad_;
 } zm_dframe;
 
 /* Resample + combine nframes device frames; outputs are device planes.
@@ -308,6 +318,19 @@ int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
                     const int32_t* mask, const zm_wcs* win, const zm_wcs* wout,
                     int kernel, double fscale, float* out_img, float* out_wgt,
                     int32_t* out_mask);
+/* zm_resample / zm_resample_dev for a BITPIX 16 mask plane (run_align on a ZTF mask, zuds/swarp.py:157-204):
+ * the int16 plane crosses PCIe as it is and is widened on the device; out_mask stays int32 (bit 16 / 17 of
+ * the products, zuds/mask.py:26-33, zuds/subtraction.py:170-171). */
+int zm_resample_i16(zm_ctx* ctx, const float* img, const float* wgt,
+                    const int16_t* mask, const zm_wcs* win, const zm_wcs* wout,
+                    int kernel, double fscale, float* out_img, float* out_wgt,
+                    int32_t* out_mask);
+int zm_resample_i16_dev(zm_ctx* ctx, const float* img, const float* wgt,
+                        const int16_t* mask, const zm_wcs* win, const zm_wcs* wout,
+                        int kernel, double fscale, float* out_img, float* out_wgt,
+                        int32_t* out_mask);
+/* out[i] = (int32_t) in[i] (sign extension), n elements, device planes. */
+int zm_mask_widen_dev(zm_ctx* ctx, const int16_t* in, int64_t n, int32_t* out);
 
 /* ---- per-pixel bookkeeping on device planes ---------------------------------- */
 /* rms = 1/sqrt(w), big_rms where bad or w <= 0 (zuds/image.py:173-208). */
@@ -357,7 +380,8 @@ int zm_negpix_test(zm_ctx* ctx, const float* img, int nx, int ny, int npos,
 /* Replaces the host-side decode / encode astropy does inside FITSFile.load_data / save
  * (zuds/fitsfile.py:69-94,146-206): raw_dev holds the big-endian data block of a primary
  * HDU as it lies on disk (n pixels of BITPIX 8 / 16 / 32 / -32 / -64); the decoded plane
- * is float32 (out_kind 0), int32 (1) or uint8 (2) with physical = bzero + bscale * stored.
+ * is float32 (out_kind 0), int32 (1), uint8 (2) or int16 (3: a BITPIX 16 mask kept at 16 bits for
+ * zm_dframe.mask_type = ZM_MASKTYPE_I16) with physical = bzero + bscale * stored.
  * Encode: float32 -> BITPIX -32 (in_kind 0), int32 -> 32 (1), uint8 -> 8 (2),
  * int32 -> BITPIX 16 (3). */
 int zm_fits_decode_dev(zm_ctx* ctx, const void* raw_dev, int bitpix, double bscale,

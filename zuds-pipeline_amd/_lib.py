@@ -30,9 +30,13 @@ class zm_wcs(C.Structure):
                 ('flags', C.c_int32), ('pad_', C.c_int32)]
 
 
+MASKTYPE_I32, MASKTYPE_I16 = 0, 1
+
+
 class zm_frame(C.Structure):
     _fields_ = [('img', C.c_void_p), ('wgt', C.c_void_p), ('mask', C.c_void_p),
-                ('wcs', zm_wcs), ('flxscale', C.c_double)]
+                ('wcs', zm_wcs), ('flxscale', C.c_double),
+                ('mask_type', C.c_int32), ('pad_', C.c_int32)]
 
 
 zm_dframe = zm_frame   # same layout; pointers are device addresses
@@ -104,6 +108,13 @@ _SIGS = {
     'zm_resample_dev': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs),
                                   C.POINTER(zm_wcs), C.c_int, C.c_double,
                                   _P, _P, _P]),
+    'zm_resample_i16': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs),
+                                  C.POINTER(zm_wcs), C.c_int, C.c_double,
+                                  _P, _P, _P]),
+    'zm_resample_i16_dev': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs),
+                                      C.POINTER(zm_wcs), C.c_int, C.c_double,
+                                      _P, _P, _P]),
+    'zm_mask_widen_dev': (C.c_int, [_P, _P, C.c_int64, _P]),
     'zm_coadd_params_default': (None, [C.POINTER(zm_coadd_params)]),
     'zm_coadd': (C.c_int, [_P, C.c_int, C.POINTER(zm_frame), C.POINTER(zm_wcs),
                            C.POINTER(zm_coadd_params), _P, _P, _P, _P]),
@@ -254,6 +265,18 @@ def as_f32(a):
 
 def as_i32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def as_mask(a):
+    """A mask plane for zm_frame.mask: an int16 array (a ZTF mask as read from its BITPIX 16 file) is
+    handed over as it is (MASKTYPE_I16, half the bytes over PCIe and from HBM); anything else as int32.
+    Returns (array or None, mask_type)."""
+    if a is None:
+        return None, MASKTYPE_I32
+    a = np.asarray(a)
+    if a.dtype == np.int16:
+        return np.ascontiguousarray(a), MASKTYPE_I16
+    return np.ascontiguousarray(a, dtype=np.int32), MASKTYPE_I32
 
 
 def wcs_struct(w):

@@ -76,7 +76,8 @@ def _coadd_from_images(cls, images, outname=None, data_product=False, tmpdir='/t
     params['mask_combine'] = msk.params['mask_combine']
     frames = sci.frames()
     for f, m in zip(frames, masks):
-        f['mask'] = np.ascontiguousarray(m.data).astype(np.int32)
+        # (a ZTF mask read from its BITPIX 16 file is int16 and goes to the GPU as it is: zm_frame.mask_type)
+        f['mask'] = m.data if m.data.dtype == np.int16 else np.ascontiguousarray(m.data).astype(np.int32)
     oimg, owgt, omask, omw = eng.coadd(frames, wout, coadd_params(**params), want_mask=True)
 
     weight_outname = outname.replace('.fits', '.weight.fits')

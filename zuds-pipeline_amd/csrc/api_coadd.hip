@@ -118,6 +118,25 @@ static int frames_background(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_c
     return 0;
 }
 
+// The int32 view of a frame's mask for the kernels that read int32 only (k_prep_box, k_resample and its
+// raw-mask fallback): an int16 plane (ZM_MASKTYPE_I16) is widened on the device into the scratch slot
+// `slot` (stream-ordered: one slot serves the frames of a loop that consumes each before the next is made).
+static int frame_mask_i32(zm_ctx* ctx, const zm_dframe* f, const char* slot, const int32_t** out) {
+    *out = nullptr;
+    if (!f->mask) return 0;
+    ZM_CHECK(f->mask_type == ZM_MASKTYPE_I32 || f->mask_type == ZM_MASKTYPE_I16, "frame: unknown mask_type %d", f->mask_type);
+    if (f->mask_type == ZM_MASKTYPE_I32) {
+        *out = (const int32_t*)f->mask;
+        return 0;
+    }
+    const int64_t n = (int64_t)f->wcs.naxis[0] * f->wcs.naxis[1];
+    int32_t* w = nullptr;
+    ZM_TRY(ctx->get(slot, sizeof(int32_t) * (size_t)n, (void**)&w));
+    ZM_TRY(zm_launch_mask_widen(ctx, (const int16_t*)f->mask, n, w));
+    *out = w;
+    return 0;
+}
+
 // Resample nframes device frames onto `wout` into `stack` (float2 [n][ony*onx]).
 // Also accumulates the mask coadd when acc_mask != NULL.
 static int resample_frames_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
@@ -177,12 +196,13 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
         ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
         // the mask rides along with its frame: same tile, same positions
         const bool with_mask = acc_mask && fr[i].mask;
+        const int32_t* m32 = nullptr;
+        if (with_mask) ZM_TRY(frame_mask_i32(ctx, &fr[i], "mask_widen", &m32));
         ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bknodes, nbx, nby, P->back_size,
-                              vscale, wthresh, src, spitch, with_mask ? fr[i].mask : nullptr,
-                              ntaps_of(P->resample)));
+                              vscale, wthresh, src, spitch, m32, ntaps_of(P->resample)));
         ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat + (size_t)i * lnx * lny, lnx, lny,
                                   P->resample, (float)fscale[i], stack + (size_t)i * opix, onx,
-                                  ony, lds[i], fr[i].mask, acc_mask, with_mask ? 2 : 0, mask_kind,
+                                  ony, lds[i], m32, acc_mask, with_mask ? 2 : 0, mask_kind,
                                   first_mask ? 1 : 0));
         if (with_mask) first_mask = false;
     }
@@ -235,8 +255,12 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     std::vector<size_t> prep_off(n), box_off(n), yt_off(n);
     std::vector<char> need_src(n, 0);
     bool any_mask = false;
+    size_t widen_bytes = 0;
+    std::vector<size_t> widen_off(n);
     for (int i = 0; i < n; ++i) {
         const int nx = fr[i].wcs.naxis[0], ny = fr[i].wcs.naxis[1], spitch = (nx + 1) & ~1;
+        ZM_CHECK(!fr[i].mask || fr[i].mask_type == ZM_MASKTYPE_I32 || fr[i].mask_type == ZM_MASKTYPE_I16,
+                 "frame %d: unknown mask_type %d", i, fr[i].mask_type);
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         double fs = 1.0;
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
@@ -258,6 +282,10 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         ff[i].fscale = (float)fs;
         ff[i].fscale2 = (float)fs * (float)fs;
         ff[i].mask = with_mask ? fr[i].mask : nullptr;
+        ff[i].mask16 = (with_mask && fr[i].mask_type == ZM_MASKTYPE_I16) ? 1 : 0;
+        // (a frame that goes through k_prep_box - it cannot be staged raw - has its int16 mask widened first)
+        widen_off[i] = widen_bytes;
+        if (ff[i].mask16 && need_src[i]) widen_bytes += ((sizeof(int32_t) * (size_t)nx * ny) + 255) & ~(size_t)255;
         ff[i].img = fr[i].img;
         ff[i].wgt = fr[i].wgt;
         ff[i].wthresh = wthresh;
@@ -272,6 +300,17 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     int* boxflags = nullptr;           // per frame: its box-OR plane holds entries that defer to the raw mask
     ZM_TRY(ctx->get("mask_box_flags", sizeof(int) * (size_t)n, (void**)&boxflags));
     ZM_HIP(hipMemsetAsync(boxflags, 0, sizeof(int) * (size_t)n, ctx->stream));
+    if (widen_bytes) {
+        char* wall = nullptr;
+        ZM_TRY(ctx->get("mask_widen_all", widen_bytes, (void**)&wall));
+        for (int i = 0; i < n; ++i)
+            if (ff[i].mask16 && need_src[i]) {
+                int32_t* w = (int32_t*)(wall + widen_off[i]);
+                ZM_TRY(zm_launch_mask_widen(ctx, (const int16_t*)ff[i].mask, (int64_t)ff[i].nx * ff[i].ny, w));
+                ff[i].mask = w;
+                ff[i].mask16 = 0;
+            }
+    }
     ZM_HIP(hipEventRecord(evs[3], ctx->stream));
     // the box-OR planes of the frames that are read raw: they need the masks only, so they go out first, on the
     // second stream, beside the mesh statistics
@@ -280,7 +319,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         uint16_t* mbox = ff[i].mask ? (uint16_t*)(box_all + box_off[i]) : nullptr;
         ff[i].mbox = mbox;
         if (mbox && !need_src[i]) {
-            boxes.push_back(zm_boxjob{ff[i].mask, mbox, boxflags + i, ff[i].nx, ff[i].ny, ff[i].mpitch, 0});
+            boxes.push_back(zm_boxjob{ff[i].mask, mbox, boxflags + i, ff[i].nx, ff[i].ny, ff[i].mpitch, ff[i].mask16});
             ff[i].mboxflag = boxflags + i;
         }
     }
@@ -316,7 +355,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             // the frame prepped into its own plane (k_prep_box also fills the box-OR plane)
             float2* src = (float2*)(prep_all + prep_off[i]);
             ZM_TRY(zm_launch_prep(ctx, fr[i].img, fr[i].wgt, nx, ny, bki[i].nodes, bki[i].nbx, bki[i].nby, P->back_size,
-                                  bki[i].vscale, wthresh, src, ff[i].spitch, ff[i].mask, 6, (uint16_t*)ff[i].mbox, ff[i].mpitch));
+                                  bki[i].vscale, wthresh, src, ff[i].spitch, (const int32_t*)ff[i].mask, 6, (uint16_t*)ff[i].mbox, ff[i].mpitch));
             ff[i].src = src;
             continue;
         }
@@ -470,18 +509,48 @@ extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
     return 0;
 }
 
+extern "C" int zm_resample_i16_dev(zm_ctx* ctx, const float* img, const float* wgt, const int16_t* mask,
+                                   const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
+                                   float* out_img, float* out_wgt, int32_t* out_mask) {
+    ZM_CHECK(ctx && win && wout, "zm_resample_i16_dev: null argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    int32_t* w = nullptr;
+    if (mask) {
+        ZM_TRY(check_wcs(win, "input frame"));
+        const int64_t n = (int64_t)win->naxis[0] * win->naxis[1];
+        ZM_TRY(ctx->get("mask_widen", sizeof(int32_t) * (size_t)n, (void**)&w));
+        ZM_TRY(zm_launch_mask_widen(ctx, mask, n, w));
+    }
+    return zm_resample_dev(ctx, img, wgt, w, win, wout, kernel, fscale, out_img, out_wgt, out_mask);
+}
+
 // ---- host-pointer flavours -------------------------------------------------------
+static int resample_host(zm_ctx* ctx, const float* img, const float* wgt, const void* mask, int mask_type,
+                         const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
+                         float* out_img, float* out_wgt, int32_t* out_mask);
 extern "C" int zm_resample(zm_ctx* ctx, const float* img, const float* wgt, const int32_t* mask,
                            const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
                            float* out_img, float* out_wgt, int32_t* out_mask) {
+    return resample_host(ctx, img, wgt, mask, ZM_MASKTYPE_I32, win, wout, kernel, fscale, out_img, out_wgt, out_mask);
+}
+extern "C" int zm_resample_i16(zm_ctx* ctx, const float* img, const float* wgt, const int16_t* mask,
+                               const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
+                               float* out_img, float* out_wgt, int32_t* out_mask) {
+    return resample_host(ctx, img, wgt, mask, ZM_MASKTYPE_I16, win, wout, kernel, fscale, out_img, out_wgt, out_mask);
+}
+static int resample_host(zm_ctx* ctx, const float* img, const float* wgt, const void* mask, int mask_type,
+                         const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
+                         float* out_img, float* out_wgt, int32_t* out_mask) {
     ZM_CHECK(ctx && win && wout, "zm_resample: null argument");
     ZM_HIP(hipSetDevice(ctx->device));
     ZM_TRY(check_wcs(win, "input frame"));
     ZM_TRY(check_wcs(wout, "output grid"));
     const size_t ipix = (size_t)win->naxis[0] * win->naxis[1];
     const size_t opix = (size_t)wout->naxis[0] * wout->naxis[1];
+    const size_t mb = mask_type == ZM_MASKTYPE_I16 ? 2 : 4;         // bytes per mask pixel over PCIe
     float *d_img = nullptr, *d_wgt = nullptr, *d_oimg = nullptr, *d_owgt = nullptr;
-    int32_t *d_mask = nullptr, *d_omask = nullptr;
+    void* d_mask = nullptr;
+    int32_t* d_omask = nullptr;
     if (img) {
         ZM_TRY(ctx->get("h_img", ipix * 4, (void**)&d_img));
         ZM_HIP(hipMemcpyAsync(d_img, img, ipix * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -493,12 +562,16 @@ extern "C" int zm_resample(zm_ctx* ctx, const float* img, const float* wgt, cons
         ZM_TRY(ctx->get("h_owgt", opix * 4, (void**)&d_owgt));
     }
     if (mask) {
-        ZM_TRY(ctx->get("h_mask", ipix * 4, (void**)&d_mask));
-        ZM_HIP(hipMemcpyAsync(d_mask, mask, ipix * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZM_TRY(ctx->get("h_mask", ipix * mb, &d_mask));
+        ZM_HIP(hipMemcpyAsync(d_mask, mask, ipix * mb, hipMemcpyHostToDevice, ctx->stream));
         ZM_TRY(ctx->get("h_omask", opix * 4, (void**)&d_omask));
     }
-    ZM_TRY(zm_resample_dev(ctx, d_img, d_wgt, d_mask, win, wout, kernel, fscale, d_oimg, d_owgt,
-                           d_omask));
+    if (mask_type == ZM_MASKTYPE_I16)
+        ZM_TRY(zm_resample_i16_dev(ctx, d_img, d_wgt, (const int16_t*)d_mask, win, wout, kernel, fscale, d_oimg,
+                                   d_owgt, d_omask));
+    else
+        ZM_TRY(zm_resample_dev(ctx, d_img, d_wgt, (const int32_t*)d_mask, win, wout, kernel, fscale, d_oimg, d_owgt,
+                               d_omask));
     if (img) {
         ZM_HIP(hipMemcpyAsync(out_img, d_oimg, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
         ZM_HIP(hipMemcpyAsync(out_wgt, d_owgt, opix * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -522,7 +595,10 @@ extern "C" int zm_coadd(zm_ctx* ctx, int nframes, const zm_frame* frames, const 
         ZM_TRY(check_wcs(&frames[i].wcs, "frame"));
         ZM_CHECK(frames[i].img != nullptr, "zm_coadd: frame %d has no image", i);
         size_t ip = (size_t)frames[i].wcs.naxis[0] * frames[i].wcs.naxis[1];
-        total += ip * 4 * (1 + (frames[i].wgt ? 1 : 0) + (frames[i].mask && out_mask ? 1 : 0));
+        ZM_CHECK(!frames[i].mask || frames[i].mask_type == ZM_MASKTYPE_I32 || frames[i].mask_type == ZM_MASKTYPE_I16,
+                 "zm_coadd: frame %d: unknown mask_type %d", i, frames[i].mask_type);
+        total += ip * 4 * (1 + (frames[i].wgt ? 1 : 0));
+        if (frames[i].mask && out_mask) total += ip * (frames[i].mask_type == ZM_MASKTYPE_I16 ? 2 : 4);
         total = (total + 255) & ~(size_t)255;
     }
     char* base = nullptr;
@@ -542,10 +618,14 @@ extern "C" int zm_coadd(zm_ctx* ctx, int nframes, const zm_frame* frames, const 
             off += ip * 4;
         }
         df[i].mask = nullptr;
+        df[i].mask_type = frames[i].mask_type;
+        df[i].pad_ = 0;
         if (frames[i].mask && out_mask) {
-            df[i].mask = (const int32_t*)(base + off);
-            ZM_HIP(hipMemcpyAsync(base + off, frames[i].mask, ip * 4, hipMemcpyHostToDevice, ctx->stream));
-            off += ip * 4;
+            // (an int16 plane - a ZTF mask as it lies on disk - crosses PCIe as it is)
+            const size_t mbytes = ip * (frames[i].mask_type == ZM_MASKTYPE_I16 ? 2 : 4);
+            df[i].mask = base + off;
+            ZM_HIP(hipMemcpyAsync(base + off, frames[i].mask, mbytes, hipMemcpyHostToDevice, ctx->stream));
+            off += mbytes;
         }
         off = (off + 255) & ~(size_t)255;
     }

@@ -119,3 +119,32 @@ extern "C" int zm_add_scalar_dev(zm_ctx* ctx, float* img, float v, int64_t n) {
     ZM_HIP(hipGetLastError());
     return 0;
 }
+
+// int16 mask plane -> int32 (sign extension: what numpy's astype(int32) gives the host path).  For the
+// paths that read int32 masks only (k_resample, k_prep_box, k_resample_mask); the fused coadd reads int16.
+__global__ __launch_bounds__(256) void k_mask_widen(const int16_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p < n; p += stride) {
+        if (p + 4 <= n && ((uintptr_t)in & 7) == 0 && ((uintptr_t)out & 15) == 0) {
+            const short4 v = *reinterpret_cast<const short4*>(in + p);
+            *reinterpret_cast<int4*>(out + p) = make_int4(v.x, v.y, v.z, v.w);
+        } else {
+            for (int64_t q = p; q < n && q < p + 4; ++q) out[q] = in[q];
+        }
+    }
+}
+
+int zm_launch_mask_widen(zm_ctx* ctx, const int16_t* in, int64_t n, int32_t* out) {
+    int ncu = 256;
+    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, (int64_t)ncu * 8));
+    hipLaunchKernelGGL(k_mask_widen, dim3(grid), dim3(256), 0, ctx->stream, in, n, out);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zm_mask_widen_dev(zm_ctx* ctx, const int16_t* in, int64_t n, int32_t* out) {
+    ZM_CHECK(ctx && in && out && n > 0, "zm_mask_widen_dev: bad argument");
+    ZM_HIP(hipSetDevice(ctx->device));
+    return zm_launch_mask_widen(ctx, in, n, out);
+}

@@ -9,7 +9,7 @@
 __device__ inline uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 __device__ inline uint16_t bswap16(uint16_t v) { return (uint16_t)((v << 8) | (v >> 8)); }
 
-// BITPIX: 8, 16, 32, -32, -64.  out_kind: 0 float32, 1 int32, 2 uint8.
+// BITPIX: 8, 16, 32, -32, -64.  out_kind: 0 float32, 1 int32, 2 uint8, 3 int16 (a BITPIX 16 mask kept at 16 bits).
 // Physical value = bzero + bscale * stored (FITS 4.0, 5.3); integer outputs take the
 // integer BZERO exactly (unsigned 16 / 32 bit conventions), NaN stays NaN.
 __global__ __launch_bounds__(256) void k_fits_decode(const uint8_t* __restrict__ raw, int bitpix,
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_fits_decode(const uint8_t* __restrict__
         if (out_kind != 0 && bscale == 1.0 && bzero == floor(bzero)) {
             iv += (int64_t)bzero;
             if (out_kind == 1) reinterpret_cast<int32_t*>(out)[p] = (int32_t)iv;
+            else if (out_kind == 3) reinterpret_cast<int16_t*>(out)[p] = (int16_t)iv;
             else reinterpret_cast<uint8_t*>(out)[p] = (uint8_t)iv;
             return;
         }
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void k_fits_decode(const uint8_t* __restrict__
     if (scaled) v = bzero + bscale * v;
     if (out_kind == 0) reinterpret_cast<float*>(out)[p] = (float)v;
     else if (out_kind == 1) reinterpret_cast<int32_t*>(out)[p] = (int32_t)v;
+    else if (out_kind == 3) reinterpret_cast<int16_t*>(out)[p] = (int16_t)v;
     else reinterpret_cast<uint8_t*>(out)[p] = (uint8_t)v;
 }
 
@@ -72,7 +74,7 @@ extern "C" int zm_fits_decode_dev(zm_ctx* ctx, const void* raw_dev, int bitpix, 
     ZM_CHECK(ctx && raw_dev && out_dev && n > 0, "zm_fits_decode_dev: bad argument");
     ZM_CHECK(bitpix == 8 || bitpix == 16 || bitpix == 32 || bitpix == -32 || bitpix == -64,
              "zm_fits_decode_dev: unsupported BITPIX %d", bitpix);
-    ZM_CHECK(out_kind >= 0 && out_kind <= 2, "zm_fits_decode_dev: unknown output kind %d", out_kind);
+    ZM_CHECK(out_kind >= 0 && out_kind <= 3, "zm_fits_decode_dev: unknown output kind %d", out_kind);
     ZM_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_fits_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint8_t*)raw_dev, bitpix, bscale, bzero, n, out_kind, out_dev);

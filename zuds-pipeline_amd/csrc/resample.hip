@@ -1382,6 +1382,12 @@ __device__ inline float2 ff_raw_pixel(const zm_ff* __restrict__ F, int x, int y)
     return prep_pixel(v, w, F->wgt != nullptr, bg, vs, F->wthresh);
 }
 
+// one word of a frame's raw mask: an int16 plane (ZM_MASKTYPE_I16) means what its sign extension means
+__device__ inline int32_t ff_mask_at(const zm_ff* __restrict__ F, size_t idx) {
+    if (F->mask16) return (int32_t)((const int16_t ZM_GLOBAL*)F->mask)[idx];
+    return ((const int32_t ZM_GLOBAL*)F->mask)[idx];
+}
+
 // result of one generic pixel: {value, weight, mask bits, inb}
 struct ff_px {
     float v, w;
@@ -1421,9 +1427,9 @@ __device__ inline ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const floa
             const int r0 = ddy ? CI : 0, r1 = ddy ? CI + 1 : NT;
 #pragma unroll 1
             for (int rr = r0; rr < r1; ++rr) {
-                const int32_t ZM_GLOBAL* mp = zm_gptr(F->mask) + (size_t)(iy + rr) * nx + ix;
+                const size_t mo = (size_t)(iy + rr) * nx + ix;
 #pragma unroll 1
-                for (int c = c0; c < c1; ++c) mres |= mp[c];
+                for (int c = c0; c < c1; ++c) mres |= ff_mask_at(F, mo + c);
             }
         }
     }
@@ -1491,9 +1497,9 @@ __device__ inline ff_px ff_generic_pixel(const zm_ff* __restrict__ F, const floa
         } else {
 #pragma unroll 1
             for (int rr = 0; rr < NT; ++rr) {
-                const int32_t ZM_GLOBAL* mp = zm_gptr(F->mask) + (size_t)(iy + rr) * nx + ix;
+                const size_t mo = (size_t)(iy + rr) * nx + ix;
 #pragma unroll 1
-                for (int c = 0; c < NT; ++c) mres |= mp[c];
+                for (int c = 0; c < NT; ++c) mres |= ff_mask_at(F, mo + c);
             }
         }
     }
@@ -1562,7 +1568,7 @@ __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restr
     const int nx = J.nx, ny = J.ny;
     const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB, tid = threadIdx.x;
     if (x0 >= nx || y0 >= ny) return;                        // (the grid covers the largest frame)
-    const int32_t* __restrict__ m = J.m;
+    const int32_t* __restrict__ m = static_cast<const int32_t*>(J.m);
     constexpr int NLD = (IH * IW + 255) / 256;          // loads first, LDS stores after: one latency
     int32_t mm[NLD];
 #pragma unroll
@@ -1598,6 +1604,130 @@ __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restr
             if (en == ZM_BOX_RAW && J.rawflag) atomicOr(J.rawflag, 1);
         }
     }
+}
+
+// The same planes from a streaming kernel (round 4): the tiled kernel above reads a 69 x 21 halo box per
+// 64 x 16 tile (1.41 x the mask) through LDS; here a WAVE owns a strip of columns and walks down a band of
+// rows, every lane holding CPL consecutive columns: the horizontal OR of a row comes from the next lane(s)
+// (cross-lane moves, no LDS tile, no barrier), the vertical OR from a ring of the last NT row results in
+// registers - the mask is read once (+ NT - 1 rows per band, + one or two lanes per strip: 1.06 x) with
+// 16-byte loads, NT rows in flight.  T = int16_t: a ZTF mask as it lies on disk (ZM_MASKTYPE_I16), half the
+// bytes; a negative word stands for its sign extension, i.e. bits above 15: ZM_BOX_RAW.
+#define MB_ROWS 121                   // output rows per band: 121 + NT - 1 = 126 = 21 x NT input rows
+// CPL columns per lane, one 16-byte load per lane and row: 8 for int16, 4 for int32.  The horizontal OR
+// reaches NT - 1 columns ahead: into the next lane (CPL = 8), into the next two (CPL = 4); the last one /
+// two lanes of a wave only supply that halo, the next strip owns their columns.
+template <typename T> struct mb_row;
+template <> struct mb_row<int32_t> {
+    enum { CPL = 4, HALO_LANES = 2 };
+    static __device__ inline void load(const int32_t* p, bool vec, int nvalid, int32_t v[4]) {
+        if (vec && nvalid == 4) {
+            const int4 q = *reinterpret_cast<const int4*>(p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = k < nvalid ? p[k] : 0;
+        }
+    }
+};
+template <> struct mb_row<int16_t> {
+    enum { CPL = 8, HALO_LANES = 1 };
+    static __device__ inline void load(const int16_t* p, bool vec, int nvalid, int32_t v[8]) {
+        if (vec && nvalid == 8) {
+            const int4 q = *reinterpret_cast<const int4*>(p);          // eight words; sign extension below
+            const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] = (int32_t)(int16_t)(w[k] & 0xffff);
+                v[2 * k + 1] = w[k] >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = k < nvalid ? (int32_t)p[k] : 0;
+        }
+    }
+};
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void k_mask_box_rows(const zm_boxjob* __restrict__ jobs) {
+    constexpr int CPL = mb_row<T>::CPL, HL = mb_row<T>::HALO_LANES, OWN = 64 - HL;
+    static_assert(NT >= 2 && NT - 1 <= CPL * HL, "the horizontal OR reaches into HALO_LANES lanes");
+    const zm_boxjob J = jobs[blockIdx.z];
+    const int nx = J.nx, ny = J.ny;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * (CPL * OWN) + CPL * lane;             // this lane's columns
+    const int y0 = (blockIdx.y * 4 + wv) * MB_ROWS;                  // first output row of this wave's band
+    if (blockIdx.x * (CPL * OWN) >= nx || y0 >= ny) return;          // (wave-uniform: the grid covers the largest frame)
+    const T* __restrict__ m = reinterpret_cast<const T*>(J.m);
+    const bool vec = (nx % CPL) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0;
+    const int nvalid = min(max(nx - x, 0), CPL);
+    const bool owner = lane < OWN;
+    int32_t ring[NT][CPL];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) ring[k][e] = 0;
+    bool raw_seen = false;
+#pragma unroll 1
+    for (int r0 = 0; r0 < MB_ROWS + NT - 1; r0 += NT) {
+        if (y0 + r0 >= ny) break;                                    // nothing below the frame contributes
+        int32_t a[NT][CPL];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {                               // NT rows requested together
+            const int y = y0 + r0 + k;
+            if (y < ny && nvalid > 0) {
+                mb_row<T>::load(m + (size_t)y * nx + x, vec, nvalid, a[k]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) a[k][e] = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int y = y0 + r0 + k;                               // input row; it completes output row y - NT + 1
+            int32_t win[CPL + NT - 1];
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) win[e] = a[k][e];
+#pragma unroll
+            for (int e = 0; e < NT - 1; ++e)                         // columns x + CPL + e: lane + 1 (+ 2 beyond its CPL)
+                win[CPL + e] = __shfl_down(a[k][e % CPL], 1 + e / CPL);
+            // h[e] = OR of columns x + e .. x + e + NT - 1 of this row
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                int32_t o = 0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o |= win[e + t];
+                ring[k][e] = o;
+            }
+            const int yo = y - (NT - 1);
+            if (yo >= y0 && yo < y0 + MB_ROWS && y < ny && owner) {
+                uint16_t en[CPL];
+                bool all_in = true;
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    int32_t o = 0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o |= ring[t][e];
+                    en[e] = box_entry(o);
+                    const bool in = x + e + NT <= nx;
+                    all_in = all_in && in;
+                    raw_seen = raw_seen || (in && en[e] == ZM_BOX_RAW);
+                }
+                uint16_t* dst = J.B + (size_t)yo * J.pitch + x;
+                if (all_in) {
+                    unsigned pk[CPL / 2];
+#pragma unroll
+                    for (int e = 0; e < CPL / 2; ++e) pk[e] = (unsigned)en[2 * e] | ((unsigned)en[2 * e + 1] << 16);
+                    if constexpr (CPL == 8) *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    else *reinterpret_cast<uint2*>(dst) = make_uint2(pk[0], pk[1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e)
+                        if (x + e + NT <= nx) dst[e] = en[e];
+                }
+            }
+        }
+    }
+    if (J.rawflag && __any(raw_seen) && lane == 0) atomicOr(J.rawflag, 1);
 }
 
 // jobs: host arrays (staged through pinned memory behind an event, like the frame descriptors)
@@ -1636,7 +1766,13 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
     char *pin = nullptr, *dev = nullptr;
     ZM_TRY(ctx->get_pinned("ff_box_h", bb, (void**)&pin));
     ZM_TRY(ctx->get("ff_box", bb, (void**)&dev));
-    memcpy(pin, boxes, bb);
+    {
+        zm_boxjob* pj = reinterpret_cast<zm_boxjob*>(pin);        // int16 jobs first, then the int32 ones
+        int k = 0;
+        for (int pass = 1; pass >= 0; --pass)
+            for (int i = 0; i < nboxes; ++i)
+                if ((boxes[i].is16 != 0) == (pass == 1)) pj[k++] = boxes[i];
+    }
     // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
     const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "mask_box");
     static const bool fork_off = getenv("ZM_FF_FORK") && getenv("ZM_FF_FORK")[0] == '0';
@@ -1646,11 +1782,32 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
     ZM_HIP(hipMemcpyAsync(dev, pin, bb, hipMemcpyHostToDevice, s));
     ZM_HIP(hipEventRecord(ev[7], s));
     int mx = 1, my = 1;
-    for (int i = 0; i < nboxes; ++i) { mx = std::max(mx, boxes[i].nx); my = std::max(my, boxes[i].ny); }
+    bool any16 = false, any32 = false;
+    for (int i = 0; i < nboxes; ++i) {
+        mx = std::max(mx, boxes[i].nx);
+        my = std::max(my, boxes[i].ny);
+        (boxes[i].is16 ? any16 : any32) = true;
+    }
     {
+        // ZM_MASK_BOX=tile: the LDS-tiled kernel of round 3 (developer A / B; int32 planes only)
+        static const bool tiled = getenv("ZM_MASK_BOX") && !strcmp(getenv("ZM_MASK_BOX"), "tile");
         zm_scope_timer t(ctx, "mask_box");
-        hipLaunchKernelGGL(k_mask_box_batch<6>, dim3(zm_div_up(mx, 64), zm_div_up(my, 16), nboxes), dim3(256), 0, s,
-                           (const zm_boxjob*)dev);
+        if (tiled && !any16) {
+            hipLaunchKernelGGL(k_mask_box_batch<6>, dim3(zm_div_up(mx, 64), zm_div_up(my, 16), nboxes), dim3(256), 0, s,
+                               (const zm_boxjob*)dev);
+        } else {
+            // one launch per mask type over the jobs of that type (a stack normally has one): the jobs are
+            // sorted by type in the staging copy, a launch covers a contiguous range of them
+            const unsigned gy = zm_div_up(zm_div_up(my, MB_ROWS), 4);
+            int n16 = 0;
+            for (int i = 0; i < nboxes; ++i) n16 += boxes[i].is16 ? 1 : 0;
+            const zm_boxjob* d = (const zm_boxjob*)dev;
+            if (n16)
+                hipLaunchKernelGGL((k_mask_box_rows<int16_t, 6>), dim3(zm_div_up(mx, 8 * 63), gy, n16), dim3(256), 0, s, d);
+            if (nboxes - n16)
+                hipLaunchKernelGGL((k_mask_box_rows<int32_t, 6>), dim3(zm_div_up(mx, 4 * 62), gy, nboxes - n16), dim3(256), 0,
+                                   s, d + n16);
+        }
     }
     ZM_HIP(hipGetLastError());
     if (side) {

@@ -124,13 +124,14 @@ struct zm_ff {                       // one input frame of a fused coadd (device
     const float2* src;               // prepped {value, variance} plane: frames that cannot be staged raw (footprints
                                      // beyond the LDS tile, BACK_SIZE not a multiple of 8, ZM_FF_RAW=0), else NULL
     const double2* lat;              // lattice of this frame
-    const int32_t* mask;             // raw mask or NULL
+    const void* mask;                // raw mask (int32, or int16 when mask16) or NULL
     const uint16_t* mbox;            // box-OR plane of the mask
     const float* bk;                 // spline nodes (4 planes [nby][nbx]) or NULL: the per-tap path of the generic code
     const int* mboxflag;             // device word: != 0 when the box-OR plane holds ZM_BOX_RAW entries (NULL: assume so)
     int nx, ny, spitch, nbx, nby, ytp;
     float invmesh, wthresh, fscale, fscale2;
     int vec_ok, mpitch;              // mpitch: pixels per row of the box-OR plane (a multiple of 4)
+    int mask16, pad_;                // the raw mask is an int16 plane (ZM_MASKTYPE_I16)
 };
 // jobs of the pre-pass of a fused coadd (resample.hip: k_bk_rows, k_mask_box_batch)
 struct zm_bkrows {
@@ -141,10 +142,10 @@ struct zm_bkrows {
     int pad[3];
 };
 struct zm_boxjob {
-    const int32_t* m;
+    const void* m;                   // int32 plane, or int16 when is16
     uint16_t* B;
     int* rawflag;                    // set when an entry defers to the raw mask (or NULL)
-    int nx, ny, pitch, pad;
+    int nx, ny, pitch, is16;
 };
 // the fused coadd's tile rows and LDS capacity in staged pixels (resample.hip: FT_H, FF_LDS_CAP)
 void zm_fused_geometry(int* tile_h, int* lds_cap);
@@ -188,3 +189,4 @@ int zm_launch_mask_accum(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t np
                          int first);
 int zm_launch_mask_finalize(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
 int zm_launch_split_pairs(zm_ctx* ctx, const float2* src, int64_t npix, float* a, float* b);
+int zm_launch_mask_widen(zm_ctx* ctx, const int16_t* in, int64_t n, int32_t* out);

@@ -36,11 +36,15 @@ class DeviceFrames(object):
         for i, f in enumerate(frames):
             img = self._dev(f['img'], torch.float32, device)
             wgt = self._dev(f.get('wgt'), torch.float32, device)
-            msk = self._dev(f.get('mask'), torch.int32, device)
+            # an int16 mask (a ZTF mask as its BITPIX 16 file holds it) stays int16 in HBM: zm_dframe.mask_type
+            m = f.get('mask')
+            m16 = m is not None and (m.dtype == torch.int16 if isinstance(m, torch.Tensor) else np.asarray(m).dtype == np.int16)
+            msk = self._dev(m, torch.int16 if m16 else torch.int32, device)
             self.tensors.append((img, wgt, msk))
             self.arr[i].img = img.data_ptr()
             self.arr[i].wgt = wgt.data_ptr() if wgt is not None else None
             self.arr[i].mask = msk.data_ptr() if msk is not None else None
+            self.arr[i].mask_type = _lib.MASKTYPE_I16 if m16 else _lib.MASKTYPE_I32
             self.arr[i].wcs = wcs_struct(f['wcs'])
             self.arr[i].flxscale = float(f.get('flxscale', 1.0))
 
@@ -202,6 +206,14 @@ class DeviceSubtraction(object):
         self.engine.set_stream(self.stream.cuda_stream)
         self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
         with self.torch.cuda.stream(self.stream):
+            # an int16 science mask (a ZTF mask as its file holds it) is widened here, once: the
+            # bookkeeping kernels below read int32 words
+            if sci_mask.dtype == self.torch.int16:
+                if getattr(self, '_scimask32', None) is None:
+                    self._scimask32 = self.torch.empty(self.shape, dtype=self.torch.int32, device=self.device)
+                check(L.zm_mask_widen_dev(ctx, sci_mask.data_ptr(), self.n, self._scimask32.data_ptr()),
+                      'zm_mask_widen_dev')
+                sci_mask = self._scimask32
             # ref.aligned_to(sci): image (WEIGHT_TYPE NONE) + mask (OR), fitsfile.py:290-314.
             # The reference aligns a transaction copy whose mask is a plain MaskImageBase
             # (zuds/subtraction.py:94-99), so run_align does NOT add bit 16 to it
@@ -252,7 +264,7 @@ class DeviceSubtraction(object):
 
 # ---------------------------------------------------------------------------
 # FITS files <-> HBM without a host-side decode
-_KIND = {'f32': 0, 'i32': 1, 'u8': 2}
+_KIND = {'f32': 0, 'i32': 1, 'u8': 2, 'i16': 3}
 
 
 class FITSDeviceIO(object):
@@ -288,7 +300,8 @@ class FITSDeviceIO(object):
         return k, self._pin[k]
 
     def load(self, path, kind='f32'):
-        """(tensor on the device, header dict).  kind: 'f32', 'i32' or 'u8'."""
+        """(tensor on the device, header dict).  kind: 'f32', 'i32', 'u8' or 'i16'; 'mask': 'i16' for a
+        BITPIX 16 file without scaling (a ZTF mask), else 'i32'."""
         from . import fits
         torch = self.torch
         hdr, _, off = fits.read_header(path)
@@ -296,7 +309,9 @@ class FITSDeviceIO(object):
                                                              for i in range(1, int(hdr['NAXIS']) + 1)]))
         k, pin = self._staging(nbytes)
         raw, hdr, _, info = fits.read_raw(path, out=pin.numpy())
-        dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8}[kind]
+        if kind == 'mask':
+            kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
+        dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]
         out = torch.empty(info['shape'], dtype=dt, device=self.device)
         self.engine.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
@@ -349,7 +364,7 @@ class FITSDeviceIO(object):
             if weight_paths is not None and weight_paths[i] is not None:
                 f['wgt'] = self.load(weight_paths[i], 'f32')[0]
             if mask_paths is not None and mask_paths[i] is not None:
-                f['mask'] = self.load(mask_paths[i], 'i32')[0]
+                f['mask'] = self.load(mask_paths[i], 'mask')[0]
             frames.append(f)
         # consumers on other streams order against the loads through the current stream
         torch = self.torch

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (COMBINE, MASKCOMB, RESAMPLE, as_f32, as_i32, check, ptr,
+from ._lib import (COMBINE, MASKCOMB, RESAMPLE, as_f32, as_i32, as_mask, check, ptr,
                    wcs_struct)
 
 _default = None
@@ -120,18 +120,17 @@ class Engine(object):
         onx, ony = sout.naxis[0], sout.naxis[1]
         img = as_f32(img)
         wgt = as_f32(wgt)
-        mask = as_i32(mask)
+        mask, mtype = as_mask(mask)
         oimg = owgt = omask = None
         if img is not None:
             oimg = np.empty((ony, onx), dtype=np.float32)
             owgt = np.empty((ony, onx), dtype=np.float32)
         if mask is not None:
             omask = np.empty((ony, onx), dtype=np.int32)
-        check(self.L.zm_resample(self._ctx, ptr(img), ptr(wgt), ptr(mask),
-                                 C.byref(sin), C.byref(sout),
-                                 _enum(RESAMPLE, kernel, 'RESAMPLING_TYPE'),
-                                 float(fscale), ptr(oimg), ptr(owgt),
-                                 ptr(omask)), 'zm_resample')
+        fn = self.L.zm_resample_i16 if mtype == _lib.MASKTYPE_I16 else self.L.zm_resample
+        check(fn(self._ctx, ptr(img), ptr(wgt), ptr(mask), C.byref(sin), C.byref(sout),
+                 _enum(RESAMPLE, kernel, 'RESAMPLING_TYPE'), float(fscale), ptr(oimg), ptr(owgt),
+                 ptr(omask)), 'zm_resample')
         return oimg, owgt, omask
 
     # -- coadd -------------------------------------------------------------------
@@ -149,7 +148,7 @@ class Engine(object):
         for i, f in enumerate(frames):
             img = as_f32(f['img'])
             wgt = as_f32(f.get('wgt'))
-            msk = as_i32(f.get('mask'))
+            msk, mtype = as_mask(f.get('mask'))      # an int16 plane goes over as it is
             keep += [img, wgt, msk]
             s = wcs_struct(f['wcs'])
             if (s.naxis[1], s.naxis[0]) != img.shape:
@@ -158,6 +157,7 @@ class Engine(object):
             arr[i].img = ptr(img)
             arr[i].wgt = ptr(wgt)
             arr[i].mask = ptr(msk)
+            arr[i].mask_type = mtype
             arr[i].wcs = s
             arr[i].flxscale = float(f.get('flxscale', 1.0))
             any_mask |= msk is not None
@@ -177,7 +177,7 @@ class Engine(object):
     def resample_mask(self, mask, win, wout, kernel='LANCZOS3', combine='OR'):
         """Resample one integer mask; returns (None, None, mask, coverage) where
         coverage == 0 marks pixels the input does not reach (bit 16)."""
-        mask = as_i32(mask)
+        mask, _ = as_mask(mask)
         p = coadd_params(combine='WEIGHTED', mask_combine=combine, resample=kernel,
                          subtract_back=False, rescale_weights=False)
         frame = dict(img=np.zeros(mask.shape, dtype=np.float32), wgt=None, mask=mask,

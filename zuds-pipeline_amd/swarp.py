@@ -137,7 +137,8 @@ class SwarpCall(object):
         for i, im in enumerate(self.images):
             if as_mask:
                 frames.append(dict(img=np.zeros(im.data.shape, dtype=np.float32), wgt=None,
-                                   mask=np.ascontiguousarray(im.data).astype(np.int32),
+                                   mask=im.data if im.data.dtype == np.int16
+                                   else np.ascontiguousarray(im.data).astype(np.int32),
                                    wcs=im.wcs, flxscale=1.0))
             else:
                 wgt = im.weight_image.data if self.use_weights else None
