@@ -343,7 +343,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         yt_off[i] = yt_bytes;
         if (!need_src[i] && bki[i].nodes) {
             ff[i].ytp = std::max(bki[i].nbx - 1, 1);
-            yt_bytes += ((sizeof(float4) * (size_t)ny * ff[i].ytp) + 255) & ~(size_t)255;
+            yt_bytes += ((sizeof(float4) * ((size_t)ny * ff[i].ytp + (size_t)nx)) + 255) & ~(size_t)255;   // y table, then x weights
         }
     }
     if (yt_bytes) ZM_TRY(ctx->get("bk_rows_all", yt_bytes, (void**)&yt_all));
@@ -365,11 +365,13 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
             ff[i].nby = bki[i].nby;
             ff[i].invmesh = 1.0f / (float)P->back_size;
             ff[i].ytab = (const float4*)(yt_all + yt_off[i]);
+            ff[i].xtab = ff[i].ytab + (size_t)ny * ff[i].ytp;
             zm_bkrows r;
             memset(&r, 0, sizeof(r));
             r.bk = bki[i].nodes; r.out = (float4*)(yt_all + yt_off[i]);
             r.nbx = bki[i].nbx; r.nby = bki[i].nby; r.ny = ny; r.ytp = ff[i].ytp;
             r.invmesh = ff[i].invmesh;
+            r.nx = nx; r.xout = r.out + (size_t)ny * ff[i].ytp;
             rows.push_back(r);
         }
     }

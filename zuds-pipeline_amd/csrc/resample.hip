@@ -1318,7 +1318,12 @@ struct ff_hdr {
     float vscale;                    // the frame's variance scale (a device scalar: fetched here, by the pre-pass)
     int sdx[FF_NSUB], sdy[FF_NSUB];  // sub-box origin minus union origin
     int frame_raw;                   // the frame's box-OR plane has entries that defer to the raw mask (pre-pass flag)
-    int pad[FF_HDR_WORDS - 34 * FF_NSUB - 9 - 2 * FF_NSUB];
+    // background columns under the box (raw-staged frames with a background; round 4): the mesh column of the
+    // box's first pixel column and the first pixel column (frame coordinates, a multiple of 4) that lies in
+    // the next mesh column - INT_MAX when the box stays inside one.  The staging of k_coadd_fused_dma picks
+    // the y-table column of a quad with one comparison instead of evaluating bk_col per quad.
+    int ia, xb;
+    int pad[FF_HDR_WORDS - 34 * FF_NSUB - 11 - 2 * FF_NSUB];
 };
 static_assert(sizeof(ff_hdr) == FF_HDR_WORDS * 4, "ff_hdr is not its record");
 static_assert(3 * sizeof(ff_hdr) + 4 * 4 + 2 * 8 * 4 <= FF_LDS_HDR, "LDS header area too small");
@@ -1368,6 +1373,19 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
             H->sdx[u] = H->sub[u].bx0 - bx0;
             H->sdy[u] = H->sub[u].by0 - by0;
         }
+    }
+    {
+        // ia / xb: lane l looks at quad column l of the box (boxes staged in LDS are at most FD_XCOLS = 96 wide)
+        const int ubx0 = __shfl(bx0, 0), ubw = __shfl(bx1 - bx0, 0);
+        int ia = 0, xb = 0x7fffffff;
+        if (F->ytab) {
+            const int nxm1 = F->nx - 1, l = threadIdx.x & 63;
+            ia = bk_col(F->nbx, F->invmesh, min(max(ubx0, 0), nxm1));
+            const bool beyond = l < (ubw >> 2) && bk_col(F->nbx, F->invmesh, min(max(ubx0 + 4 * l, 0), nxm1)) > ia;
+            const unsigned long long bal = __ballot(beyond);
+            if (bal) xb = ubx0 + 4 * (__ffsll((long long)bal) - 1);
+        }
+        if ((threadIdx.x & 63) == 0) { H->ia = ia; H->xb = xb; }
     }
 }
 
@@ -1558,6 +1576,16 @@ __global__ __launch_bounds__(256) void k_bk_rows(const zm_bkrows* __restrict__ j
     J.out[e] = bk_ypart(J.bk, J.nbx, J.nby, J.invmesh, y, i0);
 }
 
+// ... and the x part: the four x weights {dx1, dx, cdx1, cdx} of every pixel column of a frame (a function of
+// the column alone), 16 B per column.  The staging of k_coadd_fused_dma fetches the columns of a box with the
+// LDS-DMA engine instead of computing them per item (round 4).
+__global__ __launch_bounds__(256) void k_bk_cols(const zm_bkrows* __restrict__ jobs) {
+    const zm_bkrows J = jobs[blockIdx.y];
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= J.nx || !J.xout) return;
+    J.xout[x] = bk_xweights(bk_dx(J.nbx, J.invmesh, x, bk_col(J.nbx, J.invmesh, x)));
+}
+
 // box-OR planes of all masks of a stack in one launch (k_mask_box per frame: 32 launches)
 template <int NT>
 __global__ __launch_bounds__(256) void k_mask_box_batch(const zm_boxjob* __restrict__ jobs) {
@@ -1743,10 +1771,14 @@ int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows) {
     memcpy(pin, rows, rb);
     ZM_HIP(hipMemcpyAsync(dev, pin, rb, hipMemcpyHostToDevice, ctx->stream));
     ZM_HIP(hipEventRecord(ev[6], ctx->stream));
-    int most = 1;
-    for (int i = 0; i < nrows; ++i) most = std::max(most, rows[i].ny * rows[i].ytp);
+    int most = 1, mostx = 1;
+    for (int i = 0; i < nrows; ++i) {
+        most = std::max(most, rows[i].ny * rows[i].ytp);
+        mostx = std::max(mostx, rows[i].nx);
+    }
     zm_scope_timer t(ctx, "bk_rows");
     hipLaunchKernelGGL(k_bk_rows, dim3(zm_div_up(most, 256), nrows), dim3(256), 0, ctx->stream, (const zm_bkrows*)dev);
+    hipLaunchKernelGGL(k_bk_cols, dim3(zm_div_up(mostx, 256), nrows), dim3(256), 0, ctx->stream, (const zm_bkrows*)dev);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -2469,155 +2501,200 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- staging, part 1: the DMA of an item's raw planes (every wave takes chunks of 64 pieces of 16 B)
+    // Round 4: the instruction diet of the staging.  What an item needs of the background geometry comes with
+    // its header (ia / xb) instead of two bk_col evaluations per item and one per quad; the x weights of the
+    // box columns are fetched from the frame's table (k_bk_cols) by the DMA engine - the xweights pass is gone;
+    // frame fields are read one by one (the descriptor by value cost ~30 SGPRs per section, spilled to lanes).
     auto dma = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
-        // the frame descriptor BY VALUE and the header fields, all requested before the first branch: their
-        // scalar loads and LDS reads go out together (read where they are used, every section began with a
-        // round trip of its own)
-        const zm_ff Fv = fr[f];
-        const zm_ff* F = &Fv;
+        const zm_ff* F = fr + f;
         const int use_lds = H->use_lds;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        const int hia = H->ia, hxb = H->xb;
         if (!use_lds || (dbg & 4)) return;
-        const int nx = F->nx, ny = F->ny, sp = F->spitch;
+        const int nx = F->nx, ny = F->ny;
         const int nq = bw4 * bh;
-        const bool prepped = F->src != nullptr;
-        const float ZM_GLOBAL* gI = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : zm_gptr(F->img);
-        const float ZM_GLOBAL* gW = prepped ? (const float ZM_GLOBAL*)zm_gptr(F->src) : (F->wgt ? zm_gptr(F->wgt) : zm_gptr(F->img));
+        const float2* fsrc = F->src;
+        const bool prepped = fsrc != nullptr;
         const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;   // (p + 0.5) / bw4 floors right for p < 2^12
+        if (prepped) {
+            const int sp = F->spitch;
+            const float ZM_GLOBAL* gS = (const float ZM_GLOBAL*)zm_gptr(fsrc);
 #pragma unroll 1
-        for (int chunk = wv; chunk * 64 < nq; chunk += NW) {
-            const int p = chunk * 64 + lane;
-            if (p < nq) {
-                const int row = (int)(((float)p + 0.5f) * inv4), c = p - row * bw4;
-                // (element offsets of a plane fit 32 bits: one uniform base + an unsigned lane offset per load)
-                const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
-                const int gx = bx0 + 4 * c;
-                unsigned oa, ob;
-                if (prepped) {
-                    oa = (gy * (unsigned)sp + (unsigned)min(max(gx, 0), sp - 2)) * 2u;
-                    ob = (gy * (unsigned)sp + (unsigned)min(max(gx + 2, 0), sp - 2)) * 2u;
-                } else {
-                    oa = ob = gy * (unsigned)nx + (unsigned)min(max(gx, 0), nx - 4);
+            for (int chunk = wv; chunk * 64 < nq; chunk += NW) {
+                const int p = chunk * 64 + lane;
+                if (p < nq) {
+                    const int row = (int)(((float)p + 0.5f) * inv4), c = p - row * bw4;
+                    const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
+                    const int gx = bx0 + 4 * c;
+                    const unsigned oa = (gy * (unsigned)sp + (unsigned)min(max(gx, 0), sp - 2)) * 2u;
+                    const unsigned ob = (gy * (unsigned)sp + (unsigned)min(max(gx + 2, 0), sp - 2)) * 2u;
+                    ff_glds16(gS + oa, RAWI + (size_t)chunk * 1024);
+                    ff_glds16(gS + ob, RAWW + (size_t)chunk * 1024);
                 }
-                ff_glds16(gI + oa, RAWI + (size_t)chunk * 1024);
-                ff_glds16(gW + ob, RAWW + (size_t)chunk * 1024);
+            }
+        } else {
+            // (element offsets of a plane fit 32 bits: one uniform base + an unsigned lane offset per load)
+            const float* fw = F->wgt;
+            const float ZM_GLOBAL* gI = zm_gptr(F->img);
+            const float ZM_GLOBAL* gW = fw ? zm_gptr(fw) : gI;
+#pragma unroll 1
+            for (int chunk = wv; chunk * 64 < nq; chunk += NW) {
+                const int p = chunk * 64 + lane;
+                if (p < nq) {
+                    const int row = (int)(((float)p + 0.5f) * inv4), c = p - row * bw4;
+                    const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
+                    const unsigned o = gy * (unsigned)nx + (unsigned)min(max(bx0 + 4 * c, 0), nx - 4);
+                    ff_glds16(gI + o, RAWI + (size_t)chunk * 1024);
+                    ff_glds16(gW + o, RAWW + (size_t)chunk * 1024);
+                }
             }
         }
+        const uint16_t* fmb = F->mbox;
         if (MOP && F->mask) {
             // the box-OR tile starts on a multiple of 8 pixels (16-byte pieces of a plane with such a pitch)
+            const int mpitch = F->mpitch;
             const int mx0 = bx0 & ~7, bwm8 = ((bx0 + bw - mx0) + 7) >> 3, nm = bwm8 * bh;
             const float inv8 = __builtin_amdgcn_rcpf((float)bwm8) * 1.0000002f;
             char* M = reinterpret_cast<char*>(MSK0) + (size_t)mb * 2 * mcap;
+            const uint16_t ZM_GLOBAL* gM = zm_gptr(fmb);
+            // (the waves with the fewest image chunks first: chunk k goes to wave NW - 1 - k)
 #pragma unroll 1
-            for (int chunk = wv; chunk * 64 < nm; chunk += NW) {
+            for (int chunk = NW - 1 - wv; chunk * 64 < nm; chunk += NW) {
                 const int p = chunk * 64 + lane;
                 if (p < nm) {
                     const int row = (int)(((float)p + 0.5f) * inv8), c8 = p - row * bwm8;
                     const unsigned gy = (unsigned)min(max(by0 + row, 0), ny - 1);
-                    const int gxm = min(max(mx0 + 8 * c8, 0), F->mpitch - 8);
-                    ff_glds16(zm_gptr(F->mbox) + (gy * (unsigned)F->mpitch + (unsigned)gxm), M + (size_t)chunk * 1024);
+                    const int gxm = min(max(mx0 + 8 * c8, 0), mpitch - 8);
+                    ff_glds16(gM + (gy * (unsigned)mpitch + (unsigned)gxm), M + (size_t)chunk * 1024);
                 }
             }
         }
-        if (F->ytab && !prepped) {
+        const float4* fyt = F->ytab;
+        if (fyt && !prepped) {
             // the y part of the background for the box rows, one table column per mesh column under the box
-            const int ia = bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1));
-            const int ib = bk_col(F->nbx, F->invmesh, min(max(bx0 + bw - 1, 0), nx - 1));
-            if (wv <= ib - ia && wv < FD_YCOLS && lane < bh) {
-                const unsigned gy = (unsigned)min(max(by0 + lane, 0), ny - 1);
-                ff_glds16(zm_gptr(F->ytab) + (gy * (unsigned)F->ytp + (unsigned)min(ia + wv, F->ytp - 1)),
-                          reinterpret_cast<char*>(YT) + (size_t)wv * FD_YROWS * 16);
+            // (waves 4, 5), and the x weights of the box columns as [pixel of the quad][quad column] (waves 6, 7)
+            if (wv >= 4 && wv < 6) {
+                const int col = wv - 4;
+                if ((col == 0 || hxb != 0x7fffffff) && lane < bh) {
+                    const int ytp = F->ytp;
+                    const unsigned gy = (unsigned)min(max(by0 + lane, 0), ny - 1);
+                    ff_glds16(zm_gptr(fyt) + (gy * (unsigned)ytp + (unsigned)min(hia + col, ytp - 1)),
+                              reinterpret_cast<char*>(YT) + (size_t)col * FD_YROWS * 16);
+                }
+            } else if (wv >= 6) {
+                const int slot = (wv - 6) * 64 + lane;
+                if (slot < FD_XCOLS) {
+                    const int e = (slot * 2731) >> 16, c = slot - e * FD_XQ;          // slot / 24 for slot < 96
+                    const int gx = min(max(bx0 + 4 * c + e, 0), nx - 1);
+                    ff_glds16(zm_gptr(F->xtab) + gx, reinterpret_cast<char*>(XW) + (size_t)(wv - 6) * 1024);
+                }
             }
-        }
-    };
-    // the x weights of the box columns of an item (threads 0 .. bw - 1), read by its prep pass
-    auto xweights = [&](const ff_hdr* H, int f) __attribute__((always_inline)) {
-        const zm_ff Fv = fr[f];
-        const zm_ff* F = &Fv;
-        const int use_lds = H->use_lds, hbw = H->bw, hbx0 = H->bx0;     // (requested before the first branch)
-        if (!use_lds || !F->ytab || F->src) return;
-        if (tid < hbw) {
-            const int gx = hbx0 + tid;
-            const int i0 = bk_col(F->nbx, F->invmesh, min(max(gx, 0), F->nx - 1));
-            XW[(tid & 3) * FD_XQ + (tid >> 2)] = bk_xweights(bk_dx(F->nbx, F->invmesh, gx, i0));
         }
     };
     // ---- staging, part 2: raw quads -> prepped tile (background off, variance, bad pixels, fill)
-    auto prep_impl = [&](const ff_hdr* H, int f, int mb, auto fast_tag) __attribute__((always_inline)) {
+    // A thread takes quads tid and tid + FD_THREADS of the box.  Raw and prepped tiles are linear in the quad
+    // index (the DMA wrote quad q at 16 q, the pair plane holds it at 32 q): no row / column arithmetic for
+    // the addresses; the row and quad column are needed for the background and for the frame edge only.
+    // Straight-line per quad: every LDS read of both quads first, then the arithmetic (a read inside a
+    // condition is waited for on the spot).  Conditions are item-uniform branches, never per pixel.
+    auto prep_raw = [&](const ff_hdr* H, int f, auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        const zm_ff Fv = fr[f];
-        const zm_ff* F = &Fv;
-        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
-        const float hvs = H->vscale;
-        const int nx = F->nx, ny = F->ny, sp = F->spitch;
+        const zm_ff* F = fr + f;
+        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2, hxb = H->xb;
+        const float vs = H->vscale;
+        const float* fw = F->wgt;
+        const float4* fyt = F->ytab;
+        const float fwth = F->wthresh;
+        const int nx = F->nx, ny = F->ny;
         const int nq = bw4 * bh;
-        const bool prepped = F->src != nullptr;
-        const bool has_w = F->wgt != nullptr, has_y = F->ytab != nullptr && !prepped;
-        const float vs = hvs, wth = F->wthresh;
-        const float4 fill = make_float4(0.f, ZM_BIGVAR, 0.f, ZM_BIGVAR);
+        const bool has_w = fw != nullptr, has_y = fyt != nullptr;
         const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;   // (q + 0.5) / bw4 floors right for q < 2^12
-        const int ia = has_y ? bk_col(F->nbx, F->invmesh, min(max(bx0, 0), nx - 1)) : 0;
-        // (straight-line: the LDS reads of both quads of a thread first, then the arithmetic; a lane without a
-        // second quad works on the last one again and does not store - a branch per quad serialises the round trips)
         // (the second quad exists for the first waves only: a wave-uniform count)
         const int nk = (FD_THREADS + 64 * wv < nq) ? 2 : 1;
-        int qs[2], rows[2], cs[2];
-        float4 ra[2], rb[2], ry[2];
+        float4 ra[2], rb[2], ry[2], xw[2][4];
+        int rows[2], cs[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k >= nk) break;
-            qs[k] = min(tid + FD_THREADS * k, nq - 1);
-            rows[k] = (int)(((float)qs[k] + 0.5f) * inv4);
-            cs[k] = qs[k] - rows[k] * bw4;
-            ra[k] = reinterpret_cast<const float4*>(RAWI)[qs[k]];
-            rb[k] = reinterpret_cast<const float4*>(RAWW)[qs[k]];
+            const int q = min(tid + FD_THREADS * k, nq - 1);
+            ra[k] = reinterpret_cast<const float4*>(RAWI)[q];
+            rb[k] = reinterpret_cast<const float4*>(RAWW)[q];
+            rows[k] = 0;
+            cs[k] = 0;
+            if (has_y || !FAST) {
+                rows[k] = (int)(((float)q + 0.5f) * inv4);
+                cs[k] = q - rows[k] * bw4;
+            }
             if (has_y) {
-                const int gx = bx0 + 4 * cs[k];
-                const int yc = bk_col(F->nbx, F->invmesh, min(max(gx, 0), nx - 1)) - ia;
-                ry[k] = YT[min(max(yc, 0), FD_YCOLS - 1) * FD_YROWS + rows[k]];
+                const int ysel = (bx0 + 4 * cs[k] >= hxb) ? FD_YROWS : 0;
+                ry[k] = YT[ysel + rows[k]];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xw[k][e] = XW[e * FD_XQ + cs[k]];
             }
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k >= nk) break;
-            const int row = rows[k], c = cs[k];
-            const int gx = bx0 + 4 * c;
-            const float4 a = ra[k], b = rb[k];
-            const bool rowok = FAST || (unsigned)(by0 + row) < (unsigned)ny;
-            float4 o0, o1;
-            if (prepped) {
-                const bool cpa = FAST || (gx >= 0 && gx <= sp - 2), cpb = FAST || (gx + 2 >= 0 && gx + 2 <= sp - 2);
-                o0 = (rowok && cpa) ? a : fill;
-                o1 = (rowok && cpb) ? b : fill;
+            const float v[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+            const float w[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+            float bg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_y) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bg[e] = bk_xpart(ry[k], xw[k][e]);
+            }
+            float2 p[4];
+            if (has_w) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = prep_pixel(v[e], w[e], true, bg[e], vs, fwth);
             } else {
-                const bool cok = FAST || (gx >= 0 && gx + 4 <= nx);
-                const float v[4] = {a.x, a.y, a.z, a.w}, w[4] = {b.x, b.y, b.z, b.w};
-                float2 p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = prep_pixel(v[e], 1.f, false, bg[e], vs, fwth);
+            }
+            if (!FAST) {
+                const int gx = bx0 + 4 * cs[k];
+                const bool ok = (unsigned)(by0 + rows[k]) < (unsigned)ny && gx >= 0 && gx + 4 <= nx;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float bg = has_y ? bk_xpart(ry[k], XW[e * FD_XQ + c]) : 0.f;
-                    p[e] = prep_pixel(v[e], w[e], has_w, bg, vs, wth);
-                    if (!FAST) {
-                        const bool ok = rowok && cok;
-                        p[e].x = ok ? p[e].x : 0.f;
-                        p[e].y = ok ? p[e].y : ZM_BIGVAR;
-                    }
+                    p[e].x = ok ? p[e].x : 0.f;
+                    p[e].y = ok ? p[e].y : ZM_BIGVAR;
                 }
-                o0 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
-                o1 = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
             }
-            if (tid + FD_THREADS * k < nq) {
-                float4* d = reinterpret_cast<float4*>(PREP + (size_t)row * bw + 4 * c);
-                d[0] = o0;
-                d[1] = o1;
+            const int q = tid + FD_THREADS * k;
+            if (q < nq) {
+                float4* d = reinterpret_cast<float4*>(PREP) + 2 * q;
+                d[0] = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+                d[1] = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
             }
+        }
+    };
+    // frames that could not be staged raw arrive prepped (zm_ff.src): pairs as they are, fill at the frame edge
+    auto prep_src = [&](const ff_hdr* H, int f, bool fast) __attribute__((always_inline)) {
+        const zm_ff* F = fr + f;
+        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh, bw4 = bw >> 2;
+        const int ny = F->ny, sp = F->spitch;
+        const int nq = bw4 * bh;
+        const float inv4 = __builtin_amdgcn_rcpf((float)bw4) * 1.0000002f;
+#pragma unroll 1
+        for (int q = tid; q < nq; q += FD_THREADS) {
+            const float4 a = reinterpret_cast<const float4*>(RAWI)[q], b = reinterpret_cast<const float4*>(RAWW)[q];
+            const int row = (int)(((float)q + 0.5f) * inv4), c = q - row * bw4;
+            const int gx = bx0 + 4 * c;
+            const bool rowok = fast || (unsigned)(by0 + row) < (unsigned)ny;
+            const bool cpa = fast || (gx >= 0 && gx <= sp - 2), cpb = fast || (gx + 2 >= 0 && gx + 2 <= sp - 2);
+            // (component-wise: a select between whole float4 values is lowered through a stack array)
+            const bool oka = rowok && cpa, okb = rowok && cpb;
+            float4* d = reinterpret_cast<float4*>(PREP) + 2 * q;
+            d[0] = make_float4(oka ? a.x : 0.f, oka ? a.y : ZM_BIGVAR, oka ? a.z : 0.f, oka ? a.w : ZM_BIGVAR);
+            d[1] = make_float4(okb ? b.x : 0.f, okb ? b.y : ZM_BIGVAR, okb ? b.z : 0.f, okb ? b.w : ZM_BIGVAR);
         }
     };
     auto prep = [&](const ff_hdr* H, int f, int mb) __attribute__((always_inline)) {
         const int use_lds = H->use_lds, fast = H->fast;                  // (both requested before the first branch)
+        const float2* fsrc = fr[f].src;
         if (!use_lds || (dbg & 2)) return;
-        if (fast) prep_impl(H, f, mb, std::true_type{});
-        else prep_impl(H, f, mb, std::false_type{});
+        if (fsrc) prep_src(H, f, fast != 0);
+        else if (fast) prep_raw(H, f, std::true_type{});
+        else prep_raw(H, f, std::false_type{});
     };
     const int nty = ntiles / ntx;
     // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
@@ -2655,7 +2732,6 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
     __syncthreads();
     dma(&HR[0], f0, 0);
-    xweights(&HR[0], f0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     prep(&HR[0], f0, 0);
@@ -2727,10 +2803,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         const bool more = t1 < ntiles;
         // the raw planes of the next item: DMA into the raw tiles (free since the last barrier), its
         // box-OR tile into the other mask buffer; its x weights
-        if (more) {
-            dma(&HR[nslot], f1, buf ^ 1);
-            xweights(&HR[nslot], f1);
-        }
+        if (more) dma(&HR[nslot], f1, buf ^ 1);
         FD_TICK(0);
 
         const bool do_px = touches && !(dbg & 1);

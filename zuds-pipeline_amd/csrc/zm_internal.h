@@ -120,6 +120,7 @@ struct zm_ff {                       // one input frame of a fused coadd (device
     const float* img;                // raw planes: staged with background, variance and threshold applied on the way
     const float* wgt;                // ... or NULL (unit weights)
     const float4* ytab;              // y part of the background spline per (row, mesh column) (k_bk_rows), or NULL
+    const float4* xtab;              // ... and the x weights per pixel column (k_bk_cols); set with ytab
     const float* vscale;             // device scalar: variance scale (RESCALE_WEIGHTS), or NULL
     const float2* src;               // prepped {value, variance} plane: frames that cannot be staged raw (footprints
                                      // beyond the LDS tile, BACK_SIZE not a multiple of 8, ZM_FF_RAW=0), else NULL
@@ -139,7 +140,8 @@ struct zm_bkrows {
     float4* out;                     // [ny][ytp]
     int nbx, nby, ny, ytp;
     float invmesh;
-    int pad[3];
+    int nx;
+    float4* xout;                    // [nx]: the x weights of every pixel column (k_bk_cols)
 };
 struct zm_boxjob {
     const void* m;                   // int32 plane, or int16 when is16
