@@ -186,11 +186,12 @@ __device__ inline void bk_eval4(const float* __restrict__ bk, int nbx, int nby, 
 // and a multiply (1 ulp; the parity tolerance of a resampled weight is 5e-5): the staging of the
 // fused coadd evaluates this once per staged pixel.
 __device__ inline float2 prep_pixel(float v, float w, bool has_w, float bg, float var_scale, float wthresh) {
-    float val = v - bg;
-    float var = var_scale;
-    if (has_w) var = (w > wthresh) ? var_scale * __builtin_amdgcn_rcpf(w) : ZM_BIGVAR;
-    const bool nan = !(val == val);                       // NaN pixels are bad
-    return make_float2(nan ? 0.f : val, nan ? ZM_BIGVAR : var);
+    const float val = v - bg;
+    const bool ok = (val == val);                         // NaN pixels are bad
+    // (one select per plane: the weight test and the NaN test meet in the scalar condition)
+    const bool good = has_w ? (ok && w > wthresh) : ok;
+    const float var = has_w ? var_scale * __builtin_amdgcn_rcpf(w) : var_scale;
+    return make_float2(ok ? val : 0.f, good ? var : ZM_BIGVAR);
 }
 
 // four prepped pixels (x a multiple of 4): two float4 {value, variance, value, variance}
@@ -1577,13 +1578,21 @@ __global__ __launch_bounds__(256) void k_bk_rows(const zm_bkrows* __restrict__ j
 }
 
 // ... and the x part: the four x weights {dx1, dx, cdx1, cdx} of every pixel column of a frame (a function of
-// the column alone), 16 B per column.  The staging of k_coadd_fused_dma fetches the columns of a box with the
-// LDS-DMA engine instead of computing them per item (round 4).
+// the column alone).  The staging of k_coadd_fused_dma fetches the columns of a box with the LDS-DMA engine
+// instead of computing them per item (round 4).  Layout: [weight k][quad column] float4 = weight k of the four
+// pixels of a quad (nx a multiple of 4: only frames that are staged raw get a table) - the prep pass then
+// evaluates the background of two pixels per packed FMA without moving registers around.
 __global__ __launch_bounds__(256) void k_bk_cols(const zm_bkrows* __restrict__ jobs) {
     const zm_bkrows J = jobs[blockIdx.y];
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= J.nx || !J.xout) return;
-    J.xout[x] = bk_xweights(bk_dx(J.nbx, J.invmesh, x, bk_col(J.nbx, J.invmesh, x)));
+    const float4 w = bk_xweights(bk_dx(J.nbx, J.invmesh, x, bk_col(J.nbx, J.invmesh, x)));
+    float* xo = reinterpret_cast<float*>(J.xout);
+    const size_t nq4 = (size_t)(J.nx >> 2), e = (size_t)(x >> 2) * 4 + (x & 3);
+    xo[e] = w.x;
+    xo[nq4 * 4 + e] = w.y;
+    xo[nq4 * 8 + e] = w.z;
+    xo[nq4 * 12 + e] = w.w;
 }
 
 // box-OR planes of all masks of a stack in one launch (k_mask_box per frame: 32 launches)
@@ -1855,8 +1864,10 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
 struct lds_row6 {
     unsigned long long r0, r1, r2, r3, r4, r5;
 };
-__device__ inline void lds_issue6(const float2* p, lds_row6& o) {
-    const unsigned a = (unsigned)(size_t)p;
+__device__ inline void lds_issue6(unsigned a, lds_row6& o);
+__device__ inline void lds_issue6(const float2* p, lds_row6& o) { lds_issue6((unsigned)(size_t)p, o); }
+// (a: the 32-bit LDS address - row arithmetic on a generic 64-bit pointer costs 64-bit multiply-adds)
+__device__ inline void lds_issue6(unsigned a, lds_row6& o) {
     asm volatile("ds_read_b64 %0, %6\n\t"
                  "ds_read_b64 %1, %6 offset:8\n\t"
                  "ds_read_b64 %2, %6 offset:16\n\t"
@@ -1885,10 +1896,16 @@ struct lz3_node {
     zm_v2f h;
 };
 __device__ inline void lz3_issue(const float* tab, float d, lz3_node& n, float& dl) {
-    const float fi = __builtin_rintf(d * (float)LZ_N);
+    // fi = rint(d LZ_N), the node, as zm_lz3_lookup computes it - here through the magic-number addition:
+    // d LZ_N is exact (a power of two), 1.5 x 2^23 + it rounds to the nearest integer, ties to even like
+    // rint (the magic number is even), and the integer sits in the low mantissa bits: the node address is one
+    // 24-bit multiply-add on the bit pattern (the 24-bit operand ignores the exponent bits above), no
+    // float -> int conversion.  Four instructions instead of five, the same node and the same dl.
+    const float magic = 12582912.0f;                                  // 0x4B400000: mantissa field 0x400000 + fi
+    const float tm = __builtin_fmaf(d, (float)LZ_N, magic);
+    const float fi = tm - magic;
     dl = __builtin_fmaf(fi, -1.0f / LZ_N, d);
-    // (a 24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate)
-    const unsigned a = (unsigned)(size_t)tab + (unsigned)__mul24((int)fi, LZ_ENTRY * 4);
+    const unsigned a = __umul24(__float_as_uint(tm), LZ_ENTRY * 4) + ((unsigned)(size_t)tab - 0x400000u * (LZ_ENTRY * 4));
     asm volatile("ds_read_b128 %0, %5\n\t"
                  "ds_read_b128 %1, %5 offset:16\n\t"
                  "ds_read_b128 %2, %5 offset:32\n\t"
@@ -2477,13 +2494,19 @@ __device__ inline void ff_glds16(const void ZM_GLOBAL* src, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int MOP, bool AVG, bool STACK>
+// DEV: the developer instance (ZM_FF_PROF phase clocks, ZM_FF_DBG ablations).  The production instances
+// carry neither: the five phase counters and their clock alone held 12 SGPRs through the whole item loop of
+// a kernel that spills SGPRs into VGPR lanes (every spill slot costs v_readlane / v_writelane on the vector
+// pipe, and the lanes' registers count against the 128 of a wave at four waves per SIMD).
+template <int MOP, bool AVG, bool STACK, bool DEV = false>
 __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
     const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
     int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
     const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride,
-    int dbg, long long* __restrict__ prof) {
+    int dbg_arg, long long* __restrict__ prof_arg) {
+    long long* const prof = DEV ? prof_arg : nullptr;
+    const int dbg = DEV ? dbg_arg : (dbg_arg & ~255);            // (bits 8 ..: the tile budget of the yield mode)
     extern __shared__ float4 smem4[];
     char* smem = reinterpret_cast<char*>(smem4);
     ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem);                  // ring of 3 headers
@@ -2582,11 +2605,13 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                               reinterpret_cast<char*>(YT) + (size_t)col * FD_YROWS * 16);
                 }
             } else if (wv >= 6) {
+                // slot k FD_XQ + c of the LDS table: weight k of the four pixels of quad column c of the box
                 const int slot = (wv - 6) * 64 + lane;
                 if (slot < FD_XCOLS) {
-                    const int e = (slot * 2731) >> 16, c = slot - e * FD_XQ;          // slot / 24 for slot < 96
-                    const int gx = min(max(bx0 + 4 * c + e, 0), nx - 1);
-                    ff_glds16(zm_gptr(F->xtab) + gx, reinterpret_cast<char*>(XW) + (size_t)(wv - 6) * 1024);
+                    const int k = (slot * 2731) >> 16, c = slot - k * FD_XQ;          // slot / 24 for slot < 96
+                    const int nq4 = nx >> 2;
+                    const int gq = min(max((bx0 >> 2) + c, 0), nq4 - 1);
+                    ff_glds16(zm_gptr(F->xtab) + (k * nq4 + gq), reinterpret_cast<char*>(XW) + (size_t)(wv - 6) * 1024);
                 }
             }
         }
@@ -2629,7 +2654,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                 const int ysel = (bx0 + 4 * cs[k] >= hxb) ? FD_YROWS : 0;
                 ry[k] = YT[ysel + rows[k]];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xw[k][e] = XW[e * FD_XQ + cs[k]];
+                for (int e = 0; e < 4; ++e) xw[k][e] = XW[e * FD_XQ + cs[k]];      // weight e of the quad's four pixels
             }
         }
 #pragma unroll
@@ -2639,8 +2664,19 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
             const float w[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
             float bg[4] = {0.f, 0.f, 0.f, 0.f};
             if (has_y) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bg[e] = bk_xpart(ry[k], xw[k][e]);
+                // bk_xpart of the four pixels, two per packed instruction: xw[k][j] holds weight j of the four
+                // pixels, ry[k] the y part {r0, r1, e0, e1}; the same products and fused multiply-adds in the
+                // same order as bk_xpart (a product does not depend on the order of its factors)
+                const float4 *X = xw[k], Y = ry[k];
+                zm_v2f lo = (zm_v2f){X[0].x, X[0].y} * (zm_v2f){Y.x, Y.x};
+                zm_v2f hi = (zm_v2f){X[0].z, X[0].w} * (zm_v2f){Y.x, Y.x};
+                lo = __builtin_elementwise_fma((zm_v2f){X[1].x, X[1].y}, (zm_v2f){Y.y, Y.y}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){X[1].z, X[1].w}, (zm_v2f){Y.y, Y.y}, hi);
+                lo = __builtin_elementwise_fma((zm_v2f){X[2].x, X[2].y}, (zm_v2f){Y.z, Y.z}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){X[2].z, X[2].w}, (zm_v2f){Y.z, Y.z}, hi);
+                lo = __builtin_elementwise_fma((zm_v2f){X[3].x, X[3].y}, (zm_v2f){Y.w, Y.w}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){X[3].z, X[3].w}, (zm_v2f){Y.w, Y.w}, hi);
+                bg[0] = lo.x; bg[1] = lo.y; bg[2] = hi.x; bg[3] = hi.y;
             }
             float2 p[4];
             if (has_w) {
@@ -2763,8 +2799,8 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         }
     };
     long long ptk[5] = {0, 0, 0, 0, 0}, tc = 0;      // developer (ZM_FF_PROF=1): shader-clock sums per phase of this wave
-#define FD_TICK(k) do { if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
-    if (prof) tc = __builtin_amdgcn_s_memtime();
+#define FD_TICK(k) do { if (DEV && prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
+    if (DEV && prof) tc = __builtin_amdgcn_s_memtime();
     const int budget = dbg >> 8;
     int ngrab = 0;
     int slot = 0, buf = 0;
@@ -2898,13 +2934,14 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                 }
                 zm_v2f av[4];
                 lds_row6 ra, rb;
-                lds_issue6(p, ra);
+                const unsigned pa = (unsigned)(size_t)p, bw8 = (unsigned)bw * 8u;    // 32-bit LDS address, row pitch in bytes
+                lds_issue6(pa, ra);
 #pragma unroll
                 for (int rho = 0; rho < NT + 3; ++rho) {
                     lds_row6& cur = (rho & 1) ? rb : ra;
                     lds_row6& nxt = (rho & 1) ? ra : rb;
                     if (rho + 1 < NT + 3) {
-                        lds_issue6(p + (rho + 1) * bw, nxt);
+                        lds_issue6(pa + (unsigned)(rho + 1) * bw8, nxt);
                         lds_wait_n<6>(cur);
                     } else {
                         lds_wait_n<0>(cur);
@@ -3006,7 +3043,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         if (grab && tid == 0) tring[(k2 + 1) & 3] = tile_of(gnext);
         FD_TICK(4);
         __syncthreads();
-        if (prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[3] += t_ - tc; tc = t_; }
+        if (DEV && prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[3] += t_ - tc; tc = t_; }
         t0 = t1; f0 = f1;
         t1 = t2; f1 = f2;
         next_item(t2, f2, k2);
@@ -3015,7 +3052,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
         if (t0 >= ntiles) break;
     }
     if (STACK) flush();
-    if (prof && lane == 0)
+    if (DEV && prof && lane == 0)
         for (int k = 0; k < 5; ++k) prof[((size_t)blockIdx.x * NW + wv) * 5 + k] = ptk[k];
 #undef FD_TICK
 }
@@ -3096,11 +3133,12 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
 #define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
     do {                                                                                                       \
         if (use_dma) {                                                                                         \
-            auto kd = k_coadd_fused_dma<MOPV, AVGV, STACKV>;                                                   \
-            static bool dattr[64] = {};                                                                        \
-            if (!dattr[ctx->device & 63]) {                                                                    \
+            const bool devk = want_prof || (dbg & 255);                                                        \
+            auto kd = devk ? k_coadd_fused_dma<MOPV, AVGV, STACKV, true> : k_coadd_fused_dma<MOPV, AVGV, STACKV, false>; \
+            static bool dattr[2][64] = {};                                                                     \
+            if (!dattr[devk][ctx->device & 63]) {                                                              \
                 ZM_HIP(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
-                dattr[ctx->device & 63] = true;                                                                \
+                dattr[devk][ctx->device & 63] = true;                                                          \
             }                                                                                                  \
             hipLaunchKernelGGL(kd, dim3(G), dim3(FD_THREADS), shmem, ctx->stream, dev, nfr, onx, ony, lds_elems, \
                                ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, taptab, tilectr, \
