@@ -37,9 +37,12 @@ if int(os.environ.get('WORLD_SIZE', '1')) == 1:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (packed FMA), spec
+# fp64 matrix peak: 256 CUs x 4 SIMDs x one v_mfma_f64_16x16x4_f64 (2 x 16 x 16 x 4 flop) per 64 cycles (the
+# instruction cost measured for k_chol_fused) x 2.4 GHz = 78.6 TFLOP/s = AMD's FP64 matrix figure
+MFMA_F64_PEAK_TFLOPS = 78.6
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
-PMC_PROFILES = ['r03_pmc_coadd_fused.json']     # newest first; each stamped with the hash of the kernel sources it measured
+PMC_PROFILES = ['r04_pmc.json']     # newest first; each stamped with the hash of the kernel sources it measured
 
 
 def parse():
@@ -121,12 +124,13 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_profile(args, kernel):
-    """Counter figures per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; SQ_INSTS_VALU).  Counters cannot be
-    collected inside a bench run (separate --pmc passes), so they are quoted - but only from a profile
-    that was measured on THESE kernel sources (`kernel_sources_sha16`); otherwise {'stale': ...} and the
-    line carries null for traffic / valu_frac / lds_frac."""
+def pmc_profile(args):
+    """The counter profile of this tree's kernels (tools/make_pmc_json.py, one tools/gpu_round.sh call): per
+    bench command ('weighted', 'clipped') and kernel the mean of FETCH_SIZE (doubled: gfx950 tallies 128-B
+    requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE per launch and the SQ instruction counters.  Counters
+    cannot be collected inside a bench run (separate --pmc passes), so they are quoted - but only from a
+    profile measured on THESE kernel sources (`kernel_sources_sha16`) at this size / depth / mask type;
+    otherwise {'stale': why} and the line carries null for traffic / valu figures."""
     sha = kernel_sources_sha16()
     for name in PMC_PROFILES:
         try:
@@ -136,12 +140,21 @@ def pmc_profile(args, kernel):
         if d.get('kernel_sources_sha16') != sha:
             return {'stale': f'profiles/{name} was measured on kernel sources {d.get("kernel_sources_sha16")}, '
                              f'this tree is {sha}: counter figures not quoted'}
-        if d.get('size') == args.size and bool(d.get('mask')) == (not args.no_mask) and \
-                d.get('kernel', '').split('<')[0] == kernel.split('<')[0] and \
-                ('stack' in d.get('kernel', '')) == ('stack' in kernel) and \
-                d.get('frames', args.frames) == args.frames:
-            return d
-    return {}
+        if d.get('size') != args.size or d.get('frames') != args.frames or \
+                d.get('mask_dtype') != (None if args.no_mask else args.mask_dtype):
+            return {'stale': f'profiles/{name} was measured at size {d.get("size")} x {d.get("frames")} frames, masks '
+                             f'{d.get("mask_dtype")}: not this run'}
+        d['file'] = f'profiles/{name}'
+        return d
+    return {'stale': 'no counter profile committed for this round'}
+
+
+def pmc_traffic(pmc, section, prefixes):
+    """HBM bytes per launch summed over the kernels whose names start with one of `prefixes`, or None."""
+    ks = (pmc.get(section) or {}).get('kernels') or {}
+    hits = [v for k, v in ks.items() if any(k.startswith(p) for p in prefixes) and v.get('hbm_bytes_per_launch') is not None]
+    # (per launch of each kernel x its launches per coadd: the pre-pass kernels run once per stack like the fused one)
+    return int(sum(v['hbm_bytes_per_launch'] * v.get('launches_per_coadd', 1) for v in hits)) if hits else None
 
 
 def cpu_baseline(synth, size, combine, nframes=8, steps_frames=32, nreg_side=3):
@@ -605,9 +618,9 @@ def main():
     step()
     sync()
     eng.timing(False)
-    names = ['coadd_fused', 'resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter', 'bk_expand',
-             'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
-             'hp_solve', 'hp_apply']
+    names = ['coadd_fused', 'ff_headers', 'resample', 'mask_box', 'resample_mask', 'median_mad', 'prep', 'mesh_stats', 'mesh_filter',
+             'bk_expand', 'bk_rows', 'combine', 'lattice', 'hp_masks', 'hp_cells', 'hp_vectors', 'hp_gram',
+             'hp_solve', 'hp_chol', 'hp_apply']
     kt = {}
     for nme in names:
         ms, cnt = eng.timing_read(nme)
@@ -649,7 +662,8 @@ def main():
         nightly = nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local)
     if world == 1 and rank == 0:
         if sum_type and not args.no_secondary:
-            secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx)
+            secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx,
+                                          full_step=None if args.no_subtract else (coadd_leg, sub_leg, sci))
         if not args.no_clocks:
             clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
                                                  ref_rms, step, timed, 1e3 * dt / args.steps)
@@ -658,7 +672,7 @@ def main():
         torch.cuda.synchronize(device)
         np.save(args.dump_coadd, torch.stack([coadd.img, coadd.wgt]).cpu().numpy())
     if rank == 0:
-        dom = max(kt, key=lambda k: kt[k]['ms_per_step']) if kt else None
+        dom = max((k for k in kt if k != 'hp_chol'), key=lambda k: kt[k]['ms_per_step']) if kt else None   # (hp_chol lies inside hp_solve)
         if rs_cnt:      # the roofline kernel: from the timed region itself
             kt[roof_scope] = {'ms_per_step': rs_ms / args.steps, 'launches_per_step': rs_cnt // args.steps,
                               'avg_us': 1e3 * rs_ms / rs_cnt}
@@ -666,45 +680,57 @@ def main():
                 # (the 'resample' scope also holds the two align launches of the subtraction)
                 pass
         roofline = None
+        pmc = pmc_profile(args)
+        m = 0 if args.no_mask else 1
+        mask_in = 0 if not m else (2 if args.mask_dtype == 'int16' else 4)      # bytes per input pixel of a mask plane
         if roof_scope in kt:
             avg_s = kt[roof_scope]['avg_us'] * 1e-6
-            m = 0 if args.no_mask else 1
             if fused and sum_type:
-                # SURVEY.md 8(d), fused resample -> WEIGHTED coadd: 8 B per input pixel + 8 B per
-                # output pixel per stack; int32 masks riding along: + 4 B in per input pixel,
-                # + 4 B out per stack
-                bytes_per_launch = (args.frames * (8 + 4 * m) + (8 + 4 * m)) * npx
-                kname = 'k_coadd_fused<LANCZOS3' + (', mask coadd>' if m else '>')
+                # What THIS kernel moves: per input pixel image + weight (8 B) + the 2-byte
+                # box-OR entry of the mask (the mask words themselves are read by k_mask_box_rows, its own
+                # launch); per output pixel coadd + weight (+ int32 mask coadd).  SURVEY.md 8(d)'s fused figure.
+                bytes_per_launch = (args.frames * (8 + 2 * m) + (8 + 4 * m)) * npx
+                kname = 'k_coadd_fused_dma<LANCZOS3' + (', mask coadd>' if m else '>')
                 units = f'{args.frames} frames x {args.size}^2 px per launch'
             elif fused:
-                # the materialised stack out of the same kernel (STACK mode): SURVEY.md 8(d) resample,
-                # 16 B per output pixel and frame (+ 4 B mask in per input pixel, + 4 B out per stack)
-                bytes_per_launch = (args.frames * (16 + 4 * m) + 4 * m) * npx
-                kname = 'k_coadd_fused<LANCZOS3, stack' + (', mask coadd>' if m else '>')
+                # the materialised stack out of the same kernel (STACK mode): 8 B in (+ 2 B box-OR) per input
+                # pixel, 8 B {value, weight} out per output pixel and frame, + 4 B partial mask coadd per stack
+                bytes_per_launch = (args.frames * (16 + 2 * m) + 4 * m) * npx
+                kname = 'k_coadd_fused_dma<LANCZOS3, stack' + (', mask coadd>' if m else '>')
                 units = f'{args.frames} frames x {args.size}^2 px per launch'
             else:
                 bytes_per_launch = (RESAMPLE_BYTES_PER_OUTPX + MASK_BYTES_PER_OUTPX * m) * npx
                 kname = 'k_resample<LANCZOS3' + (', mask fused>' if m else '>')
                 units = f'1 frame x {args.size}^2 px per launch'
             ach = bytes_per_launch / avg_s / 1e9
-            pmc = pmc_profile(args, kname)
+            section = 'weighted' if sum_type else 'clipped'
+            kp = ((pmc.get(section) or {}).get('kernels') or {}).get('k_coadd_fused_dma') if fused else None
             roofline = {'bound': 'hbm', 'kernel': kname, 'units_per_launch': units,
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch'),
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
                         'avg_launch_us': kt[roof_scope]['avg_us'],
                         'us_per_frame': kt[roof_scope]['avg_us'] / (args.frames if fused else 1),
                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                        'algorithmic_bytes': f'per input px: image + weight 8 B{" + box-OR entry 2 B" if m else ""}; per output px: '
+                                             f'coadd + weight 8 B{" + int32 mask coadd 4 B" if m else ""} - what this launch reads and writes',
                         'dominant_by_time': dom,
-                        'counters_from': pmc.get('stale') or (f'profiles/{PMC_PROFILES[0]} (kernel sources {pmc.get("kernel_sources_sha16")})' if pmc else None)}
-            # what this kernel runs into is not HBM: its waves alternate between LDS tap reads
-            # and the packed FMAs that consume them
-            if pmc.get('valu_simd_seconds_per_launch'):
-                # vector-issue time of the launch's instruction mix (measured ns per wave-instruction,
-                # profiles/r02_valu_rate.txt) over the 1024 SIMDs, and the LDS pipe time per CU
-                roofline['valu_frac'] = pmc['valu_simd_seconds_per_launch'] / (256 * 4) / avg_s
-                if pmc.get('lds_pipe'):
-                    roofline['lds_frac'] = pmc['lds_pipe']['seconds_per_cu_per_launch'] / avg_s
-                roofline['valu_insts_per_px'] = pmc.get('valu_insts_per_px')
+                        'counters_from': pmc.get('stale') or f'{pmc.get("file")} (kernel sources {pmc.get("kernel_sources_sha16")})'}
+            if kp:
+                # vector issue, not HBM, bounds this kernel: wave-instructions per output pixel and frame
+                roofline['traffic_over_algorithmic'] = kp['hbm_bytes_per_launch'] / bytes_per_launch
+                roofline['valu_insts_per_px'] = kp.get('valu_insts_per_px')
+                roofline['lds_insts_per_px'] = kp.get('lds_insts_per_px')
+                roofline['valu_busy_frac'] = kp.get('valu_busy_frac')
+            if fused and sum_type and 'coadd_ms' in legs:
+                # the whole coadd leg against the same roof: + the estimation read of the mesh statistics (image +
+                # weight, 8 B per input pixel) and the mask words the box pre-pass reads
+                leg_bytes = (args.frames * (8 + 8 + mask_in + 0) + (8 + 4 * m)) * npx
+                leg_ach = leg_bytes / (legs['coadd_ms'] * 1e-3) / 1e9
+                roofline['leg'] = {'what': f'coadd leg: mesh statistics (8 B / input px) + box-OR pre-pass ({mask_in} B / input px of mask) + '
+                                           f'fused resample -> coadd (8 B / input px + products)',
+                                   'algorithmic_bytes': leg_bytes, 'ms': legs['coadd_ms'], 'achieved': leg_ach,
+                                   'leg_frac': leg_ach / HBM_PEAK_GBS,
+                                   'leg_traffic': pmc_traffic(pmc, 'weighted', ('k_mesh_stats', 'k_mask_box', 'k_coadd_fused'))}
             if world == 1:
                 try:
                     cc = copy_ceiling(z, eng, torch, coadd.stream, device)
@@ -712,6 +738,19 @@ def main():
                     roofline['frac_of_copy_ceiling'] = ach / cc['GBs_read_plus_write']
                 except Exception as e:                       # noqa: a probe must not fail the bench
                     roofline['copy_ceiling_error'] = repr(e)
+        # the dominant scope by time is the kernel fit's solver: the fused Cholesky against the fp64 matrix rate
+        solve_roof = None
+        if 'hp_chol' in kt and not args.no_subtract:
+            nunk, nreg = int(sub.info.ncoeff), 9
+            us = kt['hp_chol']['avg_us']
+            flop = nreg * nunk ** 3 / 3.0
+            kc = ((pmc.get('weighted') or {}).get('kernels') or {}).get('k_chol_fused')
+            solve_roof = {'bound': 'mfma', 'kernel': 'k_chol_fused', 'avg_us': us, 'launches_per_step': kt['hp_chol']['launches_per_step'],
+                          'flop_per_launch': flop, 'what': f'{nreg} Cholesky factorisations of {nunk}^2 (n^3 / 3 each) per launch, fp64',
+                          'achieved': flop / (us * 1e-6) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': flop / (us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                          'traffic': kc.get('hbm_bytes_per_launch') if kc else None,
+                          'note': 'latency-bound: 23 (12 with the 64-column super-step) dependent block steps, two cross-XCD hand-offs each'}
         # SURVEY.md 8(d), the exception to the HBM bound: the convolution of the subtraction (25 B and
         # 2 * 2 * (2r + 1)^2 flop per pixel) against both the HBM peak and the fp32 vector peak
         apply_roof = None
@@ -734,12 +773,13 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'configs[1]+[2]: {args.frames}x {args.size}x{args.size} '
                                    f'TPV frames/GPU, mesh background + weight rescale + '
-                                   f'Lanczos-3 resample + {args.combine} coadd (+ AND mask coadd)'
+                                   f'Lanczos-3 resample + {args.combine} coadd (+ AND mask coadd, {args.mask_dtype} masks)'
                                    + ((', RCCL reduce of the partial sums' if sum_type else ', row-band exchange over RCCL') if world > 1 else '')
                                    + ('' if args.no_subtract else
                                       '; then 1 science frame/GPU: align ref, hotpants 3x3 regions '
                                       'x 10x10 stamps, r=10, ko=4, subtract'),
                        'frames_per_gpu': args.frames, 'size': args.size,
+                       'mask_dtype': None if args.no_mask else args.mask_dtype,
                        'combine': args.combine, 'subtract': not args.no_subtract,
                        'hotpants': None if args.no_subtract else
                        {k: getattr(sub.info, k) for k, _ in sub.info._fields_}},
@@ -747,6 +787,7 @@ def main():
                       'launcher': os.environ.get('ZM_BENCH_LAUNCHER', 'external' if world > 1 else 'none'),
                       'ranks': ranks},
             'legs': legs,
+            'solve_roofline': solve_roof,
             'apply_roofline': apply_roof,
             'kernels': kt,      # one extra step with every scope timed ('resample': the timed region)
             'roofline': roofline,
@@ -756,7 +797,7 @@ def main():
         if pipelined is not None:
             out['pipelined'] = pipelined
         if secondary is not None:
-            out['secondary'] = secondary
+            out['clipped'] = secondary          # (rounds 2 - 3 called it `secondary`)
         if clocks is not None:
             out['clocks'] = clocks
         if tools is not None:
@@ -927,24 +968,62 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
     return out
 
 
-def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx):
-    """configs[1] with the reference's science COMBINE_TYPE (CLIPPED 4.0 / 0.3,
-    zuds/astromatic/makecoadd/default.swarp:24-31): the resident-stack path."""
+def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_step=None):
+    """The reference's DEFAULT operator in the headline's shadow: configs[1] with the science
+    COMBINE_TYPE every from_images call runs unless told otherwise (CLIPPED 4.0 / 0.3,
+    zuds/astromatic/makecoadd/default.swarp:24-31) - the resident-stack path: k_coadd_fused_dma in STACK mode
+    (samples stored, not summed) + k_combine<32> - as a coadd leg and, with `full_step`, as the whole step
+    (this coadd + the same subtraction against it), each of the two kernels with its own HBM roofline."""
     p = z.coadd_params(combine='CLIPPED', subtract_back=True, rescale_weights=True)
     co = dev.DeviceCoadd(base, p, device=local, engine=eng, want_mask=not args.no_mask)
+    m = 0 if args.no_mask else 1
+    pmc = pmc_profile(args)
+    kern = (pmc.get('clipped') or {}).get('kernels') or {}
     co.run(dframes)
-    eng.timing(True, only='combine')
-    eng.timing_reset()
-    dt = timed(lambda: co.run(dframes), args.steps)
-    eng.timing(False)
-    ms, cnt = eng.timing_read('combine')
-    out = {'combine': 'CLIPPED', 'coadd_ms': 1e3 * dt / args.steps,
-           'coadd_mpix_s': args.frames * npx / 1e6 * args.steps / dt}
+    out = {'combine': 'CLIPPED', 'what': 'COMBINE_TYPE CLIPPED, the reference default (default.swarp:24-31): resident stack'}
+    scopes = {}
+    for scope in ('coadd_fused', 'combine'):
+        eng.timing(True, only=scope)
+        eng.timing_reset()
+        dt = timed(lambda: co.run(dframes), args.steps)
+        eng.timing(False)
+        scopes[scope] = eng.timing_read(scope)
+    out['coadd_ms'] = 1e3 * dt / args.steps
+    out['coadd_mpix_s'] = args.frames * npx / 1e6 * args.steps / dt
+    ms, cnt = scopes['coadd_fused']
+    if cnt:
+        us = 1e3 * ms / cnt
+        byt = (args.frames * (16 + 2 * m) + 4 * m) * npx   # 8 B + 2 B box-OR in per input px, 8 B {value, weight} out per px and frame
+        kp = kern.get('k_coadd_fused_dma')
+        out['stack_roofline'] = {'bound': 'hbm', 'kernel': 'k_coadd_fused_dma<LANCZOS3, stack' + (', mask coadd>' if m else '>'),
+                                 'avg_launch_us': us, 'algorithmic_bytes_per_launch': byt, 'achieved': byt / (us * 1e-6) / 1e9,
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
+                                 'valu_insts_per_px': kp.get('valu_insts_per_px') if kp else None}
+    ms, cnt = scopes['combine']
     if cnt:
         us = 1e3 * ms / cnt
         byt = (8 * args.frames + 8) * npx          # SURVEY.md 8(d): one read of every sample + one write
+        kp = kern.get('k_combine')
+        out['combine_roofline'] = {'bound': 'hbm', 'kernel': f'k_combine<{args.frames}> CLIPPED', 'avg_launch_us': us,
+                                   'algorithmic_bytes_per_launch': byt, 'achieved': byt / (us * 1e-6) / 1e9,
+                                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   'traffic': kp.get('hbm_bytes_per_launch') if kp else None}
         out['combine_kernel'] = {'avg_us': us, 'algorithmic_bytes': byt, 'achieved_GBs': byt / (us * 1e-6) / 1e9,
                                  'frac_of_hbm_peak': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    out['counters_from'] = pmc.get('stale') or f'{pmc.get("file")} (kernel sources {pmc.get("kernel_sources_sha16")})'
+    if full_step is not None:
+        coadd_leg, sub_leg, sci = full_step
+
+        def step_c():
+            coadd_leg(co, dframes)
+            sub_leg(co, sci)
+        step_c()
+        dts = timed(step_c, args.steps)
+        out['ms_per_step'] = 1e3 * dts / args.steps
+        out['value_mpix_s'] = (args.frames + 1) * npx / 1e6 * args.steps / dts
+        out['step'] = 'the bench step with COMBINE_TYPE CLIPPED: mesh background + rescale + resample to the resident stack + ' \
+                      'clipped combine (+ AND mask coadd), then the same subtraction against that coadd'
     del co
     # BASELINE configs[3]: what each of 8 ranks combines after the row-band exchange of a 256-frame stack -
     # all 256 samples of its 384 rows (k_combine_wide<4>); synthetic samples, 2 % of them without weight

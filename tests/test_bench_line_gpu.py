@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '2048', '--frames', '4', '--steps', '2', '--warmup', '1',
-           '--no-clocks', '--no-nightly', '--no-secondary', '--no-pipelined', '--cpu-frames', '1']
+           '--no-clocks', '--no-nightly', '--no-pipelined', '--cpu-frames', '1']
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -40,3 +40,14 @@ def test_bench_line_contract():
         assert k in c, k
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
     assert d['apply_roofline']['valu_frac'] > 0
+    # leg-level and solver rooflines, and the reference's default operator (COMBINE_TYPE CLIPPED) beside the headline
+    leg = r['leg']
+    assert leg['leg_frac'] == pytest.approx(leg['algorithmic_bytes'] / (leg['ms'] * 1e-3) / 1e9 / 8000.0) and leg['leg_traffic'] is None
+    assert r['algorithmic_bytes_per_launch'] == (4 * (8 + 2) + 12) * 2048 * 2048          # int16 masks: 2-byte box-OR entries
+    sr = d['solve_roofline']
+    assert sr['bound'] == 'mfma' and sr['unit'] == 'TFLOP/s' and sr['frac'] == pytest.approx(sr['achieved'] / sr['peak']) and sr['frac'] > 0
+    c = d['clipped']
+    assert c['combine'] == 'CLIPPED' and c['ms_per_step'] > 0
+    for k in ('stack_roofline', 'combine_roofline'):
+        assert c[k]['bound'] == 'hbm' and c[k]['frac'] == pytest.approx(c[k]['achieved'] / 8000.0) and c[k]['traffic'] is None
+    assert c['value_mpix_s'] == pytest.approx(mpix / (c['ms_per_step'] * 1e-3), rel=1e-6)

@@ -1,14 +1,17 @@
 #!/usr/bin/env python
-"""Developer tool: the counter profile of the roofline kernel as the JSON bench.py reads
-(profiles/rNN_pmc_coadd_fused.json), from one tools/gpu_round.sh run.
+"""Developer tool: the counter profile bench.py quotes (profiles/rNN_pmc.json), from one tools/gpu_round.sh run.
 
-    python tools/make_pmc_json.py gpurun_out/<tag> profiles/r03_pmc_coadd_fused.json
+    python tools/make_pmc_json.py gpurun_out/<tag> profiles/r04_pmc.json
 
-Inputs of that directory: pmc_summary.txt (separate rocprofv3 --pmc passes, tools/pmc_summary.py),
-kernel_stats.csv (rocprofv3 --kernel-trace, tools/rocpd_stats.py), bench.json.  The JSON carries the
-hash of the kernel sources it was measured on (`kernel_sources_sha16`, the same function bench.py
-uses): bench.py drops traffic / valu_frac / lds_frac from its line when the hash of the tree it runs
-from differs, so a stale profile cannot be quoted for a changed kernel."""
+Inputs of that directory: pmc_summary.txt (+ pmc_summary_clipped.txt), written by tools/pmc_summary.py from
+separate rocprofv3 --pmc passes of the short bench command (FETCH_SIZE, WRITE_SIZE and the SQ counters each in
+a pass of their own); kernel_stats.csv (rocprofv3 --kernel-trace --stats, tools/rocpd_stats.py); bench.json.
+Per bench command ('weighted' = the headline, 'clipped' = --combine CLIPPED) and kernel: the launch on the
+largest grid (the 32-frame stack, not the science frame of the subtraction) with HBM bytes per launch =
+2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section;
+WRITE_SIZE as is) and the SQ instruction counters.  The JSON carries the hash of the kernel sources it was
+measured on (`kernel_sources_sha16`, the same function bench.py uses): bench.py drops the counter figures from
+its line when the hash of the tree it runs from differs."""
 import csv
 import hashlib
 import json
@@ -30,58 +33,73 @@ def kernel_sources_sha16(root=ROOT):
     return h.hexdigest()[:16]
 
 
+WANT = ('k_coadd_fused', 'k_mesh_stats', 'k_mesh_guess', 'k_mask_box', 'k_combine', 'k_chol_fused', 'k_hp_apply',
+        'k_bk_rows', 'k_bk_cols', 'k_ff_headers')
+
+
+def section(path, frames, npx):
+    if not os.path.exists(path):
+        return None
+    rows = {}
+    for line in open(path):
+        m = re.match(r'(\S+)\s+grid\s+(\d+)\s+(\S+)\s+mean\s+([0-9.]+)\s+launches\s+(\d+)', line)
+        if m and m.group(1).startswith(WANT):
+            rows.setdefault(m.group(1), {}).setdefault(int(m.group(2)), {})[m.group(3)] = (float(m.group(4)), int(m.group(5)))
+    kernels = {}
+    for kn, grids in rows.items():
+        gs = max(grids)                                   # the stack-sized launch
+        c = {k: v[0] for k, v in grids[gs].items()}
+        key = re.sub(r'<.*', '', kn)
+        if key in kernels and kernels[key]['grid'] >= gs:
+            continue
+        e = {'name': kn, 'grid': gs, 'launches_seen': max(v[1] for v in grids[gs].values()), 'counters': c}
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            e['hbm_bytes_per_launch'] = int(c['FETCH_SIZE'] * 1024 * 2 + c['WRITE_SIZE'] * 1024)
+            e['fetch_bytes_per_launch'] = int(c['FETCH_SIZE'] * 1024 * 2)
+        if key == 'k_coadd_fused_dma' and 'SQ_INSTS_VALU' in c:
+            waves_px = frames * npx / 64.0
+            e['valu_insts_per_px'] = c['SQ_INSTS_VALU'] / waves_px
+            e['lds_insts_per_px'] = c.get('SQ_INSTS_LDS', 0.0) / waves_px
+            if c.get('SQ_WAVE_CYCLES'):
+                # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles, the latter summed over the waves of
+                # a SIMD: at four waves per SIMD a SIMD that always issues VALU shows 1 / 4
+                e['valu_active_over_wave_cycles'] = c.get('SQ_ACTIVE_INST_VALU', 0.0) / c['SQ_WAVE_CYCLES']
+        kernels[key] = e
+    return {'kernels': kernels}
+
+
 def main(src, out):
-    pm = {}
-    for line in open(os.path.join(src, 'pmc_summary.txt')):
-        m = re.match(r'(k_coadd_fused\S*)\s+(\S+)\s+mean\s+([0-9.]+)', line)
-        if m:
-            pm[m.group(2)] = float(m.group(3))
-    avg_us = med_us = None
-    with open(os.path.join(src, 'kernel_stats.csv')) as f:
-        for r in csv.DictReader(f):
-            if 'k_coadd_fused' in r['Name']:
-                avg_us = float(r['AverageNs']) / 1e3
-                med_us = float(r.get('MedianNs') or 0) / 1e3
-                break
     bench = json.loads([l for l in open(os.path.join(src, 'bench.json')) if l.startswith('{')][-1])
     size, frames = bench['config']['size'], bench['config']['frames_per_gpu']
     npx = size * size
-    fetch, write = pm['FETCH_SIZE'] * 1024 * 2, pm['WRITE_SIZE'] * 1024      # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
-    valu, lds = pm['SQ_INSTS_VALU'], pm['SQ_INSTS_LDS']
-    waves_px = frames * npx / 64.0
-    # Issue costs measured by tools/valu_rate.hip (profiles/r02_valu_rate.txt): v_pk_*_f32 2.12 ns, other VALU
-    # 1.29 ns per wave-instruction and SIMD.  Packed share of the launch's VALU instructions: static count
-    # of the ISA (pixel groups 218 of 464; staging and issue code carry none): 2 x 218 of ~1430 per item.
-    packed = 0.30
-    valu_s = valu * (packed * 2.12e-9 + (1 - packed) * 1.29e-9)
-    # LDS pipe per 64 output pixels and frame: 13.5 + 2 ds_read_b64 (window rows shared by four pixels, table
-    # tails), 8 ds_read_b128 (two tap-table nodes), 1 ds_read_u16; staging: 1.52 staged pixels per output
-    # pixel in quads -> 0.76 ds_write_b128 pairs + 0.38 ds_write_b64
-    lds_ns = 15.5 * 1.297 + 8 * 1.95 + 1 * 1.3 + 0.76 * 6.3 + 0.38 * 3.0
     d = {
         'source': 'tools/gpu_round.sh: rocprofv3 --kernel-trace --stats, then separate --pmc FETCH_SIZE / WRITE_SIZE / SQ_* passes '
-                  'of the same bench command on one MI355X box, one commit',
+                  'of the same bench command (and of its --combine CLIPPED form) on one MI355X box, one commit',
         'kernel_sources_sha16': kernel_sources_sha16(),
-        'units': 'FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, '
-                 'MI355X_MICROARCH.md HBM section); WRITE_SIZE as is',
-        'size': size, 'frames': frames, 'mask': True,
-        'kernel': 'k_coadd_fused<LANCZOS3, mask coadd>',
-        'avg_duration_us_kernel_trace': avg_us, 'median_duration_us_kernel_trace': med_us,
-        'FETCH_SIZE_KiB': pm['FETCH_SIZE'], 'WRITE_SIZE_KiB': pm['WRITE_SIZE'],
-        'hbm_bytes_per_launch': int(fetch + write),
-        'algorithmic_bytes_per_launch': (frames * 12 + 12) * npx,
-        'needed_read_bytes': frames * npx * (8 + 2),
-        'read_over_needed': fetch / (frames * npx * (8 + 2)),
-        'counters': pm,
-        'valu_insts_per_px': valu / waves_px, 'lds_insts_per_px': lds / waves_px,
-        'packed_share_of_valu': packed,
-        'valu_simd_seconds_per_launch': valu_s,
-        'lds_pipe': {'ns_per_64px': lds_ns, 'seconds_per_cu_per_launch': waves_px * lds_ns * 1e-9 / 256},
+        'units': 'hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 tallies 128-B read requests at 64 B, '
+                 'MI355X_MICROARCH.md HBM section); per kernel the launch on its largest grid (the stack, not the science frame)',
+        'size': size, 'frames': frames, 'mask_dtype': bench['config'].get('mask_dtype'),
         'bench_ms_per_step': bench['ms_per_step'], 'bench_value_mpix_s': bench['value'],
     }
+    for name, fn in (('weighted', 'pmc_summary.txt'), ('clipped', 'pmc_summary_clipped.txt')):
+        sec = section(os.path.join(src, fn), frames, npx)
+        if sec:
+            d[name] = sec
+    ks = os.path.join(src, 'kernel_stats.csv')
+    if os.path.exists(ks):
+        with open(ks) as f:
+            for r in csv.DictReader(f):
+                for key, e in (d.get('weighted') or {}).get('kernels', {}).items():
+                    if r['Name'].startswith(('void ' + key, key)) and 'avg_duration_us_kernel_trace' not in e:
+                        e['avg_duration_us_kernel_trace'] = float(r['AverageNs']) / 1e3
+    fk = (d.get('weighted') or {}).get('kernels', {}).get('k_coadd_fused_dma')
+    if fk and 'fetch_bytes_per_launch' in fk:
+        fk['needed_read_bytes'] = frames * npx * (8 + (2 if d['mask_dtype'] else 0))
+        fk['read_over_needed'] = fk['fetch_bytes_per_launch'] / fk['needed_read_bytes']
     json.dump(d, open(out, 'w'), indent=1)
-    print(json.dumps({k: d[k] for k in ('kernel_sources_sha16', 'avg_duration_us_kernel_trace', 'hbm_bytes_per_launch',
-                                        'read_over_needed', 'valu_insts_per_px', 'lds_insts_per_px')}))
+    print(json.dumps({'kernel_sources_sha16': d['kernel_sources_sha16'],
+                      'fused': {k: fk.get(k) for k in ('avg_duration_us_kernel_trace', 'hbm_bytes_per_launch', 'read_over_needed',
+                                                        'valu_insts_per_px', 'lds_insts_per_px')} if fk else None}))
 
 
 if __name__ == '__main__':

@@ -2654,7 +2654,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     const int ldt = (P.nunk + 1 + 15) & ~15;
                     double* AT = nullptr;
                     ZM_TRY(ctx->get("hp_chol_at", sizeof(double) * (size_t)P.nreg * P.nunk * ldt, (void**)&AT));
-                    hipLaunchKernelGGL(k_chol_tp, dim3(P.nreg), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, A, AT, fail, parg, guard);
+                    {
+                        zm_scope_timer tc(ctx, "hp_chol");         // (inside hp_solve: the factorisation alone)
+                        hipLaunchKernelGGL(k_chol_tp, dim3(P.nreg), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, A, AT, fail, parg, guard);
+                    }
                     ZM_HIP(hipGetLastError());
                     if (tp_prof) {
                         std::vector<long long> hp((size_t)5 * P.nreg);
@@ -2684,8 +2687,11 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
                 // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
                 // order against the following launches of the stream on its first use)
-                hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
-                                   spin_limit, barg, parg, guard);
+                {
+                    zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
+                    hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
+                                       spin_limit, barg, parg, guard);
+                }
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
                     std::vector<long long> hp((size_t)6 * P.nreg * W);

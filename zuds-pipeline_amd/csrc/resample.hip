@@ -3124,12 +3124,14 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
     const int nwv = (use_dma ? FD_THREADS : FF_THREADS) / 64;
     if (want_prof) ZM_TRY(ctx->get("ff_prof", sizeof(long long) * 5 * nwv * (size_t)G, (void**)&prof));
-    zm_scope_timer t(ctx, "coadd_fused");
     {
+        // (its own scope: `coadd_fused` times the roofline kernel alone, as the kernel trace does)
+        zm_scope_timer th(ctx, "ff_headers");
         const long long items = (long long)ntiles * nfr;
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
                            lnx, lny, onx, ony, lds_elems, use_dma ? 1 : 0, ntx, ntiles, ghdr, tilectr, G);
     }
+    zm_scope_timer t(ctx, "coadd_fused");
 #define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
     do {                                                                                                       \
         if (use_dma) {                                                                                         \
