@@ -375,6 +375,14 @@ int zm_star_fwhm(zm_ctx* ctx, const float* img, int nx, int ny, int nstar,
 int zm_negpix_test(zm_ctx* ctx, const float* img, int nx, int ny, int npos,
                    const double* x, const double* y, double median, double sigma,
                    int32_t* out_bad);
+/* The two star measurements on planes that are already in HBM (img / bad: device pointers; positions, widths
+ * and lists: host arrays): the seeing of a coadd is estimated before it leaves the device. */
+int zm_find_stars_dev(zm_ctx* ctx, const float* img, const uint8_t* bad, int nx, int ny,
+                      float thresh_lo, float thresh_hi, int isolation, int border,
+                      int max_out, int* out_x, int* out_y, float* out_peak, int* out_n);
+int zm_star_fwhm_dev(zm_ctx* ctx, const float* img, int nx, int ny, int nstar,
+                     const int* x, const int* y, int half, double* out_fwhm,
+                     double* out_cx, double* out_cy);
 
 /* ---- FITS data blocks on the device ------------------------------------------ */
 /* Replaces the host-side decode / encode astropy does inside FITSFile.load_data / save

@@ -145,6 +145,9 @@ _SIGS = {
     'zm_find_stars': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                 C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     'zm_star_fwhm': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    'zm_find_stars_dev': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                    C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
+    'zm_star_fwhm_dev': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
     'zm_negpix_test': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_double, C.c_double, _P]),
     'zm_fits_decode_dev': (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int, _P]),
     'zm_fits_encode_dev': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),

@@ -69,11 +69,17 @@ def _coadd_from_images(cls, images, outname=None, data_product=False, tmpdir='/t
     except OSError:
         pass
 
+    params = dict(sci.params)
+    params['mask_combine'] = msk.params['mask_combine']
+    from . import objdev
+    if objdev.enabled():
+        # the device route: raw FITS blocks -> HBM -> kernels -> encoded products, every file written once
+        return _coadd_device(cls, images, masks, sci, params, outname, mskoutname, addbkg, enforce_partition,
+                             set_date, calculate_seeing, data_product)
+
     # one fused device pass: science frames and their masks share the lattice
     eng = get_engine()
     wout = sci.output_grid()
-    params = dict(sci.params)
-    params['mask_combine'] = msk.params['mask_combine']
     frames = sci.frames()
     for f, m in zip(frames, masks):
         # (a ZTF mask read from its BITPIX 16 file is int16 and goes to the GPU as it is: zm_frame.mask_type)
@@ -125,6 +131,89 @@ def _coadd_from_images(cls, images, outname=None, data_product=False, tmpdir='/t
                 coadd.header['SEEING'] = float(np.median(see))
                 coadd.header_comments['SEEING'] = 'Median SEEING of the coadd inputs (pixels)'
                 coadd.save()
+    if data_product:
+        warnings.warn('data_product=True: archiving is not part of this package')
+    return coadd
+
+
+def _coadd_device(cls, images, masks, sci, params, outname, mskoutname, addbkg, enforce_partition, set_date,
+                  calculate_seeing, data_product):
+    """``_coadd_from_images`` from the SWarp call objects on, on device planes (``objdev``): the same
+    products with the same cards as the host-pointer route below writes (``tests/test_object_route_gpu.py``),
+    without its numpy decode / widen / encode passes and without writing any file twice.  Replaces the file
+    traffic of ``zuds/coadd.py:126-163`` (two SWarp runs) and ``:165-217`` (reload, bit 16, pedestal, saves)."""
+    import ctypes as C
+
+    from . import _lib, objdev
+    from .constants import MASK_BITS, MASK_COMMENTS
+    from .device import DeviceCoadd, DeviceFrames
+    from .engine import coadd_params
+    from .mask import MaskImage
+    from .seeing import measure_seeing_dev
+    from .swarp import MSK_COPY_KEYWORDS, SCI_COPY_KEYWORDS, output_header
+    from .constants import BAD_SUM
+    oio = objdev.get_io()
+    torch, eng, L = oio.torch, oio.engine, oio.engine.L
+    check = _lib.check
+    wout = sci.output_grid()
+    want = []
+    for im, m in zip(images, masks):
+        want += [(im, 'f32'), (im.weight_image if sci.use_weights else None, 'f32'), (m, 'mask')]
+    planes = oio.planes(want)
+    frames = [dict(img=planes[3 * i], wgt=planes[3 * i + 1], mask=planes[3 * i + 2], wcs=im.wcs,
+                   flxscale=sci.flxscales[i] if sci.flxscales else 1.0) for i, im in enumerate(images)]
+    co = DeviceCoadd(wout, coadd_params(**params), device=oio.device.index, engine=eng, want_mask=True,
+                     stream=oio.stream)
+    co.run(DeviceFrames(frames, oio.device))
+    n = co.img.numel()
+    weight_outname = outname.replace('.fits', '.weight.fits')
+    # the cards of the products: what SWarp would give them + what from_images adds afterwards
+    shape = tuple(co.shape)
+    hdr, com = objdev.written_header(output_header(images, wout, SCI_COPY_KEYWORDS), {}, shape, -32)
+    whdr = dict(output_header(images, wout, SCI_COPY_KEYWORDS))
+    mhdr, mcom = objdev.written_header(output_header(masks, wout, MSK_COPY_KEYWORDS), {}, shape, 32)
+    mhdr.update(MASK_BITS)                                # refresh_bit_mask_entries_in_header (zuds/mask.py:19-24)
+    mcom.update(MASK_COMMENTS)
+    if enforce_partition:
+        for prop in GROUP_PROPERTIES:
+            v = getattr(images[0], prop, None)
+            if v is not None:
+                hdr[prop.upper()] = v
+                mhdr[prop.upper()] = v
+    if set_date:
+        hdr['MJD-OBS'] = float(np.median([get_time(i, 'mjd') for i in images]))
+        com['MJD-OBS'] = 'Median MJD of the coadd inputs (DG)'
+    eng.set_stream(oio.stream.cuda_stream)
+    with torch.cuda.stream(oio.stream):
+        # bit 16 where the resampler found no data (zuds/coadd.py:182-184, zuds/mask.py:26-33), the pedestal
+        check(L.zm_mask_flag_dev(eng.ctx, co.mask.data_ptr(), co.mask_wgt.data_ptr(), 0.0, 1 << 16, n), 'bit 16')
+        if addbkg:
+            check(L.zm_add_scalar_dev(eng.ctx, co.img.data_ptr(), float(BKG_VAL), n), 'pedestal')
+        if calculate_seeing:
+            # zuds/coadd.py:225-226 on the plane in HBM; a coadd without a usable star keeps the inputs' median
+            bad = torch.empty(co.shape, dtype=torch.uint8, device=oio.device)
+            check(L.zm_mask_bad_dev(eng.ctx, co.mask.data_ptr(), None, BAD_SUM, n, None, bad.data_ptr()), 'bpm')
+            try:
+                see, _ = measure_seeing_dev(co.img, bad, None, engine=eng)
+                hdr['SEEING'] = float(see)
+                com['SEEING'] = 'FWHM of seeing in pixels (Goldstein)'
+            except RuntimeError:
+                see = [i.header['SEEING'] for i in images if 'SEEING' in i.header]
+                if see:
+                    hdr['SEEING'] = float(np.median(see))
+                    com['SEEING'] = 'Median SEEING of the coadd inputs (pixels)'
+    oio.save_all([(outname, co.img, hdr, com), (weight_outname, co.wgt, whdr, {}),
+                  (mskoutname, co.mask, mhdr, mcom)])
+    coadd = cls.from_file(outname, load_others=False)
+    coadd._weightimg = FITSImage.from_file(weight_outname)
+    coaddmask = MaskImage.from_file(mskoutname)
+    coadd.input_images = images.tolist()
+    coadd.mask_image = coaddmask
+    coaddmask.parent_image = coadd
+    if enforce_partition:
+        for prop in GROUP_PROPERTIES:
+            for img in [coadd, coaddmask]:
+                setattr(img, prop, getattr(images[0], prop, None))
     if data_product:
         warnings.warn('data_product=True: archiving is not part of this package')
     return coadd

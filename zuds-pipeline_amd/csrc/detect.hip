@@ -114,23 +114,15 @@ __global__ void k_negpix(const float* __restrict__ img, int nx, int ny, int npos
 }
 
 // ---- host-pointer entry points (small outputs; the image is uploaded once) --------------
-extern "C" int zm_find_stars(zm_ctx* ctx, const float* img, const uint8_t* bad, int nx, int ny,
-                             float thresh_lo, float thresh_hi, int isolation, int border, int max_out,
-                             int* out_x, int* out_y, float* out_peak, int* out_n) {
-    ZM_CHECK(ctx && img && out_x && out_y && out_peak && out_n, "zm_find_stars: null argument");
+// img / bad: device planes; the candidate lists come back to host arrays (at most max_out entries)
+extern "C" int zm_find_stars_dev(zm_ctx* ctx, const float* d_img, const uint8_t* d_bad, int nx, int ny,
+                                 float thresh_lo, float thresh_hi, int isolation, int border, int max_out,
+                                 int* out_x, int* out_y, float* out_peak, int* out_n) {
+    ZM_CHECK(ctx && d_img && out_x && out_y && out_peak && out_n, "zm_find_stars: null argument");
     ZM_CHECK(nx > 0 && ny > 0 && max_out > 0, "zm_find_stars: bad sizes");
     ZM_CHECK(isolation >= 1 && isolation <= 32 && border >= isolation, "zm_find_stars: border >= isolation >= 1");
     ZM_HIP(hipSetDevice(ctx->device));
-    const size_t np = (size_t)nx * ny;
-    float* d_img = nullptr;
-    uint8_t* d_bad = nullptr;
     char* d_out = nullptr;
-    ZM_TRY(ctx->get("h_img", np * 4, (void**)&d_img));
-    ZM_HIP(hipMemcpyAsync(d_img, img, np * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (bad) {
-        ZM_TRY(ctx->get("h_bpm", np, (void**)&d_bad));
-        ZM_HIP(hipMemcpyAsync(d_bad, bad, np, hipMemcpyHostToDevice, ctx->stream));
-    }
     ZM_TRY(ctx->get("det_out", 16 + (size_t)max_out * 12, (void**)&d_out));
     int* d_n = (int*)d_out;
     int* d_x = (int*)(d_out + 16);
@@ -154,17 +146,46 @@ extern "C" int zm_find_stars(zm_ctx* ctx, const float* img, const uint8_t* bad, 
     return 0;
 }
 
+extern "C" int zm_find_stars(zm_ctx* ctx, const float* img, const uint8_t* bad, int nx, int ny,
+                             float thresh_lo, float thresh_hi, int isolation, int border, int max_out,
+                             int* out_x, int* out_y, float* out_peak, int* out_n) {
+    ZM_CHECK(ctx && img, "zm_find_stars: null argument");
+    ZM_CHECK(nx > 0 && ny > 0, "zm_find_stars: bad sizes");
+    ZM_HIP(hipSetDevice(ctx->device));
+    const size_t np = (size_t)nx * ny;
+    float* d_img = nullptr;
+    uint8_t* d_bad = nullptr;
+    ZM_TRY(ctx->get("h_img", np * 4, (void**)&d_img));
+    ZM_HIP(hipMemcpyAsync(d_img, img, np * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (bad) {
+        ZM_TRY(ctx->get("h_bpm", np, (void**)&d_bad));
+        ZM_HIP(hipMemcpyAsync(d_bad, bad, np, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return zm_find_stars_dev(ctx, d_img, d_bad, nx, ny, thresh_lo, thresh_hi, isolation, border, max_out, out_x, out_y,
+                             out_peak, out_n);
+}
+
 extern "C" int zm_star_fwhm(zm_ctx* ctx, const float* img, int nx, int ny, int nstar, const int* x,
                             const int* y, int half, double* out_fwhm, double* out_cx, double* out_cy) {
-    ZM_CHECK(ctx && img && x && y && out_fwhm && out_cx && out_cy, "zm_star_fwhm: null argument");
-    ZM_CHECK(nx > 0 && ny > 0 && nstar >= 0 && half >= 2 && half <= 64, "zm_star_fwhm: bad sizes");
+    ZM_CHECK(ctx && img, "zm_star_fwhm: null argument");
+    ZM_CHECK(nx > 0 && ny > 0, "zm_star_fwhm: bad sizes");
     if (nstar == 0) return 0;
     ZM_HIP(hipSetDevice(ctx->device));
     const size_t np = (size_t)nx * ny;
     float* d_img = nullptr;
-    char* d_s = nullptr;
     ZM_TRY(ctx->get("h_img", np * 4, (void**)&d_img));
     ZM_HIP(hipMemcpyAsync(d_img, img, np * 4, hipMemcpyHostToDevice, ctx->stream));
+    return zm_star_fwhm_dev(ctx, d_img, nx, ny, nstar, x, y, half, out_fwhm, out_cx, out_cy);
+}
+
+// img: a device plane; star positions in, widths and centroids out: host arrays
+extern "C" int zm_star_fwhm_dev(zm_ctx* ctx, const float* d_img, int nx, int ny, int nstar, const int* x,
+                                const int* y, int half, double* out_fwhm, double* out_cx, double* out_cy) {
+    ZM_CHECK(ctx && d_img && x && y && out_fwhm && out_cx && out_cy, "zm_star_fwhm: null argument");
+    ZM_CHECK(nx > 0 && ny > 0 && nstar >= 0 && half >= 2 && half <= 64, "zm_star_fwhm: bad sizes");
+    if (nstar == 0) return 0;
+    ZM_HIP(hipSetDevice(ctx->device));
+    char* d_s = nullptr;
     ZM_TRY(ctx->get("det_star", (size_t)nstar * 32, (void**)&d_s));
     double* d_f = (double*)d_s;
     double* d_cx = d_f + nstar;

@@ -62,7 +62,7 @@ class DeviceCoadd(object):
     """Resample + combine on one GPU, optionally as one shard of a multi-GPU
     stack."""
 
-    def __init__(self, wout, params=None, device=0, engine=None, want_mask=False):
+    def __init__(self, wout, params=None, device=0, engine=None, want_mask=False, stream=None):
         torch = _torch()
         self.torch = torch
         self.device = torch.device('cuda', device)
@@ -70,7 +70,7 @@ class DeviceCoadd(object):
         # a dedicated non-default stream: its handle is never 0, and torch ops
         # (RCCL collectives, copies) issued inside `with torch.cuda.stream(...)`
         # order against the kernels libzudsmi enqueues on the same stream
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
         self.engine.set_stream(self.stream.cuda_stream)
         self.params = params or coadd_params()
         self.wout = wcs_struct(wout)

@@ -54,33 +54,45 @@ def _parse_value(s):
         return v, comment
 
 
+def _read_header(read, what):
+    header, comments = {}, {}
+    nblocks = 0
+    done = False
+    while not done:
+        block = read(BLOCK)
+        if len(block) < BLOCK:
+            raise ValueError(f'{what}: truncated FITS header')
+        nblocks += 1
+        for i in range(0, BLOCK, 80):
+            card = block[i:i + 80].decode('ascii', 'replace')
+            key = card[:8].strip()
+            if key == 'END':
+                done = True
+                break
+            if not key or key in ('COMMENT', 'HISTORY') or card[8:10] != '= ':
+                continue
+            val, com = _parse_value(card[10:])
+            if val is None:
+                continue
+            header[key] = val
+            comments[key] = com
+    if header.get('SIMPLE') is not True:
+        raise ValueError(f'{what}: not a standard FITS file (SIMPLE != T)')
+    return header, comments, nblocks * BLOCK
+
+
 def read_header(path):
     """(header dict, comments dict, data offset in bytes)."""
-    header, comments = {}, {}
     with open(path, 'rb') as f:
-        nblocks = 0
-        done = False
-        while not done:
-            block = f.read(BLOCK)
-            if len(block) < BLOCK:
-                raise ValueError(f'{path}: truncated FITS header')
-            nblocks += 1
-            for i in range(0, BLOCK, 80):
-                card = block[i:i + 80].decode('ascii', 'replace')
-                key = card[:8].strip()
-                if key == 'END':
-                    done = True
-                    break
-                if not key or key in ('COMMENT', 'HISTORY') or card[8:10] != '= ':
-                    continue
-                val, com = _parse_value(card[10:])
-                if val is None:
-                    continue
-                header[key] = val
-                comments[key] = com
-    if header.get('SIMPLE') is not True:
-        raise ValueError(f'{path}: not a standard FITS file (SIMPLE != T)')
-    return header, comments, nblocks * BLOCK
+        return _read_header(f.read, path)
+
+
+def parse_header(block):
+    """(header dict, comments dict) of header bytes as ``header_block`` emits them: what ``read_header``
+    returns for a file that starts with them."""
+    import io
+    h, c, _ = _read_header(io.BytesIO(bytes(block)).read, 'header block')
+    return h, c
 
 
 def read(path, header_only=False):

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import check, ptr
 from .engine import get_engine
 
-__all__ = ['estimate_seeing', 'measure_seeing']
+__all__ = ['estimate_seeing', 'measure_seeing', 'measure_seeing_dev']
 
 NMAX = 300            # brightest stars used
 ISOLATION = 5         # pixels: a star is the maximum of its 11 x 11 box
@@ -59,6 +59,52 @@ def measure_seeing(data, bad=None, saturate=None, engine=None):
     cy = np.empty(k)
     check(eng.L.zm_star_fwhm(eng.ctx, ptr(sub), nx, ny, k, ptr(sx), ptr(sy), HALF, ptr(fw), ptr(cx),
                              ptr(cy)), 'zm_star_fwhm')
+    good = np.isfinite(fw)
+    if not good.any():
+        raise RuntimeError('Unable to measure the width of any star to estimate the seeing')
+    return float(np.nanmedian(fw)), int(good.sum())
+
+
+def measure_seeing_dev(img, bad=None, saturate=None, engine=None):
+    """``measure_seeing`` on planes that are already in HBM: ``img`` a float32 torch tensor on the
+    engine's device, ``bad`` a uint8 tensor (non-zero = unusable) or None.  The same launches with
+    device pointers (``zm_background_dev``, ``zm_find_stars_dev``, ``zm_star_fwhm_dev``): the same
+    stars, the same number.  The caller has the engine's stream current."""
+    import torch
+    eng = engine or get_engine()
+    ny, nx = img.shape
+    wgt = None if bad is None else (bad == 0).to(torch.float32)
+    sub = torch.empty_like(img)
+    stats = (C.c_double * 2)()
+    check(eng.L.zm_background_dev(eng.ctx, img.data_ptr(), wgt.data_ptr() if wgt is not None else None, nx, ny,
+                                  128, 3, None, None, sub.data_ptr(), stats), 'zm_background_dev')
+    bmean, bsig = stats[0], stats[1]
+    lo = float(NSIGMA * max(bsig, 1e-6))
+    hi = float(0.5 * saturate - bmean) if saturate else 3.0e38
+    cap = 65536
+    xs = np.empty(cap, np.int32)
+    ys = np.empty(cap, np.int32)
+    pk = np.empty(cap, np.float32)
+    n = C.c_int(0)
+    while True:
+        check(eng.L.zm_find_stars_dev(eng.ctx, sub.data_ptr(), bad.data_ptr() if bad is not None else None, nx, ny,
+                                      lo, hi, ISOLATION, BORDER, cap, ptr(xs), ptr(ys), ptr(pk), C.byref(n)),
+              'zm_find_stars_dev')
+        if n.value <= cap:
+            break
+        lo *= 2.0
+    m = n.value
+    if m == 0:
+        raise RuntimeError('Unable to find any stars to estimate the seeing')
+    order = np.lexsort((xs[:m], ys[:m], -pk[:m].astype(np.float64)))[:NMAX]
+    sx = np.ascontiguousarray(xs[:m][order])
+    sy = np.ascontiguousarray(ys[:m][order])
+    k = len(sx)
+    fw = np.empty(k)
+    cx = np.empty(k)
+    cy = np.empty(k)
+    check(eng.L.zm_star_fwhm_dev(eng.ctx, sub.data_ptr(), nx, ny, k, ptr(sx), ptr(sy), HALF, ptr(fw), ptr(cx),
+                                 ptr(cy)), 'zm_star_fwhm_dev')
     good = np.isfinite(fw)
     if not good.any():
         raise RuntimeError('Unable to measure the width of any star to estimate the seeing')

@@ -49,6 +49,90 @@ def _shallow(obj, cls, mapped=True):
     return new
 
 
+def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_new_back, hotpants_kws):
+    """``Subtraction.from_images`` on device planes: the chain of ``device.DeviceSubtraction`` (align the
+    reference + mask + rms, OR the masks, mesh background + pedestal, robust limits, kernel fit, convolve,
+    subtract, bit 17 - ``zuds/subtraction.py:57-226``, ``zuds/hotpants.py:15-95``) fed from raw FITS blocks and
+    writing each of the three products once with its final cards.  The same pixels and cards as the
+    host-pointer route (``tests/test_object_route_gpu.py``)."""
+    from . import _lib, objdev
+    from .constants import BAD_SUM, BIG_RMS
+    from .device import DeviceSubtraction
+    from .hotpants import info_cards, warn_unsolved
+    oio = objdev.get_io()
+    torch, eng, L = oio.torch, oio.engine, oio.engine.L
+    check = _lib.check
+    sci_img, sci_mask, sci_wgt, ref_img, ref_mask, ref_wgt = oio.planes(
+        [(sci, 'f32'), (sci.mask_image, 'mask'), (sci._weightimg, 'f32'),
+         (ref, 'f32'), (ref.mask_image, 'mask'), (ref._weightimg, 'f32')])
+    eng.set_stream(oio.stream.cuda_stream)
+
+    def rms_of(img, wgt, mask, header):
+        # CalibratableImageBase.rms_image (zuds/image.py:173-208): 1 / sqrt(w), BIG_RMS where the mask is bad
+        # (and within 10 % of SATURATE)
+        m32 = mask
+        if mask.dtype == torch.int16:
+            m32 = torch.empty(mask.shape, dtype=torch.int32, device=mask.device)
+            check(L.zm_mask_widen_dev(eng.ctx, mask.data_ptr(), mask.numel(), m32.data_ptr()), 'widen')
+        bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
+        rms = torch.empty_like(img)
+        check(L.zm_mask_bad_dev(eng.ctx, m32.data_ptr(), None, BAD_SUM, m32.numel(), None, bad.data_ptr()), 'bpm')
+        check(L.zm_rms_from_weight_dev(eng.ctx, wgt.data_ptr(), bad.data_ptr(), wgt.numel(), float(BIG_RMS),
+                                       rms.data_ptr()), 'rms')
+        if 'SATURATE' in header:
+            rms = torch.where(img >= 0.9 * float(header['SATURATE']), torch.full_like(rms, float(BIG_RMS)), rms)
+        return rms, m32
+    with torch.cuda.stream(oio.stream):
+        sci_rms, _ = rms_of(sci_img, sci_wgt, sci_mask, sci.header)
+        ref_rms, ref_m32 = rms_of(ref_img, ref_wgt, ref_mask, ref.header)
+    chain = DeviceSubtraction(sci.wcs, ref.wcs, device=oio.device.index, engine=eng, stream=oio.stream)
+    diff, noise, submask = chain.run(sci_img, sci_rms, sci_mask, sci_wgt, ref_img, ref_rms, ref_m32,
+                                     seeing=float(sci.header['SEEING']), nreg_side=nreg_side,
+                                     subtract_back=subtract_new_back, hotpants_kws=hotpants_kws,
+                                     ref_flxscale=float((ref.header or {}).get('FLXSCALE', 1.0)))
+    info = {k: getattr(chain.info, k) for k, _ in chain.info._fields_}
+    warn_unsolved(info, final_out)
+    # cards: what hotpants.HotpantsCall.run writes, re-read, plus what from_images adds before its save()
+    shape = tuple(chain.shape)
+    hdr0 = dict(sci.header)
+    hdr0.update(info_cards(info))
+    hdr, com = objdev.written_header(hdr0, {}, shape, -32)          # (HotpantsCall.run writes the cards without comments)
+    mh0 = dict(sci.mask_image.header or {})
+    mc0 = dict(sci.mask_image.header_comments or {})
+    mh0['BIT17'] = 17
+    mc0['BIT17'] = 'MASKED BY HOTPANTS (1e-30) / DG'
+    mhdr, mcom = objdev.written_header(mh0, mc0, shape, 32)
+    props = {}
+    for prop in ('field', 'ccdid', 'qid', 'fid'):
+        v = getattr(sci, prop, None)
+        props[prop] = v
+        if v is not None:
+            hdr[prop.upper()] = v
+            mhdr[prop.upper()] = v
+    hdr['SEEING'] = sci.header['SEEING']
+    com['SEEING'] = (sci.header_comments or {}).get('SEEING', '')
+    if issubclass(cls, CalibratedImage):
+        for key in ('MAGZP', APER_KEY):
+            if key in sci.header:
+                hdr[key] = sci.header[key]
+                com[key] = (sci.header_comments or {}).get(key, '')
+    oio.save_all([(final_out, diff, hdr, com), (final_out.replace('.fits', '.rms.fits'), noise, hdr0, {}),
+                  (outmask, submask, mhdr, mcom)])
+    sub = cls.from_file(final_out, load_others=False) \
+        if issubclass(cls, CalibratableImage) else cls.from_file(final_out)
+    finalsubmask = MaskImage.from_file(outmask)
+    sub._rmsimg = FITSImage.from_file(final_out.replace('.fits', '.rms.fits'))
+    for img in (sub, finalsubmask):
+        for prop, v in props.items():
+            setattr(img, prop, v)
+    sub.mask_image = finalsubmask
+    finalsubmask.parent_image = sub
+    sub.reference_image = ref
+    sub.target_image = sci
+    sub.hotpants_info = info
+    return sub
+
+
 class Subtraction(HasWCS):
 
     reference_image = None
@@ -80,6 +164,15 @@ class Subtraction(HasWCS):
         final_out = os.path.join(final_dir, os.path.basename(
             sub_name(sci.local_path, ref.local_path)))
         outmask = final_out.replace('.fits', '.mask.fits')
+
+        from . import objdev
+        if objdev.enabled() and hasattr(sci, '_weightimg') and 'SEEING' in sci.header and \
+                hasattr(ref, '_weightimg') and not hasattr(sci, '_rmsimg'):
+            # the device route (objdev): raw FITS blocks -> HBM -> DeviceSubtraction -> encoded products.
+            # (A science frame that still needs its rms map from the mesh background, or its SEEING
+            # measured, takes the host-pointer route below, which derives them.)
+            return _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_new_back,
+                                       hotpants_kws)
 
         # The reference works on transaction copies whose masks are plain
         # MaskImageBase objects (zuds/subtraction.py:94-99): aligning such a mask
