@@ -1055,6 +1055,53 @@ def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_
     return out
 
 
+def object_api_clock(z, d, files, sci_paths, args, nref=8):
+    """The reference's own call sites on the FITS files of the step: what a user of
+    scripts/makeref.py / dostack.py / dosub.py waits for - `ReferenceImage.from_images` of `nref` frames
+    (zuds/coadd.py:25-236, defaults: COMBINE_TYPE CLIPPED, mesh background, rescale, mask coadd, bit 16,
+    pedestal, seeing) and `SingleEpochSubtraction.from_images` of one science frame against it
+    (zuds/subtraction.py:57-226), wall clock incl. every file read and written, on the device route of the
+    object layer (objdev) and on the host-pointer route it replaced (ZM_OBJECT_API=host)."""
+    nref = min(nref, len(files['sci']))
+
+    def objects(paths_sci, paths_wgt, paths_msk):
+        out = []
+        for ps, pw, pm in zip(paths_sci, paths_wgt, paths_msk):
+            im = z.ScienceImage.from_file(ps)
+            im._weightimg = z.FITSImage.from_file(pw)
+            im.mask_image = z.MaskImage.from_file(pm)
+            out.append(im)
+        return out
+    res = {'frames': nref, 'size': args.size}
+    for route in ('device', 'host'):
+        old = os.environ.get('ZM_OBJECT_API')
+        os.environ['ZM_OBJECT_API'] = route
+        try:
+            tc, ts = [], []
+            for rep in range(2):                         # the faster of two (allocations, page cache)
+                refname = os.path.join(d, f'ref_{route}{rep}.000651_c03_q1_zg.fits')
+                ims = objects(files['sci'][:nref], files['wgt'][:nref], files['msk'][:nref])
+                t0 = time.perf_counter()
+                ref = z.ReferenceImage.from_images(ims, refname)
+                t1 = time.perf_counter()
+                sci = objects([sci_paths[0]], [sci_paths[1]], [sci_paths[2]])[0]
+                t2 = time.perf_counter()
+                sub = z.SingleEpochSubtraction.from_images(sci, ref, tmpdir=d)
+                t3 = time.perf_counter()
+                tc.append(t1 - t0)
+                ts.append(t3 - t2)
+                for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+                    os.remove(sub.local_path.replace('.fits', sfx))
+            res[route] = {'reference_from_images_ms': 1e3 * min(tc), 'subtraction_from_images_ms': 1e3 * min(ts),
+                          'coadd_mpix_s': nref * args.size ** 2 / 1e6 / min(tc), 'subtract_mpix_s': args.size ** 2 / 1e6 / min(ts)}
+        finally:
+            if old is None:
+                os.environ.pop('ZM_OBJECT_API', None)
+            else:
+                os.environ['ZM_OBJECT_API'] = old
+    return res
+
+
 def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub, ref_rms, step, timed,
                          device_ms):
     """the same step on three clocks - inputs resident in HBM (the headline),
@@ -1165,7 +1212,8 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
         files = {'sci': [], 'wgt': [], 'msk': [], 'combine': args.combine}
         for i, f in enumerate(frames + [sci]):
             hdr = dict(f['wcs'].to_header(), NAXIS1=args.size, NAXIS2=args.size,
-                       MAGZP=25.0 - 2.5 * float(np.log10(f['flxscale'])), SEEING=args.seeing)
+                       MAGZP=25.0 - 2.5 * float(np.log10(f['flxscale'])), SEEING=args.seeing,
+                       OBSMJD=58800.0 + 0.25 * i, FIELDID=651, CCDID=3, QID=1, FILTERID=1)
             for lst, key, suf, cast in (('sci', 'img', 'sciimg', None), ('wgt', 'wgt', 'weight', None),
                                         ('msk', 'mask', 'mskimg', np.int16)):
                 path = os.path.join(d, f'f{i:02d}.{suf}.fits')
@@ -1202,6 +1250,10 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
             if clocks.get(k):
                 clocks[k.replace('_ms', '_mpix_s')] = mpix / (clocks[k] * 1e-3)
         tools = reference_tools(d, files, {'coadd': z.fits.read(os.path.join(d, 'coadd.fits'))[0]})
+        try:
+            clocks['object_api_ms'] = object_api_clock(z, d, files, sci_paths, args)
+        except Exception as e:                               # noqa: report, do not fail the bench
+            clocks['object_api_error'] = repr(e)
     except Exception as e:                                   # noqa: report, do not fail the bench
         clocks['with_fits_ms'] = None
         clocks['fits_error'] = repr(e)
