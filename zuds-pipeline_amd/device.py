@@ -352,20 +352,82 @@ class FITSDeviceIO(object):
         self.stream.synchronize()
         fits.write_raw(path, pin[:nbytes].numpy(), tuple(t.shape), bp, header, comments)
 
+    def load_many(self, wanted, nreaders=4):
+        """[(path, kind), ...] -> [(tensor, header), ...] in order.  The files are read by `nreaders`
+        threads into a pool of pinned buffers (reads from the page cache scale with threads: one reader moves
+        ~11 GB/s, four ~40) while this thread enqueues copy + decode of whatever has arrived, in order."""
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        from . import fits
+        torch = self.torch
+        if getattr(self, '_pool', None) is None:
+            self._pool = ThreadPoolExecutor(nreaders)
+            self._free = queue.Queue()
+
+        def pin_of(nbytes):
+            try:
+                while True:
+                    buf, ev = self._free.get_nowait()
+                    if ev is not None:
+                        ev.synchronize()
+                    if buf.numel() >= nbytes:
+                        return buf
+            except queue.Empty:
+                pass
+            return torch.empty(int(nbytes) + 4096, dtype=torch.uint8, pin_memory=True)
+        from collections import deque
+        todo, jobs = deque(wanted), deque()
+
+        def submit():
+            path, kind = todo.popleft()
+            hdr, _, _ = fits.read_header(path)
+            nbytes = abs(int(hdr['BITPIX'])) // 8 * int(np.prod([int(hdr[f'NAXIS{i}'])
+                                                                 for i in range(1, int(hdr['NAXIS']) + 1)]))
+            pin = pin_of(nbytes)
+            jobs.append((self._pool.submit(fits.read_raw, path, pin.numpy()), pin, kind))
+        out = []
+        self.engine.set_stream(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            while todo or jobs:
+                while todo and len(jobs) < 2 * nreaders:        # a bounded window of reads in flight (pinned memory)
+                    submit()
+                fut, pin, kind = jobs.popleft()
+                raw, hdr, _, info = fut.result()
+                if kind == 'mask':
+                    kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
+                dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]
+                t = torch.empty(info['shape'], dtype=dt, device=self.device)
+                d_raw = pin[:info['nbytes']].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self._free.put((pin, ev))
+                check(self.engine.L.zm_fits_decode_dev(self.engine.ctx, d_raw.data_ptr(), info['bitpix'],
+                                                       info['bscale'], info['bzero'], info['count'],
+                                                       _KIND[kind], t.data_ptr()), 'zm_fits_decode_dev')
+                d_raw.record_stream(self.stream)
+                out.append((t, hdr))
+        return out
+
     def load_frames(self, sci_paths, weight_paths=None, mask_paths=None, zp_key='MAGZP'):
         """A DeviceFrames for ``zm_coadd_dev`` from science / weight / mask files
         (``FLXSCALE = 10^(-0.4 (MAGZP - 25))``, ``zuds/swarp.py:31``)."""
         from .wcs import WCS
-        frames = []
+        wanted, slots = [], []
         for i, sp in enumerate(sci_paths):
-            img, hdr = self.load(sp, 'f32')
-            f = dict(img=img, wcs=WCS.from_header(hdr), header=hdr,
-                     flxscale=10 ** (-0.4 * (float(hdr.get(zp_key, 25.0)) - 25.0)))
+            wanted.append((sp, 'f32'))
+            slots.append((i, 'img'))
             if weight_paths is not None and weight_paths[i] is not None:
-                f['wgt'] = self.load(weight_paths[i], 'f32')[0]
+                wanted.append((weight_paths[i], 'f32'))
+                slots.append((i, 'wgt'))
             if mask_paths is not None and mask_paths[i] is not None:
-                f['mask'] = self.load(mask_paths[i], 'mask')[0]
-            frames.append(f)
+                wanted.append((mask_paths[i], 'mask'))
+                slots.append((i, 'mask'))
+        frames = [dict() for _ in sci_paths]
+        for (i, key), (t, hdr) in zip(slots, self.load_many(wanted)):
+            frames[i][key] = t
+            if key == 'img':
+                frames[i].update(wcs=WCS.from_header(hdr), header=hdr,
+                                 flxscale=10 ** (-0.4 * (float(hdr.get(zp_key, 25.0)) - 25.0)))
         # consumers on other streams order against the loads through the current stream
         torch = self.torch
         torch.cuda.current_stream(self.device).wait_stream(self.stream)

@@ -74,57 +74,26 @@ class ObjectIO(object):
     def planes(self, wanted):
         """wanted: list of (object, kind) with kind 'f32', 'i32', 'u8' or 'mask' (int16 for a BITPIX 16
         file or an int16 array, else int32).  -> list of device tensors, in order; objects with pixels in
-        memory give those, mapped objects their file (raw block, decoded on the device)."""
+        memory give those, mapped objects their file (raw block, decoded on the device: several files in
+        flight on reader threads, ``FITSDeviceIO.load_many``)."""
         torch = self.torch
-        from ._lib import check
-        from .device import _KIND
-        jobs = []
-        for obj, kind in wanted:
-            if obj is None:
-                jobs.append(None)
-            elif '_data' in obj.__dict__:
-                jobs.append(('mem', np.asarray(obj.__dict__['_data']), kind))
-            else:
-                path = obj.local_path
-                hdr, _, _ = _fits.read_header(path)
-                nbytes = abs(int(hdr['BITPIX'])) // 8 * int(np.prod([int(hdr[f'NAXIS{i}'])
-                                                                     for i in range(1, int(hdr['NAXIS']) + 1)]))
-                pin = self._pin(nbytes)
-                fut = self.pool.submit(_fits.read_raw, path, pin.numpy())
-                jobs.append(('file', fut, pin, kind))
-        out = []
-        self.engine.set_stream(self.stream.cuda_stream)
+        out = [None] * len(wanted)
+        files = [(i, obj.local_path, kind) for i, (obj, kind) in enumerate(wanted)
+                 if obj is not None and '_data' not in obj.__dict__]
+        for (i, _, _), (t, _) in zip(files, self.io.load_many([(p, k) for _, p, k in files], NREADERS)):
+            out[i] = t
         with torch.cuda.stream(self.stream):
-            for j in jobs:
-                if j is None:
-                    out.append(None)
+            for i, (obj, kind) in enumerate(wanted):
+                if obj is None or '_data' not in obj.__dict__:
                     continue
-                if j[0] == 'mem':
-                    a, kind = j[1], j[2]
-                    if kind == 'mask':
-                        dt = torch.int16 if a.dtype == np.int16 else torch.int32
-                    else:
-                        dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8}[kind]
-                    if a.dtype == np.bool_:
-                        a = a.astype(np.uint8)
-                    t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=False).to(dt)
-                    out.append(t)
-                    continue
-                _, fut, pin, kind = j
-                raw, hdr, _, info = fut.result()
+                a = np.asarray(obj.__dict__['_data'])
                 if kind == 'mask':
-                    kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
-                dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]
-                t = torch.empty(info['shape'], dtype=dt, device=self.device)
-                d_raw = pin[:info['nbytes']].to(self.device, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.stream)
-                self._free.put((pin, ev))
-                check(self.engine.L.zm_fits_decode_dev(self.engine.ctx, d_raw.data_ptr(), info['bitpix'],
-                                                       info['bscale'], info['bzero'], info['count'],
-                                                       _KIND[kind], t.data_ptr()), 'zm_fits_decode_dev')
-                d_raw.record_stream(self.stream)
-                out.append(t)
+                    dt = torch.int16 if a.dtype == np.int16 else torch.int32
+                else:
+                    dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8}[kind]
+                if a.dtype == np.bool_:
+                    a = a.astype(np.uint8)
+                out[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dt)
         return out
 
     # -- products -----------------------------------------------------------------------------
