@@ -48,3 +48,25 @@ def test_two_gloo_ranks_on_one_card_equal_one_process(tmp_path, combine):
         assert np.array_equal(c1[1] > 0, c2[1] > 0)
         np.testing.assert_allclose(c2[0], c1[0], rtol=1e-6, atol=1e-5)
         np.testing.assert_allclose(c2[1], c1[1], rtol=1e-6)
+
+
+@pytest.mark.parametrize('combine', ['WEIGHTED', 'CLIPPED'])
+def test_four_gloo_ranks_uneven_row_bands_equal_one_process(tmp_path, combine):
+    """four ranks and a grid height that does not divide by four (1030 rows: bands of
+    258 / 258 / 257 / 257) - the banded mask reduce (the default from four ranks on) and the row-band exchange of
+    the exact CLIPPED stack with unequal bands, through bench.py's own launcher on the one card."""
+    size = ['--size', '1030']
+    four, c4 = run_bench(size + ['--gpus', '4', '--combine', combine, '--frames', '3'], {'ZM_DIST_BACKEND': 'gloo'},
+                         str(tmp_path / 'four.npy'))
+    w = four['world']
+    assert w['world_size'] == 4 and w['backend'] == 'gloo' and len({r['pid'] for r in w['ranks']}) == 4
+    assert four['n_gpus'] == 4 and four['value'] > 0
+    one, c1 = run_bench(size + ['--gpus', '1', '--emulate-ranks', '4', '--combine', combine, '--frames', '3'], {},
+                        str(tmp_path / 'one.npy'))
+    assert c1.shape == c4.shape == (2, 1030, 1030)
+    if combine == 'CLIPPED':
+        assert np.array_equal(c1, c4)
+    else:
+        assert np.array_equal(c1[1] > 0, c4[1] > 0)
+        np.testing.assert_allclose(c4[0], c1[0], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(c4[1], c1[1], rtol=1e-6)

@@ -265,11 +265,17 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
     d0, n0, i0 = engine.subtract(*data, **kw)
     monkeypatch.setenv('ZM_CHOL_FORM', 'tp')
     d1, n1, i1 = engine.subtract(*data, **kw)
+    # ... and the many-workgroup form with 64-column super-steps (k_chol_fused2, opt-in: round 4's experiment)
+    monkeypatch.setenv('ZM_CHOL_FORM', 'lat')
+    monkeypatch.setenv('ZM_CHOL_STEP', '64')
+    d2, n2, i2 = engine.subtract(*data, **kw)
+    monkeypatch.delenv('ZM_CHOL_STEP')
     monkeypatch.delenv('ZM_CHOL_FORM')
-    assert i0['status'] == 0 and i1['status'] == 0 and i0['retries'] == 0 and i1['retries'] == 0
-    assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
-    for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
-        assert i0[k] == i1[k], k
+    for d, n, i in ((d1, n1, i1), (d2, n2, i2)):
+        assert i0['status'] == 0 and i['status'] == 0 and i0['retries'] == 0 and i['retries'] == 0
+        assert np.array_equal(d0, d) and np.array_equal(n0, n)
+        for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
+            assert i0[k] == i[k], k
 
 
 def test_two_engines_side_by_side_without_a_pool(engine):

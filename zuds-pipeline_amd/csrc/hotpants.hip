@@ -1036,6 +1036,44 @@ __device__ inline void region_arrive(unsigned* ctr) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the panel chain of k_chol_fused on a half strip held as xb[column half][row]: unscaled partial sums, the
+// reciprocal diagonal at the end
+__device__ __forceinline__ void cf_chain(double (&xb)[2][2], const double2 (*Cf)[16], const double* Rd, int li,
+                                         double (&x0)[2], double (&x1)[2]) {
+    // The coefficients of step m are LDS reads; left to the scheduler they are issued one step ahead of their use
+    // and every step of the chain then waits out an LDS round trip (~100 cycles against ~40 of broadcast + FMA).
+    // Here they come in batches of eight steps, a batch ahead: the scheduling barrier keeps the reads of batch
+    // b + 1 in front of the arithmetic of batch b.
+    double2 cf[4][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cf[0][q] = Cf[q][li];
+    hp_static_for<0, 4>([&](auto B) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value;
+        if constexpr (b < 3) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (8 * (b + 1) + q < CH_NB - 1) cf[b + 1][q] = Cf[8 * (b + 1) + q][li];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hp_static_for<0, 8>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int m = 8 * b + decltype(Q)::value;
+            if constexpr (m < CH_NB - 1) {
+                constexpr int tm = m >> 4, sl = m & 15;
+                const double2 c = cf[b][m & 7];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double u = row16_bcast_d<sl>(xb[tm][h]);
+                    if (m < 15) xb[0][h] = fma(c.x, u, xb[0][h]);
+                    xb[1][h] = fma(c.y, u, xb[1][h]);
+                }
+            }
+        });
+    });
+    const double r0 = Rd[li], r1 = Rd[16 + li];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { x0[h] = xb[0][h] * r0; x1[h] = xb[1][h] * r1; }
+}
+
 // A: [reg][(n + 1)][lda], lda = n rounded up to 16 doubles so that every 16-column segment
 // of a tile is one 128-B line; Dg: [reg][2][32][33] published diagonal factors (two slots: the factor
 // of block k + 1 is written while slower workgroups may still read that of block k).
@@ -1227,21 +1265,8 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #pragma unroll
                     for (int h = 0; h < 2; ++h) xb[c][h] = (16 * c + li < nb) ? xb[c][h] : 0.0;
             }
-            hp_static_for<0, CH_NB - 1>([&](auto M) __attribute__((always_inline)) {
-                constexpr int m = decltype(M)::value;
-                constexpr int tm = m >> 4, sl = m & 15;
-                const double2 cf = Cf[m][li];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double u = row16_bcast_d<sl>(xb[tm][h]);
-                    if (m < 15) xb[0][h] = fma(cf.x, u, xb[0][h]);
-                    xb[1][h] = fma(cf.y, u, xb[1][h]);
-                }
-            });
-            const double r0 = Rd[li], r1 = Rd[16 + li];
             double x0[2], x1[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { x0[h] = xb[0][h] * r0; x1[h] = xb[1][h] * r1; }
+            cf_chain(xb, Cf, Rd, li, x0, x1);
             const int tcur = t;
             if (t + 4 < ntask) panel_fetch(t + 4);
 #pragma unroll
@@ -1356,6 +1381,587 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
     if (prof && tid == 0)
         for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
 #undef CF_TICK
+}
+
+// ---- the fused factorisation with 64-column super-steps (round 4) ---------------------------
+// k_chol_fused above spends a step of 32 columns on two cross-XCD hand-offs (panel barrier + panel
+// loads, update barrier + coefficient loads: ~10 of its 13 us) around ~3 us of arithmetic.  Here two
+// blocks share one pair of hand-offs:
+//   all    load the chain coefficients of blocks kb AND kb + 1 and the 32 x 32 block L21 between them
+//          (published by the look-ahead workgroup during the previous super-step) and solve their panel
+//          rows in two chained stages: X1 = B1 L_kb^-T; B2 - X1 L21^T on the matrix cores (what the tile
+//          update of step kb did to these columns); X2 = (...) L_kb+1^-T.                       | arrive b1
+//   wg 0   owns the 64 rows of the next TWO diagonal blocks: from its own X rows it forms, factors and
+//          publishes block kb + 2, solves the 32 rows of block kb + 3 against it (the next L21), forms,
+//          factors and publishes block kb + 3 - while
+//   wg>0   wait b1 and apply the rank-64 update to their 64 x 64 tiles (K = 64 per tile).       | barrier b2
+// Every entry sees the operations of k_chol_fused in the same order - the chain of its block column, the
+// matrix-core products in ascending chunks of four columns with the negated row operand - so the bits do
+// not change (tests/test_subtract_gpu.py compares the forms and k_chol_tp bit for bit).  A tail of fewer
+// than 64 full columns runs the one-block steps of k_chol_fused.  Four publish slots (blocks kb .. kb + 3).
+//
+// MEASURED (MI355X, 9 x 722 unknowns, W = 26; ZM_CHOL_PROF phase clocks): 301 us per factorisation against 263 us
+// for k_chol_fused - NOT faster, which is why it is opt-in (ZM_CHOL_STEP=64).  The super-step trades two
+// hand-offs of the other workgroups for a longer serial chain in the look-ahead workgroup, and that chain
+// becomes the critical path: per super-step its own 64 panel rows 10.2 us (eight half strips on four waves:
+// two rounds of chain 2.1 + products 0.5 + chain 2.1 + stores 0.4), first block 6.5 us (corner update 0.5,
+// 32 x 32 factor 4.7, publish 1.2), second block 10.8 us (update, solve, update, factor, publish), in all
+// ~30 us, while the other workgroups finish in ~18 us (load 4, panel 4, barrier 2, tiles 5 - 8) and wait
+// 9 - 14 us at the closing barrier.  Two one-block steps cost 2 x 11.4 us.  The floor of the look-ahead chain
+// (two 32 x 32 factors + the solve between them, ~17 us per 64 columns) is what the others' four hand-offs
+// cost: a super-step can only pay with a faster diagonal factor.  Kept as the record of that experiment and
+// as a second, independently written implementation the bit-identity tests run against.
+#define CF2_LDP (2 * CH_NB + 2)          // LDS pitch of the 64-column panels: conflict-free b64 operand reads
+struct cf2_lds {
+    double D[CH_NB][CH_NB + 1];
+    double2 Cf[2][CH_NB][16];             // chain coefficients of the two blocks of a super-step
+    double Rd[2][CH_NB];
+    double Lb[CH_NB][CH_NB + 2];          // L21: rows = columns of block kb + 1, columns = those of block kb
+    double Xs[4][16][CH_NB + 2];          // per wave: -X1 of its half strip (row operand of B2 - X1 L21^T)
+    double Li[64][CF2_LDP];               // tile panels (wg 0: its 64 X rows)
+    double Lj[64][CF2_LDP];               // (wg 0: scratch of the look-ahead solve)
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(256) void k_chol_fused2(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
+                                                     int* tmo, int spin_limit, unsigned* bar, long long* prof,
+                                                     const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // phase clocks (100 MHz), PROF only
+#define CF2_TICK(k) do { if (PROF) { long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
+    if (PROF) tc = wall_clock64();
+    extern __shared__ double cf2_smem[];
+    cf2_lds& S = *reinterpret_cast<cf2_lds*>(cf2_smem);
+    const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
+    double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
+    double* Dg4 = Dgall + (size_t)reg * 4 * CH_NB * (CH_NB + 1);
+    unsigned* ctr1 = bar + reg * CF_BAR_STRIDE;          // [0] panel barrier, [1] timed-out flag,
+    unsigned* ctr2 = ctr1 + 2;                           // [2] update barrier (its flag is [3])
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int nrows = n + 1;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    unsigned gen1 = 0, gen2 = 0;
+    // factor the diagonal block held (unfactored, lower triangle) in S.D; publish it in slot `blk & 3`, keep the
+    // coefficients in S.Cf[ci] / S.Rd[ci]
+    auto factor_and_publish = [&](int kk0, int nb, int blk, int ci) {
+        double* Dg = Dg4 + (size_t)(blk & 3) * CH_NB * (CH_NB + 1);
+        __syncthreads();
+        if (tid < 64) chol_diag_wave_panel_t<0>(S.D, nb, &fail[reg]);
+        __syncthreads();
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            const int m = e >> 5, i = e & 31;                      // column m of row i
+            const double cv = (i > m) ? -(S.D[i][m] * S.D[m][CH_NB]) : 0.0;
+            reinterpret_cast<double*>(&S.Cf[ci][m][i & 15])[i >> 4] = cv;
+            st_sh(&Dg[2 * (m * 16 + (i & 15)) + (i >> 4)], cv);
+            if (i < nb && m <= i) st_sh(&A[(size_t)(kk0 + i) * lda + kk0 + m], S.D[i][m]);
+        }
+        if (tid < CH_NB) {
+            S.Rd[ci][tid] = S.D[tid][CH_NB];
+            st_sh(&Dg[CH_NB * CH_NB + tid], S.D[tid][CH_NB]);
+        }
+    };
+    // fetch the published coefficients of block `blk` into S.Cf[ci] / S.Rd[ci] (loads first, stores after)
+    auto coef_load = [&](int blk, double (&dv)[5]) {
+        const double* Dg = Dg4 + (size_t)(blk & 3) * CH_NB * (CH_NB + 1);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dv[q] = ld_sh(&Dg[min(tid + 256 * q, CH_NB * (CH_NB + 1) - 1)]);
+    };
+    auto coef_put = [&](int ci, const double (&dv)[5]) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = tid + 256 * q;
+            if (e < CH_NB * CH_NB) reinterpret_cast<double*>(&S.Cf[ci][0][0])[e] = dv[q];
+            else if (e < CH_NB * (CH_NB + 1)) S.Rd[ci][e - CH_NB * CH_NB] = dv[q];
+        }
+    };
+    // wg 0: the second block of a pair.  Rows k + 32 .. k + 63 (k = first column of the pair): solve them against
+    // the factor in S.Cf[0] (-> the block L21 of the next super-step, to A and S.Lb), then form, factor and
+    // publish the diagonal block `blk` at k + 32.  withx: the rows carry the rank-64 update of the 64 X rows in
+    // S.Li (rows 0 .. 31 the first block's, 32 .. 63 this block's); without (the prologue) A is taken as it is.
+    auto second_block = [&](int k, int blk, bool withx, const double (&cB)[4], const double (&cD)[4]) {
+        const int ti = wave >> 1, tj = wave & 1;
+        {
+            double4_t c4 = {cB[0], cB[1], cB[2], cB[3]};
+            if (withx) {
+#pragma unroll
+                for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
+                    const double a = -S.Li[32 + 16 * ti + li][4 * kk + lk];
+                    const double b = S.Li[16 * tj + li][4 * kk + lk];
+                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S.Lj[16 * ti + lk + 4 * q][16 * tj + li] = c4[q];
+        }
+        __syncthreads();
+        {
+            // four half strips on four waves: rows lk + 4 (2 half + h) of strip `strip`
+            const int strip = wave >> 1, half = wave & 1;
+            double xb[2][2], x0[2], x1[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) xb[c][h] = S.Lj[16 * strip + lk + 4 * (2 * half + h)][16 * c + li];
+            cf_chain(xb, S.Cf[0], S.Rd[0], li, x0, x1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 16 * strip + lk + 4 * (2 * half + h);
+                st_sh(&A[(size_t)(k + 32 + r) * lda + k + li], x0[h]);
+                st_sh(&A[(size_t)(k + 32 + r) * lda + k + 16 + li], x1[h]);
+                S.Lb[r][li] = x0[h];
+                S.Lb[r][16 + li] = x1[h];
+            }
+        }
+        __syncthreads();
+        {
+            double4_t c4 = {cD[0], cD[1], cD[2], cD[3]};
+            if (tj <= ti) {
+                if (withx) {
+#pragma unroll
+                    for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
+                        const double a = -S.Li[32 + 16 * ti + li][4 * kk + lk];
+                        const double b = S.Li[32 + 16 * tj + li][4 * kk + lk];
+                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                    const double a = -S.Lb[16 * ti + li][4 * kk + lk];
+                    const double b = S.Lb[16 * tj + li][4 * kk + lk];
+                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
+                S.D[i][j] = (j <= i) ? c4[q] : 0.0;
+            }
+        }
+        factor_and_publish(k + 32, CH_NB, blk, 1);
+    };
+    // a 32 x 32 block of A at (r0, c0) in the accumulator layout, one 16 x 16 quadrant per wave; clamped, not masked
+    auto fetch_quadrant = [&](int r0, int c0, double (&c)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * (wave >> 1) + lk + 4 * q, j = 16 * (wave & 1) + li;
+            c[q] = ld_sh(&A[(size_t)min(r0 + i, nrows - 1) * lda + min(c0 + j, n - 1)]);
+        }
+    };
+    const bool pairs = n >= 2 * CH_NB;                   // at least one super-step
+    if (w == 0) {
+        const int nb0 = min(CH_NB, n);
+        double cB[4], cD[4];
+        if (pairs) { fetch_quadrant(CH_NB, 0, cB); fetch_quadrant(CH_NB, CH_NB, cD); }
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            const int i = e >> 5, j = e & 31;
+            S.D[i][j] = (i < nb0 && j <= i) ? ld_sh(&A[(size_t)i * lda + j]) : (i == j ? 1.0 : 0.0);
+        }
+        factor_and_publish(0, nb0, 0, 0);
+        if (pairs) {
+            __syncthreads();
+            second_block(0, 1, false, cB, cD);
+        }
+    }
+    gen2 += W;
+    bool dead = region_barrier(ctr2, gen2, spin_limit);
+    int kb = 0;
+    while (kb < nblk && !dead) {
+        const int k0 = kb * CH_NB;
+        if (n - k0 >= 2 * CH_NB) {
+            // ================= a super-step: blocks kb and kb + 1 =================
+            const int k1 = k0 + CH_NB, k2 = k0 + 2 * CH_NB;
+            const int below = nrows - k2;                            // panel rows (>= 1: the rhs row)
+            const int nb2 = max(0, min(CH_NB, n - k2));              // size of block kb + 2
+            const bool next_pair = n - k2 >= 2 * CH_NB;              // the next step is a super-step too
+            const int r0n = min(next_pair ? 2 * CH_NB : CH_NB, below);
+            const int per = (below - r0n + W - 2) / (W - 1);
+            const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
+            const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
+            const int nslice = max(pend - pbeg, 0);
+            const int ntask = 2 * ((nslice + 15) >> 4);
+            // wg 0: the unfactored blocks it will need, fetched ahead (final since the last barrier)
+            double cD2[4] = {0, 0, 0, 0}, cB[4] = {0, 0, 0, 0}, cD3[4] = {0, 0, 0, 0};
+            if (w == 0 && nb2 > 0) {
+                fetch_quadrant(k2, k2, cD2);
+                if (next_pair) { fetch_quadrant(k2 + CH_NB, k2, cB); fetch_quadrant(k2 + CH_NB, k2 + CH_NB, cD3); }
+            }
+            // tiles of the trailing matrix (rows / columns >= k2), 64 x 64, K = 64; tile 0 is wg 0's when it
+            // holds both next blocks
+            const int T = (below + 63) / 64;
+            const int t0 = next_pair ? 1 : 0;
+            const int ntile = T * (T + 1) / 2;
+            const int Wu = W - 1, wu = w - 1;
+            auto tile_of = [&](int t, int& i0, int& j0) {
+                int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+                while (ti * (ti + 1) / 2 > t) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                i0 = k2 + ti * 64;
+                j0 = k2 + tj * 64;
+            };
+            double4_t accn[4];
+            double pa[16], pb[16];
+            auto tile_fetch_acc = [&](int t) {
+                int i0, j0;
+                tile_of(t, i0, j0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                        accn[c][rg] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+                    }
+            };
+            auto tile_fetch_panels = [&](int t) {
+                int i0, j0;
+                tile_of(t, i0, j0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, r = e >> 6, m = e & 63;
+                    pa[q] = ld_sh(&A[(size_t)min(i0 + r, nrows - 1) * lda + k0 + m]);
+                    pb[q] = ld_sh(&A[(size_t)min(j0 + r, nrows - 1) * lda + k0 + m]);
+                }
+            };
+            if (w != 0 && t0 + wu < ntile) tile_fetch_acc(t0 + wu);
+            // ---- phase A: the panel rows of this workgroup, two chained stages per half strip
+            double xb1[2][2], xb2[2][2];
+            auto panel_fetch = [&](int t, double (&a1)[2][2], double (&a2)[2][2]) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int prow = k2 + pbeg + 16 * (t >> 1) + lk + 4 * (2 * (t & 1) + h);
+                        const size_t ro = (size_t)min(prow, nrows - 1) * lda;
+                        a1[c][h] = ld_sh(&A[ro + k0 + 16 * c + li]);
+                        a2[c][h] = ld_sh(&A[ro + k1 + 16 * c + li]);
+                    }
+            };
+            if (wave < ntask) panel_fetch(wave, xb1, xb2);
+            __syncthreads();                                         // LDS of the previous step is consumed
+            if (w != 0) {
+                double dv0[5], dv1[5], lb[4];
+                coef_load(kb, dv0);
+                coef_load(kb + 1, dv1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q, r = e >> 5, m = e & 31;
+                    lb[q] = ld_sh(&A[(size_t)(k1 + r) * lda + k0 + m]);
+                }
+                coef_put(0, dv0);
+                coef_put(1, dv1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q;
+                    S.Lb[e >> 5][e & 31] = lb[q];
+                }
+            }
+            __syncthreads();
+            CF2_TICK(0);
+            for (int t = wave; t < ntask; t += 4) {
+                double x0[2], x1[2], y0[2], y1[2];
+                cf_chain(xb1, S.Cf[0], S.Rd[0], li, x0, x1);
+                const int half = t & 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rr = lk + 4 * (2 * half + h);
+                    S.Xs[wave][rr][li] = -x0[h];
+                    S.Xs[wave][rr][16 + li] = -x1[h];
+                }
+                // B2 - X1 L21^T: the 16 x 32 product of the strip (the other half's rows are whatever the buffer
+                // holds: rows of a matrix-core product do not mix), accumulators = B2 in this wave's two rows
+                // (this wave's rows are accumulator rows 2 half, 2 half + 1; the other two start from the same values
+                // and end as garbage nobody reads - no register is indexed by `half`)
+                double4_t acc[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = double4_t{xb2[c][0], xb2[c][1], xb2[c][0], xb2[c][1]};
+#pragma unroll
+                for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                    const double a = S.Xs[wave][li][4 * kk + lk];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double b = S.Lb[16 * c + li][4 * kk + lk];
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    xb2[c][0] = half ? acc[c][2] : acc[c][0];
+                    xb2[c][1] = half ? acc[c][3] : acc[c][1];
+                }
+                cf_chain(xb2, S.Cf[1], S.Rd[1], li, y0, y1);
+                const int tcur = t;
+                if (t + 4 < ntask) panel_fetch(t + 4, xb1, xb2);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pr = 16 * (tcur >> 1) + lk + 4 * (2 * (tcur & 1) + h), p = pbeg + pr;
+                    if (pr < nslice) {
+                        double* row = &A[(size_t)(k2 + p) * lda];
+                        st_sh(&row[k0 + li], x0[h]);
+                        st_sh(&row[k0 + 16 + li], x1[h]);
+                        st_sh(&row[k1 + li], y0[h]);
+                        st_sh(&row[k1 + 16 + li], y1[h]);
+                    }
+                    if (w == 0 && p < 64) {
+                        const bool live = pr < nslice;
+                        S.Li[p][li] = live ? x0[h] : 0.0;
+                        S.Li[p][16 + li] = live ? x1[h] : 0.0;
+                        S.Li[p][32 + li] = live ? y0[h] : 0.0;
+                        S.Li[p][48 + li] = live ? y1[h] : 0.0;
+                    }
+                }
+            }
+            CF2_TICK(2);
+            if (w == 0) {
+                // panel rows published: arrive, do not wait
+                region_arrive(ctr1);
+                gen1 += W;
+                for (int p = max(pend, 0); p < 64; ++p)              // rows this slice does not have
+                    if (tid < 64) S.Li[p][tid] = 0.0;
+                __syncthreads();
+                if (nb2 > 0) {
+                    {
+                        const int ti = wave >> 1, tj = wave & 1;
+                        double4_t c4 = {cD2[0], cD2[1], cD2[2], cD2[3]};
+                        if (tj <= ti) {
+#pragma unroll
+                            for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
+                                const double a = -S.Li[16 * ti + li][4 * kk + lk];
+                                const double b = S.Li[16 * tj + li][4 * kk + lk];
+                                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
+                            S.D[i][j] = (i < nb2 && j <= i) ? c4[q] : ((i == j) ? 1.0 : 0.0);
+                        }
+                    }
+                    factor_and_publish(k2, nb2, kb + 2, 0);
+                    if (next_pair) {
+                        __syncthreads();
+                        CF2_TICK(3);
+                        second_block(k2, kb + 3, true, cB, cD3);
+                    }
+                }
+                CF2_TICK(4);
+            } else {
+                gen1 += W;
+                dead = region_barrier(ctr1, gen1, spin_limit);
+                CF2_TICK(3);
+                if (dead) break;
+                int t = t0 + wu;
+                if (t < ntile) tile_fetch_panels(t);
+                while (t < ntile) {
+                    int i0, j0;
+                    tile_of(t, i0, j0);
+                    double4_t acc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = accn[c];
+                    __syncthreads();                       // the previous tile's panels are consumed
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int e = tid + 256 * q, r = e >> 6, m = e & 63;
+                        S.Li[r][m] = -pa[q];
+                        S.Lj[r][m] = pb[q];
+                    }
+                    __syncthreads();
+                    CF2_TICK(1);
+                    const int tn = t + Wu;
+                    if (tn < ntile) { tile_fetch_acc(tn); tile_fetch_panels(tn); }
+#pragma unroll
+                    for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
+                        const double a = S.Li[16 * wave + li][4 * kk + lk];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double b = S.Lj[16 * c + li][4 * kk + lk];
+                            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                            const bool corner = (t == 0) && i < k2 + nb2;              // wg 0's: stored factored instead
+                            if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * lda + j], acc[c][rg]);
+                        }
+                    t = tn;
+                }
+                CF2_TICK(4);
+            }
+            gen2 += W;
+            dead = region_barrier(ctr2, gen2, spin_limit);
+            CF2_TICK(5);
+            kb += 2;
+            continue;
+        }
+        // ================= a one-block step (the tail): k_chol_fused's, on this kernel's buffers =================
+        const int nb = min(CH_NB, n - k0);
+        const int k1 = k0 + nb;                                  // first trailing row / column
+        const int below = nrows - k1;                            // panel rows (the rhs row included)
+        const int nbn = max(0, min(CH_NB, n - k1));              // size of the next diagonal block
+        const int r0n = min(CH_NB, below);
+        const int per = (below - r0n + W - 2) / (W - 1);
+        const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
+        const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
+        double cpre[4] = {0.0, 0.0, 0.0, 0.0};
+        if (w == 0 && nb == CH_NB) fetch_quadrant(k1, k1, cpre);
+        const int T = (max(below, 0) + 63) / 64;
+        const int ntile = T * (T + 1) / 2;
+        const int Wu = W - 1, wu = w - 1;
+        auto tile_of = [&](int t, int& i0, int& j0) {
+            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            i0 = k1 + ti * 64;
+            j0 = k1 + tj * 64;
+        };
+        double4_t accn[4];
+        double pa[8], pb[8];
+        auto tile_fetch_acc = [&](int t) {
+            int i0, j0;
+            tile_of(t, i0, j0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                    accn[c][rg] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+                }
+        };
+        auto tile_fetch_panels = [&](int t) {
+            int i0, j0;
+            tile_of(t, i0, j0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 256 * q, r = e >> 5, m = e & 31;
+                pa[q] = ld_sh(&A[(size_t)min(i0 + r, nrows - 1) * lda + k0 + m]);
+                pb[q] = ld_sh(&A[(size_t)min(j0 + r, nrows - 1) * lda + k0 + m]);
+            }
+        };
+        if (w != 0 && nb == CH_NB && wu < ntile) tile_fetch_acc(wu);
+        const int nslice = max(pend - pbeg, 0);
+        const int ntask = 2 * ((nslice + 15) >> 4);
+        double xb[2][2];
+        auto panel_fetch = [&](int t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = k1 + pbeg + 16 * (t >> 1) + lk + 4 * (2 * (t & 1) + h);
+                    xb[c][h] = ld_sh(&A[(size_t)min(prow, nrows - 1) * lda + min(k0 + 16 * c + li, n - 1)]);
+                }
+        };
+        if (wave < ntask) panel_fetch(wave);
+        __syncthreads();
+        if (w != 0) {
+            double dv[5];
+            coef_load(kb, dv);
+            coef_put(0, dv);
+        }
+        __syncthreads();
+        for (int t = wave; t < ntask; t += 4) {
+            if (nb < CH_NB) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) xb[c][h] = (16 * c + li < nb) ? xb[c][h] : 0.0;
+            }
+            double x0[2], x1[2];
+            cf_chain(xb, S.Cf[0], S.Rd[0], li, x0, x1);
+            const int tcur = t;
+            if (t + 4 < ntask) panel_fetch(t + 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pr = 16 * (tcur >> 1) + lk + 4 * (2 * (tcur & 1) + h), p = pbeg + pr;
+                if (pr < nslice) {
+                    if (li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + li], x0[h]);
+                    if (16 + li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + 16 + li], x1[h]);
+                }
+                if (w == 0 && p < CH_NB) {
+                    S.Li[p][li] = (pr < nslice) ? x0[h] : 0.0;
+                    S.Li[p][16 + li] = (pr < nslice) ? x1[h] : 0.0;
+                }
+            }
+        }
+        if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
+        if (w == 0) {
+            region_arrive(ctr1);
+            gen1 += W;
+            for (int p = pend; p < CH_NB; ++p)                   // rows this slice does not have
+                if (tid < CH_NB) S.Li[p][tid] = 0.0;
+            __syncthreads();
+            {
+                const int ti = wave >> 1, tj = wave & 1;
+                double4_t c4 = {cpre[0], cpre[1], cpre[2], cpre[3]};
+                if (tj <= ti) {
+#pragma unroll
+                    for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                        const double a = -S.Li[16 * ti + li][4 * kk + lk];
+                        const double b = S.Li[16 * tj + li][4 * kk + lk];
+                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
+                    S.D[i][j] = (i < nbn && j <= i) ? c4[q] : ((i == j) ? 1.0 : 0.0);
+                }
+            }
+            factor_and_publish(k1, nbn, kb + 1, 0);
+        } else {
+            gen1 += W;
+            dead = region_barrier(ctr1, gen1, spin_limit);
+            if (dead) break;
+            int t = wu;
+            if (t < ntile) tile_fetch_panels(t);
+            while (t < ntile) {
+                int i0, j0;
+                tile_of(t, i0, j0);
+                double4_t acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = accn[c];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + 256 * q, r = e >> 5, m = e & 31;
+                    S.Li[r][m] = -pa[q];
+                    S.Lj[r][m] = pb[q];
+                }
+                __syncthreads();
+                const int tn = t + Wu;
+                if (tn < ntile) { tile_fetch_acc(tn); tile_fetch_panels(tn); }
+#pragma unroll
+                for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                    const double a = S.Li[16 * wave + li][4 * kk + lk];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double b = S.Lj[16 * c + li][4 * kk + lk];
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
+                        const bool corner = (t == 0) && i < k1 + nbn;
+                        if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * lda + j], acc[c][rg]);
+                    }
+                t = tn;
+            }
+        }
+        gen2 += W;
+        dead = region_barrier(ctr2, gen2, spin_limit);
+        kb += 1;
+    }
+    if (dead && tid == 0) atomicAdd(&tmo[reg], 1);
+    if (PROF && prof && tid == 0) {
+        // (the panel phase of this wave in detail: chain 1, products, chain 2, stores; folded into slot 2 for the host's table)
+        for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
+    }
+#undef CF2_TICK
 }
 
 // ---- the same factorisation, cheap in CU-time instead of short --------------------------
@@ -2473,7 +3079,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
     ZM_TRY(ctx->get("hp_cbar", sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG, (void**)&cbar));
     double* cdg = nullptr;               // published diagonal factors of k_chol_fused
-    ZM_TRY(ctx->get("hp_cdg", sizeof(double) * 2 * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));
+    ZM_TRY(ctx->get("hp_cdg", sizeof(double) * 4 * CH_NB * (CH_NB + 1) * HP_MAXREG, (void**)&cdg));   // (k_chol_fused2: four slots)
     ZM_TRY(ctx->get("hp_X", sizeof(double) * (size_t)P.ncell * P.nX * P.npixp, (void**)&X));
     ZM_TRY(ctx->get("hp_G", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&G));
     double* Gp = nullptr;                // per-slice partial Gram matrices
@@ -2687,10 +3293,25 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
                 // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
                 // order against the following launches of the stream on its first use)
+                // ZM_CHOL_STEP=64: the 64-column super-steps (k_chol_fused2: same bits; measured, not faster - see its
+                // header); default: the one-block steps (k_chol_fused)
+                const bool step32 = !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
                 {
                     zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
-                    hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
-                                       spin_limit, barg, parg, guard);
+                    if (step32) {
+                        hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
+                                           spin_limit, barg, parg, guard);
+                    } else {
+                        auto kf = want_prof ? k_chol_fused2<true> : k_chol_fused2<false>;
+                        static bool attr_set[2][64] = {};
+                        if (!attr_set[want_prof][ctx->device & 63]) {
+                            ZM_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)sizeof(cf2_lds)));
+                            attr_set[want_prof][ctx->device & 63] = true;
+                        }
+                        hipLaunchKernelGGL(kf, dim3(P.nreg * W), b256, sizeof(cf2_lds), st, nunk, lda, W, Aarg, dgarg,
+                                           farg, tmo, spin_limit, barg, parg, guard);
+                    }
                 }
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
@@ -2698,6 +3319,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
                     ZM_HIP(hipStreamSynchronize(st));
                     static const char* nm[6] = {"load", "tilewait", "panel", "barrier1", "update", "barrier2"};
+                    // (k_chol_fused2, workgroup 0: "barrier1" = first look-ahead block, "update" = the second)
                     for (int wg : {0, 1, W - 1, W, (P.nreg - 1) * W}) {
                         fprintf(stderr, "chol wg %3d:", wg);
                         for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f us", nm[k], hp[(size_t)wg * 6 + k] * 0.01);
