@@ -211,6 +211,9 @@ struct meshf_lds {
     double red[BKF_WAVES];
     double red3[3][BKF_WAVES];
     long long wsum[3][4];
+    // block sums with ONE barrier each (round 4): three slot sets used in rotation - a set is written again
+    // only after two more barriers, when every wave has long read it
+    double rot[3][3][BKF_WAVES];
 };
 
 // per-mesh hand-off from k_mesh_stats_fast to k_mesh_guess (global memory): the histogram itself; its
@@ -234,6 +237,26 @@ __device__ inline double blockf_sum(double v, double* red) {
 #pragma unroll
     for (int w = 0; w < BKF_WAVES; ++w) t += red[w];     // fixed order: deterministic
     return t;
+}
+
+// three sums, one barrier: the waves' partial sums go into slot set `slot` (see meshf_lds::rot); fixed order:
+// deterministic
+__device__ inline void blockf_sum3_1b(double& a, double& b, double& c, double (*red)[BKF_WAVES]) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+        red[2][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    a = b = c = 0.0;
+#pragma unroll
+    for (int w = 0; w < BKF_WAVES; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
 }
 
 // three sums in one pass of barriers; fixed order: deterministic
@@ -268,15 +291,20 @@ struct bk_batch {
 
 // The statistic of one mesh from its 32 px per thread (NaN = not a sample): pivot, two moment passes,
 // histogram, prefix arrays -> *D.  Every branch is uniform over the workgroup.
+// Round 4: half the barriers.  `khint`: the value of the mesh's first pixel when that pixel is a sample (every
+// thread loaded it: a uniform pivot without a search - NaN otherwise); the block sums take one barrier each
+// (rotating slots `rot0`, `rot0 + 1`), the histogram is zeroed before the first of them.
 __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area, meshf_lds* S,
-                                             mesh_dump* __restrict__ D, const int dbg) {
+                                             mesh_dump* __restrict__ D, const int dbg, const float khint,
+                                             const int rot0) {
     const int tid = threadIdx.x;
     const float qnan = __builtin_nanf("");
     // ---- pivot: some valid pixel of the mesh.  Moments are accumulated about it, in fp64:
     // (x - K) is exact, a constant mesh gives exactly zero variance (as numpy's two-pass var
     // in the oracle does) and a nearly flat map loses nothing to cancellation, in one sweep
     // per clipping pass instead of two.
-    float kf = qnan;
+    float kf = khint;
+    if (!(khint == khint)) {
 #pragma unroll
     for (int k = BKF_PX - 1; k >= 0; --k) kf = (v[k] == v[k]) ? v[k] : kf;
     {
@@ -291,11 +319,15 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
         for (int w8 = BKF_WAVES - 1; w8 >= 0; --w8) { const double c = S->red[w8]; kd = (c == c) ? c : kd; }
         kf = (float)kd;
     }
+    }
     if (!(kf == kf)) {                                       // no valid pixel at all
         if (tid == 0) D->valid = 0;
         return;
     }
     const double K = (double)kf;
+    // (the histogram is cleared here, ahead of the two barriers of the moment passes: nobody touches it before
+    // the third.  Cleared between the passes it cost 25 registers and spills at this kernel's budget of 128.)
+    for (int k = tid; k < BK_NLEVELS; k += BKF_THREADS) S->histo[k] = 0;
     // ---- pass 1: all valid pixels
     // branch-free: an excluded pixel is replaced by the pivot (d = 0 adds nothing, exactly) and
     // counted with integers, so a pixel costs one conversion and three fp64 operations
@@ -313,7 +345,7 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
         }
         s0 = (double)cnt;
     }
-    blockf_sum3(s0, s1, s2, S->red3);
+    blockf_sum3_1b(s0, s1, s2, S->rot[rot0 % 3]);
     if (s0 < area * 0.5 || s0 < 1.0) {   // BACK_MINGOODFRAC
         if (tid == 0) D->valid = 0;
         return;
@@ -342,7 +374,7 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
         }
         s0 = (double)cnt;
     }
-    blockf_sum3(s0, s1, s2, S->red3);
+    blockf_sum3_1b(s0, s1, s2, S->rot[(rot0 + 1) % 3]);
     if (s0 < 1.0) {
         if (tid == 0) D->valid = 0;
         return;
@@ -368,8 +400,6 @@ __device__ __forceinline__ void mesh_general(float (&v)[BKF_PX], const int area,
     // y = RN(1 / qscale), q0 = RN(x y), r = RN(x - q0 qscale), q = RN(q0 + r y) is the
     // correctly rounded x / qscale (Markstein) unless the significand of qscale is all
     // ones; three instructions instead of the ten of a division.
-    for (int k = tid; k < BK_NLEVELS; k += BKF_THREADS) S->histo[k] = 0;
-    __syncthreads();
     {
         // one exec-masked LDS add per valid pixel, nothing else in the loop's control flow (a version that
         // merged runs of equal bins paid four branches per pixel for a case - flat maps - that no longer
@@ -458,6 +488,14 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
     int wcnt = 0;
     const float pinf = __builtin_inff();
     const float thr = wgt ? wthresh : -pinf;
+    // the pivot of the image statistic without a search: the mesh's first pixel, read by every thread (one
+    // address: a broadcast out of the cache), when it is a sample
+    float khint = qnan;
+    if (SEL != 1) {
+        const size_t i00 = (size_t)y0 * nx + x0;
+        const float p0 = img[i00], w0 = wgt ? wgt[i00] : 1.f;
+        khint = (w0 > thr && p0 > -BK_BIG) ? p0 : qnan;
+    }
     const int c4 = (tid & 31) * 4, r32 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < BKF_PX / 4; ++k) {
@@ -534,9 +572,9 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
             D1->mean0 = (double)inv;
             D1->valid = 2;
         }
-        __syncthreads();                                   // red3 is reused below
+        // (no barrier here: the statistics below keep their partial sums in other slots)
     }
-    if (SEL != 1) mesh_general(v, area, S, D0, dbg);
+    if (SEL != 1) mesh_general(v, area, S, D0, dbg, khint, 0);
     if (SEL == 0 || flat) return;
     if (SEL == 2) {
         // the weights of this mesh vary: read them again (the registers held the image)
@@ -559,7 +597,8 @@ __global__ __launch_bounds__(BKF_THREADS, BKF_WPS) void k_mesh_stats_fast(const 
         const bool ok = (x == x) && (val > -BK_BIG) && (val == val);
         v[k] = ok ? val : qnan;
     }
-    mesh_general(v, area, S, D1, dbg);
+    __syncthreads();                                       // (the slots and the histogram of the first statistic are consumed)
+    mesh_general(v, area, S, D1, dbg, qnan, 2);
 }
 
 // One wave per mesh: iterated clipping on the dumped prefix arrays (staged in LDS).
