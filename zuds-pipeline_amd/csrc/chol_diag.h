@@ -1,0 +1,163 @@
+// The 32 x 32 diagonal factor of the blocked Cholesky (hotpants.hip: k_chol_fused, k_chol_fused2, k_chol_tp all
+// call the same function, so the three forms give the same bits) - in a header of its own so that
+// tools/potrf_probe.hip times and checks exactly what the library runs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef CH_NB
+#define CH_NB 32
+#endif
+
+typedef double chd_double4 __attribute__((ext_vector_type(4)));
+
+__device__ inline double readlane_d(double v, int src) {
+    // src is wave-uniform (a compile-time constant after unrolling): v_readlane_b32 x 2
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// The rank-8 update of the block's trailing part after panel p (columns c0 .. c1 - 1 are final and in D):
+// two v_mfma_f64_16x16x4 per 16 x 16 tile of the lower triangle that still has unfactored columns, through
+// LDS.  One wave; LDS operations of a wave execute in order, so the panel written by the lanes is what the
+// matrix-core operands read back.
+__device__ __forceinline__ void chol_diag_trailing(double (*D)[CH_NB + 1], int c0, int c1, int li, int lk) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            if (16 * (ti + 1) <= c1 || 16 * (tj + 1) <= c1) continue;     // tile above / left of the trailing part
+            chd_double4 c4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c4[q] = D[16 * ti + lk + 4 * q][16 * tj + li];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const double av = -D[16 * ti + li][c0 + 4 * kk + lk];
+                const double bv = D[16 * tj + li][c0 + 4 * kk + lk];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * ti + lk + 4 * q, jc = 16 * tj + li;
+                if (i >= c1 && jc >= c1 && jc <= i) D[i][jc] = c4[q];
+            }
+        }
+}
+
+// Rounds 1 - 3: four panels of eight columns.  A column step: the pivot is broadcast from its lane
+// (v_readlane), 1 / sqrt by the hardware estimate + two Newton steps (full fp64 accuracy, no divide), the
+// column is scaled, broadcast lane by lane for the rank-1 update of the panel's remaining columns (2 readlanes +
+// 1 FMA per column); the rest of the block gets the panel's rank-8 update on the matrix cores.  The 32 dependent
+// column steps are the critical path of every form of the factorisation: ~150 ns each, 4.7 us per block.
+template <int TAG>
+__device__ inline void chol_diag_wave_panel_ref(double (*D)[CH_NB + 1], int nb, int* fail) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, li = lane & 15, lk = lane >> 4;
+    int bad = 0;
+    double dinv = 1.0;                                   // 1 / L[row][row]
+#pragma unroll
+    for (int p = 0; p < CH_NB / 8; ++p) {
+        const int c0 = 8 * p, c1 = c0 + 8;
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = D[row][c0 + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double ajj = readlane_d(a[j], c0 + j);
+            if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
+            double ri = __builtin_amdgcn_rsq(ajj);
+            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
+            const double dj = ajj * ri;
+            const double lj = (row == c0 + j) ? dj : a[j] * ri;   // L[row][c0 + j] (meaningful for row >= c0 + j)
+            if (row == c0 + j) dinv = ri;
+            a[j] = lj;
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) {
+                const double lc = readlane_d(lj, c0 + c);
+                a[c] -= lj * lc;
+            }
+        }
+        if (lane < CH_NB) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
+        }
+        if (c1 < CH_NB) chol_diag_trailing(D, c0, c1, li, lk);
+    }
+    if (lane < CH_NB) D[row][CH_NB] = dinv;
+    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
+}
+
+// Round 4: the same panels with a shorter column step.  What a step waits for, in order: the pivot's broadcast,
+// its reciprocal square root, the scaled column, the update of the NEXT pivot.  Three changes, all on that chain:
+//  * every lane keeps its own diagonal entry (dg) up to date beside the panel columns - `dg -= l l` needs only
+//    the lane's own l, so the next pivot is ready one broadcast (v_readlane -> SGPR -> FMA) earlier; the panel
+//    columns themselves still take their rank-1 updates, off the chain;
+//  * one third-order correction of the hardware estimate y0 instead of two second-order ones:
+//    e = 1 - a y0^2, 1 / sqrt(a) = y0 (1 + e (1/2 + 3/8 e)) to 2.5 eps0^3 (v_rsq_f64: eps0 ~ 2^-23 .. 2^-26,
+//    tools/potrf_probe.hip measures it; two Newton steps were needed because ONE second-order step stops at
+//    1.5 eps0^2) - four dependent operations instead of six;
+//  * the column scale rides in the correction: l = (a_ij y0) + (a_ij y0 e)(1/2 + 3/8 e), ready with the root;
+//  * the pivot clamp is a v_max_f64 (the bad-pivot flag is computed beside the chain).
+// Same operation count per entry elsewhere, same matrix-core updates; the factor differs from the old one by
+// rounding (<= 1 ulp per entry before propagation), all forms of the factorisation share it.
+template <int TAG, int HALF = 0>
+__device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb, int* fail) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, li = lane & 15, lk = lane >> 4;
+    int bad = 0;
+    double dinv = 1.0;                                   // 1 / L[row][row]
+#pragma unroll
+    for (int p = 0; p < CH_NB / 8; ++p) {
+        const int c0 = 8 * p, c1 = c0 + 8;
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = D[row][c0 + c];
+        double dg = D[row][row];                         // (a pivot of THIS panel only when c0 <= row < c1)
+        if (!HALF || (lane < CH_NB && (HALF == 1 || lane >= (c0 & 16))))
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double piv = readlane_d(dg, c0 + j);
+            bad |= !(piv > 1e-14);
+            double ajj;                                             // max(piv, 1e-14), NaN -> 1e-14: ONE v_max_f64
+            asm("v_max_f64 %0, %1, %2" : "=v"(ajj) : "v"(1e-14), "s"(piv));   // (fmax() puts a canonicalising max in front)
+            const double y0 = __builtin_amdgcn_rsq(ajj);
+            const double l0 = a[j] * y0;                            // beside the correction
+            const double t = ajj * y0;
+            const double e = __builtin_fma(-t, y0, 1.0);
+            const double pc = __builtin_fma(0.375, e, 0.5);
+            const double ye = y0 * e, le = l0 * e;
+            const double ri = __builtin_fma(ye, pc, y0);
+            const double lo = __builtin_fma(le, pc, l0);            // a[j] / sqrt(ajj)
+            const double lj = (row == c0 + j) ? ajj * ri : lo;      // L[row][c0 + j] (meaningful for row >= c0 + j)
+            dg = __builtin_fma(-lo, lo, dg);                        // the diagonal entry of a row below the pivot
+            if (row == c0 + j) dinv = ri;
+            a[j] = lj;
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) {
+                const double lc = readlane_d(lj, c0 + c);
+                a[c] = __builtin_fma(-lj, lc, a[c]);
+            }
+        }
+        if (lane < CH_NB && (HALF != 2 || lane >= (c0 & 16))) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
+        }
+        if (c1 < CH_NB) chol_diag_trailing(D, c0, c1, li, lk);
+    }
+    if (lane < CH_NB) D[row][CH_NB] = dinv;
+    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
+}
+
+#ifndef ZM_CHOL_DIAG_FAST
+#define ZM_CHOL_DIAG_FAST 1
+#endif
+template <int TAG>
+__device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, int* fail) {
+#if ZM_CHOL_DIAG_FAST
+    chol_diag_wave_panel_fast<TAG>(D, nb, fail);
+#else
+    chol_diag_wave_panel_ref<TAG>(D, nb, fail);
+#endif
+}

@@ -26,6 +26,7 @@
 #include <cmath>
 
 #include "zm_internal.h"
+#include "chol_diag.h"
 
 #define HP_MAXX 64        // rows of the Gram tile (nc + nbg + 1 <= 64)
 #define HP_MAXPOLY 28     // (ko + 1)(ko + 2) / 2 for ko <= 6
@@ -33,7 +34,6 @@
 #define HP_MAXREG 64
 #define CF_BAR_STRIDE 32                // one k_chol_fused barrier counter per region, 128 B apart
 #define HP_MAXF1 32       // distinct 1-D filters
-#define CH_NB 32
 #define HP_RIDGE 1e-10
 
 struct hp_plan {
@@ -849,125 +849,7 @@ __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const 
 // factoring the augmented matrix leaves y = L^-1 b in that row, so the forward substitution
 // costs nothing extra.  Block size 32; see k_chol_fused below.
 
-__device__ inline double readlane_d(double v, int src) {
-    // src is wave-uniform (a compile-time constant after unrolling): v_readlane_b32 x 2
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-template <int N>
-__device__ inline double readlane_dyn(const double (&a)[N], int idx) {
-    double r = a[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) r = (i == idx) ? a[i] : r;
-    return r;
-}
-
-// 32 x 32 Cholesky by one wave, the block held in registers (lane i = row i):
-// column j is scaled in place, then broadcast lane by lane for the rank-1 update.
-__device__ inline void chol_diag_wave(double (*D)[CH_NB + 1], int nb, int* fail) {
-    const int lane = threadIdx.x & 63;
-    const int row = lane & 31;
-    double a[CH_NB];
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) a[c] = D[row][c];     // rows >= nb are identity rows
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        double ajj = readlane_d(a[j], j);
-        if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
-        // 1 / sqrt by hardware estimate + two Newton steps (full fp64 accuracy), no divide
-        double ri = __builtin_amdgcn_rsq(ajj);
-        ri = ri * (1.5 - 0.5 * ajj * ri * ri);
-        ri = ri * (1.5 - 0.5 * ajj * ri * ri);
-        const double dj = ajj * ri;
-        const double lj = (row == j) ? dj : a[j] * ri;    // L[row][j] (meaningful for row >= j)
-        a[j] = lj;
-#pragma unroll
-        for (int c = j + 1; c < CH_NB; ++c) {
-            const double lc = readlane_d(lj, c);          // L[c][j]
-            a[c] -= lj * lc;                              // entries with row >= c are the live ones
-        }
-    }
-    if (lane < CH_NB) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c)
-            if (c <= row) D[row][c] = a[c];
-        // reciprocal of the diagonal in the (unused) upper corner D[0][1..]: the panel
-        // solve multiplies instead of dividing
-        D[row][CH_NB] = 1.0 / readlane_dyn(a, row);
-    }
-    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
-}
-
-// The same factorisation in four panels of eight columns.  The register scheme above spends
-// most of its 7 us on the rank-1 updates: column j is broadcast lane by lane (2 readlanes + 1
-// FMA per remaining column, ~500 of each).  Here only the 8 columns of a panel are updated that
-// way; the rest of the block gets the panel's rank-8 update on the f64 matrix cores (two
-// v_mfma_f64_16x16x4 per 16 x 16 tile of the lower triangle, 10 in all), through LDS.  The 32
-// dependent reciprocal square roots remain.  One wave; LDS operations of a wave execute in
-// order, so the panel written by the lanes is what the matrix-core operands read back.
-template <int TAG>
-__device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, int* fail) {
-    const int lane = threadIdx.x & 63;
-    const int row = lane & 31, li = lane & 15, lk = lane >> 4;
-    int bad = 0;
-    double dinv = 1.0;                                   // 1 / L[row][row]
-#pragma unroll
-    for (int p = 0; p < CH_NB / 8; ++p) {
-        const int c0 = 8 * p, c1 = c0 + 8;
-        double a[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = D[row][c0 + c];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            double ajj = readlane_d(a[j], c0 + j);
-            if (!(ajj > 1e-14)) { ajj = 1e-14; bad = 1; }
-            double ri = __builtin_amdgcn_rsq(ajj);
-            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
-            ri = ri * (1.5 - 0.5 * ajj * ri * ri);
-            const double dj = ajj * ri;
-            const double lj = (row == c0 + j) ? dj : a[j] * ri;   // L[row][c0 + j] (meaningful for row >= c0 + j)
-            if (row == c0 + j) dinv = ri;
-            a[j] = lj;
-#pragma unroll
-            for (int c = j + 1; c < 8; ++c) {
-                const double lc = readlane_d(lj, c0 + c);
-                a[c] -= lj * lc;
-            }
-        }
-        if (lane < CH_NB) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
-        }
-        if (c1 < CH_NB) {
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) {
-                    if (16 * (ti + 1) <= c1 || 16 * (tj + 1) <= c1) continue;     // tile above / left of the trailing part
-                    double4_t c4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) c4[q] = D[16 * ti + lk + 4 * q][16 * tj + li];
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const double av = -D[16 * ti + li][c0 + 4 * kk + lk];
-                        const double bv = D[16 * tj + li][c0 + 4 * kk + lk];
-                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = 16 * ti + lk + 4 * q, jc = 16 * tj + li;
-                        if (i >= c1 && jc >= c1 && jc <= i) D[i][jc] = c4[q];
-                    }
-                }
-        }
-    }
-    if (lane < CH_NB) D[row][CH_NB] = dinv;
-    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
-}
+// (the 32 x 32 diagonal factor every form of the factorisation calls: chol_diag.h)
 
 template <int SRC>
 __device__ __forceinline__ double row16_bcast_d(double v) {

@@ -1767,6 +1767,108 @@ __global__ __launch_bounds__(256) void k_mask_box_rows(const zm_boxjob* __restri
     if (J.rawflag && __any(raw_seen) && lane == 0) atomicOr(J.rawflag, 1);
 }
 
+// int16 masks whose rows are whole 16-byte pieces (nx a multiple of 8, aligned planes - every ZTF mask): the same
+// walk on PACKED words.  A lane keeps its eight columns as the four dwords it loaded (two mask words each), a
+// strip is 64 lanes x 8 columns = 512 columns = whole 128-byte lines (the kernel above gives a lane to the halo:
+// 504-column strips, a seventh strip of 48 columns at 3072, every row load straddling two lines).  The columns
+// right of the lane come from the next lane by a DPP wave shift (lane 63: from the first piece of the next strip,
+// loaded once per NT rows by NT lanes and handed over by v_readlane as the shift's fill value).  A negative
+// int16 word is the sign extension box_entry() turns into ZM_BOX_RAW, i.e. bit 15 of the 16-bit OR: the sliding
+// OR works on halves of dwords (f = lo | hi of a pair; even columns: OR of whole pairs; odd columns: hi of the
+// first, whole pairs, lo of the last - v_or3_b32 / v_and_or_b32 / v_lshl_or_b32), the vertical OR on the packed
+// results, and the entry is o | 0xffff per half whose bit 15 is set.  ~75 vector instructions per row of eight
+// columns instead of ~150, no LDS cross-lane traffic.  Same plane, bit for bit (tests/test_mask_i16_gpu.py).
+__device__ __forceinline__ uint32_t mb_shl1(uint32_t v, uint32_t fill) {
+    // lane i <- lane i + 1 (DPP wave_shl:1); lane 63 keeps `fill`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_mask_box_rows16(const zm_boxjob* __restrict__ jobs) {
+    static_assert(NT % 2 == 0 && NT >= 2 && NT <= 6, "pairs of columns; the halo is at most three dwords");
+    constexpr int HP = NT / 2;                                        // whole pairs in a window
+    const zm_boxjob J = jobs[blockIdx.z];
+    const int nx = J.nx, ny = J.ny;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xs = blockIdx.x * 512, x = xs + 8 * lane;              // this lane's columns
+    const int y0 = (blockIdx.y * 4 + wv) * MB_ROWS;                  // first output row of this wave's band
+    if (xs >= nx || y0 >= ny) return;                                // (wave-uniform: the grid covers the largest frame)
+    const int16_t* __restrict__ m = reinterpret_cast<const int16_t*>(J.m);
+    const bool mine = x < nx;                                        // (nx % 8 == 0: a lane's piece is whole or absent)
+    const int xh = xs + 512;                                         // the piece right of the strip
+    const bool halo = xh < nx;
+    const bool all_in = x + 7 + NT <= nx;                            // every window of this lane lies on the frame
+    uint32_t ring[NT][4];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[k][i] = 0u;
+    uint32_t rawm = 0u;
+#pragma unroll 1
+    for (int r0 = 0; r0 < MB_ROWS + NT - 1; r0 += NT) {
+        if (y0 + r0 >= ny) break;                                    // nothing below the frame contributes
+        uint4 a[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {                               // NT rows requested together
+            const int y = y0 + r0 + k;
+            a[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (y < ny && mine) a[k] = *reinterpret_cast<const uint4*>(m + (size_t)y * nx + x);
+        }
+        uint4 hp = make_uint4(0u, 0u, 0u, 0u);                       // lane k: the halo piece of row r0 + k
+        if (lane < NT && y0 + r0 + lane < ny && halo)
+            hp = *reinterpret_cast<const uint4*>(m + (size_t)(y0 + r0 + lane) * nx + xh);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int y = y0 + r0 + k;                               // input row; it completes output row y - NT + 1
+            uint32_t P[7] = {a[k].x, a[k].y, a[k].z, a[k].w, 0u, 0u, 0u};
+            const uint32_t hs[3] = {(uint32_t)__builtin_amdgcn_readlane((int)hp.x, k),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)hp.y, k),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)hp.z, k)};
+#pragma unroll
+            for (int i = 0; i < HP; ++i) P[4 + i] = mb_shl1(P[i], hs[i]);
+            uint32_t hi[7], f[7];
+#pragma unroll
+            for (int i = 0; i < 4 + HP; ++i) {
+                hi[i] = P[i] >> 16;
+                f[i] = (P[i] & 0xffffu) | hi[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t he = f[i], ho = hi[i];
+#pragma unroll
+                for (int t = 1; t < HP; ++t) { he |= f[i + t]; ho |= f[i + t]; }
+                ho |= P[i + HP] & 0xffffu;
+                ring[k][i] = he | (ho << 16);
+            }
+            const int yo = y - (NT - 1);
+            if (yo >= y0 && yo < y0 + MB_ROWS && y < ny && mine) {
+                uint32_t en[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t o = ring[0][i];
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) o |= ring[t][i];
+                    const uint32_t neg = (o >> 15) & 0x00010001u;    // halves with bit 15: a negative word in the window
+                    en[i] = o | (neg * 0xffffu);
+                    if (all_in) rawm |= neg;
+                }
+                uint16_t* dst = J.B + (size_t)yo * J.pitch + x;
+                if (all_in) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(en[0], en[1], en[2], en[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (x + e + NT <= nx) {
+                            const uint16_t v = (uint16_t)(en[e >> 1] >> (16 * (e & 1)));
+                            dst[e] = v;
+                            rawm |= v == ZM_BOX_RAW ? 1u : 0u;
+                        }
+                }
+            }
+        }
+    }
+    if (J.rawflag && __any(rawm != 0u) && lane == 0) atomicOr(J.rawflag, 1);
+}
+
 // jobs: host arrays (staged through pinned memory behind an event, like the frame descriptors)
 int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows) {
     if (nrows == 0) return 0;
@@ -1792,6 +1894,16 @@ int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows) {
     return 0;
 }
 
+// 2: int16, rows and planes in whole 16-byte pieces (k_mask_box_rows16; ZM_MASK_BOX=lanes keeps such planes on
+// the unpacked kernel: developer A / B); 1: other int16 planes; 0: int32
+static int box_kind(const zm_boxjob& b) {
+    static const bool unpacked = getenv("ZM_MASK_BOX") && !strcmp(getenv("ZM_MASK_BOX"), "lanes");
+    if (!b.is16) return 0;
+    const bool pieces = b.nx % 8 == 0 && b.pitch % 8 == 0 && (reinterpret_cast<uintptr_t>(b.m) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(b.B) & 15) == 0;
+    return pieces && !unpacked ? 2 : 1;
+}
+
 // The box-OR planes depend on the masks only.  after != NULL: the launch goes to the second stream, ordered
 // after `after` (an event recorded on the main stream before the caller enqueues the mesh statistics: nothing
 // older may still read the planes), and runs BESIDE those statistics - they are bound by their own moment /
@@ -1808,11 +1920,12 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
     ZM_TRY(ctx->get_pinned("ff_box_h", bb, (void**)&pin));
     ZM_TRY(ctx->get("ff_box", bb, (void**)&dev));
     {
-        zm_boxjob* pj = reinterpret_cast<zm_boxjob*>(pin);        // int16 jobs first, then the int32 ones
+        // int16 jobs of whole 16-byte pieces first (the packed kernel), then the other int16 ones, then int32
+        zm_boxjob* pj = reinterpret_cast<zm_boxjob*>(pin);
         int k = 0;
-        for (int pass = 1; pass >= 0; --pass)
+        for (int pass = 2; pass >= 0; --pass)
             for (int i = 0; i < nboxes; ++i)
-                if ((boxes[i].is16 != 0) == (pass == 1)) pj[k++] = boxes[i];
+                if (box_kind(boxes[i]) == pass) pj[k++] = boxes[i];
     }
     // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
     const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "mask_box");
@@ -1840,11 +1953,17 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
             // one launch per mask type over the jobs of that type (a stack normally has one): the jobs are
             // sorted by type in the staging copy, a launch covers a contiguous range of them
             const unsigned gy = zm_div_up(zm_div_up(my, MB_ROWS), 4);
-            int n16 = 0;
-            for (int i = 0; i < nboxes; ++i) n16 += boxes[i].is16 ? 1 : 0;
+            int n16 = 0, npk = 0;
+            for (int i = 0; i < nboxes; ++i) {
+                n16 += boxes[i].is16 ? 1 : 0;
+                npk += box_kind(boxes[i]) == 2 ? 1 : 0;
+            }
             const zm_boxjob* d = (const zm_boxjob*)dev;
-            if (n16)
-                hipLaunchKernelGGL((k_mask_box_rows<int16_t, 6>), dim3(zm_div_up(mx, 8 * 63), gy, n16), dim3(256), 0, s, d);
+            if (npk)
+                hipLaunchKernelGGL((k_mask_box_rows16<6>), dim3(zm_div_up(mx, 512), gy, npk), dim3(256), 0, s, d);
+            if (n16 - npk)
+                hipLaunchKernelGGL((k_mask_box_rows<int16_t, 6>), dim3(zm_div_up(mx, 8 * 63), gy, n16 - npk), dim3(256), 0, s,
+                                   d + npk);
             if (nboxes - n16)
                 hipLaunchKernelGGL((k_mask_box_rows<int32_t, 6>), dim3(zm_div_up(mx, 4 * 62), gy, nboxes - n16), dim3(256), 0,
                                    s, d + n16);
