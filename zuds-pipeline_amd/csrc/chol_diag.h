@@ -102,7 +102,12 @@ __device__ inline void chol_diag_wave_panel_ref(double (*D)[CH_NB + 1], int nb, 
 //  * the pivot clamp is a v_max_f64 (the bad-pivot flag is computed beside the chain).
 // Same operation count per entry elsewhere, same matrix-core updates; the factor differs from the old one by
 // rounding (<= 1 ulp per entry before propagation), all forms of the factorisation share it.
-template <int TAG, int HALF = 0>
+// Measured (tools/potrf_probe.hip, one wave, MI355X): 4.15 -> 3.85 us per block, ~9 200 shader clocks for ~1 750
+// instructions: a lone wave issues one vector instruction per ~5 cycles whatever depends on what, so the factor is
+// bound by its instruction COUNT on one SIMD (435 v_readlane among them), not by the chain any more.  Tried and
+// not kept: the column steps with only lanes 0 - 31 active (the upper half duplicates the rows): the same code
+// ran 3.4 us in some launches and 3.9 - 4.1 us in others.
+template <int TAG>
 __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb, int* fail) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, li = lane & 15, lk = lane >> 4;
@@ -115,7 +120,6 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
 #pragma unroll
         for (int c = 0; c < 8; ++c) a[c] = D[row][c0 + c];
         double dg = D[row][row];                         // (a pivot of THIS panel only when c0 <= row < c1)
-        if (!HALF || (lane < CH_NB && (HALF == 1 || lane >= (c0 & 16))))
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const double piv = readlane_d(dg, c0 + j);
@@ -140,7 +144,7 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
                 a[c] = __builtin_fma(-lj, lc, a[c]);
             }
         }
-        if (lane < CH_NB && (HALF != 2 || lane >= (c0 & 16))) {
+        if (lane < CH_NB) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
         }
