@@ -45,6 +45,39 @@ __device__ __forceinline__ void chol_diag_trailing(double (*D)[CH_NB + 1], int c
         }
 }
 
+// The same update with its store conditions spelled out per tile: c1 is a multiple of 8, so "row >= c1" is a
+// condition on the accumulator register q alone (row = 16 ti + lk + 4 q, lk < 4) and "column >= c1" is either
+// always / never true for a tile or the one lane predicate li >= 8.  Entries above the diagonal are written
+// too (nobody reads them).  As three-term runtime conditions per (tile, q) they were 24 loop-invariant 64-bit
+// masks: hoisted out of the block loop, spilled to VGPR lanes and reloaded (~100 v_readlane per factor).
+__device__ __forceinline__ void chol_diag_trailing_static(double (*D)[CH_NB + 1], int c0, int c1, int li, int lk) {
+    int liv = li;
+    asm volatile("" : "+v"(liv));                          // (made here: one v_cmp instead of a mask kept across the loop)
+    const bool right = liv >= 8;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            if (16 * (ti + 1) <= c1 || 16 * (tj + 1) <= c1) continue;     // tile above / left of the trailing part
+            chd_double4 c4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c4[q] = D[16 * ti + lk + 4 * q][16 * tj + li];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const double av = -D[16 * ti + li][c0 + 4 * kk + lk];
+                const double bv = D[16 * tj + li][c0 + 4 * kk + lk];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
+            }
+            const int cl = c1 - 16 * tj;                   // columns li >= cl of this tile trail the panel: <= 0 (all) or 8
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (16 * ti + 4 * q < c1) continue;        // rows 16 ti + 4 q .. + 3 lie above the trailing part
+                const int i = 16 * ti + lk + 4 * q, jc = 16 * tj + li;
+                if (cl <= 0 || right) D[i][jc] = c4[q];
+            }
+        }
+}
+
 // Rounds 1 - 3: four panels of eight columns.  A column step: the pivot is broadcast from its lane
 // (v_readlane), 1 / sqrt by the hardware estimate + two Newton steps (full fp64 accuracy, no divide), the
 // column is scaled, broadcast lane by lane for the rank-1 update of the panel's remaining columns (2 readlanes +
@@ -111,7 +144,7 @@ template <int TAG>
 __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb, int* fail) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, li = lane & 15, lk = lane >> 4;
-    int bad = 0;
+    double amin = 1.0;                                   // smallest clamped pivot: 1e-14 iff one was clamped
     double dinv = 1.0;                                   // 1 / L[row][row]
 #pragma unroll
     for (int p = 0; p < CH_NB / 8; ++p) {
@@ -122,10 +155,15 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
         double dg = D[row][row];                         // (a pivot of THIS panel only when c0 <= row < c1)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // (the pivot lane's predicate is made here, per column: hoisted, the 32 of them live in 64 scalar
+            // registers that spill to VGPR lanes - 150 v_readlane reloads on the path)
+            int rowj = row;
+            asm volatile("" : "+v"(rowj));
+            const bool pivot_lane = rowj == c0 + j;
             const double piv = readlane_d(dg, c0 + j);
-            bad |= !(piv > 1e-14);
             double ajj;                                             // max(piv, 1e-14), NaN -> 1e-14: ONE v_max_f64
             asm("v_max_f64 %0, %1, %2" : "=v"(ajj) : "v"(1e-14), "s"(piv));   // (fmax() puts a canonicalising max in front)
+            amin = __builtin_fmin(amin, ajj);                       // (beside the chain; as predicates the 32 pivots stay in SGPRs and spill)
             const double y0 = __builtin_amdgcn_rsq(ajj);
             const double l0 = a[j] * y0;                            // beside the correction
             const double t = ajj * y0;
@@ -134,9 +172,9 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
             const double ye = y0 * e, le = l0 * e;
             const double ri = __builtin_fma(ye, pc, y0);
             const double lo = __builtin_fma(le, pc, l0);            // a[j] / sqrt(ajj)
-            const double lj = (row == c0 + j) ? ajj * ri : lo;      // L[row][c0 + j] (meaningful for row >= c0 + j)
+            const double lj = pivot_lane ? ajj * ri : lo;           // L[row][c0 + j] (meaningful for row >= c0 + j)
             dg = __builtin_fma(-lo, lo, dg);                        // the diagonal entry of a row below the pivot
-            if (row == c0 + j) dinv = ri;
+            dinv = pivot_lane ? ri : dinv;
             a[j] = lj;
 #pragma unroll
             for (int c = j + 1; c < 8; ++c) {
@@ -148,10 +186,10 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
 #pragma unroll
             for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
         }
-        if (c1 < CH_NB) chol_diag_trailing(D, c0, c1, li, lk);
+        if (c1 < CH_NB) chol_diag_trailing_static(D, c0, c1, li, lk);
     }
     if (lane < CH_NB) D[row][CH_NB] = dinv;
-    if (bad && lane == 0 && fail) atomicAdd(fail, 1);
+    if (!(amin > 1e-14) && lane == 0 && fail) atomicAdd(fail, 1);
 }
 
 #ifndef ZM_CHOL_DIAG_FAST
