@@ -270,8 +270,12 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
     monkeypatch.setenv('ZM_CHOL_STEP', '64')
     d2, n2, i2 = engine.subtract(*data, **kw)
     monkeypatch.delenv('ZM_CHOL_STEP')
+    # ... and the data-flow form (k_chol_df: resident tiles, flags instead of barriers; sizes whose tiles do not
+    # fit three per workgroup run k_chol_fused under this switch)
+    monkeypatch.setenv('ZM_CHOL_FORM', 'df')
+    d3, n3, i3 = engine.subtract(*data, **kw)
     monkeypatch.delenv('ZM_CHOL_FORM')
-    for d, n, i in ((d1, n1, i1), (d2, n2, i2)):
+    for d, n, i in ((d1, n1, i1), (d2, n2, i2), (d3, n3, i3)):
         assert i0['status'] == 0 and i['status'] == 0 and i0['retries'] == 0 and i['retries'] == 0
         assert np.array_equal(d0, d) and np.array_equal(n0, n)
         for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):

@@ -828,12 +828,14 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
 }
 
 __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
-                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar, const int* __restrict__ guard) {
+                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar, const int* __restrict__ guard,
+                           unsigned* __restrict__ dff, int ndff) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
     if (c1 == 0 && c2 == 0)
         for (int k = 0; k < 4; ++k) bar[reg * CF_BAR_STRIDE + k] = 0;          // arms k_chol_fused's two region barriers
+    if (c1 == 0 && dff && c2 < ndff) dff[(size_t)reg * ndff + c2] = 0u;        // ... and k_chol_df's hand-over words
     if (c2 > c1 || c2 >= n) return;
     const double* dd = d + (size_t)reg * n;
     const size_t base0 = (size_t)reg * (size_t)(n + 1) * n;
@@ -1847,6 +1849,319 @@ __global__ __launch_bounds__(256) void k_chol_fused2(int n, int lda, int W, doub
 }
 
 // ---- the same factorisation, cheap in CU-time instead of short --------------------------
+// ---- the factorisation as a data-flow of resident tiles (round 4) ---------------------------
+// k_chol_fused moves every trailing entry through memory once per block step (accumulators in, accumulators
+// out, two panels per tile: ~400 MB per launch, the early steps are bandwidth-bound) and closes every step with
+// two region-wide barriers.  Here the lower triangle is cut ONCE into 64 x 64 tiles on a fixed grid; every tile
+// has one owner for the whole factorisation and lives in that workgroup's LDS (the accumulator layout of the
+// matrix cores, lane-major: 32 KB per tile, three tiles per workgroup) from the first step to its last:
+//   * a step of 32 columns (block kb = half h of tile column J) touches memory only for what really changes
+//     hands: the factored diagonal block's chain coefficients (Dg[kb]), the solved panel rows (written to A,
+//     where the back substitution wants them anyway) and the panels a tile's owner has to read for an update;
+//   * no barrier: a flag per (block, tile row) says "these panel rows are in A", a flag per block "the chain
+//     coefficients are published"; a workgroup waits for exactly what its next operation reads, and workgroups
+//     run as far ahead as their inputs allow;
+//   * the critical path - factor block kb, solve the 32 rows below it, update and factor block kb + 1 - stays
+//     inside ONE workgroup for two blocks (a diagonal tile holds both) and changes hands once per 64 columns:
+//     workgroup d owns the diagonal tile (d, d) AND its left neighbour (d, d - 1), so that everything the
+//     next diagonal block needs after the hand-over is computed by its owner from its own LDS.
+// Ownership (host and device run the same rule, hp_df_owner): workgroup d < NC (tile columns) owns (d, d) and
+// (d, d - 1); the other tiles ("far": two or more tile rows below the diagonal), heaviest first (they take part
+// in the most steps), go three each to the workgroups NC .. W - 1 and then fill the diagonal owners up to three.
+// Order inside a step: a workgroup first solves the panel tiles it owns (others wait for them), then updates,
+// nearest tile column first.  Every wait is a bounded spin on a word only its producer writes; producers never
+// wait for consumers, a step's solves wait only for that step's factor and its updates only for its solves:
+// no cycle, given that all workgroups are resident (the launch is sized like k_chol_fused's).
+// The arithmetic per entry is k_chol_fused's, operation for operation (chol_diag.h for the diagonal block, the
+// cf_chain for the panel rows, v_mfma_f64_16x16x4 with the negated row operand in ascending chunks of four
+// columns for the updates): same bits (tests/test_subtract_gpu.py compares all forms).
+#define DF_THREADS 512
+#define DF_MAXT 3                        // resident tiles per workgroup
+#define DF_LP (CH_NB + 2)                // pitch of the operand panels: conflict-free b64 reads
+struct df_lds {
+    double T[DF_MAXT][4][4][4][64];      // [slot][column sixteenth c][register rg][strip s][lane]
+    double Li[64][DF_LP];                // row operand of an update: -L[tile row rows][block columns]
+    double Lj[64][DF_LP];                // column operand: L[tile column rows][block columns]
+    double D[CH_NB][CH_NB + 1];
+    double2 Cf[CH_NB][16];
+    double Rd[CH_NB];
+    int tI[DF_MAXT], tJ[DF_MAXT], nt;
+    int dead;
+};
+// words per region: [0] a wait gave up, [1 + kb] factor of block kb published, [1 + nblk + kb * NT + I] the
+// panel rows of tile row I for block kb are in A
+__host__ __device__ inline int hp_df_nflags(int n) {
+    const int nblk = (n + CH_NB - 1) / CH_NB, NT = (n + 1 + 63) / 64;
+    return 1 + nblk + nblk * NT;
+}
+// the owner of tile (I, J) and the number of tiles workgroup `me` owns (list in tI / tJ, in processing order:
+// tile column ascending, then tile row); returns false when the tiles do not fit 3 per workgroup
+inline bool hp_df_owner(int n, int W, int me, int* tI, int* tJ, int* nt) {
+    const int NT = (n + 1 + 63) / 64, NC = (n + 63) / 64;
+    if (W < NC + 1 && !(NC == 1 && W >= 1)) return false;
+    int cnt[128];
+    if (W > 128) return false;
+    for (int w = 0; w < W; ++w) cnt[w] = 0;
+    int mine = 0;
+    auto give = [&](int w, int I, int J) {
+        if (w == me && mine < DF_MAXT) { tI[mine] = I; tJ[mine] = J; ++mine; }
+        ++cnt[w];
+    };
+    for (int d = 0; d < NC; ++d) {
+        give(d, d, d);
+        if (d >= 1) give(d, d, d - 1);
+    }
+    const int nfar = W - NC;
+    int nextfar = 0;
+    bool ok = true;
+    for (int J = NC - 1; J >= 0; --J)
+        for (int I = J; I < NT; ++I) {
+            if (I < NC && I - J <= 1) continue;                       // a diagonal owner's tile
+            int w = -1;
+            for (int tries = 0; tries < nfar; ++tries) {              // the far workgroups in turn, three each
+                const int c = NC + (nextfar + tries) % nfar;
+                if (cnt[c] < DF_MAXT) { w = c; nextfar = (nextfar + tries + 1) % nfar; break; }
+            }
+            if (w < 0)
+                for (int d = 0; d < NC; ++d)
+                    if (cnt[d] < DF_MAXT) { w = d; break; }
+            if (w < 0) { ok = false; continue; }
+            give(w, I, J);
+        }
+    // processing order: tile column, then tile row (insertion sort of at most three)
+    for (int a = 1; a < mine; ++a)
+        for (int b = a; b > 0 && (tJ[b] < tJ[b - 1] || (tJ[b] == tJ[b - 1] && tI[b] < tI[b - 1])); --b) {
+            int t = tI[b]; tI[b] = tI[b - 1]; tI[b - 1] = t;
+            t = tJ[b]; tJ[b] = tJ[b - 1]; tJ[b - 1] = t;
+        }
+    *nt = mine;
+    return ok;
+}
+
+// tiles: [W][1 + 2 DF_MAXT] ints per workgroup of a region - the number of its tiles, then (I, J) in processing
+// order (hp_df_owner on the host, the same table for every region)
+__global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
+                                                        int* tmo, int spin_limit, unsigned* flags_all,
+                                                        const int* __restrict__ tiles, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
+    extern __shared__ char df_raw[];
+    df_lds& S = *reinterpret_cast<df_lds*>(df_raw);
+    const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
+    const int nrows = n + 1;
+    const int nblk = (n + CH_NB - 1) / CH_NB, NT = (n + 1 + 63) / 64;
+    double* A = Aall + (size_t)reg * (size_t)nrows * lda;
+    double* Dgr = Dgall + (size_t)reg * nblk * CH_NB * (CH_NB + 1);
+    unsigned* F = flags_all + (size_t)reg * hp_df_nflags(n);
+    unsigned* Fdiag = F + 1;
+    unsigned* Fpan = F + 1 + nblk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ws = wave >> 1, wp = wave & 1;             // strip (16 tile rows) and half of this wave
+    if (tid == 0) {
+        const int* tl = tiles + w * (1 + 2 * DF_MAXT);
+        S.nt = tl[0];
+        for (int k = 0; k < DF_MAXT; ++k) { S.tI[k] = tl[1 + 2 * k]; S.tJ[k] = tl[2 + 2 * k]; }
+        S.dead = 0;
+    }
+    __syncthreads();
+    const int nt = S.nt;
+    // ---- the resident tiles: this wave's planes are (c = 2 wp, 2 wp + 1; rg = 0 .. 3; strip ws)
+    for (int sl = 0; sl < nt; ++sl) {
+        const int I = S.tI[sl], J = S.tJ[sl];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 2 * wp + cc;
+                const int i = 64 * I + 16 * ws + lk + 4 * rg, j = 64 * J + 16 * c + li;
+                S.T[sl][c][rg][ws][lane] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+            }
+    }
+    // a bounded wait for a word to become non-zero (thread 0 polls; everybody learns the outcome)
+    auto wait_flag = [&](const unsigned* f) -> bool {
+        __syncthreads();
+        if (tid == 0) {
+            int spins = 0, d = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > spin_limit || __hip_atomic_load(F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(F, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    d = 1;
+                    break;
+                }
+            }
+            if (d) S.dead = 1;
+        }
+        __syncthreads();
+        return S.dead == 0;
+    };
+    // this workgroup's stores to A / Dg are complete, then the word is set
+    auto set_flag = [&](unsigned* f) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int cf_block = -1;                                   // block whose chain coefficients are in S.Cf / S.Rd
+    int li_row = -1, lj_row = -1, l_block = -1;          // tile rows whose panels (block l_block) are in S.Li / S.Lj
+    // panel rows [r0, r1) of tile row R for block kb from A into an operand buffer (negated for the row operand)
+    auto load_panel = [&](int R, int kb, bool neg, double (*P)[DF_LP], int r0, int r1) {
+        const int k0 = kb * CH_NB;
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + DF_THREADS * q, r = e >> 5, m = e & 31;
+            v[q] = ld_sh(&A[(size_t)min(64 * R + r, nrows - 1) * lda + min(k0 + m, n - 1)]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + DF_THREADS * q, r = e >> 5, m = e & 31;
+            if (r >= r0 && r < r1) P[r][m] = neg ? -v[q] : v[q];
+        }
+    };
+    // acc(slot) -= Li Lj^T on the column sixteenths [cbeg, cend) of the strips [sbeg, 4)
+    auto update_tile = [&](int sl, int cbeg, int sbeg) {
+        if (ws < sbeg) return;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = 2 * wp + cc;
+            if (c < cbeg) continue;
+            double4_t acc;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[rg] = S.T[sl][c][rg][ws][lane];
+#pragma unroll
+            for (int kk = 0; kk < CH_NB / 4; ++kk) {
+                const double a = S.Li[16 * ws + li][4 * kk + lk];
+                const double b = S.Lj[16 * c + li][4 * kk + lk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) S.T[sl][c][rg][ws][lane] = acc[rg];
+        }
+    };
+    for (int kb = 0; kb < nblk && !S.dead; ++kb) {
+        const int J = kb >> 1, h = kb & 1;
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        const bool more = kb + 1 < nblk;                 // a block follows: the trailing part takes this one's update
+        double* Dg = Dgr + (size_t)kb * CH_NB * (CH_NB + 1);
+        for (int sl = 0; sl < nt; ++sl) {
+            const int I = S.tI[sl], Jt = S.tJ[sl];
+            if (Jt < J) continue;                        // finished
+            if (Jt == J) {
+                // ---- a tile of the panel column
+                const bool diag = I == J;
+                if (diag) {
+                    // the diagonal block (half h of the tile) out of the planes, factored, published
+                    __syncthreads();
+                    if (wp == h && (ws >> 1) == h) {
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const int i = 16 * (ws & 1) + lk + 4 * rg, j = 16 * cc + li;
+                                const double v = S.T[sl][2 * h + cc][rg][ws][lane];
+                                S.D[i][j] = (i < nb && j <= i) ? v : ((i == j) ? 1.0 : 0.0);
+                            }
+                    }
+                    __syncthreads();
+                    if (tid < 64) chol_diag_wave_panel_t<2>(S.D, nb, &fail[reg]);
+                    __syncthreads();
+                    for (int e = tid; e < CH_NB * CH_NB; e += DF_THREADS) {
+                        const int m = e >> 5, i = e & 31;                      // column m of row i
+                        const double cv = (i > m) ? -(S.D[i][m] * S.D[m][CH_NB]) : 0.0;
+                        reinterpret_cast<double*>(&S.Cf[m][i & 15])[i >> 4] = cv;
+                        st_sh(&Dg[2 * (m * 16 + (i & 15)) + (i >> 4)], cv);
+                        if (i < nb && m <= i) st_sh(&A[(size_t)(k0 + i) * lda + k0 + m], S.D[i][m]);
+                    }
+                    if (tid < CH_NB) {
+                        S.Rd[tid] = S.D[tid][CH_NB];
+                        st_sh(&Dg[CH_NB * CH_NB + tid], S.D[tid][CH_NB]);
+                    }
+                    cf_block = kb;
+                    set_flag(&Fdiag[kb]);
+                } else if (cf_block != kb) {
+                    if (!wait_flag(&Fdiag[kb])) break;
+                    constexpr int ND = (CH_NB * (CH_NB + 1) + DF_THREADS - 1) / DF_THREADS;
+                    double dv[ND];
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) dv[q] = ld_sh(&Dg[min(tid + DF_THREADS * q, CH_NB * (CH_NB + 1) - 1)]);
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) {
+                        const int e = tid + DF_THREADS * q;
+                        if (e < CH_NB * CH_NB) reinterpret_cast<double*>(&S.Cf[0][0])[e] = dv[q];
+                        else if (e < CH_NB * (CH_NB + 1)) S.Rd[e - CH_NB * CH_NB] = dv[q];
+                    }
+                    cf_block = kb;
+                }
+                __syncthreads();
+                // the rows of this tile below the diagonal block: X L^T = B, a half strip per wave
+                // (rows 16 ws + lk + 4 (2 wp + h2), h2 = 0, 1), in place, stored to A and kept as operands
+                const int rfirst = diag ? CH_NB * h + nb : 0;             // first tile row that is a panel row
+                const bool solve = 16 * ws + 15 >= rfirst && 64 * I + 16 * ws < nrows;
+                if (solve) {
+                    double xb[2][2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const double v = S.T[sl][2 * h + c][2 * wp + h2][ws][lane];
+                            xb[c][h2] = (16 * c + li < nb) ? v : 0.0;
+                        }
+                    double x0[2], x1[2];
+                    cf_chain(xb, S.Cf, S.Rd, li, x0, x1);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = 16 * ws + lk + 4 * (2 * wp + h2), gr = 64 * I + r;
+                        const bool row_ok = r >= rfirst && gr < nrows;
+                        if (row_ok) {
+                            if (li < nb) st_sh(&A[(size_t)gr * lda + k0 + li], x0[h2]);
+                            if (16 + li < nb) st_sh(&A[(size_t)gr * lda + k0 + 16 + li], x1[h2]);
+                        }
+                        const double y0 = row_ok ? x0[h2] : 0.0, y1 = row_ok ? x1[h2] : 0.0;
+                        S.Li[r][li] = -y0;
+                        S.Li[r][16 + li] = -y1;
+                        S.Lj[r][li] = y0;
+                        S.Lj[r][16 + li] = y1;
+                    }
+                } else {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = 16 * ws + lk + 4 * (2 * wp + h2);
+                        S.Li[r][li] = 0.0; S.Li[r][16 + li] = 0.0;
+                        S.Lj[r][li] = 0.0; S.Lj[r][16 + li] = 0.0;
+                    }
+                }
+                li_row = I; lj_row = I; l_block = kb;
+                set_flag(&Fpan[(size_t)kb * NT + I]);                    // (its __syncthreads also closes the operand writes)
+                // the second half of the tile takes this block's update: columns 32 .. 63 -= X L21^T, L21 = the
+                // rows 32 .. 63 of tile row J (the diagonal owner's solve of this step)
+                if (h == 0 && more) {
+                    if (!diag) {
+                        if (!wait_flag(&Fpan[(size_t)kb * NT + J])) break;
+                        load_panel(J, kb, false, S.Lj, 32, 64);
+                        lj_row = -1;                                     // (half a panel: not a cached operand)
+                        __syncthreads();
+                    }
+                    update_tile(sl, 2, diag ? 2 : 0);
+                    __syncthreads();
+                }
+                continue;
+            }
+            // ---- a trailing tile: acc -= L[rows of tile row I][block] L[rows of tile row Jt][block]^T
+            if (!more) continue;
+            const bool have_i = l_block == kb && li_row == I, have_j = l_block == kb && lj_row == Jt;
+            if (!have_i) { if (!wait_flag(&Fpan[(size_t)kb * NT + I])) break; }
+            if (!have_j && Jt != I) { if (!wait_flag(&Fpan[(size_t)kb * NT + Jt])) break; }
+            __syncthreads();                                             // the previous update's operands are consumed
+            if (!have_i) load_panel(I, kb, true, S.Li, 0, 64);
+            if (!have_j) load_panel(Jt, kb, false, S.Lj, 0, 64);
+            li_row = I; lj_row = Jt; l_block = kb;
+            __syncthreads();
+            update_tile(sl, 0, 0);
+        }
+    }
+    if (S.dead && tid == 0) atomicAdd(&tmo[reg], 1);
+}
+
 // One workgroup of 512 threads per region and nothing shared between workgroups: no region
 // barrier, nothing that has to be resident together, 9 CUs instead of 234.  Built for the case
 // where many subtractions are in flight on one GPU (zm_ctx_set_share >= 2) and as the form a
@@ -3112,8 +3427,20 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
                                    rounds == 1 ? 0 : 1, A0, rhs0, guard);
             hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc, guard);
+            // ZM_CHOL_FORM=df: the data-flow form (k_chol_df) where its tiles fit three per workgroup
+            const char* form_env0 = getenv("ZM_CHOL_FORM");
+            const bool want_df = form_env0 && !strcmp(form_env0, "df");
+            const int ndff = hp_df_nflags(P.nunk);
+            unsigned* dff = nullptr;
+            double* dfdg = nullptr;
+            if (want_df) {
+                ZM_CHECK(ndff <= 256 * zm_div_up(P.nunk, 256), "zm_subtract: %d hand-over words exceed k_hp_scale's row", ndff);
+                ZM_TRY(ctx->get("hp_dfflags", sizeof(unsigned) * (size_t)ndff * P.nreg, (void**)&dff));
+                ZM_TRY(ctx->get("hp_dfdg", sizeof(double) * (size_t)P.nreg * zm_div_up(P.nunk, CH_NB) * CH_NB * (CH_NB + 1),
+                                (void**)&dfdg));
+            }
             hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
-                               A0, rhs0, A, dsc, cbar, guard);
+                               A0, rhs0, A, dsc, cbar, guard, dff, ndff);
             {
                 // one cooperative launch: W workgroups per region, all resident
                 // One workgroup per CU: a second one on the same CU slows the serial chains of the
@@ -3178,9 +3505,44 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 // ZM_CHOL_STEP=64: the 64-column super-steps (k_chol_fused2: same bits; measured, not faster - see its
                 // header); default: the one-block steps (k_chol_fused)
                 const bool step32 = !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
+                bool df = want_df && W <= 128;
+                int* dftiles = nullptr;
+                if (df) {
+                    // the tile table of (unknowns, W): built once, kept on the device
+                    constexpr int TW = 1 + 2 * DF_MAXT;
+                    int* htl = nullptr;
+                    ZM_TRY(ctx->get_pinned("hp_dftiles_h", sizeof(int) * (3 + 128 * TW), (void**)&htl));
+                    ZM_TRY(ctx->get("hp_dftiles", sizeof(int) * 128 * TW, (void**)&dftiles));
+                    constexpr int DF_MAGIC = 0x64663031;               // (the buffer is not zeroed: a stamp says its header is ours)
+                    const bool known = htl[2] == DF_MAGIC && htl[1] == W && (htl[0] == nunk || htl[0] == -nunk - 1);
+                    if (!known) {
+                        ZM_HIP(hipStreamSynchronize(st));              // (an earlier copy out of this buffer may be in flight)
+                        bool fits = true;
+                        for (int wg = 0; wg < W; ++wg) {
+                            int ti[DF_MAXT] = {0, 0, 0}, tj[DF_MAXT] = {0, 0, 0}, ntl = 0;
+                            fits = hp_df_owner(nunk, W, wg, ti, tj, &ntl) && fits;
+                            htl[3 + wg * TW] = ntl;
+                            for (int k = 0; k < DF_MAXT; ++k) { htl[3 + wg * TW + 1 + 2 * k] = ti[k]; htl[3 + wg * TW + 2 + 2 * k] = tj[k]; }
+                        }
+                        htl[0] = fits ? nunk : -nunk - 1;              // (negative: this size does not fit, remembered too)
+                        htl[1] = W;
+                        htl[2] = DF_MAGIC;
+                        if (fits) ZM_HIP(hipMemcpyAsync(dftiles, htl + 3, sizeof(int) * W * TW, hipMemcpyHostToDevice, st));
+                    }
+                    df = htl[0] == nunk;
+                }
                 {
                     zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
-                    if (step32) {
+                    if (df) {
+                        static bool df_attr[64] = {};
+                        if (!df_attr[ctx->device & 63]) {
+                            ZM_HIP(hipFuncSetAttribute((const void*)k_chol_df, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)sizeof(df_lds)));
+                            df_attr[ctx->device & 63] = true;
+                        }
+                        hipLaunchKernelGGL(k_chol_df, dim3(P.nreg * W), dim3(DF_THREADS), sizeof(df_lds), st, nunk, lda, W, Aarg,
+                                           dfdg, farg, tmo, spin_limit, dff, dftiles, guard);
+                    } else if (step32) {
                         hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
                                            spin_limit, barg, parg, guard);
                     } else {
