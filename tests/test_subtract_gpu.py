@@ -255,9 +255,10 @@ def test_unsolved_region_warns_and_is_flagged(engine):
     dict(nx=448, ny=416, seed=14, nstars=400, kw=dict(r=3.0, rss=7.0, nsx=8, nsy=8, ko=5, bgo=0)),               # 1010
 ])
 def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkeypatch, case):
-    """The kernel fit's factorisation has two forms: k_chol_fused (many workgroups per region, region
-    barriers: short) and k_chol_tp (one workgroup per region: cheap in CU-time; what a context uses when
-    zm_ctx_set_share >= 2 and what a fit is repeated on after a barrier time-out).  Same arithmetic,
+    """The kernel fit's factorisation has several forms: k_chol_df (the default where its tiles fit: LDS-resident
+    tiles, hand-over flags, the Jacobi scaling folded into its tile load), k_chol_fused (many workgroups per
+    region, region barriers; ZM_CHOL_FORM=lat) and k_chol_tp (one workgroup per region: cheap in CU-time; what a
+    context uses when zm_ctx_set_share >= 2 and what a fit is repeated on after a time-out).  Same arithmetic,
     operation for operation: every product of the subtraction is bit-identical."""
     data = scene(nx=case['nx'], ny=case['ny'], seed=case['seed'], nstars=case['nstars'], gradient=0.3)
     kw = dict(case['kw'], **COMMON)
@@ -275,7 +276,8 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
     monkeypatch.setenv('ZM_CHOL_FORM', 'df')
     d3, n3, i3 = engine.subtract(*data, **kw)
     monkeypatch.delenv('ZM_CHOL_FORM')
-    for d, n, i in ((d1, n1, i1), (d2, n2, i2), (d3, n3, i3)):
+    d4, n4, i4 = engine.subtract(*data, **kw)            # the default choice
+    for d, n, i in ((d1, n1, i1), (d2, n2, i2), (d3, n3, i3), (d4, n4, i4)):
         assert i0['status'] == 0 and i['status'] == 0 and i0['retries'] == 0 and i['retries'] == 0
         assert np.array_equal(d0, d) and np.array_equal(n0, n)
         for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):

@@ -694,9 +694,12 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
                                                   const int* __restrict__ active,
                                                   const int* __restrict__ chg, int sign,
                                                   double* __restrict__ A,
-                                                  double* __restrict__ rhs, const int* __restrict__ guard) {
+                                                  double* __restrict__ rhs, const int* __restrict__ guard,
+                                                  unsigned* __restrict__ zero = nullptr, int nzero = 0) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     const int reg = blockIdx.z;
+    if (zero && blockIdx.x == 0 && blockIdx.y == 0)      // (the hand-over words of this round's k_chol_df)
+        for (int k = threadIdx.x; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
     const int c1 = blockIdx.y * 16 + (threadIdx.x >> 4), c2 = blockIdx.x * 16 + (threadIdx.x & 15);
     if (blockIdx.x > blockIdx.y) return;
     if (c1 >= P.nunk || c2 >= P.nunk) return;
@@ -760,9 +763,12 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
                                                       const int* __restrict__ active,
                                                       const int* __restrict__ chg, int sign,
                                                       double* __restrict__ A,
-                                                      double* __restrict__ rhs, const int* __restrict__ guard) {
+                                                      double* __restrict__ rhs, const int* __restrict__ guard,
+                                                      unsigned* __restrict__ zero = nullptr, int nzero = 0) {
     if (guard && *guard == 0) return;
     const int reg = blockIdx.z, n1 = blockIdx.y, n2 = blockIdx.x;
+    if (zero && n1 == 0 && n2 == 0)                      // (the hand-over words of this round's k_chol_df)
+        for (int k = threadIdx.x; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
     if (n2 > n1) return;
     const int p1 = threadIdx.x >> 4, p2 = threadIdx.x & 15;
     const bool k1 = n1 >= 1 && n1 < P.nc, k2 = n2 >= 1 && n2 < P.nc;   // kernel terms carry spatial factors
@@ -1885,6 +1891,7 @@ struct df_lds {
     double D[CH_NB][CH_NB + 1];
     double2 Cf[CH_NB][16];
     double Rd[CH_NB];
+    double dd[DF_MAXT][2][64];           // Jacobi scale factors of a tile's rows / columns (the scaling folded into the tile load)
     int tI[DF_MAXT], tJ[DF_MAXT], nt;
     int dead;
 };
@@ -1940,10 +1947,25 @@ inline bool hp_df_owner(int n, int W, int me, int* tI, int* tJ, int* nt) {
 
 // tiles: [W][1 + 2 DF_MAXT] ints per workgroup of a region - the number of its tiles, then (I, J) in processing
 // order (hp_df_owner on the host, the same table for every region)
+//
+// The Jacobi scaling rides in the tile load (A0all != nullptr): a workgroup reads its tiles from the UNSCALED normal
+// matrix (pitch n; row n = the right-hand side), forms d = sqrt(diag) for the rows and columns of its tiles and
+// divides on the way into LDS - k_hp_diag's and k_hp_scale's operations on every entry, the same bits - and the
+// owner of a diagonal tile writes d for the back substitution.  Every entry of the factor's lower triangle and of
+// the right-hand-side row is written to A by the solves, so A needs no initialisation: two launches and one pass
+// over both matrices per rejection round are gone.
+// PROF: wall-clock sums per phase of every workgroup (ZM_CHOL_PROF=1): 0 tile load, 1 waiting for a flag,
+// 2 coefficient load, 3 diagonal block out + factor, 4 publish, 5 panel solve + its flag, 6 panel loads, 7 updates.
+template <bool PROF>
 __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
                                                         int* tmo, int spin_limit, unsigned* flags_all,
-                                                        const int* __restrict__ tiles, const int* __restrict__ guard) {
+                                                        const int* __restrict__ tiles, const int* __restrict__ guard,
+                                                        const double* __restrict__ A0all, const double* __restrict__ rhs0all,
+                                                        double* __restrict__ dscall, long long* __restrict__ prof) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
+#define DF_TICK(k) do { if (PROF) { const long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
+    if (PROF) tc = wall_clock64();
     extern __shared__ char df_raw[];
     df_lds& S = *reinterpret_cast<df_lds*>(df_raw);
     const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
@@ -1966,17 +1988,60 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
     __syncthreads();
     const int nt = S.nt;
     // ---- the resident tiles: this wave's planes are (c = 2 wp, 2 wp + 1; rg = 0 .. 3; strip ws)
-    for (int sl = 0; sl < nt; ++sl) {
-        const int I = S.tI[sl], J = S.tJ[sl];
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c = 2 * wp + cc;
-                const int i = 64 * I + 16 * ws + lk + 4 * rg, j = 64 * J + 16 * c + li;
-                S.T[sl][c][rg][ws][lane] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+    if (A0all) {
+        const double* A0 = A0all + (size_t)reg * (size_t)(n + 1) * n;
+        const double* r0 = rhs0all + (size_t)reg * n;
+        double* dsc = dscall + (size_t)reg * n;
+        // d = sqrt(diag) (1 where the diagonal is not positive: k_hp_diag) for the rows and columns of the tiles;
+        // the right-hand-side row (index n) is not scaled by a row factor
+        for (int e = tid; e < nt * 128; e += DF_THREADS) {
+            const int sl = e >> 7, col = (e >> 6) & 1, k = e & 63;
+            const int idx = 64 * (col ? S.tJ[sl] : S.tI[sl]) + k;
+            double d = 1.0;
+            if (idx < n) {
+                const double v = A0[(size_t)idx * n + idx];
+                d = v > 0.0 ? sqrt(v) : 1.0;
+                if (col && S.tI[sl] == S.tJ[sl]) dsc[idx] = d;
             }
+            S.dd[sl][col][k] = d;
+        }
+        __syncthreads();
+        for (int sl = 0; sl < nt; ++sl) {
+            const int I = S.tI[sl], J = S.tJ[sl];
+            double a[2][4];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = 2 * wp + cc;
+                    const int i = min(64 * I + 16 * ws + lk + 4 * rg, nrows - 1), j = min(64 * J + 16 * c + li, n - 1);
+                    a[cc][rg] = (i < n) ? A0[(size_t)i * n + j] : r0[j];
+                }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = 2 * wp + cc;
+                    const int i = min(64 * I + 16 * ws + lk + 4 * rg, nrows - 1), j = min(64 * J + 16 * c + li, n - 1);
+                    double v = a[cc][rg] / (S.dd[sl][0][i - 64 * I] * S.dd[sl][1][j - 64 * J]);
+                    if (i == j) v += HP_RIDGE;                           // (k_hp_scale: keeps a rank-deficient basis solvable)
+                    S.T[sl][c][rg][ws][lane] = v;
+                }
+        }
+    } else {
+        for (int sl = 0; sl < nt; ++sl) {
+            const int I = S.tI[sl], J = S.tJ[sl];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = 2 * wp + cc;
+                    const int i = 64 * I + 16 * ws + lk + 4 * rg, j = 64 * J + 16 * c + li;
+                    S.T[sl][c][rg][ws][lane] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+                }
+        }
     }
+    DF_TICK(0);
     // a bounded wait for a word to become non-zero (thread 0 polls; everybody learns the outcome)
     auto wait_flag = [&](const unsigned* f) -> bool {
         __syncthreads();
@@ -2051,6 +2116,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                 const bool diag = I == J;
                 if (diag) {
                     // the diagonal block (half h of the tile) out of the planes, factored, published
+                    DF_TICK(7);
                     __syncthreads();
                     if (wp == h && (ws >> 1) == h) {
 #pragma unroll
@@ -2065,6 +2131,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     __syncthreads();
                     if (tid < 64) chol_diag_wave_panel_t<2>(S.D, nb, &fail[reg]);
                     __syncthreads();
+                    DF_TICK(3);
                     for (int e = tid; e < CH_NB * CH_NB; e += DF_THREADS) {
                         const int m = e >> 5, i = e & 31;                      // column m of row i
                         const double cv = (i > m) ? -(S.D[i][m] * S.D[m][CH_NB]) : 0.0;
@@ -2078,8 +2145,11 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     }
                     cf_block = kb;
                     set_flag(&Fdiag[kb]);
+                    DF_TICK(4);
                 } else if (cf_block != kb) {
+                    DF_TICK(7);
                     if (!wait_flag(&Fdiag[kb])) break;
+                    DF_TICK(1);
                     constexpr int ND = (CH_NB * (CH_NB + 1) + DF_THREADS - 1) / DF_THREADS;
                     double dv[ND];
 #pragma unroll
@@ -2091,6 +2161,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                         else if (e < CH_NB * (CH_NB + 1)) S.Rd[e - CH_NB * CH_NB] = dv[q];
                     }
                     cf_block = kb;
+                    if (PROF) { __syncthreads(); DF_TICK(2); }
                 }
                 __syncthreads();
                 // the rows of this tile below the diagonal block: X L^T = B, a half strip per wave
@@ -2132,34 +2203,44 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                 }
                 li_row = I; lj_row = I; l_block = kb;
                 set_flag(&Fpan[(size_t)kb * NT + I]);                    // (its __syncthreads also closes the operand writes)
+                DF_TICK(5);
                 // the second half of the tile takes this block's update: columns 32 .. 63 -= X L21^T, L21 = the
                 // rows 32 .. 63 of tile row J (the diagonal owner's solve of this step)
                 if (h == 0 && more) {
                     if (!diag) {
                         if (!wait_flag(&Fpan[(size_t)kb * NT + J])) break;
+                        DF_TICK(1);
                         load_panel(J, kb, false, S.Lj, 32, 64);
                         lj_row = -1;                                     // (half a panel: not a cached operand)
                         __syncthreads();
+                        DF_TICK(6);
                     }
                     update_tile(sl, 2, diag ? 2 : 0);
                     __syncthreads();
+                    DF_TICK(7);
                 }
                 continue;
             }
             // ---- a trailing tile: acc -= L[rows of tile row I][block] L[rows of tile row Jt][block]^T
             if (!more) continue;
             const bool have_i = l_block == kb && li_row == I, have_j = l_block == kb && lj_row == Jt;
+            DF_TICK(7);
             if (!have_i) { if (!wait_flag(&Fpan[(size_t)kb * NT + I])) break; }
             if (!have_j && Jt != I) { if (!wait_flag(&Fpan[(size_t)kb * NT + Jt])) break; }
             __syncthreads();                                             // the previous update's operands are consumed
+            DF_TICK(1);
             if (!have_i) load_panel(I, kb, true, S.Li, 0, 64);
             if (!have_j) load_panel(Jt, kb, false, S.Lj, 0, 64);
             li_row = I; lj_row = Jt; l_block = kb;
             __syncthreads();
+            DF_TICK(6);
             update_tile(sl, 0, 0);
         }
     }
     if (S.dead && tid == 0) atomicAdd(&tmo[reg], 1);
+    if (PROF && prof && tid == 0)
+        for (int k = 0; k < 8; ++k) prof[(size_t)blockIdx.x * 8 + k] = pt[k];
+#undef DF_TICK
 }
 
 // One workgroup of 512 threads per region and nothing shared between workgroups: no region
@@ -3420,48 +3501,79 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         {
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            if (P.nkp <= 16)
-                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg,
-                                   rounds == 1 ? 0 : 1, A0, rhs0, guard);
-            else
-                hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
-                                   rounds == 1 ? 0 : 1, A0, rhs0, guard);
-            hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc, guard);
-            // ZM_CHOL_FORM=df: the data-flow form (k_chol_df) where its tiles fit three per workgroup
-            const char* form_env0 = getenv("ZM_CHOL_FORM");
-            const bool want_df = form_env0 && !strcmp(form_env0, "df");
+            // Which form of the factorisation: the throughput form (one workgroup per region, nothing shared) when
+            // `share` contexts subtract at the same time (zm_ctx_set_share), when another context of this process is
+            // fitting, and for the repeat after a time-out; otherwise a latency form - the data-flow form (k_chol_df)
+            // where its tiles fit three per workgroup, else the barrier form (k_chol_fused).  Same bits either way.
+            // ZM_CHOL_FORM = tp / lat (k_chol_fused) / df overrides (tests, A / B timing).
+            const char* form_env = getenv("ZM_CHOL_FORM");
+            bool tp = safe || ctx->share >= 2 || fitting.shared();
+            if (form_env && !strcmp(form_env, "tp")) tp = true;
+            if (form_env && (!strcmp(form_env, "lat") || !strcmp(form_env, "df")) && !safe) tp = false;
+            if (!ctx->hp_wg_cap) {
+                // One workgroup per CU: a second one on the same CU slows the serial chains of the
+                // look-ahead workgroup (measured: 806 us at 26 workgroups per region, 917 at 32).
+                // The occupancy API only bounds it (it can be one block per CU high; keep a margin).
+                int occ = 0, ncu = 0;
+                ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
+                ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+                ctx->hp_wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
+                if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
+            }
+            // this context's share of the resident workgroups: each of `share` contexts keeps its launch fully resident
+            const int wg_cap = ctx->hp_wg_cap / std::max(ctx->share, 1);
+            const int W = std::max(2, std::min(68, wg_cap / P.nreg));
+            const int nunk = P.nunk;
+            static const bool want_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
+            const bool want_df = !tp && !(form_env && !strcmp(form_env, "lat")) && 2 * P.nreg <= wg_cap && W <= 128 &&
+                                 !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
             const int ndff = hp_df_nflags(P.nunk);
             unsigned* dff = nullptr;
             double* dfdg = nullptr;
-            if (want_df) {
-                ZM_CHECK(ndff <= 256 * zm_div_up(P.nunk, 256), "zm_subtract: %d hand-over words exceed k_hp_scale's row", ndff);
+            int* dftiles = nullptr;
+            bool df = want_df;
+            if (df) {
+                // the tile table of (unknowns, W): built once, kept on the device
+                constexpr int TW = 1 + 2 * DF_MAXT;
+                int* htl = nullptr;
+                ZM_TRY(ctx->get_pinned("hp_dftiles_h", sizeof(int) * (3 + 128 * TW), (void**)&htl));
+                ZM_TRY(ctx->get("hp_dftiles", sizeof(int) * 128 * TW, (void**)&dftiles));
+                constexpr int DF_MAGIC = 0x64663031;               // (the buffer is not zeroed: a stamp says its header is ours)
+                const bool known = htl[2] == DF_MAGIC && htl[1] == W && (htl[0] == nunk || htl[0] == -nunk - 1);
+                if (!known) {
+                    ZM_HIP(hipStreamSynchronize(st));              // (an earlier copy out of this buffer may be in flight)
+                    bool fits = true;
+                    for (int wg = 0; wg < W; ++wg) {
+                        int ti[DF_MAXT] = {0, 0, 0}, tj[DF_MAXT] = {0, 0, 0}, ntl = 0;
+                        fits = hp_df_owner(nunk, W, wg, ti, tj, &ntl) && fits;
+                        htl[3 + wg * TW] = ntl;
+                        for (int k = 0; k < DF_MAXT; ++k) { htl[3 + wg * TW + 1 + 2 * k] = ti[k]; htl[3 + wg * TW + 2 + 2 * k] = tj[k]; }
+                    }
+                    htl[0] = fits ? nunk : -nunk - 1;              // (negative: this size does not fit, remembered too)
+                    htl[1] = W;
+                    htl[2] = DF_MAGIC;
+                    if (fits) ZM_HIP(hipMemcpyAsync(dftiles, htl + 3, sizeof(int) * W * TW, hipMemcpyHostToDevice, st));
+                }
+                df = htl[0] == nunk;
+            }
+            if (df) {
                 ZM_TRY(ctx->get("hp_dfflags", sizeof(unsigned) * (size_t)ndff * P.nreg, (void**)&dff));
                 ZM_TRY(ctx->get("hp_dfdg", sizeof(double) * (size_t)P.nreg * zm_div_up(P.nunk, CH_NB) * CH_NB * (CH_NB + 1),
                                 (void**)&dfdg));
             }
-            hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
-                               A0, rhs0, A, dsc, cbar, guard, dff, ndff);
+            if (P.nkp <= 16)
+                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                                   rounds == 1 ? 0 : 1, A0, rhs0, guard, dff, ndff);
+            else
+                hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                                   rounds == 1 ? 0 : 1, A0, rhs0, guard, dff, ndff);
+            if (!df) {
+                // (the data-flow form scales on its way into LDS and writes the scale factors itself)
+                hipLaunchKernelGGL(k_hp_diag, dim3(zm_div_up(P.nunk, 256), P.nreg), b256, 0, st, P.nunk, A0, dsc, guard);
+                hipLaunchKernelGGL(k_hp_scale, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg), b256, 0, st, P.nunk, lda,
+                                   A0, rhs0, A, dsc, cbar, guard, nullptr, 0);
+            }
             {
-                // one cooperative launch: W workgroups per region, all resident
-                // One workgroup per CU: a second one on the same CU slows the serial chains of the
-                // look-ahead workgroup (measured: 806 us at 26 workgroups per region, 917 at 32).
-                // The occupancy API only bounds it (it can be one block per CU high; keep a margin).
-                if (!ctx->hp_wg_cap) {
-                    int occ = 0, ncu = 0;
-                    ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
-                    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-                    ctx->hp_wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
-                    if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
-                }
-                // Which form: the latency form (W workgroups per region, all resident, one per CU) for a
-                // context that has the GPU to itself; the throughput form (one workgroup per region,
-                // nothing shared) when `share` contexts subtract at the same time (zm_ctx_set_share)
-                // and for the repeat after a barrier time-out.  Same bits either way.  ZM_CHOL_FORM=tp /
-                // lat overrides (tests, A / B timing).
-                const char* form_env = getenv("ZM_CHOL_FORM");
-                bool tp = safe || ctx->share >= 2 || fitting.shared();
-                if (form_env && !strcmp(form_env, "tp")) tp = true;
-                if (form_env && !strcmp(form_env, "lat") && !safe) tp = false;
                 if (tp) {
                     static const bool tp_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
                     long long* parg = nullptr;
@@ -3484,67 +3596,34 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                         fprintf(stderr, "\n");
                     }
                 } else {
-                // this context's share of the resident workgroups: each of `share` contexts keeps its
-                // launch fully resident
-                const int wg_cap = ctx->hp_wg_cap / std::max(ctx->share, 1);
+                // A latency form: W workgroups per region, all resident, one per CU.  A plain launch sized to be
+                // fully resident (hipLaunchCooperativeKernel does not order against the following launches of the
+                // stream on its first use).
                 ZM_CHECK(2 * P.nreg <= wg_cap,
                          "zm_subtract: %d regions exceed the %d resident workgroups of this context's share (1 / %d)",
                          P.nreg, wg_cap, ctx->share);
-                int W = std::max(2, std::min(68, wg_cap / P.nreg));
-                int nunk = P.nunk;
-                double* Aarg = A;
-                int* farg = fail;
-                unsigned* barg = cbar;
-                double* dgarg = cdg;
                 // ZM_CHOL_PROF=1: per-phase clocks of every workgroup, printed after the launch
-                static const bool want_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
+                const int nprof = df ? 8 : 6;
                 long long* parg = nullptr;
-                if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 6 * P.nreg * W, (void**)&parg));
-                // A plain launch sized to be fully resident (hipLaunchCooperativeKernel does not
-                // order against the following launches of the stream on its first use)
+                if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 8 * P.nreg * W, (void**)&parg));
                 // ZM_CHOL_STEP=64: the 64-column super-steps (k_chol_fused2: same bits; measured, not faster - see its
-                // header); default: the one-block steps (k_chol_fused)
+                // header)
                 const bool step32 = !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
-                bool df = want_df && W <= 128;
-                int* dftiles = nullptr;
-                if (df) {
-                    // the tile table of (unknowns, W): built once, kept on the device
-                    constexpr int TW = 1 + 2 * DF_MAXT;
-                    int* htl = nullptr;
-                    ZM_TRY(ctx->get_pinned("hp_dftiles_h", sizeof(int) * (3 + 128 * TW), (void**)&htl));
-                    ZM_TRY(ctx->get("hp_dftiles", sizeof(int) * 128 * TW, (void**)&dftiles));
-                    constexpr int DF_MAGIC = 0x64663031;               // (the buffer is not zeroed: a stamp says its header is ours)
-                    const bool known = htl[2] == DF_MAGIC && htl[1] == W && (htl[0] == nunk || htl[0] == -nunk - 1);
-                    if (!known) {
-                        ZM_HIP(hipStreamSynchronize(st));              // (an earlier copy out of this buffer may be in flight)
-                        bool fits = true;
-                        for (int wg = 0; wg < W; ++wg) {
-                            int ti[DF_MAXT] = {0, 0, 0}, tj[DF_MAXT] = {0, 0, 0}, ntl = 0;
-                            fits = hp_df_owner(nunk, W, wg, ti, tj, &ntl) && fits;
-                            htl[3 + wg * TW] = ntl;
-                            for (int k = 0; k < DF_MAXT; ++k) { htl[3 + wg * TW + 1 + 2 * k] = ti[k]; htl[3 + wg * TW + 2 + 2 * k] = tj[k]; }
-                        }
-                        htl[0] = fits ? nunk : -nunk - 1;              // (negative: this size does not fit, remembered too)
-                        htl[1] = W;
-                        htl[2] = DF_MAGIC;
-                        if (fits) ZM_HIP(hipMemcpyAsync(dftiles, htl + 3, sizeof(int) * W * TW, hipMemcpyHostToDevice, st));
-                    }
-                    df = htl[0] == nunk;
-                }
                 {
                     zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
                     if (df) {
-                        static bool df_attr[64] = {};
-                        if (!df_attr[ctx->device & 63]) {
-                            ZM_HIP(hipFuncSetAttribute((const void*)k_chol_df, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        auto kf = want_prof ? k_chol_df<true> : k_chol_df<false>;
+                        static bool df_attr[2][64] = {};
+                        if (!df_attr[want_prof][ctx->device & 63]) {
+                            ZM_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)sizeof(df_lds)));
-                            df_attr[ctx->device & 63] = true;
+                            df_attr[want_prof][ctx->device & 63] = true;
                         }
-                        hipLaunchKernelGGL(k_chol_df, dim3(P.nreg * W), dim3(DF_THREADS), sizeof(df_lds), st, nunk, lda, W, Aarg,
-                                           dfdg, farg, tmo, spin_limit, dff, dftiles, guard);
+                        hipLaunchKernelGGL(kf, dim3(P.nreg * W), dim3(DF_THREADS), sizeof(df_lds), st, nunk, lda, W, A,
+                                           dfdg, fail, tmo, spin_limit, dff, dftiles, guard, A0, rhs0, dsc, parg);
                     } else if (step32) {
-                        hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, Aarg, dgarg, farg, tmo,
-                                           spin_limit, barg, parg, guard);
+                        hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, A, cdg, fail, tmo,
+                                           spin_limit, cbar, parg, guard);
                     } else {
                         auto kf = want_prof ? k_chol_fused2<true> : k_chol_fused2<false>;
                         static bool attr_set[2][64] = {};
@@ -3553,20 +3632,25 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                                                        (int)sizeof(cf2_lds)));
                             attr_set[want_prof][ctx->device & 63] = true;
                         }
-                        hipLaunchKernelGGL(kf, dim3(P.nreg * W), b256, sizeof(cf2_lds), st, nunk, lda, W, Aarg, dgarg,
-                                           farg, tmo, spin_limit, barg, parg, guard);
+                        hipLaunchKernelGGL(kf, dim3(P.nreg * W), b256, sizeof(cf2_lds), st, nunk, lda, W, A, cdg,
+                                           fail, tmo, spin_limit, cbar, parg, guard);
                     }
                 }
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
-                    std::vector<long long> hp((size_t)6 * P.nreg * W);
+                    std::vector<long long> hp((size_t)nprof * P.nreg * W);
                     ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
                     ZM_HIP(hipStreamSynchronize(st));
-                    static const char* nm[6] = {"load", "tilewait", "panel", "barrier1", "update", "barrier2"};
+                    static const char* nm6[6] = {"load", "tilewait", "panel", "barrier1", "update", "barrier2"};
+                    static const char* nm8[8] = {"load", "flagwait", "coeff", "factor", "publish", "solve", "panels", "update"};
                     // (k_chol_fused2, workgroup 0: "barrier1" = first look-ahead block, "update" = the second)
-                    for (int wg : {0, 1, W - 1, W, (P.nreg - 1) * W}) {
+                    const int NCd = (nunk + 63) / 64;
+                    std::vector<int> show = {0, 1, W - 1, W, (P.nreg - 1) * W};
+                    if (df) show = {0, 1, NCd / 2, NCd - 1, std::min(NCd, W - 1), W - 1, (P.nreg - 1) * W + 1};
+                    for (int wg : show) {
                         fprintf(stderr, "chol wg %3d:", wg);
-                        for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f us", nm[k], hp[(size_t)wg * 6 + k] * 0.01);
+                        for (int k = 0; k < nprof; ++k)
+                            fprintf(stderr, " %s %.1f us", df ? nm8[k] : nm6[k], hp[(size_t)wg * nprof + k] * 0.01);
                         fprintf(stderr, "\n");
                     }
                 }
