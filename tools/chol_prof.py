@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-os.environ['ZM_CHOL_PROF'] = '1'
+os.environ.setdefault('ZM_CHOL_PROF', '1')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 z = importlib.import_module('zuds-pipeline_amd')
 s = importlib.import_module('zuds-pipeline_amd.synth')

@@ -846,10 +846,13 @@ __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const 
     const double* dd = d + (size_t)reg * n;
     const size_t base0 = (size_t)reg * (size_t)(n + 1) * n;
     const size_t base = (size_t)reg * (size_t)(n + 1) * lda;     // rows of A are padded to whole 128-B lines
-    double v = A0[base0 + (size_t)c1 * n + c2] / (dd[c1] * dd[c2]);
-    if (c1 == c2) v += HP_RIDGE;   // keeps a rank-deficient basis solvable (oracle: RIDGE)
+    // (round 4: by the reciprocals of d - k_chol_df scales its tiles on their way into LDS with two multiplications
+    // per entry where an fp64 division costs ~40 instructions; every form multiplies the same way: same bits)
+    const double r1 = 1.0 / dd[c1], r2 = 1.0 / dd[c2];
+    double v = __dmul_rn(A0[base0 + (size_t)c1 * n + c2], __dmul_rn(r1, r2));     // (no contraction: k_chol_df does the same)
+    if (c1 == c2) v = __dadd_rn(v, HP_RIDGE);   // keeps a rank-deficient basis solvable (oracle: RIDGE)
     A[base + (size_t)c1 * lda + c2] = v;
-    if (c2 == 0) A[base + (size_t)n * lda + c1] = rhs0[(size_t)reg * n + c1] / dd[c1];   // rhs row
+    if (c2 == 0) A[base + (size_t)n * lda + c1] = __dmul_rn(rhs0[(size_t)reg * n + c1], r1);   // rhs row
 }
 
 // ---- blocked Cholesky, lower, in place ------------------------------------------------
@@ -1956,7 +1959,7 @@ inline bool hp_df_owner(int n, int W, int me, int* tI, int* tJ, int* nt) {
 // over both matrices per rejection round are gone.
 // PROF: wall-clock sums per phase of every workgroup (ZM_CHOL_PROF=1): 0 tile load, 1 waiting for a flag,
 // 2 coefficient load, 3 diagonal block out + factor, 4 publish, 5 panel solve + its flag, 6 panel loads, 7 updates.
-template <bool PROF>
+template <int PROF>
 __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
                                                         int* tmo, int spin_limit, unsigned* flags_all,
                                                         const int* __restrict__ tiles, const int* __restrict__ guard,
@@ -1964,8 +1967,12 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                                                         double* __restrict__ dscall, long long* __restrict__ prof) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
-#define DF_TICK(k) do { if (PROF) { const long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
-    if (PROF) tc = wall_clock64();
+#define DF_TICK(k) do { if (PROF == 1) { const long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
+    // (PROF: wall-clock stamps of the critical chain per block behind the per-workgroup sums: [0] diagonal block
+    // taken up, [1] factored, [2] published by its owner; [3] coefficients in LDS, [4] rows solved, [5] second half /
+    // own diagonal tile updated at the owner of the tile below it)
+#define DF_STAMP(kb_, e_) do { if (PROF == 2 && prof && threadIdx.x == 0) prof[(size_t)gridDim.x * 8 + ((size_t)(blockIdx.x / W) * ((n + CH_NB - 1) / CH_NB) + (kb_)) * 8 + (e_)] = wall_clock64(); } while (0)
+    if (PROF == 1) tc = wall_clock64();
     extern __shared__ char df_raw[];
     df_lds& S = *reinterpret_cast<df_lds*>(df_raw);
     const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
@@ -1987,10 +1994,11 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
     }
     __syncthreads();
     const int nt = S.nt;
+    if (nt == 0) return;                                 // (more workgroups than tiles: small systems)
     // ---- the resident tiles: this wave's planes are (c = 2 wp, 2 wp + 1; rg = 0 .. 3; strip ws)
+    const double* A0 = A0all ? A0all + (size_t)reg * (size_t)(n + 1) * n : nullptr;
+    const double* r0 = A0all ? rhs0all + (size_t)reg * n : nullptr;
     if (A0all) {
-        const double* A0 = A0all + (size_t)reg * (size_t)(n + 1) * n;
-        const double* r0 = rhs0all + (size_t)reg * n;
         double* dsc = dscall + (size_t)reg * n;
         // d = sqrt(diag) (1 where the diagonal is not positive: k_hp_diag) for the rows and columns of the tiles;
         // the right-hand-side row (index n) is not scaled by a row factor
@@ -2003,47 +2011,67 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                 d = v > 0.0 ? sqrt(v) : 1.0;
                 if (col && S.tI[sl] == S.tJ[sl]) dsc[idx] = d;
             }
-            S.dd[sl][col][k] = d;
+            S.dd[sl][col][k] = 1.0 / d;                  // (k_hp_scale multiplies by the reciprocals)
         }
         __syncthreads();
-        for (int sl = 0; sl < nt; ++sl) {
-            const int I = S.tI[sl], J = S.tJ[sl];
-            double a[2][4];
+    }
+    // every load of the (up to three) tiles goes out before the first value is used
+    {
+        double a[DF_MAXT][2][4];
+#pragma unroll
+        for (int sl = 0; sl < DF_MAXT; ++sl) {
+            const int I = S.tI[min(sl, nt - 1)], J = S.tJ[min(sl, nt - 1)];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int c = 2 * wp + cc;
                     const int i = min(64 * I + 16 * ws + lk + 4 * rg, nrows - 1), j = min(64 * J + 16 * c + li, n - 1);
-                    a[cc][rg] = (i < n) ? A0[(size_t)i * n + j] : r0[j];
-                }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int c = 2 * wp + cc;
-                    const int i = min(64 * I + 16 * ws + lk + 4 * rg, nrows - 1), j = min(64 * J + 16 * c + li, n - 1);
-                    double v = a[cc][rg] / (S.dd[sl][0][i - 64 * I] * S.dd[sl][1][j - 64 * J]);
-                    if (i == j) v += HP_RIDGE;                           // (k_hp_scale: keeps a rank-deficient basis solvable)
-                    S.T[sl][c][rg][ws][lane] = v;
+                    if (A0) a[sl][cc][rg] = (i < n) ? A0[(size_t)i * n + j] : r0[j];
+                    else a[sl][cc][rg] = ld_sh(&A[(size_t)i * lda + j]);
                 }
         }
-    } else {
-        for (int sl = 0; sl < nt; ++sl) {
+#pragma unroll
+        for (int sl = 0; sl < DF_MAXT; ++sl) {
+            if (sl >= nt) break;
             const int I = S.tI[sl], J = S.tJ[sl];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int c = 2 * wp + cc;
-                    const int i = 64 * I + 16 * ws + lk + 4 * rg, j = 64 * J + 16 * c + li;
-                    S.T[sl][c][rg][ws][lane] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
+                    const int i = min(64 * I + 16 * ws + lk + 4 * rg, nrows - 1), j = min(64 * J + 16 * c + li, n - 1);
+                    double v = a[sl][cc][rg];
+                    if (A0) {
+                        v = __dmul_rn(v, __dmul_rn(S.dd[sl][0][i - 64 * I], S.dd[sl][1][j - 64 * J]));
+                        if (i == j) v = __dadd_rn(v, HP_RIDGE);          // (k_hp_scale: keeps a rank-deficient basis solvable)
+                    }
+                    S.T[sl][c][rg][ws][lane] = v;
                 }
         }
     }
     DF_TICK(0);
+    // this workgroup's stores to A / Dg are complete, then the word is set - together with a panel flag that was
+    // left pending: after a panel solve the workgroup carries on with what only needs the solved rows in LDS (its
+    // own updates: the critical path) and lets the stores to A land meanwhile; the flag goes out at the next point
+    // where the workgroup would wait or publish anyway (producers still never wait for consumers)
+    unsigned *pend0 = nullptr, *pend1 = nullptr, *pend2 = nullptr;
+    int npend = 0;
+    auto set_flag = [&](unsigned* f) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (npend > 0) __hip_atomic_store(pend0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (npend > 1) __hip_atomic_store(pend1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (npend > 2) __hip_atomic_store(pend2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        npend = 0;
+    };
+    auto flush = [&]() { if (npend) set_flag(nullptr); };
     // a bounded wait for a word to become non-zero (thread 0 polls; everybody learns the outcome)
     auto wait_flag = [&](const unsigned* f) -> bool {
+        if (npend) set_flag(nullptr);
         __syncthreads();
         if (tid == 0) {
             int spins = 0, d = 0;
@@ -2059,12 +2087,6 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
         }
         __syncthreads();
         return S.dead == 0;
-    };
-    // this workgroup's stores to A / Dg are complete, then the word is set
-    auto set_flag = [&](unsigned* f) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     int cf_block = -1;                                   // block whose chain coefficients are in S.Cf / S.Rd
     int li_row = -1, lj_row = -1, l_block = -1;          // tile rows whose panels (block l_block) are in S.Li / S.Lj
@@ -2117,6 +2139,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                 if (diag) {
                     // the diagonal block (half h of the tile) out of the planes, factored, published
                     DF_TICK(7);
+                    DF_STAMP(kb, 0);
                     __syncthreads();
                     if (wp == h && (ws >> 1) == h) {
 #pragma unroll
@@ -2132,6 +2155,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     if (tid < 64) chol_diag_wave_panel_t<2>(S.D, nb, &fail[reg]);
                     __syncthreads();
                     DF_TICK(3);
+                    DF_STAMP(kb, 1);
                     for (int e = tid; e < CH_NB * CH_NB; e += DF_THREADS) {
                         const int m = e >> 5, i = e & 31;                      // column m of row i
                         const double cv = (i > m) ? -(S.D[i][m] * S.D[m][CH_NB]) : 0.0;
@@ -2146,6 +2170,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     cf_block = kb;
                     set_flag(&Fdiag[kb]);
                     DF_TICK(4);
+                    DF_STAMP(kb, 2);
                 } else if (cf_block != kb) {
                     DF_TICK(7);
                     if (!wait_flag(&Fdiag[kb])) break;
@@ -2161,9 +2186,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                         else if (e < CH_NB * (CH_NB + 1)) S.Rd[e - CH_NB * CH_NB] = dv[q];
                     }
                     cf_block = kb;
-                    if (PROF) { __syncthreads(); DF_TICK(2); }
+                    if (PROF == 1) { __syncthreads(); DF_TICK(2); }
                 }
                 __syncthreads();
+                if (I == J + 1) DF_STAMP(kb, 3);
                 // the rows of this tile below the diagonal block: X L^T = B, a half strip per wave
                 // (rows 16 ws + lk + 4 (2 wp + h2), h2 = 0, 1), in place, stored to A and kept as operands
                 const int rfirst = diag ? CH_NB * h + nb : 0;             // first tile row that is a panel row
@@ -2202,8 +2228,15 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     }
                 }
                 li_row = I; lj_row = I; l_block = kb;
-                set_flag(&Fpan[(size_t)kb * NT + I]);                    // (its __syncthreads also closes the operand writes)
+                __syncthreads();                                         // (the operand writes)
+                if (npend == DF_MAXT) flush();
+                {
+                    unsigned* pf = &Fpan[(size_t)kb * NT + I];           // the stores to A land while the updates run
+                    if (npend == 0) pend0 = pf; else if (npend == 1) pend1 = pf; else pend2 = pf;
+                    ++npend;
+                }
                 DF_TICK(5);
+                if (I == J + 1) DF_STAMP(kb, 4);
                 // the second half of the tile takes this block's update: columns 32 .. 63 -= X L21^T, L21 = the
                 // rows 32 .. 63 of tile row J (the diagonal owner's solve of this step)
                 if (h == 0 && more) {
@@ -2218,6 +2251,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     update_tile(sl, 2, diag ? 2 : 0);
                     __syncthreads();
                     DF_TICK(7);
+                    if (I == J + 1) DF_STAMP(kb, 5);
                 }
                 continue;
             }
@@ -2235,12 +2269,16 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
             __syncthreads();
             DF_TICK(6);
             update_tile(sl, 0, 0);
+            if (PROF == 2 && I == Jt && I == J + 1 && h == 1) { __syncthreads(); DF_STAMP(kb, 5); }
         }
+        flush();
     }
+    flush();
     if (S.dead && tid == 0) atomicAdd(&tmo[reg], 1);
-    if (PROF && prof && tid == 0)
+    if (PROF == 1 && prof && tid == 0)
         for (int k = 0; k < 8; ++k) prof[(size_t)blockIdx.x * 8 + k] = pt[k];
 #undef DF_TICK
+#undef DF_STAMP
 }
 
 // One workgroup of 512 threads per region and nothing shared between workgroups: no region
@@ -2569,12 +2607,43 @@ __global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, 
     __shared__ double ys[CH_NB];                 // right-hand side of the coming chain
     const double* A = Aall + (size_t)blockIdx.x * (size_t)(n + 1) * lda;
     const int tid = threadIdx.x;
-    const bool chain = tid < 64;
-    const int c = tid - 64;
     const int nblk = (n + CH_NB - 1) / CH_NB;
-    double yc = 0.0, a[CH_NB], dnext[2] = {0.0, 0.0};
+    // The two roles are two code paths with the same sequence of barriers (s_barrier counts waves, whatever their
+    // program counter): in one path the chain's 32 coefficients and the column threads' 32 rows of L were live
+    // together and the 128 registers of a wave (1024 threads) spilled.
+    if (tid < 64) {
+        // ---- wave 0: the 32-step chain of the block whose diagonal is in Dn and whose right-hand side is in ys.
+        // Round 4: the chain carries the UNSCALED partial sums (the panel chains of the factorisation do the same):
+        // u_i = y_i - sum_{k > i} L[k][i] x_k, x_j = u_j / L[j][j].  Lane i keeps c[j] = L[j][i] / L[j][j] for the
+        // rows j > i of its column and subtracts c[j] u_j as soon as u_j is final - a step is the broadcast of u_j
+        // (v_readlane) and one FMA, the reciprocal diagonal comes in once at the end (before: two broadcasts, a
+        // multiply, an FMA and two selects per step).  Dn holds 0 on and above the diagonal and the reciprocal
+        // diagonal in column 32: no select anywhere.
+        auto run_chain = [&](double* xout) {
+            const int li = tid & 31;
+            double col[CH_NB];
 #pragma unroll
-    for (int m = 0; m < CH_NB; ++m) a[m] = 0.0;
+            for (int j = 0; j < CH_NB; ++j) col[j] = Dn[j][li];
+            const double rdl = Dn[li][CH_NB];
+            double u = ys[li];
+#pragma unroll
+            for (int j = 1; j < CH_NB; ++j) col[j] *= readlane_d(rdl, j);
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 1; --j) u = __builtin_fma(-col[j], readlane_d(u, j), u);
+            if (tid < CH_NB) xout[tid] = u * rdl;
+        };
+        __syncthreads();
+        run_chain(xs[0]);
+        __syncthreads();
+        for (int kb = nblk - 1; kb >= 1; --kb) {
+            __syncthreads();                                 // (phase A of the column threads)
+            run_chain(xs[(nblk - kb) & 1]);                  // block kb - 1, beside their phase B
+            __syncthreads();
+        }
+        return;
+    }
+    const int c = tid - 64;
+    double yc = 0.0, a[CH_NB], dnext[2] = {0.0, 0.0};
     // element e of a diagonal block (row e >> 5, column e & 31); rows >= nb are identity rows
     auto diag_elem = [&](int k0, int nb, int e) -> double {
         const int i = e >> 5, j = e & 31;
@@ -2582,89 +2651,62 @@ __global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, 
     };
     auto diag_put = [&](int e, double v) {
         const int i = e >> 5, j = e & 31;
-        Dn[i][j] = v;
+        Dn[i][j] = (i == j) ? 0.0 : v;                   // (the chain wants the diagonal as its reciprocal only)
         if (i == j) Dn[i][CH_NB] = 1.0 / v;
     };
     {
         const int kb = nblk - 1, k0 = kb * CH_NB, nb = n - k0;
-        if (!chain) {
-            yc = (c < n) ? A[(size_t)n * lda + c] : 0.0;
-            diag_put(c, diag_elem(k0, nb, c));
-            if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, diag_elem(k0, nb, c + CBC_COLS));
-            if (c >= k0 && c < k0 + CH_NB) ys[c - k0] = yc;          // 0 beyond column n - 1
+        yc = (c < n) ? A[(size_t)n * lda + c] : 0.0;
+        diag_put(c, diag_elem(k0, nb, c));
+        if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, diag_elem(k0, nb, c + CBC_COLS));
+        if (c >= k0 && c < k0 + CH_NB) ys[c - k0] = yc;          // 0 beyond column n - 1
 #pragma unroll
-            for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0 && m < nb) ? A[(size_t)(k0 + m) * lda + c] : 0.0;
-            if (kb > 0) {
-                dnext[0] = diag_elem(k0 - CH_NB, CH_NB, c);
-                if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0 - CH_NB, CH_NB, c + CBC_COLS);
-            }
+        for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0 && m < nb) ? A[(size_t)(k0 + m) * lda + c] : 0.0;
+        if (kb > 0) {
+            dnext[0] = diag_elem(k0 - CH_NB, CH_NB, c);
+            if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0 - CH_NB, CH_NB, c + CBC_COLS);
         }
     }
     __syncthreads();
-    // the 32-step chain of the block whose diagonal is in Dn and whose right-hand side is in ys
-    auto run_chain = [&](double* xout) {
-        // lane i keeps column i of the block (L[j][i], j = 0 .. 31) and the reciprocal
-        // diagonal in registers: a step of the chain is a readlane, a multiply and an FMA
-        const int li = tid & 31;
-        double col[CH_NB];
-#pragma unroll
-        for (int j = 0; j < CH_NB; ++j) col[j] = Dn[j][li];
-        const double rdl = Dn[li][CH_NB];
-        double bi = ys[li];
-#pragma unroll
-        for (int j = CH_NB - 1; j >= 0; --j) {
-            const double xj = readlane_d(bi, j) * readlane_d(rdl, j);
-            bi = (li == j) ? xj : ((li < j) ? bi - col[j] * xj : bi);   // L^T[i][j] = L[j][i]
-        }
-        if (tid < CH_NB) xout[tid] = bi;
-    };
     // Look-ahead: once block kb is solved, the 32 columns of block kb - 1 take its contribution first
     // (phase A), then wave 0 runs the chain of block kb - 1 WHILE the other columns take theirs and
     // request the rows of the next block (phase B) - the chain overlaps the column sweep and its
     // loads instead of standing between them.  Every y[c] still receives the same products in the
     // same order (one block of 32 at a time, m ascending).
-    if (chain) run_chain(xs[0]);
-    __syncthreads();
+    __syncthreads();                                         // (the chain of the last block)
     for (int kb = nblk - 1; kb >= 1; --kb) {
         const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
         const int k0n = k0 - CH_NB;
         const double* xc = xs[(nblk - 1 - kb) & 1];          // solution of block kb
-        double* xn = xs[(nblk - kb) & 1];                    // block kb - 1 goes here
         // ---- phase A: this block's columns are final; the next block's columns finish their sums
-        if (!chain) {
-            if (c >= k0 && c < k0 + nb) yc = xc[c - k0];
-            if (c >= k0n && c < k0) {
-                double acc = 0.0;
+        if (c >= k0 && c < k0 + nb) yc = xc[c - k0];
+        if (c >= k0n && c < k0) {
+            double acc = 0.0;
 #pragma unroll
-                for (int m = 0; m < CH_NB; ++m) acc += a[m] * xc[m];
-                yc -= acc;
-                ys[c - k0n] = yc;
-            }
-            diag_put(c, dnext[0]);
-            if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, dnext[1]);
+            for (int m = 0; m < CH_NB; ++m) acc += a[m] * xc[m];
+            yc -= acc;
+            ys[c - k0n] = yc;
         }
+        diag_put(c, dnext[0]);
+        if (c + CBC_COLS < CH_NB * CH_NB) diag_put(c + CBC_COLS, dnext[1]);
         __syncthreads();
-        // ---- phase B: chain of block kb - 1 beside the sweep of the columns left of it
-        if (chain) {
-            run_chain(xn);
-        } else {
-            if (c < k0n) {
-                double acc = 0.0;
+        // ---- phase B: the sweep of the columns left of block kb - 1, beside its chain
+        if (c < k0n) {
+            double acc = 0.0;
 #pragma unroll
-                for (int m = 0; m < CH_NB; ++m) acc += a[m] * xc[m];
-                yc -= acc;
-            }
+            for (int m = 0; m < CH_NB; ++m) acc += a[m] * xc[m];
+            yc -= acc;
+        }
 #pragma unroll
-            for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0n) ? A[(size_t)(k0n + m) * lda + c] : 0.0;
-            if (kb > 1) {
-                dnext[0] = diag_elem(k0n - CH_NB, CH_NB, c);
-                if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0n - CH_NB, CH_NB, c + CBC_COLS);
-            }
+        for (int m = 0; m < CH_NB; ++m) a[m] = (c < k0n) ? A[(size_t)(k0n + m) * lda + c] : 0.0;
+        if (kb > 1) {
+            dnext[0] = diag_elem(k0n - CH_NB, CH_NB, c);
+            if (c + CBC_COLS < CH_NB * CH_NB) dnext[1] = diag_elem(k0n - CH_NB, CH_NB, c + CBC_COLS);
         }
         __syncthreads();
     }
-    if (!chain && c < min(CH_NB, n)) yc = xs[(nblk - 1) & 1][c];       // block 0
-    if (!chain && c < n) xall[(size_t)blockIdx.x * n + c] = yc / dall[(size_t)blockIdx.x * n + c];
+    if (c < min(CH_NB, n)) yc = xs[(nblk - 1) & 1][c];       // block 0
+    if (c < n) xall[(size_t)blockIdx.x * n + c] = yc / dall[(size_t)blockIdx.x * n + c];
 }
 
 // ---------------------------------------------------------------------------
@@ -3605,19 +3647,21 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 // ZM_CHOL_PROF=1: per-phase clocks of every workgroup, printed after the launch
                 const int nprof = df ? 8 : 6;
                 long long* parg = nullptr;
-                if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 8 * P.nreg * W, (void**)&parg));
+                const int nblkp = zm_div_up(nunk, CH_NB);
+                if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 8 * ((size_t)P.nreg * W + (size_t)P.nreg * nblkp), (void**)&parg));
                 // ZM_CHOL_STEP=64: the 64-column super-steps (k_chol_fused2: same bits; measured, not faster - see its
                 // header)
                 const bool step32 = !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
                 {
                     zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
                     if (df) {
-                        auto kf = want_prof ? k_chol_df<true> : k_chol_df<false>;
-                        static bool df_attr[2][64] = {};
-                        if (!df_attr[want_prof][ctx->device & 63]) {
+                        static const int prof_mode = want_prof ? std::min(2, atoi(getenv("ZM_CHOL_PROF"))) : 0;
+                        auto kf = prof_mode == 2 ? k_chol_df<2> : prof_mode == 1 ? k_chol_df<1> : k_chol_df<0>;
+                        static bool df_attr[3][64] = {};
+                        if (!df_attr[prof_mode][ctx->device & 63]) {
                             ZM_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)sizeof(df_lds)));
-                            df_attr[want_prof][ctx->device & 63] = true;
+                            df_attr[prof_mode][ctx->device & 63] = true;
                         }
                         hipLaunchKernelGGL(kf, dim3(P.nreg * W), dim3(DF_THREADS), sizeof(df_lds), st, nunk, lda, W, A,
                                            dfdg, fail, tmo, spin_limit, dff, dftiles, guard, A0, rhs0, dsc, parg);
@@ -3638,7 +3682,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 }
                 ZM_HIP(hipGetLastError());
                 if (want_prof) {
-                    std::vector<long long> hp((size_t)nprof * P.nreg * W);
+                    std::vector<long long> hp((size_t)8 * ((size_t)P.nreg * W + (size_t)P.nreg * nblkp));
                     ZM_HIP(hipMemcpyAsync(hp.data(), parg, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost, st));
                     ZM_HIP(hipStreamSynchronize(st));
                     static const char* nm6[6] = {"load", "tilewait", "panel", "barrier1", "update", "barrier2"};
@@ -3652,6 +3696,15 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                         for (int k = 0; k < nprof; ++k)
                             fprintf(stderr, " %s %.1f us", df ? nm8[k] : nm6[k], hp[(size_t)wg * nprof + k] * 0.01);
                         fprintf(stderr, "\n");
+                    }
+                    if (df && getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) >= 2) {
+                        // region 0: the chain per block, microseconds since the first block was taken up
+                        const long long* ts = hp.data() + (size_t)8 * P.nreg * W;
+                        for (int kb = 0; kb < nblkp; ++kb) {
+                            fprintf(stderr, "chol kb %2d:", kb);
+                            for (int e = 0; e < 6; ++e) fprintf(stderr, " %7.2f", (ts[kb * 8 + e] - ts[0]) * 0.01);
+                            fprintf(stderr, "\n");
+                        }
                     }
                 }
                 }   // latency form
