@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                                                     const int* __restrict__ need,
                                                     double* __restrict__ X,
                                                     double* __restrict__ phi,         // [cell][nkp]
-                                                    double* __restrict__ vbar, const int* __restrict__ guard) {
+                                                    double* __restrict__ vbar, const int* __restrict__ guard,
+                                                    double* __restrict__ phiold) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double hp_smem[];
     constexpr int STEP = 2 * HWK + 1;
@@ -498,6 +499,9 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     if (tid == 0 && part == 0) {
         vbar[cell] = vs / P.npix;
         double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
+        // (the spatial terms of the substamp this one replaces stay available to the fused normal-matrix update)
+        if (phiold)
+            for (int p = 0; p < P.nkp; ++p) phiold[(size_t)cell * P.nkp + p] = phi[(size_t)cell * P.nkp + p];
         for (int p = 0; p < P.nkp; ++p)
             phi[(size_t)cell * P.nkp + p] = ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
     }
@@ -659,16 +663,19 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
 __global__ __launch_bounds__(256) void k_hp_gram_sum(const double* __restrict__ Gp,
                                                      const int* __restrict__ need,
                                                      const int* __restrict__ active,
-                                                     double* __restrict__ G, const int* __restrict__ guard) {
+                                                     double* __restrict__ G, const int* __restrict__ guard,
+                                                     double* __restrict__ Gold) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     const int cell = blockIdx.x;
     if (!need[cell] || active[cell] < 0) return;
     const double* src = Gp + (size_t)cell * GR_SPLIT * HP_MAXX * HP_MAXX;
     double* dst = G + (size_t)cell * HP_MAXX * HP_MAXX;
+    double* old = Gold ? Gold + (size_t)cell * HP_MAXX * HP_MAXX : nullptr;
     for (int e = threadIdx.x; e < HP_MAXX * HP_MAXX; e += 256) {
         double v = 0.0;
 #pragma unroll
         for (int sl = 0; sl < GR_SPLIT; ++sl) v += src[(size_t)sl * HP_MAXX * HP_MAXX + e];
+        if (old) old[e] = dst[e];        // (the Gram matrix of the substamp this one replaces: the fused normal-matrix update takes it out)
         dst[e] = v;
     }
 }
@@ -764,21 +771,26 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
                                                       const int* __restrict__ chg, int sign,
                                                       double* __restrict__ A,
                                                       double* __restrict__ rhs, const int* __restrict__ guard,
-                                                      unsigned* __restrict__ zero = nullptr, int nzero = 0) {
+                                                      unsigned* __restrict__ zero = nullptr, int nzero = 0,
+                                                      const double* __restrict__ Gold = nullptr,
+                                                      const double* __restrict__ phiold = nullptr,
+                                                      const int* __restrict__ need = nullptr) {
     if (guard && *guard == 0) return;
-    const int reg = blockIdx.z, n1 = blockIdx.y, n2 = blockIdx.x;
+    // (a triangular grid: x = pair index of (n1, n2 <= n1) - the square grid dispatched as many empty workgroups again)
+    const int reg = blockIdx.z;
+    int n1 = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
+    while (n1 * (n1 + 1) / 2 > (int)blockIdx.x) --n1;
+    while ((n1 + 1) * (n1 + 2) / 2 <= (int)blockIdx.x) ++n1;
+    const int n2 = (int)blockIdx.x - n1 * (n1 + 1) / 2;
     if (zero && n1 == 0 && n2 == 0)                      // (the hand-over words of this round's k_chol_df)
         for (int k = threadIdx.x; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
-    if (n2 > n1) return;
     const int p1 = threadIdx.x >> 4, p2 = threadIdx.x & 15;
     const bool k1 = n1 >= 1 && n1 < P.nc, k2 = n2 >= 1 && n2 < P.nc;   // kernel terms carry spatial factors
     const int nk = (P.nc - 1) * P.nkp;
     const int c1 = n1 == 0 ? 0 : (k1 ? 1 + (n1 - 1) * P.nkp + p1 : 1 + nk + (n1 - P.nc));
     const int c2 = n2 == 0 ? 0 : (k2 ? 1 + (n2 - 1) * P.nkp + p2 : 1 + nk + (n2 - P.nc));
     const bool live = p1 < (k1 ? P.nkp : 1) && p2 < (k2 ? P.nkp : 1) && c2 <= c1;
-    double acc = 0.0, racc = 0.0;
     const bool do_rhs = (c2 == 0);
-    bool any = false;
     const int* list = chg + P.ncell + reg * (P.ncellr + 1);
     const int ncand = (sign == 0) ? P.ncellr : list[0];
     // the candidates' Gram entries, right-hand-side entries, spatial terms and flags are staged in
@@ -786,41 +798,64 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
     __shared__ double gs[BB_CH], grs[BB_CH], phs[BB_CH * 16];
     __shared__ int ons[BB_CH];
     const int tid = threadIdx.x;
-    for (int s0 = 0; s0 < ncand; s0 += BB_CH) {
-        const int nch = min(BB_CH, ncand - s0);
-        __syncthreads();
-        if (tid < nch) {
-            const int cell = (sign == 0) ? reg * P.ncellr + s0 + tid : list[1 + s0 + tid];
-            const int on = !(active[cell] < 0 && sign >= 0);
-            const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
-            ons[tid] = on;
-            gs[tid] = on ? Gc[n1 * HP_MAXX + n2] : 0.0;
-            grs[tid] = (on && n2 == 0) ? Gc[n1 * HP_MAXX + P.nE] : 0.0;
-        }
-        for (int e = tid; e < nch * P.nkp; e += 256) {
-            const int k = e / P.nkp, pp = e - k * P.nkp;
-            const int cell = (sign == 0) ? reg * P.ncellr + s0 + k : list[1 + s0 + k];
-            phs[k * 16 + pp] = phi[(size_t)cell * P.nkp + pp];
-        }
-        __syncthreads();
-        if (live) {
-            for (int k = 0; k < nch; ++k) {
-                if (!ons[k]) continue;
-                any = true;
-                const double w1 = k1 ? phs[k * 16 + p1] : 1.0, w2 = k2 ? phs[k * 16 + p2] : 1.0;
-                acc += w1 * w2 * gs[k];
-                if (do_rhs) racc += w1 * grs[k];
+    const size_t ia = (size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2;
+    // sign == 2 (round 4): both updates of a rejection round in one launch - the changed cells leave with the Gram
+    // matrix and spatial terms they had (kept by k_hp_gram_sum / k_hp_vectors when they wrote the new ones: Gold,
+    // phiold; a cell that was dropped still has them in place), then come back with the new ones; an entry takes
+    // the two sums one after the other, as the two launches applied them: the same roundings.
+    double av = 0.0, rv = 0.0;
+    bool touched = false;
+    const int npass = sign == 2 ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int sg = sign == 2 ? (pass == 0 ? -1 : 1) : sign;
+        double acc = 0.0, racc = 0.0;
+        bool any = false;
+        for (int s0 = 0; s0 < ncand; s0 += BB_CH) {
+            const int nch = min(BB_CH, ncand - s0);
+            __syncthreads();
+            if (tid < nch) {
+                const int cell = (sg == 0) ? reg * P.ncellr + s0 + tid : list[1 + s0 + tid];
+                const int on = !(active[cell] < 0 && sg >= 0);
+                const bool was = sign == 2 && pass == 0 && need[cell];       // recomputed since: the old copy
+                const double* Gc = (was ? Gold : G) + (size_t)cell * HP_MAXX * HP_MAXX;
+                ons[tid] = on;
+                gs[tid] = on ? Gc[n1 * HP_MAXX + n2] : 0.0;
+                grs[tid] = (on && n2 == 0) ? Gc[n1 * HP_MAXX + P.nE] : 0.0;
+            }
+            for (int e = tid; e < nch * P.nkp; e += 256) {
+                const int k = e / P.nkp, pp = e - k * P.nkp;
+                const int cell = (sg == 0) ? reg * P.ncellr + s0 + k : list[1 + s0 + k];
+                const bool was = sign == 2 && pass == 0 && need[cell];
+                phs[k * 16 + pp] = (was ? phiold : phi)[(size_t)cell * P.nkp + pp];
+            }
+            __syncthreads();
+            if (live) {
+                for (int k = 0; k < nch; ++k) {
+                    if (!ons[k]) continue;
+                    any = true;
+                    const double w1 = k1 ? phs[k * 16 + p1] : 1.0, w2 = k2 ? phs[k * 16 + p2] : 1.0;
+                    acc += w1 * w2 * gs[k];
+                    if (do_rhs) racc += w1 * grs[k];
+                }
             }
         }
+        if (!live) continue;
+        if (sg == 0) {
+            A[ia] = acc;
+            if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
+        } else if (any) {
+            if (!touched) {
+                av = A[ia];
+                if (do_rhs) rv = rhs[(size_t)reg * P.nunk + c1];
+                touched = true;
+            }
+            av += (double)sg * acc;
+            if (do_rhs) rv += (double)sg * racc;
+        }
     }
-    if (!live) return;
-    const size_t ia = (size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2;
-    if (sign == 0) {
-        A[ia] = acc;
-        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = racc;
-    } else if (any) {
-        A[ia] += sign * acc;
-        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] += sign * racc;
+    if (live && touched) {
+        A[ia] = av;
+        if (do_rhs) rhs[(size_t)reg * P.nunk + c1] = rv;
     }
 }
 
@@ -2140,7 +2175,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                     // the diagonal block (half h of the tile) out of the planes, factored, published
                     DF_TICK(7);
                     DF_STAMP(kb, 0);
-                    __syncthreads();
+                    // (no barrier in front: a wave copies from its own planes, and S.D was last read before the
+                    // barriers of the step before)
                     if (wp == h && (ws >> 1) == h) {
 #pragma unroll
                         for (int cc = 0; cc < 2; ++cc)
@@ -3405,6 +3441,11 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     double* Gp = nullptr;                // per-slice partial Gram matrices
     ZM_TRY(ctx->get("hp_Gp", sizeof(double) * (size_t)P.ncell * GR_SPLIT * HP_MAXX * HP_MAXX, (void**)&Gp));
     ZM_TRY(ctx->get("hp_phi", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phi));
+    // what a cell's Gram matrix and spatial terms were before its substamp was replaced (the fused update of the
+    // normal matrix takes the old contribution out and puts the new one in in one launch)
+    double *Gold = nullptr, *phiold = nullptr;
+    ZM_TRY(ctx->get("hp_Gold", sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX, (void**)&Gold));
+    ZM_TRY(ctx->get("hp_phiold", sizeof(double) * (size_t)P.ncell * P.nkp, (void**)&phiold));
     ZM_TRY(ctx->get("hp_vbar", sizeof(double) * P.ncell, (void**)&vbar));
     const int lda = (P.nunk + 15) & ~15;       // factored storage: rows padded to whole 128-B lines
     ZM_TRY(ctx->get("hp_A", sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * lda, (void**)&A));
@@ -3514,9 +3555,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             // terms, before k_hp_vectors / k_hp_gram overwrite them
             zm_scope_timer t(ctx, "hp_solve");
             int nt = zm_div_up(P.nunk, 16);
-            if (P.nkp <= 16)
-                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
-            else
+            // (k_hp_build_blk takes both updates of the round in one launch, below: sign 2)
+            if (P.nkp > 16)
                 hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg, -1, A0, rhs0, guard);
         }
         {
@@ -3524,7 +3564,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
     hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar, guard); break;
+                       centres, active, need, X, phi, vbar, guard, phiold); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
                 HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
@@ -3537,7 +3577,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         {
             zm_scope_timer t(ctx, "hp_gram");
             hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell, GR_SPLIT), b256, 0, st, P, X, need, active, Gp, guard);
-            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G, guard);
+            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G, guard, Gold);
             ZM_HIP(hipGetLastError());
         }
         {
@@ -3604,8 +3644,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                                 (void**)&dfdg));
             }
             if (P.nkp <= 16)
-                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE, P.nE, P.nreg), b256, 0, st, P, G, phi, active, chg,
-                                   rounds == 1 ? 0 : 1, A0, rhs0, guard, dff, ndff);
+                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE * (P.nE + 1) / 2, 1, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                                   rounds == 1 ? 0 : 2, A0, rhs0, guard, dff, ndff, Gold, phiold, need);
             else
                 hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,
                                    rounds == 1 ? 0 : 1, A0, rhs0, guard, dff, ndff);
