@@ -141,7 +141,7 @@ __device__ inline void chol_diag_wave_panel_ref(double (*D)[CH_NB + 1], int nb, 
 // not kept: the column steps with only lanes 0 - 31 active (the upper half duplicates the rows): the same code
 // ran 3.4 us in some launches and 3.9 - 4.1 us in others.
 template <int TAG>
-__device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb, int* fail) {
+__device__ __forceinline__ void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb, int* fail) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, li = lane & 15, lk = lane >> 4;
     double amin = 1.0;                                   // smallest clamped pivot: 1e-14 iff one was clamped
@@ -197,6 +197,18 @@ __device__ inline void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1], int nb,
 #endif
 template <int TAG>
 __device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, int* fail) {
+#if ZM_CHOL_DIAG_FAST
+    chol_diag_wave_panel_fast<TAG>(D, nb, fail);
+#else
+    chol_diag_wave_panel_ref<TAG>(D, nb, fail);
+#endif
+}
+
+// The same, always expanded in place: k_chol_df calls the factor from the middle of its step loop, where an
+// out-of-line call saves and restores ~120 scalar registers through vector lanes on the critical wave (measured:
+// 1.54 -> 1.51 ms per seven factorisations); the barrier forms and k_chol_tp are better off with the call.
+template <int TAG>
+__device__ __forceinline__ void chol_diag_wave_panel_inl(double (*D)[CH_NB + 1], int nb, int* fail) {
 #if ZM_CHOL_DIAG_FAST
     chol_diag_wave_panel_fast<TAG>(D, nb, fail);
 #else

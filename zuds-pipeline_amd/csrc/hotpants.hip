@@ -2188,7 +2188,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
                             }
                     }
                     __syncthreads();
-                    if (tid < 64) chol_diag_wave_panel_t<2>(S.D, nb, &fail[reg]);
+                    if (tid < 64) chol_diag_wave_panel_inl<2>(S.D, nb, &fail[reg]);
                     __syncthreads();
                     DF_TICK(3);
                     DF_STAMP(kb, 1);
