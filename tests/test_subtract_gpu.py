@@ -284,6 +284,27 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
             assert i0[k] == i[k], k
 
 
+@pytest.mark.parametrize('r', [5.0, 7.0, 10.0])
+def test_the_two_forms_of_the_convolution_agree(engine, monkeypatch, r):
+    """Round 4: the convolution of the template runs one wave per kernel block with the taps as scalar operands
+    (k_hp_kbasis + k_hp_ktable + k_hp_apply_w) where a block fills most of a wave; ZM_APPLY_FORM=tile is the
+    workgroup-per-six-blocks kernel of rounds 1 - 3.  The block kernels are the same sums in another order (the
+    spatial terms outside), so the fp32 taps differ in the last bit here and there: the products agree to a few
+    1e-7 of the template, the fill pattern and the fit summary exactly."""
+    data = scene(nx=700, ny=660, seed=31, nstars=500, gradient=0.3)
+    kw = dict(r=r, rss=2.4 * r, nsx=5, nsy=5, nrx=2, nry=2, ko=2, bgo=0, **COMMON)
+    d0, n0, i0 = engine.subtract(*data, **kw)
+    monkeypatch.setenv('ZM_APPLY_FORM', 'tile')
+    d1, n1, i1 = engine.subtract(*data, **kw)
+    monkeypatch.delenv('ZM_APPLY_FORM')
+    assert i0 == i1
+    fill = np.float32(1e-30)
+    assert np.array_equal(d0 == fill, d1 == fill)
+    scale = float(np.abs(data[2]).max())
+    assert np.abs(d0 - d1).max() <= 2e-6 * scale
+    assert np.abs(n0 - n1).max() <= 2e-6 * float(np.abs(n1[np.isfinite(n1)]).max())
+
+
 def test_two_engines_side_by_side_without_a_pool(engine):
     """two contexts that subtract at the same time without having declared it
     (zm_ctx_set_share) used to size the many-workgroup factorisation to the whole GPU each.  A context

@@ -2987,6 +2987,15 @@ constexpr int apply_pitch(int width, int lpr, int r, int step) {
     return best;
 }
 
+constexpr int apply_pitch_n(int width, int lpr, int r, int step, int range) {
+    int best = width, bw = apply_bank_passes(width, lpr, r, step);
+    for (int p = width + 1; p <= width + range; ++p) {
+        const int w = apply_bank_passes(p, lpr, r, step);
+        if (w < bw) { bw = w; best = p; }
+    }
+    return best;
+}
+
 template <int HWK> struct apply_cfg {
     enum { STEP = 2 * HWK + 1,
            LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? 2 : 3),   // lanes per block row
@@ -3248,6 +3257,288 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
 }
 
 // ---------------------------------------------------------------------------
+// Apply, one wave per kernel block (round 4).  k_hp_apply above spends more time around its convolution than in
+// it (41 % of the vector issue slots at 3 waves per SIMD): every workgroup first evaluates its blocks' kernels in
+// fp64 behind five barriers, the {k, k^2} taps take a third of the LDS reads of the inner loop (a block is 42
+// lanes: a wave straddles two blocks, the taps are not uniform), and 70 KB of LDS per workgroup leave two
+// workgroups per CU.  Here:
+//   * the block kernels are evaluated once by a kernel of their own (k_hp_kernels: the arithmetic of k_hp_apply's
+//     prologue, the same bits) into a {k, k^2} table in global memory, 3.5 KB per block;
+//   * a wave owns ONE block (STEP rows x LPR strips of R columns <= 64 lanes), so its taps are wave-uniform: they
+//     arrive through the scalar cache (s_load_dwordx16, a tap row ahead) and enter v_pk_fma_f32 as a scalar
+//     operand - no LDS read, no vector register;
+//   * LDS holds the {T, V} tile only (34 KB for four blocks of 21): four workgroups per CU.
+// The sums run in k_hp_apply's order (v outer, u inner, one packed FMA per tap and pixel): the same bits.
+template <int HWK> struct applyw_cfg {
+    enum { STEP = 2 * HWK + 1,
+           LPR = 64 / STEP > 0 ? 64 / STEP : 1,          // lanes per block row (strips)
+           R = (STEP + LPR - 1) / LPR,                   // output pixels per lane
+           NBW = 4,                                      // blocks (= waves) per workgroup
+           TW = NBW * STEP + 2 * HWK,
+           TH = STEP + 2 * HWK,
+           // tile row pitch in float2 units: the window loads of a wave (lane = (row, strip)) free of bank
+           // conflicts where a pitch within 32 of the width allows it (HWK 10: 117 - with 105 every load took
+           // two passes and the kernel was bound by the LDS pipe: 308 us)
+           TP = apply_pitch_n(NBW * STEP + 2 * HWK, 64 / STEP > 0 ? 64 / STEP : 1,
+                              (STEP + (64 / STEP > 0 ? 64 / STEP : 1) - 1) / (64 / STEP > 0 ? 64 / STEP : 1), STEP, 32) };
+    // lanes doing useful work x columns doing useful work, in percent
+    enum { EFF = (100 * STEP * LPR / 64) * STEP / (LPR * R) };
+};
+
+// The table of block kernels.  k_hp_apply evaluates a block's kernel as K = sum_n c_n B_n with the coefficients
+// c_n = sum_p x[n, p] X^i_p Y^j_p taken at the block centre first - per block a chain of small fp64 stages behind
+// five barriers (as a kernel of its own: 115 us per frame, all latency).  The same sum with the spatial terms
+// outside, K = x_0 B_0 + sum_p (X^i_p Y^j_p) M_p, M_p = sum_n x[n, p] B_n, has per-REGION matrices M_p
+// (k_hp_kbasis, a few hundred thousand products per subtraction) and leaves nkp fused multiply-adds per tap and
+// block (k_hp_ktable: a thread keeps the M_p of its taps in registers and walks along a row of blocks).  Equal to
+// k_hp_apply's kernels up to fp64 rounding of the reordered sums, i.e. to the last bit of the fp32 taps in all but
+// ~1e-8 of them.
+#define HPK_MAXP 15   // spatial terms the register path holds (ko <= 4); more: k_hp_apply
+#define HPK_NBK 16    // blocks per workgroup of k_hp_ktable
+template <int HWK>
+__global__ __launch_bounds__(256) void k_hp_kbasis(const hp_plan P, const double* __restrict__ filt,
+                                                   const double* __restrict__ xsol, double* __restrict__ Mt) {
+    constexpr int STEP = 2 * HWK + 1, NT = STEP * STEP;
+    const int reg = blockIdx.y, p = blockIdx.x;          // p == HPK_MAXP: the constant part x_0 B_0
+    const double* x = xsol + (size_t)reg * P.nunk;
+    // the term tables, this spatial term's coefficients and the 1-D filters in LDS first (read through the
+    // kernel-argument segment and global memory inside the sum, every term paid two dependent latencies: 17 us)
+    __shared__ double xq[HP_MAXX], sn[HP_MAXX], flt[HP_MAXF1 * STEP];
+    __shared__ int txn[HP_MAXX], tyn[HP_MAXX], sbn[HP_MAXX];
+    const int tid = threadIdx.x;
+    for (int n = tid; n < P.nc; n += 256) {
+        sn[n] = P.tscale[n];
+        txn[n] = P.tfx[n] * STEP;
+        tyn[n] = P.tfy[n] * STEP;
+        sbn[n] = P.tsub0[n];
+        xq[n] = (n >= 1 && p < P.nkp) ? x[1 + (size_t)(n - 1) * P.nkp + p] : 0.0;
+    }
+    for (int e = tid; e < P.nf1 * STEP; e += 256) flt[e] = filt[e];
+    __syncthreads();
+    for (int tap = tid; tap < NT; tap += 256) {
+        const int v = tap / STEP, u = tap - v * STEP;
+        const double b0 = sn[0] * flt[tyn[0] + v] * flt[txn[0] + u];
+        double acc = 0.0;
+        if (p == HPK_MAXP) {
+            acc = x[0] * (b0 - (sbn[0] ? b0 : 0.0));
+        } else if (p < P.nkp) {
+#pragma unroll 8
+            for (int n = 1; n < P.nc; ++n) {
+                const double bn = sn[n] * flt[tyn[n] + v] * flt[txn[n] + u];
+                acc += xq[n] * (bn - (sbn[n] ? b0 : 0.0));
+            }
+        }
+        Mt[((size_t)reg * (HPK_MAXP + 1) + p) * NT + tap] = acc;
+    }
+}
+
+template <int HWK>
+__global__ __launch_bounds__(512) void k_hp_ktable(const hp_plan P, const double* __restrict__ Mt, int maxbx, int maxby,
+                                                   float2* __restrict__ kcg) {
+    constexpr int STEP = 2 * HWK + 1, NT = STEP * STEP, TPT = (NT + 511) / 512;
+    __shared__ double W[HPK_NBK][HPK_MAXP + 1];
+    const int reg = blockIdx.z, tid = threadIdx.x;
+    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
+    const int bx0 = blockIdx.x * HPK_NBK;
+    const int gx0 = x0r + bx0 * STEP, gy0 = y0r + blockIdx.y * STEP;
+    if (gx0 >= x1r || gy0 >= y1r) return;
+    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
+    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
+    // the spatial terms at the nominal block centres (k_hp_apply's coordinates)
+    for (int e = tid; e < HPK_NBK * (HPK_MAXP + 1); e += 512) {
+        const int b = e / (HPK_MAXP + 1), pp = e - b * (HPK_MAXP + 1);
+        double w = 0.0;
+        if (pp < P.nkp) {
+            const double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
+            w = ipowd(fx, P.kpi[pp]) * ipowd(fy, P.kpj[pp]);
+        }
+        W[b][pp] = w;
+    }
+    double m[TPT][HPK_MAXP + 1];
+#pragma unroll
+    for (int t = 0; t < TPT; ++t)
+#pragma unroll
+        for (int pp = 0; pp <= HPK_MAXP; ++pp) {
+            const int tap = min(tid + 512 * t, NT - 1);
+            m[t][pp] = Mt[((size_t)reg * (HPK_MAXP + 1) + pp) * NT + tap];
+        }
+    __syncthreads();
+    for (int b = 0; b < HPK_NBK; ++b) {
+        const int bx = bx0 + b;
+        if (bx >= maxbx || gx0 + b * STEP >= x1r) break;
+        float2* out = kcg + (((size_t)reg * maxby + blockIdx.y) * maxbx + bx) * NT;
+        double w[HPK_MAXP];
+#pragma unroll
+        for (int pp = 0; pp < HPK_MAXP; ++pp) w[pp] = W[b][pp];
+#pragma unroll
+        for (int t = 0; t < TPT; ++t) {
+            double acc = m[t][HPK_MAXP];
+#pragma unroll
+            for (int pp = 0; pp < HPK_MAXP; ++pp) acc = fma(w[pp], m[t][pp], acc);
+            const float k = (float)acc;
+            const int tap = tid + 512 * t;
+            if (tap < NT) out[tap] = make_float2(k, k * k);
+        }
+    }
+}
+
+template <int HWK>
+__global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, unsigned long long solved_mask,
+                                                    const float* __restrict__ sci,
+                                                    const float* __restrict__ ref,
+                                                    const float* __restrict__ srms,
+                                                    const float* __restrict__ trms,
+                                                    const uint8_t* __restrict__ outbad,
+                                                    const double* __restrict__ xsol,
+                                                    const float2* __restrict__ kcg, int maxbx, int maxby,
+                                                    float* __restrict__ diff,
+                                                    float* __restrict__ noise,
+                                                    int* __restrict__ nmasked) {
+    const int reg = blockIdx.z;
+    const int solved = (int)((solved_mask >> reg) & 1ull);
+    typedef applyw_cfg<HWK> C;
+    constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, NB = C::NBW, TW = C::TW, TP = C::TP, TH = C::TH;
+    typedef float ap_v2f __attribute__((ext_vector_type(2)));
+    extern __shared__ float apw_smem[];
+    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(apw_smem);             // [TH][TP]
+    __shared__ int wmask[4];
+    const int tid = threadIdx.x;
+    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
+    const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
+    const int gy0 = y0r + blockIdx.y * STEP;
+    if (gx0 >= x1r || gy0 >= y1r) return;              // beyond this (smaller) region
+    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
+    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
+    const double bg0 = xsol[(size_t)reg * P.nunk + 1 + (size_t)(P.nc - 1) * P.nkp];     // constant background term
+    const float norm = P.normalize ? (float)(1.0 / xsol[(size_t)reg * P.nunk]) : 1.f;
+    // tile of template and template variance (zeros outside the frame / non-finite), every load of a thread
+    // ahead of its first LDS store
+    {
+        constexpr int NIT = (TH * TW + 255) / 256;
+        float tt[NIT], tr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it;
+            const int yy = e / TW, xx = e - yy * TW;
+            const int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
+            tt[it] = 0.f;
+            tr[it] = 0.f;
+            if (e < TH * TW && gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
+                const size_t idx = (size_t)gy * P.nx + gx;
+                tt[it] = ref[idx];
+                tr[it] = trms[idx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it;
+            float t = tt[it], v = tr[it] * tr[it];
+            if (!(fabsf(t) < 3e38f)) t = 0.f;
+            if (!(fabsf(v) < 3e38f)) v = 0.f;
+            if (e < TH * TW) tTV[(e / TW) * TP + e % TW] = (ap_v2f){t, v};
+        }
+    }
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);        // this wave's block
+    const int l = tid & 63;
+    const int row = l / LPR, strip = l - row * LPR;
+    const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
+    const bool live = row < STEP && gx0 + b * STEP < x1r && gy0 + row < y1r && gy0 + row < P.ny;
+    ap_v2f acc2[R];                                    // {sum k T, sum k^2 V}
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc2[q] = (ap_v2f){0.f, 0.f};
+    {
+        // (every lane runs the loop - rows beyond the block read a clamped tile row - so that the taps stay
+        // wave-uniform scalar loads; dead lanes do not store)
+        const int bxi = min((int)blockIdx.x * NB + b, maxbx - 1);
+        const ap_v2f* kb = reinterpret_cast<const ap_v2f*>(kcg) +
+                           (((size_t)reg * maxby + blockIdx.y) * maxbx + bxi) * (STEP * STEP);
+        const int rowc = min(row, STEP - 1);
+        // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
+#pragma unroll 1
+        for (int v = -HWK; v <= HWK; ++v) {
+            const ap_v2f* rt = tTV + (rowc + HWK - v) * TP + ox0;    // T(x - u): column ox0 + q + HWK - u
+            ap_v2f w2[R + 2 * HWK];
+            // (strips that reach beyond the block's last column - LPR R > STEP - stay inside the tile row)
+#pragma unroll
+            for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[(LPR * R == STEP) ? q : min(q, TW - 1 - ox0)];
+            const ap_v2f* kr = kb + (v + HWK) * STEP;
+#pragma unroll
+            for (int u = -HWK; u <= HWK; ++u) {
+                const ap_v2f k2 = kr[u + HWK];
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
+            }
+        }
+    }
+    // the sums go through LDS (the tile's space) so that the science / noise planes are read and
+    // the outputs written along rows: NB STEP consecutive pixels per row instead of R per thread
+    constexpr int OW = NB * STEP;
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (strip * R + q < STEP) tTV[row * OW + ox0 + q] = acc2[q];
+    }
+    __syncthreads();
+    int masked = 0;
+    {
+        constexpr int NE = (STEP * OW + 255) / 256;
+        float es[NE], er[NE];
+        bool eb[NE], ein[NE];
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int e = tid + 256 * it;
+            const int orow = e / OW, ocol = e - orow * OW;
+            const int gx = gx0 + ocol, gy = gy0 + orow;
+            ein[it] = e < STEP * OW && gx < x1r && gx < P.nx && gy < y1r && gy < P.ny;
+            es[it] = er[it] = 0.f;
+            eb[it] = true;
+            if (ein[it]) {
+                const size_t idx = (size_t)gy * P.nx + gx;
+                eb[it] = outbad[idx] != 0;
+                es[it] = sci[idx];
+                er[it] = srms[idx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            if (!ein[it]) continue;
+            const int e = tid + 256 * it;
+            const int orow = e / OW, ocol = e - orow * OW;
+            const int gx = gx0 + ocol, gy = gy0 + orow;
+            const size_t idx = (size_t)gy * P.nx + gx;
+            float d = P.fi, nz = P.fin;
+            if (solved && !eb[it]) {
+                double bg = bg0;
+                if (P.nbg > 1) {
+                    const double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
+                    bg = 0.0;
+                    for (int t = 0; t < P.nbg; ++t)
+                        bg += xs_bg(xsol, reg, P, t) * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
+                }
+                const ap_v2f a = tTV[e];
+                d = (es[it] - a.x - (float)bg) * norm;
+                nz = sqrtf(fmaxf(er[it] * er[it] + a.y, 0.f)) * fabsf(norm);
+            } else {
+                masked += 1;
+            }
+            diff[idx] = d;
+            noise[idx] = nz;
+        }
+    }
+    // one atomic per workgroup
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) masked += __shfl_xor(masked, o);
+    if ((tid & 63) == 0) wmask[tid >> 6] = masked;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wmask[0] + wmask[1] + wmask[2] + wmask[3];
+        if (tot) atomicAdd(nmasked, tot);
+    }
+}
+
+// ---------------------------------------------------------------------------
 extern "C" void zm_hp_params_default(zm_hp_params* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));
@@ -3389,6 +3680,31 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved
     for (int reg = 0; reg < P.nreg; ++reg) {
         W = std::max(W, P.rx1[reg] - P.rx0[reg]);
         H = std::max(H, P.ry1[reg] - P.ry0[reg]);
+    }
+    // Round 4: one wave per block with the taps as scalar operands (k_hp_kernels + k_hp_apply_w) where a block
+    // fills most of a wave; ZM_APPLY_FORM=tile runs the workgroup-per-six-blocks kernel (A / B, tests).
+    typedef applyw_cfg<HWK> CW;
+    const char* form = getenv("ZM_APPLY_FORM");
+    const bool wave_form = (form ? !strcmp(form, "wave") : (CW::EFF >= 60 && HWK >= 4)) && P.nkp <= HPK_MAXP;
+    if (wave_form && !(form && !strcmp(form, "tile"))) {
+        const int maxbx = zm_div_up(W, STEP), maxby = zm_div_up(H, STEP);
+        float2* kcg = nullptr;
+        ZM_TRY(ctx->get("hp_kcg", sizeof(float2) * (size_t)P.nreg * maxby * maxbx * STEP * STEP, (void**)&kcg));
+        double* Mt = nullptr;
+        ZM_TRY(ctx->get("hp_kmt", sizeof(double) * (size_t)P.nreg * (HPK_MAXP + 1) * STEP * STEP, (void**)&Mt));
+        hipLaunchKernelGGL(k_hp_kbasis<HWK>, dim3(HPK_MAXP + 1, P.nreg), dim3(256), 0, ctx->stream, P, filt, xsol, Mt);
+        hipLaunchKernelGGL(k_hp_ktable<HWK>, dim3(zm_div_up(maxbx, HPK_NBK), maxby, P.nreg), dim3(512), 0, ctx->stream,
+                           P, Mt, maxbx, maxby, kcg);
+        const size_t wsh = sizeof(float2) * (size_t)CW::TH * CW::TP;
+        static bool wset[16][64] = {};
+        if (wsh > 65536 && !wset[HWK][ctx->device & 63]) {
+            ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply_w<HWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsh));
+            wset[HWK][ctx->device & 63] = true;
+        }
+        hipLaunchKernelGGL(k_hp_apply_w<HWK>, dim3(zm_div_up(maxbx, CW::NBW), maxby, P.nreg), dim3(256), wsh, ctx->stream,
+                           P, solved_mask, sci, ref, srms, trms, outbad, xsol, kcg, maxbx, maxby, diff, noise, nmasked);
+        ZM_HIP(hipGetLastError());
+        return 0;
     }
     dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
     hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
