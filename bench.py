@@ -803,15 +803,21 @@ def main():
         solve_roof = None
         if 'hp_chol' in kt and not args.no_subtract:
             nunk, nreg = int(sub.info.ncoeff), 9
-            us = kt['hp_chol']['avg_us']
+            # (the launches of a step: one per rejection round that ran + the one enqueued ahead of the host that
+            # found nothing to do and returned at its guard - the factorisation's own time is per round that ran)
+            nl, niter = kt['hp_chol']['launches_per_step'], max(int(sub.info.niter), 1)
+            us = kt['hp_chol']['ms_per_step'] * 1e3 / min(nl, niter)
             flop = nreg * nunk ** 3 / 3.0
-            kc = ((pmc.get('weighted') or {}).get('kernels') or {}).get('k_chol_fused')
-            solve_roof = {'bound': 'mfma', 'kernel': 'k_chol_fused', 'avg_us': us, 'launches_per_step': kt['hp_chol']['launches_per_step'],
+            form = os.environ.get('ZM_CHOL_FORM', 'df')
+            kname = {'df': 'k_chol_df', 'lat': 'k_chol_fused', 'tp': 'k_chol_tp'}.get(form, 'k_chol_df')
+            kc = ((pmc.get('weighted') or {}).get('kernels') or {}).get(kname)
+            solve_roof = {'bound': 'mfma', 'kernel': kname, 'avg_us': us, 'launches_per_step': nl, 'rounds': niter,
                           'flop_per_launch': flop, 'what': f'{nreg} Cholesky factorisations of {nunk}^2 (n^3 / 3 each) per launch, fp64',
                           'achieved': flop / (us * 1e-6) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': flop / (us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS,
                           'traffic': kc.get('hbm_bytes_per_launch') if kc else None,
-                          'note': 'latency-bound: 23 (12 with the 64-column super-step) dependent block steps, two cross-XCD hand-offs each'}
+                          'note': 'latency-bound: 23 dependent block steps (diagonal factor by one wave, panel chains, '
+                                  'one hand-over between workgroups per 64 columns); tiles stay in LDS'}
         # SURVEY.md 8(d), the exception to the HBM bound: the convolution of the subtraction (25 B and
         # 2 * 2 * (2r + 1)^2 flop per pixel) against both the HBM peak and the fp32 vector peak
         apply_roof = None
@@ -819,7 +825,7 @@ def main():
             us = kt['hp_apply']['avg_us']
             hw = int(2.5 * args.seeing)
             flop = 4.0 * (2 * hw + 1) ** 2 * npx
-            apply_roof = {'kernel': f'k_hp_apply<{hw}>', 'avg_us': us, 'algorithmic_bytes': 25 * npx,
+            apply_roof = {'kernel': f'k_hp_apply_w<{hw}> (+ k_hp_kbasis, k_hp_ktable: the block kernels)', 'avg_us': us, 'algorithmic_bytes': 25 * npx,
                           'achieved_GBs': 25 * npx / (us * 1e-6) / 1e9, 'hbm_frac': 25 * npx / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           'flop': flop, 'achieved_TFLOPs': flop / (us * 1e-6) / 1e12,
                           'valu_frac': flop / (us * 1e-6) / 1e12 / VALU_F32_PEAK_TFLOPS,

@@ -33,7 +33,7 @@ def kernel_sources_sha16(root=ROOT):
     return h.hexdigest()[:16]
 
 
-WANT = ('k_coadd_fused', 'k_mesh_stats', 'k_mesh_guess', 'k_mask_box', 'k_combine', 'k_chol_fused', 'k_hp_apply',
+WANT = ('k_coadd_fused', 'k_mesh_stats', 'k_mesh_guess', 'k_mask_box', 'k_combine', 'k_chol_fused', 'k_chol_df', 'k_hp_apply', 'k_hp_ktable',
         'k_bk_rows', 'k_bk_cols', 'k_ff_headers')
 
 
