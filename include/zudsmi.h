@@ -167,6 +167,15 @@ typedef struct zm_hp_params {
     int32_t deg[4];           /* 6 4 2 */
     int32_t pad_[3];
     double sigma[4];          /* 0.7 1.5 3.0 */
+    /* Round 4: lower data limits taken on the device.  When limits_dev is not NULL it points at the six doubles
+     * zm_median_mad2_async_dev left in device memory ({median, 1.4826 MAD, count} of the science frame, then of
+     * the template), and the subtraction uses il = median_a - limits_nsigma * sigma_a, tl = median_b -
+     * limits_nsigma * sigma_b (zuds/hotpants.py:65-72: nsigma = 10) instead of the `il` / `tl` fields above:
+     * the two quick_background_estimate calls and the fit are enqueued back to back, without the host reading
+     * the estimates in between.  Device entry points only (zm_subtract_dev); NULL (zm_hp_params_default): the
+     * fields above. */
+    const double* limits_dev;
+    double limits_nsigma;
 } zm_hp_params;
 
 void zm_hp_params_default(zm_hp_params* p);
@@ -214,6 +223,12 @@ int zm_median_mad_dev(zm_ctx* ctx, const float* img, const int32_t* mask,
 int zm_median_mad2_dev(zm_ctx* ctx, const float* img_a, const int32_t* mask_a,
                        const float* img_b, const int32_t* mask_b, int64_t n,
                        double* out4);
+/* The same two estimates left on the device (round 4): out6_dev receives {median_a, sigma_a, count_a, median_b,
+ * sigma_b, count_b} as doubles when the stream reaches that point; nothing is copied back, nothing is waited
+ * for.  A frame without a single valid pixel has count 0 (the host entry points raise; here the caller looks
+ * at the counts when it reads the estimates).  Consumer: zm_hp_params.limits_dev. */
+int zm_median_mad2_async_dev(zm_ctx* ctx, const float* img_a, const int32_t* mask_a,
+                             const float* img_b, const int32_t* mask_b, int64_t n, double* out6_dev);
 
 /* ---- forced aperture photometry ------------------------------------------- */
 /* Replaces photutils.aperture_photometry(method='exact') + the bounding-box flag

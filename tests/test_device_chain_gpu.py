@@ -265,6 +265,35 @@ def test_device_subtraction_equals_from_images_bit_for_bit(chain, device_sub):
     assert np.array_equal(submask, sub.mask_image.data)
 
 
+def test_limits_taken_on_the_device_equal_the_host_round_trip(chain, engine, monkeypatch):
+    """Round 4: the two background estimates of prepare_hotpants stay on the device (zm_median_mad2_async_dev)
+    and the subtraction derives its lower data limits there (zm_hp_params.limits_dev) - no copy back between
+    the estimates and the fit.  ZM_HOST_LIMITS=1 is the host round trip of rounds 1 - 3: the same limits, the
+    same products bit for bit."""
+    z, torch = chain['z'], chain['torch']
+    dmod = __import__('importlib').import_module('zuds-pipeline_amd.device')
+    ref, sci, f = chain['ref'], chain['ims'][3], chain['frames'][3]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to('cuda:0')
+    args = (t(f['img'], np.float32), t(sci.rms_image.data, np.float32), t(f['mask'], np.int32),
+            t(sci.weight_image.data, np.float32), t(ref.data, np.float32),
+            t(ref.rms_image.data, np.float32), t(ref.mask_image.data, np.int32))
+    out = []
+    for host in ('0', '1'):
+        monkeypatch.setenv('ZM_HOST_LIMITS', host)
+        ds = dmod.DeviceSubtraction(sci.wcs, ref.wcs, device=0, engine=engine)
+        torch.cuda.synchronize()
+        diff, noise, submask = ds.run(*args, seeing=2.0, nreg_side=1, hotpants_kws=chain['kws'],
+                                      ref_flxscale=float(ref.header.get('FLXSCALE', 1.0)))
+        ds.stream.synchronize()
+        out.append((diff.cpu().numpy(), noise.cpu().numpy(), submask.cpu().numpy(), dict(ds.limits),
+                    {k: getattr(ds.info, k) for k, _ in ds.info._fields_}))
+    engine.set_stream(0)
+    a, b = out
+    assert a[3] == b[3] and a[4] == b[4]
+    for k in range(3):
+        assert np.array_equal(a[k], b[k])
+
+
 def test_aligned_reference_mask_has_no_bit16_and_uncovered_pixels_count(chain, device_sub):
     ds, diff, noise, submask = device_sub
     uncovered = ds.ref_al_w.cpu().numpy() == 0

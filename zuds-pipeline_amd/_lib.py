@@ -62,7 +62,8 @@ class zm_hp_params(C.Structure):
                 ('ft', C.c_double), ('ks', C.c_double),
                 ('ngauss', C.c_int32), ('deg', C.c_int32 * 4),
                 ('pad_', C.c_int32 * 3),
-                ('sigma', C.c_double * 4)]
+                ('sigma', C.c_double * 4),
+                ('limits_dev', C.c_void_p), ('limits_nsigma', C.c_double)]
 
 
 class zm_hp_info(C.Structure):
@@ -161,6 +162,7 @@ _SIGS = {
     'zm_comm_band_bounds': (C.c_int, [C.c_int, C.c_int, _P]),
     'zm_comm_mask_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(zm_mask_plan)]),
     'zm_median_mad2_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_double)]),
+    'zm_median_mad2_async_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
     'zm_rms_from_weight_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     'zm_weight_from_rms_dev': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P]),
     'zm_mask_bad_dev': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P]),

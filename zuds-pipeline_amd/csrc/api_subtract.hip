@@ -196,8 +196,14 @@ __global__ __launch_bounds__(256) void k_rsel_scan(int pass, int mode, int shift
     }
 }
 
-// median, 1.4826 MAD and count of each image -> out3[3 * nimg] (host)
-static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t n, double* out3) {
+__global__ void k_rsel_out(const rs_state* __restrict__ st, int nimg, double* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < 3 * nimg) out[t] = st[t / 3].out[t % 3];
+}
+
+// median, 1.4826 MAD and count of each image -> out3[3 * nimg] (host), or - out3 == nullptr - left on the
+// device in out_dev[3 * nimg] without a copy back or a wait
+static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t n, double* out3, double* out_dev = nullptr) {
     ZM_CHECK(nimg >= 1 && nimg <= ZM_RS_MAXIMG, "median_mad_batch: 1..%d images", ZM_RS_MAXIMG);
     rs_state* d_st = nullptr;
     unsigned int* d_hist = nullptr;
@@ -229,6 +235,11 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
                                    d_st, d_hist);
             }
         ZM_HIP(hipGetLastError());
+    }
+    if (!out3) {
+        hipLaunchKernelGGL(k_rsel_out, dim3(1), dim3(64), 0, s, d_st, nimg, out_dev);
+        ZM_HIP(hipGetLastError());
+        return 0;
     }
     rs_state* h_st = nullptr;
     ZM_TRY(ctx->get_pinned("rs_state_h", sizeof(rs_state) * ZM_RS_MAXIMG, (void**)&h_st));
@@ -267,6 +278,16 @@ extern "C" int zm_median_mad2_dev(zm_ctx* ctx, const float* img_a, const int32_t
     ZM_CHECK(o[2] > 0 && o[5] > 0, "zm_median_mad2: every pixel is masked");
     out4[0] = o[0]; out4[1] = o[1]; out4[2] = o[3]; out4[3] = o[4];
     return 0;
+}
+
+extern "C" int zm_median_mad2_async_dev(zm_ctx* ctx, const float* img_a, const int32_t* mask_a,
+                                        const float* img_b, const int32_t* mask_b, int64_t n,
+                                        double* out6_dev) {
+    ZM_CHECK(ctx && img_a && img_b && out6_dev, "zm_median_mad2_async_dev: null argument");
+    ZM_CHECK(n > 0, "zm_median_mad2_async_dev: empty image");
+    ZM_HIP(hipSetDevice(ctx->device));
+    rs_image im[2] = {{img_a, mask_a}, {img_b, mask_b}};
+    return median_mad_batch(ctx, 2, im, n, nullptr, out6_dev);
 }
 
 extern "C" int zm_median_mad(zm_ctx* ctx, const float* img, const int32_t* mask, int64_t n,

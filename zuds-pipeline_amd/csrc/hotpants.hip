@@ -54,10 +54,18 @@ struct hp_plan {
 };
 
 // ---------------------------------------------------------------------------
+// lim != nullptr (zm_hp_params.limits_dev): the lower limits come from the background estimates that
+// zm_median_mad2_async_dev left on the device - {median, sigma, count} of the science frame, then of the
+// template - with the host's arithmetic (double, then rounded to float as a kernel argument would be)
 __global__ void k_hp_valid(const float* __restrict__ sci, const float* __restrict__ ref,
                            const uint8_t* __restrict__ bpm, int64_t n, float il, float iu,
-                           float tl, float tu, uint8_t* __restrict__ bad) {
+                           float tl, float tu, uint8_t* __restrict__ bad,
+                           const double* __restrict__ lim, double nsig) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lim) {
+        il = (float)(lim[0] - nsig * lim[1]);
+        tl = (float)(lim[3] - nsig * lim[4]);
+    }
     if (p >= n) return;
     float s = sci[p], t = ref[p];
     bool ok = (s == s) && (t == t) && fabsf(s) < 3e38f && fabsf(t) < 3e38f;
@@ -3551,6 +3559,7 @@ extern "C" void zm_hp_params_default(zm_hp_params* p) {
     p->ngauss = 3;
     p->deg[0] = 6; p->deg[1] = 4; p->deg[2] = 2;
     p->sigma[0] = 0.7; p->sigma[1] = 1.5; p->sigma[2] = 3.0;
+    p->limits_dev = nullptr; p->limits_nsigma = 10.0;
 }
 
 static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::vector<double>* filt,
@@ -3773,18 +3782,25 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
     ZM_TRY(ctx->get("hp_stats", sizeof(double) * 2 * HP_MAXREG, (void**)&stats));
     ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
-    // small constant tables: staged through pinned memory owned per call generation
-    double* h_tab = nullptr;
-    ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * filt.size(), (void**)&h_tab));
-    ZM_HIP(hipStreamSynchronize(st));   // the previous call may still be reading the staging area
-    memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
-    ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
+    // small constant tables: staged through pinned memory owned per call generation.  The table depends on the
+    // parameters only (half width, Gaussians): a context that subtracts frame after frame with the same ones keeps
+    // the device copy and neither waits for the stream nor copies (round 4: with the data limits taken on the
+    // device - limits_dev - nothing between the background estimates and the fit waits for the host any more)
+    if (!(ctx->hp_filt_dev == (const void*)d_filt && ctx->hp_filt_host == filt)) {
+        double* h_tab = nullptr;
+        ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * filt.size(), (void**)&h_tab));
+        ZM_HIP(hipStreamSynchronize(st));   // the previous call may still be reading the staging area
+        memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
+        ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
+        ctx->hp_filt_host = filt;
+        ctx->hp_filt_dev = d_filt;
+    }
 
     const dim3 b256(256);
     {
         zm_scope_timer t(ctx, "hp_masks");
         hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
-                           (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad);
+                           (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad, hp->limits_dev, hp->limits_nsigma);
         ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
         const size_t rsh = sizeof(int) * ((size_t)nx + 1);
         dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));

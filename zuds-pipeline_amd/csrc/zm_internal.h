@@ -70,6 +70,8 @@ struct zm_ctx {
     int hp_wg_cap = 0;
     bool hp_rset = false, hp_bset = false;
     std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
+    std::vector<double> hp_filt_host;          // the 1-D filter table the device copy (scratch slot "hp_filt") holds
+    const void* hp_filt_dev = nullptr;
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed

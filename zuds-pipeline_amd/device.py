@@ -11,6 +11,7 @@ exchanges row bands of the resampled stacks with an all-to-all and combines its
 own band; subtractions are independent per job.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -242,15 +243,31 @@ class DeviceSubtraction(object):
             check(L.zm_resample_dev(ctx, ref_rms.data_ptr(), None, None, C.byref(self.wref),
                                     C.byref(self.wsci), LAN, fs_rms.value, self.refrms_al.data_ptr(),
                                     self.refrms_al_w.data_ptr(), None), 'align ref rms')
-            # quick_background_estimate x 2 (hotpants.py:65-67)
-            mm = (C.c_double * 4)()
-            check(L.zm_median_mad2_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
-                                       self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
-                                       self.n, mm), 'sci / ref bkg')
-            m1, s1, m2, s2 = (float(v) for v in mm)
-            self.limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
-            p = hp_params(**job_params(seeing, nx, ny, nreg_side, self.limits['il'],
-                                       self.limits['tl'], hotpants_kws))
+            # quick_background_estimate x 2 (hotpants.py:65-67).  Round 4: the estimates stay on the device and
+            # the subtraction takes its lower limits (median - 10 sigma, hotpants.py:69-72) from there - the fit is
+            # enqueued behind them without the host reading them in between; `limits` fetches them afterwards.
+            # ZM_HOST_LIMITS=1: the host round trip of rounds 1 - 3 (A / B, tests: the same products bit for bit).
+            kws = dict(hotpants_kws or {})
+            user_limits = 'il' in kws or 'tl' in kws
+            if os.environ.get('ZM_HOST_LIMITS') == '1' or user_limits:
+                mm = (C.c_double * 4)()
+                check(L.zm_median_mad2_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
+                                           self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
+                                           self.n, mm), 'sci / ref bkg')
+                m1, s1, m2, s2 = (float(v) for v in mm)
+                self._limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
+                p = hp_params(**job_params(seeing, nx, ny, nreg_side, self._limits['il'],
+                                           self._limits['tl'], hotpants_kws))
+            else:
+                if getattr(self, '_lim_dev', None) is None:
+                    self._lim_dev = self.torch.zeros(6, dtype=self.torch.float64, device=self.device)
+                check(L.zm_median_mad2_async_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
+                                                 self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
+                                                 self.n, self._lim_dev.data_ptr()), 'sci / ref bkg')
+                self._limits = None
+                p = hp_params(**job_params(seeing, nx, ny, nreg_side, 0.0, 0.0, hotpants_kws))
+                p.limits_dev = self._lim_dev.data_ptr()
+                p.limits_nsigma = 10.0
             check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
                                     self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
                                     self.bpm.data_ptr(), nx, ny, C.byref(p),
@@ -260,6 +277,19 @@ class DeviceSubtraction(object):
             check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
                                      1 << 17, self.n), 'bit17')
         return self.diff, self.noise, self.submask
+
+    @property
+    def limits(self):
+        """``{'il', 'tl'}``: the lower data limits of the last run (``zuds/hotpants.py:65-72``).  When they
+        were taken on the device this reads the estimates back (a synchronisation) and raises, as the host
+        entry points do, when a frame had no valid pixel."""
+        if getattr(self, '_limits', None) is None:
+            self.stream.synchronize()
+            m1, s1, c1, m2, s2, c2 = (float(v) for v in self._lim_dev.cpu())
+            if not (c1 > 0 and c2 > 0):
+                raise _lib.ZMError('zm_median_mad2: every pixel is masked')
+            self._limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
+        return self._limits
 
 
 # ---------------------------------------------------------------------------

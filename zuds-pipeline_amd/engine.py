@@ -302,7 +302,8 @@ Engine.aperture_photometry = _engine_aperture
 def hp_params(**kw):
     """zm_hp_params with hotpants' defaults, overridden by keyword (tu, tl, iu, il,
     r, rss, fin, fi, nsx, nsy, nrx, nry, ko, bgo, nss, normalize, ft, ks, deg,
-    sigma)."""
+    sigma; limits_dev / limits_nsigma: the lower data limits taken from background
+    estimates that stayed on the device, ``zm_hp_params`` in include/zudsmi.h)."""
     p = _lib.zm_hp_params()
     _lib.lib().zm_hp_params_default(C.byref(p))
     for k, v in kw.items():
@@ -315,6 +316,8 @@ def hp_params(**kw):
                 p.sigma[i] = float(s)
         elif k in ('nsx', 'nsy', 'nrx', 'nry', 'ko', 'bgo', 'nss', 'normalize'):
             setattr(p, k, int(v))
+        elif k == 'limits_dev':
+            p.limits_dev = int(v) if v else None       # device address of the six doubles of zm_median_mad2_async_dev
         elif hasattr(p, k):
             setattr(p, k, float(v))
         else:
