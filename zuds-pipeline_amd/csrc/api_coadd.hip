@@ -501,9 +501,9 @@ extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
         ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
         ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix, (void**)&dst));
         ZM_TRY(zm_launch_prep(ctx, img, wgt, nx, ny, nullptr, 0, 0, 0, nullptr, 1e-30f, src, spitch));
+        // (value and weight leave the resample kernel as the two planes the caller asked for)
         ZM_TRY(zm_launch_resample(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, (float)fscale,
-                                  dst, onx, ony, lds, mask, out_mask, mask ? 1 : 0, 0, 1));
-        ZM_TRY(zm_launch_split_pairs(ctx, dst, opix, out_img, out_wgt));
+                                  dst, onx, ony, lds, mask, out_mask, mask ? 1 : 0, 0, 1, out_img, out_wgt));
     } else if (mask) {
         ZM_TRY(zm_launch_resample_mask(ctx, mask, nx, ny, lat, lnx, lny, kernel, out_mask, onx,
                                        ony, 0));

@@ -772,7 +772,10 @@ __global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
     const int32_t* __restrict__ mask, const uint16_t* __restrict__ mbox, int32_t* __restrict__ macc,
-    int mkind, int mfirst, int ntx, int ntiles, const float* __restrict__ taptab) {
+    int mkind, int mfirst, int ntx, int ntiles, const float* __restrict__ taptab,
+    float* __restrict__ plane_a, float* __restrict__ plane_b) {
+    // (plane_a / plane_b: value and weight as two planes - what an alignment hands back - instead of the pair
+    // plane `dst` that a stack keeps: no pass to split them afterwards)
     extern __shared__ float4 smem4[];
     rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
     // Lanczos-3: the tap table sits between the headers and the pixel tile
@@ -995,7 +998,12 @@ __global__ __launch_bounds__(256, 4) void k_resample(
                 }
             }
             const size_t oidx = (size_t)oy * onx + ox;
-            dst[oidx] = res;
+            if (plane_a) {
+                plane_a[oidx] = res.x;
+                plane_b[oidx] = res.y;
+            } else {
+                dst[oidx] = res;
+            }
             if (MASKOP == 1) {
                 macc[oidx] = mres;
             } else if (MASKOP == 2) {
@@ -1050,7 +1058,7 @@ template <int KIND>
 static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float2* src, int nx, int ny,
                                 int spitch, const double2* lat, int lnx, int lny, float fscale,
                                 float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
-                                int32_t* macc, int mop, int mkind, int mfirst) {
+                                int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b) {
     dim3 blk(256, 1, 1);
     const int ntx = grd.x, ntiles = grd.x * grd.y;
     uint16_t* mbox = nullptr;
@@ -1074,13 +1082,13 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
     dim3 pgrd(std::min(ntiles, 256 * 4), 1, 1);
     if (mop == 0)
         hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
     else if (mop == 1)
         hipLaunchKernelGGL((k_resample<KIND, 1>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
     else
         hipLaunchKernelGGL((k_resample<KIND, 2>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -1090,7 +1098,7 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
                        float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
-                       int32_t* macc, int mop, int mkind, int mfirst) {
+                       int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b) {
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
     dim3 rgrd(zm_div_up(onx, TW), zm_div_up(ony, RTH), 1);     // k_resample: 64 x 32 tiles
     if (!mask || !macc) mop = 0;
@@ -1099,16 +1107,17 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
     if (kernel == ZM_RESAMPLE_LANCZOS3)
         return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                          macc, mop, mkind, mfirst);
+                                                          macc, mop, mkind, mfirst, plane_a, plane_b);
     if (kernel == ZM_RESAMPLE_BILINEAR)
         return launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                           lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                          macc, mop, mkind, mfirst);
+                                                          macc, mop, mkind, mfirst, plane_a, plane_b);
     if (kernel == ZM_RESAMPLE_NEAREST) {
         zm_scope_timer t(ctx, "resample");
         hipLaunchKernelGGL(k_resample_nearest, grd, blk, 0, ctx->stream, src, nx, ny, spitch, lat, lnx,
                            lny, fscale, dst, onx, ony);
         ZM_HIP(hipGetLastError());
+        if (plane_a) ZM_TRY(zm_launch_split_pairs(ctx, dst, (int64_t)onx * ony, plane_a, plane_b));
         if (mop) {
             // nearest neighbour has no footprint: the stand-alone mask kernel + accumulate
             int32_t* tmp = nullptr;

@@ -182,7 +182,8 @@ int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, f
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
                        float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
-                       int32_t* macc, int mop, int mkind, int mfirst);
+                       int32_t* macc, int mop, int mkind, int mfirst,
+                       float* plane_a = nullptr, float* plane_b = nullptr);
 int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny,
                             const double2* lat, int lnx, int lny, int kernel,
                             int32_t* dst, int onx, int ony, int32_t fill);
