@@ -186,6 +186,24 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
+// the same sum for NW waves (a power of two): pairwise - waves that contribute 0 leave the bits alone
+template <int NW>
+__device__ inline double block_sum_waves(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    // (pairwise, block_sum256's grouping for the first four waves)
+    double t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = red[w];
+#pragma unroll
+    for (int step = 1; step < NW; step *= 2)
+#pragma unroll
+        for (int w = 0; w + step < NW; w += 2 * step) t[w] += t[w + step];
+    return t[0];
+}
+
 __device__ inline double block_sum256(double v, double* red) {
     v = wave_sum_d(v);
     __syncthreads();
@@ -415,8 +433,13 @@ __device__ inline double ipowd(double x, int n) {
 #define HV_SPLIT_ALL 5
 #define HV_SPLIT_FEW 15
 
+// Round 4: 512 threads per workgroup.  A pass has 343 (y) or 483 (x) work items of eight outputs: with 256 threads
+// it ran as two rounds, the second a third full, and after the first rejection round the latency of one cell's
+// passes is the kernel time (38 us); the LDS footprint (70 KB) allows two workgroups per CU either way, so 512
+// threads also double the waves that cover each other's LDS reads in the first round.
+#define HV_THREADS 512
 template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
+__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
                                                     const float* __restrict__ ref,
                                                     const float* __restrict__ srms,
                                                     const float* __restrict__ trms,
@@ -427,16 +450,24 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
                                                     double* __restrict__ X,
                                                     double* __restrict__ phi,         // [cell][nkp]
                                                     double* __restrict__ vbar, const int* __restrict__ guard,
-                                                    double* __restrict__ phiold) {
+                                                    double* __restrict__ phiold, const int* __restrict__ list) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double hp_smem[];
     constexpr int STEP = 2 * HWK + 1;
     constexpr int WIN = HV_R + 2 * HWK;
-    const int cell = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int part = blockIdx.y, nparts = gridDim.y;
-    if (!need[cell]) return;
+    // cells: every cell of the grid (first round: list == nullptr), or the cells the last rejection gave a new
+    // substamp (`list`: [count, cells ...], written by k_hp_reject*) - a grid over all 900 cells of which a
+    // handful have work spent a third of the launch dispatching workgroups that return at once
+    const int ncl = list ? list[0] : (int)gridDim.x;
+#pragma unroll 1
+    for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
+    const int cell = list ? list[1 + ci] : ci;
+    __syncthreads();                                     // (the LDS of the cell before is consumed)
+    if (!need[cell]) continue;
     const int act = active[cell];
-    if (act < 0) return;
+    if (act < 0) continue;
     const int2 cc = centres[cell * P.nss + act];
     const int r = cell / P.ncellr;
     const int pw = P.pw, sw = P.sw, hwss = P.hwss;
@@ -446,33 +477,34 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
     const int pp = pw + HV_R;                           // patch row pitch
     double* xp = hp_smem;                               // [pw + HV_R][sw]
     double* w0 = xp + (size_t)(pw + HV_R) * sw;         // [npix]
-    double* red = w0 + P.npix;                          // [4]
-    float* patch = reinterpret_cast<float*>(red + 4);   // [pw][pp]
+    double* red = w0 + P.npix;                          // [8]
+    float* patch = reinterpret_cast<float*>(red + 8);   // [pw][pp]
     // (loads in batches, stores after: a loop of load -> store pays one memory latency per
     // iteration, and after the first round a cell's latency is the kernel time)
-    for (int k0 = tid; k0 < pw * pw; k0 += 256 * 10) {
+    for (int k0 = tid; k0 < pw * pw; k0 += HV_THREADS * 10) {
         float t[10];
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
-            const int k = k0 + 256 * u;
+            const int k = k0 + HV_THREADS * u;
             const int yy = k / pw, xx = k - yy * pw;
             t[u] = (k < pw * pw) ? ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
-            const int k = k0 + 256 * u;
+            const int k = k0 + HV_THREADS * u;
             const int yy = k / pw, xx = k - yy * pw;
             if (k < pw * pw) patch[yy * pp + xx] = t[u];
         }
     }
-    for (int k = tid; k < pw * HV_R; k += 256) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
-    for (int k = tid; k < HV_R * sw; k += 256) xp[(size_t)pw * sw + k] = 0.0;
+    for (int k = tid; k < pw * HV_R; k += HV_THREADS) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
+    for (int k = tid; k < HV_R * sw; k += HV_THREADS) xp[(size_t)pw * sw + k] = 0.0;
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
     double* Xc = X + (size_t)cell * P.nX * P.npixp;
     // science row, background rows, variance mean, zero padding: part 0
     double vs = 0.0;
-    for (int k0 = tid; part == 0 && k0 < P.npixp; k0 += 256 * 5) {
+    // (the first 256 threads, as before: the partial sums of the variance mean keep their grouping)
+    for (int k0 = tid; part == 0 && tid < 256 && k0 < P.npixp; k0 += 256 * 5) {
         float ts[5], ta[5], tb[5];
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
@@ -503,11 +535,13 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             }
         }
     }
-    vs = block_sum256(vs, red);
+    vs = block_sum_waves<HV_THREADS / 64>(vs, red);
     if (tid == 0 && part == 0) {
         vbar[cell] = vs / P.npix;
         double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
         // (the spatial terms of the substamp this one replaces stay available to the fused normal-matrix update)
+        // (one thread: the exponent tables sit in the kernel-argument segment - indexed by a lane they are copied
+        // to scratch by every thread of the launch, and the first round took 365 us instead of 220)
         if (phiold)
             for (int p = 0; p < P.nkp; ++p) phiold[(size_t)cell * P.nkp + p] = phi[(size_t)cell * P.nkp + p];
         for (int p = 0; p < P.nkp; ++p)
@@ -531,7 +565,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         if (!mine && !for_w0) continue;
         const double* fxv = filt + f * STEP;            // uniform address: scalar loads, no LDS traffic
         // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
-        for (int e = tid; e < pw * nstrip; e += 256) {
+        for (int e = tid; e < pw * nstrip; e += HV_THREADS) {
             const int yy = e / nstrip, j0 = (e - yy * nstrip) * HV_R;
             const float* pr = patch + yy * pp + j0;
             double wv[WIN];
@@ -557,7 +591,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
             const double sc = P.tscale[n];
             const bool sub0 = n != 0 && P.tsub0[n] != 0;
             // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
-            for (int e = tid; e < sw * nstrip; e += 256) {
+            for (int e = tid; e < sw * nstrip; e += HV_THREADS) {
                 const int s = e / sw, j = e - s * sw;      // consecutive lanes = consecutive columns
                 const int i0 = s * HV_R;
                 const double* col = xp + i0 * sw + j;
@@ -597,6 +631,7 @@ __global__ __launch_bounds__(256) void k_hp_vectors(const hp_plan P, const float
         }
         __syncthreads();
     }
+    }   // cells
 }
 
 // ---------------------------------------------------------------------------
@@ -613,11 +648,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
                                                  const int* __restrict__ need,
                                                  const int* __restrict__ active,
-                                                 double* __restrict__ Gp, const int* __restrict__ guard) {
+                                                 double* __restrict__ Gp, const int* __restrict__ guard,
+                                                 const int* __restrict__ list) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double L[HP_MAXX * GR_PITCH];
-    const int cell = blockIdx.x, tid = threadIdx.x;
-    if (!need[cell] || active[cell] < 0) return;
+    const int tid = threadIdx.x;
+    const int ncl = list ? list[0] : (int)gridDim.x;     // (k_hp_vectors: the cells with a new substamp)
+#pragma unroll 1
+    for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
+    const int cell = list ? list[1 + ci] : ci;
+    __syncthreads();
+    if (!need[cell] || active[cell] < 0) continue;
     const double* Xc = X + (size_t)cell * P.nX * P.npixp;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -666,26 +707,45 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
             Gc[(size_t)(16 * wave + lk + 4 * rg) * HP_MAXX + 16 * c + li] = acc[c][rg];
+    }   // cells
 }
 
-__global__ __launch_bounds__(256) void k_hp_gram_sum(const double* __restrict__ Gp,
+// (round 4: four entries per thread with all their loads in flight - with sixteen entries per thread taken one
+// after the other the kernel was sixteen memory latencies long, 11 us for a handful of cells)
+#define GS_THREADS 1024
+__global__ __launch_bounds__(GS_THREADS) void k_hp_gram_sum(const double* __restrict__ Gp,
                                                      const int* __restrict__ need,
                                                      const int* __restrict__ active,
                                                      double* __restrict__ G, const int* __restrict__ guard,
-                                                     double* __restrict__ Gold) {
+                                                     double* __restrict__ Gold, const int* __restrict__ list) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
-    const int cell = blockIdx.x;
-    if (!need[cell] || active[cell] < 0) return;
-    const double* src = Gp + (size_t)cell * GR_SPLIT * HP_MAXX * HP_MAXX;
-    double* dst = G + (size_t)cell * HP_MAXX * HP_MAXX;
-    double* old = Gold ? Gold + (size_t)cell * HP_MAXX * HP_MAXX : nullptr;
-    for (int e = threadIdx.x; e < HP_MAXX * HP_MAXX; e += 256) {
-        double v = 0.0;
+    const int ncl = list ? list[0] : (int)gridDim.x;
+    constexpr int NE = HP_MAXX * HP_MAXX / GS_THREADS;   // 4
+#pragma unroll 1
+    for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
+        const int cell = list ? list[1 + ci] : ci;
+        if (!need[cell] || active[cell] < 0) continue;
+        const double* src = Gp + (size_t)cell * GR_SPLIT * HP_MAXX * HP_MAXX;
+        double* dst = G + (size_t)cell * HP_MAXX * HP_MAXX;
+        double* old = Gold ? Gold + (size_t)cell * HP_MAXX * HP_MAXX : nullptr;
+        double part[NE][GR_SPLIT], prev[NE];
 #pragma unroll
-        for (int sl = 0; sl < GR_SPLIT; ++sl) v += src[(size_t)sl * HP_MAXX * HP_MAXX + e];
-        if (old) old[e] = dst[e];        // (the Gram matrix of the substamp this one replaces: the fused normal-matrix update takes it out)
-        dst[e] = v;
-    }
+        for (int q = 0; q < NE; ++q) {
+            const int e = threadIdx.x + GS_THREADS * q;
+#pragma unroll
+            for (int sl = 0; sl < GR_SPLIT; ++sl) part[q][sl] = src[(size_t)sl * HP_MAXX * HP_MAXX + e];
+            prev[q] = old ? dst[e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = threadIdx.x + GS_THREADS * q;
+            double v = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < GR_SPLIT; ++sl) v += part[q][sl];      // slice order: deterministic
+            if (old) old[e] = prev[q];   // (the Gram matrix of the substamp this one replaces: the fused normal-matrix update takes it out)
+            dst[e] = v;
+        }
+    }   // cells
 }
 
 // ---------------------------------------------------------------------------
@@ -2760,10 +2820,12 @@ __global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* 
                                                  const double* __restrict__ vbar,
                                                  const int* __restrict__ active,
                                                  const double* __restrict__ xsol,
-                                                 double* __restrict__ merit, const int* __restrict__ guard) {
+                                                 double* __restrict__ merit, const int* __restrict__ guard,
+                                                 int* __restrict__ needlist) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double c[HP_MAXX];
     const int cell = blockIdx.x, lane = threadIdx.x;
+    if (needlist && cell == 0 && lane == 0) needlist[0] = 0;        // (this round's rejection starts a new list)
     if (active[cell] < 0) { if (lane == 0) merit[cell] = -1.0; return; }
     const int reg = cell / P.ncellr;
     const double* x = xsol + (size_t)reg * P.nunk;
@@ -2794,7 +2856,8 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
                                                    const int2* __restrict__ centres,
                                                    int* __restrict__ active, int* __restrict__ need,
                                                    int* __restrict__ chg, int* __restrict__ nrej,
-                                                   double* __restrict__ stats, const int* __restrict__ guard, int* __restrict__ round_flag) {
+                                                   double* __restrict__ stats, const int* __restrict__ guard, int* __restrict__ round_flag,
+                                                   int* __restrict__ needlist) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double red[4];
     const int reg = blockIdx.x, tid = threadIdx.x;
@@ -2834,7 +2897,10 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
             cnt += 1.0;
             a += 1;
             if (a >= P.nss || centres[cell * P.nss + a].x < 0) a = -1;
-            else need[cell] = 1;
+            else {
+                need[cell] = 1;
+                if (needlist) needlist[1 + atomicAdd(&needlist[0], 1)] = cell;   // (the order does not matter: per-cell work)
+            }
             active[cell] = a;
             chg[cell] = 1;              // its contribution leaves the normal matrix (and may come back)
         }
@@ -2868,7 +2934,7 @@ __global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const do
                                                        int* __restrict__ active, int* __restrict__ need,
                                                        int* __restrict__ chg, int* __restrict__ nrej,
                                                        double* __restrict__ stats, const int* __restrict__ guard,
-                                                       int* __restrict__ round_flag) {
+                                                       int* __restrict__ round_flag, int* __restrict__ needlist) {
     if (guard && *guard == 0) return;
     const int reg = blockIdx.x, lane = threadIdx.x;
     double mv[4];
@@ -2922,6 +2988,9 @@ __global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const do
             }
             need[cell] = nd;
             chg[cell] = changed ? 1 : 0;
+            // the cells with a new substamp, all regions in one list: what the next round's vector / Gram
+            // kernels run over (the order does not matter: per-cell work into per-cell slots)
+            if (nd && needlist) needlist[1 + atomicAdd(&needlist[0], 1)] = cell;
         }
         chm[u] = __ballot(changed);
     }
@@ -3751,6 +3820,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_centres", sizeof(int2) * P.ncell * P.nss, (void**)&centres));
     ZM_TRY(ctx->get("hp_active", sizeof(int) * P.ncell, (void**)&active));
     ZM_TRY(ctx->get("hp_need", sizeof(int) * P.ncell, (void**)&need));
+    int* needlist = nullptr;             // [count, cells ...]: the cells the last rejection gave a new substamp
+    ZM_TRY(ctx->get("hp_needlist", sizeof(int) * ((size_t)P.ncell + 1), (void**)&needlist));
     int* chg = nullptr;                  // cells whose substamp the last rejection changed
     ZM_TRY(ctx->get("hp_chg", sizeof(int) * (2 * (size_t)P.ncell + P.nreg), (void**)&chg));   // flags + per-region lists
     constexpr int HP_NIBUF = 4 * HP_MAXREG + 4;
@@ -3864,7 +3935,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         ZM_HIP(hipGetLastError());
     }
     // LDS of k_hp_vectors
-    size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 4) +
+    size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 8) +
                  sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
 
@@ -3882,6 +3953,9 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_HIP(hipMemsetAsync(rflags, 0, sizeof(int) * 16, st));
     auto enqueue_round = [&](const int rounds) -> int {
         const int* guard = rounds > 1 ? rflags + (rounds - 1) : nullptr;
+        // later rounds: the vector / Gram kernels run over the list of cells with a new substamp; this many
+        // workgroup columns walk it (a handful of cells per round is the rule, more loop)
+        const int ncl_grid = std::min(P.ncell, 48);
         if (rounds > 1) {
             // the rejected cells leave the normal matrix with their old Gram matrices / spatial
             // terms, before k_hp_vectors / k_hp_gram overwrite them
@@ -3895,8 +3969,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             zm_scope_timer t(ctx, "hp_vectors");
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(P.ncell, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), b256, vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar, guard, phiold); break;
+    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(rounds == 1 ? P.ncell : ncl_grid, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
+                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
                 HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
@@ -3908,8 +3982,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         }
         {
             zm_scope_timer t(ctx, "hp_gram");
-            hipLaunchKernelGGL(k_hp_gram, dim3(P.ncell, GR_SPLIT), b256, 0, st, P, X, need, active, Gp, guard);
-            hipLaunchKernelGGL(k_hp_gram_sum, dim3(P.ncell), b256, 0, st, Gp, need, active, G, guard, Gold);
+            hipLaunchKernelGGL(k_hp_gram, dim3(rounds == 1 ? P.ncell : ncl_grid, GR_SPLIT), b256, 0, st, P, X, need, active, Gp, guard,
+                               rounds == 1 ? nullptr : needlist);
+            hipLaunchKernelGGL(k_hp_gram_sum, dim3(rounds == 1 ? P.ncell : ncl_grid), dim3(GS_THREADS), 0, st, Gp, need, active, G, guard, Gold,
+                               rounds == 1 ? nullptr : needlist);
             ZM_HIP(hipGetLastError());
         }
         {
@@ -4095,13 +4171,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 else
                     hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs, guard);
             }
-            hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard);
+            hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard, needlist);
             if (P.ncellr <= 256)
                 hipLaunchKernelGGL(k_hp_reject_wave, dim3(P.nreg), dim3(64), 0, st, P, merit, centres, active, need,
-                                   chg, nrej, stats, guard, rflags + rounds);
+                                   chg, nrej, stats, guard, rflags + rounds, needlist);
             else
                 hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
-                                   nrej, stats, guard, rflags + rounds);
+                                   nrej, stats, guard, rflags + rounds, needlist);
             ZM_HIP(hipGetLastError());
         }
         ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
