@@ -927,6 +927,93 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
     }
 }
 
+// The first round's normal matrix on the f64 matrix cores (round 4).  The block of a pair of source vectors
+// (n1, n2) is a small matrix product over the region's cells, A[p1][p2] = sum_k phi_k[p1] (phi_k[p2] g_k) with
+// g_k = G_k[n1][n2]: C = F1 (F2 diag(g))^T, 15 x 15 (x number of cells) - one wave per pair, a
+// v_mfma_f64_16x16x4 per four cells, the right-hand side riding as column 15 (sum_k phi_k[p1] G_k[n1][nE]).  As
+// scalar sums (k_hp_build_blk, sign 0) every product read LDS three times: 0.7 G reads, 100 us.  The products are
+// grouped differently ((phi g) phi instead of (phi phi) g, four cells per instruction): the entries agree with
+// k_hp_build_blk's to fp64 rounding, not to the bit; the later rounds' updates (k_hp_build_blk, sign 2) take a
+// changed cell's contribution out in their own rounding - a residue of 1e-16 of an entry, far below what the
+// conditioning of the fit resolves (the parity tests against the oracle hold at their tolerances).
+#define BM_CH 128     // cells per chunk
+__global__ __launch_bounds__(256) void k_hp_build_mfma(const hp_plan P, const double* __restrict__ G,
+                                                       const double* __restrict__ phi, const int* __restrict__ active,
+                                                       double* __restrict__ A, double* __restrict__ rhs,
+                                                       unsigned* __restrict__ zero, int nzero) {
+    typedef double bm_double4 __attribute__((ext_vector_type(4)));
+    __shared__ double phs[BM_CH][16];        // spatial terms of the chunk's cells (0 beyond nkp, rows of inactive cells 0)
+    __shared__ double gw[4][2][BM_CH];       // per wave: g_k and the right-hand-side entry of its pair
+    const int reg = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    if (zero && blockIdx.x == 0)             // (the hand-over words of this round's k_chol_df)
+        for (int k = tid; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
+    const int npair = P.nE * (P.nE + 1) / 2;
+    const int pair = blockIdx.x * 4 + wave;
+    const bool have = pair < npair;          // (wave-uniform; every wave takes part in the staging barriers)
+    int n1 = 0, n2 = 0;
+    if (have) {
+        n1 = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+        while (n1 * (n1 + 1) / 2 > pair) --n1;
+        while ((n1 + 1) * (n1 + 2) / 2 <= pair) ++n1;
+        n2 = pair - n1 * (n1 + 1) / 2;
+    }
+    const bool k1 = n1 >= 1 && n1 < P.nc, k2 = n2 >= 1 && n2 < P.nc;   // kernel terms carry spatial factors
+    const int nk = (P.nc - 1) * P.nkp;
+    const int b1 = n1 == 0 ? 0 : (k1 ? 1 + (n1 - 1) * P.nkp : 1 + nk + (n1 - P.nc));
+    const int b2 = n2 == 0 ? 0 : (k2 ? 1 + (n2 - 1) * P.nkp : 1 + nk + (n2 - P.nc));
+    const int np1 = k1 ? P.nkp : 1, np2 = k2 ? P.nkp : 1;
+    bm_double4 c4 = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < P.ncellr; s0 += BM_CH) {
+        const int nch = min(BM_CH, P.ncellr - s0);
+        __syncthreads();
+        for (int e = tid; e < BM_CH * 16; e += 256) {
+            const int k = e >> 4, pp = e & 15;
+            double v = 0.0;
+            if (k < nch && pp < P.nkp) {
+                const int cell = reg * P.ncellr + s0 + k;
+                if (active[cell] >= 0) v = phi[(size_t)cell * P.nkp + pp];
+            }
+            phs[k][pp] = v;
+        }
+        for (int k = lane; k < BM_CH; k += 64) {
+            double g = 0.0, gr = 0.0;
+            if (have && k < nch) {
+                const int cell = reg * P.ncellr + s0 + k;
+                if (active[cell] >= 0) {
+                    const double* Gc = G + (size_t)cell * HP_MAXX * HP_MAXX;
+                    g = Gc[n1 * HP_MAXX + n2];
+                    if (n2 == 0) gr = Gc[n1 * HP_MAXX + P.nE];
+                }
+            }
+            gw[wave][0][k] = g;
+            gw[wave][1][k] = gr;
+        }
+        __syncthreads();
+        if (have) {
+            for (int kk = 0; kk < (nch + 3) / 4; ++kk) {
+                const int k = 4 * kk + lk;                    // (cells beyond the chunk: g = 0 and phi = 0)
+                const double f1 = k1 ? phs[k][li] : (li == 0 ? 1.0 : 0.0);    // (an inactive cell has g = 0 on the other side)
+                const double f2 = k2 ? phs[k][li] : (li == 0 ? 1.0 : 0.0);
+                const double bv = (li == 15) ? gw[wave][1][k] : f2 * gw[wave][0][k];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bv, c4, 0, 0, 0);
+            }
+        }
+    }
+    if (!have) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p1 = lk + 4 * q, p2 = li;
+        if (p1 >= np1) continue;
+        const int c1 = b1 + p1;
+        if (p2 == 15) {
+            if (n2 == 0) rhs[(size_t)reg * P.nunk + c1] = c4[q];
+        } else if (p2 < np2) {
+            const int c2 = b2 + p2;
+            if (c2 <= c1) A[(size_t)reg * (size_t)(P.nunk + 1) * P.nunk + (size_t)c1 * P.nunk + c2] = c4[q];
+        }
+    }
+}
+
 // Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
 __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
@@ -4051,7 +4138,11 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 ZM_TRY(ctx->get("hp_dfdg", sizeof(double) * (size_t)P.nreg * zm_div_up(P.nunk, CH_NB) * CH_NB * (CH_NB + 1),
                                 (void**)&dfdg));
             }
-            if (P.nkp <= 16)
+            static const bool build_scalar = getenv("ZM_BUILD_FORM") && !strcmp(getenv("ZM_BUILD_FORM"), "scalar");
+            if (P.nkp <= 15 && rounds == 1 && !build_scalar)
+                hipLaunchKernelGGL(k_hp_build_mfma, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg), b256, 0, st, P, G, phi, active,
+                                   A0, rhs0, dff, ndff);
+            else if (P.nkp <= 16)
                 hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE * (P.nE + 1) / 2, 1, P.nreg), b256, 0, st, P, G, phi, active, chg,
                                    rounds == 1 ? 0 : 2, A0, rhs0, guard, dff, ndff, Gold, phiold, need);
             else
