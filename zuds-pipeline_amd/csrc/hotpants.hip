@@ -3171,7 +3171,7 @@ template <int HWK> struct apply_cfg {
 };
 
 template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long long solved_mask,
+__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, const unsigned long long* __restrict__ solved_mask,
                                                   const float* __restrict__ sci,
                                                   const float* __restrict__ ref,
                                                   const float* __restrict__ srms,
@@ -3184,7 +3184,7 @@ __global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, unsigned long
                                                   int* __restrict__ nmasked) {
     // every region in one launch: blockIdx.z = region (the grid covers the largest one)
     const int reg = blockIdx.z;
-    const int solved = (int)((solved_mask >> reg) & 1ull);
+    const int solved = (int)((*solved_mask >> reg) & 1ull);      // (k_hp_solved: the fit's outcome, read on the device)
     typedef apply_cfg<HWK> C;
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
     constexpr int TW = C::TW;                 // tile width
@@ -3547,7 +3547,7 @@ __global__ __launch_bounds__(512) void k_hp_ktable(const hp_plan P, const double
 }
 
 template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, unsigned long long solved_mask,
+__global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, const unsigned long long* __restrict__ solved_mask,
                                                     const float* __restrict__ sci,
                                                     const float* __restrict__ ref,
                                                     const float* __restrict__ srms,
@@ -3559,7 +3559,7 @@ __global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, unsigned lo
                                                     float* __restrict__ noise,
                                                     int* __restrict__ nmasked) {
     const int reg = blockIdx.z;
-    const int solved = (int)((solved_mask >> reg) & 1ull);
+    const int solved = (int)((*solved_mask >> reg) & 1ull);      // (k_hp_solved: the fit's outcome, read on the device)
     typedef applyw_cfg<HWK> C;
     constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, NB = C::NBW, TW = C::TW, TP = C::TP, TH = C::TH;
     typedef float ap_v2f __attribute__((ext_vector_type(2)));
@@ -3821,8 +3821,28 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
     return 0;
 }
 
+// Which regions have a usable fit - at least one stamp fitted, no clamped pivot, no wait that gave up, a finite
+// solution - as a bit mask in device memory: the convolution is enqueued right behind the last rejection round and
+// reads it there, instead of the host reading the fit summary first (round 4: three small copies, a
+// synchronisation and ~70 us of idle GPU per subtraction; the host evaluates the same rule on its one copy of
+// the summary after the convolution, for zm_hp_info and for the repeat after a time-out).
+__global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
+                            const int* __restrict__ tmo, const double* __restrict__ x,
+                            unsigned long long* __restrict__ mask) {
+    unsigned long long m = 0;
+    const int reg = threadIdx.x;
+    if (reg < nreg) {
+        const double x0 = x[(size_t)reg * nunk];
+        const bool ok = stats[2 * reg + 1] >= 1.0 && fail[reg] == 0 && tmo[reg] == 0 && isfinite(x0);
+        m = ok ? 1ull << reg : 0ull;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m |= __shfl_xor(m, o);
+    if (threadIdx.x == 0) *mask = m;
+}
+
 template <int HWK>
-static int launch_apply(zm_ctx* ctx, const hp_plan& P, unsigned long long solved_mask, const float* sci,
+static int launch_apply(zm_ctx* ctx, const hp_plan& P, const unsigned long long* solved_mask, const float* sci,
                         const float* ref, const float* srms, const float* trms, const uint8_t* outbad,
                         const double* filt, const double* xsol, float* diff, float* noise,
                         int* nmasked) {
@@ -4283,6 +4303,25 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         rounds = r;
         if (h_rflags[r] == 0) break;
     }
+    // the convolution behind the last round, on the device's own view of which regions are solved
+    {
+        zm_scope_timer t(ctx, "hp_apply");
+        unsigned long long* smask = nullptr;
+        ZM_TRY(ctx->get("hp_smask", sizeof(unsigned long long), (void**)&smask));
+        hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, st, P.nreg, P.nunk, stats, fail, tmo, rhs, smask);
+        {
+#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, smask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
+            switch (P.hwk) {
+                HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
+                HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
+                HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
+                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+            }
+#undef HP_APPLY_CASE
+        }
+    }
+    // ... and ONE read of the fit summary (counters incl. the convolution's masked-pixel count, stamp statistics,
+    // solutions) when everything is done
     ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * HP_NIBUF, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
@@ -4298,30 +4337,12 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     }
     }   // attempts
     fitting.release();
-    // a region is solved when it fitted at least one stamp and the factorisation held
+    // a region is solved when it fitted at least one stamp and the factorisation held (k_hp_solved's rule)
     auto reg_solved = [&](int reg) {
         return h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
                h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x[(size_t)reg * P.nunk]);
     };
-    {
-        zm_scope_timer t(ctx, "hp_apply");
-        unsigned long long solved_mask = 0;
-        for (int reg = 0; reg < P.nreg; ++reg)
-            if (reg_solved(reg)) solved_mask |= 1ull << reg;
-        {
-#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, solved_mask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
-            switch (P.hwk) {
-                HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
-                HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
-                HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
-                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-            }
-#undef HP_APPLY_CASE
-        }
-    }
     if (info) {
-        ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * HP_NIBUF, hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipStreamSynchronize(st));
         memset(info, 0, sizeof(*info));
         double ks = 0, chi = 0;
         int nsolved = 0;
