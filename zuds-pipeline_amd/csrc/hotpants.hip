@@ -431,7 +431,7 @@ __device__ inline double ipowd(double x, int n) {
 // not the throughput, sets the kernel time: the first round runs HV_SPLIT_ALL parts per cell
 // (less of term 0 rebuilt), the later ones HV_SPLIT_FEW.
 #define HV_SPLIT_ALL 5
-#define HV_SPLIT_FEW 15
+#define HV_SPLIT_FEW 16   // later rounds: part 0 = the science / background rows and the spatial terms, 15 parts of filters
 
 // Round 4: 512 threads per workgroup.  A pass has 343 (y) or 483 (x) work items of eight outputs: with 256 threads
 // it ran as two rounds, the second a third full, and after the first rejection round the latency of one cell's
@@ -450,7 +450,8 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
                                                     double* __restrict__ X,
                                                     double* __restrict__ phi,         // [cell][nkp]
                                                     double* __restrict__ vbar, const int* __restrict__ guard,
-                                                    double* __restrict__ phiold, const int* __restrict__ list) {
+                                                    double* __restrict__ phiold, const int* __restrict__ list,
+                                                    int special) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double hp_smem[];
     constexpr int STEP = 2 * HWK + 1;
@@ -471,6 +472,12 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
     const int2 cc = centres[cell * P.nss + act];
     const int r = cell / P.ncellr;
     const int pw = P.pw, sw = P.sw, hwss = P.hwss;
+    // `special` (the later rounds, where a handful of cells is all there is and the slowest workgroup of a cell is
+    // the kernel time): part 0 does nothing but the science row, the background rows, the variance mean and the
+    // spatial terms - ~11 us of loads and a serial loop of one thread that used to sit on top of its share of the
+    // filters - and the filters are dealt to the other parts
+    const bool only_special = special && part == 0;
+    const int fpart = special ? part - 1 : part, fparts = special ? nparts - 1 : nparts;
     // xp has HV_R zero rows below, patch HV_R zero columns to the right of the data: the register
     // windows of the two passes run over the edge unconditionally (a conditional LDS read is
     // waited for one by one)
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
     float* patch = reinterpret_cast<float*>(red + 8);   // [pw][pp]
     // (loads in batches, stores after: a loop of load -> store pays one memory latency per
     // iteration, and after the first round a cell's latency is the kernel time)
-    for (int k0 = tid; k0 < pw * pw; k0 += HV_THREADS * 10) {
+    for (int k0 = tid; !only_special && k0 < pw * pw; k0 += HV_THREADS * 10) {
         float t[10];
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
@@ -548,6 +555,7 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
             phi[(size_t)cell * P.nkp + p] = ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
     }
     __syncthreads();
+    if (only_special) continue;
     const int nstrip = (sw + HV_R - 1) / HV_R;
     // basis vectors: for each x filter, one x pass, then a y pass per term using it.
     // Both passes slide a register window: HV_R outputs share HV_R + 2 HWK loads.
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
         // scalar load and its latency per entry, 15 x 49 of them per workgroup)
         const int tn0 = P.tf0[f], tn1 = tn0 + P.tfn[f];
         if (tn1 == tn0) continue;
-        const bool mine = (fidx % nparts) == part;
+        const bool mine = (fidx % fparts) == fpart;
         ++fidx;
         const bool for_w0 = (P.tfx[0] == f);
         if (!mine && !for_w0) continue;
@@ -4077,7 +4085,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
 #define HP_VEC_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
     hipLaunchKernelGGL(k_hp_vectors<H>, dim3(rounds == 1 ? P.ncell : ncl_grid, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist); break;
+                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist, rounds == 1 ? 0 : 1); break;
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
                 HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
