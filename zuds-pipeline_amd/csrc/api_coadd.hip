@@ -380,6 +380,9 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         }
     }
     ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size()));
+    // the descriptors are final: the item headers go out on the second stream, behind the box-OR planes and the
+    // lattices they read, beside the background chain of the main stream
+    ZM_TRY(zm_launch_fused_headers_early(ctx, ff.data(), n, lnx, lny, onx, ony, lds));
     if (boxes_done) ZM_HIP(hipStreamWaitEvent(ctx->stream, boxes_done, 0));
     S->lds = lds;
     S->any_mask = any_mask;

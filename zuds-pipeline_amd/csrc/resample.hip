@@ -1339,7 +1339,7 @@ static_assert(sizeof(ff_hdr) == FF_HDR_WORDS * 4, "ff_hdr is not its record");
 static_assert(3 * sizeof(ff_hdr) + 4 * 4 + 2 * 8 * 4 <= FF_LDS_HDR, "LDS header area too small");
 
 __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int lnx, int lny, int t, int ntx,
-                                       int onx, int ony, int lds_cap, int dma, ff_hdr* H) {
+                                       int onx, int ony, int lds_cap, int dma, ff_hdr* H, int skip_vscale = 0) {
     constexpr int NT = 6, OFF = -2;
     const int tyi = t / ntx, txi = t - tyi * ntx;
     const zm_ff* F = fr + f;
@@ -1376,7 +1376,7 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         // fast: the box lies on the frame and the tile on the grid - no bounds test anywhere.  edge (staged,
         // not fast): what lies off the frame becomes {0, BIGVAR} at the store.
         H->fast = use_lds && inside;
-        H->vscale = F->vscale ? *F->vscale : 1.f;
+        H->vscale = (F->vscale && !skip_vscale) ? *F->vscale : 1.f;     // (skip_vscale: k_ff_vscale fills it in later)
         H->frame_raw = F->mboxflag ? *F->mboxflag : 1;
 #pragma unroll
         for (int u = 0; u < FF_NSUB; ++u) {
@@ -1558,7 +1558,8 @@ __device__ inline int32_t ff_mask_result(int32_t a) {       // k_mask_accum's co
 // persistent kernel fetches a header two items ahead with one 4-byte load per lane.
 __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr, int nfr, int lnx, int lny,
                                                     int onx, int ony, int lds_cap, int dma, int ntx, int ntiles,
-                                                    int* __restrict__ out, int* __restrict__ tilectr, int ctr0) {
+                                                    int* __restrict__ out, int* __restrict__ tilectr, int ctr0,
+                                                    int skip_vscale) {
     __shared__ ff_hdr H[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) *tilectr = ctr0;     // k_coadd_fused's tile queue starts behind its first wave of tiles
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1566,13 +1567,25 @@ __global__ __launch_bounds__(256) void k_ff_headers(const zm_ff* __restrict__ fr
     const bool live = item < (long long)ntiles * nfr;
     if (live) {
         const int t = (int)(item / nfr), f = (int)(item - (long long)t * nfr);
-        ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, dma, &H[w]);
+        ff_build_header(fr, f, lnx, lny, t, ntx, onx, ony, lds_cap, dma, &H[w], skip_vscale);
     }
     __syncthreads();
     if (live) {
         if (lane < FF_HDR_WORDS) out[item * FF_HDR_WORDS + lane] = ((const int*)&H[w])[lane];
         if (lane + 64 < FF_HDR_WORDS) out[item * FF_HDR_WORDS + 64 + lane] = ((const int*)&H[w])[64 + lane];
     }
+}
+
+// The variance scale of a frame comes out of the background chain (k_var_scale_batch), the rest of a header
+// does not: round 4 builds the headers on the second stream BESIDE the mesh statistics (k_ff_headers with
+// skip_vscale) and this pass drops the one word into every header once the scales exist.
+__global__ __launch_bounds__(256) void k_ff_vscale(const zm_ff* __restrict__ fr, int nfr, long long items,
+                                                   int* __restrict__ out) {
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= items) return;
+    const int f = (int)(item % nfr);
+    const float* vs = fr[f].vscale;
+    reinterpret_cast<float*>(out)[item * FF_HDR_WORDS + offsetof(ff_hdr, vscale) / 4] = vs ? *vs : 1.f;
 }
 
 // ---- the y part of the background spline, once per frame row and mesh column ---------------
@@ -3196,54 +3209,132 @@ void zm_fused_geometry(int* tile_h, int* lds_cap) {
 }
 
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
+// geometry of a fused launch: LDS tile, grid, yield budget (shared by the early header pass and the launch)
+struct ff_geom {
+    bool use_dma;
+    int lds_elems, ntx, ntiles, G, budget;
+    size_t shmem;
+};
+static int ff_geometry(zm_ctx* ctx, int onx, int ony, int lds_elems, ff_geom* g) {
+    g->ntx = zm_div_up(onx, TW);
+    g->ntiles = g->ntx * zm_div_up(ony, FT_H);
+    g->use_dma = ff_use_dma();
+    lds_elems = std::min(std::max(lds_elems, 64), g->use_dma ? FD_LDS_CAP : FF_LDS_CAP);
+    g->lds_elems = (lds_elems + 7) & ~7;
+    g->shmem = g->use_dma ? (size_t)FD_OFF_RAW + 20 * (size_t)g->lds_elems + 4 * 8 * FD_YROWS
+                          : (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)g->lds_elems * (sizeof(float2) + sizeof(uint16_t));
+    ZM_CHECK(g->shmem <= 160 * 1024 / FF_WG_PER_CU, "zm_launch_coadd_fused: LDS tile of %zu bytes", g->shmem);
+    // persistent grid: FF_WG_PER_CU workgroups per CU (what their LDS tiles leave room for), each starting
+    // on the tile of its index and taking further tiles from a queue (a counter behind the item
+    // headers, set to G by k_ff_headers)
+    int ncu = 256;
+    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    g->G = std::min(g->ntiles, std::max(ncu, 1) * FF_WG_PER_CU);
+    // yield mode (a context that shares the GPU: zm_ctx_set_share >= 2, or ZM_FF_YIELD = tiles per workgroup):
+    // more workgroups than fit, each retiring after a few tiles, so that the kernels of other streams get CU
+    // slots while this launch runs (the persistent form holds every slot for its whole 2.4 ms)
+    g->budget = 0;
+    if (g->use_dma) {
+        const char* ye = getenv("ZM_FF_YIELD");
+        g->budget = ye ? atoi(ye) : (ctx->share >= 2 ? 2 : 0);
+        if (g->budget > 0 && (g->ntiles + g->budget - 1) / g->budget > g->G) g->G = (g->ntiles + g->budget - 1) / g->budget;
+        else g->budget = 0;
+    }
+    return 0;
+}
+
+// descriptors to the device + the item headers, on stream `s`; skip_vscale: see k_ff_vscale
+static int ff_upload_and_headers(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
+                                 const ff_geom& g, hipStream_t s, int skip_vscale, zm_ff** dev_out, int** ghdr_out) {
+    // descriptors: pinned staging guarded by an event (a later call must not overwrite a copy in flight)
+    zm_ff *pin = nullptr, *dev = nullptr;
+    int* ghdr = nullptr;
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 10, &ev));
+    ZM_HIP(hipEventSynchronize(ev[5]));
+    ZM_TRY(ctx->get_pinned("ff_frames_h", sizeof(zm_ff) * (size_t)nfr, (void**)&pin));
+    ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
+    ZM_TRY(ctx->get("ff_headers", sizeof(int) * (FF_HDR_WORDS * (size_t)g.ntiles * nfr + 16), (void**)&ghdr));
+    int* tilectr = ghdr + FF_HDR_WORDS * (size_t)g.ntiles * nfr;
+    memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
+    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, s));
+    ZM_HIP(hipEventRecord(ev[5], s));
+    {
+        // (its own scope: `coadd_fused` times the roofline kernel alone, as the kernel trace does)
+        zm_scope_timer th(ctx, "ff_headers");
+        const long long items = (long long)g.ntiles * nfr;
+        hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, dev, nfr,
+                           lnx, lny, onx, ony, g.lds_elems, g.use_dma ? 1 : 0, g.ntx, g.ntiles, ghdr, tilectr, g.G, skip_vscale);
+    }
+    ZM_HIP(hipGetLastError());
+    *dev_out = dev;
+    *ghdr_out = ghdr;
+    return 0;
+}
+
+// Round 4: the item headers of a fused coadd built EARLY, on the context's second stream, beside the mesh
+// statistics (they need the lattices and the box-OR flags - both made on that stream just before - but nothing of
+// the background chain except the variance scales, which k_ff_vscale drops in later): 80 us off the main stream.
+// Call when the descriptors are final; zm_launch_coadd_fused then finds the headers made (ctx->ff_pre_*).
+int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
+                                  int lds_elems) {
+    ctx->ff_pre_valid = false;
+    static const bool fork_off = getenv("ZM_FF_FORK") && getenv("ZM_FF_FORK")[0] == '0';
+    if (!ctx->aux || ctx->timing || fork_off) return 0;      // (scope timers keep a timed kernel on the main stream)
+    ff_geom g;
+    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, &g));
+    zm_ff* dev = nullptr;
+    int* ghdr = nullptr;
+    ZM_TRY(ff_upload_and_headers(ctx, frames_host, nfr, lnx, lny, onx, ony, g, ctx->aux, 1, &dev, &ghdr));
+    hipEvent_t* ev = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 10, &ev));
+    ZM_HIP(hipEventRecord(ev[9], ctx->aux));
+    ctx->ff_pre_valid = true;
+    ctx->ff_pre_nfr = nfr;
+    ctx->ff_pre_onx = onx;
+    ctx->ff_pre_ony = ony;
+    ctx->ff_pre_lds = lds_elems;
+    return 0;
+}
+
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
                           float2* stack, int64_t fstride) {
-    const int ntx = zm_div_up(onx, TW), ntiles = ntx * zm_div_up(ony, FT_H);
     if (unmasked_out) {
         // a mask coadd was asked for but no frame carries a mask: "nothing covered" everywhere
         const size_t opix = (size_t)onx * ony;
         ZM_HIP(hipMemsetAsync(unmasked_out, partial ? 0xFF : 0, sizeof(int32_t) * opix, ctx->stream));
         if (!partial && out_cov) ZM_HIP(hipMemsetAsync(out_cov, 0, sizeof(float) * opix, ctx->stream));
     }
-    const bool use_dma = ff_use_dma();
-    lds_elems = std::min(std::max(lds_elems, 64), use_dma ? FD_LDS_CAP : FF_LDS_CAP);
-    lds_elems = (lds_elems + 7) & ~7;
-    const size_t shmem = use_dma ? (size_t)FD_OFF_RAW + 20 * (size_t)lds_elems + 4 * 8 * FD_YROWS
-                                 : (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)lds_elems * (sizeof(float2) + sizeof(uint16_t));
-    ZM_CHECK(shmem <= 160 * 1024 / FF_WG_PER_CU, "zm_launch_coadd_fused: LDS tile of %zu bytes", shmem);
+    const int lds_in = lds_elems;
+    ff_geom g;
+    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, &g));
+    const bool use_dma = g.use_dma;
+    lds_elems = g.lds_elems;
+    const size_t shmem = g.shmem;
+    const int ntx = g.ntx, ntiles = g.ntiles, G = g.G, budget = g.budget;
     const float* taptab = nullptr;
     ZM_TRY(zm_get_lanczos_table(ctx, &taptab));
-    // descriptors: pinned staging guarded by an event (a later call must not overwrite a copy in flight)
-    zm_ff *pin = nullptr, *dev = nullptr;
+    zm_ff* dev = nullptr;
     int* ghdr = nullptr;
-    hipEvent_t* ev = nullptr;
-    ZM_TRY(zm_get_sync_events(ctx, 7, &ev));
-    ZM_HIP(hipEventSynchronize(ev[5]));
-    ZM_TRY(ctx->get_pinned("ff_frames_h", sizeof(zm_ff) * (size_t)nfr, (void**)&pin));
-    ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
-    ZM_TRY(ctx->get("ff_headers", sizeof(int) * (FF_HDR_WORDS * (size_t)ntiles * nfr + 16), (void**)&ghdr));
-    int* tilectr = ghdr + FF_HDR_WORDS * (size_t)ntiles * nfr;
-    memcpy(pin, frames_host, sizeof(zm_ff) * (size_t)nfr);
-    ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_ff) * (size_t)nfr, hipMemcpyHostToDevice, ctx->stream));
-    ZM_HIP(hipEventRecord(ev[5], ctx->stream));
-    // persistent grid: FF_WG_PER_CU workgroups per CU (what their LDS tiles leave room for), each starting
-    // on the tile of its index and taking further tiles from a queue (a counter behind the item
-    // headers, set to G by k_ff_headers)
-    int ncu = 256;
-    ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    int G = std::min(ntiles, std::max(ncu, 1) * FF_WG_PER_CU);
-    // yield mode (a context that shares the GPU: zm_ctx_set_share >= 2, or ZM_FF_YIELD = tiles per workgroup):
-    // more workgroups than fit, each retiring after a few tiles, so that the kernels of other streams get CU
-    // slots while this launch runs (the persistent form holds every slot for its whole 2.4 ms)
-    int budget = 0;
-    if (use_dma) {
-        const char* ye = getenv("ZM_FF_YIELD");
-        budget = ye ? atoi(ye) : (ctx->share >= 2 ? 2 : 0);
-        if (budget > 0 && (ntiles + budget - 1) / budget > G) G = (ntiles + budget - 1) / budget;
-        else budget = 0;
+    const bool pre = ctx->ff_pre_valid && ctx->ff_pre_nfr == nfr && ctx->ff_pre_onx == onx && ctx->ff_pre_ony == ony &&
+                     ctx->ff_pre_lds == lds_in;
+    ctx->ff_pre_valid = false;
+    if (pre) {
+        // the headers were made on the second stream (zm_launch_fused_headers_early): wait for them, fill in the
+        // variance scales
+        hipEvent_t* ev = nullptr;
+        ZM_TRY(zm_get_sync_events(ctx, 10, &ev));
+        ZM_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
+        ZM_TRY(ctx->get("ff_frames", sizeof(zm_ff) * (size_t)nfr, (void**)&dev));
+        ZM_TRY(ctx->get("ff_headers", sizeof(int) * (FF_HDR_WORDS * (size_t)ntiles * nfr + 16), (void**)&ghdr));
+        const long long items = (long long)ntiles * nfr;
+        hipLaunchKernelGGL(k_ff_vscale, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, dev, nfr, items, ghdr);
+    } else {
+        ZM_TRY(ff_upload_and_headers(ctx, frames_host, nfr, lnx, lny, onx, ony, g, ctx->stream, 0, &dev, &ghdr));
     }
+    int* tilectr = ghdr + FF_HDR_WORDS * (size_t)ntiles * nfr;
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
     // ZM_FF_DBG (developer, tools/ff_probe.py): 1 no pixel work, 2 no prep / LDS store, 4 no staging loads
@@ -3252,13 +3343,6 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
     const int nwv = (use_dma ? FD_THREADS : FF_THREADS) / 64;
     if (want_prof) ZM_TRY(ctx->get("ff_prof", sizeof(long long) * 5 * nwv * (size_t)G, (void**)&prof));
-    {
-        // (its own scope: `coadd_fused` times the roofline kernel alone, as the kernel trace does)
-        zm_scope_timer th(ctx, "ff_headers");
-        const long long items = (long long)ntiles * nfr;
-        hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, ctx->stream, dev, nfr,
-                           lnx, lny, onx, ony, lds_elems, use_dma ? 1 : 0, ntx, ntiles, ghdr, tilectr, G);
-    }
     zm_scope_timer t(ctx, "coadd_fused");
 #define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
     do {                                                                                                       \

@@ -72,6 +72,9 @@ struct zm_ctx {
     std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
     std::vector<double> hp_filt_host;          // the 1-D filter table the device copy (scratch slot "hp_filt") holds
     const void* hp_filt_dev = nullptr;
+    // item headers of a fused coadd made ahead of the launch, on the second stream (zm_launch_fused_headers_early)
+    bool ff_pre_valid = false;
+    int ff_pre_nfr = 0, ff_pre_onx = 0, ff_pre_ony = 0, ff_pre_lds = 0;
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed
@@ -155,6 +158,8 @@ struct zm_boxjob {
 void zm_fused_geometry(int* tile_h, int* lds_cap);
 int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows);
 int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined);
+int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
+                                  int lds_elems);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
