@@ -16,9 +16,23 @@ void zm_wcs_frame(const zm_wcs* w, double fr[9]) {
     fr[6] = cd * ca;  fr[7] = cd * sa;  fr[8] = sd;    // pole (towards CRVAL)
 }
 
+// the polynomial order of a TPV WCS into bits 8 - 11 of the flags of a PRIVATE copy (bit 12: radial terms): what
+// zm_tpv_eval leaves out (zm_wcs.flags of a caller's struct only ever carries bit 0)
+static void mark_order(zm_wcs* w) {
+    w->flags &= 1;
+    if (!(w->flags & 1)) return;
+    const int o1 = zm_tpv_order(w->pv1), o2 = zm_tpv_order(w->pv2);
+    const int order = o1 > o2 ? o1 : o2;
+    const bool radial = w->pv1[3] != 0.0 || w->pv1[11] != 0.0 || w->pv1[23] != 0.0 || w->pv1[39] != 0.0 ||
+                        w->pv2[3] != 0.0 || w->pv2[11] != 0.0 || w->pv2[23] != 0.0 || w->pv2[39] != 0.0;
+    w->flags |= (order << 8) | (radial ? 1 << 12 : 0);
+}
+
 void zm_make_map(const zm_wcs* wout, const zm_wcs* win, zm_map_params* mp) {
     mp->wout = *wout;
     mp->win = *win;
+    mark_order(&mp->wout);
+    mark_order(&mp->win);
     double fo[9], fi[9];
     zm_wcs_frame(wout, fo);
     zm_wcs_frame(win, fi);
