@@ -326,6 +326,29 @@ int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms,
                     const float* ref, const float* ref_rms, const uint8_t* bpm,
                     int nx, int ny, const zm_hp_params* params, float* out_diff,
                     float* out_rms, zm_hp_info* out_info_host);
+/* Many subtractions, one call (round 4; the reference runs one hotpants process per job, 64 per node:
+ * nersc/controller.py:101, scripts/donightly.py:21-40 -> zuds/subtraction.py:144-162).  Every job is what
+ * zm_subtract_dev takes - planes of nx x ny pixels in device memory, its own flags (`params`: the data limits
+ * and fill values may differ from job to job; everything that shapes the fit - half widths, basis, orders,
+ * regions, stamps, thresholds - has to agree, else the call returns non-zero) - and gets the same bits.  The
+ * kernel fit of all jobs runs as ONE chain of launches with the job as a grid dimension (a job that has
+ * converged rides along as empty workgroups), on the one-workgroup-per-region factorisation; validity masks,
+ * stamp search and the final convolution are enqueued job after job.  out_info_host: njobs entries.  A
+ * configuration the batched kernels do not cover (more than 15 spatial kernel terms, more than 960 unknowns or
+ * 256 stamps per region) runs job by job through zm_subtract_dev.  1 <= njobs <= ZM_SUB_BATCH_MAX. */
+#define ZM_SUB_BATCH_MAX 64
+typedef struct zm_sub_job {
+    const float* sci;          /* background-subtracted science frame (+ pedestal) */
+    const float* sci_rms;
+    const float* ref;          /* template on the science grid */
+    const float* ref_rms;
+    const uint8_t* bpm;        /* boolean bad-pixel map or NULL */
+    const zm_hp_params* params;
+    float* out_diff;
+    float* out_rms;
+} zm_sub_job;
+int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* jobs, int nx, int ny,
+                          zm_hp_info* out_info_host);
 int zm_background_dev(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                       int ny, int mesh, int filtersize, float* out_bkg,
                       float* out_rms, float* out_sub, double* out_stats_host);

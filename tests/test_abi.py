@@ -42,7 +42,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     structs = {'zm_wcs': z._lib.zm_wcs, 'zm_frame': z._lib.zm_frame, 'zm_dframe': z._lib.zm_dframe,
                'zm_coadd_params': z._lib.zm_coadd_params, 'zm_hp_params': z._lib.zm_hp_params,
-               'zm_hp_info': z._lib.zm_hp_info, 'zm_mask_plan': z._lib.zm_mask_plan}
+               'zm_hp_info': z._lib.zm_hp_info, 'zm_mask_plan': z._lib.zm_mask_plan,
+               'zm_sub_job': z._lib.zm_sub_job}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zudsmi.h"', 'int main(void) {']
     for name, cls in structs.items():
         lines.append(f'  printf("{name} . %zu\\n", sizeof({name}));')

@@ -13,7 +13,7 @@ from util import pkg, synth
 pytestmark = pytest.mark.gpu
 
 
-def make_jobs(torch, z, s, njob, nx, ny, nreg_side, kws, seed=900):
+def make_jobs(torch, z, s, njob, nx, ny, nreg_side, kws, seed=900, variables=0):
     base = s.ztf_wcs(nx, ny, tpv=True)
     rng = np.random.default_rng(seed)
     nst = int(nx * ny / 2500)
@@ -29,7 +29,15 @@ def make_jobs(torch, z, s, njob, nx, ny, nreg_side, kws, seed=900):
     jobs = []
     for i in range(njob):
         w = s.ztf_wcs(nx, ny, dx=rng.uniform(-6, 6), dy=rng.uniform(-6, 6), rot_deg=rng.uniform(-0.05, 0.05))
-        f = s.make_frame(nx, ny, seed + 1 + i, w, star_sky=(ra, dec, fl), fwhm=2.4, sky=180.0 + 10 * i, nbad=30)
+        fli = fl.copy()
+        if variables:
+            # a few of the brighter stars changed their flux since the reference was taken: their stamps
+            # fail the merit test and the fit needs rejection rounds, more in some jobs than in others
+            # (bright, yet below the saturation limit of the command line - 5e3 at the peak - after the change)
+            cand = np.flatnonzero((fl > 4e3) & (fl < 1e4))
+            pick = rng.choice(cand, size=min((i % 3) * variables, cand.size), replace=False)
+            fli[pick] *= rng.uniform(1.8, 2.5, pick.size)
+        f = s.make_frame(nx, ny, seed + 1 + i, w, star_sky=(ra, dec, fli), fwhm=2.4, sky=180.0 + 10 * i, nbad=30)
         sci = dict(img=dev(f['img'], np.float32), rms=dev(np.full((ny, nx), 5.0), np.float32),
                    mask=dev(f['mask'], np.int32), wgt=dev(f['wgt'], np.float32), wcs=w, seeing=2.4)
         nm = importlib.import_module('zuds-pipeline_amd.nightly')
@@ -148,3 +156,95 @@ def test_differential_fuzz_across_solver_layouts():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(40, 2026, verbose=False) == 0
+
+
+def _same(torch, x, y):
+    assert x['tag'] == y['tag']
+    assert x['info'] == y['info'], (x['info'], y['info'])
+    for k in ('diff', 'noise', 'mask'):
+        assert torch.equal(x[k], y[k]), k
+    for k in ('flux', 'fluxerr', 'flags'):
+        assert np.array_equal(x['phot'][k], y['phot'][k], equal_nan=True), k
+
+
+def test_batched_fits_equal_one_at_a_time(engine):
+    """``SubtractionPool(J, batch=B)``: the kernel fits of B jobs as one chain of launches with the job as a
+    grid dimension (``zm_subtract_batch_dev``).  Same bits as one job at a time, whatever the batch size, the
+    number of lanes and the order of the jobs; jobs that converge in different rounds ride along."""
+    import torch
+    z, s = pkg(), synth()
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    jobs = make_jobs(torch, z, s, 7, 640, 600, 2, {'ko': 1, 'bgo': 0}, seed=900, variables=8)
+    one = nm.SubtractionPool(1)
+    a = one.map(jobs)
+    one.close()
+    print('rounds per job:', [r['info']['niter'] for r in a], 'status', [r['info']['status'] for r in a])
+    assert sum(r['info']['status'] == 0 for r in a) >= 5
+    assert len({r['info']['niter'] for r in a}) > 1            # not every job needs the same rounds
+    p = nm.SubtractionPool(1, batch=4)                          # batches of 4 and 3
+    b = p.map(jobs)
+    p.close()
+    p = nm.SubtractionPool(2, batch=3)                          # two lanes: 3 + 3 + 1 (a batch of one: the lone path)
+    c = p.map(jobs[::-1])[::-1]
+    p.close()
+    for x, y, y2 in zip(a, b, c):
+        _same(torch, x, y)
+        _same(torch, x, y2)
+
+
+def test_batched_fits_at_the_reference_parameters(engine):
+    """3 x 3 regions, ko = 4: 722 unknowns per region, 27 factorisations per launch of the batch."""
+    import torch
+    z, s = pkg(), synth()
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    jobs = make_jobs(torch, z, s, 3, 1280, 1240, 3, {}, seed=950)
+    for j in jobs:
+        j.sci['seeing'] = 3.0
+    one = nm.SubtractionPool(1)
+    a = one.map(jobs)
+    one.close()
+    p = nm.SubtractionPool(1, batch=3)
+    b = p.map(jobs)
+    p.close()
+    for x, y in zip(a, b):
+        assert x['info']['ncoeff'] == 722
+        _same(torch, x, y)
+
+
+def test_batches_are_formed_per_fit_shape(engine):
+    """Jobs whose fits differ in shape (regions, orders, seeing -> half widths) never share a batch; the C entry
+    point refuses such a batch instead of fitting the wrong operator."""
+    import ctypes as C
+    import torch
+    z, s = pkg(), synth()
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    jobs = make_jobs(torch, z, s, 4, 640, 600, 2, {'ko': 1, 'bgo': 0}, seed=1700)
+    jobs[1].nreg_side = 1
+    jobs[2].hotpants_kws = {'ko': 2, 'bgo': 0}
+    jobs[3].sci['seeing'] = 2.9
+    assert len({nm._fit_key(j) for j in jobs}) == 4
+    one = nm.SubtractionPool(1)
+    a = one.map(jobs)
+    one.close()
+    p = nm.SubtractionPool(1, batch=4)
+    b = p.map(jobs)
+    p.close()
+    for x, y in zip(a, b):
+        _same(torch, x, y)
+    # the entry point itself: two jobs, two shapes
+    L = z._lib.lib()
+    ny, nx = 600, 640
+    f = torch.ones((ny, nx), dtype=torch.float32, device='cuda:0')
+    out = torch.empty((4, ny, nx), dtype=torch.float32, device='cuda:0')
+    hp = importlib.import_module('zuds-pipeline_amd.engine').hp_params
+    from_kw = importlib.import_module('zuds-pipeline_amd.hotpants').job_params
+    p0 = hp(**from_kw(2.4, nx, ny, 2, 0.0, 0.0, {'ko': 1}))
+    p1 = hp(**from_kw(2.4, nx, ny, 2, 0.0, 0.0, {'ko': 2}))
+    arr = (z._lib.zm_sub_job * 2)()
+    for k, pp in enumerate((p0, p1)):
+        arr[k] = z._lib.zm_sub_job(f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), None, C.pointer(pp),
+                                   out[2 * k].data_ptr(), out[2 * k + 1].data_ptr())
+    infos = (z._lib.zm_hp_info * 2)()
+    rc = L.zm_subtract_batch_dev(engine.ctx, 2, arr, nx, ny, infos)
+    assert rc != 0 and b'different fit' in L.zm_last_error()
+    assert L.zm_subtract_batch_dev(engine.ctx, 0, arr, nx, ny, infos) != 0

@@ -66,6 +66,14 @@ class zm_hp_params(C.Structure):
                 ('limits_dev', C.c_void_p), ('limits_nsigma', C.c_double)]
 
 
+class zm_sub_job(C.Structure):
+    """One job of ``zm_subtract_batch_dev`` (include/zudsmi.h): device pointers + its hotpants flags."""
+    _fields_ = [('sci', C.c_void_p), ('sci_rms', C.c_void_p), ('ref', C.c_void_p),
+                ('ref_rms', C.c_void_p), ('bpm', C.c_void_p),
+                ('params', C.POINTER(zm_hp_params)),
+                ('out_diff', C.c_void_p), ('out_rms', C.c_void_p)]
+
+
 class zm_hp_info(C.Structure):
     _fields_ = [('nstamps_total', C.c_int32), ('nstamps_used', C.c_int32),
                 ('niter', C.c_int32), ('ncoeff', C.c_int32),
@@ -139,6 +147,8 @@ _SIGS = {
     'zm_subtract_dev': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.POINTER(zm_hp_params), _P, _P,
                                   C.POINTER(zm_hp_info)]),
+    'zm_subtract_batch_dev': (C.c_int, [_P, C.c_int, C.POINTER(zm_sub_job), C.c_int, C.c_int,
+                                        C.POINTER(zm_hp_info)]),
     'zm_median_mad': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),

@@ -439,7 +439,7 @@ __device__ inline double ipowd(double x, int n) {
 // threads also double the waves that cover each other's LDS reads in the first round.
 #define HV_THREADS 512
 template <int HWK>
-__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
+static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const float* __restrict__ sci,
                                                     const float* __restrict__ ref,
                                                     const float* __restrict__ srms,
                                                     const float* __restrict__ trms,
@@ -653,7 +653,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // matrices go to Gp[cell][slice], k_hp_gram_sum adds them in slice order (deterministic).
 // As for the vectors: after the first round a cell's latency sets the kernel time.
 #define GR_SPLIT 8
-__global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
+static __device__ __forceinline__ void hp_gram_body(const hp_plan& P, const double* __restrict__ X,
                                                  const int* __restrict__ need,
                                                  const int* __restrict__ active,
                                                  double* __restrict__ Gp, const int* __restrict__ guard,
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* 
 // (round 4: four entries per thread with all their loads in flight - with sixteen entries per thread taken one
 // after the other the kernel was sixteen memory latencies long, 11 us for a handful of cells)
 #define GS_THREADS 1024
-__global__ __launch_bounds__(GS_THREADS) void k_hp_gram_sum(const double* __restrict__ Gp,
+static __device__ __forceinline__ void hp_gram_sum_body(const double* __restrict__ Gp,
                                                      const int* __restrict__ need,
                                                      const int* __restrict__ active,
                                                      double* __restrict__ G, const int* __restrict__ guard,
@@ -841,19 +841,18 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
 // scalar load) and the spatial terms of its threads, i.e. 2 loads and 3 flops per unknown pair and
 // cell where k_hp_build decodes and gathers per pair (1.2 x 10^8 pair-cell products per round-1
 // build).  Same products, same cell order: the results are identical to the last bit.
-__global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const double* __restrict__ G,
+static __device__ __forceinline__ void hp_build_blk_body(const int reg, const hp_plan& P, const double* __restrict__ G,
                                                       const double* __restrict__ phi,
                                                       const int* __restrict__ active,
                                                       const int* __restrict__ chg, int sign,
                                                       double* __restrict__ A,
                                                       double* __restrict__ rhs, const int* __restrict__ guard,
-                                                      unsigned* __restrict__ zero = nullptr, int nzero = 0,
-                                                      const double* __restrict__ Gold = nullptr,
-                                                      const double* __restrict__ phiold = nullptr,
-                                                      const int* __restrict__ need = nullptr) {
+                                                      unsigned* __restrict__ zero, int nzero,
+                                                      const double* __restrict__ Gold,
+                                                      const double* __restrict__ phiold,
+                                                      const int* __restrict__ need) {
     if (guard && *guard == 0) return;
     // (a triangular grid: x = pair index of (n1, n2 <= n1) - the square grid dispatched as many empty workgroups again)
-    const int reg = blockIdx.z;
     int n1 = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
     while (n1 * (n1 + 1) / 2 > (int)blockIdx.x) --n1;
     while ((n1 + 1) * (n1 + 2) / 2 <= (int)blockIdx.x) ++n1;
@@ -945,7 +944,7 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
 // changed cell's contribution out in their own rounding - a residue of 1e-16 of an entry, far below what the
 // conditioning of the fit resolves (the parity tests against the oracle hold at their tolerances).
 #define BM_CH 128     // cells per chunk
-__global__ __launch_bounds__(256) void k_hp_build_mfma(const hp_plan P, const double* __restrict__ G,
+static __device__ __forceinline__ void hp_build_mfma_body(const hp_plan& P, const double* __restrict__ G,
                                                        const double* __restrict__ phi, const int* __restrict__ active,
                                                        double* __restrict__ A, double* __restrict__ rhs,
                                                        unsigned* __restrict__ zero, int nzero) {
@@ -1023,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_hp_build_mfma(const hp_plan P, const do
 }
 
 // Jacobi scaling: d = sqrt(diag); A <- A / (d d^T); rhs <- rhs / d
-__global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
+static __device__ __forceinline__ void hp_diag_body(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     int reg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
@@ -1031,11 +1030,10 @@ __global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restric
     d[(size_t)reg * n + c] = v > 0.0 ? sqrt(v) : 1.0;
 }
 
-__global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
+static __device__ __forceinline__ void hp_scale_body(const int reg, int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
                            double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar, const int* __restrict__ guard,
                            unsigned* __restrict__ dff, int ndff) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
-    int reg = blockIdx.z;
     int c2 = blockIdx.x * blockDim.x + threadIdx.x, c1 = blockIdx.y;
     if (c1 == 0 && c2 == 0)
         for (int k = 0; k < 4; ++k) bar[reg * CF_BAR_STRIDE + k] = 0;          // arms k_chol_fused's two region barriers
@@ -2705,7 +2703,7 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, double* __restri
 }
 
 // AT: [reg][n][ldt] scratch, ldt = n + 1 rounded up to 16: the panels of L once more, column by column
-__global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, int ldt, double* Aall, double* ATall, int* fail,
+static __device__ __forceinline__ void chol_tp_body(int n, int lda, int ldt, double* Aall, double* ATall, int* fail,
                                                         long long* prof, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ ct_lds S;
@@ -2797,7 +2795,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(int n, int lda, const double
 // (k_chol_back above pays a dependent global load per block on top of it).
 #define CBC_THREADS 1024
 #define CBC_COLS (CBC_THREADS - 64)
-__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, const double* __restrict__ Aall,
+static __device__ __forceinline__ void chol_back_cols_body(int n, int lda, const double* __restrict__ Aall,
                                                                 const double* __restrict__ dall,
                                                                 double* __restrict__ xall, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
@@ -2910,7 +2908,7 @@ __global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, 
 
 // ---------------------------------------------------------------------------
 // merit[cell] = (I.I - 2 c.b + c^T Q c) / (npix vbar), c = per-cell coefficients
-__global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* __restrict__ G,
+static __device__ __forceinline__ void hp_merit_body(const hp_plan& P, const double* __restrict__ G,
                                                  const double* __restrict__ phi,
                                                  const double* __restrict__ vbar,
                                                  const int* __restrict__ active,
@@ -3024,7 +3022,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
 // The same for regions of at most 256 cells, by one wave: lane l keeps cells l, l + 64, l + 128,
 // l + 192 in registers and every sum is a wave reduction - no barrier (the 256-thread version
 // spends its time in fifteen two-barrier block sums over a hundred values).
-__global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const double* __restrict__ merit,
+static __device__ __forceinline__ void hp_reject_wave_body(const hp_plan& P, const double* __restrict__ merit,
                                                        const int2* __restrict__ centres,
                                                        int* __restrict__ active, int* __restrict__ need,
                                                        int* __restrict__ chg, int* __restrict__ nrej,
@@ -3711,6 +3709,160 @@ __global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, const unsig
 }
 
 // ---------------------------------------------------------------------------
+// The kernels of the fit, twice: for ONE subtraction (the arguments are that job's buffers), and for a BATCH of
+// subtractions in one launch (`*_b`: one more grid dimension picks the job, whose buffers come from a table in device
+// memory, read through the scalar cache; its guard is the job's own round flag, so a job that has converged costs
+// empty workgroups while the others go on).  Both forms inline the same body: the same bits per job.
+struct hp_job {                      // one job of a batched fit: its planes and its slice of the batch's scratch
+    const float *sci, *ref, *srms, *trms;
+    int2* centres;
+    int *active, *need, *needlist, *chg, *ibuf, *rflags;
+    unsigned* cbar;
+    double *X, *G, *Gp, *Gold, *phi, *phiold, *vbar, *A, *AT, *rhs, *A0, *rhs0, *dsc, *merit, *stats;
+    unsigned long long* smask;
+};
+#define HPJ_NREJ(J) ((J).ibuf)
+#define HPJ_NTOTAL(J) ((J).ibuf + HP_MAXREG)
+#define HPJ_FAIL(J) ((J).ibuf + 2 * HP_MAXREG)
+#define HPJ_NMASKED(J) ((J).ibuf + 3 * HP_MAXREG)
+#define HPJ_TMO(J) ((J).ibuf + 3 * HP_MAXREG + 4)
+#define HPJ_GUARD(J, round) ((round) > 1 ? (J).rflags + ((round) - 1) : nullptr)
+
+template <int HWK>
+__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
+                                                    const float* __restrict__ ref, const float* __restrict__ srms,
+                                                    const float* __restrict__ trms, const double* __restrict__ filt,
+                                                    const int2* __restrict__ centres, const int* __restrict__ active,
+                                                    const int* __restrict__ need, double* __restrict__ X,
+                                                    double* __restrict__ phi, double* __restrict__ vbar,
+                                                    const int* __restrict__ guard, double* __restrict__ phiold,
+                                                    const int* __restrict__ list, int special) {
+    hp_vectors_body<HWK>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special);
+}
+template <int HWK>
+__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors_b(const hp_plan P, const hp_job* __restrict__ jobs,
+                                                      const double* __restrict__ filt, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_vectors_body<HWK>(P, J.sci, J.ref, J.srms, J.trms, filt, J.centres, J.active, J.need, J.X, J.phi, J.vbar,
+                         HPJ_GUARD(J, round), J.phiold, round > 1 ? J.needlist : nullptr, round > 1 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
+                                                 const int* __restrict__ need, const int* __restrict__ active,
+                                                 double* __restrict__ Gp, const int* __restrict__ guard,
+                                                 const int* __restrict__ list) {
+    hp_gram_body(P, X, need, active, Gp, guard, list);
+}
+__global__ __launch_bounds__(256) void k_hp_gram_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_gram_body(P, J.X, J.need, J.active, J.Gp, HPJ_GUARD(J, round), round > 1 ? J.needlist : nullptr);
+}
+
+__global__ __launch_bounds__(GS_THREADS) void k_hp_gram_sum(const double* __restrict__ Gp, const int* __restrict__ need,
+                                                     const int* __restrict__ active, double* __restrict__ G,
+                                                     const int* __restrict__ guard, double* __restrict__ Gold,
+                                                     const int* __restrict__ list) {
+    hp_gram_sum_body(Gp, need, active, G, guard, Gold, list);
+}
+__global__ __launch_bounds__(GS_THREADS) void k_hp_gram_sum_b(const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_gram_sum_body(J.Gp, J.need, J.active, J.G, HPJ_GUARD(J, round), J.Gold, round > 1 ? J.needlist : nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const double* __restrict__ G,
+                                                      const double* __restrict__ phi, const int* __restrict__ active,
+                                                      const int* __restrict__ chg, int sign, double* __restrict__ A,
+                                                      double* __restrict__ rhs, const int* __restrict__ guard,
+                                                      unsigned* __restrict__ zero = nullptr, int nzero = 0,
+                                                      const double* __restrict__ Gold = nullptr,
+                                                      const double* __restrict__ phiold = nullptr,
+                                                      const int* __restrict__ need = nullptr) {
+    hp_build_blk_body(blockIdx.z, P, G, phi, active, chg, sign, A, rhs, guard, zero, nzero, Gold, phiold, need);
+}
+// (grid: x = pair of source vectors, y = job, z = region)
+__global__ __launch_bounds__(256) void k_hp_build_blk_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.y];
+    hp_build_blk_body(blockIdx.z, P, J.G, J.phi, J.active, J.chg, round == 1 ? 0 : 2, J.A0, J.rhs0, HPJ_GUARD(J, round),
+                      nullptr, 0, J.Gold, J.phiold, J.need);
+}
+
+__global__ __launch_bounds__(256) void k_hp_build_mfma(const hp_plan P, const double* __restrict__ G,
+                                                       const double* __restrict__ phi, const int* __restrict__ active,
+                                                       double* __restrict__ A, double* __restrict__ rhs,
+                                                       unsigned* __restrict__ zero, int nzero) {
+    hp_build_mfma_body(P, G, phi, active, A, rhs, zero, nzero);
+}
+__global__ __launch_bounds__(256) void k_hp_build_mfma_b(const hp_plan P, const hp_job* __restrict__ jobs) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_build_mfma_body(P, J.G, J.phi, J.active, J.A0, J.rhs0, nullptr, 0);
+}
+
+__global__ void k_hp_diag(int n, const double* __restrict__ A, double* __restrict__ d, const int* __restrict__ guard) {
+    hp_diag_body(n, A, d, guard);
+}
+__global__ void k_hp_diag_b(int n, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_diag_body(n, J.A0, J.dsc, HPJ_GUARD(J, round));
+}
+
+__global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const double* __restrict__ rhs0,
+                           double* __restrict__ A, const double* __restrict__ d, unsigned* __restrict__ bar,
+                           const int* __restrict__ guard, unsigned* __restrict__ dff, int ndff) {
+    hp_scale_body(blockIdx.z, n, lda, A0, rhs0, A, d, bar, guard, dff, ndff);
+}
+// (grid: x, y = columns and rows as in k_hp_scale, z = job * nreg + region)
+__global__ void k_hp_scale_b(int n, int lda, int nreg, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z / nreg];
+    hp_scale_body(blockIdx.z % nreg, n, lda, J.A0, J.rhs0, J.A, J.dsc, J.cbar, HPJ_GUARD(J, round), nullptr, 0);
+}
+
+// AT: [reg][n][ldt] scratch, ldt = n + 1 rounded up to 16: the panels of L once more, column by column
+__global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, int ldt, double* Aall, double* ATall, int* fail,
+                                                        long long* prof, const int* __restrict__ guard) {
+    chol_tp_body(n, lda, ldt, Aall, ATall, fail, prof, guard);
+}
+__global__ __launch_bounds__(CT_THREADS) void k_chol_tp_b(int n, int lda, int ldt, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    chol_tp_body(n, lda, ldt, J.A, J.AT, HPJ_FAIL(J), nullptr, HPJ_GUARD(J, round));
+}
+
+__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, const double* __restrict__ Aall,
+                                                                const double* __restrict__ dall,
+                                                                double* __restrict__ xall, const int* __restrict__ guard) {
+    chol_back_cols_body(n, lda, Aall, dall, xall, guard);
+}
+__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols_b(int n, int lda, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    chol_back_cols_body(n, lda, J.A, J.dsc, J.rhs, HPJ_GUARD(J, round));
+}
+
+__global__ __launch_bounds__(64) void k_hp_merit(const hp_plan P, const double* __restrict__ G,
+                                                 const double* __restrict__ phi, const double* __restrict__ vbar,
+                                                 const int* __restrict__ active, const double* __restrict__ xsol,
+                                                 double* __restrict__ merit, const int* __restrict__ guard,
+                                                 int* __restrict__ needlist) {
+    hp_merit_body(P, G, phi, vbar, active, xsol, merit, guard, needlist);
+}
+__global__ __launch_bounds__(64) void k_hp_merit_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_merit_body(P, J.G, J.phi, J.vbar, J.active, J.rhs, J.merit, HPJ_GUARD(J, round), J.needlist);
+}
+
+__global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const double* __restrict__ merit,
+                                                       const int2* __restrict__ centres, int* __restrict__ active,
+                                                       int* __restrict__ need, int* __restrict__ chg,
+                                                       int* __restrict__ nrej, double* __restrict__ stats,
+                                                       const int* __restrict__ guard, int* __restrict__ round_flag,
+                                                       int* __restrict__ needlist) {
+    hp_reject_wave_body(P, merit, centres, active, need, chg, nrej, stats, guard, round_flag, needlist);
+}
+__global__ __launch_bounds__(64) void k_hp_reject_wave_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_reject_wave_body(P, J.merit, J.centres, J.active, J.need, J.chg, HPJ_NREJ(J), J.stats, HPJ_GUARD(J, round),
+                        J.rflags + round, J.needlist);
+}
+
+// ---------------------------------------------------------------------------
 extern "C" void zm_hp_params_default(zm_hp_params* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));
@@ -3834,7 +3986,7 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
 // reads it there, instead of the host reading the fit summary first (round 4: three small copies, a
 // synchronisation and ~70 us of idle GPU per subtraction; the host evaluates the same rule on its one copy of
 // the summary after the convolution, for zm_hp_info and for the repeat after a time-out).
-__global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
+static __device__ __forceinline__ void hp_solved_body(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
                             const int* __restrict__ tmo, const double* __restrict__ x,
                             unsigned long long* __restrict__ mask) {
     unsigned long long m = 0;
@@ -3848,6 +4000,16 @@ __global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats
     for (int o = 32; o >= 1; o >>= 1) m |= __shfl_xor(m, o);
     if (threadIdx.x == 0) *mask = m;
 }
+__global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
+                            const int* __restrict__ tmo, const double* __restrict__ x,
+                            unsigned long long* __restrict__ mask) {
+    hp_solved_body(nreg, nunk, stats, fail, tmo, x, mask);
+}
+__global__ void k_hp_solved_b(int nreg, int nunk, const hp_job* __restrict__ jobs) {
+    const hp_job& J = jobs[blockIdx.z];
+    hp_solved_body(nreg, nunk, J.stats, HPJ_FAIL(J), HPJ_TMO(J), J.rhs, J.smask);
+}
+
 
 template <int HWK>
 static int launch_apply(zm_ctx* ctx, const hp_plan& P, const unsigned long long* solved_mask, const float* sci,
@@ -3902,6 +4064,54 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, const unsigned long long*
     dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
     hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
                        trms, outbad, filt, xsol, diff, noise, nmasked);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+// The validity mask of a subtraction and its two dilations (substamp footprint: `dirty`; kernel footprint: `outbad`)
+static int hp_launch_masks(zm_ctx* ctx, const hp_plan& P, const zm_hp_params* hp, const float* sci, const float* ref,
+                           const uint8_t* bpm, uint8_t* bad, uint8_t* tmp8, uint8_t* dirty, uint8_t* outbad) {
+    const int nx = P.nx, ny = P.ny;
+    const int64_t np = (int64_t)nx * ny;
+    hipStream_t st = ctx->stream;
+    const dim3 b256(256);
+    zm_scope_timer t(ctx, "hp_masks");
+    hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
+                       (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad, hp->limits_dev, hp->limits_nsigma);
+    ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
+    const size_t rsh = sizeof(int) * ((size_t)nx + 1);
+    dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));
+    if (!ctx->hp_rset && rsh > 65536) {
+        ZM_HIP(hipFuncSetAttribute((const void*)k_hp_rowany, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(int) * (HP_ROWMAX + 1))));
+        ctx->hp_rset = true;
+    }
+    hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
+    const bool col4 = (nx % 4 == 0) && (((uintptr_t)tmp8 | (uintptr_t)dirty | (uintptr_t)outbad) & 3) == 0;
+    dim3 gc4(zm_div_up(nx / 4, 256), zm_div_up(ny, HP_COLSTRIP4));
+    if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+    else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+    hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hwk, tmp8);
+    if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+    else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
+// The stamp search of every cell and the first list of active cells
+static int hp_launch_cells(zm_ctx* ctx, const hp_plan& P, const float* ref, const uint8_t* bad, const uint8_t* dirty,
+                           int2* centres, int* active, int* need, int* ntotal) {
+    hipStream_t st = ctx->stream;
+    const dim3 b256(256);
+    zm_scope_timer t(ctx, "hp_cells");
+    int maxcell = 0;
+    for (int r = 0; r < P.nreg; ++r)
+        maxcell = std::max(maxcell, ((P.rx1[r] - P.rx0[r]) / P.nsx) * ((P.ry1[r] - P.ry0[r]) / P.nsy));
+    if (maxcell <= 256 * HC_PX)
+        hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+    else
+        hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+    hipLaunchKernelGGL(k_hp_init_active, dim3(zm_div_up(P.ncell, 256)), b256, 0, st, P, centres, active, need, ntotal);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -3983,28 +4193,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     }
 
     const dim3 b256(256);
-    {
-        zm_scope_timer t(ctx, "hp_masks");
-        hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
-                           (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad, hp->limits_dev, hp->limits_nsigma);
-        ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
-        const size_t rsh = sizeof(int) * ((size_t)nx + 1);
-        dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));
-        if (!ctx->hp_rset && rsh > 65536) {
-            ZM_HIP(hipFuncSetAttribute((const void*)k_hp_rowany, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(int) * (HP_ROWMAX + 1))));
-            ctx->hp_rset = true;
-        }
-        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
-        const bool col4 = (nx % 4 == 0) && (((uintptr_t)tmp8 | (uintptr_t)dirty | (uintptr_t)outbad) & 3) == 0;
-        dim3 gc4(zm_div_up(nx / 4, 256), zm_div_up(ny, HP_COLSTRIP4));
-        if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
-        else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
-        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hwk, tmp8);
-        if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
-        else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
-        ZM_HIP(hipGetLastError());
-    }
+    ZM_TRY(hp_launch_masks(ctx, P, hp, sci, ref, bpm, bad, tmp8, dirty, outbad));
     // The fit (stamp search ... rejection rounds) is one repeatable attempt: when a barrier of the
     // fused factorisation timed out - its workgroups were not all resident, something else held
     // the GPU - every later round worked on a garbage solution, so the whole fit is run again on
@@ -4034,21 +4223,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     const bool safe = attempt > 0;
     const int spin_limit = (!safe && spin_env) ? atoi(spin_env) : CF_SPIN_LIMIT;
     ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * HP_NIBUF, st));
-    {
-        zm_scope_timer t(ctx, "hp_cells");
-        {
-            int maxcell = 0;
-            for (int r = 0; r < P.nreg; ++r)
-                maxcell = std::max(maxcell, ((P.rx1[r] - P.rx0[r]) / P.nsx) * ((P.ry1[r] - P.ry0[r]) / P.nsy));
-            if (maxcell <= 256 * HC_PX)
-                hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
-            else
-                hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
-        }
-        hipLaunchKernelGGL(k_hp_init_active, dim3(zm_div_up(P.ncell, 256)), b256, 0, st, P, centres, active,
-                           need, ntotal);
-        ZM_HIP(hipGetLastError());
-    }
+    ZM_TRY(hp_launch_cells(ctx, P, ref, bad, dirty, centres, active, need, ntotal));
     // LDS of k_hp_vectors
     size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 8) +
                  sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
@@ -4376,6 +4551,243 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         info->status = (nsolved == P.nreg ? 0 : ZM_HP_UNSOLVED);
         info->nunsolved = P.nreg - nsolved;
         info->retries = retries;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Many subtractions in one call (include/zudsmi.h: zm_subtract_batch_dev).  A lone subtraction is bound by the
+// latency of its fit (a dozen small launches per rejection round, a 23-step factorisation); a pool of J contexts on J
+// streams gets at most six kernels in flight whatever J is.  Here the job is a grid dimension of every launch of the
+// fit: nine regions x J jobs of k_chol_tp are 9 J workgroups on 9 J compute units for the time ONE factorisation
+// takes.  The throughput kernels (masks, stamp search, convolution: each fills the GPU alone) are enqueued job after
+// job around it.  Same kernels' bodies, same order of operations per job: the bits of zm_subtract_dev.
+static bool hp_plans_agree(const hp_plan& a, const hp_plan& b) {
+    hp_plan x = a, y = b;
+    x.tu = x.tl = x.iu = x.il = 0; y.tu = y.tl = y.iu = y.il = 0;
+    x.fi = x.fin = 0; y.fi = y.fin = 0;
+    return memcmp(&x, &y, sizeof(hp_plan)) == 0;
+}
+
+extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* jobs, int nx, int ny,
+                                     zm_hp_info* infos) {
+    ZM_CHECK(ctx && jobs && njobs >= 1 && njobs <= ZM_SUB_BATCH_MAX, "zm_subtract_batch_dev: 1 .. %d jobs", ZM_SUB_BATCH_MAX);
+    ZM_CHECK(nx > 0 && ny > 0, "zm_subtract_batch_dev: empty image");
+    ZM_HIP(hipSetDevice(ctx->device));
+    std::vector<hp_plan> Pj(njobs);
+    std::vector<double> filt, basis, filt_j, basis_j;
+    for (int j = 0; j < njobs; ++j) {
+        const zm_sub_job& jb = jobs[j];
+        ZM_CHECK(jb.sci && jb.sci_rms && jb.ref && jb.ref_rms && jb.params && jb.out_diff && jb.out_rms,
+                 "zm_subtract_batch_dev: null argument in job %d", j);
+        ZM_TRY(make_plan(jb.params, nx, ny, &Pj[j], j == 0 ? &filt : &filt_j, j == 0 ? &basis : &basis_j));
+        ZM_CHECK(j == 0 || (hp_plans_agree(Pj[0], Pj[j]) && filt_j == filt),
+                 "zm_subtract_batch_dev: job %d asks for a different fit (half widths, basis, orders, regions, stamps or "
+                 "thresholds) than job 0 - batch jobs of one configuration", j);
+    }
+    const hp_plan& P = Pj[0];
+    ZM_CHECK(nx > 2 * P.hw + 1 && ny > 2 * P.hw + 1, "zm_subtract_batch_dev: image smaller than a substamp");
+    if (P.nkp > 15 || P.nunk > CBC_COLS || P.ncellr > 256 || njobs == 1) {
+        // what the batched kernels do not cover (and the batch of one): job by job
+        for (int j = 0; j < njobs; ++j)
+            ZM_TRY(zm_subtract_dev(ctx, jobs[j].sci, jobs[j].sci_rms, jobs[j].ref, jobs[j].ref_rms, jobs[j].bpm, nx, ny,
+                                   jobs[j].params, jobs[j].out_diff, jobs[j].out_rms, infos ? &infos[j] : nullptr));
+        return 0;
+    }
+    const int64_t np = (int64_t)nx * ny;
+    hipStream_t st = ctx->stream;
+    const int lda = (P.nunk + 15) & ~15;
+    const int ldt = (P.nunk + 1 + 15) & ~15;
+    constexpr int HP_NIBUF = 4 * HP_MAXREG + 4;
+
+    // one slab of scratch per job, every buffer at the same offset in every slab
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_bad = take(np), o_dirty = take(np), o_outbad = take(np);
+    const size_t o_centres = take(sizeof(int2) * P.ncell * P.nss);
+    const size_t o_active = take(sizeof(int) * P.ncell), o_need = take(sizeof(int) * P.ncell);
+    const size_t o_needlist = take(sizeof(int) * ((size_t)P.ncell + 1));
+    const size_t o_chg = take(sizeof(int) * (2 * (size_t)P.ncell + P.nreg));
+    const size_t o_cbar = take(sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG);
+    const size_t o_X = take(sizeof(double) * (size_t)P.ncell * P.nX * P.npixp);
+    const size_t o_G = take(sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX);
+    const size_t o_Gp = take(sizeof(double) * (size_t)P.ncell * GR_SPLIT * HP_MAXX * HP_MAXX);
+    const size_t o_Gold = take(sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX);
+    const size_t o_phi = take(sizeof(double) * (size_t)P.ncell * P.nkp);
+    const size_t o_phiold = take(sizeof(double) * (size_t)P.ncell * P.nkp);
+    const size_t o_vbar = take(sizeof(double) * P.ncell);
+    const size_t o_A = take(sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * lda);
+    const size_t o_AT = take(sizeof(double) * (size_t)P.nreg * P.nunk * ldt);
+    const size_t o_rhs = take(sizeof(double) * (size_t)P.nreg * P.nunk);
+    const size_t o_A0 = take(sizeof(double) * (size_t)P.nreg * (P.nunk + 1) * P.nunk);
+    const size_t o_rhs0 = take(sizeof(double) * (size_t)P.nreg * P.nunk);
+    const size_t o_dsc = take(sizeof(double) * (size_t)P.nreg * P.nunk);
+    const size_t o_merit = take(sizeof(double) * P.ncell);
+    const size_t o_stats = take(sizeof(double) * 2 * HP_MAXREG);
+    const size_t o_smask = take(sizeof(unsigned long long));
+    const size_t slab = off;
+    char* base = nullptr;
+    ZM_TRY(ctx->get("hpb_slab", slab * (size_t)njobs, (void**)&base));
+    uint8_t* tmp8 = nullptr;
+    ZM_TRY(ctx->get("hp_tmp8", np, (void**)&tmp8));
+    int *ibuf_all = nullptr, *rflags_all = nullptr, *h_rflags = nullptr;
+    ZM_TRY(ctx->get("hpb_ibuf", sizeof(int) * HP_NIBUF * (size_t)njobs, (void**)&ibuf_all));
+    ZM_TRY(ctx->get("hpb_rflags", sizeof(int) * 16 * (size_t)njobs, (void**)&rflags_all));
+    // (two host copies of the flags, by parity of the round: the copy of round r + 1 may land while round r's is read)
+    ZM_TRY(ctx->get_pinned("hpb_rflags_h", sizeof(int) * 32 * (size_t)njobs, (void**)&h_rflags));
+    hp_job *h_jobs = nullptr, *d_jobs = nullptr;
+    ZM_TRY(ctx->get_pinned("hpb_jobs_h", sizeof(hp_job) * (size_t)njobs, (void**)&h_jobs));
+    ZM_TRY(ctx->get("hpb_jobs", sizeof(hp_job) * (size_t)njobs, (void**)&d_jobs));
+    double* d_filt = nullptr;
+    ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
+    hipEvent_t* evs = nullptr;
+    ZM_TRY(zm_get_sync_events(ctx, 3, &evs));
+    ZM_HIP(hipStreamSynchronize(st));           // (the pinned tables of the call before are no longer being read)
+    if (!(ctx->hp_filt_dev == (const void*)d_filt && ctx->hp_filt_host == filt)) {
+        double* h_tab = nullptr;
+        ZM_TRY(ctx->get_pinned("hp_tab", sizeof(double) * filt.size(), (void**)&h_tab));
+        memcpy(h_tab, filt.data(), sizeof(double) * filt.size());
+        ZM_HIP(hipMemcpyAsync(d_filt, h_tab, sizeof(double) * filt.size(), hipMemcpyHostToDevice, st));
+        ctx->hp_filt_host = filt;
+        ctx->hp_filt_dev = d_filt;
+    }
+    for (int j = 0; j < njobs; ++j) {
+        char* sb = base + slab * (size_t)j;
+        hp_job& J = h_jobs[j];
+        J.sci = jobs[j].sci; J.ref = jobs[j].ref; J.srms = jobs[j].sci_rms; J.trms = jobs[j].ref_rms;
+        J.centres = (int2*)(sb + o_centres);
+        J.active = (int*)(sb + o_active); J.need = (int*)(sb + o_need); J.needlist = (int*)(sb + o_needlist);
+        J.chg = (int*)(sb + o_chg);
+        J.ibuf = ibuf_all + (size_t)HP_NIBUF * j; J.rflags = rflags_all + 16 * (size_t)j;
+        J.cbar = (unsigned*)(sb + o_cbar);
+        J.X = (double*)(sb + o_X); J.G = (double*)(sb + o_G); J.Gp = (double*)(sb + o_Gp); J.Gold = (double*)(sb + o_Gold);
+        J.phi = (double*)(sb + o_phi); J.phiold = (double*)(sb + o_phiold); J.vbar = (double*)(sb + o_vbar);
+        J.A = (double*)(sb + o_A); J.AT = (double*)(sb + o_AT); J.rhs = (double*)(sb + o_rhs);
+        J.A0 = (double*)(sb + o_A0); J.rhs0 = (double*)(sb + o_rhs0); J.dsc = (double*)(sb + o_dsc);
+        J.merit = (double*)(sb + o_merit); J.stats = (double*)(sb + o_stats);
+        J.smask = (unsigned long long*)(sb + o_smask);
+    }
+    ZM_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(hp_job) * (size_t)njobs, hipMemcpyHostToDevice, st));
+    ZM_HIP(hipMemsetAsync(ibuf_all, 0, sizeof(int) * HP_NIBUF * (size_t)njobs, st));
+    ZM_HIP(hipMemsetAsync(rflags_all, 0, sizeof(int) * 16 * (size_t)njobs, st));
+
+    // per job: validity masks, stamp search
+    for (int j = 0; j < njobs; ++j) {
+        char* sb = base + slab * (size_t)j;
+        const hp_job& J = h_jobs[j];
+        ZM_TRY(hp_launch_masks(ctx, Pj[j], jobs[j].params, jobs[j].sci, jobs[j].ref, jobs[j].bpm, (uint8_t*)(sb + o_bad), tmp8,
+                               (uint8_t*)(sb + o_dirty), (uint8_t*)(sb + o_outbad)));
+        ZM_TRY(hp_launch_cells(ctx, Pj[j], jobs[j].ref, (uint8_t*)(sb + o_bad), (uint8_t*)(sb + o_dirty), J.centres, J.active,
+                               J.need, HPJ_NTOTAL(J)));
+    }
+
+    // the fit of all jobs: the rejection rounds, one ahead of the host as in zm_subtract_dev; a job is guarded by its
+    // own round flags
+    const size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 8) +
+                       sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
+    ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
+    const dim3 b256(256);
+    const unsigned NJ = (unsigned)njobs;
+    auto enqueue_round = [&](const int round) -> int {
+        zm_scope_timer t(ctx, "hpb_fit");
+        const int ncl_grid = std::min(P.ncell, 48);
+        const unsigned gcells = round == 1 ? P.ncell : ncl_grid;
+#define HP_VECB_CASE(H) case H: \
+    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_b<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
+    hipLaunchKernelGGL(k_hp_vectors_b<H>, dim3(gcells, round == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW, NJ), dim3(HV_THREADS), vsh, st, \
+                       P, d_jobs, d_filt, round); break;
+        switch (P.hwk) {
+            HP_VECB_CASE(1) HP_VECB_CASE(2) HP_VECB_CASE(3) HP_VECB_CASE(4) HP_VECB_CASE(5)
+            HP_VECB_CASE(6) HP_VECB_CASE(7) HP_VECB_CASE(8) HP_VECB_CASE(9) HP_VECB_CASE(10)
+            HP_VECB_CASE(11) HP_VECB_CASE(12) HP_VECB_CASE(13) HP_VECB_CASE(14) HP_VECB_CASE(15)
+            default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+        }
+#undef HP_VECB_CASE
+        hipLaunchKernelGGL(k_hp_gram_b, dim3(gcells, GR_SPLIT, NJ), b256, 0, st, P, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_gram_sum_b, dim3(gcells, 1, NJ), dim3(GS_THREADS), 0, st, d_jobs, round);
+        static const bool build_scalar = getenv("ZM_BUILD_FORM") && !strcmp(getenv("ZM_BUILD_FORM"), "scalar");
+        if (round == 1 && !build_scalar)
+            hipLaunchKernelGGL(k_hp_build_mfma_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg, NJ), b256, 0, st, P, d_jobs);
+        else
+            hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
+                           d_jobs, round);
+        hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_jobs, round);
+        hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_merit_b, dim3(P.ncell, 1, NJ), dim3(64), 0, st, P, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_reject_wave_b, dim3(P.nreg, 1, NJ), dim3(64), 0, st, P, d_jobs, round);
+        ZM_HIP(hipGetLastError());
+        ZM_HIP(hipMemcpyAsync(h_rflags + 16 * (size_t)njobs * (round & 1), rflags_all, sizeof(int) * 16 * (size_t)njobs,
+                              hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipEventRecord(evs[1 + (round & 1)], st));
+        return 0;
+    };
+    std::vector<int> rounds(njobs, 0);
+    ZM_TRY(enqueue_round(1));
+    for (int r = 1; r <= 8; ++r) {
+        if (r < 8) ZM_TRY(enqueue_round(r + 1));
+        ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
+        const int* fl = h_rflags + 16 * (size_t)njobs * (r & 1);
+        bool more = false;
+        for (int j = 0; j < njobs; ++j) {
+            if (rounds[j]) continue;                     // (converged in an earlier round)
+            if (fl[16 * j + r] == 0 || r == 8) rounds[j] = r;
+            else more = true;
+        }
+        if (!more) break;
+    }
+
+    // per job: the convolution on the device's view of which regions are solved
+    hipLaunchKernelGGL(k_hp_solved_b, dim3(1, 1, NJ), dim3(64), 0, st, P.nreg, P.nunk, d_jobs);
+    for (int j = 0; j < njobs; ++j) {
+        zm_scope_timer t(ctx, "hp_apply");
+        char* sb = base + slab * (size_t)j;
+        const hp_job& J = h_jobs[j];
+#define HP_APPLYB_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, Pj[j], J.smask, jobs[j].sci, jobs[j].ref, jobs[j].sci_rms, \
+    jobs[j].ref_rms, (uint8_t*)(sb + o_outbad), d_filt, J.rhs, jobs[j].out_diff, jobs[j].out_rms, HPJ_NMASKED(J))); break;
+        switch (P.hwk) {
+            HP_APPLYB_CASE(1) HP_APPLYB_CASE(2) HP_APPLYB_CASE(3) HP_APPLYB_CASE(4) HP_APPLYB_CASE(5)
+            HP_APPLYB_CASE(6) HP_APPLYB_CASE(7) HP_APPLYB_CASE(8) HP_APPLYB_CASE(9) HP_APPLYB_CASE(10)
+            HP_APPLYB_CASE(11) HP_APPLYB_CASE(12) HP_APPLYB_CASE(13) HP_APPLYB_CASE(14) HP_APPLYB_CASE(15)
+            default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+        }
+#undef HP_APPLYB_CASE
+    }
+    // one read of the fit summaries
+    std::vector<int> h_int((size_t)HP_NIBUF * njobs);
+    std::vector<double> h_stats((size_t)2 * HP_MAXREG * njobs), h_x((size_t)P.nreg * P.nunk * njobs);
+    ZM_HIP(hipMemcpyAsync(h_int.data(), ibuf_all, sizeof(int) * h_int.size(), hipMemcpyDeviceToHost, st));
+    for (int j = 0; j < njobs; ++j) {
+        ZM_HIP(hipMemcpyAsync(h_stats.data() + (size_t)2 * HP_MAXREG * j, h_jobs[j].stats, sizeof(double) * 2 * P.nreg,
+                              hipMemcpyDeviceToHost, st));
+        ZM_HIP(hipMemcpyAsync(h_x.data() + (size_t)P.nreg * P.nunk * j, h_jobs[j].rhs, sizeof(double) * (size_t)P.nreg * P.nunk,
+                              hipMemcpyDeviceToHost, st));
+    }
+    ZM_HIP(hipStreamSynchronize(st));
+    for (int j = 0; j < njobs && infos; ++j) {
+        const int* hi = h_int.data() + (size_t)HP_NIBUF * j;
+        const double* hs = h_stats.data() + (size_t)2 * HP_MAXREG * j;
+        const double* hx = h_x.data() + (size_t)P.nreg * P.nunk * j;
+        zm_hp_info* info = &infos[j];
+        memset(info, 0, sizeof(*info));
+        double ks = 0, chi = 0;
+        int nsolved = 0;
+        for (int r = 0; r < P.nreg; ++r) {
+            info->nstamps_total += hi[HP_MAXREG + r];
+            info->nstamps_used += (int)hs[2 * r + 1];
+            const bool solved = hs[2 * r + 1] >= 1.0 && hi[2 * HP_MAXREG + r] == 0 && hi[3 * HP_MAXREG + 4 + r] == 0 &&
+                                std::isfinite(hx[(size_t)r * P.nunk]);
+            if (solved) { ks += hx[(size_t)r * P.nunk]; chi += hs[2 * r]; ++nsolved; }
+        }
+        info->niter = rounds[j];
+        info->ncoeff = P.nunk;
+        info->kernel_sum = nsolved ? ks / nsolved : 0.0;
+        info->chi2 = nsolved ? chi / nsolved : 0.0;
+        info->nmasked = hi[3 * HP_MAXREG];
+        info->status = (nsolved == P.nreg ? 0 : ZM_HP_UNSOLVED);
+        info->nunsolved = P.nreg - nsolved;
+        info->retries = 0;
     }
     return 0;
 }

@@ -192,6 +192,40 @@ class DeviceSubtraction(object):
         science FWHM in pixels (header SEEING); ``ref_flxscale`` the FLXSCALE card of the
         reference (SWarp applies it on resampling, ``swarp.run_align``).
         Returns (diff, noise, submask)."""
+        L, ctx = self.engine.L, self.engine.ctx
+        ny, nx = self.shape
+        scim, p = self.prepare(sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
+                               nreg_side=nreg_side, subtract_back=subtract_back, hotpants_kws=hotpants_kws,
+                               ref_flxscale=ref_flxscale, ref_rms_flxscale=ref_rms_flxscale)
+        with self.torch.cuda.stream(self.stream):
+            check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
+                                    self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
+                                    self.bpm.data_ptr(), nx, ny, C.byref(p),
+                                    self.diff.data_ptr(), self.noise.data_ptr(),
+                                    C.byref(self.info)), 'zm_subtract_dev')
+        return self.finish()
+
+    def job(self, scim, sci_rms, p):
+        """The ``zm_sub_job`` of a prepared chain (``zm_subtract_batch_dev``: many chains, one fit)."""
+        return _lib.zm_sub_job(scim.data_ptr(), sci_rms.data_ptr(), self.ref_al.data_ptr(),
+                               self.refrms_al.data_ptr(), self.bpm.data_ptr(), C.pointer(p),
+                               self.diff.data_ptr(), self.noise.data_ptr())
+
+    def finish(self):
+        """Behind the hotpants step: bit 17 where it masked (subtraction.py:167-177)."""
+        L, ctx = self.engine.L, self.engine.ctx
+        self.engine.set_stream(self.stream.cuda_stream)
+        with self.torch.cuda.stream(self.stream):
+            check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
+                                     1 << 17, self.n), 'bit17')
+        return self.diff, self.noise, self.submask
+
+    def prepare(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
+                nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
+                ref_rms_flxscale=None):
+        """Everything in front of the hotpants step, enqueued on this chain's stream: alignment of the
+        reference and its rms map, bad-pixel map, mesh background, the two background estimates.
+        Returns (science frame minus background, the job's ``zm_hp_params``)."""
         from .engine import hp_params
         from .hotpants import job_params
         L, ctx = self.engine.L, self.engine.ctx
@@ -268,15 +302,8 @@ class DeviceSubtraction(object):
                 p = hp_params(**job_params(seeing, nx, ny, nreg_side, 0.0, 0.0, hotpants_kws))
                 p.limits_dev = self._lim_dev.data_ptr()
                 p.limits_nsigma = 10.0
-            check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
-                                    self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
-                                    self.bpm.data_ptr(), nx, ny, C.byref(p),
-                                    self.diff.data_ptr(), self.noise.data_ptr(),
-                                    C.byref(self.info)), 'zm_subtract_dev')
-            # bit 17 where hotpants masked (subtraction.py:167-177)
-            check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
-                                     1 << 17, self.n), 'bit17')
-        return self.diff, self.noise, self.submask
+        self._sci_rms = sci_rms                          # (kept alive until the fit has read it)
+        return scim, p
 
     @property
     def limits(self):

@@ -10,6 +10,14 @@ steps each - and leaves most of the GPU idle, so this module runs J of them conc
 J engines (contexts, each with its own stream and scratch) driven by J host threads; the
 ctypes calls release the GIL.  ``Engine.set_share(J)`` makes every engine size the solver's
 resident grid to 1 / J of the CUs.  Results do not depend on J (tests/test_nightly_gpu.py).
+
+``SubtractionPool(J, batch=B)`` (round 4) is the other shape of the same work: the hardware runs at most six
+kernels of J streams side by side, so beyond six chains a job's latency sets the rate.  With ``batch`` the kernel
+fits of B jobs are ONE chain of launches with the job as a grid dimension (``zm_subtract_batch_dev``: 9 regions x B
+jobs of the one-workgroup factorisation fill 9 B compute units for the time one factorisation takes); what fills the
+GPU by itself - alignment, backgrounds, masks, stamp search, the convolution - is enqueued job after job around
+it.  J is then the number of such lanes (threads, engines, streams) working on different batches at the same time,
+so that one lane's throughput kernels run beside another lane's fit.  Same products, bit for bit.
 """
 import os
 import threading
@@ -82,37 +90,131 @@ class _Worker(object):
                                    ref['rms'], ref['mask'], seeing=float(sci['seeing']),
                                    nreg_side=job.nreg_side, hotpants_kws=job.hotpants_kws,
                                    ref_flxscale=float(ref.get('flxscale', 1.0)))
-        out = dict(tag=job.tag, info={k: getattr(ch.info, k) for k, _ in ch.info._fields_})
-        if job.radec is not None:
-            # forced photometry on the planes that are still in HBM (scripts/dophot.py:131-133)
-            ra, dec = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in job.radec)
-            x, y = sci['wcs'].all_world2pix(ra, dec, 0)
-            n = x.size
-            with torch.cuda.stream(self.stream):
-                pos = torch.from_numpy(np.ascontiguousarray(np.stack([x, y]))).to(ch.device, non_blocking=True)
-                res = torch.empty((2, n), dtype=torch.float64, device=ch.device)
-                flg = torch.empty(n, dtype=torch.int32, device=ch.device)
-                ny_, nx_ = ch.shape
-                check(self.engine.L.zm_aperture_photometry_dev(
-                    self.engine.ctx, diff.data_ptr(), noise.data_ptr(), mask.data_ptr(), nx_, ny_, n,
-                    pos[0].data_ptr(), pos[1].data_ptr(), float(APERTURE_RADIUS), res[0].data_ptr(),
-                    res[1].data_ptr(), flg.data_ptr()), 'zm_aperture_photometry_dev')
-                res_h, flg_h = res.cpu(), flg.cpu()
-            out['phot'] = dict(x=x, y=y, flux=res_h[0].numpy(), fluxerr=res_h[1].numpy(), flags=flg_h.numpy())
-        if keep:
-            with torch.cuda.stream(self.stream):
-                out['diff'], out['noise'], out['mask'] = diff.clone(), noise.clone(), mask.clone()
+        out = _collect(self, ch, job, ch.info, diff, noise, mask, keep)
         self.stream.synchronize()
-        return out
+        return _settle(out)
+
+
+def _collect(w, ch, job, info, diff, noise, mask, keep):
+    """What a finished chain hands back: the fit summary, the forced photometry on the planes that are
+    still in HBM (scripts/dophot.py:131-133) and, with ``keep``, copies of the three products.  Enqueued on
+    the worker's stream; the caller synchronises."""
+    torch, sci = w.torch, job.sci
+    out = dict(tag=job.tag, info={k: getattr(info, k) for k, _ in info._fields_})
+    if job.radec is not None:
+        ra, dec = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in job.radec)
+        x, y = sci['wcs'].all_world2pix(ra, dec, 0)
+        n = x.size
+        with torch.cuda.stream(w.stream):
+            pos = torch.from_numpy(np.ascontiguousarray(np.stack([x, y]))).to(ch.device, non_blocking=True)
+            res = torch.empty((2, n), dtype=torch.float64, device=ch.device)
+            flg = torch.empty(n, dtype=torch.int32, device=ch.device)
+            ny_, nx_ = ch.shape
+            check(w.engine.L.zm_aperture_photometry_dev(
+                w.engine.ctx, diff.data_ptr(), noise.data_ptr(), mask.data_ptr(), nx_, ny_, n,
+                pos[0].data_ptr(), pos[1].data_ptr(), float(APERTURE_RADIUS), res[0].data_ptr(),
+                res[1].data_ptr(), flg.data_ptr()), 'zm_aperture_photometry_dev')
+            # (copies into pinned memory, not waited for here: a lane enqueues the next job's work first;
+            # _settle turns them into arrays once the stream has been synchronised)
+            res_h = torch.empty((2, n), dtype=torch.float64, pin_memory=True)
+            flg_h = torch.empty(n, dtype=torch.int32, pin_memory=True)
+            res_h.copy_(res, non_blocking=True)
+            flg_h.copy_(flg, non_blocking=True)
+        out['phot'] = dict(x=x, y=y, _pending=(res_h, flg_h, res, flg, pos))
+    if keep:
+        with torch.cuda.stream(w.stream):
+            out['diff'], out['noise'], out['mask'] = diff.clone(), noise.clone(), mask.clone()
+    return out
+
+
+def _settle(out):
+    """After the stream synchronisation: the photometry of ``_collect`` as numpy arrays."""
+    ph = out.get('phot')
+    if ph and '_pending' in ph:
+        res_h, flg_h = ph.pop('_pending')[:2]
+        ph.update(flux=res_h[0].numpy().copy(), fluxerr=res_h[1].numpy().copy(), flags=flg_h.numpy().copy())
+    return out
+
+
+def _fit_key(job):
+    """Jobs whose kernel fits have the same shape (frame size, half widths, basis, orders, regions, stamps,
+    thresholds) can share a batch; data limits and fill values may differ (zm_subtract_batch_dev)."""
+    from .hotpants import job_params
+    ny, nx = (int(v) for v in job.sci['img'].shape)
+    p = job_params(float(job.sci['seeing']), nx, ny, job.nreg_side, 0.0, 0.0, job.hotpants_kws)
+    for k in ('tu', 'tl', 'iu', 'il', 'fin', 'fi'):
+        p.pop(k, None)
+    p['r'], p['rss'] = int(p['r']), int(p['rss'])
+    return (ny, nx) + tuple(sorted((k, tuple(v) if isinstance(v, list) else v) for k, v in p.items()))
+
+
+class _BatchLane(object):
+    """An engine, its stream and up to ``batch`` subtraction chains whose kernel fits run as one batch."""
+
+    def __init__(self, device, batch):
+        import torch
+        self.torch = torch
+        self.engine = Engine(device)
+        self.stream = torch.cuda.Stream(torch.device('cuda', device))
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.device, self.batch = device, batch
+        self.chains, self.key = [], None
+
+    @property
+    def chain(self):
+        return self.chains
+
+    @chain.setter
+    def chain(self, v):                                  # (SubtractionPool.close drops the planes)
+        self.chains = []
+
+    def subtract(self, jobs, keep=True):
+        """``jobs``: at most ``batch`` jobs of one fit key.  Returns their results in order."""
+        import ctypes as C
+        from .device import DeviceSubtraction
+        shape = tuple(jobs[0].sci['img'].shape)
+        if self.key != shape:
+            self.chains, self.key = [], shape            # frees the planes of another frame size first
+        while len(self.chains) < len(jobs):
+            self.chains.append(DeviceSubtraction(jobs[0].sci['wcs'], jobs[0].ref['wcs'], device=self.device,
+                                                 engine=self.engine, stream=self.stream))
+        n = len(jobs)
+        arr = (_lib.zm_sub_job * n)()
+        infos = (_lib.zm_hp_info * n)()
+        held = []
+        for k, job in enumerate(jobs):
+            ch, sci, ref = self.chains[k], job.sci, job.ref
+            ch.wsci = _lib.wcs_struct(sci['wcs'])
+            ch.wref = _lib.wcs_struct(ref['wcs'])
+            scim, p = ch.prepare(sci['img'], sci['rms'], sci['mask'], sci.get('wgt'), ref['img'], ref['rms'],
+                                 ref['mask'], seeing=float(sci['seeing']), nreg_side=job.nreg_side,
+                                 hotpants_kws=job.hotpants_kws, ref_flxscale=float(ref.get('flxscale', 1.0)))
+            arr[k] = ch.job(scim, sci['rms'], p)
+            held.append((scim, p))
+        ny, nx = shape
+        self.engine.set_stream(self.stream.cuda_stream)
+        check(self.engine.L.zm_subtract_batch_dev(self.engine.ctx, n, arr, nx, ny, infos), 'zm_subtract_batch_dev')
+        outs = []
+        for k, job in enumerate(jobs):
+            ch = self.chains[k]
+            C.memmove(C.byref(ch.info), C.byref(infos[k]), C.sizeof(_lib.zm_hp_info))
+            diff, noise, mask = ch.finish()
+            outs.append(_collect(self, ch, job, infos[k], diff, noise, mask, keep))
+        self.stream.synchronize()
+        return [_settle(o) for o in outs]
 
 
 class SubtractionPool(object):
-    """``njobs`` subtraction chains running side by side on one GPU."""
+    """``njobs`` subtraction chains running side by side on one GPU; with ``batch`` >= 2, ``njobs`` lanes of
+    ``batch`` chains each whose kernel fits run as one batch (module docstring)."""
 
-    def __init__(self, njobs=8, device=0):
+    def __init__(self, njobs=8, device=0, batch=0):
         if not 1 <= njobs <= 64:
             raise ValueError('njobs must be in 1 .. 64')
+        if not 0 <= batch <= 64:
+            raise ValueError('batch must be in 0 .. 64')
         self.njobs, self.device = int(njobs), int(device)
+        self.batch = int(batch) if int(batch) >= 2 else 0
         # share >= 2 selects the one-workgroup-per-region form of the kernel fit's factorisation, which
         # claims nothing for itself (a lone job keeps the many-workgroup form); ZM_POOL_SHARE overrides
         # (developer: with ZM_CHOL_FORM=lat it is the fraction of the CUs each job's resident grid gets)
@@ -128,7 +230,8 @@ class SubtractionPool(object):
         if w is None:
             import torch
             torch.cuda.set_device(self.device)
-            w = self._local.w = _Worker(self.device, self.share)
+            w = self._local.w = (_BatchLane(self.device, self.batch) if self.batch
+                                 else _Worker(self.device, self.share))
             with self._lock:
                 self._workers.append(w)
         return w
@@ -141,12 +244,37 @@ class SubtractionPool(object):
         except _lib.ZMError as exc:
             return dict(tag=job.tag, error=str(exc))
 
+    def _run_batch(self, jobs, keep):
+        try:
+            return self._worker().subtract(jobs, keep=keep)
+        except _lib.ZMError:
+            # a batch that fails as a whole is taken apart: every job on its own, failures per job
+            outs = []
+            for job in jobs:
+                try:
+                    outs.extend(self._worker().subtract([job], keep=keep))
+                except _lib.ZMError as exc:
+                    outs.append(dict(tag=job.tag, error=str(exc)))
+            return outs
+
     def map(self, jobs, keep=True):
         """Run every job; results in job order.  ``keep``: clone diff / noise / mask of each job
         out of the worker's planes (off for throughput runs that only want the photometry)."""
         import torch
         torch.cuda.synchronize(self.device)               # inputs produced on other streams are complete
-        return list(self._pool.map(lambda j: self._run(j, keep), jobs))
+        jobs = list(jobs)
+        if not self.batch:
+            return list(self._pool.map(lambda j: self._run(j, keep), jobs))
+        # batches: consecutive jobs of one fit key, at most `batch` of them
+        groups = {}
+        for i, job in enumerate(jobs):
+            groups.setdefault(_fit_key(job), []).append(i)
+        chunks = [idx[k:k + self.batch] for idx in groups.values() for k in range(0, len(idx), self.batch)]
+        results = [None] * len(jobs)
+        for idx, outs in zip(chunks, self._pool.map(lambda c: self._run_batch([jobs[i] for i in c], keep), chunks)):
+            for i, o in zip(idx, outs):
+                results[i] = o
+        return results
 
     def close(self):
         self._pool.shutdown(wait=True)
