@@ -69,6 +69,9 @@ def parse():
     ap.add_argument('--pipelined-depth', type=int, default=4, help='subtractions in flight in the pipelined leg')
     ap.add_argument('--nightly-jobs', type=int, default=32, help='subtractions of the concurrent leg')
     ap.add_argument('--nightly-pools', default='1,2,4,8,16', help='jobs in flight to time in the concurrent leg')
+    ap.add_argument('--nightly-batches', default='1x8,1x16,2x8,2x16,3x8',
+                    help='lanes x batch of the batched pools to time in the concurrent leg (SubtractionPool(J, batch=B): '
+                         'the kernel fits of B jobs as one chain of launches); empty: none')
     ap.add_argument('--dump-coadd', default=None,
                     help='developer / tests: rank 0 saves the coadd planes [img, wgt] (.npy) after the run')
     ap.add_argument('--emulate-ranks', type=int, default=1,
@@ -1006,13 +1009,12 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
         rms = torch.where(wgt > 0, 1.0 / torch.sqrt(wgt.clamp_min(1e-20)), big).to(torch.float32)
         sci = dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=args.seeing)
         jobs.append(nm.SubtractionJob(sci, ref, radec=(ra, dec), nreg_side=3))
-    out = {'jobs': njobs, 'photometry_positions': 500, 'pools': {}}
-    for J in [int(v) for v in args.nightly_pools.split(',')]:
-        if J > njobs:
-            continue
-        pool = nm.SubtractionPool(J, device=local)
+    out = {'jobs': njobs, 'photometry_positions': 500, 'pools': {}, 'batched': {}}
+
+    def timed_pool(J, batch):
+        pool = nm.SubtractionPool(J, device=local, batch=batch)
         try:
-            pool.map(jobs[:J], keep=False)                 # allocations, code objects
+            pool.map(jobs[:max(J * max(batch, 1), 1)], keep=False)      # allocations, code objects
             torch.cuda.synchronize()
             reps = []
             for _ in range(2):                             # (host threads: the faster of two passes)
@@ -1025,12 +1027,27 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
             pool.close()
         # (a job that raised comes back as {'tag', 'error'} without 'info': nightly.SubtractionPool._run)
         bad = [r for r in res if 'error' in r or r['info']['status'] != 0]
-        out['pools'][str(J)] = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
-                                'passes_ms': [1e3 * t / njobs for t in reps], 'failed': len(bad)}
+        rec = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
+               'passes_ms': [1e3 * t / njobs for t in reps], 'failed': len(bad)}
         errs = [r['error'] for r in bad if 'error' in r]
         if errs:
-            out['pools'][str(J)]['first_error'] = str(errs[0])[:200]
-    best = max(out['pools'].values(), key=lambda v: v['subtract_mpix_s'])
+            rec['first_error'] = str(errs[0])[:200]
+        return rec
+
+    for J in [int(v) for v in args.nightly_pools.split(',')]:
+        if J <= njobs:
+            out['pools'][str(J)] = timed_pool(J, 0)
+    # the batched form: `lanes x batch` - the fits of `batch` jobs are one chain of launches (zm_subtract_batch_dev)
+    for spec in [v for v in args.nightly_batches.split(',') if v]:
+        J, B = (int(v) for v in spec.split('x'))
+        if J * B <= njobs:
+            out['batched'][spec] = timed_pool(J, B)
+    if out['batched']:
+        bb = max(out['batched'].items(), key=lambda kv: kv[1]['subtract_mpix_s'])
+        out['batched_best'] = {'lanes_x_batch': bb[0], 'ms_per_subtraction': bb[1]['ms_per_subtraction'],
+                               'over_one_worker': out['pools']['1']['ms_per_subtraction'] / bb[1]['ms_per_subtraction']
+                               if '1' in out['pools'] else None}
+    best = max(list(out['pools'].values()) + list(out['batched'].values()), key=lambda v: v['subtract_mpix_s'])
     out['subtract_mpix_s'] = best['subtract_mpix_s']
     return out
 

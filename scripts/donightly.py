@@ -103,6 +103,9 @@ def main(argv=None):
     ap.add_argument('--jobs', type=int, default=4, help='subtractions in flight on the GPU')
     ap.add_argument('--nreg-side', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='science frames resident at a time')
+    ap.add_argument('--fit-batch', type=int, default=0,
+                    help='kernel fits per launch chain (SubtractionPool(jobs, batch=N): --jobs lanes whose N fits run '
+                         'as one batch, zm_subtract_batch_dev); 0: one chain per job')
     args = ap.parse_args(argv)
 
     nightly = importlib.import_module('zuds-pipeline_amd.nightly')
@@ -119,7 +122,7 @@ def main(argv=None):
 
     io = device.FITSDeviceIO(local, engine=zuds.Engine(local))
     ref = load_reference(io, args.refname)
-    pool = nightly.SubtractionPool(args.jobs, device=local)
+    pool = nightly.SubtractionPool(args.jobs, device=local, batch=args.fit_batch)
     done = []
     try:
         for b0 in range(0, len(imgs), args.batch):

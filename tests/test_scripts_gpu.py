@@ -71,6 +71,18 @@ def test_donightly_products_equal_the_object_api(tmp_path, engine):
     # a second run finds its products and does nothing
     assert script.main([os.path.join(d, 'images.txt'), refname, '--jobs', '2', '--nreg-side', '1']) == []
     got = {}
+    first = {out: [open(out.replace('.fits', sfx), 'rb').read() for sfx in ('.fits', '.rms.fits', '.mask.fits', '.phot.txt')]
+             for out in done}
+    for out in done:
+        for suffix in ('.fits', '.rms.fits', '.mask.fits', '.phot.txt'):
+            os.remove(out.replace('.fits', suffix))
+    # ... and with the three kernel fits as one batch of launches (--fit-batch): the same files, byte for byte
+    again = script.main([os.path.join(d, 'images.txt'), refname, os.path.join(d, 'positions.txt'),
+                         '--jobs', '1', '--fit-batch', '3', '--nreg-side', '1'])
+    assert again == done
+    for out in done:
+        for k, sfx in enumerate(('.fits', '.rms.fits', '.mask.fits', '.phot.txt')):
+            assert open(out.replace('.fits', sfx), 'rb').read() == first[out][k], (out, sfx)
     for out in done:
         assert os.path.basename(out) == os.path.basename(z.sub_name(names[done.index(out)], refname))
         got[out] = [z.fits.read(out)[0], z.fits.read(out.replace('.fits', '.rms.fits'))[0],

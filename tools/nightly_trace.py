@@ -1,5 +1,5 @@
 """Developer tool: J subtractions side by side (nightly.SubtractionPool) on synthetic config-2 data,
-for a kernel trace.  usage: nightly_trace.py J [njobs]   (rocprofv3 --kernel-trace -- python3 tools/nightly_trace.py 4)
+for a kernel trace.  usage: nightly_trace.py J [njobs [batch]]   (batch >= 2: J lanes of batched fits; rocprofv3 --kernel-trace -- python3 tools/nightly_trace.py 4)
 Prints ms per subtraction; tools/rocpd_overlap.py turns the trace into per-kernel times and the overlap."""
 import importlib
 import os
@@ -17,6 +17,7 @@ def main():
     import torch
     J = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     njobs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     size = 3072
     z = importlib.import_module('zuds-pipeline_amd')
     synth = importlib.import_module('zuds-pipeline_amd.synth')
@@ -55,16 +56,16 @@ def main():
         rms = torch.where(wgt > 0, 1.0 / torch.sqrt(wgt.clamp_min(1e-20)), float(np.sqrt(50000.0))).to(torch.float32)
         jobs.append(nm.SubtractionJob(dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=4.0), ref,
                                       radec=(ra, dec), nreg_side=3))
-    pool = nm.SubtractionPool(J, device=0)
+    pool = nm.SubtractionPool(J, device=0, batch=batch)
     try:
-        pool.map(jobs[:J], keep=False)
+        pool.map(jobs[:J * max(batch, 1)], keep=False)
         torch.cuda.synchronize()
         for rep in range(2):
             t0 = time.perf_counter()
             res = pool.map(jobs, keep=False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(f'J = {J}: {1e3 * dt / njobs:.2f} ms per subtraction ({njobs} jobs, '
+            print(f'J = {J} batch = {batch}: {1e3 * dt / njobs:.2f} ms per subtraction ({njobs} jobs, '
                   f'{sum(("error" in r) or r["info"]["status"] != 0 for r in res)} failed)', flush=True)
     finally:
         pool.close()

@@ -3810,10 +3810,32 @@ __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const 
                            const int* __restrict__ guard, unsigned* __restrict__ dff, int ndff) {
     hp_scale_body(blockIdx.z, n, lda, A0, rhs0, A, d, bar, guard, dff, ndff);
 }
-// (grid: x, y = columns and rows as in k_hp_scale, z = job * nreg + region)
-__global__ void k_hp_scale_b(int n, int lda, int nreg, const hp_job* __restrict__ jobs, int round) {
-    const hp_job& J = jobs[blockIdx.z / nreg];
-    hp_scale_body(blockIdx.z % nreg, n, lda, J.A0, J.rhs0, J.A, J.dsc, J.cbar, HPJ_GUARD(J, round), nullptr, 0);
+// The batch's form: a workgroup takes HSB_ROWS rows of one region of one job (grid: x = row block, y = job * nreg +
+// region) - k_hp_scale's grid of one workgroup per row and 256 columns is 312 000 workgroups for 16 jobs and is bound
+// by their dispatch (222 us, whatever the number of jobs still fitting).  The arithmetic per entry is k_hp_scale's.
+#define HSB_ROWS 8
+__global__ __launch_bounds__(256) void k_hp_scale_b(int n, int lda, int nreg, const hp_job* __restrict__ jobs, int round) {
+    const hp_job& J = jobs[blockIdx.y / nreg];
+    const int* guard = HPJ_GUARD(J, round);
+    if (guard && *guard == 0) return;
+    const int reg = blockIdx.y % nreg;
+    const double* __restrict__ dd = J.dsc + (size_t)reg * n;
+    const double* __restrict__ A0 = J.A0 + (size_t)reg * (size_t)(n + 1) * n;
+    const double* __restrict__ rhs0 = J.rhs0 + (size_t)reg * n;
+    double* __restrict__ A = J.A + (size_t)reg * (size_t)(n + 1) * lda;
+#pragma unroll 1
+    for (int k = 0; k < HSB_ROWS; ++k) {
+        const int c1 = blockIdx.x * HSB_ROWS + k;
+        if (c1 >= n) break;
+        const double r1 = 1.0 / dd[c1];
+        for (int c2 = threadIdx.x; c2 <= c1; c2 += 256) {
+            const double r2 = 1.0 / dd[c2];
+            double v = __dmul_rn(A0[(size_t)c1 * n + c2], __dmul_rn(r1, r2));
+            if (c1 == c2) v = __dadd_rn(v, HP_RIDGE);
+            A[(size_t)c1 * lda + c2] = v;
+        }
+        if (threadIdx.x == 0) A[(size_t)n * lda + c1] = __dmul_rn(rhs0[c1], r1);   // rhs row
+    }
 }
 
 // AT: [reg][n][ldt] scratch, ldt = n + 1 rounded up to 16: the panels of L once more, column by column
@@ -4690,7 +4712,9 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     const unsigned NJ = (unsigned)njobs;
     auto enqueue_round = [&](const int round) -> int {
         zm_scope_timer t(ctx, "hpb_fit");
-        const int ncl_grid = std::min(P.ncell, 48);
+        // (later rounds: a job has a handful of cells with a new substamp; the workgroup columns walk its list - a
+        // dozen per job here, where the lone subtraction takes 48: the batch pays for every empty workgroup J times)
+        const int ncl_grid = std::min(P.ncell, 12);
         const unsigned gcells = round == 1 ? P.ncell : ncl_grid;
 #define HP_VECB_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_b<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
@@ -4711,7 +4735,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         else
             hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_jobs, round);
         hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_jobs, round);
-        hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, 256), P.nunk, P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
+        hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, HSB_ROWS), P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
                            d_jobs, round);
         hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_jobs, round);
         hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_jobs, round);
