@@ -4657,9 +4657,10 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     ZM_TRY(ctx->get("hpb_rflags", sizeof(int) * 16 * (size_t)njobs, (void**)&rflags_all));
     // (two host copies of the flags, by parity of the round: the copy of round r + 1 may land while round r's is read)
     ZM_TRY(ctx->get_pinned("hpb_rflags_h", sizeof(int) * 32 * (size_t)njobs, (void**)&h_rflags));
+    // job tables: the full one, and one per later round holding only the jobs that can still be fitting then
     hp_job *h_jobs = nullptr, *d_jobs = nullptr;
-    ZM_TRY(ctx->get_pinned("hpb_jobs_h", sizeof(hp_job) * (size_t)njobs, (void**)&h_jobs));
-    ZM_TRY(ctx->get("hpb_jobs", sizeof(hp_job) * (size_t)njobs, (void**)&d_jobs));
+    ZM_TRY(ctx->get_pinned("hpb_jobs_h", sizeof(hp_job) * (size_t)njobs * 9, (void**)&h_jobs));
+    ZM_TRY(ctx->get("hpb_jobs", sizeof(hp_job) * (size_t)njobs * 9, (void**)&d_jobs));
     double* d_filt = nullptr;
     ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
     hipEvent_t* evs = nullptr;
@@ -4709,9 +4710,23 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
                        sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
     ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
     const dim3 b256(256);
-    const unsigned NJ = (unsigned)njobs;
+    // A job leaves the launches two rounds after it converged: round r + 1 is enqueued when the host has the flags
+    // of round r - 1, and takes the jobs that rejected something then (the others' rounds would be void anyway: the
+    // table of a later round is the list of jobs that can still be fitting, and the grids shrink with it)
+    std::vector<int> live(njobs);
+    for (int j = 0; j < njobs; ++j) live[j] = j;
     auto enqueue_round = [&](const int round) -> int {
         zm_scope_timer t(ctx, "hpb_fit");
+        const hp_job* d_tab = d_jobs;
+        unsigned NJ = (unsigned)njobs;
+        if (round >= 3) {
+            hp_job* h_tab = h_jobs + (size_t)njobs * (round - 1);
+            for (size_t k = 0; k < live.size(); ++k) h_tab[k] = h_jobs[live[k]];
+            NJ = (unsigned)live.size();
+            if (NJ == 0) return 0;
+            d_tab = d_jobs + (size_t)njobs * (round - 1);
+            ZM_HIP(hipMemcpyAsync((void*)d_tab, h_tab, sizeof(hp_job) * NJ, hipMemcpyHostToDevice, st));
+        }
         // (later rounds: a job has a handful of cells with a new substamp; the workgroup columns walk its list - a
         // dozen per job here, where the lone subtraction takes 48: the batch pays for every empty workgroup J times)
         const int ncl_grid = std::min(P.ncell, 12);
@@ -4719,7 +4734,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
 #define HP_VECB_CASE(H) case H: \
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_b<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
     hipLaunchKernelGGL(k_hp_vectors_b<H>, dim3(gcells, round == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW, NJ), dim3(HV_THREADS), vsh, st, \
-                       P, d_jobs, d_filt, round); break;
+                       P, d_tab, d_filt, round); break;
         switch (P.hwk) {
             HP_VECB_CASE(1) HP_VECB_CASE(2) HP_VECB_CASE(3) HP_VECB_CASE(4) HP_VECB_CASE(5)
             HP_VECB_CASE(6) HP_VECB_CASE(7) HP_VECB_CASE(8) HP_VECB_CASE(9) HP_VECB_CASE(10)
@@ -4727,47 +4742,36 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
         }
 #undef HP_VECB_CASE
-        hipLaunchKernelGGL(k_hp_gram_b, dim3(gcells, GR_SPLIT, NJ), b256, 0, st, P, d_jobs, round);
-        hipLaunchKernelGGL(k_hp_gram_sum_b, dim3(gcells, 1, NJ), dim3(GS_THREADS), 0, st, d_jobs, round);
+        hipLaunchKernelGGL(k_hp_gram_b, dim3(gcells, GR_SPLIT, NJ), b256, 0, st, P, d_tab, round);
+        hipLaunchKernelGGL(k_hp_gram_sum_b, dim3(gcells, 1, NJ), dim3(GS_THREADS), 0, st, d_tab, round);
         static const bool build_scalar = getenv("ZM_BUILD_FORM") && !strcmp(getenv("ZM_BUILD_FORM"), "scalar");
         if (round == 1 && !build_scalar)
-            hipLaunchKernelGGL(k_hp_build_mfma_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg, NJ), b256, 0, st, P, d_jobs);
+            hipLaunchKernelGGL(k_hp_build_mfma_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg, NJ), b256, 0, st, P, d_tab);
         else
-            hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_jobs, round);
-        hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_jobs, round);
+            hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_tab, round);
+        hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_tab, round);
         hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, HSB_ROWS), P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
-                           d_jobs, round);
-        hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_jobs, round);
-        hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_jobs, round);
-        hipLaunchKernelGGL(k_hp_merit_b, dim3(P.ncell, 1, NJ), dim3(64), 0, st, P, d_jobs, round);
-        hipLaunchKernelGGL(k_hp_reject_wave_b, dim3(P.nreg, 1, NJ), dim3(64), 0, st, P, d_jobs, round);
+                           d_tab, round);
+        hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_tab, round);
+        hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_tab, round);
+        hipLaunchKernelGGL(k_hp_merit_b, dim3(P.ncell, 1, NJ), dim3(64), 0, st, P, d_tab, round);
+        hipLaunchKernelGGL(k_hp_reject_wave_b, dim3(P.nreg, 1, NJ), dim3(64), 0, st, P, d_tab, round);
         ZM_HIP(hipGetLastError());
         ZM_HIP(hipMemcpyAsync(h_rflags + 16 * (size_t)njobs * (round & 1), rflags_all, sizeof(int) * 16 * (size_t)njobs,
                               hipMemcpyDeviceToHost, st));
         ZM_HIP(hipEventRecord(evs[1 + (round & 1)], st));
         return 0;
     };
-    std::vector<int> rounds(njobs, 0);
-    ZM_TRY(enqueue_round(1));
-    for (int r = 1; r <= 8; ++r) {
-        if (r < 8) ZM_TRY(enqueue_round(r + 1));
-        ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
-        const int* fl = h_rflags + 16 * (size_t)njobs * (r & 1);
-        bool more = false;
-        for (int j = 0; j < njobs; ++j) {
-            if (rounds[j]) continue;                     // (converged in an earlier round)
-            if (fl[16 * j + r] == 0 || r == 8) rounds[j] = r;
-            else more = true;
-        }
-        if (!more) break;
-    }
-
-    // per job: the convolution on the device's view of which regions are solved
-    hipLaunchKernelGGL(k_hp_solved_b, dim3(1, 1, NJ), dim3(64), 0, st, P.nreg, P.nunk, d_jobs);
-    for (int j = 0; j < njobs; ++j) {
+    // The convolution of a job is enqueued as soon as the host knows that the job has converged - on the context's
+    // second stream, beside the rounds the other jobs still need (the factorisations of a late round leave most of
+    // the GPU idle).  The host has seen the event behind the job's last live round by then, and the void rounds
+    // that follow write nothing of the job: no further ordering is needed.
+    auto enqueue_apply = [&](const int j) -> int {
         zm_scope_timer t(ctx, "hp_apply");
         char* sb = base + slab * (size_t)j;
         const hp_job& J = h_jobs[j];
+        hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, ctx->stream, P.nreg, P.nunk, J.stats, HPJ_FAIL(J), HPJ_TMO(J),
+                           J.rhs, J.smask);
 #define HP_APPLYB_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, Pj[j], J.smask, jobs[j].sci, jobs[j].ref, jobs[j].sci_rms, \
     jobs[j].ref_rms, (uint8_t*)(sb + o_outbad), d_filt, J.rhs, jobs[j].out_diff, jobs[j].out_rms, HPJ_NMASKED(J))); break;
         switch (P.hwk) {
@@ -4777,6 +4781,40 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
         }
 #undef HP_APPLYB_CASE
+        return 0;
+    };
+    static const bool apply_beside = !(getenv("ZM_BATCH_APPLY") && !strcmp(getenv("ZM_BATCH_APPLY"), "after"));
+    struct stream_swap {                                  // (launch_apply and the timers enqueue on ctx->stream)
+        zm_ctx* c; hipStream_t keep;
+        stream_swap(zm_ctx* cc, hipStream_t s) : c(cc), keep(cc->stream) { c->stream = s; }
+        ~stream_swap() { c->stream = keep; }
+    };
+    std::vector<int> rounds(njobs, 0);
+    ZM_TRY(enqueue_round(1));
+    for (int r = 1; r <= 8; ++r) {
+        if (r < 8) ZM_TRY(enqueue_round(r + 1));
+        ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
+        const int* fl = h_rflags + 16 * (size_t)njobs * (r & 1);
+        live.clear();
+        for (int j = 0; j < njobs; ++j) {
+            if (rounds[j]) continue;                     // (converged in an earlier round)
+            if (fl[16 * j + r] == 0 || r == 8) {
+                rounds[j] = r;
+                if (apply_beside) {
+                    stream_swap sw(ctx, ctx->aux);
+                    ZM_TRY(enqueue_apply(j));
+                }
+            } else {
+                live.push_back(j);
+            }
+        }
+        if (live.empty()) break;
+    }
+    if (apply_beside) {
+        ZM_HIP(hipEventRecord(evs[0], ctx->aux));
+        ZM_HIP(hipStreamWaitEvent(st, evs[0], 0));
+    } else {
+        for (int j = 0; j < njobs; ++j) ZM_TRY(enqueue_apply(j));
     }
     // one read of the fit summaries
     std::vector<int> h_int((size_t)HP_NIBUF * njobs);
