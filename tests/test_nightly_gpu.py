@@ -248,3 +248,51 @@ def test_batches_are_formed_per_fit_shape(engine):
     rc = L.zm_subtract_batch_dev(engine.ctx, 2, arr, nx, ny, infos)
     assert rc != 0 and b'different fit' in L.zm_last_error()
     assert L.zm_subtract_batch_dev(engine.ctx, 0, arr, nx, ny, infos) != 0
+
+
+def test_batch_with_an_unsolved_region_and_without_bad_pixel_maps(engine):
+    """A job whose fit loses a region (status ZM_HP_UNSOLVED: fill value, bit 17) rides in a batch without touching
+    the others, and its own products are those of the lone path; jobs straight through the C entry point with
+    bpm = NULL and host-side data limits (no limits_dev) work too."""
+    import ctypes as C
+    import torch
+    z, s = pkg(), synth()
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    jobs = make_jobs(torch, z, s, 5, 640, 600, 2, {'ko': 1, 'bgo': 0}, seed=2100, variables=8)
+    # one quadrant of job 1 has no usable pixel: that region has no stamps
+    jobs[1].sci['mask'][:300, :320] = 1
+    one = nm.SubtractionPool(1)
+    a = one.map(jobs)
+    one.close()
+    assert a[1]['info']['status'] & 1 and a[1]['info']['nunsolved'] >= 1
+    p = nm.SubtractionPool(1, batch=5)
+    b = p.map(jobs)
+    p.close()
+    for x, y in zip(a, b):
+        _same(torch, x, y)
+    # the entry point on plain planes: no bad-pixel map, limits from the host
+    L = z._lib.lib()
+    hp = importlib.import_module('zuds-pipeline_amd.engine').hp_params
+    from_kw = importlib.import_module('zuds-pipeline_amd.hotpants').job_params
+    ny, nx = 600, 640
+    n = 3
+    planes, arr, ps = [], (z._lib.zm_sub_job * n)(), []
+    for k in range(n):
+        sci, ref = jobs[k].sci, jobs[k].ref
+        out = torch.empty((4, ny, nx), dtype=torch.float32, device='cuda:0')
+        pp = hp(**from_kw(2.4, nx, ny, 2, 20.0 + k, 10.0, {'ko': 1, 'bgo': 0}))
+        ps.append(pp)
+        planes.append(out)
+        arr[k] = z._lib.zm_sub_job(sci['img'].data_ptr(), sci['rms'].data_ptr(), ref['img'].data_ptr(),
+                                   ref['rms'].data_ptr(), None, C.pointer(pp), out[0].data_ptr(), out[1].data_ptr())
+    infos = (z._lib.zm_hp_info * n)()
+    z._lib.check(L.zm_subtract_batch_dev(engine.ctx, n, arr, nx, ny, infos), 'batch')
+    for k in range(n):
+        info = z._lib.zm_hp_info()
+        z._lib.check(L.zm_subtract_dev(engine.ctx, arr[k].sci, arr[k].sci_rms, arr[k].ref, arr[k].ref_rms, None, nx, ny,
+                                       C.byref(ps[k]), planes[k][2].data_ptr(), planes[k][3].data_ptr(), C.byref(info)),
+                     'lone')
+        torch.cuda.synchronize()
+        assert torch.equal(planes[k][0], planes[k][2]) and torch.equal(planes[k][1], planes[k][3])
+        for f, _ in z._lib.zm_hp_info._fields_:
+            assert getattr(info, f) == getattr(infos[k], f), f
