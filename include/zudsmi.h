@@ -349,6 +349,10 @@ typedef struct zm_sub_job {
 } zm_sub_job;
 int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* jobs, int nx, int ny,
                           zm_hp_info* out_info_host);
+/* The same on host planes (every pointer of a job in host memory; `params->limits_dev` must be NULL): staged to
+ * the device, subtracted as one batch, products copied back - zm_subtract for many frames of one configuration. */
+int zm_subtract_batch(zm_ctx* ctx, int njobs, const zm_sub_job* jobs, int nx, int ny,
+                      zm_hp_info* out_info);
 int zm_background_dev(zm_ctx* ctx, const float* img, const float* wgt, int nx,
                       int ny, int mesh, int filtersize, float* out_bkg,
                       float* out_rms, float* out_sub, double* out_stats_host);

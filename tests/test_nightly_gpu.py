@@ -148,7 +148,8 @@ def test_differential_fuzz_across_solver_layouts():
     """40 random scenes and parameter sets (frame size, kernel half width, 1 - 9 regions, cells, ko 0 - 3,
     bgo 0 - 1) through contexts that own the GPU, share it 3 ways and 9 ways (26, 8 and 2 workgroups per
     region in the fused Cholesky): difference, noise and fit summary agree bit for bit
-    (tools/fuzz_subtract.py; 150 cases were run once: no mismatch)."""
+    (tools/fuzz_subtract.py; 150 cases were run once: no mismatch).  Round 4: every case also runs three scenes of
+    its shape as ONE batch (zm_subtract_batch) against the three one at a time (560 cases run once: no mismatch)."""
     import importlib.util
     import pathlib
     spec = importlib.util.spec_from_file_location(

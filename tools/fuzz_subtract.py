@@ -1,7 +1,9 @@
 """Developer tool: differential fuzzing of the subtraction across the two forms of the solver - the same random
 scene and parameters through one context that owns the GPU (k_chol_fused: 26 workgroups per region) and
 through contexts declared to share it 3 and 9 ways (k_chol_tp: one workgroup per region): difference image,
-noise image and the fit summary must agree bit for bit (the two forms run the same arithmetic).
+noise image and the fit summary must agree bit for bit (the two forms run the same arithmetic).  Every case also
+runs three scenes of its size and parameters (the case's own, two more; the data limits differ per scene) as ONE
+batch (zm_subtract_batch: the job as a grid dimension of every launch of the fit) against the three one at a time.
 usage: fuzz_subtract.py [ncases] [seed]"""
 import importlib
 import os
@@ -60,6 +62,20 @@ def run(ncases, seed, verbose=True):
             continue
         ok = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2]
                  for o in outs[1:])
+        # the batch: this scene and two more of its shape, different lower limits per job
+        frames = [data, scene(s, rng, nx, ny), scene(s, rng, nx, ny)]
+        hp = importlib.import_module('zuds-pipeline_amd.engine').hp_params
+        plist = [hp(**dict(kw, il=-1e3 + 7 * k, tl=-1e3 - 3 * k)) for k in range(3)]
+        lone = [engines[0].subtract(*frames[k], params=plist[k]) for k in range(3)]
+        try:
+            got = engines[0].subtract_batch(frames, params=plist)
+        except z.ZMError as err:
+            got = None
+            ok = False
+            print(f'case {case}: batch refused ({str(err)[:120]})', flush=True)
+        if got is not None:
+            ok = ok and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+                            for a, b in zip(lone, got))
         if not ok:
             bad += 1
             print(f'case {case}: MISMATCH {nx}x{ny} {kw} info {[o[2] for o in outs]}', flush=True)

@@ -149,6 +149,8 @@ _SIGS = {
                                   C.POINTER(zm_hp_info)]),
     'zm_subtract_batch_dev': (C.c_int, [_P, C.c_int, C.POINTER(zm_sub_job), C.c_int, C.c_int,
                                         C.POINTER(zm_hp_info)]),
+    'zm_subtract_batch': (C.c_int, [_P, C.c_int, C.POINTER(zm_sub_job), C.c_int, C.c_int,
+                                    C.POINTER(zm_hp_info)]),
     'zm_median_mad': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     'zm_median_mad_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double),

@@ -4878,3 +4878,39 @@ extern "C" int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms, 
     ZM_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+
+// zm_subtract_batch_dev on host planes: the jobs' planes are staged in one device buffer (seven planes per job),
+// the products copied back when the batch is done.
+extern "C" int zm_subtract_batch(zm_ctx* ctx, int njobs, const zm_sub_job* jobs, int nx, int ny, zm_hp_info* infos) {
+    ZM_CHECK(ctx && jobs && njobs >= 1 && njobs <= ZM_SUB_BATCH_MAX, "zm_subtract_batch: 1 .. %d jobs", ZM_SUB_BATCH_MAX);
+    ZM_CHECK(nx > 0 && ny > 0, "zm_subtract_batch: empty image");
+    ZM_HIP(hipSetDevice(ctx->device));
+    const size_t np = (size_t)nx * ny, npa = (np + 63) & ~(size_t)63;
+    char* stage = nullptr;
+    ZM_TRY(ctx->get("hsb_planes", (size_t)njobs * (6 * 4 + 1) * npa, (void**)&stage));
+    std::vector<zm_sub_job> dj(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        const zm_sub_job& jb = jobs[j];
+        ZM_CHECK(jb.sci && jb.sci_rms && jb.ref && jb.ref_rms && jb.params && jb.out_diff && jb.out_rms,
+                 "zm_subtract_batch: null argument in job %d", j);
+        ZM_CHECK(!jb.params->limits_dev, "zm_subtract_batch: limits_dev belongs to the device entry points");
+        char* b = stage + (size_t)j * 25 * npa;
+        float* d[6];
+        for (int i = 0; i < 6; ++i) d[i] = (float*)(b + (size_t)i * 4 * npa);
+        uint8_t* d_bpm = (uint8_t*)(b + (size_t)24 * npa);
+        const float* h[4] = {jb.sci, jb.sci_rms, jb.ref, jb.ref_rms};
+        for (int i = 0; i < 4; ++i) ZM_HIP(hipMemcpyAsync(d[i], h[i], np * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (jb.bpm) ZM_HIP(hipMemcpyAsync(d_bpm, jb.bpm, np, hipMemcpyHostToDevice, ctx->stream));
+        dj[j] = jb;
+        dj[j].sci = d[0]; dj[j].sci_rms = d[1]; dj[j].ref = d[2]; dj[j].ref_rms = d[3];
+        dj[j].bpm = jb.bpm ? d_bpm : nullptr;
+        dj[j].out_diff = d[4]; dj[j].out_rms = d[5];
+    }
+    ZM_TRY(zm_subtract_batch_dev(ctx, njobs, dj.data(), nx, ny, infos));
+    for (int j = 0; j < njobs; ++j) {
+        ZM_HIP(hipMemcpyAsync(jobs[j].out_diff, dj[j].out_diff, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZM_HIP(hipMemcpyAsync(jobs[j].out_rms, dj[j].out_rms, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

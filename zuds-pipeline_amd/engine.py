@@ -264,6 +264,45 @@ class Engine(object):
                                  C.byref(info)), 'zm_subtract')
         return diff, noise, {k: getattr(info, k) for k, _ in info._fields_}
 
+    def subtract_batch(self, frames, params=None, **kw):
+        """Many subtractions of one configuration in one call (``zm_subtract_batch``: the kernel fits of all
+        frames as one chain of launches; same products as :meth:`subtract` frame by frame).
+
+        ``frames``: sequence of ``(sci, sci_rms, ref, ref_rms, bpm or None)``, all of one shape; ``params``: one
+        ``zm_hp_params`` for all, or a sequence (data limits and fill values may differ per frame), or
+        keywords as for :meth:`subtract`.  Returns a list of (diff, noise, info dict)."""
+        frames = list(frames)
+        n = len(frames)
+        if n == 0:
+            return []
+        if params is None:
+            params = hp_params(**kw)
+        plist = list(params) if isinstance(params, (list, tuple)) else [params] * n
+        if len(plist) != n:
+            raise ValueError('one zm_hp_params per frame, or one for all')
+        arr = (_lib.zm_sub_job * n)()
+        infos = (_lib.zm_hp_info * n)()
+        keep, outs = [], []
+        ny, nx = as_f32(frames[0][0]).shape
+        for k, (sci, sci_rms, ref, ref_rms, bpm) in enumerate(frames):
+            planes = [as_f32(a) for a in (sci, sci_rms, ref, ref_rms)]
+            for a, nm in zip(planes, ('sci', 'sci_rms', 'ref', 'ref_rms')):
+                if a.shape != (ny, nx):
+                    raise ValueError(f'frame {k}: {nm} has shape {a.shape}, expected {(ny, nx)}')
+            if bpm is not None:
+                bpm = np.ascontiguousarray(bpm).astype(np.uint8, copy=False)
+                if bpm.shape != (ny, nx):
+                    raise ValueError(f'frame {k}: bpm has shape {bpm.shape}, expected {(ny, nx)}')
+            diff = np.empty((ny, nx), dtype=np.float32)
+            noise = np.empty((ny, nx), dtype=np.float32)
+            keep.append((planes, bpm))
+            outs.append((diff, noise))
+            arr[k] = _lib.zm_sub_job(ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), ptr(planes[3]), ptr(bpm),
+                                     C.pointer(plist[k]), ptr(diff), ptr(noise))
+        check(self.L.zm_subtract_batch(self._ctx, n, arr, nx, ny, infos), 'zm_subtract_batch')
+        return [(d, nz, {f: getattr(infos[k], f) for f, _ in _lib.zm_hp_info._fields_})
+                for k, (d, nz) in enumerate(outs)]
+
     def median_mad(self, img, mask=None):
         """(median, 1.4826 MAD) of the pixels whose mask is 0
         (quick_background_estimate, zuds/utils.py:32-53)."""
