@@ -41,9 +41,9 @@ def scene(nx=384, ny=352, seed=1, nstars=120, ksig=0.9, scale=1.3, bg=20.0,
             ref.astype(np.float32), np.full((ny, nx), 0.5, np.float32), bpm)
 
 
-def compare(engine, data, tol=1e-5, **kw):
+def compare(engine, data, tol=1e-5, got=None, **kw):
     sci, srms, ref, rrms, bpm = data
-    d, n, info = engine.subtract(sci, srms, ref, rrms, bpm, **kw)
+    d, n, info = got if got is not None else engine.subtract(sci, srms, ref, rrms, bpm, **kw)
     rd, rn, rinfo = ohp.subtract(sci, ref, srms, rrms, bpm, **kw)
     fi = kw.get('fi', 1e-30)
     gm, rm = d == np.float32(fi), rd == fi
@@ -67,6 +67,19 @@ def compare(engine, data, tol=1e-5, **kw):
 
 
 COMMON = dict(tu=1e6, iu=1e6, tl=-1e3, il=-1e3)
+
+
+def test_a_batch_of_subtractions_against_the_oracle(engine):
+    """``zm_subtract_batch``: three frames of one configuration, their kernel fits as one chain of launches with
+    the frame as a grid dimension - each product against the oracle like a lone subtraction's, and bit for bit
+    the lone subtraction's."""
+    kw = dict(r=5.0, rss=12.0, nsx=4, nsy=4, nrx=2, nry=1, ko=1, bgo=1, **COMMON)
+    frames = [scene(seed=11), scene(seed=12, ksig=1.2, scale=0.9, bg=5.0), scene(seed=13, gradient=0.3)]
+    got = engine.subtract_batch(frames, **kw)
+    for data, g in zip(frames, got):
+        compare(engine, data, got=g, **kw)
+        d, n, info = engine.subtract(*data, **kw)
+        assert np.array_equal(d, g[0]) and np.array_equal(n, g[1]) and info == g[2]
 
 
 def test_constant_kernel_recovers_the_injected_convolution(engine):
