@@ -3739,8 +3739,11 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
                                                     const int* __restrict__ list, int special) {
     hp_vectors_body<HWK>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special);
 }
+// (four waves per SIMD - two workgroups per CU - like the one-job kernel: without the bound the job table's pointers
+// push this instance to 131 registers, one workgroup per CU, and the first round of a batch ran 40 % slower per job;
+// half widths above 11 need more than 128 registers in the one-job kernel too)
 template <int HWK>
-__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors_b(const hp_plan P, const hp_job* __restrict__ jobs,
+__global__ __launch_bounds__(HV_THREADS, (HWK <= 11 ? 4 : 2)) void k_hp_vectors_b(const hp_plan P, const hp_job* __restrict__ jobs,
                                                       const double* __restrict__ filt, int round) {
     const hp_job& J = jobs[blockIdx.z];
     hp_vectors_body<HWK>(P, J.sci, J.ref, J.srms, J.trms, filt, J.centres, J.active, J.need, J.X, J.phi, J.vbar,
