@@ -108,6 +108,73 @@ __global__ __launch_bounds__(256) void k_hp_rowany(const uint8_t* __restrict__ i
     }
 }
 
+// k_hp_valid and both row dilations of a subtraction in one pass over the row (round 4): the validity of a pixel
+// is worked out where the prefix counts need it, `bad` is written for the stamp search, and the row goes out
+// dilated by hw1 (substamp footprint) and by hw2 (kernel footprint) from the one prefix array.  Three launches
+// and two more reads of the validity plane less per subtraction; the same bytes in every plane.
+__global__ __launch_bounds__(256) void k_hp_valid_rows(const float* __restrict__ sci, const float* __restrict__ ref,
+                                                       const uint8_t* __restrict__ bpm, int nx, int ny, float il, float iu,
+                                                       float tl, float tu, const double* __restrict__ lim, double nsig,
+                                                       int hw1, int hw2, uint8_t* __restrict__ bad,
+                                                       uint8_t* __restrict__ out1, uint8_t* __restrict__ out2) {
+    extern __shared__ int ra_pre[];                       // [nx + 1], ra_pre[0] = 0
+    __shared__ int wsum[HP_ROWMAX / 64], wtot[4];         // bad pixels per (chunk of 256, wave), then their offsets
+    if (lim) {
+        il = (float)(lim[0] - nsig * lim[1]);
+        tl = (float)(lim[3] - nsig * lim[4]);
+    }
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const size_t r0 = (size_t)y * nx;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nch = (nx + 255) / 256;
+    // pixels x = 256 c + tid (coalesced loads); counts inside a wave by ballot, the (chunk, wave) totals by one
+    // block-wide scan: four barriers per row, whatever its length
+    for (int c = 0; c < nch; ++c) {
+        const int x = 256 * c + tid;
+        bool b = false;
+        if (x < nx) {
+            const float s = sci[r0 + x], t = ref[r0 + x];
+            bool ok = (s == s) && (t == t) && fabsf(s) < 3e38f && fabsf(t) < 3e38f;
+            ok = ok && s >= il && s <= iu && t >= tl && t <= tu;
+            if (bpm) ok = ok && bpm[r0 + x] == 0;
+            b = !ok;
+            bad[r0 + x] = b ? 1 : 0;
+        }
+        const unsigned long long m = __ballot(b);
+        if (x < nx) ra_pre[x + 1] = __popcll(m & ((2ull << lane) - 1ull));      // inclusive, inside the wave
+        if (lane == 0) wsum[4 * c + wave] = __popcll(m);
+    }
+    if (tid == 0) ra_pre[0] = 0;
+    __syncthreads();
+    {
+        // exclusive scan of the 4 nch totals (<= 256: one per thread)
+        const int v = tid < 4 * nch ? wsum[tid] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int off = inc - v;
+        for (int w = 0; w < wave; ++w) off += wtot[w];
+        if (tid < 4 * nch) wsum[tid] = off;
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int x = 256 * c + tid;
+        if (x < nx) ra_pre[x + 1] += wsum[4 * c + wave];
+    }
+    __syncthreads();
+    for (int x = tid; x < nx; x += 256) {
+        const int a1 = max(x - hw1, 0), b1 = min(x + hw1, nx - 1);
+        const int a2 = max(x - hw2, 0), b2 = min(x + hw2, nx - 1);
+        out1[r0 + x] = (ra_pre[b1 + 1] - ra_pre[a1]) > 0;
+        out2[r0 + x] = (ra_pre[b2 + 1] - ra_pre[a2]) > 0;
+    }
+}
+
 // the same along columns: one thread per column walks a strip of rows with a running count
 // of the window (coalesced row reads); edge != 0 also flags the hw-wide frame border
 #define HP_COLSTRIP 96
@@ -4101,24 +4168,42 @@ static int hp_launch_masks(zm_ctx* ctx, const hp_plan& P, const zm_hp_params* hp
     hipStream_t st = ctx->stream;
     const dim3 b256(256);
     zm_scope_timer t(ctx, "hp_masks");
-    hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
-                       (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad, hp->limits_dev, hp->limits_nsigma);
     ZM_CHECK(nx <= HP_ROWMAX, "zm_subtract: frames wider than %d pixels are not supported", HP_ROWMAX);
     const size_t rsh = sizeof(int) * ((size_t)nx + 1);
     dim3 gc(zm_div_up(nx, 256), zm_div_up(ny, HP_COLSTRIP));
     if (!ctx->hp_rset && rsh > 65536) {
         ZM_HIP(hipFuncSetAttribute((const void*)k_hp_rowany, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(sizeof(int) * (HP_ROWMAX + 1))));
+        ZM_HIP(hipFuncSetAttribute((const void*)k_hp_valid_rows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(int) * (HP_ROWMAX + 1))));
         ctx->hp_rset = true;
     }
-    hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
     const bool col4 = (nx % 4 == 0) && (((uintptr_t)tmp8 | (uintptr_t)dirty | (uintptr_t)outbad) & 3) == 0;
     dim3 gc4(zm_div_up(nx / 4, 256), zm_div_up(ny, HP_COLSTRIP4));
-    if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
-    else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
-    hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hwk, tmp8);
-    if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
-    else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+    // validity + both row dilations in one pass (k_hp_valid_rows); ZM_HP_MASKS=split: the five launches of rounds 1 - 3
+    static const bool split = getenv("ZM_HP_MASKS") && !strcmp(getenv("ZM_HP_MASKS"), "split");
+    uint8_t* tmp8b = nullptr;
+    if (!split) ZM_TRY(ctx->get("hp_tmp8b", np, (void**)&tmp8b));
+    if (!split && (((uintptr_t)tmp8b & 3) == 0)) {
+        hipLaunchKernelGGL(k_hp_valid_rows, dim3(ny), b256, rsh, st, sci, ref, bpm, nx, ny, (float)P.il, (float)P.iu,
+                           (float)P.tl, (float)P.tu, hp->limits_dev, hp->limits_nsigma, P.hw, P.hwk, bad, tmp8, tmp8b);
+        if (col4) {
+            hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+            hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8b, nx, ny, P.hwk, 1, outbad);
+        } else {
+            hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+            hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8b, nx, ny, P.hwk, 1, outbad);
+        }
+    } else {
+        hipLaunchKernelGGL(k_hp_valid, dim3((unsigned)((np + 255) / 256)), b256, 0, st, sci, ref, bpm, np,
+                           (float)P.il, (float)P.iu, (float)P.tl, (float)P.tu, bad, hp->limits_dev, hp->limits_nsigma);
+        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hw, tmp8);
+        if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+        else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hw, 1, dirty);
+        hipLaunchKernelGGL(k_hp_rowany, dim3(ny), b256, rsh, st, bad, nx, ny, P.hwk, tmp8);
+        if (col4) hipLaunchKernelGGL(k_hp_colany4, gc4, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+        else hipLaunchKernelGGL(k_hp_colany, gc, b256, 0, st, tmp8, nx, ny, P.hwk, 1, outbad);
+    }
     ZM_HIP(hipGetLastError());
     return 0;
 }
