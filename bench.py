@@ -654,6 +654,18 @@ def main():
             step()
             sync()
             print(f'step {i}: {1e3 * (time.perf_counter() - t0):.2f} ms', file=sys.stderr)
+    if os.environ.get('ZM_BENCH_HOSTPROBE'):           # developer: how far ahead of the GPU the host enqueues a step
+        for i in range(12):
+            sync()
+            t0 = time.perf_counter()
+            coadd_leg(coadd, dframes)
+            t1 = time.perf_counter()
+            sub_leg(coadd, sci)
+            t2 = time.perf_counter()
+            sync()
+            t3 = time.perf_counter()
+            print(f'step {i}: coadd enqueued in {1e3 * (t1 - t0):.3f} ms, subtraction returned after '
+                  f'{1e3 * (t2 - t0):.3f} ms, drained after {1e3 * (t3 - t0):.3f} ms', file=sys.stderr)
     # Runtime spin-up, before the W warm-up steps the contract asks for: a fresh process stalls
     # once, for ~40 ms, at its fourth step (HIP runtime state that is set up lazily - seen with
     # ZM_BENCH_TRACE=1: 15, 11, 11, 53, 11, 11, ... ms); with a small W that stall would land in

@@ -176,6 +176,14 @@ typedef struct zm_hp_params {
      * fields above. */
     const double* limits_dev;
     double limits_nsigma;
+    /* Round 4: the step behind hotpants folded into the call.  The reference sets bit 17 of the subtraction's mask
+     * where hotpants left its fill value (zuds/subtraction.py:167-177: `submask[sub.data == 1e-30] |= 2**17`); when
+     * flag_mask_dev is not NULL (device entry points only) the call enqueues exactly that - mask |= flag_bit where
+     * out_diff == 1e-30f - behind the convolution, before it waits for the fit summary, instead of the caller
+     * launching zm_mask_flag_dev after the call has returned (a launch with the GPU idle).  NULL: nothing. */
+    int32_t* flag_mask_dev;
+    int32_t flag_bit;
+    int32_t pad2_;
 } zm_hp_params;
 
 void zm_hp_params_default(zm_hp_params* p);

@@ -63,7 +63,8 @@ class zm_hp_params(C.Structure):
                 ('ngauss', C.c_int32), ('deg', C.c_int32 * 4),
                 ('pad_', C.c_int32 * 3),
                 ('sigma', C.c_double * 4),
-                ('limits_dev', C.c_void_p), ('limits_nsigma', C.c_double)]
+                ('limits_dev', C.c_void_p), ('limits_nsigma', C.c_double),
+                ('flag_mask_dev', C.c_void_p), ('flag_bit', C.c_int32), ('pad2_', C.c_int32)]
 
 
 class zm_sub_job(C.Structure):

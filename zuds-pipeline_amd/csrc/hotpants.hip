@@ -3954,6 +3954,19 @@ __global__ __launch_bounds__(64) void k_hp_reject_wave_b(const hp_plan P, const 
                         J.rflags + round, J.needlist);
 }
 
+// zm_hp_params.flag_mask_dev: mask |= bit where the difference image carries hotpants' fill value (k_mask_flag,
+// elementwise.hip) - unless a wait of this attempt's factorisation gave up (tmo: the fit is going to be repeated
+// and this attempt's fill pattern is not the product's)
+__global__ void k_hp_flag(int32_t* __restrict__ mask, const float* __restrict__ img, float value, int32_t bit,
+                          int64_t n, const int* __restrict__ tmo, int nreg) {
+    int gaveup = 0;
+    for (int r = 0; r < nreg; ++r) gaveup |= tmo[r];
+    if (gaveup) return;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (img[p] == value) mask[p] |= bit;
+}
+
 // ---------------------------------------------------------------------------
 extern "C" void zm_hp_params_default(zm_hp_params* p) {
     if (!p) return;
@@ -4080,11 +4093,12 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
 // the summary after the convolution, for zm_hp_info and for the repeat after a time-out).
 static __device__ __forceinline__ void hp_solved_body(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
                             const int* __restrict__ tmo, const double* __restrict__ x,
-                            unsigned long long* __restrict__ mask) {
+                            unsigned long long* __restrict__ mask, double* __restrict__ x0out = nullptr) {
     unsigned long long m = 0;
     const int reg = threadIdx.x;
     if (reg < nreg) {
         const double x0 = x[(size_t)reg * nunk];
+        if (x0out) x0out[reg] = x0;              // (the kernel sum of the region: all the host wants of the solution)
         const bool ok = stats[2 * reg + 1] >= 1.0 && fail[reg] == 0 && tmo[reg] == 0 && isfinite(x0);
         m = ok ? 1ull << reg : 0ull;
     }
@@ -4094,8 +4108,8 @@ static __device__ __forceinline__ void hp_solved_body(int nreg, int nunk, const 
 }
 __global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats, const int* __restrict__ fail,
                             const int* __restrict__ tmo, const double* __restrict__ x,
-                            unsigned long long* __restrict__ mask) {
-    hp_solved_body(nreg, nunk, stats, fail, tmo, x, mask);
+                            unsigned long long* __restrict__ mask, double* __restrict__ x0out = nullptr) {
+    hp_solved_body(nreg, nunk, stats, fail, tmo, x, mask, x0out);
 }
 __global__ void k_hp_solved_b(int nreg, int nunk, const hp_job* __restrict__ jobs) {
     const hp_job& J = jobs[blockIdx.z];
@@ -4260,7 +4274,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     int* chg = nullptr;                  // cells whose substamp the last rejection changed
     ZM_TRY(ctx->get("hp_chg", sizeof(int) * (2 * (size_t)P.ncell + P.nreg), (void**)&chg));   // flags + per-region lists
     constexpr int HP_NIBUF = 4 * HP_MAXREG + 4;
-    ZM_TRY(ctx->get("hp_ibuf", sizeof(int) * HP_NIBUF, (void**)&ibuf));
+    // the fit summary - counters, stamp statistics, the regions' kernel sums - is ONE buffer: one copy back when the
+    // subtraction is done (round 4, late: three copies with the GPU idle cost a launch latency each)
+    constexpr size_t HP_SUMBYTES = sizeof(int) * HP_NIBUF + sizeof(double) * 3 * HP_MAXREG;
+    static_assert((sizeof(int) * HP_NIBUF) % 8 == 0, "the statistics behind the counters are doubles");
+    char* sumbuf = nullptr;
+    ZM_TRY(ctx->get("hp_summary", HP_SUMBYTES, (void**)&sumbuf));
+    ibuf = reinterpret_cast<int*>(sumbuf);
     int *nrej = ibuf, *ntotal = ibuf + HP_MAXREG, *fail = ibuf + 2 * HP_MAXREG, *nmasked = ibuf + 3 * HP_MAXREG;
     int* tmo = ibuf + 3 * HP_MAXREG + 4;  // barrier time-outs of k_chol_fused per region
     unsigned* cbar = nullptr;            // region barrier counters of k_chol_fused (zeroed by k_hp_scale)
@@ -4286,7 +4306,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_TRY(ctx->get("hp_rhs0", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&rhs0));
     ZM_TRY(ctx->get("hp_dsc", sizeof(double) * (size_t)P.nreg * P.nunk, (void**)&dsc));
     ZM_TRY(ctx->get("hp_merit", sizeof(double) * P.ncell, (void**)&merit));
-    ZM_TRY(ctx->get("hp_stats", sizeof(double) * 2 * HP_MAXREG, (void**)&stats));
+    stats = reinterpret_cast<double*>(sumbuf + sizeof(int) * HP_NIBUF);
+    double* x0sum = stats + 2 * HP_MAXREG;
     ZM_TRY(ctx->get("hp_filt", sizeof(double) * filt.size(), (void**)&d_filt));
     // small constant tables: staged through pinned memory owned per call generation.  The table depends on the
     // parameters only (half width, Gaussians): a context that subtracts frame after frame with the same ones keeps
@@ -4309,8 +4330,11 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     // the GPU - every later round worked on a garbage solution, so the whole fit is run again on
     // the one-workgroup-per-region form of the factorisation (k_chol_tp: it waits for nobody; slower, same bits).
     // ZM_CHOL_SPIN_LIMIT (developer / tests): spins before a barrier gives up in the FIRST attempt.
-    int h_int[HP_NIBUF];
-    std::vector<double> h_stats(2 * HP_MAXREG), h_x((size_t)P.nreg * P.nunk);
+    char* h_sum = nullptr;
+    ZM_TRY(ctx->get_pinned("hp_summary_h", HP_SUMBYTES, (void**)&h_sum));
+    const int* h_int = reinterpret_cast<const int*>(h_sum);
+    const double* h_stats = reinterpret_cast<const double*>(h_sum + sizeof(int) * HP_NIBUF);
+    const double* h_x0 = h_stats + 2 * HP_MAXREG;
     int rounds = 0, retries = 0, ntimeouts = 0;
     const char* spin_env = getenv("ZM_CHOL_SPIN_LIMIT");
     // Contexts of this process that are fitting on this device right now: the many-workgroup form of the
@@ -4601,7 +4625,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         zm_scope_timer t(ctx, "hp_apply");
         unsigned long long* smask = nullptr;
         ZM_TRY(ctx->get("hp_smask", sizeof(unsigned long long), (void**)&smask));
-        hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, st, P.nreg, P.nunk, stats, fail, tmo, rhs, smask);
+        hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, st, P.nreg, P.nunk, stats, fail, tmo, rhs, smask, x0sum);
         {
 #define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, smask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
             switch (P.hwk) {
@@ -4613,11 +4637,16 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
 #undef HP_APPLY_CASE
         }
     }
+    // what the reference does behind hotpants - bit 17 where the fill value landed - enqueued here when asked for
+    // (zm_hp_params.flag_mask_dev), not by the caller after this call has waited for the GPU
+    if (hp->flag_mask_dev) {
+        hipLaunchKernelGGL(k_hp_flag, dim3((unsigned)((np + 255) / 256)), b256, 0, st, hp->flag_mask_dev, out_diff, 1e-30f,
+                           hp->flag_bit, np, tmo, P.nreg);
+        ZM_HIP(hipGetLastError());
+    }
     // ... and ONE read of the fit summary (counters incl. the convolution's masked-pixel count, stamp statistics,
-    // solutions) when everything is done
-    ZM_HIP(hipMemcpyAsync(h_int, ibuf, sizeof(int) * HP_NIBUF, hipMemcpyDeviceToHost, st));
-    ZM_HIP(hipMemcpyAsync(h_stats.data(), stats, sizeof(double) * 2 * P.nreg, hipMemcpyDeviceToHost, st));
-    ZM_HIP(hipMemcpyAsync(h_x.data(), rhs, sizeof(double) * (size_t)P.nreg * P.nunk, hipMemcpyDeviceToHost, st));
+    // the regions' kernel sums), one copy, when everything is done
+    ZM_HIP(hipMemcpyAsync(h_sum, sumbuf, HP_SUMBYTES, hipMemcpyDeviceToHost, st));
     ZM_HIP(hipStreamSynchronize(st));
     ntimeouts = 0;
     for (int reg = 0; reg < P.nreg; ++reg) ntimeouts += h_int[3 * HP_MAXREG + 4 + reg];
@@ -4633,7 +4662,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     // a region is solved when it fitted at least one stamp and the factorisation held (k_hp_solved's rule)
     auto reg_solved = [&](int reg) {
         return h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
-               h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x[(size_t)reg * P.nunk]);
+               h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x0[reg]);
     };
     if (info) {
         memset(info, 0, sizeof(*info));
@@ -4643,7 +4672,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             info->nstamps_total += h_int[HP_MAXREG + r];
             info->nstamps_used += (int)h_stats[2 * r + 1];
             if (reg_solved(r)) {
-                ks += h_x[(size_t)r * P.nunk];
+                ks += h_x0[r];
                 chi += h_stats[2 * r];
                 ++nsolved;
             }
@@ -4869,6 +4898,8 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
         }
 #undef HP_APPLYB_CASE
+        if (jobs[j].params->flag_mask_dev)
+            ZM_TRY(zm_mask_flag_dev(ctx, jobs[j].params->flag_mask_dev, jobs[j].out_diff, 1e-30f, jobs[j].params->flag_bit, np));
         return 0;
     };
     static const bool apply_beside = !(getenv("ZM_BATCH_APPLY") && !strcmp(getenv("ZM_BATCH_APPLY"), "after"));
@@ -4948,6 +4979,7 @@ extern "C" int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms, 
     ZM_CHECK(ctx && sci && sci_rms && ref && ref_rms && hp && out_diff && out_rms,
              "zm_subtract: null argument");
     ZM_CHECK(nx > 0 && ny > 0, "zm_subtract: empty image");
+    ZM_CHECK(!hp->flag_mask_dev && !hp->limits_dev, "zm_subtract: limits_dev / flag_mask_dev belong to the device entry points");
     ZM_HIP(hipSetDevice(ctx->device));
     const size_t np = (size_t)nx * ny;
     float* d[6];
@@ -4981,7 +5013,8 @@ extern "C" int zm_subtract_batch(zm_ctx* ctx, int njobs, const zm_sub_job* jobs,
         const zm_sub_job& jb = jobs[j];
         ZM_CHECK(jb.sci && jb.sci_rms && jb.ref && jb.ref_rms && jb.params && jb.out_diff && jb.out_rms,
                  "zm_subtract_batch: null argument in job %d", j);
-        ZM_CHECK(!jb.params->limits_dev, "zm_subtract_batch: limits_dev belongs to the device entry points");
+        ZM_CHECK(!jb.params->limits_dev && !jb.params->flag_mask_dev,
+                 "zm_subtract_batch: limits_dev / flag_mask_dev belong to the device entry points");
         char* b = stage + (size_t)j * 25 * npa;
         float* d[6];
         for (int i = 0; i < 6; ++i) d[i] = (float*)(b + (size_t)i * 4 * npa);

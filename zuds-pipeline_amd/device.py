@@ -212,12 +212,8 @@ class DeviceSubtraction(object):
                                self.diff.data_ptr(), self.noise.data_ptr())
 
     def finish(self):
-        """Behind the hotpants step: bit 17 where it masked (subtraction.py:167-177)."""
-        L, ctx = self.engine.L, self.engine.ctx
-        self.engine.set_stream(self.stream.cuda_stream)
-        with self.torch.cuda.stream(self.stream):
-            check(L.zm_mask_flag_dev(ctx, self.submask.data_ptr(), self.diff.data_ptr(), 1e-30,
-                                     1 << 17, self.n), 'bit17')
+        """Behind the hotpants step: nothing is left to enqueue - bit 17 where hotpants masked
+        (subtraction.py:167-177) was set by the subtraction itself (``prepare``: flag_mask_dev)."""
         return self.diff, self.noise, self.submask
 
     def prepare(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
@@ -302,6 +298,10 @@ class DeviceSubtraction(object):
                 p = hp_params(**job_params(seeing, nx, ny, nreg_side, 0.0, 0.0, hotpants_kws))
                 p.limits_dev = self._lim_dev.data_ptr()
                 p.limits_nsigma = 10.0
+        # bit 17 where hotpants masked (subtraction.py:167-177): enqueued by the subtraction itself, behind its
+        # convolution and before it waits for the fit summary (zm_hp_params.flag_mask_dev)
+        p.flag_mask_dev = self.submask.data_ptr()
+        p.flag_bit = 1 << 17
         self._sci_rms = sci_rms                          # (kept alive until the fit has read it)
         return scim, p
 

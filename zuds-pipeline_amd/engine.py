@@ -357,6 +357,10 @@ def hp_params(**kw):
             setattr(p, k, int(v))
         elif k == 'limits_dev':
             p.limits_dev = int(v) if v else None       # device address of the six doubles of zm_median_mad2_async_dev
+        elif k == 'flag_mask_dev':
+            p.flag_mask_dev = int(v) if v else None    # device address of the int32 mask plane that takes flag_bit
+        elif k == 'flag_bit':
+            p.flag_bit = int(v)
         elif hasattr(p, k):
             setattr(p, k, float(v))
         else:
