@@ -4772,6 +4772,10 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     int *ibuf_all = nullptr, *rflags_all = nullptr, *h_rflags = nullptr;
     ZM_TRY(ctx->get("hpb_ibuf", sizeof(int) * HP_NIBUF * (size_t)njobs, (void**)&ibuf_all));
     ZM_TRY(ctx->get("hpb_rflags", sizeof(int) * 16 * (size_t)njobs, (void**)&rflags_all));
+    // stamp statistics and kernel sums of all jobs side by side: with the counters, two copies bring the batch's
+    // fit summaries back (the solution vectors stay on the device)
+    double* sum_all = nullptr;
+    ZM_TRY(ctx->get("hpb_sum", sizeof(double) * 3 * HP_MAXREG * (size_t)njobs, (void**)&sum_all));
     // (two host copies of the flags, by parity of the round: the copy of round r + 1 may land while round r's is read)
     ZM_TRY(ctx->get_pinned("hpb_rflags_h", sizeof(int) * 32 * (size_t)njobs, (void**)&h_rflags));
     // job tables: the full one, and one per later round holding only the jobs that can still be fitting then
@@ -4804,7 +4808,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         J.phi = (double*)(sb + o_phi); J.phiold = (double*)(sb + o_phiold); J.vbar = (double*)(sb + o_vbar);
         J.A = (double*)(sb + o_A); J.AT = (double*)(sb + o_AT); J.rhs = (double*)(sb + o_rhs);
         J.A0 = (double*)(sb + o_A0); J.rhs0 = (double*)(sb + o_rhs0); J.dsc = (double*)(sb + o_dsc);
-        J.merit = (double*)(sb + o_merit); J.stats = (double*)(sb + o_stats);
+        J.merit = (double*)(sb + o_merit); J.stats = sum_all + (size_t)3 * HP_MAXREG * j;
         J.smask = (unsigned long long*)(sb + o_smask);
     }
     ZM_HIP(hipMemcpyAsync(d_jobs, h_jobs, sizeof(hp_job) * (size_t)njobs, hipMemcpyHostToDevice, st));
@@ -4888,7 +4892,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         char* sb = base + slab * (size_t)j;
         const hp_job& J = h_jobs[j];
         hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, ctx->stream, P.nreg, P.nunk, J.stats, HPJ_FAIL(J), HPJ_TMO(J),
-                           J.rhs, J.smask);
+                           J.rhs, J.smask, J.stats + 2 * HP_MAXREG);
 #define HP_APPLYB_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, Pj[j], J.smask, jobs[j].sci, jobs[j].ref, jobs[j].sci_rms, \
     jobs[j].ref_rms, (uint8_t*)(sb + o_outbad), d_filt, J.rhs, jobs[j].out_diff, jobs[j].out_rms, HPJ_NMASKED(J))); break;
         switch (P.hwk) {
@@ -4937,19 +4941,14 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     }
     // one read of the fit summaries
     std::vector<int> h_int((size_t)HP_NIBUF * njobs);
-    std::vector<double> h_stats((size_t)2 * HP_MAXREG * njobs), h_x((size_t)P.nreg * P.nunk * njobs);
+    std::vector<double> h_sum((size_t)3 * HP_MAXREG * njobs);
     ZM_HIP(hipMemcpyAsync(h_int.data(), ibuf_all, sizeof(int) * h_int.size(), hipMemcpyDeviceToHost, st));
-    for (int j = 0; j < njobs; ++j) {
-        ZM_HIP(hipMemcpyAsync(h_stats.data() + (size_t)2 * HP_MAXREG * j, h_jobs[j].stats, sizeof(double) * 2 * P.nreg,
-                              hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipMemcpyAsync(h_x.data() + (size_t)P.nreg * P.nunk * j, h_jobs[j].rhs, sizeof(double) * (size_t)P.nreg * P.nunk,
-                              hipMemcpyDeviceToHost, st));
-    }
+    ZM_HIP(hipMemcpyAsync(h_sum.data(), sum_all, sizeof(double) * h_sum.size(), hipMemcpyDeviceToHost, st));
     ZM_HIP(hipStreamSynchronize(st));
     for (int j = 0; j < njobs && infos; ++j) {
         const int* hi = h_int.data() + (size_t)HP_NIBUF * j;
-        const double* hs = h_stats.data() + (size_t)2 * HP_MAXREG * j;
-        const double* hx = h_x.data() + (size_t)P.nreg * P.nunk * j;
+        const double* hs = h_sum.data() + (size_t)3 * HP_MAXREG * j;
+        const double* hx0 = hs + 2 * HP_MAXREG;
         zm_hp_info* info = &infos[j];
         memset(info, 0, sizeof(*info));
         double ks = 0, chi = 0;
@@ -4958,8 +4957,8 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             info->nstamps_total += hi[HP_MAXREG + r];
             info->nstamps_used += (int)hs[2 * r + 1];
             const bool solved = hs[2 * r + 1] >= 1.0 && hi[2 * HP_MAXREG + r] == 0 && hi[3 * HP_MAXREG + 4 + r] == 0 &&
-                                std::isfinite(hx[(size_t)r * P.nunk]);
-            if (solved) { ks += hx[(size_t)r * P.nunk]; chi += hs[2 * r]; ++nsolved; }
+                                std::isfinite(hx0[r]);
+            if (solved) { ks += hx0[r]; chi += hs[2 * r]; ++nsolved; }
         }
         info->niter = rounds[j];
         info->ncoeff = P.nunk;
