@@ -3794,6 +3794,11 @@ struct hp_job {                      // one job of a batched fit: its planes and
 #define HPJ_NMASKED(J) ((J).ibuf + 3 * HP_MAXREG)
 #define HPJ_TMO(J) ((J).ibuf + 3 * HP_MAXREG + 4)
 #define HPJ_GUARD(J, round) ((round) > 1 ? (J).rflags + ((round) - 1) : nullptr)
+// A region whose last rejection changed nothing keeps its normal matrix, hence its factor and its solution: from the
+// second round on the scaling, the factorisation and the back substitution of such a region are skipped (the list of
+// changed cells of a region, k_hp_reject*: chg[ncell + reg (ncellr + 1)] is its length) - the same bits, fewer
+// workgroups holding a CU each while other jobs' kernels wait
+#define HPJ_REGION_IDLE(J, round, reg, ncell, ncellr) ((round) > 1 && (J).chg[(ncell) + (reg) * ((ncellr) + 1)] == 0)
 
 template <int HWK>
 __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
@@ -3884,11 +3889,13 @@ __global__ void k_hp_scale(int n, int lda, const double* __restrict__ A0, const 
 // region) - k_hp_scale's grid of one workgroup per row and 256 columns is 312 000 workgroups for 16 jobs and is bound
 // by their dispatch (222 us, whatever the number of jobs still fitting).  The arithmetic per entry is k_hp_scale's.
 #define HSB_ROWS 8
-__global__ __launch_bounds__(256) void k_hp_scale_b(int n, int lda, int nreg, const hp_job* __restrict__ jobs, int round) {
+__global__ __launch_bounds__(256) void k_hp_scale_b(int n, int lda, int nreg, const hp_job* __restrict__ jobs, int round,
+                                                    int ncell, int ncellr) {
     const hp_job& J = jobs[blockIdx.y / nreg];
     const int* guard = HPJ_GUARD(J, round);
     if (guard && *guard == 0) return;
     const int reg = blockIdx.y % nreg;
+    if (HPJ_REGION_IDLE(J, round, reg, ncell, ncellr)) return;
     const double* __restrict__ dd = J.dsc + (size_t)reg * n;
     const double* __restrict__ A0 = J.A0 + (size_t)reg * (size_t)(n + 1) * n;
     const double* __restrict__ rhs0 = J.rhs0 + (size_t)reg * n;
@@ -3913,8 +3920,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_chol_tp(int n, int lda, int ldt,
                                                         long long* prof, const int* __restrict__ guard) {
     chol_tp_body(n, lda, ldt, Aall, ATall, fail, prof, guard);
 }
-__global__ __launch_bounds__(CT_THREADS) void k_chol_tp_b(int n, int lda, int ldt, const hp_job* __restrict__ jobs, int round) {
+__global__ __launch_bounds__(CT_THREADS) void k_chol_tp_b(int n, int lda, int ldt, const hp_job* __restrict__ jobs, int round,
+                                                          int ncell, int ncellr) {
     const hp_job& J = jobs[blockIdx.z];
+    if (HPJ_REGION_IDLE(J, round, (int)blockIdx.x, ncell, ncellr)) return;
     chol_tp_body(n, lda, ldt, J.A, J.AT, HPJ_FAIL(J), nullptr, HPJ_GUARD(J, round));
 }
 
@@ -3923,8 +3932,10 @@ __global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols(int n, int lda, 
                                                                 double* __restrict__ xall, const int* __restrict__ guard) {
     chol_back_cols_body(n, lda, Aall, dall, xall, guard);
 }
-__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols_b(int n, int lda, const hp_job* __restrict__ jobs, int round) {
+__global__ __launch_bounds__(CBC_THREADS) void k_chol_back_cols_b(int n, int lda, const hp_job* __restrict__ jobs, int round,
+                                                                  int ncell, int ncellr) {
     const hp_job& J = jobs[blockIdx.z];
+    if (HPJ_REGION_IDLE(J, round, (int)blockIdx.x, ncell, ncellr)) return;
     chol_back_cols_body(n, lda, J.A, J.dsc, J.rhs, HPJ_GUARD(J, round));
 }
 
@@ -4872,9 +4883,9 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_tab, round);
         hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_tab, round);
         hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, HSB_ROWS), P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
-                           d_tab, round);
-        hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_tab, round);
-        hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_tab, round);
+                           d_tab, round, P.ncell, P.ncellr);
+        hipLaunchKernelGGL(k_chol_tp_b, dim3(P.nreg, 1, NJ), dim3(CT_THREADS), 0, st, P.nunk, lda, ldt, d_tab, round, P.ncell, P.ncellr);
+        hipLaunchKernelGGL(k_chol_back_cols_b, dim3(P.nreg, 1, NJ), dim3(CBC_THREADS), 0, st, P.nunk, lda, d_tab, round, P.ncell, P.ncellr);
         hipLaunchKernelGGL(k_hp_merit_b, dim3(P.ncell, 1, NJ), dim3(64), 0, st, P, d_tab, round);
         hipLaunchKernelGGL(k_hp_reject_wave_b, dim3(P.nreg, 1, NJ), dim3(64), 0, st, P, d_tab, round);
         ZM_HIP(hipGetLastError());
