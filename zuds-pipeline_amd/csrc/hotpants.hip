@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void k_hp_build(const hp_plan P, const double*
 // scalar load) and the spatial terms of its threads, i.e. 2 loads and 3 flops per unknown pair and
 // cell where k_hp_build decodes and gathers per pair (1.2 x 10^8 pair-cell products per round-1
 // build).  Same products, same cell order: the results are identical to the last bit.
-static __device__ __forceinline__ void hp_build_blk_body(const int reg, const hp_plan& P, const double* __restrict__ G,
+static __device__ __forceinline__ void hp_build_blk_body(const int reg, const int pair, const hp_plan& P, const double* __restrict__ G,
                                                       const double* __restrict__ phi,
                                                       const int* __restrict__ active,
                                                       const int* __restrict__ chg, int sign,
@@ -920,10 +920,10 @@ static __device__ __forceinline__ void hp_build_blk_body(const int reg, const hp
                                                       const int* __restrict__ need) {
     if (guard && *guard == 0) return;
     // (a triangular grid: x = pair index of (n1, n2 <= n1) - the square grid dispatched as many empty workgroups again)
-    int n1 = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
-    while (n1 * (n1 + 1) / 2 > (int)blockIdx.x) --n1;
-    while ((n1 + 1) * (n1 + 2) / 2 <= (int)blockIdx.x) ++n1;
-    const int n2 = (int)blockIdx.x - n1 * (n1 + 1) / 2;
+    int n1 = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+    while (n1 * (n1 + 1) / 2 > pair) --n1;
+    while ((n1 + 1) * (n1 + 2) / 2 <= pair) ++n1;
+    const int n2 = pair - n1 * (n1 + 1) / 2;
     if (zero && n1 == 0 && n2 == 0)                      // (the hand-over words of this round's k_chol_df)
         for (int k = threadIdx.x; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
     const int p1 = threadIdx.x >> 4, p2 = threadIdx.x & 15;
@@ -3852,13 +3852,24 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
                                                       const double* __restrict__ Gold = nullptr,
                                                       const double* __restrict__ phiold = nullptr,
                                                       const int* __restrict__ need = nullptr) {
-    hp_build_blk_body(blockIdx.z, P, G, phi, active, chg, sign, A, rhs, guard, zero, nzero, Gold, phiold, need);
+    hp_build_blk_body(blockIdx.z, blockIdx.x, P, G, phi, active, chg, sign, A, rhs, guard, zero, nzero, Gold, phiold, need);
 }
-// (grid: x = pair of source vectors, y = job, z = region)
+// (grid: x = HBB_PAIRS pairs of source vectors, y = job, z = region.  One workgroup per pair, job and region is
+// 183 600 workgroups for 16 jobs, most of them - every region whose last rejection changed nothing, every job that
+// has converged - without work: the launch was bound by their dispatch, 0.3 - 0.45 ms per round.  A workgroup
+// takes several pairs one after the other and leaves at once when its region has nothing to update.)
+#define HBB_PAIRS 5
 __global__ __launch_bounds__(256) void k_hp_build_blk_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
     const hp_job& J = jobs[blockIdx.y];
-    hp_build_blk_body(blockIdx.z, P, J.G, J.phi, J.active, J.chg, round == 1 ? 0 : 2, J.A0, J.rhs0, HPJ_GUARD(J, round),
-                      nullptr, 0, J.Gold, J.phiold, J.need);
+    const int* guard = HPJ_GUARD(J, round);
+    if (guard && *guard == 0) return;
+    const int reg = blockIdx.z;
+    if (HPJ_REGION_IDLE(J, round, reg, P.ncell, P.ncellr)) return;
+    const int npair = P.nE * (P.nE + 1) / 2;
+#pragma unroll 1
+    for (int pair = blockIdx.x * HBB_PAIRS; pair < min((int)(blockIdx.x + 1) * HBB_PAIRS, npair); ++pair)
+        hp_build_blk_body(reg, pair, P, J.G, J.phi, J.active, J.chg, round == 1 ? 0 : 2, J.A0, J.rhs0, guard,
+                          nullptr, 0, J.Gold, J.phiold, J.need);
 }
 
 __global__ __launch_bounds__(256) void k_hp_build_mfma(const hp_plan P, const double* __restrict__ G,
@@ -4880,7 +4891,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         if (round == 1 && !build_scalar)
             hipLaunchKernelGGL(k_hp_build_mfma_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg, NJ), b256, 0, st, P, d_tab);
         else
-            hipLaunchKernelGGL(k_hp_build_blk_b, dim3(P.nE * (P.nE + 1) / 2, NJ, P.nreg), b256, 0, st, P, d_tab, round);
+            hipLaunchKernelGGL(k_hp_build_blk_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, HBB_PAIRS), NJ, P.nreg), b256, 0, st, P, d_tab, round);
         hipLaunchKernelGGL(k_hp_diag_b, dim3(zm_div_up(P.nunk, 256), P.nreg, NJ), b256, 0, st, P.nunk, d_tab, round);
         hipLaunchKernelGGL(k_hp_scale_b, dim3(zm_div_up(P.nunk, HSB_ROWS), P.nreg * NJ), b256, 0, st, P.nunk, lda, P.nreg,
                            d_tab, round, P.ncell, P.ncellr);
