@@ -3844,6 +3844,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_hp_gram_sum_b(const hp_job* __re
     hp_gram_sum_body(J.Gp, J.need, J.active, J.G, HPJ_GUARD(J, round), J.Gold, round > 1 ? J.needlist : nullptr);
 }
 
+#define HBB_PAIRS 5
 __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const double* __restrict__ G,
                                                       const double* __restrict__ phi, const int* __restrict__ active,
                                                       const int* __restrict__ chg, int sign, double* __restrict__ A,
@@ -3852,13 +3853,25 @@ __global__ __launch_bounds__(256) void k_hp_build_blk(const hp_plan P, const dou
                                                       const double* __restrict__ Gold = nullptr,
                                                       const double* __restrict__ phiold = nullptr,
                                                       const int* __restrict__ need = nullptr) {
-    hp_build_blk_body(blockIdx.z, blockIdx.x, P, G, phi, active, chg, sign, A, rhs, guard, zero, nzero, Gold, phiold, need);
+    // (grid: x = HBB_PAIRS pairs of source vectors, z = region: see k_hp_build_blk_b.  A region whose last rejection
+    // changed nothing has nothing to update - sign 2 - and its workgroups leave once the hand-over words of this
+    // round's k_chol_df are cleared: 11 475 workgroups per round became 2 295, most of them gone at once)
+    if (guard && *guard == 0) return;
+    const int reg = blockIdx.z;
+    if (sign == 2 && chg[P.ncell + reg * (P.ncellr + 1)] == 0) {
+        if (zero && blockIdx.x == 0)
+            for (int k = threadIdx.x; k < nzero; k += 256) zero[(size_t)reg * nzero + k] = 0u;
+        return;
+    }
+    const int npair = P.nE * (P.nE + 1) / 2;
+#pragma unroll 1
+    for (int pair = blockIdx.x * HBB_PAIRS; pair < min((int)(blockIdx.x + 1) * HBB_PAIRS, npair); ++pair)
+        hp_build_blk_body(reg, pair, P, G, phi, active, chg, sign, A, rhs, guard, zero, nzero, Gold, phiold, need);
 }
 // (grid: x = HBB_PAIRS pairs of source vectors, y = job, z = region.  One workgroup per pair, job and region is
 // 183 600 workgroups for 16 jobs, most of them - every region whose last rejection changed nothing, every job that
 // has converged - without work: the launch was bound by their dispatch, 0.3 - 0.45 ms per round.  A workgroup
 // takes several pairs one after the other and leaves at once when its region has nothing to update.)
-#define HBB_PAIRS 5
 __global__ __launch_bounds__(256) void k_hp_build_blk_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
     const hp_job& J = jobs[blockIdx.y];
     const int* guard = HPJ_GUARD(J, round);
@@ -4502,7 +4515,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 hipLaunchKernelGGL(k_hp_build_mfma, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg), b256, 0, st, P, G, phi, active,
                                    A0, rhs0, dff, ndff);
             else if (P.nkp <= 16)
-                hipLaunchKernelGGL(k_hp_build_blk, dim3(P.nE * (P.nE + 1) / 2, 1, P.nreg), b256, 0, st, P, G, phi, active, chg,
+                hipLaunchKernelGGL(k_hp_build_blk, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, HBB_PAIRS), 1, P.nreg), b256, 0, st, P, G, phi, active, chg,
                                    rounds == 1 ? 0 : 2, A0, rhs0, guard, dff, ndff, Gold, phiold, need);
             else
                 hipLaunchKernelGGL(k_hp_build, dim3(nt, nt, P.nreg), b256, 0, st, P, G, phi, active, chg,

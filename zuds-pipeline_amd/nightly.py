@@ -67,6 +67,10 @@ class _Worker(object):
         self.chain = None
         self.key = None
 
+    def release(self):
+        """Drop the device planes (``SubtractionPool.close``)."""
+        self.chain, self.key = None, None
+
     def subtract(self, job, keep=True):
         from .device import DeviceSubtraction
         torch = self.torch
@@ -165,13 +169,9 @@ class _BatchLane(object):
         # instead of its preparation
         self.turn = turn
 
-    @property
-    def chain(self):
-        return self.chains
-
-    @chain.setter
-    def chain(self, v):                                  # (SubtractionPool.close drops the planes)
-        self.chains = []
+    def release(self):
+        """Drop the device planes (``SubtractionPool.close``)."""
+        self.chains, self.key = [], None
 
     def subtract(self, jobs, keep=True):
         """``jobs``: at most ``batch`` jobs of one fit key.  Returns their results in order."""
@@ -304,6 +304,6 @@ class SubtractionPool(object):
     def close(self):
         self._pool.shutdown(wait=True)
         for w in self._workers:
-            w.chain = None
+            w.release()
             w.engine.close()
         self._workers = []
