@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """Nightly subtractions + forced photometry: the job of the reference's
 ``scripts/donightly.py`` (per image: ``dosub.do_one``) followed by ``scripts/dophot.py``
-(``raw_aperture_photometry`` at known sky positions), database-free, with J subtractions in
-flight on the GPU (``nightly.SubtractionPool``).
+(``raw_aperture_photometry`` at known sky positions), database-free, with the kernel fits of B
+subtractions as one batch of launches on each of J lanes (``nightly.SubtractionPool(J, batch=B)``;
+``--fit-batch 0``: J separate subtractions in flight).
 
-usage: donightly.py images.txt ref.fits [positions.txt] [--jobs J] [--nreg-side N]
+usage: donightly.py images.txt ref.fits [positions.txt] [--jobs J] [--fit-batch B] [--batch FRAMES] [--nreg-side N]
 
 * ``images.txt``: science image paths (``*sciimg.fits``; the mask is ``*mskimg.fits``; a
   ``.weight.fits`` sibling is required: 1 / rms^2, 0 on bad pixels).  The list is sharded over
@@ -100,12 +101,15 @@ def main(argv=None):
     ap.add_argument('infile')
     ap.add_argument('refname')
     ap.add_argument('positions', nargs='?')
-    ap.add_argument('--jobs', type=int, default=4, help='subtractions in flight on the GPU')
+    ap.add_argument('--jobs', type=int, default=2,
+                    help='lanes (host thread, context, stream) working on the GPU at the same time; with --fit-batch 0: '
+                         'subtractions in flight')
     ap.add_argument('--nreg-side', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='science frames resident at a time')
-    ap.add_argument('--fit-batch', type=int, default=0,
+    ap.add_argument('--batch', type=int, default=32, help='science frames resident at a time')
+    ap.add_argument('--fit-batch', type=int, default=16,
                     help='kernel fits per launch chain (SubtractionPool(jobs, batch=N): --jobs lanes whose N fits run '
-                         'as one batch, zm_subtract_batch_dev); 0: one chain per job')
+                         'as one batch, zm_subtract_batch_dev; measured: two lanes of 16 = 2.0 ms per 3072^2 '
+                         'subtraction against 3.0 - 3.1 with 8 - 16 separate chains); 0: one chain per job')
     args = ap.parse_args(argv)
 
     nightly = importlib.import_module('zuds-pipeline_amd.nightly')
