@@ -85,6 +85,7 @@ def test_config4_full_quadrant_nightly(engine):
     NREF, NEPOCH, NPOS = 16, 8, 500
     p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True)
     one, four = nm.SubtractionPool(1), nm.SubtractionPool(4)
+    lanes = nm.SubtractionPool(2, batch=4)        # the same night with the kernel fits of four epochs per launch chain
     try:
         for quad in range(4):
             rng = np.random.default_rng(5000 + quad)
@@ -116,6 +117,14 @@ def test_config4_full_quadrant_nightly(engine):
                 jobs.append(nm.SubtractionJob(sci, ref, radec=(pra, pdec), nreg_side=3, tag=len(jobs)))
             a = one.map(jobs)
             b = four.map(jobs)
+            c = lanes.map(jobs)
+            for x, y in zip(a, c):
+                assert 'error' not in y and x['info'] == y['info'], (quad, x['tag'])
+                for k in ('diff', 'noise', 'mask'):
+                    assert torch.equal(x[k], y[k]), (quad, x['tag'], k, 'batched')
+                for k in ('flux', 'fluxerr', 'flags'):
+                    assert np.array_equal(x['phot'][k], y['phot'][k], equal_nan=True), (quad, x['tag'], k, 'batched')
+            del c
             for x, y in zip(a, b):
                 assert 'error' not in x and 'error' not in y
                 assert x['info'] == y['info'], (quad, x['tag'])
@@ -148,3 +157,4 @@ def test_config4_full_quadrant_nightly(engine):
     finally:
         one.close()
         four.close()
+        lanes.close()
