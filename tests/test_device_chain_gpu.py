@@ -294,6 +294,34 @@ def test_limits_taken_on_the_device_equal_the_host_round_trip(chain, engine, mon
         assert np.array_equal(a[k], b[k])
 
 
+def test_bit17_is_set_by_the_subtraction_itself_and_only_by_its_final_attempt(chain, device_sub, engine, monkeypatch):
+    """Round 4: bit 17 where hotpants left its fill value (zuds/subtraction.py:167-177) is enqueued by
+    zm_subtract_dev behind its convolution (zm_hp_params.flag_mask_dev), before the call waits for the fit summary.
+    An attempt whose factorisation gave up waiting is repeated: its fill pattern must not reach the mask
+    (k_hp_flag looks at the attempt's time-outs).  ZM_CHOL_SPIN_LIMIT=0 forces the repeat."""
+    z, torch = chain['z'], chain['torch']
+    dmod = __import__('importlib').import_module('zuds-pipeline_amd.device')
+    ds0, diff0, noise0, submask0 = device_sub
+    fill = diff0 == np.float32(1e-30)
+    assert np.array_equal(fill, (submask0 & (1 << 17)) != 0) and 0 < fill.mean() < 0.5
+    ref, sci, f = chain['ref'], chain['ims'][3], chain['frames'][3]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to('cuda:0')
+    args = (t(f['img'], np.float32), t(sci.rms_image.data, np.float32), t(f['mask'], np.int32),
+            t(sci.weight_image.data, np.float32), t(ref.data, np.float32),
+            t(ref.rms_image.data, np.float32), t(ref.mask_image.data, np.int32))
+    ds = dmod.DeviceSubtraction(sci.wcs, ref.wcs, device=0, engine=engine)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('ZM_CHOL_SPIN_LIMIT', '0')
+    diff, noise, submask = ds.run(*args, seeing=2.0, nreg_side=1, hotpants_kws=chain['kws'],
+                                  ref_flxscale=float(ref.header.get('FLXSCALE', 1.0)))
+    ds.stream.synchronize()
+    monkeypatch.delenv('ZM_CHOL_SPIN_LIMIT')
+    engine.set_stream(0)
+    assert ds.info.retries == 1 and ds.info.status == 0
+    assert np.array_equal(diff.cpu().numpy(), diff0) and np.array_equal(noise.cpu().numpy(), noise0)
+    assert np.array_equal(submask.cpu().numpy(), submask0)
+
+
 def test_aligned_reference_mask_has_no_bit16_and_uncovered_pixels_count(chain, device_sub):
     ds, diff, noise, submask = device_sub
     uncovered = ds.ref_al_w.cpu().numpy() == 0
