@@ -1026,7 +1026,7 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
     def timed_pool(J, batch):
         pool = nm.SubtractionPool(J, device=local, batch=batch)
         try:
-            pool.map(jobs[:max(J * max(batch, 1), 1)], keep=False)      # allocations, code objects
+            pool.map(jobs[:min(max(J * max(batch, 1), 1), len(jobs))], keep=False)      # allocations, code objects
             torch.cuda.synchronize()
             reps = []
             for _ in range(2):                             # (host threads: the faster of two passes)
@@ -1052,7 +1052,7 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
     # the batched form: `lanes x batch` - the fits of `batch` jobs are one chain of launches (zm_subtract_batch_dev)
     for spec in [v for v in args.nightly_batches.split(',') if v]:
         J, B = (int(v) for v in spec.split('x'))
-        if J * B <= njobs:
+        if B <= njobs:
             out['batched'][spec] = timed_pool(J, B)
     if out['batched']:
         bb = max(out['batched'].items(), key=lambda kv: kv[1]['subtract_mpix_s'])
