@@ -101,15 +101,16 @@ def main(argv=None):
     ap.add_argument('infile')
     ap.add_argument('refname')
     ap.add_argument('positions', nargs='?')
-    ap.add_argument('--jobs', type=int, default=2,
+    ap.add_argument('--jobs', type=int, default=3,
                     help='lanes (host thread, context, stream) working on the GPU at the same time; with --fit-batch 0: '
                          'subtractions in flight')
     ap.add_argument('--nreg-side', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='science frames resident at a time')
-    ap.add_argument('--fit-batch', type=int, default=16,
+    ap.add_argument('--batch', type=int, default=36, help='science frames resident at a time')
+    ap.add_argument('--fit-batch', type=int, default=12,
                     help='kernel fits per launch chain (SubtractionPool(jobs, batch=N): --jobs lanes whose N fits run '
-                         'as one batch, zm_subtract_batch_dev; measured: two lanes of 16 = 2.0 ms per 3072^2 '
-                         'subtraction against 3.0 - 3.1 with 8 - 16 separate chains); 0: one chain per job')
+                         'as one batch, zm_subtract_batch_dev; measured on 32 subtractions of 3072^2: three lanes of '
+                         '11 = 2.0 - 2.1 ms each whether the frames share one seeing or fall into three seeing '
+                         'groups, two lanes of 16 1.95 / 2.8, 8 - 16 separate chains 3.0); 0: one chain per job')
     args = ap.parse_args(argv)
 
     nightly = importlib.import_module('zuds-pipeline_amd.nightly')

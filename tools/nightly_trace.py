@@ -1,5 +1,5 @@
 """Developer tool: J subtractions side by side (nightly.SubtractionPool) on synthetic config-2 data,
-for a kernel trace.  usage: nightly_trace.py J [njobs [batch]]   (batch >= 2: J lanes of batched fits; rocprofv3 --kernel-trace -- python3 tools/nightly_trace.py 4)
+for a kernel trace.  usage: nightly_trace.py J [njobs [batch [mixed]]]   (batch >= 2: J lanes of batched fits; rocprofv3 --kernel-trace -- python3 tools/nightly_trace.py 4)
 Prints ms per subtraction; tools/rocpd_overlap.py turns the trace into per-kernel times and the overlap."""
 import importlib
 import os
@@ -18,6 +18,7 @@ def main():
     J = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     njobs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    mixed = len(sys.argv) > 4 and sys.argv[4] == 'mixed'      # three seeing groups: r = 9 / 10 / 11, rss = 21 / 24 / 26
     size = 3072
     z = importlib.import_module('zuds-pipeline_amd')
     synth = importlib.import_module('zuds-pipeline_amd.synth')
@@ -54,7 +55,7 @@ def main():
         m = m.to(device)
         wgt = torch.where(m != 0, 0.0, float(f['wgt'].max())).to(torch.float32)
         rms = torch.where(wgt > 0, 1.0 / torch.sqrt(wgt.clamp_min(1e-20)), float(np.sqrt(50000.0))).to(torch.float32)
-        jobs.append(nm.SubtractionJob(dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=4.0), ref,
+        jobs.append(nm.SubtractionJob(dict(img=f['img'], rms=rms, mask=m, wgt=wgt, wcs=f['wcs'], seeing=(3.6, 4.0, 4.4)[i % 3] if mixed else 4.0), ref,
                                       radec=(ra, dec), nreg_side=3))
     pool = nm.SubtractionPool(J, device=0, batch=batch)
     try:
