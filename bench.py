@@ -69,7 +69,7 @@ def parse():
     ap.add_argument('--pipelined-depth', type=int, default=4, help='subtractions in flight in the pipelined leg')
     ap.add_argument('--nightly-jobs', type=int, default=32, help='subtractions of the concurrent leg')
     ap.add_argument('--nightly-pools', default='1,2,4,8,16', help='jobs in flight to time in the concurrent leg')
-    ap.add_argument('--nightly-batches', default='1x8,1x16,2x8,2x16,3x8',
+    ap.add_argument('--nightly-batches', default='1x8,1x16,2x8,2x16,3x8,3x11',
                     help='lanes x batch of the batched pools to time in the concurrent leg (SubtractionPool(J, batch=B): '
                          'the kernel fits of B jobs as one chain of launches); empty: none')
     ap.add_argument('--dump-coadd', default=None,
