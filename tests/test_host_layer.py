@@ -275,3 +275,33 @@ def test_hotpants_keyword_classes_raise_ignore_or_warn():
         hp.job_params(2.0, 512, 512, 1, 0, 0, {'oci': 'conv.fits'})
         hp.job_params(2.0, 512, 512, 1, 0, 0, {'oci': 'conv.fits'})
     assert len(w) == 1 and 'oci' in str(w[0].message)
+
+
+def test_batches_of_the_subtraction_pool_are_formed_per_fit_shape_and_balanced():
+    """nightly._batches / _fit_key (host logic of SubtractionPool(J, batch=B)): jobs share a batch only when their
+    kernel fits have one shape - frame size, int(2.5 SEEING), int(6 SEEING), regions, orders, basis - and a group
+    is cut into the fewest batches of equal size."""
+    import importlib
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    assert nm._batches(['a'] * 32, 14) == [list(range(0, 11)), list(range(11, 22)), list(range(22, 32))]
+    assert nm._batches(['a'] * 32, 16) == [list(range(0, 16)), list(range(16, 32))]
+    assert nm._batches(['a', 'b', 'a', 'a', 'b'], 2) == [[0, 2], [3], [1, 4]]
+    assert nm._batches([], 8) == []
+    assert sorted(i for c in nm._batches(list('abcabcabca'), 3) for i in c) == list(range(10))
+
+    class Img(object):
+        def __init__(self, shape):
+            self.shape = shape
+
+    def job(seeing, shape=(3072, 3072), nreg_side=3, kws=None):
+        return nm.SubtractionJob(dict(img=Img(shape), seeing=seeing), None, nreg_side=nreg_side, hotpants_kws=kws)
+
+    k = nm._fit_key(job(4.0))
+    assert k == nm._fit_key(job(4.1))                    # r = 10.0 / 10.25, rss = 24.0 / 24.6: the same integers
+    assert k != nm._fit_key(job(3.6))                    # r = 9, rss = 21
+    assert k != nm._fit_key(job(4.0, nreg_side=2))
+    assert k != nm._fit_key(job(4.0, kws={'ko': 2}))
+    assert k != nm._fit_key(job(4.0, shape=(3080, 3072)))
+    assert k == nm._fit_key(job(4.0, kws={'il': -50.0, 'tl': -20.0}))      # data limits are per job
+    with pytest.raises(ValueError):
+        nm._fit_key(job(4.0, kws={'convolve': 'i'}))     # the keyword policy of job_params applies here too

@@ -152,6 +152,25 @@ def _fit_key(job):
     return (ny, nx) + tuple(sorted((k, tuple(v) if isinstance(v, list) else v) for k, v in p.items()))
 
 
+def _batches(keys, batch):
+    """Job indices -> batches: jobs of one fit key, in job order, at most ``batch`` of them; a group is cut into the
+    fewest batches that hold it, of equal size up to one job (32 jobs at batch 14 are 11 + 11 + 10, not 14 + 14 + 4:
+    the factorisations of a batch take the time of one whatever its size, so the largest batch sets the pace)."""
+    groups = {}
+    for i, key in enumerate(keys):
+        groups.setdefault(key, []).append(i)
+    chunks = []
+    for idx in groups.values():
+        nb = -(-len(idx) // batch)
+        q, r = divmod(len(idx), nb)
+        k = 0
+        for b in range(nb):
+            n = q + (1 if b < r else 0)
+            chunks.append(idx[k:k + n])
+            k += n
+    return chunks
+
+
 class _BatchLane(object):
     """An engine, its stream and up to ``batch`` subtraction chains whose kernel fits run as one batch."""
 
@@ -280,21 +299,7 @@ class SubtractionPool(object):
         jobs = list(jobs)
         if not self.batch:
             return list(self._pool.map(lambda j: self._run(j, keep), jobs))
-        # batches: consecutive jobs of one fit key, at most `batch` of them
-        groups = {}
-        for i, job in enumerate(jobs):
-            groups.setdefault(_fit_key(job), []).append(i)
-        # (a group is cut into the fewest batches that hold it, of equal size up to one job: 32 jobs at batch 14
-        # are 11 + 11 + 10, not 14 + 14 + 4)
-        chunks = []
-        for idx in groups.values():
-            nb = -(-len(idx) // self.batch)
-            q, r = divmod(len(idx), nb)
-            k = 0
-            for b in range(nb):
-                n = q + (1 if b < r else 0)
-                chunks.append(idx[k:k + n])
-                k += n
+        chunks = _batches([_fit_key(job) for job in jobs], self.batch)
         results = [None] * len(jobs)
         for idx, outs in zip(chunks, self._pool.map(lambda c: self._run_batch([jobs[i] for i in c], keep), chunks)):
             for i, o in zip(idx, outs):
