@@ -3784,7 +3784,6 @@ struct hp_job {                      // one job of a batched fit: its planes and
     const float *sci, *ref, *srms, *trms;
     int2* centres;
     int *active, *need, *needlist, *chg, *ibuf, *rflags;
-    unsigned* cbar;
     double *X, *G, *Gp, *Gold, *phi, *phiold, *vbar, *A, *AT, *rhs, *A0, *rhs0, *dsc, *merit, *stats;
     unsigned long long* smask;
 };
@@ -4145,10 +4144,6 @@ __global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats
                             const int* __restrict__ tmo, const double* __restrict__ x,
                             unsigned long long* __restrict__ mask, double* __restrict__ x0out = nullptr) {
     hp_solved_body(nreg, nunk, stats, fail, tmo, x, mask, x0out);
-}
-__global__ void k_hp_solved_b(int nreg, int nunk, const hp_job* __restrict__ jobs) {
-    const hp_job& J = jobs[blockIdx.z];
-    hp_solved_body(nreg, nunk, J.stats, HPJ_FAIL(J), HPJ_TMO(J), J.rhs, J.smask);
 }
 
 
@@ -4782,7 +4777,6 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     const size_t o_active = take(sizeof(int) * P.ncell), o_need = take(sizeof(int) * P.ncell);
     const size_t o_needlist = take(sizeof(int) * ((size_t)P.ncell + 1));
     const size_t o_chg = take(sizeof(int) * (2 * (size_t)P.ncell + P.nreg));
-    const size_t o_cbar = take(sizeof(unsigned) * CF_BAR_STRIDE * HP_MAXREG);
     const size_t o_X = take(sizeof(double) * (size_t)P.ncell * P.nX * P.npixp);
     const size_t o_G = take(sizeof(double) * (size_t)P.ncell * HP_MAXX * HP_MAXX);
     const size_t o_Gp = take(sizeof(double) * (size_t)P.ncell * GR_SPLIT * HP_MAXX * HP_MAXX);
@@ -4797,7 +4791,6 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     const size_t o_rhs0 = take(sizeof(double) * (size_t)P.nreg * P.nunk);
     const size_t o_dsc = take(sizeof(double) * (size_t)P.nreg * P.nunk);
     const size_t o_merit = take(sizeof(double) * P.ncell);
-    const size_t o_stats = take(sizeof(double) * 2 * HP_MAXREG);
     const size_t o_smask = take(sizeof(unsigned long long));
     const size_t slab = off;
     char* base = nullptr;
@@ -4838,7 +4831,6 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         J.active = (int*)(sb + o_active); J.need = (int*)(sb + o_need); J.needlist = (int*)(sb + o_needlist);
         J.chg = (int*)(sb + o_chg);
         J.ibuf = ibuf_all + (size_t)HP_NIBUF * j; J.rflags = rflags_all + 16 * (size_t)j;
-        J.cbar = (unsigned*)(sb + o_cbar);
         J.X = (double*)(sb + o_X); J.G = (double*)(sb + o_G); J.Gp = (double*)(sb + o_Gp); J.Gold = (double*)(sb + o_Gold);
         J.phi = (double*)(sb + o_phi); J.phiold = (double*)(sb + o_phiold); J.vbar = (double*)(sb + o_vbar);
         J.A = (double*)(sb + o_A); J.AT = (double*)(sb + o_AT); J.rhs = (double*)(sb + o_rhs);
