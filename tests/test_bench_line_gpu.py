@@ -51,3 +51,26 @@ def test_bench_line_contract():
     for k in ('stack_roofline', 'combine_roofline'):
         assert c[k]['bound'] == 'hbm' and c[k]['frac'] == pytest.approx(c[k]['achieved'] / 8000.0) and c[k]['traffic'] is None
     assert c['value_mpix_s'] == pytest.approx(mpix / (c['ms_per_step'] * 1e-3), rel=1e-6)
+
+
+def test_bench_line_nightly_leg_with_batched_pools():
+    """The many-subtractions leg of the line: `nightly.pools` (J separate chains) and `nightly.batched`
+    (lanes x batch: the kernel fits of a batch as one chain of launches), no failed job, `batched_best` against one
+    worker.  Reduced size; the numbers are not looked at."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '2048', '--frames', '4', '--steps', '2', '--warmup', '1',
+           '--no-clocks', '--no-pipelined', '--no-secondary', '--no-cpu-baseline', '--nightly-jobs', '4',
+           '--nightly-pools', '1,2', '--nightly-batches', '1x2,2x2,1x4']
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    n = d['nightly']
+    assert n['jobs'] == 4 and set(n['pools']) == {'1', '2'} and set(n['batched']) == {'1x2', '2x2', '1x4'}
+    # (`failed` counts jobs with a non-zero status: at this reduced size a region of some frame may have no stamp;
+    # what matters here: no job raised, and every pool sees the same jobs fail - the products do not depend on it)
+    for rec in list(n['pools'].values()) + list(n['batched'].values()):
+        assert 'first_error' not in rec and rec['ms_per_subtraction'] > 0 and len(rec['passes_ms']) == 2
+        assert rec['failed'] == n['pools']['1']['failed']
+    bb = n['batched_best']
+    assert bb['lanes_x_batch'] in n['batched']
+    assert bb['over_one_worker'] == pytest.approx(n['pools']['1']['ms_per_subtraction'] / bb['ms_per_subtraction'])
+    assert n['subtract_mpix_s'] == pytest.approx(max(r['subtract_mpix_s'] for r in list(n['pools'].values()) + list(n['batched'].values())))
