@@ -36,13 +36,14 @@ if int(os.environ.get('WORLD_SIZE', '1')) == 1:
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_ACHIEVABLE_GBS = 6290.0    # ... and what that guide measures for a float4 copy (79 % of the spec)
 VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (packed FMA), spec
 # fp64 matrix peak: 256 CUs x 4 SIMDs x one v_mfma_f64_16x16x4_f64 (2 x 16 x 16 x 4 flop) per 64 cycles (the
 # instruction cost measured for k_chol_fused) x 2.4 GHz = 78.6 TFLOP/s = AMD's FP64 matrix figure
 MFMA_F64_PEAK_TFLOPS = 78.6
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
-PMC_PROFILES = ['r04_pmc.json']     # newest first; each stamped with the hash of the kernel sources it measured
+PMC_PROFILES = ['r05_pmc.json', 'r04_pmc.json']     # newest first; each stamped with the hash of the kernel sources it measured
 
 
 def parse():
@@ -352,7 +353,7 @@ def copy_ceiling(z, eng, torch, stream, device):
     n = 1 << 30
     src = torch.empty(n, dtype=torch.uint8, device=device)
     dst = torch.empty(n, dtype=torch.uint8, device=device)
-    src.zero_()
+    src.random_()            # (not zeros: the chip clocks higher on trivial data, MI355X_MICROARCH.md DVFS)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
         for _ in range(3):
@@ -364,7 +365,7 @@ def copy_ceiling(z, eng, torch, stream, device):
     b.synchronize()
     ms = a.elapsed_time(b) / 10
     del src, dst
-    return {'kernel': 'k_copy4 (float4, grid-stride, 8 workgroups per CU)', 'bytes_each_way': n,
+    return {'kernel': 'k_copy4 (float4, four loads in flight per thread, non-temporal stores, 8 workgroups per CU)', 'bytes_each_way': n,
             'avg_us': 1e3 * ms, 'GBs_read_plus_write': 2 * n / (ms * 1e-3) / 1e9}
 
 
@@ -784,6 +785,7 @@ def main():
             roofline = {'bound': 'hbm', 'kernel': kname, 'units_per_launch': units,
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
+                        'frac_of_achievable': ach / HBM_ACHIEVABLE_GBS, 'achievable': HBM_ACHIEVABLE_GBS,
                         'avg_launch_us': kt[roof_scope]['avg_us'],
                         'us_per_frame': kt[roof_scope]['avg_us'] / (args.frames if fused else 1),
                         'algorithmic_bytes_per_launch': bytes_per_launch,
@@ -793,7 +795,7 @@ def main():
                         'counters_from': pmc.get('stale') or f'{pmc.get("file")} (kernel sources {pmc.get("kernel_sources_sha16")})'}
             if kp:
                 # vector issue, not HBM, bounds this kernel: wave-instructions per output pixel and frame
-                roofline['traffic_over_algorithmic'] = kp['hbm_bytes_per_launch'] / bytes_per_launch
+                roofline['traffic_over_algorithmic'] = roofline['wasted'] = kp['hbm_bytes_per_launch'] / bytes_per_launch
                 roofline['valu_insts_per_px'] = kp.get('valu_insts_per_px')
                 roofline['lds_insts_per_px'] = kp.get('lds_insts_per_px')
                 roofline['valu_busy_frac'] = kp.get('valu_busy_frac')
@@ -812,6 +814,7 @@ def main():
                     cc = copy_ceiling(z, eng, torch, coadd.stream, device)
                     roofline['copy_ceiling'] = cc
                     roofline['frac_of_copy_ceiling'] = ach / cc['GBs_read_plus_write']
+                    cc['guide_float4_copy_GBs'] = HBM_ACHIEVABLE_GBS
                 except Exception as e:                       # noqa: a probe must not fail the bench
                     roofline['copy_ceiling_error'] = repr(e)
         # the dominant scope by time is the kernel fit's solver: the fused Cholesky against the fp64 matrix rate
@@ -831,6 +834,9 @@ def main():
                           'achieved': flop / (us * 1e-6) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': flop / (us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS,
                           'traffic': kc.get('hbm_bytes_per_launch') if kc else None,
+                          'traffic_note': 'HBM bytes per launch by the counters; the algorithmic minimum is the unscaled matrix in and the '
+                                          f'factor out: {2 * nreg * nunk * nunk * 8} B',
+                          'wasted': (kc['hbm_bytes_per_launch'] / (2.0 * nreg * nunk * nunk * 8)) if kc and kc.get('hbm_bytes_per_launch') else None,
                           'note': 'latency-bound: 23 dependent block steps (diagonal factor by one wave, panel chains, '
                                   'one hand-over between workgroups per 64 columns); tiles stay in LDS'}
         # SURVEY.md 8(d), the exception to the HBM bound: the convolution of the subtraction (25 B and
@@ -1095,6 +1101,7 @@ def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_
                                  'avg_launch_us': us, 'algorithmic_bytes_per_launch': byt, 'achieved': byt / (us * 1e-6) / 1e9,
                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
+                                 'wasted': kp['hbm_bytes_per_launch'] / byt if kp and kp.get('hbm_bytes_per_launch') else None,
                                  'valu_insts_per_px': kp.get('valu_insts_per_px') if kp else None}
     ms, cnt = scopes['combine']
     if cnt:
@@ -1104,7 +1111,9 @@ def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_
         out['combine_roofline'] = {'bound': 'hbm', 'kernel': f'k_combine<{args.frames}> CLIPPED', 'avg_launch_us': us,
                                    'algorithmic_bytes_per_launch': byt, 'achieved': byt / (us * 1e-6) / 1e9,
                                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                   'traffic': kp.get('hbm_bytes_per_launch') if kp else None}
+                                   'frac_of_achievable': byt / (us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBS,
+                                   'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
+                                   'wasted': kp['hbm_bytes_per_launch'] / byt if kp and kp.get('hbm_bytes_per_launch') else None}
         out['combine_kernel'] = {'avg_us': us, 'algorithmic_bytes': byt, 'achieved_GBs': byt / (us * 1e-6) / 1e9,
                                  'frac_of_hbm_peak': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     out['counters_from'] = pmc.get('stale') or f'{pmc.get("file")} (kernel sources {pmc.get("kernel_sources_sha16")})'

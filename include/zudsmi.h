@@ -292,7 +292,8 @@ int zm_mask_finalize_dev(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);
  * zm_coadd_reduce_dev: sum-reduce of S1 / S0, the two planes of ONE buffer of 2 npix floats as
  * zm_coadd_dev(partial = 1) fills them when out_wgt == out_img + npix; then zm_coadd_finalize_dev.
  * zm_mask_reduce_dev: the partial masks (-1 marker) of all ranks folded with AND / OR by row
- * bands, every rank ends with the finalised mask (cov may be NULL).  All enqueue on the stream. */
+ * bands, every rank ends with the finalised mask (cov may be NULL).  All enqueue on the stream.
+ * A communicator holds at most ZM_COMM_MAX_RANKS (64) ranks: zm_comm_init refuses more. */
 #define ZM_COMM_ID_BYTES 128
 typedef struct zm_comm zm_comm;
 int zm_comm_unique_id(void* id128);

@@ -36,7 +36,7 @@ grep -E "k_coadd_fused|k_combine" $out/pmc_summary_clipped.txt | grep -E "FETCH|
 python3 tools/make_pmc_json.py $out $out/pmc.json
 # ... and the full bench line LAST, with this round's counter profile in the place bench.py reads it from (on
 # this box's copy of the tree), so that the committed line quotes counters taken at its own commit
-cp $out/pmc.json profiles/r04_pmc.json
+cp $out/pmc.json profiles/r05_pmc.json
 cp $out/bench.json $out/bench_short.json
 rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_SQ $out/prof    # (raw traces: tens of MB)
 timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }

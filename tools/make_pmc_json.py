@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: the counter profile bench.py quotes (profiles/rNN_pmc.json), from one tools/gpu_round.sh run.
 
-    python tools/make_pmc_json.py gpurun_out/<tag> profiles/r04_pmc.json
+    python tools/make_pmc_json.py gpurun_out/<tag> profiles/r05_pmc.json
 
 Inputs of that directory: pmc_summary.txt (+ pmc_summary_clipped.txt), written by tools/pmc_summary.py from
 separate rocprofv3 --pmc passes of the short bench command (FETCH_SIZE, WRITE_SIZE and the SQ counters each in
@@ -64,6 +64,10 @@ def section(path, frames, npx):
                 # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles, the latter summed over the waves of
                 # a SIMD: at four waves per SIMD a SIMD that always issues VALU shows 1 / 4
                 e['valu_active_over_wave_cycles'] = c.get('SQ_ACTIVE_INST_VALU', 0.0) / c['SQ_WAVE_CYCLES']
+                # the share of a SIMD's time with a vector instruction in its pipe: x the resident waves per SIMD
+                # (two 512-thread workgroups per CU = four waves per SIMD)
+                e['waves_per_simd'] = 4
+                e['valu_busy_frac'] = e['valu_active_over_wave_cycles'] * e['waves_per_simd']
         kernels[key] = e
     return {'kernels': kernels}
 

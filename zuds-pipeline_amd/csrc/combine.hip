@@ -33,16 +33,21 @@ __device__ inline void bitonic_sort(float (&a)[N]) {
     }
 }
 
-template <int N>
-__device__ inline float pick(const float (&a)[N], int idx) {
-    float r = a[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) r = (i == idx) ? a[i] : r;
-    return r;
+// The median of the valid samples without a data-dependent pick: an invalid sample's key is an infinity, minus
+// and plus by turns (the first invalid sample gets minus), so that ceil(m / 2) of the m pads sort in front of the
+// valid keys and the rest behind them.  The valid samples' middle then sits at fixed positions of the sorted
+// array: N / 2 - 1 and N / 2 for an even count, N / 2 (twice) for an odd one - the elements (nv - 1) >> 1 and
+// nv >> 1 of the valid keys in both cases, i.e. the value oracle/combine.py takes.  (The select chain over a
+// lane-varying index that used to fetch them was turned into a stack array by the compiler: the sorted keys
+// written to scratch, 136 B per pixel and launch of HBM writes)
+__device__ __forceinline__ float pad_key(bool ok, float v, unsigned& par) {
+    const float pad = __uint_as_float(0x7f800000u | (par << 31));     // par = 1: -inf, 0: +inf
+    par ^= ok ? 0u : 1u;
+    return ok ? v : pad;
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(256) void k_combine(const float2* __restrict__ stack,
+__global__ __launch_bounds__(256, NMAX <= 32 ? 4 : 2) void k_combine(const float2* __restrict__ stack,
                                                  int64_t fstride, int n, int64_t npix, int kind,
                                                  float clip_sigma, float clip_ampfrac,
                                                  float* __restrict__ out_img,
@@ -79,16 +84,17 @@ __global__ __launch_bounds__(256) void k_combine(const float2* __restrict__ stac
     float key[NMAX];
     int nv = 0;
     float sw = 0.f;
+    unsigned par = 1u;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
-        bool ok = w[i] > 0.f;
-        key[i] = ok ? v[i] : __builtin_inff();
+        const bool ok = w[i] > 0.f;
+        key[i] = pad_key(ok, v[i], par);
         nv += ok ? 1 : 0;
         sw += w[i];
     }
     bitonic_sort<NMAX>(key);
     float med = 0.f;
-    if (nv > 0) med = 0.5f * (pick<NMAX>(key, (nv - 1) >> 1) + pick<NMAX>(key, nv >> 1));
+    if (nv > 0) med = 0.5f * (((nv & 1) ? key[NMAX / 2] : key[NMAX / 2 - 1]) + key[NMAX / 2]);
     if (kind == ZM_COMBINE_MEDIAN) {
         out_img[p] = med;
         out_wgt[p] = sw;
@@ -96,15 +102,20 @@ __global__ __launch_bounds__(256) void k_combine(const float2* __restrict__ stac
     }
     // CLIPPED
     const float amp = clip_ampfrac * fabsf(med);
+    // (branch-free: the sums of the kept samples in frame order, the same operations as the nested conditions)
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
-        if (w[i] > 0.f) {
-            float sig = rsqrtf(w[i]);
-            if (fabsf(v[i] - med) <= clip_sigma * sig + amp) {
-                s1 = fmaf(w[i], v[i], s1);
-                s0 += w[i];
-            }
-        }
+        float wi = w[i];
+        // (opaque, and behind the median: carried over from the key loop a validity predicate is held in a scalar
+        // register pair across the sort; hoisted above it, every sample's sigma costs a register)
+        asm volatile("" : "+v"(wi) : "v"(med), "v"(s0));
+        // (an invalid sample - weight 0, sigma infinite - passes the test and adds exact zeros: one predicate)
+        const float sig = rsqrtf(wi), vi = wi > 0.f ? v[i] : 0.f;
+        const bool keep = fabsf(vi - med) <= clip_sigma * sig + amp;
+        const float t1 = fmaf(wi, vi, s1), t0 = s0 + wi;
+        s1 = keep ? t1 : s1;
+        s0 = keep ? t0 : s0;
+        __builtin_amdgcn_sched_barrier(0);          // (one sample at a time: hoisted, the 32 - 64 sigmas cost a register each)
     }
     out_img[p] = s0 > 0.f ? s1 / s0 : 0.f;
     out_wgt[p] = s0;
@@ -154,7 +165,7 @@ __device__ __forceinline__ void wide_level(float (&key)[64], const int sub) {
 // in LDS and Shell-sorted it: 64 KB of LDS per wave at n = 256, two waves per CU, 29.6 ms for the
 // 256 x 384 x 3072 band of an 8-GPU stack against 0.7 ms for the same samples at n = 32.)
 template <int LPP>
-__global__ __launch_bounds__(256) void k_combine_wide(const float2* __restrict__ stack, int64_t fstride, int n,
+__global__ __launch_bounds__(256, 2) void k_combine_wide(const float2* __restrict__ stack, int64_t fstride, int n,
                                                       int64_t npix, int kind, float clip_sigma,
                                                       float clip_ampfrac, float* __restrict__ out_img,
                                                       float* __restrict__ out_wgt) {
@@ -173,16 +184,24 @@ __global__ __launch_bounds__(256) void k_combine_wide(const float2* __restrict__
         v[r] = s.x;
         w[r] = s.y > 0.f ? s.y : 0.f;
     }
-    float key[NL];
+    // the pads of the pixel's invalid samples alternate over the whole pixel (pad_key): lane `sub` starts with the
+    // parity of the invalid samples of the lanes before it
     int nv = 0;
     float sw = 0.f;
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
-        const bool ok = w[r] > 0.f;
-        key[r] = ok ? v[r] : __builtin_inff();
-        nv += ok ? 1 : 0;
+        nv += w[r] > 0.f ? 1 : 0;
         sw += w[r];
     }
+    unsigned par = 1u;
+#pragma unroll
+    for (int s = 0; s < LPP - 1; ++s) {
+        const int o = __shfl(NL - nv, s * PPW + px);
+        par ^= (s < sub) ? ((unsigned)o & 1u) : 0u;
+    }
+    float key[NL];
+#pragma unroll
+    for (int r = 0; r < NL; ++r) key[r] = pad_key(w[r] > 0.f, v[r], par);
 #pragma unroll
     for (int o = PPW; o < 64; o <<= 1) {                 // over the lanes of the pixel, fixed order
         nv += __shfl_xor(nv, o);
@@ -191,10 +210,9 @@ __global__ __launch_bounds__(256) void k_combine_wide(const float2* __restrict__
     wide_level<LPP, 2>(key, sub);
     float med = 0.f;
     {
-        const int e1 = nv > 0 ? (nv - 1) >> 1 : 0, e2 = nv >> 1 < N ? nv >> 1 : N - 1;
-        const float c1 = pick<NL>(key, e1 & (NL - 1)), c2 = pick<NL>(key, e2 & (NL - 1));
-        const float m1 = __shfl(c1, (e1 >> 6) * PPW + px), m2 = __shfl(c2, (e2 >> 6) * PPW + px);
-        if (nv > 0) med = 0.5f * (m1 + m2);
+        // sorted positions N / 2 - 1 and N / 2: the last register of lane LPP / 2 - 1, the first of lane LPP / 2
+        const float m1 = __shfl(key[NL - 1], (LPP / 2 - 1) * PPW + px), m2 = __shfl(key[0], (LPP / 2) * PPW + px);
+        if (nv > 0) med = 0.5f * (((nv & 1) ? m2 : m1) + m2);
     }
     if (kind == ZM_COMBINE_MEDIAN) {
         if (live && sub == 0) {
@@ -208,13 +226,15 @@ __global__ __launch_bounds__(256) void k_combine_wide(const float2* __restrict__
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
-        if (w[r] > 0.f) {
-            const float sig = rsqrtf(w[r]);
-            if (fabsf(v[r] - med) <= clip_sigma * sig + amp) {
-                s1 = fmaf(w[r], v[r], s1);
-                s0 += w[r];
-            }
-        }
+        float wi = w[r];
+        asm volatile("" : "+v"(wi) : "v"(med), "v"(s0));
+        // (an invalid sample - weight 0, sigma infinite - passes the test and adds exact zeros: one predicate)
+        const float sig = rsqrtf(wi), vi = wi > 0.f ? v[r] : 0.f;
+        const bool keep = fabsf(vi - med) <= clip_sigma * sig + amp;
+        const float t1 = fmaf(wi, vi, s1), t0 = s0 + wi;
+        s1 = keep ? t1 : s1;
+        s0 = keep ? t0 : s0;
+        __builtin_amdgcn_sched_barrier(0);          // (one sample at a time: hoisted, the 32 - 64 sigmas cost a register each)
     }
 #pragma unroll
     for (int o = PPW; o < 64; o <<= 1) {

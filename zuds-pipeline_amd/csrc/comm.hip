@@ -110,6 +110,10 @@ extern "C" int zm_comm_unique_id(void* id128) {
 extern "C" int zm_comm_init(zm_ctx* ctx, int nranks, int rank, const void* id128, zm_comm** out) {
     ZM_CHECK(ctx && id128 && out, "zm_comm_init: null argument");
     ZM_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "zm_comm_init: rank %d of %d", rank, nranks);
+    // (the banded mask reduction runs the fixed-size plan of zm_comm_mask_plan - refuse here, with the
+    // reason, a communicator whose mask reduction would fail later; 64 ranks are eight 8-GPU nodes)
+    ZM_CHECK(nranks <= ZM_COMM_MAX_RANKS, "zm_comm_init: %d ranks, this library plans its band exchanges for at most %d "
+             "(ZM_COMM_MAX_RANKS, include/zudsmi.h)", nranks, ZM_COMM_MAX_RANKS);
     ZM_TRY(rccl_load());
     ZM_HIP(hipSetDevice(ctx->device));
     ncclUniqueId id;

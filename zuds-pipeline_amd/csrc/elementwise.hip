@@ -92,11 +92,28 @@ extern "C" int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, fl
     return 0;
 }
 
-// float4 copy, grid-stride over a launch sized to the chip (8 workgroups per CU): the rate a plain
-// streaming kernel reaches on this GPU, read + write
+// float4 copy: the rate a plain streaming kernel reaches on this GPU, read + write ("an achieved-copy
+// ceiling with a float4 copy kernel").  A workgroup walks slabs of 4 x 256 float4 (16 KB): four independent
+// 16-byte loads in flight per thread, stores non-temporal (written once, never read back by the launch); eight
+// workgroups per CU.  (Round 4's form - one float4 per thread and iteration, plain stores - reported 4.9 TB/s
+// where MI355X_MICROARCH.md measures 6.29 for a float4 copy: a ceiling that flattered every kernel held
+// against it)
 __global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n4; p += stride) dst[p] = src[p];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* s = reinterpret_cast<const v4f*>(src);
+    v4f* d = reinterpret_cast<v4f*>(dst);
+    const int64_t nslab = n4 >> 10;
+    for (int64_t b = blockIdx.x; b < nslab; b += gridDim.x) {
+        const int64_t o = (b << 10) + threadIdx.x;
+        const v4f r0 = s[o], r1 = s[o + 256], r2 = s[o + 512], r3 = s[o + 768];
+        __builtin_nontemporal_store(r0, d + o);
+        __builtin_nontemporal_store(r1, d + o + 256);
+        __builtin_nontemporal_store(r2, d + o + 512);
+        __builtin_nontemporal_store(r3, d + o + 768);
+    }
+    for (int64_t p = (nslab << 10) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n4;
+         p += (int64_t)gridDim.x * blockDim.x)
+        d[p] = s[p];
 }
 
 extern "C" int zm_copy_probe_dev(zm_ctx* ctx, const void* src, void* dst, int64_t nbytes) {

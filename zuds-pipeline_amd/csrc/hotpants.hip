@@ -4271,6 +4271,17 @@ static int hp_launch_cells(zm_ctx* ctx, const hp_plan& P, const float* ref, cons
 }
 
 static std::atomic<int> g_hp_fitting[64];    // per device: contexts inside the kernel fit
+// A context inside its kernel fit (zm_subtract_dev and, ADVICE r4, zm_subtract_batch_dev: a lone subtraction that
+// starts beside a batch must see it and take the one-workgroup-per-region factorisation, whose launches need
+// nothing resident - the batch's kernels hold CUs the many-workgroup form would wait for until its spins give up).
+struct hp_fit_guard {
+    std::atomic<int>* c;
+    int others;
+    explicit hp_fit_guard(std::atomic<int>* cc) : c(cc), others(cc->fetch_add(1)) {}
+    bool shared() const { return c && (others > 0 || c->load(std::memory_order_relaxed) > 1); }
+    void release() { if (c) c->fetch_sub(1); c = nullptr; }
+    ~hp_fit_guard() { release(); }
+};
 
 extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms, const float* ref,
                                const float* ref_rms, const uint8_t* bpm, int nx, int ny,
@@ -4375,14 +4386,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     // (the count is read again whenever a factorisation is enqueued - a context that started alone
     // gives up the many-workgroup form as soon as a second one begins to fit - and it covers the fit only,
     // not the convolution behind it.)
-    struct fit_guard {
-        std::atomic<int>* c;
-        int others;
-        explicit fit_guard(std::atomic<int>* cc) : c(cc), others(cc->fetch_add(1)) {}
-        bool shared() const { return c && (others > 0 || c->load(std::memory_order_relaxed) > 1); }
-        void release() { if (c) c->fetch_sub(1); c = nullptr; }
-        ~fit_guard() { release(); }
-    } fitting(&g_hp_fitting[ctx->device & 63]);
+    hp_fit_guard fitting(&g_hp_fitting[ctx->device & 63]);
     for (int attempt = 0; attempt < 2; ++attempt) {
     const bool safe = attempt > 0;
     const int spin_limit = (!safe && spin_env) ? atoi(spin_env) : CF_SPIN_LIMIT;
@@ -4940,6 +4944,17 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         ~stream_swap() { c->stream = keep; }
     };
     std::vector<int> rounds(njobs, 0);
+    //  the batch counts as a fitting context of this device for as long as its rounds run, and
+    // convolutions enqueued on the second stream are joined to the main one on EVERY way out of the call - also
+    // when a launch in between fails and the caller goes on to reuse the products' planes
+    hp_fit_guard fitting(&g_hp_fitting[ctx->device & 63]);
+    struct aux_join {
+        zm_ctx* c; hipStream_t st; hipEvent_t ev; bool armed;
+        ~aux_join() {
+            if (!armed) return;
+            if (hipEventRecord(ev, c->aux) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+        }
+    } join{ctx, st, evs[0], false};
     ZM_TRY(enqueue_round(1));
     for (int r = 1; r <= 8; ++r) {
         if (r < 8) ZM_TRY(enqueue_round(r + 1));
@@ -4952,6 +4967,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
                 rounds[j] = r;
                 if (apply_beside) {
                     stream_swap sw(ctx, ctx->aux);
+                    join.armed = true;
                     ZM_TRY(enqueue_apply(j));
                 }
             } else {
@@ -4960,7 +4976,9 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         }
         if (live.empty()) break;
     }
+    fitting.release();
     if (apply_beside) {
+        join.armed = false;
         ZM_HIP(hipEventRecord(evs[0], ctx->aux));
         ZM_HIP(hipStreamWaitEvent(st, evs[0], 0));
     } else {

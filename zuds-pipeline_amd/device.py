@@ -203,6 +203,7 @@ class DeviceSubtraction(object):
                                     self.bpm.data_ptr(), nx, ny, C.byref(p),
                                     self.diff.data_ptr(), self.noise.data_ptr(),
                                     C.byref(self.info)), 'zm_subtract_dev')
+        self.check_limits()
         return self.finish()
 
     def job(self, scim, sci_rms, p):
@@ -294,6 +295,11 @@ class DeviceSubtraction(object):
                 check(L.zm_median_mad2_async_dev(ctx, scim.data_ptr(), sci_mask.data_ptr(),
                                                  self.ref_al.data_ptr(), self.refmask_al.data_ptr(),
                                                  self.n, self._lim_dev.data_ptr()), 'sci / ref bkg')
+                # (the two sample counts travel to a pinned buffer behind the estimates, so that the call
+                # that waits for the fit anyway can refuse a frame without a valid pixel as the host path does)
+                if getattr(self, '_lim_host', None) is None:
+                    self._lim_host = self.torch.zeros(6, dtype=self.torch.float64).pin_memory()
+                self._lim_host.copy_(self._lim_dev, non_blocking=True)
                 self._limits = None
                 p = hp_params(**job_params(seeing, nx, ny, nreg_side, 0.0, 0.0, hotpants_kws))
                 p.limits_dev = self._lim_dev.data_ptr()
@@ -312,11 +318,19 @@ class DeviceSubtraction(object):
         entry points do, when a frame had no valid pixel."""
         if getattr(self, '_limits', None) is None:
             self.stream.synchronize()
-            m1, s1, c1, m2, s2, c2 = (float(v) for v in self._lim_dev.cpu())
-            if not (c1 > 0 and c2 > 0):
-                raise _lib.ZMError('zm_median_mad2: every pixel is masked')
+            self.check_limits()
+            m1, s1, _, m2, s2, _ = (float(v) for v in self._lim_host)
             self._limits = dict(il=m1 - 10 * s1, tl=m2 - 10 * s2)
         return self._limits
+
+    def check_limits(self):
+        """Behind a wait for this chain's fit (``zm_subtract_dev`` / ``zm_subtract_batch_dev`` return with the fit
+        summary, which the stream delivers after the estimates): raise, as the host entry point
+        ``zm_median_mad2`` does, when the science frame or the aligned reference had no valid pixel - the fit of
+        such a job ran on limits of 0 and its products are fill values."""
+        if getattr(self, '_limits', None) is None and getattr(self, '_lim_host', None) is not None:
+            if not (float(self._lim_host[2]) > 0 and float(self._lim_host[5]) > 0):
+                raise _lib.ZMError('zm_median_mad2: every pixel is masked')
 
 
 # ---------------------------------------------------------------------------

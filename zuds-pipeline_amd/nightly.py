@@ -174,10 +174,15 @@ def _batches(keys, batch):
 class _BatchLane(object):
     """An engine, its stream and up to ``batch`` subtraction chains whose kernel fits run as one batch."""
 
-    def __init__(self, device, batch, turn=None):
+    def __init__(self, device, batch, turn=None, share=1):
         import torch
         self.torch = torch
         self.engine = Engine(device)
+        # (ADVICE r4) a chunk of ONE job - a fit-key group of size 1, the per-job repeat after a failed batch -
+        # goes through zm_subtract_dev: with other lanes at work it must take the one-workgroup-per-region
+        # factorisation like the workers of an unbatched pool, not the form that wants the GPU to itself
+        if share >= 2:
+            self.engine.set_share(share)
         self.stream = torch.cuda.Stream(torch.device('cuda', device))
         self.engine.set_stream(self.stream.cuda_stream)
         self.device, self.batch = device, batch
@@ -230,6 +235,11 @@ class _BatchLane(object):
         for k, job in enumerate(jobs):
             ch = self.chains[k]
             C.memmove(C.byref(ch.info), C.byref(infos[k]), C.sizeof(_lib.zm_hp_info))
+            try:
+                ch.check_limits()              # (a frame without a valid pixel fails its job, not the batch)
+            except _lib.ZMError as exc:
+                outs.append(dict(tag=job.tag, error=str(exc)))
+                continue
             diff, noise, mask = ch.finish()
             outs.append(_collect(self, ch, job, infos[k], diff, noise, mask, keep))
         self.stream.synchronize()
@@ -264,7 +274,7 @@ class SubtractionPool(object):
         if w is None:
             import torch
             torch.cuda.set_device(self.device)
-            w = self._local.w = (_BatchLane(self.device, self.batch, self._turn) if self.batch
+            w = self._local.w = (_BatchLane(self.device, self.batch, self._turn, self.share if self.njobs > 1 else 1) if self.batch
                                  else _Worker(self.device, self.share))
             with self._lock:
                 self._workers.append(w)
