@@ -365,7 +365,7 @@ def copy_ceiling(z, eng, torch, stream, device):
     b.synchronize()
     ms = a.elapsed_time(b) / 10
     del src, dst
-    return {'kernel': 'k_copy4 (float4, four loads in flight per thread, non-temporal stores, 8 workgroups per CU)', 'bytes_each_way': n,
+    return {'kernel': 'k_copy4 (float4, four non-temporal loads in flight per thread, non-temporal stores, 8 workgroups per CU)', 'bytes_each_way': n,
             'avg_us': 1e3 * ms, 'GBs_read_plus_write': 2 * n / (ms * 1e-3) / 1e9}
 
 

@@ -38,7 +38,7 @@ static int check_wcs(const zm_wcs* w, const char* what) {
 // the opt-in); the fused coadd: 64 x 64 tiles made of two k_resample boxes (their union: one more
 // alignment step), `cap` elements - a larger plan means the frame's footprints exceed the LDS tile.
 static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw = 64, int th = 32, int cap = 8000,
-                    bool exact = false) {
+                    bool exact = false, int* box_w = nullptr, int* box_h = nullptr) {
     double wmax = 0, hmax = 0;
     for (int sy = 0; sy < 3; ++sy)
         for (int sx = 0; sx < 3; ++sx) {
@@ -59,6 +59,10 @@ static int plan_lds(const zm_map_params* mp, int onx, int ony, int ntaps, int tw
         w = (double)(((long long)(ceil(wmax) + ntaps + 10)) & ~3LL);
         h = ceil(hmax) + ntaps + 4;
     }
+    // what build_tile_header3 makes of the largest sampled extents (the fixed slot of k_coadd_fused_own is sized
+    // by these, not by the area): bw = (floor(mxx) + 5 - ((floor(mnx) - 3) & ~3) + 4) & ~3, bh = floor(mxy) - floor(mny) + 9
+    if (box_w) *box_w = (int)std::min(1e6, (double)((((long long)floor(wmax)) + 16) & ~3LL));
+    if (box_h) *box_h = (int)std::min(1e6, floor(hmax) + 10);
     double e = w * h;
     if (!(e > 0) || e > cap) return cap + 1;
     return (int)e;
@@ -231,6 +235,7 @@ struct fused_stage {
     std::vector<zm_ff> ff;
     int lds = 0, lnx = 0, lny = 0;
     bool any_mask = false;
+    bool fits_own = true;          // every frame's planned box fits the fixed slot of k_coadd_fused_own (80 x 42)
 };
 static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
                          bool want_mask, fused_stage* S) {
@@ -274,7 +279,9 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         zm_make_map(wout, &fr[i].wcs, &mp_host[i]);
         double fs = 1.0;
         ZM_TRY(zm_flux_scale(&fr[i].wcs, wout, fr[i].flxscale, &fs));
-        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, ff_th, ff_cap, true);
+        int pbw = 0, pbh = 0;
+        const int plan = plan_lds(&mp_host[i], onx, ony, 6, 64, ff_th, ff_cap, true, &pbw, &pbh);
+        if (pbw > 80 || pbh > 42 || ff_th != 32) S->fits_own = false;
         // a footprint beyond the LDS tile is gathered from global memory: from a prepped plane
         // (a frame without 16-byte rows is prepped into a plane, which has them)
         const int vec_ok = (nx % 4 == 0) && (((uintptr_t)fr[i].img & 15) == 0) && (((uintptr_t)fr[i].wgt & 15) == 0);
@@ -382,7 +389,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     ZM_TRY(zm_launch_fused_prepass(ctx, rows.data(), (int)rows.size()));
     // the descriptors are final: the item headers go out on the second stream, behind the box-OR planes and the
     // lattices they read, beside the background chain of the main stream
-    ZM_TRY(zm_launch_fused_headers_early(ctx, ff.data(), n, lnx, lny, onx, ony, lds));
+    ZM_TRY(zm_launch_fused_headers_early(ctx, ff.data(), n, lnx, lny, onx, ony, lds, S->fits_own));
     if (boxes_done) ZM_HIP(hipStreamWaitEvent(ctx->stream, boxes_done, 0));
     S->lds = lds;
     S->any_mask = any_mask;
@@ -403,7 +410,7 @@ static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wo
     ZM_TRY(fused_prepare(ctx, n, fr, wout, P, out_mask != nullptr, &S));
     return zm_launch_coadd_fused(ctx, S.ff.data(), n, S.lnx, S.lny, onx, ony, S.lds, P->combine, P->mask_combine,
                                  out_img, out_wgt, (out_mask && S.any_mask) ? out_mask : nullptr, out_cov, partial,
-                                 out_mask && !S.any_mask ? out_mask : nullptr);
+                                 out_mask && !S.any_mask ? out_mask : nullptr, nullptr, 0, S.fits_own);
 }
 
 // The resampled stack of a CLIPPED / MEDIAN coadd through the same kernel (STACK mode: samples stored,
@@ -416,7 +423,7 @@ static int resample_frames_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const 
     ZM_TRY(fused_prepare(ctx, n, fr, wout, P, acc_mask != nullptr, &S));
     return zm_launch_coadd_fused(ctx, S.ff.data(), n, S.lnx, S.lny, onx, ony, S.lds, ZM_COMBINE_WEIGHTED,
                                  P->mask_combine, nullptr, nullptr, (acc_mask && S.any_mask) ? acc_mask : nullptr,
-                                 nullptr, 1, acc_mask && !S.any_mask ? acc_mask : nullptr, stack, opix);
+                                 nullptr, 1, acc_mask && !S.any_mask ? acc_mask : nullptr, stack, opix, S.fits_own);
 }
 
 extern "C" int zm_resample_stack_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,

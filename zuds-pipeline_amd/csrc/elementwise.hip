@@ -98,20 +98,21 @@ extern "C" int zm_mask_flag_dev(zm_ctx* ctx, int32_t* mask, const float* img, fl
 // workgroups per CU.  (Round 4's form - one float4 per thread and iteration, plain stores - reported 4.9 TB/s
 // where MI355X_MICROARCH.md measures 6.29 for a float4 copy: a ceiling that flattered every kernel held
 // against it)
+template <int U, bool NTL>
 __global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f* s = reinterpret_cast<const v4f*>(src);
     v4f* d = reinterpret_cast<v4f*>(dst);
-    const int64_t nslab = n4 >> 10;
+    const int64_t nslab = n4 / (256 * U);
     for (int64_t b = blockIdx.x; b < nslab; b += gridDim.x) {
-        const int64_t o = (b << 10) + threadIdx.x;
-        const v4f r0 = s[o], r1 = s[o + 256], r2 = s[o + 512], r3 = s[o + 768];
-        __builtin_nontemporal_store(r0, d + o);
-        __builtin_nontemporal_store(r1, d + o + 256);
-        __builtin_nontemporal_store(r2, d + o + 512);
-        __builtin_nontemporal_store(r3, d + o + 768);
+        const int64_t o = b * (256 * U) + threadIdx.x;
+        v4f r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = NTL ? __builtin_nontemporal_load(s + o + 256 * u) : s[o + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(r[u], d + o + 256 * u);
     }
-    for (int64_t p = (nslab << 10) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n4;
+    for (int64_t p = nslab * (256 * U) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n4;
          p += (int64_t)gridDim.x * blockDim.x)
         d[p] = s[p];
 }
@@ -124,7 +125,15 @@ extern "C" int zm_copy_probe_dev(zm_ctx* ctx, const void* src, void* dst, int64_
     ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     const int64_t n4 = nbytes / 16;
     const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)ncu * 8);
-    hipLaunchKernelGGL(k_copy4, dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
+    // (developer: ZM_COPY_FORM = loads in flight per thread (4, 8) + 'n' for non-temporal loads, e.g. "8n")
+    // (measured, GB/s read + write on one box: 4: 5558, 4n: 5865, 8: 5323, 8n: 5681 - the default is 4n)
+    const char* cf = getenv("ZM_COPY_FORM");
+    const int u = cf ? atoi(cf) : 4;
+    const bool ntl = cf ? strchr(cf, 'n') != nullptr : true;
+    if (u == 8 && ntl) hipLaunchKernelGGL((k_copy4<8, true>), dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
+    else if (u == 8) hipLaunchKernelGGL((k_copy4<8, false>), dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
+    else if (ntl) hipLaunchKernelGGL((k_copy4<4, true>), dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
+    else hipLaunchKernelGGL((k_copy4<4, false>), dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);
     ZM_HIP(hipGetLastError());
     return 0;
 }

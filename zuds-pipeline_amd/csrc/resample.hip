@@ -1366,8 +1366,10 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         const long long area = (long long)bw * bh;
         // what the staging registers hold: FF_NSLOT rows per thread of a [512 / (bw / 4)] x [bw / 4] arrangement
         // (the DMA-staged kernel: rows of the y table, columns of the x-weight table)
+        // (dma == 2: the owner-staged kernel, whose slots hold a box of at most 80 x 42 pixels at a fixed pitch)
         const int use_lds = touches && area <= (long long)lds_cap && bw >= 8 && bh >= 1 &&
-                            (dma ? (bw <= FD_XCOLS && bh <= FD_YROWS) : (bw <= 256 && bh <= FF_NSLOT * (FF_THREADS / (bw >> 2))));
+                            (dma == 2 ? (bw <= 80 && bh <= 42)
+                             : dma ? (bw <= FD_XCOLS && bh <= FD_YROWS) : (bw <= 256 && bh <= FF_NSLOT * (FF_THREADS / (bw >> 2))));
         const int inside = bx0 >= 0 && by0 >= 0 && bx1 <= nx && by1 <= ny && (txi + 1) * TW <= onx &&
                            (tyi + 1) * FT_H <= ony;
         H->bx0 = bx0; H->by0 = by0; H->bw = bw; H->bh = bh;
@@ -2454,6 +2456,7 @@ __global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
                 {
                     lz3_node na, nb;
                     float dla, dlb;
+                    asm volatile("; ZM_LGKM_BEGIN" ::: "memory");   // (tests/test_isa_lint.py: no compiler-made lgkm operation up to ZM_LGKM_END)
                     lz3_issue(ltab, dxs[0], na, dla);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -2505,6 +2508,7 @@ __global__ __launch_bounds__(FF_THREADS, FF_WG_PER_CU) void k_coadd_fused(
                         av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
                     }
                 }
+                asm volatile("; ZM_LGKM_END" ::: "memory");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     constexpr int Q0 = 4 * G;
@@ -3076,6 +3080,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                 zm_v2f av[4];
                 lds_row6 ra, rb;
                 const unsigned pa = (unsigned)(size_t)p, bw8 = (unsigned)bw * 8u;    // 32-bit LDS address, row pitch in bytes
+                asm volatile("; ZM_LGKM_BEGIN" ::: "memory");   // (tests/test_isa_lint.py: no compiler-made lgkm operation up to ZM_LGKM_END)
                 lds_issue6(pa, ra);
 #pragma unroll
                 for (int rho = 0; rho < NT + 3; ++rho) {
@@ -3102,6 +3107,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
                         av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
                     }
                 }
+                asm volatile("; ZM_LGKM_END" ::: "memory");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float acc = av[j].x, vacc = av[j].y;
@@ -3198,6 +3204,684 @@ __global__ __launch_bounds__(FD_THREADS, 2) void k_coadd_fused_dma(
 #undef FD_TICK
 }
 
+// ===========================================================================
+// Round 5: the owner-staged form of the same fused coadd (k_coadd_fused_own).
+//
+// k_coadd_fused_dma closes every item with TWO workgroup barriers: the raw planes of item i + 1 land in one
+// buffer (RAW) and are prepped into another (PREP) that the pixels of item i are still reading, so "everybody is
+// through with PREP" and "everybody has prepped" are two separate rendezvous, and between them the waves that
+// hold one chunk of the box wait for those that hold two.  Here the two buffers are two SLOTS that take turns:
+// the raw quads of item i + 1 are DMA'd into the slot the pixels of item i do NOT read and are prepped IN
+// PLACE by the wave that issued their DMA - its own `s_waitcnt vmcnt(0)` is all the ordering the DMA -> prep
+// hand-over needs (MI355X_MICROARCH.md: nothing orders a ds_read behind a pending LDS-DMA except the issuing
+// wave's vmcnt) - so an item ends with ONE barrier: "slot of item i + 1 prepped, slot of item i free".
+// What the prep of a chunk needs from OTHER waves' DMA - the x weights and the y table of the background - is
+// fetched TWO items ahead into buffers that take turns as well, i.e. it is covered by the barrier of the item
+// before (headers are therefore fetched three items ahead, a ring of four).
+//
+// In place: a chunk is 3 box rows x 20 quads = 60 lanes; the DMA writes its image quads to bytes [0, 960) and
+// its weight quads to [960, 1920) of the chunk (lane-linear, 16 B per lane: what the engine can do); the
+// prepped chunk is the same 1920 bytes as 60 x {v0, var0, v1, var1, v2, var2, v3, var3} = three rows of the
+// {value, variance} pair plane at a FIXED pitch of 80 pixels (640 B).  A wave reads both raw quads of its
+// lanes, then writes the pairs: every read of the chunk precedes every write (one wave, LDS in order).
+// The fixed pitch and the fixed lane -> (row, quad column) map take the divisions, multiplications and row-pitch
+// additions out of all three phases ("what would shrink it"): the DMA address of a piece is
+// a clamp and a multiply-add on per-lane constants, the prep knows its row and column without arithmetic, the
+// nine window rows of a pixel group are immediate offsets of ONE address register.
+// Items whose box is wider than 80 or taller than 42 pixels take the generic per-pixel code (their header says
+// so: use_lds = 0); the launcher picks this kernel only for stacks whose planned footprints fit (near-unit
+// scale, rotations below about a degree) - everything else runs k_coadd_fused_dma as before.
+// Results: bit-identical to k_coadd_fused_dma and to the k_resample path (the same prep_pixel / bk_* / tap
+// and filter code in the same order; only LDS addresses differ).
+#define FO_PQ 20                                 // quads per staged row
+#define FO_P (4 * FO_PQ)                         // the fixed pitch: 80 pixels
+#define FO_RPC 3                                 // box rows per raw chunk (60 of 64 lanes)
+#define FO_NCH 14                                // raw chunks per slot
+#define FO_ROWS (FO_RPC * FO_NCH)                // 42 box rows
+#define FO_CHB (FO_RPC * FO_PQ * 32)             // 1920 B: a chunk, raw (image 960 | weight 960) or prepped
+#define FO_SLOT (FO_NCH * FO_CHB)                // 26880 B
+#define FO_MPC 11                                // 16-byte pieces (8 entries) per row of the box-OR tile
+#define FO_MP (8 * FO_MPC)                       // its pitch: 88 entries
+#define FO_MRPC 5                                // rows per mask chunk (55 of 64 lanes)
+#define FO_NMCH 9                                // mask chunks per tile (45 rows)
+#define FO_MCHB (FO_MRPC * FO_MPC * 16)          // 880 B
+#define FO_MSLOT (FO_NMCH * FO_MCHB)             // 7920 B
+#define FO_YROWS 44                              // rows of a y-table column
+#define FO_XWB (4 * FO_PQ * 16)                  // x weights of an item: [weight][quad column] float4, 1280 B
+#define FO_YTB (2 * FO_YROWS * 16)               // y table of an item: [mesh column][box row] float4, 1408 B
+#define FO_OFF_TAB 896                           // [4 headers 768][tile ring 16] ... tap table
+#define FO_OFF_XW (FO_OFF_TAB + FF_LDS_TAB)
+#define FO_OFF_YT (FO_OFF_XW + 2 * FO_XWB)
+#define FO_OFF_SLOT (FO_OFF_YT + 2 * FO_YTB)
+#define FO_OFF_MSK (FO_OFF_SLOT + 2 * FO_SLOT)
+#define FO_LDS (FO_OFF_MSK + 2 * FO_MSLOT)
+static_assert(4 * sizeof(ff_hdr) + 4 * 4 <= FO_OFF_TAB, "owner-staged kernel: header ring");
+static_assert(FO_OFF_XW % 16 == 0 && FO_OFF_YT % 16 == 0 && FO_OFF_SLOT % 16 == 0 && FO_OFF_MSK % 16 == 0, "16-byte LDS pieces");
+static_assert(FO_LDS <= 80 * 1024, "owner-staged kernel: LDS budget of half a CU");
+static_assert(FF_NSUB == 1, "owner-staged kernel: one k_resample tile per item");
+
+// the six pairs of window row ROW (pitch FO_P pairs) as immediate offsets of one address register
+template <int ROW>
+__device__ inline void lds_issue6_row(unsigned a, lds_row6& o) {
+    asm volatile("ds_read_b64 %0, %6 offset:%7\n\t"
+                 "ds_read_b64 %1, %6 offset:%8\n\t"
+                 "ds_read_b64 %2, %6 offset:%9\n\t"
+                 "ds_read_b64 %3, %6 offset:%10\n\t"
+                 "ds_read_b64 %4, %6 offset:%11\n\t"
+                 "ds_read_b64 %5, %6 offset:%12"
+                 : "=&v"(o.r0), "=&v"(o.r1), "=&v"(o.r2), "=&v"(o.r3), "=&v"(o.r4), "=&v"(o.r5)
+                 : "v"(a), "n"(ROW * FO_P * 8), "n"(ROW * FO_P * 8 + 8), "n"(ROW * FO_P * 8 + 16),
+                   "n"(ROW * FO_P * 8 + 24), "n"(ROW * FO_P * 8 + 32), "n"(ROW * FO_P * 8 + 40)
+                 : "memory");
+}
+
+// (launch bounds: the second argument is waves per SIMD - four, i.e. two workgroups per CU, at most 128 vector
+// registers.  With "2" the compiler is free to take 256 and did, on an unrelated edit: 208 registers, ONE workgroup
+// per CU, 1.75 -> 2.57 ms.)
+// Wave priority behind a wave-uniform condition, as ONE opaque statement: a C++ `if` around s_setprio inside the
+// pixel group splits its straight-line block, and the register allocator answered with 208 registers (or, capped
+// at 128, 100 spills).  sel: a scalar register; the priority becomes PRIO when sel == WHEN.
+template <int WHEN, int PRIO>
+__device__ __forceinline__ void ff_setprio_when(int sel) {
+    asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_setprio %2\n1:" : : "s"(sel), "n"(WHEN), "n"(PRIO) : "scc");
+}
+template <int MOP, bool AVG, bool STACK, bool DEV = false>
+__global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
+    const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
+    const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
+    int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
+    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride,
+    int dbg_arg, long long* __restrict__ prof_arg) {
+    long long* const prof = DEV ? prof_arg : nullptr;
+    const int dbg = (DEV ? dbg_arg : (dbg_arg & ~255)) & 0x00ffffff;   // (bits 8 .. 23: the tile budget of the yield mode)
+    // developer switches (ZM_FF_PRIO, ZM_FF_DEAL): s_setprio 1 for 1 = the DMA issue, 2 = the prep, 4 = waves 4 - 7 in
+    // their pixel phase, 8 .. 12 = waves 4 - 7 in its first part (below); deal: who stages what (below)
+    // (the production instances carry the measured choice as constants: deal 1, switch point 2 - the runtime
+    // switches cost scalar registers in a kernel that spills them)
+    const int prio = DEV ? ((dbg_arg >> 24) & 15) : 9, deal = DEV ? ((dbg_arg >> 28) & 3) : 1;
+    extern __shared__ float4 smem4[];
+    char* smem = reinterpret_cast<char*>(smem4);
+    ff_hdr* HR = reinterpret_cast<ff_hdr*>(smem);                  // ring of 4 headers
+    int* tring = reinterpret_cast<int*>(smem + 4 * sizeof(ff_hdr));   // tiles held, by ordinal & 3
+    const float* ltab = reinterpret_cast<const float*>(smem + FO_OFF_TAB);
+    constexpr int NT = 6, OFF = -2, NW = FD_THREADS / 64, NPX = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (prio >= 8: the younger half - waves 4 - 7, which the SIMDs serve after the older waves - runs the FIRST part
+    // of its pixel phase at priority 1 and drops back at switch point prio - 7: 1 = behind the tap lookups,
+    // 2 .. 5 = behind window row 1, 3, 5, 7)
+    int ysw = __builtin_amdgcn_readfirstlane((prio >= 8 && wv >= 4) ? prio - 7 : 0);
+    asm volatile("" : "+s"(ysw));
+    // Who stages what.  The SIMDs serve their OLDER waves first (MI355X_MICROARCH.md, "Two waves per SIMD"): the
+    // phase clocks of the even deal (chunk k to wave k mod 8) showed waves 0 - 3 through their pixels in 1.48 M
+    // cycles per launch and waves 4 - 7 in 1.9 M, the former waiting 0.85 M at the barrier.  So the older half gets
+    // the staging: raw chunks 0 - 9 go to waves 0 - 3 (three, three, two, two), chunks 10 - 13 one each to waves
+    // 4 - 7; the box-OR chunks (no prep) and the tables fill up the lighter waves.
+    // deal 0: chunk k to wave k mod 8 (two, two, ..., one, one), box-OR chunks and tables to waves 6, 7;
+    // deal 1: the older half heavy, as above; deal 2: three raw chunks each to waves 0 - 3, one each to waves 4, 5,
+    // waves 6, 7 stage no raw chunk (and skip the prep): the box-OR chunks and the tables only
+    const int own0 = deal == 0 ? wv : deal == 1 ? (wv < 4 ? wv : wv + 6) : (wv < 4 ? wv : wv + 8);   // first raw chunk
+    const int owns = deal == 0 ? 8 : 4;                                                                // ... stride
+    const int ownn = deal == 0 ? 2 : deal == 1 ? (wv < 2 ? 3 : wv < 4 ? 2 : 1) : (wv < 4 ? 3 : wv < 6 ? 1 : 0);
+    // box-OR chunks m0, m0 + ms, ... (nm of them at most)
+    const int m0 = deal == 0 ? wv - 6 : deal == 1 ? (wv < 4 ? wv - 2 : wv) : (wv < 6 ? wv - 4 : wv - 4);
+    const int ms = deal == 0 ? 2 : deal == 1 ? (wv < 4 ? 2 : 1) : 4;
+    const int nm = deal == 0 ? (wv >= 6 ? 5 : 0) : deal == 1 ? (wv < 2 ? 0 : wv < 4 ? 2 : wv == 7 ? 2 : 1)
+                                                              : (wv < 4 ? 0 : wv == 4 ? 3 : 2);
+    const int ytw = deal == 0 ? 6 : deal == 1 ? 4 : 6, xww = deal == 0 ? 7 : deal == 1 ? 5 : 7;
+
+    // ---- staging, part 1: the DMA of an item's raw planes and of its box-OR tile.  A raw chunk (box rows
+    // 3 k .. 3 k + 2) is prepped by the wave that issued its DMA; the box-OR chunks are five rows each.
+    auto dma_item = [&](const ff_hdr* H, int f, int sl) __attribute__((always_inline)) {
+        const zm_ff* F = fr + f;
+        const int use_lds = H->use_lds;
+        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh;
+        if (!use_lds || (dbg & 4)) return;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));             // (the lane map is recomputed per item: held across the pixel
+                                                 // phase its four values would cost registers the group needs)
+        const int lrow = (ln * 205) >> 12, lcol = ln - lrow * FO_PQ;      // ln / 20 for ln < 80
+        const int nx = F->nx, ny = F->ny;
+        char* SL = smem + FO_OFF_SLOT + sl * FO_SLOT;
+        const float2* fsrc = F->src;
+        const int gx = bx0 + 4 * lcol;
+        const bool lok = lrow < FO_RPC && lcol < (bw >> 2);
+        if (fsrc) {
+            const int sp = F->spitch;
+            const float ZM_GLOBAL* gS = (const float ZM_GLOBAL*)zm_gptr(fsrc);
+            const unsigned xa = (unsigned)min(max(gx, 0), sp - 2), xb = (unsigned)min(max(gx + 2, 0), sp - 2);
+#pragma unroll 1
+            for (int j = 0; j < ownn; ++j) {
+                const int k = own0 + owns * j, r = FO_RPC * k + lrow;
+                if (lok && r < bh) {
+                    const unsigned gy = (unsigned)min(max(by0 + r, 0), ny - 1);
+                    ff_glds16(gS + (gy * (unsigned)sp + xa) * 2u, SL + k * FO_CHB);
+                    ff_glds16(gS + (gy * (unsigned)sp + xb) * 2u, SL + k * FO_CHB + FO_CHB / 2);
+                }
+            }
+        } else {
+            const float* fw = F->wgt;
+            const float ZM_GLOBAL* gI = zm_gptr(F->img);
+            const float ZM_GLOBAL* gW = fw ? zm_gptr(fw) : gI;
+            const unsigned xo = (unsigned)min(max(gx, 0), nx - 4);
+#pragma unroll 1
+            for (int j = 0; j < ownn; ++j) {
+                const int k = own0 + owns * j, r = FO_RPC * k + lrow;
+                if (lok && r < bh) {
+                    const unsigned o = (unsigned)min(max(by0 + r, 0), ny - 1) * (unsigned)nx + xo;
+                    ff_glds16(gI + o, SL + k * FO_CHB);
+                    ff_glds16(gW + o, SL + k * FO_CHB + FO_CHB / 2);
+                }
+            }
+        }
+        if (MOP && F->mask && nm > 0) {
+            const uint16_t* fmb = F->mbox;
+            const int mpitch = F->mpitch;
+            const int mrow = (ln * 187) >> 11, mcol = ln - mrow * FO_MPC;   // ln / 11 for ln < 64
+            const int mx0 = bx0 & ~7, bwm8 = ((bx0 + bw - mx0) + 7) >> 3;
+            char* M = smem + FO_OFF_MSK + sl * FO_MSLOT;
+            const uint16_t ZM_GLOBAL* gM = zm_gptr(fmb);
+            const bool mok = mrow < FO_MRPC && mcol < bwm8;
+            const unsigned gxm = (unsigned)min(max(mx0 + 8 * mcol, 0), mpitch - 8);
+#pragma unroll 1
+            for (int j = 0; j < nm; ++j) {
+                const int m = m0 + ms * j, r = FO_MRPC * m + mrow;
+                if (m >= FO_NMCH) break;
+                if (mok && r < bh)
+                    ff_glds16(gM + ((unsigned)min(max(by0 + r, 0), ny - 1) * (unsigned)mpitch + gxm), M + m * FO_MCHB);
+            }
+        }
+    };
+    // ... and of the tables its prep reads (two items ahead): the y part of the background for the box rows,
+    // one column per mesh column under the box (wave 4), the x weights of the box columns as
+    // [weight][quad column] (wave 5)
+    auto dma_tabs = [&](const ff_hdr* H, int f, int tb) __attribute__((always_inline)) {
+        const zm_ff* F = fr + f;
+        const int use_lds = H->use_lds;
+        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hia = H->ia, hxb = H->xb;
+        const float4* fyt = F->ytab;
+        const float2* fsrc = F->src;
+        if (!use_lds || (dbg & 4) || !fyt || fsrc || (wv != ytw && wv != xww)) return;
+        if (wv == ytw) {
+            const int ny = F->ny, ytp = F->ytp;
+            char* YT = smem + FO_OFF_YT + tb * FO_YTB;
+            const unsigned gy = (unsigned)min(max(by0 + lane, 0), ny - 1);
+            if (lane < bh) {
+                ff_glds16(zm_gptr(fyt) + (gy * (unsigned)ytp + (unsigned)min(hia, ytp - 1)), YT);
+                if (hxb != 0x7fffffff)
+                    ff_glds16(zm_gptr(fyt) + (gy * (unsigned)ytp + (unsigned)min(hia + 1, ytp - 1)), YT + FO_YROWS * 16);
+            }
+        } else {
+            const int nq4 = F->nx >> 2;
+            char* XW = smem + FO_OFF_XW + tb * FO_XWB;
+            const float4 ZM_GLOBAL* gX = zm_gptr(F->xtab);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int slot = j * 64 + lane;
+                if (slot < 4 * FO_PQ) {
+                    const int k = (slot * 205) >> 12, c = slot - k * FO_PQ;         // slot / 20 for slot < 80
+                    const int gq = min(max((bx0 >> 2) + c, 0), nq4 - 1);
+                    ff_glds16(gX + (k * nq4 + gq), XW + j * 1024);
+                }
+            }
+        }
+    };
+    // ---- staging, part 2: the wave's own chunks, raw quads -> pairs, in place (background off, variance, bad
+    // pixels, fill).  Straight-line per chunk: the LDS reads of both chunks first, then the arithmetic; the
+    // conditions are item-uniform branches, never per pixel.
+    auto prep_raw = [&](const ff_hdr* H, int f, int sl, int tb, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const zm_ff* F = fr + f;
+        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hxb = H->xb;
+        const float vs = H->vscale;
+        const float* fw = F->wgt;
+        const float4* fyt = F->ytab;
+        const float fwth = F->wthresh;
+        const int nx = F->nx, ny = F->ny;
+        const bool has_w = fw != nullptr, has_y = fyt != nullptr;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lrow = (ln * 205) >> 12, lcol = ln - lrow * FO_PQ;
+        const int gx = bx0 + 4 * lcol;
+        char* SL = smem + FO_OFF_SLOT + sl * FO_SLOT;
+        const float4* XW = reinterpret_cast<const float4*>(smem + FO_OFF_XW + tb * FO_XWB);
+        const float4* YT = reinterpret_cast<const float4*>(smem + FO_OFF_YT + tb * FO_YTB) + ((gx >= hxb) ? FO_YROWS : 0);
+        float4 xw[4];
+        if (has_y) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xw[e] = XW[e * FO_PQ + lcol];      // weight e of the quad's four pixels
+        }
+        // one chunk at a time, the next chunk's raw quads requested before the arithmetic of this one
+        float4 ra, rb, ry = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto fetch = [&](int k) __attribute__((always_inline)) {
+            const char* C = SL + k * FO_CHB;
+            ra = reinterpret_cast<const float4*>(C)[ln];
+            rb = reinterpret_cast<const float4*>(C + FO_CHB / 2)[ln];
+            if (has_y) ry = YT[min(FO_RPC * k + lrow, FO_YROWS - 1)];
+        };
+        fetch(own0);
+#pragma unroll 1
+        for (int j = 0; j < ownn; ++j) {
+            const int k = own0 + owns * j;
+            if (FO_RPC * k >= bh) break;
+            const float v[4] = {ra.x, ra.y, ra.z, ra.w};
+            const float w[4] = {rb.x, rb.y, rb.z, rb.w};
+            const float4 Y = ry;
+            if (j + 1 < ownn) fetch(k + owns);
+            float bg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_y) {
+                // bk_xpart of the four pixels, two per packed instruction (k_coadd_fused_dma's sequence)
+                zm_v2f lo = (zm_v2f){xw[0].x, xw[0].y} * (zm_v2f){Y.x, Y.x};
+                zm_v2f hi = (zm_v2f){xw[0].z, xw[0].w} * (zm_v2f){Y.x, Y.x};
+                lo = __builtin_elementwise_fma((zm_v2f){xw[1].x, xw[1].y}, (zm_v2f){Y.y, Y.y}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){xw[1].z, xw[1].w}, (zm_v2f){Y.y, Y.y}, hi);
+                lo = __builtin_elementwise_fma((zm_v2f){xw[2].x, xw[2].y}, (zm_v2f){Y.z, Y.z}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){xw[2].z, xw[2].w}, (zm_v2f){Y.z, Y.z}, hi);
+                lo = __builtin_elementwise_fma((zm_v2f){xw[3].x, xw[3].y}, (zm_v2f){Y.w, Y.w}, lo);
+                hi = __builtin_elementwise_fma((zm_v2f){xw[3].z, xw[3].w}, (zm_v2f){Y.w, Y.w}, hi);
+                bg[0] = lo.x; bg[1] = lo.y; bg[2] = hi.x; bg[3] = hi.y;
+            }
+            float2 p[4];
+            if (has_w) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = prep_pixel(v[e], w[e], true, bg[e], vs, fwth);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = prep_pixel(v[e], 1.f, false, bg[e], vs, fwth);
+            }
+            if (!FAST) {
+                const int r = FO_RPC * k + lrow;
+                const bool ok = (unsigned)(by0 + r) < (unsigned)ny && gx >= 0 && gx + 4 <= nx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e].x = ok ? p[e].x : 0.f;
+                    p[e].y = ok ? p[e].y : ZM_BIGVAR;
+                }
+            }
+            // (every raw quad of chunk k was read before this point - one wave, LDS in order, the values are in
+            // v / w - so its pairs may land on the raw bytes of other lanes; the next chunk is another 1920 bytes)
+            asm volatile("" ::: "memory");
+            if (lrow < FO_RPC) {
+                float4* d = reinterpret_cast<float4*>(SL + k * FO_CHB) + 2 * ln;
+                d[0] = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+                d[1] = make_float4(p[2].x, p[2].y, p[3].x, p[3].y);
+            }
+        }
+    };
+    // frames that could not be staged raw arrive prepped (zm_ff.src): pairs as they are, fill at the frame edge
+    auto prep_src = [&](const ff_hdr* H, int f, int sl, bool fast) __attribute__((always_inline)) {
+        const zm_ff* F = fr + f;
+        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh;
+        const int ny = F->ny, sp = F->spitch;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lrow = (ln * 205) >> 12, lcol = ln - lrow * FO_PQ;
+        const int gx = bx0 + 4 * lcol;
+        char* SL = smem + FO_OFF_SLOT + sl * FO_SLOT;
+#pragma unroll 1
+        for (int j = 0; j < ownn; ++j) {
+            const int k = own0 + owns * j;
+            if (FO_RPC * k >= bh) break;
+            const float4 a = reinterpret_cast<const float4*>(SL + k * FO_CHB)[ln];
+            const float4 b = reinterpret_cast<const float4*>(SL + k * FO_CHB + FO_CHB / 2)[ln];
+            const int r = FO_RPC * k + lrow;
+            const bool rowok = fast || (unsigned)(by0 + r) < (unsigned)ny;
+            const bool cpa = fast || (gx >= 0 && gx <= sp - 2), cpb = fast || (gx + 2 >= 0 && gx + 2 <= sp - 2);
+            const bool oka = rowok && cpa, okb = rowok && cpb;
+            asm volatile("" ::: "memory");
+            if (lrow < FO_RPC) {
+                float4* d = reinterpret_cast<float4*>(SL + k * FO_CHB) + 2 * ln;
+                d[0] = make_float4(oka ? a.x : 0.f, oka ? a.y : ZM_BIGVAR, oka ? a.z : 0.f, oka ? a.w : ZM_BIGVAR);
+                d[1] = make_float4(okb ? b.x : 0.f, okb ? b.y : ZM_BIGVAR, okb ? b.z : 0.f, okb ? b.w : ZM_BIGVAR);
+            }
+        }
+    };
+    auto prep = [&](const ff_hdr* H, int f, int sl, int tb) __attribute__((always_inline)) {
+        const int use_lds = H->use_lds, fast = H->fast;                  // (both requested before the first branch)
+        const float2* fsrc = fr[f].src;
+        if (!use_lds || (dbg & 2) || ownn == 0) return;
+        if (fsrc) prep_src(H, f, sl, fast != 0);
+        else if (fast) prep_raw(H, f, sl, tb, std::true_type{});
+        else prep_raw(H, f, sl, tb, std::false_type{});
+    };
+    const int nty = ntiles / ntx;
+    // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
+    auto tile_of = [&](int s) -> int {
+        if (s >= ntiles) return s;
+        const int r = s / ntx, c = s - r * ntx;
+        return (r == 0 ? 0 : r == 1 ? nty - 1 : r - 1) * ntx + c;
+    };
+    auto next_item = [&](int& tt, int& ff, int& kk) {
+        if (++ff == nfr) { ff = 0; ++kk; tt = tring[kk & 3]; }
+    };
+    auto hdr_word = [&](int tt, int ff) -> int {          // this thread's word of the header of item (tt, ff)
+        return tid < FF_HDR_WORDS ? ghdr[((size_t)tt * nfr + ff) * FF_HDR_WORDS + tid] : 0;
+    };
+    auto hdr_put = [&](int sl, int wd) {
+        if (tid < FF_HDR_WORDS) reinterpret_cast<int*>(&HR[sl])[tid] = wd;
+    };
+
+    if ((int)blockIdx.x >= ntiles) return;
+    int t0 = tile_of(blockIdx.x), f0 = 0, k3 = 0;
+    for (int e = tid; e < LZ_FLOATS / 4; e += FD_THREADS)
+        reinterpret_cast<float4*>(smem + FO_OFF_TAB)[e] = reinterpret_cast<const float4*>(taptab)[e];
+    if (tid == 0) {
+        // the look-ahead of three items spans 3 / nfr further tiles at the start
+        tring[0] = t0;
+        for (int o = 1; o <= 3 / nfr; ++o) tring[o] = tile_of(atomicAdd(tilectr, 1));
+    }
+    __syncthreads();
+    int t1 = t0, f1 = f0;
+    next_item(t1, f1, k3);
+    int t2 = t1, f2 = f1;
+    next_item(t2, f2, k3);
+    int t3 = t2, f3 = f2;
+    next_item(t3, f3, k3);
+    hdr_put(0, hdr_word(t0, f0));
+    if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
+    if (t2 < ntiles) hdr_put(2, hdr_word(t2, f2));
+    __syncthreads();
+    dma_tabs(&HR[0], f0, 0);
+    if (t1 < ntiles) dma_tabs(&HR[1], f1, 1);
+    dma_item(&HR[0], f0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    prep(&HR[0], f0, 0, 0);
+    __syncthreads();
+
+    // ---- this thread's pixels: column tx, rows 4 wv .. 4 wv + 3 of the 64 x 32 tile (one group)
+    const int tx = lane;
+    const int cr = wv >> 2;
+    const int cell = tx >> 4;
+    const float fx = (float)(tx & 15) * (1.f / LSTEP);
+    const float fyb = (float)((4 * wv) & 15) * (1.f / LSTEP);
+    float S1[NPX], S0[NPX], SW[NPX];
+    int32_t MK[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; SW[q] = 0.f; MK[q] = -1; }
+
+    // STACK: the samples of item (pt, pfr), held in S1 / S0, to plane pfr of the stack
+    int pt = -1, pfr = 0;
+    auto flush = [&]() {
+        if (pt < 0) return;
+        const int ptyi = pt / ntx, ptxi = pt - ptyi * ntx;
+        const int pox = ptxi * TW + tx, poy0 = ptyi * RTH + wv * NPX;
+        float2* plane = stack + (size_t)pfr * (size_t)fstride;
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            const int oy = poy0 + q;
+            if (pox < onx && oy < ony)
+                __builtin_nontemporal_store((zm_v2f){S1[q], S0[q]}, reinterpret_cast<zm_v2f*>(plane + (size_t)oy * onx + pox));
+        }
+    };
+    long long ptk[5] = {0, 0, 0, 0, 0}, tc = 0;      // developer (ZM_FF_PROF=1): shader-clock sums per phase of this wave
+#define FO_TICK(k) do { if (DEV && prof) { const long long t_ = __builtin_amdgcn_s_memtime(); ptk[k] += t_ - tc; tc = t_; } } while (0)
+    if (DEV && prof) tc = __builtin_amdgcn_s_memtime();
+    const int budget = dbg >> 8;
+    int ngrab = 0;
+    int hs = 0, sl = 0;
+    for (;;) {
+        const ff_hdr* H = &HR[hs];
+        const int h1 = (hs + 1) & 3, h2 = (hs + 2) & 3, h3 = (hs + 3) & 3;
+        const zm_ff* F = fr + f0;
+        const bool use_lds = H->use_lds, touches = H->touches, fast = H->fast;
+        const tile_hdr3* SH = &H->sub[0];
+        const int sbx0 = SH->bx0, sby0 = SH->by0;
+        const int mx0 = sbx0 & ~7;                                    // origin of the box-OR tile
+        const float2* tile = reinterpret_cast<const float2*>(smem + FO_OFF_SLOT + sl * FO_SLOT);
+        const uint16_t* mtile = reinterpret_cast<const uint16_t*>(smem + FO_OFF_MSK + sl * FO_MSLOT);
+        const int tyi = t0 / ntx, txi = t0 - tyi * ntx;
+        const int ox0 = txi * TW, oy0 = tyi * RTH + wv * NPX;
+        const int ox = ox0 + tx;
+        if (STACK) {
+            flush();
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) { S1[q] = 0.f; S0[q] = 0.f; }
+            pt = t0;
+            pfr = f0;
+        }
+        int hw3 = 0;
+        if (t3 < ntiles) hw3 = hdr_word(t3, f3);
+        const bool grab = f3 == nfr - 1;
+        int gnext = 0;
+        if (grab) {
+            // a tile budget (yield mode: the workgroup retires after `budget` tiles and leaves its CU slot to
+            // whatever else is queued on the GPU; later workgroups of the launch carry on)
+            const bool allowed = budget == 0 || ngrab + 1 < budget;
+            if (tid == 0) gnext = allowed ? atomicAdd(tilectr, 1) : ntiles;
+            ++ngrab;
+        }
+        const bool more = t1 < ntiles;
+        // the raw planes and the box-OR tile of the next item into the other slot (free since the last barrier);
+        // the tables of the item after it into the table buffer the prep of THIS item used
+        if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(1);
+        if (more) dma_item(&HR[h1], f1, sl ^ 1);
+        if (t2 < ntiles) dma_tabs(&HR[h2], f2, sl);
+        if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(0);
+        FO_TICK(0);
+
+        const bool do_px = touches && !(dbg & 1);
+        if (prio == 4 && wv >= 4) __builtin_amdgcn_s_setprio(1);
+        {
+            // x part of the bilinear lattice interpolation, once per item (k_resample's operations)
+            const float x0a = SH->nrel[cr][cell][0], x1a = SH->nrel[cr][cell + 1][0];
+            const float y0a = SH->nrel[cr][cell][1], y1a = SH->nrel[cr][cell + 1][1];
+            const float x0b = SH->nrel[cr + 1][cell][0], x1b = SH->nrel[cr + 1][cell + 1][0];
+            const float y0b = SH->nrel[cr + 1][cell][1], y1b = SH->nrel[cr + 1][cell + 1][1];
+            const float xa = __builtin_fmaf(fx, x1a - x0a, x0a), ya = __builtin_fmaf(fx, y1a - y0a, y0a);
+            const float xb = __builtin_fmaf(fx, x1b - x0b, x0b), yb = __builtin_fmaf(fx, y1b - y0b, y0b);
+            const float xd = xb - xa, yd = yb - ya;
+            const bool with_mask = MOP && F->mask != nullptr;
+            unsigned slow = !do_px ? 0u : use_lds ? 0u : 0xfu;
+            const bool any_raw = MOP && with_mask && use_lds && H->frame_raw != 0;
+            const float fscale = F->fscale, fscale2 = F->fscale2;
+            // (32-bit LDS addresses of the window origin (0, 0) and of its box-OR entry)
+            const unsigned tbase = (unsigned)(size_t)tile + 8u * (unsigned)(OFF * FO_P + OFF);
+            const uint16_t* mbase = mtile + (OFF * FO_MP + OFF + (sbx0 - mx0));
+            const int enx = F->nx, eny = F->ny;
+            const bool EDGE = !fast;
+            auto group = [&]() __attribute__((always_inline)) {
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" : : "s"(ysw) : "scc");
+                float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
+                bool shape = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float fy = fyb;
+                    asm volatile("" : "+v"(fy));
+                    fy += (float)j * (1.f / LSTEP);
+                    const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
+                    const float fxf = floorf(px), fyf = floorf(py);
+                    const float dx = px - fxf, dy = py - fyf;
+                    dxs[j] = dx;
+                    dys[j] = dy;
+                    if (j == 0) { fxf0 = fxf; fyf0 = fyf; }
+                    const float edge = fminf(fminf(dx, 1.f - dx), fminf(dy, 1.f - dy));
+                    shape = shape && !(edge < ZM_SNAP) && fxf == fxf0 && fyf == fyf0 + (float)j;
+                }
+                if (!__all(shape)) {
+                    slow |= 0xfu;
+                    return;
+                }
+                const int ix0 = (int)fxf0, iy0 = (int)fyf0;
+                unsigned inbm = 0xfu;
+                if (EDGE && MOP) {
+                    const int ix = sbx0 + OFF + ix0, iy = sby0 + OFF + iy0;
+                    const bool xin = ix >= 0 && ix + NT <= enx && ox < onx;
+                    inbm = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        inbm |= (xin && iy + j >= 0 && iy + j + NT <= eny && oy0 + j < ony) ? (1u << j) : 0u;
+                }
+                int32_t mterm[4] = {-1, -1, -1, -1};
+                if (MOP) {
+                    const int lom = __mul24(iy0, FO_MP) + ix0;
+                    uint32_t m16[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m16[j] = mbase[lom + j * FO_MP];
+                    if (any_raw) {
+                        bool defer = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) defer |= m16[j] == ZM_BOX_RAW && ((inbm >> j) & 1u);
+                        if (__any(defer)) {
+                            slow |= 0xfu;
+                            return;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t t = ff_mask_term<MOP>((int32_t)m16[j]);
+                        mterm[j] = (with_mask && ((inbm >> j) & 1u)) ? t : -1;
+                    }
+                }
+                zm_v2f txp[4][3], typ[4][3];
+                {
+                    lz3_node nd;
+                    float dl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        lz3_issue(ltab, (i & 1) ? dys[i >> 1] : dxs[i >> 1], nd, dl);
+                        lz3_wait<0>(nd);
+                        if (i & 1) lz3_eval(nd, dl, typ[i >> 1]);
+                        else lz3_eval(nd, dl, txp[i >> 1]);
+                    }
+                }
+                // (NOTHING conditional in C++ may sit inside the two hand-counted loops: a scalar load the compiler
+                // sinks into them - a kernel argument behind a condition - counts in lgkmcnt, returns out of order, and
+                // lets lds_wait_n<6> pass early: wrong window rows for the group's last pixel, found the hard way.
+                // ff_setprio_when is one opaque statement on a pinned scalar register.)
+                ff_setprio_when<1, 0>(ysw);
+                zm_v2f av[4];
+                lds_row6 ra, rb;
+                const unsigned pa = tbase + 8u * (unsigned)(__mul24(iy0, FO_P) + ix0);
+                asm volatile("; ZM_LGKM_BEGIN" ::: "memory");   // (tests/test_isa_lint.py: no compiler-made lgkm operation up to ZM_LGKM_END)
+                lds_issue6_row<0>(pa, ra);
+                zm_static_for<0, NT + 3>([&](auto rho_c) __attribute__((always_inline)) {
+                    constexpr int rho = decltype(rho_c)::value;
+                    if constexpr (rho == 2 || rho == 4 || rho == 6 || rho == 8) ff_setprio_when<rho / 2 + 1, 0>(ysw);
+                    lds_row6& cur = (rho & 1) ? rb : ra;
+                    lds_row6& nxt = (rho & 1) ? ra : rb;
+                    if constexpr (rho + 1 < NT + 3) {
+                        lds_issue6_row<rho + 1>(pa, nxt);
+                        lds_wait_n<6>(cur);
+                    } else {
+                        lds_wait_n<0>(cur);
+                    }
+                    const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rho - j;
+                        if (r < 0 || r >= NT) continue;
+                        zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) {
+                            const float tc = (c & 1) ? txp[j][c >> 1].y : txp[j][c >> 1].x;
+                            rv2 = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rv2);
+                        }
+                        const float tr = (r & 1) ? typ[j][r >> 1].y : typ[j][r >> 1].x;
+                        av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
+                    }
+                });
+                asm volatile("; ZM_LGKM_END" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float acc = av[j].x, vacc = av[j].y;
+                    const bool ok = vacc > 0.f && vacc < ZM_BADVAR_TEST;
+                    const float v = ok ? acc * fscale : 0.f;
+                    const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
+                    const float ww = AVG ? (w > 0.f ? 1.f : 0.f) : w;
+                    if (STACK) {
+                        S1[j] = v;
+                        S0[j] = w;
+                    } else {
+                        S1[j] = fmaf(ww, v, S1[j]);
+                        S0[j] += ww;
+                    }
+                    if (AVG) SW[j] += w;
+                    if (MOP) MK[j] &= mterm[j];
+                }
+            };
+            if (do_px && use_lds) group();
+            // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
+#pragma unroll 1
+            while (slow) {
+                const int q = __builtin_ctz(slow);
+                slow &= slow - 1;
+                const int oy = oy0 + q;
+                if (ox >= onx || oy >= ony) continue;
+                const float fy = fyb + (float)q * (1.f / LSTEP);
+                const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
+                const ff_px r = ff_generic_pixel<MOP>(F, tile, ltab, use_lds, touches, sbx0, sby0, FO_P, px, py);
+                const float ww = AVG ? (r.w > 0.f ? 1.f : 0.f) : r.w;
+#pragma unroll
+                for (int k = 0; k < NPX; ++k) {
+                    const bool me = (k == q);
+                    S1[k] = me ? (STACK ? r.v : fmaf(ww, r.v, S1[k])) : S1[k];
+                    S0[k] = me ? (STACK ? r.w : S0[k] + ww) : S0[k];
+                    if (AVG) SW[k] = me ? SW[k] + r.w : SW[k];
+                    if (MOP) MK[k] = (me && with_mask && r.inb) ? ff_mask_fold<MOP>(MK[k], r.m) : MK[k];
+                }
+            }
+        }
+
+        if (f0 == nfr - 1) {
+            // the tile is complete: coadd (or partial sums) and mask coadd, once
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) {
+                const int oy = oy0 + q;
+                if (ox < onx && oy < ony) {
+                    const size_t o = (size_t)oy * onx + ox;
+                    const float s1 = S1[q], s0 = S0[q];
+                    if (STACK) {
+                    } else if (partial) {
+                        out_img[o] = s1;
+                        out_wgt[o] = s0;
+                    } else {
+                        out_img[o] = s0 > 0.f ? s1 / s0 : 0.f;
+                        out_wgt[o] = AVG ? SW[q] : s0;
+                    }
+                    if (MOP) {
+                        const int32_t a = ff_mask_result<MOP>(MK[q]);
+                        if (partial) {
+                            out_mask[o] = a;
+                        } else {
+                            out_mask[o] = a == -1 ? 0 : a;
+                            if (out_cov) out_cov[o] = a == -1 ? 0.f : 1.f;
+                        }
+                    }
+                }
+                if (!STACK) { S1[q] = 0.f; S0[q] = 0.f; }
+                SW[q] = 0.f; MK[q] = -1;
+            }
+        }
+        if (prio == 4 && wv >= 4) __builtin_amdgcn_s_setprio(0);
+        FO_TICK(1);
+        // this wave's DMA has landed: its chunks of the next item are prepped where they lie
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FO_TICK(2);
+        if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(1);
+        if (more) prep(&HR[h1], f1, sl ^ 1, sl ^ 1);
+        if (t3 < ntiles) hdr_put(h3, hw3);
+        if (grab && tid == 0) tring[(k3 + 1) & 3] = tile_of(gnext);
+        if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(0);
+        FO_TICK(4);
+        // the one rendezvous of an item: the next item's slot, box-OR tile and tables are complete, this item's
+        // slot is free
+        __syncthreads();
+        FO_TICK(3);
+        t0 = t1; f0 = f1;
+        t1 = t2; f1 = f2;
+        t2 = t3; f2 = f3;
+        next_item(t3, f3, k3);
+        hs = h1;
+        sl ^= 1;
+        if (t0 >= ntiles) break;
+    }
+    if (STACK) flush();
+    if (DEV && prof && lane == 0)
+        for (int k = 0; k < 5; ++k) prof[((size_t)blockIdx.x * NW + wv) * 5 + k] = ptk[k];
+#undef FO_TICK
+}
+
 // ZM_FF_DMA=0: the register-staged kernel (developer: A / B); default: the DMA-staged one
 static bool ff_use_dma() {
     const char* e = getenv("ZM_FF_DMA");
@@ -3211,17 +3895,25 @@ void zm_fused_geometry(int* tile_h, int* lds_cap) {
 // frames: nfr descriptors on the host (device pointers inside); out_mask may be NULL (no mask coadd)
 // geometry of a fused launch: LDS tile, grid, yield budget (shared by the early header pass and the launch)
 struct ff_geom {
-    bool use_dma;
+    bool use_dma, own;
     int lds_elems, ntx, ntiles, G, budget;
     size_t shmem;
 };
-static int ff_geometry(zm_ctx* ctx, int onx, int ony, int lds_elems, ff_geom* g) {
+// ZM_FF_FORM=dma: k_coadd_fused_dma also where the owner-staged kernel would run (developer: A / B)
+static bool ff_use_own() {
+    const char* e = getenv("ZM_FF_FORM");
+    return ff_use_dma() && !(e && !strcmp(e, "dma"));
+}
+// fits_own: every frame's planned footprint fits the fixed slot of k_coadd_fused_own (fused_prepare's verdict)
+static int ff_geometry(zm_ctx* ctx, int onx, int ony, int lds_elems, bool fits_own, ff_geom* g) {
     g->ntx = zm_div_up(onx, TW);
     g->ntiles = g->ntx * zm_div_up(ony, FT_H);
     g->use_dma = ff_use_dma();
+    g->own = fits_own && ff_use_own();
     lds_elems = std::min(std::max(lds_elems, 64), g->use_dma ? FD_LDS_CAP : FF_LDS_CAP);
     g->lds_elems = (lds_elems + 7) & ~7;
-    g->shmem = g->use_dma ? (size_t)FD_OFF_RAW + 20 * (size_t)g->lds_elems + 4 * 8 * FD_YROWS
+    g->shmem = g->own ? (size_t)FO_LDS
+               : g->use_dma ? (size_t)FD_OFF_RAW + 20 * (size_t)g->lds_elems + 4 * 8 * FD_YROWS
                           : (size_t)FF_LDS_HDR + FF_LDS_TAB + 2 * (size_t)g->lds_elems * (sizeof(float2) + sizeof(uint16_t));
     ZM_CHECK(g->shmem <= 160 * 1024 / FF_WG_PER_CU, "zm_launch_coadd_fused: LDS tile of %zu bytes", g->shmem);
     // persistent grid: FF_WG_PER_CU workgroups per CU (what their LDS tiles leave room for), each starting
@@ -3264,7 +3956,7 @@ static int ff_upload_and_headers(zm_ctx* ctx, const zm_ff* frames_host, int nfr,
         zm_scope_timer th(ctx, "ff_headers");
         const long long items = (long long)g.ntiles * nfr;
         hipLaunchKernelGGL(k_ff_headers, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, dev, nfr,
-                           lnx, lny, onx, ony, g.lds_elems, g.use_dma ? 1 : 0, g.ntx, g.ntiles, ghdr, tilectr, g.G, skip_vscale);
+                           lnx, lny, onx, ony, g.lds_elems, g.own ? 2 : g.use_dma ? 1 : 0, g.ntx, g.ntiles, ghdr, tilectr, g.G, skip_vscale);
     }
     ZM_HIP(hipGetLastError());
     *dev_out = dev;
@@ -3277,12 +3969,12 @@ static int ff_upload_and_headers(zm_ctx* ctx, const zm_ff* frames_host, int nfr,
 // the background chain except the variance scales, which k_ff_vscale drops in later): 80 us off the main stream.
 // Call when the descriptors are final; zm_launch_coadd_fused then finds the headers made (ctx->ff_pre_*).
 int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
-                                  int lds_elems) {
+                                  int lds_elems, bool fits_own) {
     ctx->ff_pre_valid = false;
     static const bool fork_off = getenv("ZM_FF_FORK") && getenv("ZM_FF_FORK")[0] == '0';
     if (!ctx->aux || ctx->timing || fork_off) return 0;      // (scope timers keep a timed kernel on the main stream)
     ff_geom g;
-    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, &g));
+    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, fits_own, &g));
     zm_ff* dev = nullptr;
     int* ghdr = nullptr;
     ZM_TRY(ff_upload_and_headers(ctx, frames_host, nfr, lnx, lny, onx, ony, g, ctx->aux, 1, &dev, &ghdr));
@@ -3294,13 +3986,14 @@ int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr
     ctx->ff_pre_onx = onx;
     ctx->ff_pre_ony = ony;
     ctx->ff_pre_lds = lds_elems;
+    ctx->ff_pre_own = fits_own;
     return 0;
 }
 
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
-                          float2* stack, int64_t fstride) {
+                          float2* stack, int64_t fstride, bool fits_own) {
     if (unmasked_out) {
         // a mask coadd was asked for but no frame carries a mask: "nothing covered" everywhere
         const size_t opix = (size_t)onx * ony;
@@ -3309,8 +4002,8 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     }
     const int lds_in = lds_elems;
     ff_geom g;
-    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, &g));
-    const bool use_dma = g.use_dma;
+    ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, fits_own, &g));
+    const bool use_dma = g.use_dma, own = g.own;
     lds_elems = g.lds_elems;
     const size_t shmem = g.shmem;
     const int ntx = g.ntx, ntiles = g.ntiles, G = g.G, budget = g.budget;
@@ -3319,7 +4012,7 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     zm_ff* dev = nullptr;
     int* ghdr = nullptr;
     const bool pre = ctx->ff_pre_valid && ctx->ff_pre_nfr == nfr && ctx->ff_pre_onx == onx && ctx->ff_pre_ony == ony &&
-                     ctx->ff_pre_lds == lds_in;
+                     ctx->ff_pre_lds == lds_in && ctx->ff_pre_own == fits_own;
     ctx->ff_pre_valid = false;
     if (pre) {
         // the headers were made on the second stream (zm_launch_fused_headers_early): wait for them, fill in the
@@ -3338,7 +4031,9 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     const bool avg = combine == ZM_COMBINE_AVERAGE;
     const int mop = out_mask ? (mask_kind == ZM_MASK_AND ? 1 : 2) : 0;
     // ZM_FF_DBG (developer, tools/ff_probe.py): 1 no pixel work, 2 no prep / LDS store, 4 no staging loads
-    const int dbg = (getenv("ZM_FF_DBG") ? (atoi(getenv("ZM_FF_DBG")) & 255) : 0) | (budget << 8);
+    const int dbg = (getenv("ZM_FF_DBG") ? (atoi(getenv("ZM_FF_DBG")) & 255) : 0) | ((budget & 0xffff) << 8) |
+                    (own && getenv("ZM_FF_PRIO") ? ((atoi(getenv("ZM_FF_PRIO")) & 15) << 24) : 0) |
+                    (own ? (((getenv("ZM_FF_DEAL") ? atoi(getenv("ZM_FF_DEAL")) : 1) & 3) << 28) : 0);
     long long* prof = nullptr;
     const bool want_prof = getenv("ZM_FF_PROF") && atoi(getenv("ZM_FF_PROF")) != 0;
     const int nwv = (use_dma ? FD_THREADS : FF_THREADS) / 64;
@@ -3346,6 +4041,19 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
     zm_scope_timer t(ctx, "coadd_fused");
 #define ZM_FF_LAUNCH(MOPV, AVGV, STACKV)                                                                      \
     do {                                                                                                       \
+        if (own) {                                                                                             \
+            const bool devk = want_prof || (dbg & 255);                                                        \
+            auto ko = devk ? k_coadd_fused_own<MOPV, AVGV, STACKV, true> : k_coadd_fused_own<MOPV, AVGV, STACKV, false>; \
+            static bool oattr[2][64] = {};                                                                     \
+            if (!oattr[devk][ctx->device & 63]) {                                                              \
+                ZM_HIP(hipFuncSetAttribute((const void*)ko, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+                oattr[devk][ctx->device & 63] = true;                                                          \
+            }                                                                                                  \
+            hipLaunchKernelGGL(ko, dim3(G), dim3(FD_THREADS), shmem, ctx->stream, dev, nfr, onx, ony, lds_elems, \
+                               ntx, ntiles, ghdr, out_img, out_wgt, out_mask, out_cov, partial, taptab, tilectr, \
+                               stack, (long long)fstride, dbg, prof);                                          \
+            break;                                                                                             \
+        }                                                                                                      \
         if (use_dma) {                                                                                         \
             const bool devk = want_prof || (dbg & 255);                                                        \
             auto kd = devk ? k_coadd_fused_dma<MOPV, AVGV, STACKV, true> : k_coadd_fused_dma<MOPV, AVGV, STACKV, false>; \
@@ -3392,6 +4100,17 @@ int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int ln
         fprintf(stderr, "k_coadd_fused phases, mean per wave (kilo-cycles of the shader clock):");
         for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f", nm[k], sum[k] / ((double)nwv * G) * 1e-3);
         fprintf(stderr, "\n");
+        if (atoi(getenv("ZM_FF_PROF")) >= 2) {
+            // by wave index of the workgroup: which waves the barrier waits for
+            for (int w = 0; w < nwv; ++w) {
+                double sw[5] = {0, 0, 0, 0, 0};
+                for (int b = 0; b < G; ++b)
+                    for (int k = 0; k < 5; ++k) sw[k] += (double)h[((size_t)b * nwv + w) * 5 + k];
+                fprintf(stderr, "  wave %d:", w);
+                for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.1f", nm[k], sw[k] / G * 1e-3);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     return 0;
 }

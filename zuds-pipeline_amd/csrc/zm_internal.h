@@ -75,6 +75,7 @@ struct zm_ctx {
     // item headers of a fused coadd made ahead of the launch, on the second stream (zm_launch_fused_headers_early)
     bool ff_pre_valid = false;
     int ff_pre_nfr = 0, ff_pre_onx = 0, ff_pre_ony = 0, ff_pre_lds = 0;
+    bool ff_pre_own = false;
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed
@@ -159,11 +160,11 @@ void zm_fused_geometry(int* tile_h, int* lds_cap);
 int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows);
 int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined);
 int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
-                                  int lds_elems);
+                                  int lds_elems, bool fits_own);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                           int lds_elems, int combine, int mask_kind, float* out_img, float* out_wgt,
                           int32_t* out_mask, float* out_cov, int partial, int32_t* unmasked_out,
-                          float2* stack = nullptr, int64_t fstride = 0);
+                          float2* stack = nullptr, int64_t fstride = 0, bool fits_own = false);
 int zm_get_lanczos_table(zm_ctx* ctx, const float** out);
 int zm_frame_background(zm_ctx* ctx, const float* img, const float* wgt, int nx, int ny,
                         int mesh, int fsize, float wthresh, int mode0, int nmode,
