@@ -732,6 +732,13 @@ def main():
     clocks = None
     tools = None
     pipelined = None
+    # (round 5: the PCIe / FITS clocks run FIRST of the extra legs.  Behind the pipelined and nightly legs - dozens of
+    # engines, each with two streams, all mapped onto GPU_MAX_HW_QUEUES hardware queues - the copy stream created here
+    # shared a queue with a compute stream and the H2D copies of step k + 1 queued behind the kernels of step k:
+    # with_pcie_ms 56 -> 69 ms in the round-4 line, 1.00 x the copy alone again when measured on a fresh process.)
+    if world == 1 and rank == 0 and not args.no_clocks:
+        clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
+                                             ref_rms, step, timed, 1e3 * dt / args.steps)
     if world == 1 and rank == 0 and not args.no_subtract and not args.no_pipelined and sum_type:
         pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local)
     nightly = None
@@ -741,9 +748,6 @@ def main():
         if sum_type and not args.no_secondary:
             secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx,
                                           full_step=None if args.no_subtract else (coadd_leg, sub_leg, sci))
-        if not args.no_clocks:
-            clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
-                                                 ref_rms, step, timed, 1e3 * dt / args.steps)
 
     if rank == 0 and args.dump_coadd:
         torch.cuda.synchronize(device)
@@ -1250,7 +1254,9 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
             S['m16'] = {id(f): torch.empty(f['mask'].shape, dtype=torch.int16, device=device)
                         for f in S['frames'] + [S['sci']]}
             S['free'] = None                         # event: the compute that read this set is done
-        cs, ds = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        # (high-priority streams: the runtime gives them hardware queues of their own, so a copy never waits in a
+        # queue behind a kernel of the step it is meant to overlap with)
+        cs, ds = torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device, priority=-1)
         state = {'k': 0, 'd2h': None}
 
         def enqueue_copies(S):
@@ -1309,6 +1315,8 @@ def data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub
         clocks['with_pcie_ms'] = None
         clocks['pcie_error'] = repr(e)
 
+    if os.environ.get('ZM_BENCH_PCIE_ONLY') == '1':          # developer (tools/pcie_bisect.sh): the PCIe clock alone
+        return clocks, tools
     d = tempfile.mkdtemp(prefix='zmbench_', dir=os.environ.get('TMPDIR') or None)
     try:
         need = sum(t.numel() * t.element_size() for f, k in planes for t in [f[k]])

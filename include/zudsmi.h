@@ -384,12 +384,19 @@ int zm_resample_i16_dev(zm_ctx* ctx, const float* img, const float* wgt,
 int zm_mask_widen_dev(zm_ctx* ctx, const int16_t* in, int64_t n, int32_t* out);
 
 /* ---- per-pixel bookkeeping on device planes ---------------------------------- */
-/* rms = 1/sqrt(w), big_rms where bad or w <= 0 (zuds/image.py:173-208). */
+/* rms = 1/sqrt(w), big_rms where bad or w <= 0 (zuds/image.py:173-208; the reference's numpy gives inf for a
+ * zero weight on a pixel its mask does not flag - the object layer restores that, subtraction.py). */
 int zm_rms_from_weight_dev(zm_ctx* ctx, const float* wgt, const uint8_t* bad,
                            int64_t n, float big_rms, float* out);
 /* w = 1/rms^2, 0 where bad or img >= satur (0.9 SATURATE; zuds/image.py:136-171). */
 int zm_weight_from_rms_dev(zm_ctx* ctx, const float* rms, const uint8_t* bad,
                            const float* img, float satur, int64_t n, float* out);
+/* The false weight map of a background run without weights (zuds/sextractor.py:80-96: 1, 0 where the mask has a
+ * bad bit, 0 in a `border`-pixel frame for raw science images) and / or the boolean bad-pixel map of the mask
+ * (zuds/mask.py:42-72); mask_type ZM_MASKTYPE_I32 / _I16.  What `rms_image` / `weight_image` of a frame without
+ * .rms.fits / .weight.fits need in front of zm_background_dev and zm_weight_from_rms_dev (zuds/image.py:136-208). */
+int zm_false_weight_dev(zm_ctx* ctx, const void* mask, int mask_type, int32_t badsum, int border,
+                        int nx, int ny, float* out_wgt, uint8_t* out_bpm);
 /* out_or = a | b (b may be NULL); out_bpm = (out_or & badsum) != 0
  * (zuds/subtraction.py:135-142, zuds/mask.py:42-72). */
 int zm_mask_bad_dev(zm_ctx* ctx, const int32_t* a, const int32_t* b,

@@ -74,3 +74,22 @@ def test_bench_line_nightly_leg_with_batched_pools():
     assert bb['lanes_x_batch'] in n['batched']
     assert bb['over_one_worker'] == pytest.approx(n['pools']['1']['ms_per_subtraction'] / bb['ms_per_subtraction'])
     assert n['subtract_mpix_s'] == pytest.approx(max(r['subtract_mpix_s'] for r in list(n['pools'].values()) + list(n['batched'].values())))
+
+
+def test_h2d_copies_overlap_the_step():
+    """`clocks.with_pcie_ms`: the H2D copies of step k + 1 run under the kernels of step k, so a step with the data
+    movement inside costs max(copy, device), not their sum (the ratio had slipped from 1.01 to
+    1.22 unnoticed).  Sixteen full-size frames: the copy (1.6 GB, ~30 ms) is several times the device time, and the
+    D2H of the products (0.23 GB on the same link: PCIe is full duplex, but the two directions are not free of each
+    other - about 2 ms per step) stays below the tolerance."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--frames', '16', '--steps', '2', '--warmup', '1',
+           '--no-secondary', '--no-pipelined', '--no-nightly', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900,
+                         env=dict(os.environ, ZM_BENCH_PCIE_ONLY='1'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    c = d['clocks']
+    assert c.get('with_pcie_ms'), c
+    p = c['pcie']
+    assert p['h2d_copy_alone_ms'] > 2 * c['device_ms']            # (the case the overlap is for)
+    assert p['ratio_to_max_of_copy_and_device'] <= 1.10, c

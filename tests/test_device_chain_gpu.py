@@ -294,6 +294,26 @@ def test_limits_taken_on_the_device_equal_the_host_round_trip(chain, engine, mon
         assert np.array_equal(a[k], b[k])
 
 
+def test_a_frame_without_a_valid_pixel_is_refused_on_the_device_limits_path_too(chain, engine):
+    """with the limits taken on the device nobody looked at the sample counts any more - a science frame
+    whose every pixel is masked ran its fit on limits of 0 and came back as an "unsolved" product.  The host entry
+    point (zm_median_mad2) raises 'every pixel is masked'; so does the chain now, behind the wait for its fit."""
+    z, torch = chain['z'], chain['torch']
+    dmod = __import__('importlib').import_module('zuds-pipeline_amd.device')
+    ref, sci, f = chain['ref'], chain['ims'][3], chain['frames'][3]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to('cuda:0')
+    allbad = np.full(f['mask'].shape, 256, np.int32)
+    args = (t(f['img'], np.float32), t(sci.rms_image.data, np.float32), t(allbad, np.int32),
+            t(sci.weight_image.data, np.float32), t(ref.data, np.float32),
+            t(ref.rms_image.data, np.float32), t(ref.mask_image.data, np.int32))
+    ds = dmod.DeviceSubtraction(sci.wcs, ref.wcs, device=0, engine=engine)
+    torch.cuda.synchronize()
+    with pytest.raises(z._lib.ZMError, match='every pixel is masked'):
+        ds.run(*args, seeing=2.0, nreg_side=1, hotpants_kws=chain['kws'], ref_flxscale=float(ref.header.get('FLXSCALE', 1.0)))
+    ds.stream.synchronize()
+    engine.set_stream(0)
+
+
 def test_bit17_is_set_by_the_subtraction_itself_and_only_by_its_final_attempt(chain, device_sub, engine, monkeypatch):
     """Round 4: bit 17 where hotpants left its fill value (zuds/subtraction.py:167-177) is enqueued by
     zm_subtract_dev behind its convolution (zm_hp_params.flag_mask_dev), before the call waits for the fit summary.

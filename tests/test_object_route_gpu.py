@@ -121,3 +121,136 @@ def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine
         assert list(h.header.items()) == list(v.header.items())
         assert {k: h.hotpants_info[k] for k in h.hotpants_info} == {k: v.hotpants_info[k] for k in v.hotpants_info}
         assert v.header['ZMSTATUS'] == 0 and v.hotpants_info['ncoeff'] > 0 and v.header['SEEING'] == 2.6
+
+
+def drop_maps(d):
+    for f in os.listdir(d):
+        if f.endswith(('.rms.fits', '.weight.fits')) and f.startswith('ztf_'):
+            os.remove(os.path.join(d, f))
+
+
+def test_cold_frames_get_their_maps_on_the_device_and_the_same_files(tmp_path, engine):
+    """A frame as ZTF delivers it - science image + mask, no `.rms.fits`, no `.weight.fits`:
+    `rms_image` (scripts/dosub.py:35-47) and `weight_image` (zuds/swarp.py:43-51) make the maps from the mesh
+    background (zuds/image.py:136-208, zuds/sextractor.py:80-96).  On the device route the planes never leave HBM
+    between the file read and the two file writes; the files equal the host route's byte for byte, the objects end
+    up in the same state, and the planes wait in the cache for the from_images call that follows."""
+    z, s = pkg(), synth()
+    from importlib import import_module
+    objdev = import_module('zuds-pipeline_amd.objdev')
+    d = str(tmp_path)
+    _, paths = _scene(z, s, d, 640, 600, 3, 5600, '202005', extra=lambda i: {'SATURATE': 30000.0 + 4000 * i})
+    kept = {}
+    for name in ('host', 'device'):
+        drop_maps(d)
+        ims = reopen(z, paths)
+        assert not any(hasattr(im, '_rmsimg') or hasattr(im, '_weightimg') for im in ims)
+        # one frame asks for its rms map first (the dosub.py order), the others for their weights straight away
+        route(name, lambda: ims[0].rms_image)
+        assert os.path.exists(paths[0].replace('.fits', '.rms.fits')) and not os.path.exists(paths[0].replace('.fits', '.weight.fits'))
+        for im in ims:
+            w = route(name, lambda: im.weight_image)
+            assert w.ismapped and im._rmsimg.ismapped and '_data' not in w.__dict__
+        for p in paths:
+            for sfx in ('.rms.fits', '.weight.fits'):
+                kept[name, p, sfx] = os.path.join(d, f'{name}_' + os.path.basename(p).replace('.fits', sfx))
+                os.replace(p.replace('.fits', sfx), kept[name, p, sfx])
+    for p in paths:
+        for sfx in ('.rms.fits', '.weight.fits'):
+            same_file(z, kept['host', p, sfx], kept['device', p, sfx])
+    w = z.fits.read(kept['device', paths[1], '.weight.fits'])[0]
+    img = z.fits.read(paths[1])[0]
+    assert (w[img >= 0.9 * 34000.0] == 0).all() and (w > 0).mean() > 0.9
+    # the cache: a plane made from a file is dropped when the file changes
+    oio = objdev.get_io()
+    drop_maps(d)
+    im = reopen(z, paths[:1])[0]
+    route('device', lambda: im.weight_image)
+    assert oio.cache_get(im._weightimg.local_path, 'f32') is not None and oio.cache_get(paths[0], 'f32') is not None
+    z.fits.write(paths[0], img + np.float32(1.0), z.fits.read(paths[0])[1])
+    assert oio.cache_get(paths[0], 'f32') is None
+
+
+def test_cold_from_images_device_route_equals_host_route(tmp_path, engine):
+    """`ReferenceImage.from_images` on frames without maps and `SingleEpochSubtraction.from_images` on a science
+    frame that got its rms map from `sci.rms_image` a moment ago (the order of scripts/dosub.py:35-47, 97): device
+    route against host route, products and derived siblings file by file."""
+    z, s = pkg(), synth()
+    d = str(tmp_path)
+    _, rpaths = _scene(z, s, d, 640, 600, 3, 5700, '201911', fwhm=2.0)
+    refs = {}
+    for name in ('host', 'device'):
+        drop_maps(d)
+        out = os.path.join(d, f'ref_{name}.000651_c03_q1_zg.fits')
+        refs[name] = route(name, lambda: z.ReferenceImage.from_images(reopen(z, rpaths), out,
+                                                                      sci_swarp_kws={'COMBINE_TYPE': 'WEIGHTED'}))
+        for p in rpaths:                                  # the maps were written next to the inputs (the reference saves them)
+            assert os.path.exists(p.replace('.fits', '.rms.fits')) and os.path.exists(p.replace('.fits', '.weight.fits'))
+    for sfx in ('.fits', '.weight.fits', '.mask.fits'):
+        same_file(z, refs['host'].local_path.replace('.fits', sfx), refs['device'].local_path.replace('.fits', sfx))
+    refname = refs['device'].local_path
+    _, spaths = _scene(z, s, d, 640, 600, 1, 5800, '202004', fwhm=2.6, extra=lambda i: {'SEEING': 2.6, 'SATURATE': 40000.0})
+    res = {}
+    for name in ('host', 'device'):
+        for f in os.listdir(d):
+            if f.endswith(('.rms.fits', '.weight.fits')) and f.startswith('ztf_202004'):
+                os.remove(os.path.join(d, f))
+        sci = reopen(z, spaths)[0]
+        route(name, lambda: sci.rms_image)                # scripts/dosub.py:44-47
+        assert hasattr(sci, '_rmsimg') and not hasattr(sci, '_weightimg')
+        ref = z.ReferenceImage.from_file(refname, load_others=False)
+        ref.mask_image = z.MaskImage.from_file(refname.replace('.fits', '.mask.fits'))
+        ref._weightimg = z.FITSImage.from_file(refname.replace('.fits', '.weight.fits'))
+        sub = route(name, lambda: z.SingleEpochSubtraction.from_images(sci, ref, nreg_side=1, tmpdir=d))
+        res[name] = sub
+        for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+            os.replace(sub.local_path.replace('.fits', sfx), sub.local_path.replace('.fits', f'.{name}{sfx}'))
+        os.replace(spaths[0].replace('.fits', '.rms.fits'), os.path.join(d, f'scirms_{name}.fits'))
+        assert not os.path.exists(spaths[0].replace('.fits', '.weight.fits'))      # (a transaction copy's weight stays in memory)
+        for f in os.listdir(d):
+            if f.endswith('.rms.fits') and f.startswith('ref_'):
+                os.remove(os.path.join(d, f))
+    out = res['device'].local_path
+    for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+        same_file(z, out.replace('.fits', f'.host{sfx}'), out.replace('.fits', f'.device{sfx}'))
+    same_file(z, os.path.join(d, 'scirms_host.fits'), os.path.join(d, 'scirms_device.fits'))
+    assert list(res['host'].header.items()) == list(res['device'].header.items())
+    assert res['device'].header['ZMSTATUS'] == 0
+
+
+def test_zero_weight_on_an_unmasked_pixel_gives_the_reference_infinity(tmp_path, engine):
+    """`rms_image` from a weight map divides wherever the MASK is good (zuds/image.py:190-203): a weight
+    of zero on an unmasked pixel is 1 / sqrt(0) = inf in the reference and on the host route, not BIG_RMS; the device
+    route of `Subtraction.from_images` reproduces it (its noise product is the host route's, file by file)."""
+    z, s = pkg(), synth()
+    d = str(tmp_path)
+    refims, rpaths = _scene(z, s, d, 640, 600, 3, 5900, '201910', fwhm=2.0)
+    with_weights(z, refims)
+    refname = os.path.join(d, 'ref.000651_c03_q1_zg.fits')
+    route('device', lambda: z.ReferenceImage.from_images(reopen(z, rpaths), refname, sci_swarp_kws={'COMBINE_TYPE': 'WEIGHTED'}))
+    sims, spaths = _scene(z, s, d, 640, 600, 1, 6000, '202006', fwhm=2.6, extra=lambda i: {'SEEING': 2.6})
+    with_weights(z, sims)
+    wpath = spaths[0].replace('.fits', '.weight.fits')
+    w, wh, _ = z.fits.read(wpath)
+    msk = z.fits.read(spaths[0].replace('sciimg', 'mskimg'))[0]
+    good = np.argwhere((msk == 0) & (w > 0))
+    yy, xx = good[len(good) // 3]
+    w = w.copy()
+    w[yy, xx] = 0.0
+    z.fits.write(wpath, w, wh)
+    res = {}
+    for name in ('host', 'device'):
+        sci = reopen(z, spaths)[0]
+        ref = z.ReferenceImage.from_file(refname, load_others=False)
+        ref.mask_image = z.MaskImage.from_file(refname.replace('.fits', '.mask.fits'))
+        ref._weightimg = z.FITSImage.from_file(refname.replace('.fits', '.weight.fits'))
+        with np.errstate(divide='ignore'):
+            sub = route(name, lambda: z.SingleEpochSubtraction.from_images(sci, ref, nreg_side=1, tmpdir=d))
+        for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+            os.replace(sub.local_path.replace('.fits', sfx), sub.local_path.replace('.fits', f'.{name}{sfx}'))
+        res[name] = sub.local_path
+        for f in os.listdir(d):
+            if f.endswith('.rms.fits') and not f.startswith('sub.'):
+                os.remove(os.path.join(d, f))
+    for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+        same_file(z, res['host'].replace('.fits', f'.host{sfx}'), res['device'].replace('.fits', f'.device{sfx}'))

@@ -178,6 +178,7 @@ _SIGS = {
     'zm_median_mad2_async_dev': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
     'zm_rms_from_weight_dev': (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     'zm_weight_from_rms_dev': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, _P]),
+    'zm_false_weight_dev': (C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int, _P, _P]),
     'zm_mask_bad_dev': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     'zm_mask_flag_dev': (C.c_int, [_P, _P, _P, C.c_float, C.c_int32, C.c_int64]),
     'zm_add_scalar_dev': (C.c_int, [_P, _P, C.c_float, C.c_int64]),

@@ -12,6 +12,8 @@ __global__ void k_rms_from_weight(const float* __restrict__ w, const uint8_t* __
                                   int64_t n, float big, float* __restrict__ out) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    // (a weight that carries no information gets BIG_RMS too - also on a pixel the mask does not flag, where the
+    // reference's numpy gives 1 / sqrt(0) = inf: callers that must reproduce that put it back, subtraction.py)
     float ww = w[p];
     bool b = !(ww > 0.f) || (bad && bad[p]);
     out[p] = b ? big : 1.0f / sqrtf(ww);
@@ -26,6 +28,35 @@ __global__ void k_weight_from_rms(const float* __restrict__ rms, const uint8_t* 
     float r = rms[p];
     bool b = (bad && bad[p]) || (img && satur > 0.f && img[p] >= satur);
     out[p] = b ? 0.f : 1.0f / (r * r);
+}
+
+// The "false weight map" of a background run without weights (zuds/sextractor.py:80-96): 1, and 0 where the mask
+// carries a bad bit or - raw science frames - inside the 10-pixel border; beside it the boolean bad-pixel map of the
+// mask alone (MaskImageBase.boolean, zuds/mask.py:42-72).  T: int16 (a ZTF mask as its file holds it) or int32.
+template <typename T>
+__global__ void k_false_weight(const T* __restrict__ m, int32_t badsum, int border, int nx, int ny,
+                               float* __restrict__ out_w, uint8_t* __restrict__ out_bpm) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)nx * ny) return;
+    const int y = (int)(p / nx), x = (int)(p - (int64_t)y * nx);
+    const bool bad = ((int32_t)m[p] & badsum) != 0;
+    const bool edge = x < border || x >= nx - border || y < border || y >= ny - border;
+    if (out_w) out_w[p] = (bad || edge) ? 0.f : 1.f;
+    if (out_bpm) out_bpm[p] = bad ? 1 : 0;
+}
+
+extern "C" int zm_false_weight_dev(zm_ctx* ctx, const void* mask, int mask_type, int32_t badsum, int border,
+                                   int nx, int ny, float* out_wgt, uint8_t* out_bpm) {
+    ZM_CHECK(ctx && mask && nx > 0 && ny > 0 && border >= 0 && (out_wgt || out_bpm), "zm_false_weight_dev: bad argument");
+    ZM_CHECK(mask_type == ZM_MASKTYPE_I32 || mask_type == ZM_MASKTYPE_I16, "zm_false_weight_dev: unknown mask_type %d", mask_type);
+    ZM_HIP(hipSetDevice(ctx->device));
+    const int64_t n = (int64_t)nx * ny;
+    if (mask_type == ZM_MASKTYPE_I16)
+        hipLaunchKernelGGL(k_false_weight<int16_t>, EW_GRID(n), (const int16_t*)mask, badsum, border, nx, ny, out_wgt, out_bpm);
+    else
+        hipLaunchKernelGGL(k_false_weight<int32_t>, EW_GRID(n), (const int32_t*)mask, badsum, border, nx, ny, out_wgt, out_bpm);
+    ZM_HIP(hipGetLastError());
+    return 0;
 }
 
 // out_or = a | b; out_bpm = ((a | b) & badsum) > 0

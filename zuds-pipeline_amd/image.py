@@ -68,6 +68,12 @@ class CalibratableImageBase(FITSImage):
         try:
             return self._weightimg
         except AttributeError:
+            from . import objdev
+            if objdev.can_derive(self) and (not hasattr(self, '_rmsimg') or
+                                            (self._rmsimg.ismapped and '_data' not in self._rmsimg.__dict__)):
+                # a frame on disk without maps: derived on the device planes (objdev.derive_maps), same files
+                objdev.derive_maps(self, want_weight=True)
+                return self._weightimg
             ind = self.mask_image.boolean.data
             wgt = np.empty_like(ind, dtype='<f4')
             wgt[~ind] = 1 / self.rms_image.data[~ind] ** 2
@@ -95,7 +101,11 @@ class CalibratableImageBase(FITSImage):
                 self._rmsimg = self._derived('.rms.fits', rms)
                 return self._rmsimg
             else:
-                self._call_source_extractor(checkimage_type=['rms'], use_weightmap=False)
+                from . import objdev
+                if objdev.can_derive(self):
+                    objdev.derive_maps(self, want_weight=False)
+                else:
+                    self._call_source_extractor(checkimage_type=['rms'], use_weightmap=False)
         return self._rmsimg
 
     @property

@@ -53,6 +53,51 @@ class ObjectIO(object):
         self.pool = ThreadPoolExecutor(NREADERS)
         self._free = queue.Queue()
         self._pins = 0
+        # planes that are already in HBM, by file: what derive_maps made (and wrote) or read on the way - the
+        # from_images call that follows takes them from here instead of the file (ZM_OBJDEV_CACHE_GB, default 12)
+        self._cache = {}
+        self._cache_bytes = 0
+        self._cache_cap = int(float(os.environ.get('ZM_OBJDEV_CACHE_GB', '12')) * 1e9)
+
+    # -- plane cache --------------------------------------------------------------------------
+    @staticmethod
+    def _stamp(path):
+        st = os.stat(path)
+        return (st.st_mtime_ns, st.st_size)
+
+    def cache_put(self, path, kind, tensor):
+        """Remember that `tensor` is the decoded data of the file at `path` as it is on disk NOW."""
+        try:
+            key, stamp = (os.path.abspath(path), kind), self._stamp(path)
+        except OSError:
+            return
+        nbytes = tensor.numel() * tensor.element_size()
+        old = self._cache.pop(key, None)
+        if old is not None:
+            self._cache_bytes -= old[2]
+        while self._cache and self._cache_bytes + nbytes > self._cache_cap:
+            k0 = next(iter(self._cache))                  # oldest first (dicts keep insertion order)
+            self._cache_bytes -= self._cache.pop(k0)[2]
+        if nbytes <= self._cache_cap:
+            self._cache[key] = (tensor, stamp, nbytes)
+            self._cache_bytes += nbytes
+
+    def cache_get(self, path, kind):
+        key = (os.path.abspath(path), kind)
+        hit = self._cache.get(key)
+        if hit is None:
+            return None
+        try:
+            if self._stamp(path) != hit[1]:               # the file changed since: not this plane any more
+                raise OSError
+        except OSError:
+            self._cache_bytes -= self._cache.pop(key)[2]
+            return None
+        return hit[0]
+
+    def cache_clear(self):
+        self._cache.clear()
+        self._cache_bytes = 0
 
     # -- inputs -------------------------------------------------------------------------------
     def _pin(self, nbytes):
@@ -78,9 +123,16 @@ class ObjectIO(object):
         flight on reader threads, ``FITSDeviceIO.load_many``)."""
         torch = self.torch
         out = [None] * len(wanted)
-        files = [(i, obj.local_path, kind) for i, (obj, kind) in enumerate(wanted)
-                 if obj is not None and '_data' not in obj.__dict__]
-        for (i, _, _), (t, _) in zip(files, self.io.load_many([(p, k) for _, p, k in files], NREADERS)):
+        files = []
+        for i, (obj, kind) in enumerate(wanted):
+            if obj is None or '_data' in obj.__dict__:
+                continue
+            hit = self.cache_get(obj.local_path, kind)
+            if hit is not None:
+                out[i] = hit
+            else:
+                files.append((i, obj.local_path, kind))
+        for (i, p, k), (t, _) in zip(files, self.io.load_many([(p, k) for _, p, k in files], NREADERS)):
             out[i] = t
         with torch.cuda.stream(self.stream):
             for i, (obj, kind) in enumerate(wanted):
@@ -135,6 +187,71 @@ class ObjectIO(object):
             return pin
         for pin in self.pool.map(write, staged):
             self._free.put((pin, None))
+
+
+def can_derive(image):
+    """The maps of `image` can be made on the device: it is a file on disk whose pixels nobody holds (or has
+    changed) in memory, and so is its mask."""
+    m = getattr(image, 'mask_image', None)
+    return (enabled() and m is not None and image.ismapped and m.ismapped and
+            '_data' not in image.__dict__ and '_data' not in m.__dict__)
+
+
+def derive_maps(image, want_weight=False):
+    """``rms_image`` (and ``weight_image``) of a frame that came without ``.rms.fits`` / ``.weight.fits`` - the way
+    ZTF delivers science frames - on the device.  The reference makes them with a SExtractor run
+    and numpy (``zuds/image.py:136-208``, ``zuds/sextractor.py:80-96``, called from ``scripts/dosub.py:35-47`` and
+    ``zuds/swarp.py:43-51``); the host route here does the same through the host-pointer ``zm_background``.  Here:
+    image + mask go to HBM as they lie on disk (6 B per pixel), the false weight map, the mesh background's rms map
+    and ``w = 1 / rms^2`` (0 under bad bits and within 10 % of SATURATE) are kernels on those planes, each derived
+    map is encoded on the device and written ONCE next to the image (the reference saves them too), and the planes
+    stay in the plane cache for the ``from_images`` call that asked for them.  Sets ``image._rmsimg`` (and
+    ``_weightimg``) to file-mapped objects, like the host route after its ``save()``."""
+    from . import _lib
+    from .constants import BAD_SUM, BKG_BOX_SIZE, MASK_BORDER
+    from .image import FITSImage
+    oio = get_io()
+    torch, eng, L = oio.torch, oio.engine, oio.engine.L
+    check = _lib.check
+    img, mask = oio.planes([(image, 'f32'), (image.mask_image, 'mask')])
+    oio.cache_put(image.local_path, 'f32', img)
+    oio.cache_put(image.mask_image.local_path, 'mask', mask)
+    ny, nx = img.shape
+    n = img.numel()
+    header, comments = dict(image.header), dict(image.header_comments or {})
+    base = image.local_path
+    eng.set_stream(oio.stream.cuda_stream)
+    mt = _lib.MASKTYPE_I16 if mask.dtype == torch.int16 else _lib.MASKTYPE_I32
+    items = []
+    with torch.cuda.stream(oio.stream):
+        bpm = torch.empty((ny, nx), dtype=torch.uint8, device=oio.device)
+        if not hasattr(image, '_rmsimg'):
+            fw = torch.empty((ny, nx), dtype=torch.float32, device=oio.device)
+            border = MASK_BORDER if image.basename.endswith('sciimg.fits') else 0
+            check(L.zm_false_weight_dev(eng.ctx, mask.data_ptr(), mt, BAD_SUM, border, nx, ny, fw.data_ptr(),
+                                        bpm.data_ptr()), 'zm_false_weight_dev')
+            rms = torch.empty((ny, nx), dtype=torch.float32, device=oio.device)
+            check(L.zm_background_dev(eng.ctx, img.data_ptr(), fw.data_ptr(), nx, ny, int(BKG_BOX_SIZE), 3, None,
+                                      rms.data_ptr(), None, None), 'zm_background_dev')
+            items.append(('_rmsimg', base.replace('.fits', '.rms.fits'), rms))
+        else:
+            (rms,) = oio.planes([(image._rmsimg, 'f32')])
+            check(L.zm_false_weight_dev(eng.ctx, mask.data_ptr(), mt, BAD_SUM, 0, nx, ny, None, bpm.data_ptr()),
+                  'zm_false_weight_dev')
+        if want_weight:
+            wgt = torch.empty((ny, nx), dtype=torch.float32, device=oio.device)
+            satur = 0.9 * float(header['SATURATE']) if 'SATURATE' in header else 0.0
+            check(L.zm_weight_from_rms_dev(eng.ctx, rms.data_ptr(), bpm.data_ptr(), img.data_ptr() if satur else None,
+                                           satur, n, wgt.data_ptr()), 'zm_weight_from_rms_dev')
+            items.append(('_weightimg', base.replace('.fits', '.weight.fits'), wgt))
+    oio.save_all([(path, t, header, comments) for _, path, t in items])
+    for attr, path, t in items:
+        im = FITSImage()
+        im.basename = os.path.basename(path)
+        im.header, im.header_comments = dict(header), dict(comments)
+        im.map_to_local_file(path)
+        setattr(image, attr, im)
+        oio.cache_put(path, 'f32', t)
 
 
 def get_io(device=0):

@@ -62,8 +62,11 @@ def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_n
     oio = objdev.get_io()
     torch, eng, L = oio.torch, oio.engine, oio.engine.L
     check = _lib.check
-    sci_img, sci_mask, sci_wgt, ref_img, ref_mask, ref_wgt = oio.planes(
-        [(sci, 'f32'), (sci.mask_image, 'mask'), (sci._weightimg, 'f32'),
+    # the science frame comes with a weight map, or with an rms map (the mesh BACKGROUND_RMS map `sci.rms_image`
+    # makes for a frame that was delivered without either, scripts/dosub.py:35-47), or with both
+    sci_img, sci_mask, sci_wgt, sci_rms0, ref_img, ref_mask, ref_wgt = oio.planes(
+        [(sci, 'f32'), (sci.mask_image, 'mask'), (getattr(sci, '_weightimg', None), 'f32'),
+         (getattr(sci, '_rmsimg', None), 'f32'),
          (ref, 'f32'), (ref.mask_image, 'mask'), (ref._weightimg, 'f32')])
     eng.set_stream(oio.stream.cuda_stream)
 
@@ -79,11 +82,33 @@ def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_n
         check(L.zm_mask_bad_dev(eng.ctx, m32.data_ptr(), None, BAD_SUM, m32.numel(), None, bad.data_ptr()), 'bpm')
         check(L.zm_rms_from_weight_dev(eng.ctx, wgt.data_ptr(), bad.data_ptr(), wgt.numel(), float(BIG_RMS),
                                        rms.data_ptr()), 'rms')
+        # (zm_rms_from_weight_dev also gives BIG_RMS to a weight <= 0 on a pixel the mask does not flag; the
+        # reference's numpy divides there - 1 / sqrt(0) = inf -, and so does the host route: ADVICE r4)
+        rms = torch.where((wgt <= 0) & (bad == 0), 1.0 / torch.sqrt(wgt), rms)
         if 'SATURATE' in header:
             rms = torch.where(img >= 0.9 * float(header['SATURATE']), torch.full_like(rms, float(BIG_RMS)), rms)
         return rms, m32
+
+    def weight_of(img, rms, mask, header):
+        # CalibratableImageBase.weight_image (zuds/image.py:136-171) from an rms map: 1 / rms^2, 0 where the mask
+        # is bad or the pixel is within 10 % of SATURATE - in memory only, as on the host route (the transaction
+        # copy of the science frame is unmapped: nothing lands next to the caller's file)
+        mt = _lib.MASKTYPE_I16 if mask.dtype == torch.int16 else _lib.MASKTYPE_I32
+        ny, nx = img.shape
+        bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
+        check(L.zm_false_weight_dev(eng.ctx, mask.data_ptr(), mt, BAD_SUM, 0, nx, ny, None, bad.data_ptr()), 'bpm')
+        wgt = torch.empty_like(img)
+        satur = 0.9 * float(header['SATURATE']) if 'SATURATE' in header else 0.0
+        check(L.zm_weight_from_rms_dev(eng.ctx, rms.data_ptr(), bad.data_ptr(), img.data_ptr() if satur else None,
+                                       satur, img.numel(), wgt.data_ptr()), 'weight')
+        return wgt
     with torch.cuda.stream(oio.stream):
-        sci_rms, _ = rms_of(sci_img, sci_wgt, sci_mask, sci.header)
+        if sci_rms0 is not None:
+            sci_rms = sci_rms0
+            if sci_wgt is None:
+                sci_wgt = weight_of(sci_img, sci_rms, sci_mask, sci.header)
+        else:
+            sci_rms, _ = rms_of(sci_img, sci_wgt, sci_mask, sci.header)
         ref_rms, ref_m32 = rms_of(ref_img, ref_wgt, ref_mask, ref.header)
     chain = DeviceSubtraction(sci.wcs, ref.wcs, device=oio.device.index, engine=eng, stream=oio.stream)
     diff, noise, submask = chain.run(sci_img, sci_rms, sci_mask, sci_wgt, ref_img, ref_rms, ref_m32,
@@ -166,11 +191,11 @@ class Subtraction(HasWCS):
         outmask = final_out.replace('.fits', '.mask.fits')
 
         from . import objdev
-        if objdev.enabled() and hasattr(sci, '_weightimg') and 'SEEING' in sci.header and \
-                hasattr(ref, '_weightimg') and not hasattr(sci, '_rmsimg'):
-            # the device route (objdev): raw FITS blocks -> HBM -> DeviceSubtraction -> encoded products.
-            # (A science frame that still needs its rms map from the mesh background, or its SEEING
-            # measured, takes the host-pointer route below, which derives them.)
+        if objdev.enabled() and 'SEEING' in sci.header and hasattr(ref, '_weightimg'):
+            # the device route (objdev): raw FITS blocks -> HBM -> DeviceSubtraction -> encoded products; round 5:
+            # also for a science frame that carries an rms map instead of a weight map - the cold case of
+            # scripts/dosub.py:35-47, whose map `sci.rms_image` has just made on the device (objdev.derive_maps).
+            # (A science frame whose SEEING still has to be measured takes the host-pointer route below.)
             return _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_new_back,
                                        hotpants_kws)
 
