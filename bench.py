@@ -635,6 +635,8 @@ def main():
             dist.barrier(device_ids=[local]) if backend == 'nccl' else dist.barrier()
             torch.cuda.synchronize(device)
 
+    local_dt = {}
+
     def timed(fn, n):
         sync()
         t0 = time.perf_counter()
@@ -642,6 +644,7 @@ def main():
             fn()
         sync()
         dt = time.perf_counter() - t0
+        local_dt['last'] = dt              # this rank's own clock (the line carries the maximum over the ranks)
         if multi:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -688,6 +691,7 @@ def main():
     eng.timing(True, only=roof_scope)
     eng.timing_reset()
     dt = timed(step, args.steps)
+    my_ms_per_step = 1e3 * local_dt['last'] / args.steps
     eng.timing(False)
     rs_ms, rs_cnt = eng.timing_read(roof_scope)
     eng.timing_reset()
@@ -722,7 +726,20 @@ def main():
         legs['subtract_mpix_s'] = world * npx / 1e6 * args.steps / dt_s
 
     # who ran where: the world RCCL / gloo actually formed
-    me = {'rank': rank, 'device': local, 'name': torch.cuda.get_device_name(local), 'pid': os.getpid()}
+    me = {'rank': rank, 'device': local, 'name': torch.cuda.get_device_name(local), 'pid': os.getpid(),
+          'ms_per_step': my_ms_per_step}
+    if multi:
+        # one more step with the exchange steps of this rank on a wall clock of their own (parallel.PROBE: each
+        # bracketed by device synchronisations - never inside the timed region): what a first run on a real
+        # multi-GPU node needs to explain its scaling
+        par_mod = importlib.import_module('zuds-pipeline_amd.parallel')
+        par_mod.PROBE = {}
+        try:
+            coadd_leg(coadd, dframes)
+            sync()
+        finally:
+            me['exchange_ms'] = {k: 1e3 * v for k, v in par_mod.PROBE.items()}
+            par_mod.PROBE = None
     ranks = [me]
     if world > 1:
         ranks = [None] * world
@@ -1203,6 +1220,51 @@ def object_api_clock(z, d, files, sci_paths, args, nref=8):
                     os.remove(sub.local_path.replace('.fits', sfx))
             res[route] = {'reference_from_images_ms': 1e3 * min(tc), 'subtraction_from_images_ms': 1e3 * min(ts),
                           'coadd_mpix_s': nref * args.size ** 2 / 1e6 / min(tc), 'subtract_mpix_s': args.size ** 2 / 1e6 / min(ts)}
+            if route == 'device':
+                # ... and COLD: the frames as ZTF delivers them - science image + mask, no
+                # .weight.fits / .rms.fits.  from_images asks every frame for its weight map (zuds/swarp.py:43-51),
+                # dosub.py asks the science frame for its rms map first (scripts/dosub.py:35-47): mesh background,
+                # 1 / rms^2 with the bad-bit and SATURATE rules, the derived maps written next to the inputs - all
+                # on the device planes (objdev.derive_maps).  The derived files and the plane cache are dropped
+                # between the repeats, so every repeat starts cold.
+                objdev = importlib.import_module('zuds-pipeline_amd.objdev')
+
+                def cold_objects(paths_sci, paths_msk):
+                    out = []
+                    for ps, pm in zip(paths_sci, paths_msk):
+                        for sfx in ('.rms.fits', '.weight.fits'):
+                            if os.path.exists(ps.replace('.fits', sfx)):
+                                os.remove(ps.replace('.fits', sfx))
+                        im = z.ScienceImage.from_file(ps)
+                        im.mask_image = z.MaskImage.from_file(pm)
+                        out.append(im)
+                    return out
+                tc, ts, td = [], [], []
+                for rep in range(2):
+                    objdev.get_io().cache_clear()
+                    refname = os.path.join(d, f'ref_cold{rep}.000651_c03_q1_zg.fits')
+                    ims = cold_objects(files['sci'][:nref], files['msk'][:nref])
+                    t0 = time.perf_counter()
+                    ref = z.ReferenceImage.from_images(ims, refname)
+                    t1 = time.perf_counter()
+                    sci = cold_objects([sci_paths[0]], [sci_paths[2]])[0]
+                    t2 = time.perf_counter()
+                    _ = sci.rms_image
+                    t3 = time.perf_counter()
+                    sub = z.SingleEpochSubtraction.from_images(sci, ref, tmpdir=d)
+                    t4 = time.perf_counter()
+                    tc.append(t1 - t0)
+                    td.append(t3 - t2)
+                    ts.append(t4 - t2)
+                    for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+                        os.remove(sub.local_path.replace('.fits', sfx))
+                cold_objects(files['sci'][:nref] + [sci_paths[0]], files['msk'][:nref] + [sci_paths[2]])   # (removes the maps)
+                res['cold'] = {'reference_from_images_ms': 1e3 * min(tc), 'subtraction_from_images_ms': 1e3 * min(ts),
+                               'of_which_rms_image_ms': 1e3 * min(td),
+                               'what': 'device route, inputs without .weight.fits / .rms.fits: the maps are derived on the '
+                                       'device (mesh background rms, 1 / rms^2) and written next to the inputs; the '
+                                       'subtraction clock includes sci.rms_image (scripts/dosub.py:35-47)',
+                               'h2d_bytes_per_cold_frame_px': 6, 'derived_files_written': 2 * nref + 1}
         finally:
             if old is None:
                 os.environ.pop('ZM_OBJECT_API', None)

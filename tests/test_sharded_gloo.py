@@ -270,3 +270,120 @@ def test_four_ranks(kind):
             else:
                 assert np.array_equal(out['img'], ref_img.numpy()), f'rank {rank}'
                 assert np.array_equal(out['wgt'], ref_wgt.numpy()), f'rank {rank}'
+
+
+# ---- eight ranks, 3080 rows (bands of 385): what `bench.py --gpus 8` does on a node, on the CPU, and the banded
+# ---- mask schedule the native RCCL layer would issue (zm_comm_mask_plan) replayed beside torch.distributed's
+
+def make_tall_frames():
+    s = synth()
+    base = s.ztf_wcs(20, 3080, tpv=True)
+    frames = []
+    for i in range(9):
+        r = np.random.default_rng(900 + i)
+        w = s.ztf_wcs(20, 3080, dx=r.uniform(-2, 2), dy=r.uniform(-3, 3), rot_deg=r.uniform(-0.01, 0.01))
+        frames.append(s.make_frame(20, 3080, 900 + i, w, nstars=30, nbad=200))
+    frames[4]['img'][1500:1503, 8:11] += 5000
+    return base, frames
+
+
+def eight_worker(rank, world, port, kind, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = __import__('importlib').import_module('zuds-pipeline_amd.parallel')
+    base, frames = make_tall_frames()
+    mine = frames[:2] if rank == 0 else frames[rank + 1:rank + 2]            # 2 + 1 + 1 + ... frames
+    par.PROBE = {}
+    if kind == 'MASK':
+        part = partial_mask(mine, base, 'OR')
+        acc = torch.from_numpy(part.copy())
+        par.reduce_masks(acc, np_accum('OR'), np_finalize)                   # banded by default from 4 ranks on
+        out = dict(mask=acc.numpy().copy(), part=part)
+    else:
+        sc = par.ShardedCoadd(OneBufferBackend(base, kind))
+        img, wgt = sc.weighted(mine) if kind == 'WEIGHTED' else sc.exact(mine)
+        out = dict(img=img.numpy().copy(), wgt=wgt.numpy().copy())
+    out['probe'] = sorted(par.PROBE)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def replay_native_mask_plan(parts, nx, ny, kind):
+    """The banded schedule of csrc/comm.hip (zm_comm_mask_plan of every rank) on numpy arrays: sends in place,
+    receives into slots, fold with the -1 marker, all-gather through slots of the largest band."""
+    import ctypes as C
+    z = pkg()
+    L = z._lib.lib()
+    world = len(parts)
+    plans = []
+    for r in range(world):
+        P = z._lib.zm_mask_plan()
+        assert L.zm_comm_mask_plan(nx, ny, world, r, C.byref(P)) == 0
+        plans.append(P)
+    recv = [np.full(world * P.band_px, -7, np.int32) for P in plans]
+    for r, P in enumerate(plans):
+        for g in range(world):
+            Q = plans[g]
+            recv[g][Q.recv_off[r]:Q.recv_off[r] + Q.recv_cnt[r]] = parts[r].ravel()[P.send_off[g]:P.send_off[g] + P.send_cnt[g]]
+    gathered = np.full(world * plans[0].band_px, -7, np.int32)
+    for g, Q in enumerate(plans):
+        acc = np.full(Q.my_px, -1, np.int32)
+        for r in range(world):
+            m = recv[g][Q.recv_off[r]:Q.recv_off[r] + Q.my_px]
+            both = (acc != -1) & (m != -1)
+            acc = np.where(both, (acc & m) if kind == 'AND' else (acc | m), np.where(acc == -1, m, acc))
+        gathered[Q.gather_off[g]:Q.gather_off[g] + Q.my_px] = acc
+    out = np.empty(nx * ny, np.int32)
+    P = plans[0]
+    for g in range(world):
+        out[P.send_off[g]:P.send_off[g] + P.send_cnt[g]] = gathered[P.gather_off[g]:P.gather_off[g] + P.send_cnt[g]]
+    out[out == -1] = 0
+    return out.reshape(ny, nx), [P.my_px // nx for P in plans]
+
+
+@pytest.mark.parametrize('kind', ['WEIGHTED', 'CLIPPED', 'MASK'])
+def test_eight_ranks_3080_rows(kind):
+    """the exchange of an 8-rank stack (frames 2 + 1 x 7, 3080 rows -> bands of 385) for the
+    sum-reduce, the exact CLIPPED row-band transpose and the banded mask reduce, each against one process; the mask
+    also against the schedule the native RCCL layer issues, replayed from its exported plan."""
+    base, frames = make_tall_frames()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=eight_worker, args=(r, 8, port, kind, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(8))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ny, nx = base.naxis[1], base.naxis[0]
+    if kind == 'MASK':
+        ref = partial_mask(frames, base, 'OR')
+        ref[ref == -1] = 0
+        assert (ref != 0).any()
+        native, rows = replay_native_mask_plan([results[r]['part'] for r in range(8)], nx, ny, 'OR')
+        assert rows == [385] * 8
+        assert np.array_equal(native, ref)
+        for rank in range(8):
+            assert np.array_equal(results[rank]['mask'], ref), f'rank {rank}'
+            assert results[rank]['probe'] == ['mask_band_exchange', 'mask_band_gather']
+        return
+    ob = OracleBackend(base, kind)
+    if kind == 'WEIGHTED':
+        ref_img, ref_wgt = ob.finalize(*ob.partial_sums(frames))
+    else:
+        ref_img, ref_wgt = ob.combine(ob.resample_stack(frames))
+    assert float((ref_wgt.numpy() > 0).mean()) > 0.8
+    for rank in range(8):
+        out = results[rank]
+        if kind == 'WEIGHTED':
+            np.testing.assert_allclose(out['img'], ref_img.numpy(), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(out['wgt'], ref_wgt.numpy(), rtol=1e-12)
+            assert out['probe'] == ['all_reduce_planes']
+        else:
+            assert np.array_equal(out['img'], ref_img.numpy()), f'rank {rank}'
+            assert np.array_equal(out['wgt'], ref_wgt.numpy()), f'rank {rank}'
+            assert out['probe'] == ['band_combine', 'band_gather', 'stack_band_exchange']

@@ -156,6 +156,12 @@ def _coadd_device(cls, images, masks, sci, params, outname, mskoutname, addbkg, 
     torch, eng, L = oio.torch, oio.engine, oio.engine.L
     check = _lib.check
     wout = sci.output_grid()
+    if sci.use_weights:
+        # frames that came without maps (science image + mask only): their rms and weight maps in one batch on the
+        # device, instead of one `weight_image` after the other (zuds/swarp.py:43-51 asks frame by frame)
+        cold = [im for im in images if not hasattr(im, '_weightimg') and objdev.can_derive(im) and
+                (not hasattr(im, '_rmsimg') or (im._rmsimg.ismapped and '_data' not in im._rmsimg.__dict__))]
+        objdev.derive_maps_many(cold, want_weight=True)
     want = []
     for im, m in zip(images, masks):
         want += [(im, 'f32'), (im.weight_image if sci.use_weights else None, 'f32'), (m, 'mask')]

@@ -23,6 +23,34 @@ from ._lib import check, wcs_struct
 # communicator of one): the one-GPU box then exercises the same calls an 8-GPU node makes.
 FORCE_COLLECTIVES = False
 
+# Developer / bench: wall-clock seconds per named exchange step of this rank (`bench.py --gpus N` sets it to a dict
+# for ONE extra step behind its timed region and prints it per rank: the first real multi-GPU run should explain
+# itself - VERDICT r4 item 8).  Each probed step is bracketed by device synchronisations, so it is never on.
+PROBE = None
+
+
+class _probed(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROBE is not None:
+            import time
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if PROBE is not None:
+            import time
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            PROBE[self.name] = PROBE.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
 
 def band_bounds(nrows, world):
     """Row-band boundaries, ``np.array_split`` semantics (as ``zuds/mpi.py:52-60``
@@ -63,7 +91,8 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
     multi = world > 1 or (on and FORCE_COLLECTIVES)
     if multi and not banded:
         parts = [torch.empty_like(acc) for _ in range(world)]
-        dist.all_gather(parts, acc.contiguous(), group=group)
+        with _probed('mask_all_gather'):
+            dist.all_gather(parts, acc.contiguous(), group=group)
         for r, m in enumerate(parts):
             accum(acc, m, r == 0)
     elif multi:
@@ -83,8 +112,9 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
             if recv[g].numel():
                 ops.append(dist.P2POp(dist.irecv, recv[g], peer(g), group))
         if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            with _probed('mask_band_exchange'):
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
         folded = torch.empty_like(mine)
         for r, m in enumerate(recv):
             if m.numel():
@@ -94,7 +124,8 @@ def reduce_masks(acc, accum, finalize, group=None, banded=None):
         pad = torch.empty((maxr,) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
         pad[:folded.shape[0]] = folded
         allp = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(allp, pad, group=group)
+        with _probed('mask_band_gather'):
+            dist.all_gather(allp, pad, group=group)
         for g in range(world):
             acc[bounds[g]:bounds[g + 1]] = allp[g][:bounds[g + 1] - bounds[g]]
     finalize(acc)
@@ -110,10 +141,12 @@ def all_reduce_planes(s1, s0, group=None):
             and s1.untyped_storage().data_ptr() == s0.untyped_storage().data_ptr()
             and s0.storage_offset() == s1.storage_offset() + n):
         both = s1.new_empty(0).set_(s1.untyped_storage(), s1.storage_offset(), (2 * n,))
-        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        with _probed('all_reduce_planes'):
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
     else:
-        dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=group)
+        with _probed('all_reduce_planes'):
+            dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(s0, op=dist.ReduceOp.SUM, group=group)
 
 
 class NativeComm(object):
@@ -336,9 +369,11 @@ class ShardedCoadd(object):
                     for i in range(nfr[g]):
                         ops.append(dist.P2POp(dist.irecv, band[first[g] + i], self._peer(g), self.group))
             if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-        img_b, wgt_b = self.backend.combine(band)
+                with _probed('stack_band_exchange'):
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+        with _probed('band_combine'):
+            img_b, wgt_b = self.backend.combine(band)
         with self.backend.scope():
             # bands may differ by one row: gather through padded buffers
             maxr = max(bounds[g + 1] - bounds[g] for g in range(world))
@@ -346,7 +381,8 @@ class ShardedCoadd(object):
             pad[0, :my_rows] = img_b
             pad[1, :my_rows] = wgt_b
             allp = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(allp, pad, group=self.group)
+            with _probed('band_gather'):
+                dist.all_gather(allp, pad, group=self.group)
             img = torch.cat([allp[g][0, :bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
             wgt = torch.cat([allp[g][1, :bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
         return img, wgt
