@@ -779,6 +779,10 @@ def main():
                 pass
         roofline = None
         pmc = pmc_profile(args)
+        # (which form of the fused kernel ran: the owner-staged one where the footprints fit its slot - this stack's do -
+        # unless ZM_FF_FORM / ZM_FF_DMA say otherwise)
+        ff_kernel = 'k_coadd_fused_own' if (os.environ.get('ZM_FF_FORM', 'own') != 'dma' and os.environ.get('ZM_FF_DMA', '1') != '0') else \
+            ('k_coadd_fused_dma' if os.environ.get('ZM_FF_DMA', '1') != '0' else 'k_coadd_fused')
         m = 0 if args.no_mask else 1
         mask_in = 0 if not m else (2 if args.mask_dtype == 'int16' else 4)      # bytes per input pixel of a mask plane
         if roof_scope in kt:
@@ -788,13 +792,13 @@ def main():
                 # box-OR entry of the mask (the mask words themselves are read by k_mask_box_rows, its own
                 # launch); per output pixel coadd + weight (+ int32 mask coadd).  SURVEY.md 8(d)'s fused figure.
                 bytes_per_launch = (args.frames * (8 + 2 * m) + (8 + 4 * m)) * npx
-                kname = 'k_coadd_fused_dma<LANCZOS3' + (', mask coadd>' if m else '>')
+                kname = ff_kernel + '<LANCZOS3' + (', mask coadd>' if m else '>')
                 units = f'{args.frames} frames x {args.size}^2 px per launch'
             elif fused:
                 # the materialised stack out of the same kernel (STACK mode): 8 B in (+ 2 B box-OR) per input
                 # pixel, 8 B {value, weight} out per output pixel and frame, + 4 B partial mask coadd per stack
                 bytes_per_launch = (args.frames * (16 + 2 * m) + 4 * m) * npx
-                kname = 'k_coadd_fused_dma<LANCZOS3, stack' + (', mask coadd>' if m else '>')
+                kname = ff_kernel + '<LANCZOS3, stack' + (', mask coadd>' if m else '>')
                 units = f'{args.frames} frames x {args.size}^2 px per launch'
             else:
                 bytes_per_launch = (RESAMPLE_BYTES_PER_OUTPX + MASK_BYTES_PER_OUTPX * m) * npx
@@ -802,7 +806,8 @@ def main():
                 units = f'1 frame x {args.size}^2 px per launch'
             ach = bytes_per_launch / avg_s / 1e9
             section = 'weighted' if sum_type else 'clipped'
-            kp = ((pmc.get(section) or {}).get('kernels') or {}).get('k_coadd_fused_dma') if fused else None
+            kern_pmc = (pmc.get(section) or {}).get('kernels') or {}
+            kp = (kern_pmc.get('k_coadd_fused') or kern_pmc.get('k_coadd_fused_dma')) if fused else None
             roofline = {'bound': 'hbm', 'kernel': kname, 'units_per_launch': units,
                         'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': kp.get('hbm_bytes_per_launch') if kp else None,
@@ -1117,8 +1122,8 @@ def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_
     if cnt:
         us = 1e3 * ms / cnt
         byt = (args.frames * (16 + 2 * m) + 4 * m) * npx   # 8 B + 2 B box-OR in per input px, 8 B {value, weight} out per px and frame
-        kp = kern.get('k_coadd_fused_dma')
-        out['stack_roofline'] = {'bound': 'hbm', 'kernel': 'k_coadd_fused_dma<LANCZOS3, stack' + (', mask coadd>' if m else '>'),
+        kp = kern.get('k_coadd_fused') or kern.get('k_coadd_fused_dma')
+        out['stack_roofline'] = {'bound': 'hbm', 'kernel': (kp or {}).get('name', 'k_coadd_fused_own / _dma') + ' (LANCZOS3, stack' + (', mask coadd)' if m else ')'),
                                  'avg_launch_us': us, 'algorithmic_bytes_per_launch': byt, 'achieved': byt / (us * 1e-6) / 1e9,
                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  'traffic': kp.get('hbm_bytes_per_launch') if kp else None,

@@ -270,12 +270,17 @@ def test_differential_fuzz_against_the_k_resample_path(engine):
 
 
 @pytest.mark.parametrize('variant', [{'ZM_FF_DMA': '0'}, {'ZM_FF_RAW': '0'}, {'ZM_FF_DMA': '0', 'ZM_FF_RAW': '0'},
-                                     {'ZM_FF_FORK': '0'}])
+                                     {'ZM_FF_FORK': '0'}, {'ZM_FF_FORM': 'dma'}, {'ZM_FF_FORM': 'dma', 'ZM_FF_RAW': '0'},
+                                     {'ZM_FF_YIELD': '2'}, {'ZM_FF_YIELD': '1', 'ZM_FF_FORM': 'dma'},
+                                     {'ZM_FF_PROF': '1', 'ZM_FF_DEAL': '0'}, {'ZM_FF_PROF': '1', 'ZM_FF_DEAL': '2', 'ZM_FF_PRIO': '10'}])
 def test_kernel_variants_behind_the_switches(engine, monkeypatch, variant):
-    """The library ships two fused kernels (LDS-DMA staging, the default, and the register-staged one:
-    ZM_FF_DMA=0) and two ways to feed them (raw planes prepped in the kernel, the default, and planes
-    prepped ahead: ZM_FF_RAW=0, also what frames without 16-byte rows or with large footprints take).
-    Every combination gives the bits of the materialised path, on interior and edge tiles."""
+    """The library ships three fused kernels (the owner-staged one - in-place prep, one barrier per item -
+    wherever the footprints fit its fixed slot; the LDS-DMA staged one elsewhere or with ZM_FF_FORM=dma; the
+    register-staged one: ZM_FF_DMA=0) and two ways to feed them (raw planes prepped in the kernel, the default,
+    and planes prepped ahead: ZM_FF_RAW=0, also what frames without 16-byte rows or with large footprints take);
+    the yield mode of a context that shares the GPU (ZM_FF_YIELD: workgroups retire after a few tiles); the
+    developer instances with their switches (ZM_FF_PROF: phase clocks; ZM_FF_DEAL: who stages what; ZM_FF_PRIO:
+    wave priorities).  Every combination gives the bits of the materialised path, on interior and edge tiles."""
     z = pkg()
     for k, v in variant.items():
         monkeypatch.setenv(k, v)

@@ -31,6 +31,7 @@ done
 python3 tools/pmc_summary.py $(find $out/pmc_weighted_* -name '*counter_collection.csv') > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $(find $out/pmc_clipped_* -name '*counter_collection.csv') > $out/pmc_summary_clipped.txt
 grep -E "k_coadd_fused|k_mask_box|k_mesh_stats|k_chol_df|k_hp_apply" $out/pmc_summary.txt | grep -E "FETCH|WRITE|INSTS_VALU"
+cp $out/tests.log $out/tests_tail.log 2>/dev/null; tail -3 $out/tests.log > $out/tests_tail.log 2>/dev/null
 grep -E "k_coadd_fused|k_combine" $out/pmc_summary_clipped.txt | grep -E "FETCH|WRITE"
 # the counter profile bench.py quotes, stamped with the hash of these kernel sources (copy it to profiles/)
 python3 tools/make_pmc_json.py $out $out/pmc.json

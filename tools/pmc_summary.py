@@ -14,7 +14,7 @@ def short(name):
     t = re.search(r'k_resample<(\d+), (\d+)>', name)
     if t:
         return f'k_resample<{t.group(1)},{t.group(2)}>'
-    t = re.match(r'(k_coadd_fused_dma)<(\d+), (\w+), (\w+), (\w+)>', name)
+    t = re.match(r'(k_coadd_fused_dma|k_coadd_fused_own)<(\d+), (\w+), (\w+), (\w+)>', name)
     if t:     # <MOP, AVG, STACK, DEV>
         return f'{t.group(1)}<{"stack" if t.group(4) == "true" else "sum"}>'
     m = re.match(r'([A-Za-z_0-9:<>]+)', name)

@@ -406,9 +406,14 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
     double m = 0.0, s = 0.0;
     for (int pass = 0; pass < 4; ++pass) {
         double s0 = 0, s1 = 0;
+        // (round 5: the conversions are made HERE, per pass - v[] does not change, so the compiler kept all 48
+        // doubles beside the 48 floats across the passes, and the picks' 96 pixel coordinates too: 256 registers
+        // and 64 spilled ones, 260 B of scratch per lane.  An opaque copy per use keeps only the floats live.)
 #pragma unroll
         for (int i = 0; i < HC_PX; ++i) {
-            const double vv = v[i];
+            float vf = v[i];
+            asm volatile("" : "+v"(vf));
+            const double vv = vf;
             if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) { s0 += 1.0; s1 += vv; }
         }
         s0 = block_sum256(s0, red);
@@ -418,7 +423,9 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
         double s2 = 0;
 #pragma unroll
         for (int i = 0; i < HC_PX; ++i) {
-            const double vv = v[i];
+            float vf = v[i];
+            asm volatile("" : "+v"(vf));
+            const double vv = vf;
             if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) s2 += (vv - mn) * (vv - mn);
         }
         s2 = block_sum256(s2, red);
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
         int bi = 0x7fffffff;
         {
             int yy = yy0, xx = xx0;
+            asm volatile("" : "+v"(yy), "+v"(xx));       // (the coordinates are walked per pick, not kept: see above)
 #pragma unroll
             for (int i = 0; i < HC_PX; ++i) {
                 if (cand >> i & 1) {
@@ -2238,7 +2246,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_chol_df(int n, int lda, int W, d
     if (PROF == 1) tc = wall_clock64();
     extern __shared__ char df_raw[];
     df_lds& S = *reinterpret_cast<df_lds*>(df_raw);
-    const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
+    // (the region and the workgroup's number in it are wave-uniform, but a division leaves them in vector registers -
+    // and with them every pointer derived below, two registers each for the whole kernel: readfirstlane moves the
+    // lot to the scalar file; round 5)
+    const int reg = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / W)), w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - reg * W));
     const int nrows = n + 1;
     const int nblk = (n + CH_NB - 1) / CH_NB, NT = (n + 1 + 63) / 64;
     double* A = Aall + (size_t)reg * (size_t)nrows * lda;
