@@ -3278,6 +3278,23 @@ __device__ inline void lds_issue6_row(unsigned a, lds_row6& o) {
 // (launch bounds: the second argument is waves per SIMD - four, i.e. two workgroups per CU, at most 128 vector
 // registers.  With "2" the compiler is free to take 256 and did, on an unrelated edit: 208 registers, ONE workgroup
 // per CU, 1.75 -> 2.57 ms.)
+// A kernel argument fetched where it is used, from the kernarg segment, behind an opaque offset (the load cannot be
+// hoisted out of the item loop): the products' pointers are needed once per 32 items, at a tile's completion; held
+// in scalar registers for the whole loop they were a third of the kernel's scalar spills.
+struct ff_own_args {                 // the argument list of k_coadd_fused_own as the kernarg segment holds it
+    const zm_ff* fr; int nfr, onx, ony, lds_cap, ntx, ntiles; const int* ghdr; float* out_img; float* out_wgt;
+    int32_t* out_mask; float* out_cov; int partial; const float* taptab; int* tilectr; float2* stack; long long fstride;
+    int dbg_arg; long long* prof_arg;
+};
+template <typename T>
+__device__ __forceinline__ T ff_karg(int byte_off) {
+    asm volatile("" : "+s"(byte_off));
+    typedef const char __attribute__((address_space(4))) kchar;
+    kchar* k = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const T __attribute__((address_space(4)))*)(k + byte_off);
+}
+#define FF_KARG(field) ff_karg<decltype(ff_own_args::field)>((int)offsetof(ff_own_args, field))
+
 // Wave priority behind a wave-uniform condition, as ONE opaque statement: a C++ `if` around s_setprio inside the
 // pixel group splits its straight-line block, and the register allocator answered with 208 registers (or, capped
 // at 128, 100 spills).  sel: a scalar register; the priority becomes PRIO when sel == WHEN.
@@ -3288,10 +3305,11 @@ __device__ __forceinline__ void ff_setprio_when(int sel) {
 template <int MOP, bool AVG, bool STACK, bool DEV = false>
 __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     const zm_ff* __restrict__ fr, int nfr, int onx, int ony, int lds_cap, int ntx, int ntiles,
-    const int* __restrict__ ghdr, float* __restrict__ out_img, float* __restrict__ out_wgt,
-    int32_t* __restrict__ out_mask, float* __restrict__ out_cov, int partial,
-    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack, long long fstride,
+    const int* __restrict__ ghdr, float* __restrict__ out_img_, float* __restrict__ out_wgt_,
+    int32_t* __restrict__ out_mask_, float* __restrict__ out_cov_, int partial_,
+    const float* __restrict__ taptab, int* __restrict__ tilectr, float2* __restrict__ stack_, long long fstride_,
     int dbg_arg, long long* __restrict__ prof_arg) {
+    // (out_img_ ... fstride_: read through FF_KARG where they are used)
     long long* const prof = DEV ? prof_arg : nullptr;
     const int dbg = (DEV ? dbg_arg : (dbg_arg & ~255)) & 0x00ffffff;   // (bits 8 .. 23: the tile budget of the yield mode)
     // developer switches (ZM_FF_PRIO, ZM_FF_DEAL): s_setprio 1 for 1 = the DMA issue, 2 = the prep, 4 = waves 4 - 7 in
@@ -3332,7 +3350,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
 
     // ---- staging, part 1: the DMA of an item's raw planes and of its box-OR tile.  A raw chunk (box rows
     // 3 k .. 3 k + 2) is prepped by the wave that issued its DMA; the box-OR chunks are five rows each.
-    auto dma_item = [&](const ff_hdr* H, int f, int sl) __attribute__((always_inline)) {
+    auto dma_item = [&](auto H, int f, int sl) __attribute__((always_inline)) {
         const zm_ff* F = fr + f;
         const int use_lds = H->use_lds;
         const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh;
@@ -3395,7 +3413,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     // ... and of the tables its prep reads (two items ahead): the y part of the background for the box rows,
     // one column per mesh column under the box (wave 4), the x weights of the box columns as
     // [weight][quad column] (wave 5)
-    auto dma_tabs = [&](const ff_hdr* H, int f, int tb) __attribute__((always_inline)) {
+    auto dma_tabs = [&](auto H, int f, int tb) __attribute__((always_inline)) {
         const zm_ff* F = fr + f;
         const int use_lds = H->use_lds;
         const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hia = H->ia, hxb = H->xb;
@@ -3429,7 +3447,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     // ---- staging, part 2: the wave's own chunks, raw quads -> pairs, in place (background off, variance, bad
     // pixels, fill).  Straight-line per chunk: the LDS reads of both chunks first, then the arithmetic; the
     // conditions are item-uniform branches, never per pixel.
-    auto prep_raw = [&](const ff_hdr* H, int f, int sl, int tb, auto fast_tag) __attribute__((always_inline)) {
+    auto prep_raw = [&](auto H, int f, int sl, int tb, auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
         const zm_ff* F = fr + f;
         const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hxb = H->xb;
@@ -3509,7 +3527,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         }
     };
     // frames that could not be staged raw arrive prepped (zm_ff.src): pairs as they are, fill at the frame edge
-    auto prep_src = [&](const ff_hdr* H, int f, int sl, bool fast) __attribute__((always_inline)) {
+    auto prep_src = [&](auto H, int f, int sl, bool fast) __attribute__((always_inline)) {
         const zm_ff* F = fr + f;
         const int bx0 = H->bx0, by0 = H->by0, bh = H->bh;
         const int ny = F->ny, sp = F->spitch;
@@ -3536,7 +3554,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
             }
         }
     };
-    auto prep = [&](const ff_hdr* H, int f, int sl, int tb) __attribute__((always_inline)) {
+    auto prep = [&](auto H, int f, int sl, int tb) __attribute__((always_inline)) {
         const int use_lds = H->use_lds, fast = H->fast;                  // (both requested before the first branch)
         const float2* fsrc = fr[f].src;
         if (!use_lds || (dbg & 2) || ownn == 0) return;
@@ -3559,6 +3577,14 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     };
     auto hdr_put = [&](int sl, int wd) {
         if (tid < FF_HDR_WORDS) reinterpret_cast<int*>(&HR[sl])[tid] = wd;
+    };
+    // The staging reads the scalar fields of an item's header (box, flags, variance scale, mesh columns) straight
+    // from the header array in global memory: wave-uniform addresses, i.e. scalar loads through the constant cache -
+    // the words were fetched into the L2 by hdr_word iterations ago.  From the LDS copy every field is a ds_read
+    // into a vector register and a v_readfirstlane back: ~20 vector-pipe instructions per wave and item for
+    // values the scalar unit can fetch by itself.  (The LDS copy stays for what lanes index: the lattice nodes.)
+    auto hdr_g = [&](int tt, int ff) {
+        return reinterpret_cast<const ff_hdr ZM_GLOBAL*>(zm_gptr(ghdr) + ((size_t)tt * nfr + ff) * FF_HDR_WORDS);
     };
 
     if ((int)blockIdx.x >= ntiles) return;
@@ -3606,7 +3632,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         if (pt < 0) return;
         const int ptyi = pt / ntx, ptxi = pt - ptyi * ntx;
         const int pox = ptxi * TW + tx, poy0 = ptyi * RTH + wv * NPX;
-        float2* plane = stack + (size_t)pfr * (size_t)fstride;
+        float2* plane = FF_KARG(stack) + (size_t)pfr * (size_t)FF_KARG(fstride);
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
             const int oy = poy0 + q;
@@ -3655,8 +3681,8 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         // the raw planes and the box-OR tile of the next item into the other slot (free since the last barrier);
         // the tables of the item after it into the table buffer the prep of THIS item used
         if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(1);
-        if (more) dma_item(&HR[h1], f1, sl ^ 1);
-        if (t2 < ntiles) dma_tabs(&HR[h2], f2, sl);
+        if (more) dma_item(hdr_g(t1, f1), f1, sl ^ 1);
+        if (t2 < ntiles) dma_tabs(hdr_g(t2, f2), f2, sl);
         if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(0);
         FO_TICK(0);
 
@@ -3825,6 +3851,11 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
 
         if (f0 == nfr - 1) {
             // the tile is complete: coadd (or partial sums) and mask coadd, once
+            float* const out_img = FF_KARG(out_img);
+            float* const out_wgt = FF_KARG(out_wgt);
+            int32_t* const out_mask = FF_KARG(out_mask);
+            float* const out_cov = FF_KARG(out_cov);
+            const int partial = FF_KARG(partial);
 #pragma unroll
             for (int q = 0; q < NPX; ++q) {
                 const int oy = oy0 + q;
@@ -3859,7 +3890,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FO_TICK(2);
         if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(1);
-        if (more) prep(&HR[h1], f1, sl ^ 1, sl ^ 1);
+        if (more) prep(hdr_g(t1, f1), f1, sl ^ 1, sl ^ 1);
         if (t3 < ntiles) hdr_put(h3, hw3);
         if (grab && tid == 0) tring[(k3 + 1) & 3] = tile_of(gnext);
         if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(0);
