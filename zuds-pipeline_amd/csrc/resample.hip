@@ -3348,24 +3348,67 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                                                               : (wv < 4 ? 0 : wv == 4 ? 3 : 2);
     const int ytw = deal == 0 ? 6 : deal == 1 ? 4 : 6, xww = deal == 0 ? 7 : deal == 1 ? 5 : 7;
 
+    // ---- the scalars of an item's staging, fetched in ONE batch (round 5, late).  The header fields and the frame
+    // descriptor's fields used to be read where the code needed them, behind the conditions that decide whether it
+    // does: in the ISA five to eight scalar loads one after the other, each waited for with lgkmcnt(0) before the
+    // branch that guards the next - 2 900 cycles per wave and item of "DMA issue", a fifth of a wave's time, for a
+    // handful of address computations.  Now every scalar of the DMA issue (item i + 1: box, frame size, plane
+    // pointers; item i + 2: the tables) is requested before the first is used and one asm statement that names them
+    // all keeps the compiler from sinking a load back behind a branch: one round trip through the scalar cache.
+    auto hdr_g = [&](int tt, int ff) {
+        // (the item's number on the scalar unit, 32 bits: with the 64-bit product the compiler moved the address to the
+        // vector unit and the header fields became vector loads + v_readfirstlane behind a vmcnt(0))
+        const unsigned it = __builtin_amdgcn_readfirstlane((unsigned)tt * (unsigned)nfr + (unsigned)ff);
+        return reinterpret_cast<const ff_hdr ZM_GLOBAL*>(zm_gptr(ghdr) + (size_t)it * FF_HDR_WORDS);
+    };
+    struct dma_sc {                  // item i + 1
+        int use_lds, bx0, by0, bw, bh, nx, ny, spitch, mpitch;
+        const float2* src; const float* img; const float* wgt; const void* mask; const uint16_t* mbox;
+    };
+    struct prep_sc {                 // item i + 1, at its prep
+        int use_lds, fast, bx0, by0, bh, xb, nx, ny, spitch;
+        float vscale, wthresh;
+        const float2* src; const float* wgt; const float4* ytab;
+    };
+    struct tab_sc {                  // item i + 2 (the waves that fetch tables)
+        int use_lds, bx0, by0, bh, ia, xb, nx, ny, ytp;
+        const float4* ytab; const float4* xtab; const float2* src;
+    };
+    auto load_dma_sc = [&](int tt, int ff, dma_sc& D) __attribute__((always_inline)) {
+        const auto H = hdr_g(tt, ff);
+        const zm_ff* F = fr + ff;
+        D.use_lds = H->use_lds; D.bx0 = H->bx0; D.by0 = H->by0; D.bw = H->bw; D.bh = H->bh;
+        D.nx = F->nx; D.ny = F->ny; D.spitch = F->spitch; D.mpitch = F->mpitch;
+        D.src = F->src; D.img = F->img; D.wgt = F->wgt; D.mask = F->mask; D.mbox = F->mbox;
+    };
+    auto load_tab_sc = [&](int tt, int ff, tab_sc& T) __attribute__((always_inline)) {
+        const auto H = hdr_g(tt, ff);
+        const zm_ff* F = fr + ff;
+        T.use_lds = H->use_lds; T.bx0 = H->bx0; T.by0 = H->by0; T.bh = H->bh; T.ia = H->ia; T.xb = H->xb;
+        T.nx = F->nx; T.ny = F->ny; T.ytp = F->ytp;
+        T.ytab = F->ytab; T.xtab = F->xtab; T.src = F->src;
+    };
+#define FO_PIN_DMA(D) asm volatile("; staging scalars (item + 1)" : : "s"(D.use_lds), "s"(D.bx0), "s"(D.by0), "s"(D.bw), "s"(D.bh), \
+        "s"(D.nx), "s"(D.ny), "s"(D.spitch), "s"(D.mpitch), "s"(D.src), "s"(D.img), "s"(D.wgt), "s"(D.mask), "s"(D.mbox))
+#define FO_PIN_TAB(T) asm volatile("; staging scalars (item + 2)" : : "s"(T.use_lds), "s"(T.bx0), "s"(T.by0), "s"(T.bh), "s"(T.ia), \
+        "s"(T.xb), "s"(T.nx), "s"(T.ny), "s"(T.ytp), "s"(T.ytab), "s"(T.xtab), "s"(T.src))
+    const bool tabs_wave = wv == ytw || wv == xww;
     // ---- staging, part 1: the DMA of an item's raw planes and of its box-OR tile.  A raw chunk (box rows
     // 3 k .. 3 k + 2) is prepped by the wave that issued its DMA; the box-OR chunks are five rows each.
-    auto dma_item = [&](auto H, int f, int sl) __attribute__((always_inline)) {
-        const zm_ff* F = fr + f;
-        const int use_lds = H->use_lds;
-        const int bx0 = H->bx0, by0 = H->by0, bw = H->bw, bh = H->bh;
-        if (!use_lds || (dbg & 4)) return;
+    auto dma_item = [&](const dma_sc& D, int sl) __attribute__((always_inline)) {
+        const int bx0 = D.bx0, by0 = D.by0, bw = D.bw, bh = D.bh;
+        if (!D.use_lds || (dbg & 4)) return;
         int ln = lane;
         asm volatile("" : "+v"(ln));             // (the lane map is recomputed per item: held across the pixel
                                                  // phase its four values would cost registers the group needs)
         const int lrow = (ln * 205) >> 12, lcol = ln - lrow * FO_PQ;      // ln / 20 for ln < 80
-        const int nx = F->nx, ny = F->ny;
+        const int nx = D.nx, ny = D.ny;
         char* SL = smem + FO_OFF_SLOT + sl * FO_SLOT;
-        const float2* fsrc = F->src;
+        const float2* fsrc = D.src;
         const int gx = bx0 + 4 * lcol;
         const bool lok = lrow < FO_RPC && lcol < (bw >> 2);
         if (fsrc) {
-            const int sp = F->spitch;
+            const int sp = D.spitch;
             const float ZM_GLOBAL* gS = (const float ZM_GLOBAL*)zm_gptr(fsrc);
             const unsigned xa = (unsigned)min(max(gx, 0), sp - 2), xb = (unsigned)min(max(gx + 2, 0), sp - 2);
 #pragma unroll 1
@@ -3378,8 +3421,8 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                 }
             }
         } else {
-            const float* fw = F->wgt;
-            const float ZM_GLOBAL* gI = zm_gptr(F->img);
+            const float* fw = D.wgt;
+            const float ZM_GLOBAL* gI = zm_gptr(D.img);
             const float ZM_GLOBAL* gW = fw ? zm_gptr(fw) : gI;
             const unsigned xo = (unsigned)min(max(gx, 0), nx - 4);
 #pragma unroll 1
@@ -3392,9 +3435,9 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                 }
             }
         }
-        if (MOP && F->mask && nm > 0) {
-            const uint16_t* fmb = F->mbox;
-            const int mpitch = F->mpitch;
+        if (MOP && D.mask && nm > 0) {
+            const uint16_t* fmb = D.mbox;
+            const int mpitch = D.mpitch;
             const int mrow = (ln * 187) >> 11, mcol = ln - mrow * FO_MPC;   // ln / 11 for ln < 64
             const int mx0 = bx0 & ~7, bwm8 = ((bx0 + bw - mx0) + 7) >> 3;
             char* M = smem + FO_OFF_MSK + sl * FO_MSLOT;
@@ -3411,17 +3454,14 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         }
     };
     // ... and of the tables its prep reads (two items ahead): the y part of the background for the box rows,
-    // one column per mesh column under the box (wave 4), the x weights of the box columns as
-    // [weight][quad column] (wave 5)
-    auto dma_tabs = [&](auto H, int f, int tb) __attribute__((always_inline)) {
-        const zm_ff* F = fr + f;
-        const int use_lds = H->use_lds;
-        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hia = H->ia, hxb = H->xb;
-        const float4* fyt = F->ytab;
-        const float2* fsrc = F->src;
-        if (!use_lds || (dbg & 4) || !fyt || fsrc || (wv != ytw && wv != xww)) return;
+    // one column per mesh column under the box (wave ytw), the x weights of the box columns as
+    // [weight][quad column] (wave xww)
+    auto dma_tabs = [&](const tab_sc& T, int tb) __attribute__((always_inline)) {
+        const int bx0 = T.bx0, by0 = T.by0, bh = T.bh, hia = T.ia, hxb = T.xb;
+        const float4* fyt = T.ytab;
+        if (!T.use_lds || (dbg & 4) || !fyt || T.src || !tabs_wave) return;
         if (wv == ytw) {
-            const int ny = F->ny, ytp = F->ytp;
+            const int ny = T.ny, ytp = T.ytp;
             char* YT = smem + FO_OFF_YT + tb * FO_YTB;
             const unsigned gy = (unsigned)min(max(by0 + lane, 0), ny - 1);
             if (lane < bh) {
@@ -3430,9 +3470,9 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                     ff_glds16(zm_gptr(fyt) + (gy * (unsigned)ytp + (unsigned)min(hia + 1, ytp - 1)), YT + FO_YROWS * 16);
             }
         } else {
-            const int nq4 = F->nx >> 2;
+            const int nq4 = T.nx >> 2;
             char* XW = smem + FO_OFF_XW + tb * FO_XWB;
-            const float4 ZM_GLOBAL* gX = zm_gptr(F->xtab);
+            const float4 ZM_GLOBAL* gX = zm_gptr(T.xtab);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int slot = j * 64 + lane;
@@ -3447,15 +3487,14 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     // ---- staging, part 2: the wave's own chunks, raw quads -> pairs, in place (background off, variance, bad
     // pixels, fill).  Straight-line per chunk: the LDS reads of both chunks first, then the arithmetic; the
     // conditions are item-uniform branches, never per pixel.
-    auto prep_raw = [&](auto H, int f, int sl, int tb, auto fast_tag) __attribute__((always_inline)) {
+    auto prep_raw = [&](const prep_sc& P, int sl, int tb, auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        const zm_ff* F = fr + f;
-        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh, hxb = H->xb;
-        const float vs = H->vscale;
-        const float* fw = F->wgt;
-        const float4* fyt = F->ytab;
-        const float fwth = F->wthresh;
-        const int nx = F->nx, ny = F->ny;
+        const int bx0 = P.bx0, by0 = P.by0, bh = P.bh, hxb = P.xb;
+        const float vs = P.vscale;
+        const float* fw = P.wgt;
+        const float4* fyt = P.ytab;
+        const float fwth = P.wthresh;
+        const int nx = P.nx, ny = P.ny;
         const bool has_w = fw != nullptr, has_y = fyt != nullptr;
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -3527,10 +3566,9 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         }
     };
     // frames that could not be staged raw arrive prepped (zm_ff.src): pairs as they are, fill at the frame edge
-    auto prep_src = [&](auto H, int f, int sl, bool fast) __attribute__((always_inline)) {
-        const zm_ff* F = fr + f;
-        const int bx0 = H->bx0, by0 = H->by0, bh = H->bh;
-        const int ny = F->ny, sp = F->spitch;
+    auto prep_src = [&](const prep_sc& P, int sl, bool fast) __attribute__((always_inline)) {
+        const int bx0 = P.bx0, by0 = P.by0, bh = P.bh;
+        const int ny = P.ny, sp = P.spitch;
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int lrow = (ln * 205) >> 12, lcol = ln - lrow * FO_PQ;
@@ -3554,13 +3592,22 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
             }
         }
     };
-    auto prep = [&](auto H, int f, int sl, int tb) __attribute__((always_inline)) {
-        const int use_lds = H->use_lds, fast = H->fast;                  // (both requested before the first branch)
-        const float2* fsrc = fr[f].src;
-        if (!use_lds || (dbg & 2) || ownn == 0) return;
-        if (fsrc) prep_src(H, f, sl, fast != 0);
-        else if (fast) prep_raw(H, f, sl, tb, std::true_type{});
-        else prep_raw(H, f, sl, tb, std::false_type{});
+    // (the scalars of the prep in one batch, like those of the DMA issue - requested BEFORE the wave waits for its DMA)
+    auto prep_load = [&](int tt, int ff, prep_sc& P) __attribute__((always_inline)) {
+        const auto H = hdr_g(tt, ff);
+        const zm_ff* F = fr + ff;
+        P.use_lds = H->use_lds; P.fast = H->fast; P.bx0 = H->bx0; P.by0 = H->by0; P.bh = H->bh; P.xb = H->xb;
+        P.vscale = H->vscale;
+        P.nx = F->nx; P.ny = F->ny; P.spitch = F->spitch; P.wthresh = F->wthresh;
+        P.src = F->src; P.wgt = F->wgt; P.ytab = F->ytab;
+    };
+#define FO_PIN_PREP(P) asm volatile("; prep scalars" : : "s"(P.use_lds), "s"(P.fast), "s"(P.bx0), "s"(P.by0), "s"(P.bh), "s"(P.xb), \
+        "s"(P.vscale), "s"(P.nx), "s"(P.ny), "s"(P.spitch), "s"(P.wthresh), "s"(P.src), "s"(P.wgt), "s"(P.ytab))
+    auto prep = [&](const prep_sc& P, int sl, int tb) __attribute__((always_inline)) {
+        if (!P.use_lds || (dbg & 2) || ownn == 0) return;
+        if (P.src) prep_src(P, sl, P.fast != 0);
+        else if (P.fast) prep_raw(P, sl, tb, std::true_type{});
+        else prep_raw(P, sl, tb, std::false_type{});
     };
     const int nty = ntiles / ntx;
     // queue position -> tile: the top and bottom rows of tiles (edge items: the slow ones) go first
@@ -3583,9 +3630,6 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     // the words were fetched into the L2 by hdr_word iterations ago.  From the LDS copy every field is a ds_read
     // into a vector register and a v_readfirstlane back: ~20 vector-pipe instructions per wave and item for
     // values the scalar unit can fetch by itself.  (The LDS copy stays for what lanes index: the lattice nodes.)
-    auto hdr_g = [&](int tt, int ff) {
-        return reinterpret_cast<const ff_hdr ZM_GLOBAL*>(zm_gptr(ghdr) + ((size_t)tt * nfr + ff) * FF_HDR_WORDS);
-    };
 
     if ((int)blockIdx.x >= ntiles) return;
     int t0 = tile_of(blockIdx.x), f0 = 0, k3 = 0;
@@ -3607,12 +3651,25 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     if (t1 < ntiles) hdr_put(1, hdr_word(t1, f1));
     if (t2 < ntiles) hdr_put(2, hdr_word(t2, f2));
     __syncthreads();
-    dma_tabs(&HR[0], f0, 0);
-    if (t1 < ntiles) dma_tabs(&HR[1], f1, 1);
-    dma_item(&HR[0], f0, 0);
+    {
+        dma_sc D0;
+        tab_sc T0, T1;
+        load_dma_sc(t0, f0, D0);
+        load_tab_sc(t0, f0, T0);
+        load_tab_sc(t1 < ntiles ? t1 : t0, t1 < ntiles ? f1 : f0, T1);
+        FO_PIN_DMA(D0);
+        dma_tabs(T0, 0);
+        if (t1 < ntiles) dma_tabs(T1, 1);
+        dma_item(D0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    prep(&HR[0], f0, 0, 0);
+    {
+        prep_sc P0;
+        prep_load(t0, f0, P0);
+        FO_PIN_PREP(P0);
+        prep(P0, 0, 0);
+    }
     __syncthreads();
 
     // ---- this thread's pixels: column tx, rows 4 wv .. 4 wv + 3 of the 64 x 32 tile (one group)
@@ -3681,8 +3738,19 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         // the raw planes and the box-OR tile of the next item into the other slot (free since the last barrier);
         // the tables of the item after it into the table buffer the prep of THIS item used
         if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(1);
-        if (more) dma_item(hdr_g(t1, f1), f1, sl ^ 1);
-        if (t2 < ntiles) dma_tabs(hdr_g(t2, f2), f2, sl);
+        {
+            // (an item that does not exist: the scalars of the current one, valid and unused)
+            dma_sc D1;
+            tab_sc T2;
+            const bool more2 = t2 < ntiles;
+            load_dma_sc(more ? t1 : t0, more ? f1 : f0, D1);
+            if (tabs_wave) load_tab_sc(more2 ? t2 : t0, more2 ? f2 : f0, T2);
+            else T2 = tab_sc{0, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+            FO_PIN_DMA(D1);
+            FO_PIN_TAB(T2);
+            if (more) dma_item(D1, sl ^ 1);
+            if (more2) dma_tabs(T2, sl);
+        }
         if (prio == 1 || prio == 3) __builtin_amdgcn_s_setprio(0);
         FO_TICK(0);
 
@@ -3708,35 +3776,49 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
             const bool EDGE = !fast;
             auto group = [&]() __attribute__((always_inline)) {
                 asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" : : "s"(ysw) : "scc");
-                float fxf0 = 0.f, fyf0 = 0.f, dxs[4], dys[4];
-                bool shape = true;
+                // Shape of the group (round 5, late: 45 -> 25 vector instructions).  The four pixels share the fast
+                // path when they sit in one source column, in four consecutive source rows, none within ZM_SNAP of a
+                // sample (delta taps: the generic code).  Positions are rounded FMAs of one linear function of the row
+                // fraction - monotone - so equal column floors of pixels 0 and 3 hold for 1 and 2; for the rows,
+                // floor(py_3) = floor(py_0) + 3 together with every fraction inside [SNAP, 1 - 2 SNAP] pins the two
+                // in between (the exact values are collinear and a rounded one differs from the exact one by less than
+                // SNAP: box coordinates stay below 128).  The fractions of pixels 1 and 2 are v_fract (= x - floor(x),
+                // exact for these positive values); the test is conservative - who fails it takes the generic code,
+                // which gives the same bits.
+                float dxs[4], dys[4], pxs[4], pys[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float fy = fyb;
-                    asm volatile("" : "+v"(fy));
-                    fy += (float)j * (1.f / LSTEP);
-                    const float px = __builtin_fmaf(fy, xd, xa), py = __builtin_fmaf(fy, yd, ya);
-                    const float fxf = floorf(px), fyf = floorf(py);
-                    const float dx = px - fxf, dy = py - fyf;
-                    dxs[j] = dx;
-                    dys[j] = dy;
-                    if (j == 0) { fxf0 = fxf; fyf0 = fyf; }
-                    const float edge = fminf(fminf(dx, 1.f - dx), fminf(dy, 1.f - dy));
-                    shape = shape && !(edge < ZM_SNAP) && fxf == fxf0 && fyf == fyf0 + (float)j;
+                    if (j == 1) asm volatile("v_add_f32 %0, 0x3d800000, %1" : "=v"(fy) : "v"(fyb));       // + 1 / 16
+                    if (j == 2) asm volatile("v_add_f32 %0, 0x3e000000, %1" : "=v"(fy) : "v"(fyb));       // + 2 / 16
+                    if (j == 3) asm volatile("v_add_f32 %0, 0x3e400000, %1" : "=v"(fy) : "v"(fyb));       // + 3 / 16
+                    pxs[j] = __builtin_fmaf(fy, xd, xa);
+                    pys[j] = __builtin_fmaf(fy, yd, ya);
                 }
+                static_assert(LSTEP == 16, "row fractions of the group: sixteenths");
+                const float fxf0 = floorf(pxs[0]), fyf0 = floorf(pys[0]), fxf3 = floorf(pxs[3]), fyf3 = floorf(pys[3]);
+                dxs[0] = pxs[0] - fxf0; dys[0] = pys[0] - fyf0;
+                dxs[3] = pxs[3] - fxf3; dys[3] = pys[3] - fyf3;
+                dxs[1] = __builtin_amdgcn_fractf(pxs[1]); dys[1] = __builtin_amdgcn_fractf(pys[1]);
+                dxs[2] = __builtin_amdgcn_fractf(pxs[2]); dys[2] = __builtin_amdgcn_fractf(pys[2]);
+                const float dlo = fminf(__builtin_fminf(__builtin_fminf(dxs[0], dys[0]), __builtin_fminf(dxs[1], dys[1])),
+                                        __builtin_fminf(__builtin_fminf(dxs[2], dys[2]), __builtin_fminf(dxs[3], dys[3])));
+                const float dhi = fmaxf(__builtin_fmaxf(__builtin_fmaxf(dxs[0], dys[0]), __builtin_fmaxf(dxs[1], dys[1])),
+                                        __builtin_fmaxf(__builtin_fmaxf(dxs[2], dys[2]), __builtin_fmaxf(dxs[3], dys[3])));
+                const bool shape = dlo >= ZM_SNAP && dhi <= 1.f - 2.f * ZM_SNAP && fxf3 == fxf0 && fyf3 == fyf0 + 3.f;
                 if (!__all(shape)) {
                     slow |= 0xfu;
                     return;
                 }
                 const int ix0 = (int)fxf0, iy0 = (int)fyf0;
-                unsigned inbm = 0xfu;
+                // outm: pixels of the group whose box-OR entry does not count (no mask, or the footprint leaves the frame)
+                unsigned outm = with_mask ? 0u : 0xfu;
                 if (EDGE && MOP) {
                     const int ix = sbx0 + OFF + ix0, iy = sby0 + OFF + iy0;
                     const bool xin = ix >= 0 && ix + NT <= enx && ox < onx;
-                    inbm = 0u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        inbm |= (xin && iy + j >= 0 && iy + j + NT <= eny && oy0 + j < ony) ? (1u << j) : 0u;
+                        outm |= (xin && iy + j >= 0 && iy + j + NT <= eny && oy0 + j < ony) ? 0u : (1u << j);
                 }
                 int32_t mterm[4] = {-1, -1, -1, -1};
                 if (MOP) {
@@ -3747,17 +3829,15 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                     if (any_raw) {
                         bool defer = false;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) defer |= m16[j] == ZM_BOX_RAW && ((inbm >> j) & 1u);
+                        for (int j = 0; j < 4; ++j) defer |= m16[j] == ZM_BOX_RAW && !((outm >> j) & 1u);
                         if (__any(defer)) {
                             slow |= 0xfu;
                             return;
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int32_t t = ff_mask_term<MOP>((int32_t)m16[j]);
-                        mterm[j] = (with_mask && ((inbm >> j) & 1u)) ? t : -1;
-                    }
+                    for (int j = 0; j < 4; ++j)      // (the term, or -1 = "no vote" where the entry does not count)
+                        mterm[j] = ff_mask_term<MOP>((int32_t)m16[j]) | __builtin_amdgcn_sbfe(outm, j, 1);
                 }
                 zm_v2f txp[4][3], typ[4][3];
                 {
@@ -3793,27 +3873,44 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                         lds_wait_n<0>(cur);
                     }
                     const unsigned long long rr[NT] = {cur.r0, cur.r1, cur.r2, cur.r3, cur.r4, cur.r5};
+                    // (two pixels' row sums side by side: back to back, a packed FMA that takes the high half of its
+                    // first operand for both lanes is followed by a compiler-made s_nop before the FMA that reads its
+                    // result - 31 of them per group; per pixel the operations and their order are unchanged)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = rho - j;
-                        if (r < 0 || r >= NT) continue;
-                        zm_v2f rv2 = (zm_v2f){0.f, 0.f};
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        const int ra_ = rho - jp, rb_ = rho - jp - 1;
+                        const bool oa = ra_ >= 0 && ra_ < NT, ob = rb_ >= 0 && rb_ < NT;
+                        if (!oa && !ob) continue;
+                        zm_v2f rva = (zm_v2f){0.f, 0.f}, rvb = (zm_v2f){0.f, 0.f};
 #pragma unroll
                         for (int c = 0; c < NT; ++c) {
-                            const float tc = (c & 1) ? txp[j][c >> 1].y : txp[j][c >> 1].x;
-                            rv2 = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rv2);
+                            if (oa) {
+                                const float tc = (c & 1) ? txp[jp][c >> 1].y : txp[jp][c >> 1].x;
+                                rva = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rva);
+                            }
+                            if (ob) {
+                                const float tc = (c & 1) ? txp[jp + 1][c >> 1].y : txp[jp + 1][c >> 1].x;
+                                rvb = __builtin_elementwise_fma((zm_v2f){tc, tc}, lds_pair(rr[c]), rvb);
+                            }
                         }
-                        const float tr = (r & 1) ? typ[j][r >> 1].y : typ[j][r >> 1].x;
-                        av[j] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rv2, r == 0 ? (zm_v2f){0.f, 0.f} : av[j]);
+                        if (oa) {
+                            const float tr = (ra_ & 1) ? typ[jp][ra_ >> 1].y : typ[jp][ra_ >> 1].x;
+                            av[jp] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rva, ra_ == 0 ? (zm_v2f){0.f, 0.f} : av[jp]);
+                        }
+                        if (ob) {
+                            const float tr = (rb_ & 1) ? typ[jp + 1][rb_ >> 1].y : typ[jp + 1][rb_ >> 1].x;
+                            av[jp + 1] = __builtin_elementwise_fma((zm_v2f){tr, tr}, rvb, rb_ == 0 ? (zm_v2f){0.f, 0.f} : av[jp + 1]);
+                        }
                     }
                 });
                 asm volatile("; ZM_LGKM_END" ::: "memory");
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float acc = av[j].x, vacc = av[j].y;
+                    const float vacc = av[j].y;
                     const bool ok = vacc > 0.f && vacc < ZM_BADVAR_TEST;
-                    const float v = ok ? acc * fscale : 0.f;
-                    const float w = ok ? __builtin_amdgcn_rcpf(vacc * fscale2) : 0.f;
+                    const zm_v2f sc = av[j] * (zm_v2f){fscale, fscale2};        // (one packed multiplication: the same two products)
+                    const float v = ok ? sc.x : 0.f;
+                    const float w = ok ? __builtin_amdgcn_rcpf(sc.y) : 0.f;
                     const float ww = AVG ? (w > 0.f ? 1.f : 0.f) : w;
                     if (STACK) {
                         S1[j] = v;
@@ -3827,6 +3924,17 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
                 }
             };
             if (do_px && use_lds) group();
+            if (DEV && (dbg & 24)) {
+                // developer (ZM_FF_DBG bits 8 / 16): 64 / 128 extra independent FMAs per wave and item - does the
+                // launch grow by their issue time (the vector pipe is the bound) or not (latency is)?
+                float e0 = fx, e1 = fyb, e2 = fx + 1.f, e3 = fyb + 1.f;
+                const int nrep = (dbg & 16) ? 32 : 16;
+#pragma unroll 1
+                for (int r = 0; r < nrep; ++r)
+                    asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+                                 : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+                if (e0 + e1 + e2 + e3 == 12345.678f) S1[0] += 1.f;
+            }
             // the generic code, once: delta kernels, windows of another shape, footprints beyond the LDS tile
 #pragma unroll 1
             while (slow) {
@@ -3886,11 +3994,14 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
         }
         if (prio == 4 && wv >= 4) __builtin_amdgcn_s_setprio(0);
         FO_TICK(1);
+        prep_sc P1;
+        prep_load(more ? t1 : t0, more ? f1 : f0, P1);
+        FO_PIN_PREP(P1);
         // this wave's DMA has landed: its chunks of the next item are prepped where they lie
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FO_TICK(2);
         if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(1);
-        if (more) prep(hdr_g(t1, f1), f1, sl ^ 1, sl ^ 1);
+        if (more) prep(P1, sl ^ 1, sl ^ 1);
         if (t3 < ntiles) hdr_put(h3, hw3);
         if (grab && tid == 0) tring[(k3 + 1) & 3] = tile_of(gnext);
         if (prio == 2 || prio == 3) __builtin_amdgcn_s_setprio(0);
@@ -3911,6 +4022,9 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
     if (DEV && prof && lane == 0)
         for (int k = 0; k < 5; ++k) prof[((size_t)blockIdx.x * NW + wv) * 5 + k] = ptk[k];
 #undef FO_TICK
+#undef FO_PIN_DMA
+#undef FO_PIN_TAB
+#undef FO_PIN_PREP
 }
 
 // ZM_FF_DMA=0: the register-staged kernel (developer: A / B); default: the DMA-staged one
