@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "chol_diag.h"
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(64) void k_potrf(const double* A, double* L, int re
         __syncthreads();
         const long long t0 = wall_clock64(), c0 = clock64();
         if (FORM == 0) chol_diag_wave_panel_ref<0>(D, CH_NB, fail);
-        else chol_diag_wave_panel_fast<0>(D, CH_NB, fail);
+        else if (FORM == 1) chol_diag_wave_panel_fast<0>(D, CH_NB, fail);
+        else chol_diag_wave_panel_dpp<0>(D, CH_NB, fail);
         __syncthreads();
         t += wall_clock64() - t0;
         tc += clock64() - c0;
@@ -90,8 +92,8 @@ int main() {
     int* dfail;
     CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dL, CH_NB * (CH_NB + 1) * 8)); CK(hipMalloc(&dt, 16)); CK(hipMalloc(&dfail, 4));
     CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-    std::vector<double> L[2];
-    for (int form = 0; form < 2; ++form) {
+    std::vector<double> L[3];
+    for (int form = 0; form < 3; ++form) {
         L[form].resize(CH_NB * (CH_NB + 1));
         const int rep = 2000;
         long long ticks = 0, tk[2] = {0, 0};
@@ -99,7 +101,8 @@ int main() {
         for (int pass = 0; pass < 5; ++pass) {
             CK(hipMemset(dfail, 0, 4));
             if (form == 0) hipLaunchKernelGGL(k_potrf<0>, dim3(1), dim3(64), 0, 0, dA, dL, rep, dt, dfail);
-            else hipLaunchKernelGGL(k_potrf<1>, dim3(1), dim3(64), 0, 0, dA, dL, rep, dt, dfail);
+            else if (form == 1) hipLaunchKernelGGL(k_potrf<1>, dim3(1), dim3(64), 0, 0, dA, dL, rep, dt, dfail);
+            else hipLaunchKernelGGL(k_potrf<2>, dim3(1), dim3(64), 0, 0, dA, dL, rep, dt, dfail);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(tk, dt, 16, hipMemcpyDeviceToHost));
             printf("  form %d pass %d: %.3f us, %.0f shader clocks per block\n", form, pass, tk[0] * 0.01 / rep, (double)tk[1] / rep);
@@ -123,12 +126,24 @@ int main() {
             rinv = q > rinv ? q : rinv;
         }
         printf("form %d (%s): %.2f us per 32 x 32 block (wall clock 100 MHz, %d repetitions), max |L L^T - A| %.2Le, "
-               "max |dinv L_ii - 1| %.2Le, clamped pivots %d\n", form, form == 0 ? "rounds 1 - 3" : "round 4",
+               "max |dinv L_ii - 1| %.2Le, clamped pivots %d\n", form, form == 0 ? "rounds 1 - 3" : form == 1 ? "round 4" : "round 5: DPP broadcasts",
                ticks * 0.01 / rep, rep, res, rinv, fail / rep);
     }
     double dmax = 0;
     for (int i = 0; i < CH_NB; ++i)
         for (int j = 0; j <= i; ++j) dmax = fmax(dmax, fabs(L[0][i * (CH_NB + 1) + j] - L[1][i * (CH_NB + 1) + j]));
     printf("max |L(round 4) - L(rounds 1 - 3)| = %.2e\n", dmax);
+    {
+        // the DPP form against the round-4 form: the same operations per entry, so the same bits (lower triangle and
+        // the reciprocal diagonal in column 32)
+        int ndiff = 0;
+        for (int i = 0; i < CH_NB; ++i) {
+            for (int j = 0; j <= i; ++j)
+                if (memcmp(&L[2][i * (CH_NB + 1) + j], &L[1][i * (CH_NB + 1) + j], 8)) ++ndiff;
+            if (memcmp(&L[2][i * (CH_NB + 1) + CH_NB], &L[1][i * (CH_NB + 1) + CH_NB], 8)) ++ndiff;
+        }
+        printf("entries of L(round 5, DPP) that differ in any bit from L(round 4): %d\n", ndiff);
+        if (ndiff) return 1;
+    }
     return 0;
 }

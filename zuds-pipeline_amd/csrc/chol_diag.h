@@ -3,6 +3,7 @@
 // tools/potrf_probe.hip times and checks exactly what the library runs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #ifndef CH_NB
 #define CH_NB 32
@@ -192,12 +193,114 @@ __device__ __forceinline__ void chol_diag_wave_panel_fast(double (*D)[CH_NB + 1]
     if (!(amin > 1e-14) && lane == 0 && fail) atomicAdd(fail, 1);
 }
 
+// Round 5: the same factor with the broadcasts on the data-parallel-primitive path.  A lone wave issues one
+// instruction per ~5 cycles whatever it is, so the factor's time is its instruction count - and a broadcast through
+// the scalar file is three instructions per rank-1 update (two v_readlane_b32 and the FMA).  gfx950 has DPP forms of
+// the fp64 move and the fp64 fused multiply-add (v_mov_b64_dpp, v_fmac_f64_dpp) with `row_newbcast:k` - lane k of
+// every ROW OF 16 LANES to the 16 lanes of that row.  So the lanes are dealt anew for every panel: lanes 0 - 7 of
+// each of the four rows all hold the panel's eight matrix rows (four identical copies: the values every update
+// broadcasts are then present in every row of lanes), lanes 8 - 15 hold eight of the up to 24 matrix rows below
+// the panel.  A rank-1 update is ONE instruction, the pivot's broadcast one instead of two.  Per entry the
+// operations and their order are those of chol_diag_wave_panel_fast: the same bits (tools/potrf_probe.hip compares).
+// Hazard: a DPP operand written by one of the two preceding vector instructions is read stale (no interlock);
+// the asm statements carry their own s_nop where the producer can be that close.
+template <int SRC, bool NOP>
+__device__ __forceinline__ double chd_bcast16(double v) {
+    double r;
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(SRC));
+    else
+        asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(SRC));
+    return r;
+}
+// acc -= (lane SRC's b) * m      (NOP: b may have been written by the instruction before)
+template <int SRC, bool NOP>
+__device__ __forceinline__ void chd_fnma_bcast16(double& acc, double b, double m) {
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(m), "n"(SRC));
+    else
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(m), "n"(SRC));
+}
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void chd_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        chd_static_for<I + 1, N>(fn);
+    }
+}
+template <int TAG>
+__device__ __forceinline__ void chol_diag_wave_panel_dpp(double (*D)[CH_NB + 1], int nb, int* fail) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 15, r = lane >> 4;              // lane q of lane row r (also the matrix-core roles li, lk)
+    double amin = 1.0;                                   // smallest clamped pivot: 1e-14 iff one was clamped
+    chd_static_for<0, CH_NB / 8>([&](auto P) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value;
+        constexpr int c0 = 8 * p, c1 = c0 + 8;
+        // this panel's deal: its own rows in lanes 0 - 7 of every lane row, the rows below it in lanes 8 - 15
+        const int row = q < 8 ? c0 + q : c1 + 8 * r + (q - 8);
+        const bool live = row < CH_NB;                   // (idle lanes work on a copy of the last row, unstored)
+        const int rr = live ? row : CH_NB - 1;
+        double a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = D[rr][c0 + c];
+        double dg = D[rr][rr];                           // (a pivot of THIS panel only in lanes 0 - 7)
+        double dinv = 1.0;
+        chd_static_for<0, 8>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            int qj = q;
+            asm volatile("" : "+v"(qj));                 // (the pivot lane's predicate made per column: see the fast form)
+            const bool pivot_lane = qj == j;
+            // (dg was written by the asm statement of the column before and the updates between are asm statements too:
+            // at least two of them for j <= 6, one for j = 7; at j = 0 it comes from LDS)
+            const double piv = chd_bcast16<j, j == 7>(dg);
+            double ajj;                                             // max(piv, 1e-14), NaN -> 1e-14: ONE v_max_f64
+            asm("v_max_f64 %0, %1, %2" : "=v"(ajj) : "v"(1e-14), "v"(piv));
+            amin = __builtin_fmin(amin, ajj);
+            const double y0 = __builtin_amdgcn_rsq(ajj);
+            const double l0 = a[j] * y0;                            // beside the correction
+            const double t = ajj * y0;
+            const double e = __builtin_fma(-t, y0, 1.0);
+            const double pc = __builtin_fma(0.375, e, 0.5);
+            const double ye = y0 * e, le = l0 * e;
+            const double ri = __builtin_fma(ye, pc, y0);
+            const double lo = __builtin_fma(le, pc, l0);            // a[j] / sqrt(ajj)
+            const double lj = pivot_lane ? ajj * ri : lo;           // L[row][c0 + j] (meaningful for row >= c0 + j)
+            // the diagonal entry of a row below the pivot and the reciprocal diagonal, as asm statements BEHIND lj (their
+            // fake operand): three vector instructions between lj's last write and its first DPP read, no s_nop
+            asm volatile("v_fma_f64 %0, -%1, %1, %0" : "+v"(dg) : "v"(lo), "v"(lj));
+            {
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(pivot_lane);
+                unsigned dlo = (unsigned)__double_as_longlong(dinv), dhi = (unsigned)(__double_as_longlong(dinv) >> 32);
+                const unsigned rlo = (unsigned)__double_as_longlong(ri), rhi = (unsigned)(__double_as_longlong(ri) >> 32);
+                asm volatile("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %4"
+                             : "+v"(dlo), "+v"(dhi) : "v"(rlo), "v"(rhi), "s"(pm), "v"(lj));
+                dinv = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+            }
+            a[j] = lj;
+            // a[c] -= L[row][c0 + j] L[c0 + c][c0 + j]: the second factor sits in lane c of this lane row
+            chd_static_for<j + 1, 8>([&](auto C) __attribute__((always_inline)) {
+                constexpr int c = decltype(C)::value;
+                chd_fnma_bcast16<c, false>(a[c], lj, lj);
+            });
+        });
+        if (live && (q >= 8 || r == 0)) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) D[row][c0 + c] = a[c];    // (above the diagonal: finite values nobody reads)
+            if (q < 8) D[row][CH_NB] = dinv;
+        }
+        if (c1 < CH_NB) chol_diag_trailing_static(D, c0, c1, q, r);
+    });
+    if (!(amin > 1e-14) && lane == 0 && fail) atomicAdd(fail, 1);
+}
+
 #ifndef ZM_CHOL_DIAG_FAST
-#define ZM_CHOL_DIAG_FAST 1
+#define ZM_CHOL_DIAG_FAST 2
 #endif
 template <int TAG>
 __device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, int* fail) {
-#if ZM_CHOL_DIAG_FAST
+#if ZM_CHOL_DIAG_FAST == 2
+    chol_diag_wave_panel_dpp<TAG>(D, nb, fail);
+#elif ZM_CHOL_DIAG_FAST
     chol_diag_wave_panel_fast<TAG>(D, nb, fail);
 #else
     chol_diag_wave_panel_ref<TAG>(D, nb, fail);
@@ -209,7 +312,9 @@ __device__ inline void chol_diag_wave_panel_t(double (*D)[CH_NB + 1], int nb, in
 // 1.54 -> 1.51 ms per seven factorisations); the barrier forms and k_chol_tp are better off with the call.
 template <int TAG>
 __device__ __forceinline__ void chol_diag_wave_panel_inl(double (*D)[CH_NB + 1], int nb, int* fail) {
-#if ZM_CHOL_DIAG_FAST
+#if ZM_CHOL_DIAG_FAST == 2
+    chol_diag_wave_panel_dpp<TAG>(D, nb, fail);
+#elif ZM_CHOL_DIAG_FAST
     chol_diag_wave_panel_fast<TAG>(D, nb, fail);
 #else
     chol_diag_wave_panel_ref<TAG>(D, nb, fail);

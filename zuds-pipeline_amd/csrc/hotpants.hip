@@ -1222,14 +1222,34 @@ __device__ __forceinline__ void cf_chain(double (&xb)[2][2], const double2 (*Cf)
         hp_static_for<0, 8>([&](auto Q) __attribute__((always_inline)) {
             constexpr int m = 8 * b + decltype(Q)::value;
             if constexpr (m < CH_NB - 1) {
-                constexpr int tm = m >> 4, sl = m & 15;
+                constexpr int sl = m & 15;
                 const double2 c = cf[b][m & 7];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double u = row16_bcast_d<sl>(xb[tm][h]);
-                    if (m < 15) xb[0][h] = fma(c.x, u, xb[0][h]);
-                    xb[1][h] = fma(c.y, u, xb[1][h]);
-                }
+                // Round 5: x += c * (lane sl's u) as ONE instruction - v_fmac_f64 with its first operand through the
+                // DPP row broadcast - instead of two 32-bit DPP moves and the FMA: 216 -> 108 instructions per chain,
+                // on a wave that issues one per ~5 cycles.  The same products and sums.  A DPP operand written by one
+                // of the two instructions before is read stale (no interlock): the order below keeps two instructions
+                // between every write of a source and its next broadcast (steps >= 15 touch only the second column
+                // half, with an s_nop for the distance); lane sl's own coefficient c.x is 0 - its entry is final -
+                // so the source of a step is not changed by the step.
+                if constexpr (m == 0)
+                    asm volatile("s_nop 1");
+                if constexpr (m < 15)
+                    asm volatile("v_fmac_f64_dpp %1, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %3, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1]) : "v"(c.x), "v"(c.y), "n"(sl));
+                else if constexpr (m == 15)
+                    asm volatile("s_nop 0\n\t"
+                                 "v_fmac_f64_dpp %1, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %3, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 0"
+                                 : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1]) : "v"(c.y), "n"(sl));
+                else
+                    asm volatile("v_fmac_f64_dpp %0, %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 0"
+                                 : "+v"(xb[1][0]), "+v"(xb[1][1]) : "v"(c.y), "n"(sl));
             }
         });
     });
@@ -2735,14 +2755,24 @@ __device__ __forceinline__ void ct_pass(double* __restrict__ A, double* __restri
             constexpr int m = decltype(M)::value;
             constexpr int tm = m >> 4, sl = m & 15;
             const double2 cf = S->Cf[m][li];
+            // (round 5: one v_fmac_f64 with a DPP row broadcast per update, as in cf_chain; the second column half
+            // first - it reads the sources this step's first-half updates rewrite - and 4 NQ independent rows
+            // between a write and the next broadcast of the same register: no s_nop except for one strip at m >= 16)
+            if constexpr (m == 0) asm volatile("s_nop 1");
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const double u = row16_bcast_d<sl>(acc[q][tm][rg]);
-                    if (m < 15) acc[q][0][rg] = fma(cf.x, u, acc[q][0][rg]);
-                    acc[q][1][rg] = fma(cf.y, u, acc[q][1][rg]);
-                }
+                for (int rg = 0; rg < 4; ++rg)
+                    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(acc[q][1][rg]) : "v"(acc[q][tm][rg]), "v"(cf.y), "n"(sl));
+            if constexpr (m < 15) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(acc[q][0][rg]) : "v"(cf.x), "n"(sl));
+            }
         });
         const double r0 = S->Rd[li], r1 = S->Rd[16 + li];
         // (the chunk buffers are idle here: 16 x 17 doubles of them per wave turn a tile for the column-major copy)
