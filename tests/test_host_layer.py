@@ -195,8 +195,9 @@ def test_coadd_argument_checks_do_not_need_a_gpu(tmp_path):
 
 def test_job_params_follow_prepare_hotpants_and_clamp_large_seeing():
     """zuds/hotpants.py:44-93: r = 2.5 SEEING, rss = 6 SEEING, NAXIS / 100 / nreg_side stamps
-    (integer), limits 5e3, -bgo 0 -ko 4 unless overridden; SEEING > 6.4 px is clamped to the
-    largest kernel libzudsmi instantiates, with a warning, instead of failing."""
+    (integer), limits 5e3, -bgo 0 -ko 4 unless overridden; SEEING up to 8 px passes unclamped
+    (r = 20, rss = 48: round 5), beyond 8.4 px it is clamped to the largest kernel libzudsmi
+    instantiates, with a warning, instead of failing."""
     import importlib
     import warnings
     hp = importlib.import_module('zuds-pipeline_amd.hotpants')
@@ -207,9 +208,13 @@ def test_job_params_follow_prepare_hotpants_and_clamp_large_seeing():
     assert (p['nsx'], p['ko'], p['bgo'], p['normalize'], p['ks']) == (1, 1, 2, 1, 3.5) and 'v' not in p
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
-        p = hp.job_params(9.0, 3072, 3080, 3, 0, 0)
+        p = hp.job_params(8.0, 3072, 3080, 3, 0, 0)
+    assert len(w) == 0 and (p['r'], p['rss']) == (20.0, 48.0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        p = hp.job_params(11.0, 3072, 3080, 3, 0, 0)
     assert len(w) == 1 and 'clamped' in str(w[0].message)
-    assert int(p['r']) == 15 and int(p['rss']) == 48
+    assert int(p['r']) == 20 and int(p['rss']) == 60
 
 
 def test_swarp_keyword_classes_raise_ignore_or_warn():

@@ -130,10 +130,22 @@ def test_spatially_varying_kernel_ko2_bgo1(engine):
     assert info['ncoeff'] == 1 + 48 * 6 + 3
 
 
-@pytest.mark.parametrize('hwk', [2, 3, 7, 10])
+@pytest.mark.parametrize('hwk', [2, 3, 7, 10, 14])
 def test_kernel_half_widths(engine, hwk):
     data = scene(nx=320, ny=300, seed=10 + hwk, nstars=90)
     compare(engine, data, r=hwk + 0.7, rss=2 * hwk + 1.2, nsx=3, nsy=3, ko=1, bgo=0, **COMMON)
+
+
+@pytest.mark.parametrize('r, rss', [(16.3, 38.5), (20.9, 48.2), (6.5, 60.4), (18.2, 27.0)])
+def test_half_widths_above_15_and_substamps_above_48(engine, r, rss):
+    """zuds/hotpants.py:42-44 passes -r 2.5 SEEING -rss 6 SEEING unclamped: SEEING 6.5 px is (16, 39), 8 px is
+    (20, 48).  There the x-filtered patch, term 0 and the template patch no longer fit the LDS together:
+    k_hp_vectors_big builds the basis vectors in column chunks with term 0 in global memory (the last case is a wide
+    kernel on a small substamp: the resident form at half width 18).  Against the oracle like every other case."""
+    hw = int(r) + int(rss)
+    data = scene(nx=2 * hw + 260, ny=2 * hw + 230, seed=int(r) + int(rss), nstars=160, ksig=2.2)
+    d, n, info, rd = compare(engine, data, r=r, rss=rss, nsx=2, nsy=2, ko=1, bgo=0, **COMMON)
+    assert info['nstamps_used'] >= 2
 
 
 def test_normalise_to_template(engine):
@@ -297,7 +309,7 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
             assert i0[k] == i[k], k
 
 
-@pytest.mark.parametrize('r', [5.0, 7.0, 10.0])
+@pytest.mark.parametrize('r', [5.0, 7.0, 10.0, 17.0, 20.0])
 def test_the_two_forms_of_the_convolution_agree(engine, monkeypatch, r):
     """Round 4: the convolution of the template runs one wave per kernel block with the taps as scalar operands
     (k_hp_kbasis + k_hp_ktable + k_hp_apply_w) where a block fills most of a wave; ZM_APPLY_FORM=tile is the
@@ -305,7 +317,8 @@ def test_the_two_forms_of_the_convolution_agree(engine, monkeypatch, r):
     spatial terms outside), so the fp32 taps differ in the last bit here and there: the products agree to a few
     1e-7 of the template, the fill pattern and the fit summary exactly."""
     data = scene(nx=700, ny=660, seed=31, nstars=500, gradient=0.3)
-    kw = dict(r=r, rss=2.4 * r, nsx=5, nsy=5, nrx=2, nry=2, ko=2, bgo=0, **COMMON)
+    kw = dict(r=r, rss=2.4 * r, nsx=5 if r <= 10 else 2, nsy=5 if r <= 10 else 2, nrx=2, nry=2, ko=2, bgo=0, **COMMON)
+    monkeypatch.setenv('ZM_APPLY_FORM', 'wave')          # (the default only where a block fills most of a wave)
     d0, n0, i0 = engine.subtract(*data, **kw)
     monkeypatch.setenv('ZM_APPLY_FORM', 'tile')
     d1, n1, i1 = engine.subtract(*data, **kw)

@@ -44,10 +44,16 @@ def run(ncases, seed, verbose=True):
     bad = 0
     for case in range(ncases):
         nx, ny = int(rng.integers(220, 720)), int(rng.integers(220, 720))
-        data = scene(s, rng, nx, ny)
         hwk = int(rng.integers(2, 9))
+        rss = int(rng.integers(hwk + 3, 22))
+        if rng.random() < 0.12:
+            # round 5: wide kernels / large substamps (the chunked form of k_hp_vectors, the wide convolutions)
+            hwk = int(rng.integers(11, 21))
+            rss = int(rng.integers(hwk + 4, 61))
+            nx, ny = max(nx, 2 * (hwk + rss) + 150), max(ny, 2 * (hwk + rss) + 130)
+        data = scene(s, rng, nx, ny)
         nreg = int(rng.integers(1, 4))
-        kw = dict(r=float(hwk), rss=float(rng.integers(hwk + 3, 22)), nrx=nreg, nry=int(rng.integers(1, 4)),
+        kw = dict(r=float(hwk), rss=float(rss), nrx=nreg, nry=int(rng.integers(1, 4)),
                   nsx=int(rng.integers(2, 6)), nsy=int(rng.integers(2, 6)), ko=int(rng.integers(0, 4)),
                   bgo=int(rng.integers(0, 2)), tu=1e6, iu=1e6, tl=-1e3, il=-1e3)
         if min(nx // kw['nrx'], ny // kw['nry']) < 2 * (hwk + int(kw['rss'])) + 8:

@@ -513,7 +513,28 @@ __device__ inline double ipowd(double x, int n) {
 // passes is the kernel time (38 us); the LDS footprint (70 KB) allows two workgroups per CU either way, so 512
 // threads also double the waves that cover each other's LDS reads in the first round.
 #define HV_THREADS 512
-template <int HWK>
+#define HP_MAX_HWK 20                    // kernel half widths 1 .. 20 (41 x 41 taps), substamp half widths 1 .. 60: SEEING up to
+#define HP_MAX_HWSS 60                   // 8 px at hotpants' -r 2.5 SEEING -rss 6 SEEING (zuds/hotpants.py:42-44)
+// LDS plan of k_hp_vectors for a substamp geometry: resident form where everything fits, else term 0 in global memory
+// and, if still too large, the x-filtered patch in column chunks
+struct hv_cfg { bool big; bool w0_global; int cw; size_t shmem; };
+static inline hv_cfg hp_vectors_cfg(int pw, int sw, int npix) {
+    const size_t lim = 160 * 1024, patch = sizeof(float) * (size_t)pw * (pw + 8) + 16;   // (HV_R = 8)
+    const size_t fast = sizeof(double) * ((size_t)(pw + 8) * sw + npix + 8) + patch;
+    if (fast <= lim) return {false, false, sw, fast};
+    const size_t full = sizeof(double) * ((size_t)(pw + 8) * sw + 8) + patch;
+    if (full <= lim) return {true, true, sw, full};
+    if (patch + sizeof(double) * 8 + sizeof(double) * (size_t)(pw + 8) * 8 > lim) return {true, true, 0, 0};   // (does not fit at all)
+    int cw = (int)((lim - patch - sizeof(double) * 8) / (sizeof(double) * (size_t)(pw + 8)));
+    cw &= ~7;
+    return {true, true, cw, sizeof(double) * ((size_t)(pw + 8) * cw + 8) + patch};
+}
+// BIG (round 5: half widths up to 20, substamps up to 60 - hotpants takes -r 2.5 SEEING, -rss 6 SEEING unclamped,
+// zuds/hotpants.py:42-44): where the x-filtered patch, term 0 and the template patch do not fit 160 KB of LDS
+// together, the x-filtered patch is built and consumed in chunks of `cwarg` substamp columns (a column's y pass
+// needs that column only) and term 0 lives in global memory (`w0g`: one vector per workgroup of the launch, written
+// and read by that workgroup alone, a barrier between).  Per entry the sums are those of the resident form.
+template <int HWK, bool BIG = false>
 static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const float* __restrict__ sci,
                                                     const float* __restrict__ ref,
                                                     const float* __restrict__ srms,
@@ -526,7 +547,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
                                                     double* __restrict__ phi,         // [cell][nkp]
                                                     double* __restrict__ vbar, const int* __restrict__ guard,
                                                     double* __restrict__ phiold, const int* __restrict__ list,
-                                                    int special) {
+                                                    int special, int cwarg = 0, double* __restrict__ w0g = nullptr) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     extern __shared__ double hp_smem[];
     constexpr int STEP = 2 * HWK + 1;
@@ -536,7 +557,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
     // cells: every cell of the grid (first round: list == nullptr), or the cells the last rejection gave a new
     // substamp (`list`: [count, cells ...], written by k_hp_reject*) - a grid over all 900 cells of which a
     // handful have work spent a third of the launch dispatching workgroups that return at once
-    const int ncl = list ? list[0] : (int)gridDim.x;
+    const int ncl = list ? list[0] : P.ncell;
 #pragma unroll 1
     for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
     const int cell = list ? list[1 + ci] : ci;
@@ -557,9 +578,11 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
     // windows of the two passes run over the edge unconditionally (a conditional LDS read is
     // waited for one by one)
     const int pp = pw + HV_R;                           // patch row pitch
-    double* xp = hp_smem;                               // [pw + HV_R][sw]
-    double* w0 = xp + (size_t)(pw + HV_R) * sw;         // [npix]
-    double* red = w0 + P.npix;                          // [8]
+    const int cw = BIG ? cwarg : sw;                    // columns of the x-filtered patch held at a time (a multiple of HV_R, or sw)
+    double* xp = hp_smem;                               // [pw + HV_R][cw]
+    double* w0 = (BIG && w0g) ? w0g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)P.npix
+                              : xp + (size_t)(pw + HV_R) * cw;         // [npix]
+    double* red = (BIG && w0g) ? xp + (size_t)(pw + HV_R) * cw : w0 + P.npix;   // [8]
     float* patch = reinterpret_cast<float*>(red + 8);   // [pw][pp]
     // (loads in batches, stores after: a loop of load -> store pays one memory latency per
     // iteration, and after the first round a cell's latency is the kernel time)
@@ -579,7 +602,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
         }
     }
     for (int k = tid; k < pw * HV_R; k += HV_THREADS) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
-    for (int k = tid; k < HV_R * sw; k += HV_THREADS) xp[(size_t)pw * sw + k] = 0.0;
+    for (int k = tid; k < HV_R * cw; k += HV_THREADS) xp[(size_t)pw * cw + k] = 0.0;
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
     double* Xc = X + (size_t)cell * P.nX * P.npixp;
@@ -647,9 +670,12 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
         const bool for_w0 = (P.tfx[0] == f);
         if (!mine && !for_w0) continue;
         const double* fxv = filt + f * STEP;            // uniform address: scalar loads, no LDS traffic
+#pragma unroll 1
+        for (int c0 = 0; c0 < sw; c0 += cw) {           // (one chunk unless BIG)
+        const int cwe = min(cw, sw - c0), nstripc = (cwe + HV_R - 1) / HV_R;
         // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
-        for (int e = tid; e < pw * nstrip; e += HV_THREADS) {
-            const int yy = e / nstrip, j0 = (e - yy * nstrip) * HV_R;
+        for (int e = tid; e < pw * nstripc; e += HV_THREADS) {
+            const int yy = e / nstripc, jl0 = (e - yy * nstripc) * HV_R, j0 = c0 + jl0;
             const float* pr = patch + yy * pp + j0;
             double wv[WIN];
 #pragma unroll
@@ -665,7 +691,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
             }
 #pragma unroll
             for (int q = 0; q < HV_R; ++q)
-                if (j0 + q < sw) xp[yy * sw + j0 + q] = acc[q];
+                if (j0 + q < sw) xp[yy * cw + jl0 + q] = acc[q];
         }
         __syncthreads();
         for (int n = tn0; n < tn1; ++n) {
@@ -674,13 +700,13 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
             const double sc = P.tscale[n];
             const bool sub0 = n != 0 && P.tsub0[n] != 0;
             // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
-            for (int e = tid; e < sw * nstrip; e += HV_THREADS) {
-                const int s = e / sw, j = e - s * sw;      // consecutive lanes = consecutive columns
+            for (int e = tid; e < cwe * nstrip; e += HV_THREADS) {
+                const int s = e / cwe, jl = e - s * cwe, j = c0 + jl;      // consecutive lanes = consecutive columns
                 const int i0 = s * HV_R;
-                const double* col = xp + i0 * sw + j;
+                const double* col = xp + i0 * cw + jl;
                 double wv[WIN];
 #pragma unroll
-                for (int k = 0; k < WIN; ++k) wv[k] = col[k * sw];        // rows >= pw are zero
+                for (int k = 0; k < WIN; ++k) wv[k] = col[k * cw];        // rows >= pw are zero
                 double acc[HV_R];
 #pragma unroll
                 for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
@@ -713,6 +739,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
             if (n == 0) __syncthreads();
         }
         __syncthreads();
+        }   // column chunks
     }
     }   // cells
 }
@@ -3851,6 +3878,18 @@ __global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, cons
                                                     const int* __restrict__ list, int special) {
     hp_vectors_body<HWK>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special);
 }
+template <int HWK>
+__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors_big(const hp_plan P, const float* __restrict__ sci,
+                                                    const float* __restrict__ ref, const float* __restrict__ srms,
+                                                    const float* __restrict__ trms, const double* __restrict__ filt,
+                                                    const int2* __restrict__ centres, const int* __restrict__ active,
+                                                    const int* __restrict__ need, double* __restrict__ X,
+                                                    double* __restrict__ phi, double* __restrict__ vbar,
+                                                    const int* __restrict__ guard, double* __restrict__ phiold,
+                                                    const int* __restrict__ list, int special, int cw, double* __restrict__ w0g) {
+    hp_vectors_body<HWK, true>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special,
+                               cw, w0g);
+}
 // (four waves per SIMD - two workgroups per CU - like the one-job kernel: without the bound the job table's pointers
 // push this instance to 131 registers, one workgroup per CU, and the first round of a batch ran 40 % slower per job;
 // half widths above 11 need more than 128 registers in the one-job kernel too)
@@ -4063,8 +4102,8 @@ static int make_plan(const zm_hp_params* hp, int nx, int ny, hp_plan* P, std::ve
     memset(P, 0, sizeof(*P));
     P->nx = nx; P->ny = ny;
     P->hwk = (int)hp->r; P->hwss = (int)hp->rss;
-    ZM_CHECK(P->hwk >= 1 && P->hwk <= 15, "zm_subtract: kernel half width int(r) = %d outside [1, 15]", P->hwk);
-    ZM_CHECK(P->hwss >= 1 && P->hwss <= 48, "zm_subtract: substamp half width int(rss) = %d outside [1, 48]", P->hwss);
+    ZM_CHECK(P->hwk >= 1 && P->hwk <= HP_MAX_HWK, "zm_subtract: kernel half width int(r) = %d outside [1, %d]", P->hwk, HP_MAX_HWK);
+    ZM_CHECK(P->hwss >= 1 && P->hwss <= HP_MAX_HWSS, "zm_subtract: substamp half width int(rss) = %d outside [1, %d]", P->hwss, HP_MAX_HWSS);
     P->hw = P->hwk + P->hwss;
     P->step = 2 * P->hwk + 1; P->sw = 2 * P->hwss + 1; P->pw = 2 * P->hw + 1;
     P->npix = P->sw * P->sw;
@@ -4228,7 +4267,7 @@ static int launch_apply(zm_ctx* ctx, const hp_plan& P, const unsigned long long*
         hipLaunchKernelGGL(k_hp_ktable<HWK>, dim3(zm_div_up(maxbx, HPK_NBK), maxby, P.nreg), dim3(512), 0, ctx->stream,
                            P, Mt, maxbx, maxby, kcg);
         const size_t wsh = sizeof(float2) * (size_t)CW::TH * CW::TP;
-        static bool wset[16][64] = {};
+        static bool wset[HP_MAX_HWK + 1][64] = {};
         if (wsh > 65536 && !wset[HWK][ctx->device & 63]) {
             ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply_w<HWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsh));
             wset[HWK][ctx->device & 63] = true;
@@ -4434,9 +4473,14 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_HIP(hipMemsetAsync(ibuf, 0, sizeof(int) * HP_NIBUF, st));
     ZM_TRY(hp_launch_cells(ctx, P, ref, bad, dirty, centres, active, need, ntotal));
     // LDS of k_hp_vectors
-    size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 8) +
-                 sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
-    ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
+    const hv_cfg hvc = hp_vectors_cfg(P.pw, P.sw, P.npix);
+    ZM_CHECK(hvc.cw >= 8, "zm_subtract: r = %d, rss = %d: the template patch alone exceeds the LDS", P.hwk, P.hwss);
+    size_t vsh = hvc.shmem;
+    // (the chunked form: term 0 of every workgroup of the launch in global memory; the grid is capped, cells loop)
+    const int hv_gx = hvc.big ? std::min(P.ncell, 128) : P.ncell;
+    double* hv_w0g = nullptr;
+    if (hvc.w0_global)
+        ZM_TRY(ctx->get("hp_w0g", sizeof(double) * (size_t)hv_gx * HV_SPLIT_FEW * P.npix, (void**)&hv_w0g));
 
     // Rejection rounds without a host round trip on the critical path: round r + 1 is enqueued
     // before the host learns whether round r rejected anything.  k_hp_reject of round r adds its
@@ -4470,13 +4514,28 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
     hipLaunchKernelGGL(k_hp_vectors<H>, dim3(rounds == 1 ? P.ncell : ncl_grid, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
                        centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist, rounds == 1 ? 0 : 1); break;
+#define HP_VECBIG_CASE(H) case H: \
+    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_big<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
+    hipLaunchKernelGGL(k_hp_vectors_big<H>, dim3(rounds == 1 ? hv_gx : std::min(ncl_grid, hv_gx), rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
+                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist, rounds == 1 ? 0 : 1, hvc.cw, hv_w0g); break;
+            if (hvc.big) {
+                switch (P.hwk) {
+                    HP_VECBIG_CASE(1) HP_VECBIG_CASE(2) HP_VECBIG_CASE(3) HP_VECBIG_CASE(4) HP_VECBIG_CASE(5)
+                    HP_VECBIG_CASE(6) HP_VECBIG_CASE(7) HP_VECBIG_CASE(8) HP_VECBIG_CASE(9) HP_VECBIG_CASE(10)
+                    HP_VECBIG_CASE(11) HP_VECBIG_CASE(12) HP_VECBIG_CASE(13) HP_VECBIG_CASE(14) HP_VECBIG_CASE(15)
+                    HP_VECBIG_CASE(16) HP_VECBIG_CASE(17) HP_VECBIG_CASE(18) HP_VECBIG_CASE(19) HP_VECBIG_CASE(20)
+                    default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
+                }
+            } else
             switch (P.hwk) {
                 HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
                 HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
                 HP_VEC_CASE(11) HP_VEC_CASE(12) HP_VEC_CASE(13) HP_VEC_CASE(14) HP_VEC_CASE(15)
+                HP_VEC_CASE(16) HP_VEC_CASE(17) HP_VEC_CASE(18) HP_VEC_CASE(19) HP_VEC_CASE(20)
                 default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
             }
 #undef HP_VEC_CASE
+#undef HP_VECBIG_CASE
             ZM_HIP(hipGetLastError());
         }
         {
@@ -4707,6 +4766,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
                 HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
                 HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
+                HP_APPLY_CASE(16) HP_APPLY_CASE(17) HP_APPLY_CASE(18) HP_APPLY_CASE(19) HP_APPLY_CASE(20)
                 default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
             }
 #undef HP_APPLY_CASE
@@ -4801,7 +4861,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     }
     const hp_plan& P = Pj[0];
     ZM_CHECK(nx > 2 * P.hw + 1 && ny > 2 * P.hw + 1, "zm_subtract_batch_dev: image smaller than a substamp");
-    if (P.nkp > 15 || P.nunk > CBC_COLS || P.ncellr > 256 || njobs == 1) {
+    if (P.nkp > 15 || P.nunk > CBC_COLS || P.ncellr > 256 || njobs == 1 || P.hwk > 15 || hp_vectors_cfg(P.pw, P.sw, P.npix).big) {
         // what the batched kernels do not cover (and the batch of one): job by job
         for (int j = 0; j < njobs; ++j)
             ZM_TRY(zm_subtract_dev(ctx, jobs[j].sci, jobs[j].sci_rms, jobs[j].ref, jobs[j].ref_rms, jobs[j].bpm, nx, ny,
@@ -4899,9 +4959,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
 
     // the fit of all jobs: the rejection rounds, one ahead of the host as in zm_subtract_dev; a job is guarded by its
     // own round flags
-    const size_t vsh = sizeof(double) * ((size_t)(P.pw + HV_R) * P.sw + P.npix + 8) +
-                       sizeof(float) * (size_t)P.pw * (P.pw + HV_R) + 16;
-    ZM_CHECK(vsh <= 160 * 1024, "zm_subtract: r = %d, rss = %d need %zu B of LDS (> 160 KiB)", P.hwk, P.hwss, vsh);
+    const size_t vsh = hp_vectors_cfg(P.pw, P.sw, P.npix).shmem;             // (the resident form: checked above)
     const dim3 b256(256);
     // A job leaves the launches two rounds after it converged: round r + 1 is enqueued when the host has the flags
     // of round r - 1, and takes the jobs that rejected something then (the others' rounds would be void anyway: the
@@ -4971,6 +5029,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             HP_APPLYB_CASE(1) HP_APPLYB_CASE(2) HP_APPLYB_CASE(3) HP_APPLYB_CASE(4) HP_APPLYB_CASE(5)
             HP_APPLYB_CASE(6) HP_APPLYB_CASE(7) HP_APPLYB_CASE(8) HP_APPLYB_CASE(9) HP_APPLYB_CASE(10)
             HP_APPLYB_CASE(11) HP_APPLYB_CASE(12) HP_APPLYB_CASE(13) HP_APPLYB_CASE(14) HP_APPLYB_CASE(15)
+            HP_APPLYB_CASE(16) HP_APPLYB_CASE(17) HP_APPLYB_CASE(18) HP_APPLYB_CASE(19) HP_APPLYB_CASE(20)
             default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
         }
 #undef HP_APPLYB_CASE

@@ -12,7 +12,7 @@ from .utils import initialize_directory, quick_background_estimate
 
 __all__ = ['prepare_hotpants', 'HotpantsCall']
 
-MAX_R, MAX_RSS = 15, 48             # largest kernel / substamp half widths of zm_subtract
+MAX_R, MAX_RSS = 20, 60             # largest kernel / substamp half widths of zm_subtract (SEEING 8 px)
 _INT_KEYS = ('ko', 'bgo', 'nss', 'nsx', 'nsy', 'nrx', 'nry')
 _FLT_KEYS = ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks')
 # The `-key value` pass-through (zuds/hotpants.py:86-87) reaches hotpants itself.  Beyond the keys above
@@ -35,7 +35,7 @@ def job_params(seeing, naxis1, naxis2, nreg_side, il, tl, hotpants_kws=None):
     r, rss = 2.5 * seeing, 6. * seeing
     if int(r) > MAX_R or int(rss) > MAX_RSS:
         # hotpants takes any half width; libzudsmi's convolution kernels are instantiated up to
-        # 15 (31 x 31 taps) and its substamps up to 48.  A frame with SEEING > 6.4 px is still
+        # 20 (41 x 41 taps) and its substamps up to 60.  A frame with SEEING > 8.4 px is still
         # subtracted, with the largest kernel available, instead of being dropped by the drivers'
         # try / except (scripts/dosub.py:205-213)
         import warnings
