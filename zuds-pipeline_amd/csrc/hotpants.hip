@@ -557,7 +557,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
     // cells: every cell of the grid (first round: list == nullptr), or the cells the last rejection gave a new
     // substamp (`list`: [count, cells ...], written by k_hp_reject*) - a grid over all 900 cells of which a
     // handful have work spent a third of the launch dispatching workgroups that return at once
-    const int ncl = list ? list[0] : P.ncell;
+    const int ncl = list ? list[0] : (BIG ? P.ncell : (int)gridDim.x);   // (BIG: a capped grid whose workgroups loop)
 #pragma unroll 1
     for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
     const int cell = list ? list[1 + ci] : ci;
@@ -578,7 +578,7 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
     // windows of the two passes run over the edge unconditionally (a conditional LDS read is
     // waited for one by one)
     const int pp = pw + HV_R;                           // patch row pitch
-    const int cw = BIG ? cwarg : sw;                    // columns of the x-filtered patch held at a time (a multiple of HV_R, or sw)
+    const int cw = BIG ? cwarg : P.sw;                  // columns of the x-filtered patch held at a time (a multiple of HV_R, or sw)
     double* xp = hp_smem;                               // [pw + HV_R][cw]
     double* w0 = (BIG && w0g) ? w0g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)P.npix
                               : xp + (size_t)(pw + HV_R) * cw;         // [npix]
@@ -670,9 +670,14 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
         const bool for_w0 = (P.tfx[0] == f);
         if (!mine && !for_w0) continue;
         const double* fxv = filt + f * STEP;            // uniform address: scalar loads, no LDS traffic
-#pragma unroll 1
-        for (int c0 = 0; c0 < sw; c0 += cw) {           // (one chunk unless BIG)
-        const int cwe = min(cw, sw - c0), nstripc = (cwe + HV_R - 1) / HV_R;
+        // (one chunk - a loop of constant trip count 1 over constants the compiler folds: the resident form keeps its
+        // 124 registers and two workgroups per CU - unless BIG.  Not a lambda: a closure takes the plan's address,
+        // and the batched kernel then keeps a copy of the plan in scratch - 3.5 KB per lane, the pool 2 x slower)
+        const int nchunks = BIG ? (sw + cw - 1) / cw : 1;
+        for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = BIG ? ch * cw : 0;
+        const int cwe = BIG ? min(cw, sw - c0) : sw;
+        const int nstripc = BIG ? (cwe + HV_R - 1) / HV_R : nstrip;
         // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
         for (int e = tid; e < pw * nstripc; e += HV_THREADS) {
             const int yy = e / nstripc, jl0 = (e - yy * nstripc) * HV_R, j0 = c0 + jl0;
