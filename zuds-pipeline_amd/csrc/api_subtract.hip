@@ -57,16 +57,28 @@ __global__ void k_rsel_init(rs_state* __restrict__ st, unsigned int* __restrict_
 // mode 0: v = img[p]; mode 1: v = |img[p] - centre| (float32 arithmetic, as numpy).
 // hist[im][t][bin]: t = 0 counts the keys under prefix[0]; t = 1 those under prefix[1]
 // when it differs (the two middle ranks straddle a bin boundary: rare).
-__global__ __launch_bounds__(256) void k_rsel_hist(const rs_batch B, int vec_ok, int mode, int shift,
-                                                   int nbins, const rs_state* __restrict__ st,
-                                                   unsigned int* __restrict__ hist) {
+// Round 5.  (1) 1 024 threads per workgroup, 256 workgroups (was 256 x 512): a workgroup's histograms are flushed
+// with one global atomic per non-empty bin - 512 x 2 048 of them per pass and image were 8 us of a 33 us pass
+// (`tools/rs_probe.py`: 214 -> 177 us per median + MAD of two frames).  (2) The validity of a pixel (mask == 0,
+// not NaN) is the same in all six passes: the FIRST pass writes it as one bit per pixel - the 64-lane ballot of each
+// of a lane's four pixels, four 64-bit words per wave and iteration - and the other five read 0.125 B per pixel
+// instead of the 4 B mask (- 10 us: the passes are bound by their histogram work and their launches, not by bytes).
+// Measured and not kept: the next iteration's pixels requested ahead (no change); the scan run by the last
+// workgroup of a pass to finish instead of a launch of its own (a ticket per image; + 50 us: every thread waits for
+// the acknowledgement of its atomics, and the scan reads the histogram past the caches).
+// vbits: [image][n / 256 rounded up][4] words, or NULL (masks read every time).  vmode: 1 = masks, and write the
+// bits, 2 = bits.
+__global__ __launch_bounds__(1024) void k_rsel_hist(const rs_batch B, int vec_ok, int mode, int shift,
+                                                    int nbins, const rs_state* __restrict__ st,
+                                                    unsigned int* __restrict__ hist,
+                                                    unsigned long long* __restrict__ vbits, int vmode) {
     __shared__ unsigned int lh[2][RS_BINS];
     const int im = blockIdx.y;
     const float* __restrict__ img = B.im[im].img;
     const int32_t* __restrict__ mask = B.im[im].mask;
     const rs_state S = st[im];
     const bool two = S.prefix[1] != S.prefix[0];
-    for (int k = threadIdx.x; k < nbins; k += 256) { lh[0][k] = 0; lh[1][k] = 0; }
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) { lh[0][k] = 0; lh[1][k] = 0; }
     __syncthreads();
     int cur = -1;
     unsigned int run = 0;              // run-length aggregation: sky pixels share a bin
@@ -89,19 +101,44 @@ __global__ __launch_bounds__(256) void k_rsel_hist(const rs_batch B, int vec_ok,
     };
     const int64_t n = B.n;
     const int64_t n4 = vec_ok ? n / 4 : 0;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
-        const float4 v = reinterpret_cast<const float4*>(img)[q];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long* vb = vbits ? vbits + (size_t)im * (size_t)((n4 + 63) / 64) * 4 : nullptr;
+    const int lane = threadIdx.x & 63;
+    // (with the bit plane whole waves walk the loop together: the bound is rounded up to the wave, lanes beyond n4
+    // carry invalid pixels)
+    const int64_t n4w = vb ? ((n4 + 63) / 64) * 64 : n4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4w; q += stride) {
+        const bool in = q < n4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = reinterpret_cast<const float4*>(img)[q];
         int4 m = make_int4(0, 0, 0, 0);
-        if (mask) m = reinterpret_cast<const int4*>(mask)[q];
+        if (vb && vmode == 2) {
+            // (four words per wave: the same address for every lane - one transaction)
+            const unsigned long long* w = vb + (q >> 6) * 4;
+            m.x = ((w[0] >> lane) & 1ull) ? 0 : 1;
+            m.y = ((w[1] >> lane) & 1ull) ? 0 : 1;
+            m.z = ((w[2] >> lane) & 1ull) ? 0 : 1;
+            m.w = ((w[3] >> lane) & 1ull) ? 0 : 1;
+        } else {
+            if (mask && in) m = reinterpret_cast<const int4*>(mask)[q];
+            if (!in) m = make_int4(1, 1, 1, 1);
+            if (vb) {
+                const unsigned long long b0 = __ballot(m.x == 0 && v.x == v.x), b1 = __ballot(m.y == 0 && v.y == v.y);
+                const unsigned long long b2 = __ballot(m.z == 0 && v.z == v.z), b3 = __ballot(m.w == 0 && v.w == v.w);
+                if (lane == 0) {
+                    unsigned long long* w = vb + (q >> 6) * 4;
+                    w[0] = b0; w[1] = b1; w[2] = b2; w[3] = b3;
+                }
+            }
+        }
         put(v.x, m.x); put(v.y, m.y); put(v.z, m.z); put(v.w, m.w);
     }
-    for (int64_t p = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += stride)
+    for (int64_t p = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
         put(img[p], mask ? mask[p] : 0);
     if (run) atomicAdd(&lh[0][cur], run);
     __syncthreads();
     unsigned int* h = hist + (size_t)im * 2 * RS_BINS;
-    for (int k = threadIdx.x; k < nbins; k += 256) {
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
         if (lh[0][k]) atomicAdd(&h[k], lh[0][k]);
         if (two && lh[1][k]) atomicAdd(&h[RS_BINS + k], lh[1][k]);
     }
@@ -209,6 +246,7 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
     unsigned int* d_hist = nullptr;
     ZM_TRY(ctx->get("rs_state", sizeof(rs_state) * ZM_RS_MAXIMG, (void**)&d_st));
     ZM_TRY(ctx->get("rs_hist", sizeof(unsigned int) * 2 * RS_BINS * ZM_RS_MAXIMG, (void**)&d_hist));
+    unsigned long long* d_vbits = nullptr;
     rs_batch B;
     memset(&B, 0, sizeof(B));
     B.n = n;
@@ -217,10 +255,18 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
         B.im[i] = ims[i];
         if (((uintptr_t)ims[i].img & 15) || ((uintptr_t)ims[i].mask & 15)) vec_ok = 0;
     }
-    // two workgroups per CU: fewer histogram zero / flush rounds than 1024, enough loads in flight
-    // (sweep on 3072^2: 256 / 384 / 512 / 768 / 1024 workgroups -> 280 / 252 / 238 / 254 / 270 us)
-    int grid = (int)std::min<int64_t>((n / 4 + 255) / 256, 512);
+    // one workgroup of 1 024 threads per CU (round 5; rounds 1 - 4: two of 256 per CU; ZM_RS_THREADS / ZM_RS_GRID for A / B:
+    // 256 x 512 214 us, 512 x 256 196, 512 x 512 191, 1024 x 128 182, 1024 x 256 177, 1024 x 64 286 per median + MAD of two frames)
+    static const int rs_threads = getenv("ZM_RS_THREADS") ? atoi(getenv("ZM_RS_THREADS")) : 1024;
+    static const int rs_grid = getenv("ZM_RS_GRID") ? atoi(getenv("ZM_RS_GRID")) : 256;
+    int grid = (int)std::min<int64_t>((n / 4 + rs_threads - 1) / rs_threads, rs_grid);
     if (grid < 1) grid = 1;
+    // the validity bit plane: where the vector path runs and there is a mask to save (ZM_RS_BITS=0: masks every pass)
+    bool any_mask = false;
+    for (int i = 0; i < nimg; ++i) any_mask = any_mask || ims[i].mask != nullptr;
+    static const bool bits_off = getenv("ZM_RS_BITS") && getenv("ZM_RS_BITS")[0] == '0';
+    if (vec_ok && any_mask && n >= 4096 && !bits_off)
+        ZM_TRY(ctx->get("rs_vbits", sizeof(unsigned long long) * 4 * (size_t)((n / 4 + 63) / 64) * ZM_RS_MAXIMG, (void**)&d_vbits));
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     hipStream_t s = ctx->stream;
     {
@@ -229,8 +275,8 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
         for (int mode = 0; mode < 2; ++mode)
             for (int pass = 0; pass < 3; ++pass) {
                 const int nb = 1 << bits[pass];
-                hipLaunchKernelGGL(k_rsel_hist, dim3(grid, nimg), dim3(256), 0, s, B, vec_ok, mode,
-                                   shifts[pass], nb, d_st, d_hist);
+                hipLaunchKernelGGL(k_rsel_hist, dim3(grid, nimg), dim3(rs_threads), 0, s, B, vec_ok, mode,
+                                   shifts[pass], nb, d_st, d_hist, d_vbits, (mode == 0 && pass == 0) ? 1 : 2);
                 hipLaunchKernelGGL(k_rsel_scan, dim3(nimg), dim3(256), 0, s, pass, mode, shifts[pass], nb,
                                    d_st, d_hist);
             }
