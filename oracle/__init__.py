@@ -16,7 +16,13 @@ box, and the reference's only two known-answer stamps
 need network inputs.  What is restated here is therefore (a) the operator
 *definition* the reference fixes by its flags and configs (cited per function)
 and (b) the published algorithms of the three tools, each adopted as an explicit
-convention and pinned by analytic known-answer tests in ``tests/``.
+convention and pinned by analytic known-answer tests in ``tests/``.  Pieces that
+an independent implementation on this image can check are checked against it
+(``tests/test_independent_pins.py``): the normalised Lanczos-3 kernel against
+Pillow's resampler, bilinear interpolation against scipy.ndimage, the natural
+bicubic spline of the background map against scipy.interpolate; WCS and FITS
+against astropy-made vectors (``tests/golden``).  The tools' own conventions
+(edges, snapping, masks, the mode estimator, all of hotpants) stay unpinned.
 
 Everything is numpy float64 unless a function says otherwise.
 """
