@@ -1251,39 +1251,140 @@ __device__ __forceinline__ void cf_chain(double (&xb)[2][2], const double2 (*Cf)
                 if (8 * (b + 1) + q < CH_NB - 1) cf[b + 1][q] = Cf[8 * (b + 1) + q][li];
         }
         __builtin_amdgcn_sched_barrier(0);
-        hp_static_for<0, 8>([&](auto Q) __attribute__((always_inline)) {
-            constexpr int m = 8 * b + decltype(Q)::value;
-            if constexpr (m < CH_NB - 1) {
-                constexpr int sl = m & 15;
-                const double2 c = cf[b][m & 7];
-                // Round 5: x += c * (lane sl's u) as ONE instruction - v_fmac_f64 with its first operand through the
-                // DPP row broadcast - instead of two 32-bit DPP moves and the FMA: 216 -> 108 instructions per chain,
-                // on a wave that issues one per ~5 cycles.  The same products and sums.  A DPP operand written by one
-                // of the two instructions before is read stale (no interlock): the order below keeps two instructions
-                // between every write of a source and its next broadcast (steps >= 15 touch only the second column
-                // half, with an s_nop for the distance); lane sl's own coefficient c.x is 0 - its entry is final -
-                // so the source of a step is not changed by the step.
-                if constexpr (m == 0)
-                    asm volatile("s_nop 1");
-                if constexpr (m < 15)
-                    asm volatile("v_fmac_f64_dpp %1, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %3, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
-                                 : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1]) : "v"(c.x), "v"(c.y), "n"(sl));
-                else if constexpr (m == 15)
-                    asm volatile("s_nop 0\n\t"
-                                 "v_fmac_f64_dpp %1, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %3, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 0"
-                                 : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1]) : "v"(c.y), "n"(sl));
-                else
-                    asm volatile("v_fmac_f64_dpp %0, %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_nop 0"
-                                 : "+v"(xb[1][0]), "+v"(xb[1][1]) : "v"(c.y), "n"(sl));
-            }
-        });
+        // Round 5: x += c * (lane sl's u) as ONE instruction - v_fmac_f64 with its first operand through the DPP
+        // row broadcast - instead of two 32-bit DPP moves and the FMA: 216 -> 108 instructions per chain, on a wave
+        // that issues one per ~5 cycles.  The same products and sums.  A DPP operand written by one of the two
+        // instructions before is read stale (no interlock): within a step the order below keeps two instructions
+        // between every write of a source and its next broadcast (steps >= 15 touch only the second column half, with
+        // an s_nop for the distance); lane sl's own coefficient c.x is 0 - its entry is final - so the source of a
+        // step is not changed by the step.  The eight steps of a batch are ONE asm statement that opens with its own
+        // s_nop: the compiler cannot put a register copy between two of them (it did, in k_chol_fused2, between
+        // steps 13 and 14 of the per-step form - tests/test_isa_lint.py found it and now guards every DPP read).
+        if constexpr (b == 0)
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %1, %0, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+                         : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1])
+                         : "v"(cf[0][0].x), "v"(cf[0][0].y), "v"(cf[0][1].x), "v"(cf[0][1].y), "v"(cf[0][2].x), "v"(cf[0][2].y), "v"(cf[0][3].x), "v"(cf[0][3].y), "v"(cf[0][4].x), "v"(cf[0][4].y), "v"(cf[0][5].x), "v"(cf[0][5].y), "v"(cf[0][6].x), "v"(cf[0][6].y), "v"(cf[0][7].x), "v"(cf[0][7].y));
+        if constexpr (b == 1)
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %1, %0, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %4 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %4 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %7 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %6 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %7 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %6 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %8 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %8 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %10 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %10 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %14 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %14 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %0, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %0, %0, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %0, %19 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %2, %19 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0"
+                         : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1])
+                         : "v"(cf[1][0].x), "v"(cf[1][0].y), "v"(cf[1][1].x), "v"(cf[1][1].y), "v"(cf[1][2].x), "v"(cf[1][2].y), "v"(cf[1][3].x), "v"(cf[1][3].y), "v"(cf[1][4].x), "v"(cf[1][4].y), "v"(cf[1][5].x), "v"(cf[1][5].y), "v"(cf[1][6].x), "v"(cf[1][6].y), "v"(cf[1][7].x), "v"(cf[1][7].y));
+        if constexpr (b == 2)
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %1, %1, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %7 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0"
+                         : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1])
+                         : "v"(cf[2][0].x), "v"(cf[2][0].y), "v"(cf[2][1].x), "v"(cf[2][1].y), "v"(cf[2][2].x), "v"(cf[2][2].y), "v"(cf[2][3].x), "v"(cf[2][3].y), "v"(cf[2][4].x), "v"(cf[2][4].y), "v"(cf[2][5].x), "v"(cf[2][5].y), "v"(cf[2][6].x), "v"(cf[2][6].y), "v"(cf[2][7].x), "v"(cf[2][7].y));
+        if constexpr (b == 3)
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %1, %1, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %7 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %7 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %13 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_fmac_f64_dpp %1, %1, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %3, %3, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0"
+                         : "+v"(xb[0][0]), "+v"(xb[1][0]), "+v"(xb[0][1]), "+v"(xb[1][1])
+                         : "v"(cf[3][0].x), "v"(cf[3][0].y), "v"(cf[3][1].x), "v"(cf[3][1].y), "v"(cf[3][2].x), "v"(cf[3][2].y), "v"(cf[3][3].x), "v"(cf[3][3].y), "v"(cf[3][4].x), "v"(cf[3][4].y), "v"(cf[3][5].x), "v"(cf[3][5].y), "v"(cf[3][6].x), "v"(cf[3][6].y));
     });
     const double r0 = Rd[li], r1 = Rd[16 + li];
 #pragma unroll
