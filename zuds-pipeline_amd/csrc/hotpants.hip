@@ -364,17 +364,21 @@ __global__ __launch_bounds__(256) void k_hp_cells(const hp_plan P, const float* 
     }
 }
 
-// The same for cells of at most 256 * HC_PX pixels: a thread keeps its pixels (k = tid + 256 i,
-// the order of the loops above, so the sums are the same to the last bit) and their two flags in
-// registers; the eight clipping sweeps and the greedy picks then read no memory at all.
-#define HC_PX 48
-__global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const float* __restrict__ ref,
+// The same for cells of at most HC_THREADS * HC_PX pixels: a thread keeps its pixels (k = tid + HC_THREADS i)
+// and their two flags in registers; the eight clipping sweeps and the greedy picks then read no memory at all.
+#define HC_PX 24
+// Round 5 (late): 512 threads and 24 pixels per thread (was 256 x 48) - the kernel is a chain of twelve block sums and
+// three picks behind loops over a thread's pixels, 900 workgroups two per CU: per-thread loops of half the length,
+// the same number of resident workgroups.  (The partial sums group differently from k_hp_cells' now: m, s and the
+// threshold move in their last bits, like between any two summation orders; the oracle's own order is numpy's.)
+#define HC_THREADS 512
+__global__ __launch_bounds__(HC_THREADS, 4) void k_hp_cells_reg(const hp_plan P, const float* __restrict__ ref,
                                                       const uint8_t* __restrict__ bad,
                                                       const uint8_t* __restrict__ dirty,
                                                       int2* __restrict__ centres) {
-    __shared__ double red[4];
-    __shared__ float bval[4];
-    __shared__ int bidx[4];
+    __shared__ double red[HC_THREADS / 64];
+    __shared__ float bval[HC_THREADS / 64];
+    __shared__ int bidx[HC_THREADS / 64];
     __shared__ int2 chosen[HP_MAXNSS];
     const int cell = blockIdx.x, tid = threadIdx.x;
     const int r = cell / P.ncellr, c = cell - r * P.ncellr;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
     const int cw = (P.rx1[r] - P.rx0[r]) / P.nsx, ch = (P.ry1[r] - P.ry0[r]) / P.nsy;
     const int cx0 = P.rx0[r] + sx * cw, cy0 = P.ry0[r] + sy * ch;
     const int n = cw * ch;
-    const int dyy = 256 / cw, dxx = 256 - dyy * cw;        // (yy, xx) advance by 256 pixels
+    const int dyy = HC_THREADS / cw, dxx = HC_THREADS - dyy * cw;        // (yy, xx) advance by HC_THREADS pixels
     const int yy0 = tid / cw, xx0 = tid - yy0 * cw;
     float v[HC_PX];
     unsigned long long okm = 0, cleanm = 0;                // bit i: pixel i is not bad / not dirty
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
         int yy = yy0, xx = xx0;
 #pragma unroll
         for (int i = 0; i < HC_PX; ++i) {
-            const int k = tid + 256 * i;
+            const int k = tid + HC_THREADS * i;
             float val = 0.f;
             if (k < n) {
                 const size_t idx = (size_t)(cy0 + yy) * P.nx + cx0 + xx;
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
             const double vv = vf;
             if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) { s0 += 1.0; s1 += vv; }
         }
-        s0 = block_sum256(s0, red);
-        s1 = block_sum256(s1, red);
+        s0 = block_sum_waves<HC_THREADS / 64>(s0, red);
+        s1 = block_sum_waves<HC_THREADS / 64>(s1, red);
         if (s0 < 1.0) break;
         const double mn = s1 / s0;
         double s2 = 0;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
             const double vv = vf;
             if ((okm >> i & 1) && (pass == 0 || fabs(vv - m) <= 3.0 * s)) s2 += (vv - mn) * (vv - mn);
         }
-        s2 = block_sum256(s2, red);
+        s2 = block_sum_waves<HC_THREADS / 64>(s2, red);
         m = mn;
         s = sqrt(s2 / s0);
     }
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
                 if (cand >> i & 1) {
                     // candidates near an earlier pick were struck out when it was made: only the
                     // latest pick is new
-                    const int x = cx0 + xx, y = cy0 + yy, q = tid + 256 * i;
+                    const int x = cx0 + xx, y = cy0 + yy, q = tid + HC_THREADS * i;
                     const bool excl = (abs(x - last.x) <= P.hwss) && (abs(y - last.y) <= P.hwss);
                     if (excl) cand &= ~(1ull << i);          // stays excluded for the later picks
                     else if (v[i] > best || (v[i] == best && q < bi)) { best = v[i]; bi = q; }
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_hp_cells_reg(const hp_plan P, const 
         if ((tid & 63) == 0) { bval[tid >> 6] = best; bidx[tid >> 6] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < HC_THREADS / 64; ++w)
                 if (bval[w] > best || (bval[w] == best && bidx[w] < bi)) { best = bval[w]; bi = bidx[w]; }
             int2 cc = make_int2(-1, -1);
             if (bi != 0x7fffffff) { int yy = bi / cw; cc = make_int2(cx0 + bi - yy * cw, cy0 + yy); }
@@ -4447,8 +4451,8 @@ static int hp_launch_cells(zm_ctx* ctx, const hp_plan& P, const float* ref, cons
     int maxcell = 0;
     for (int r = 0; r < P.nreg; ++r)
         maxcell = std::max(maxcell, ((P.rx1[r] - P.rx0[r]) / P.nsx) * ((P.ry1[r] - P.ry0[r]) / P.nsy));
-    if (maxcell <= 256 * HC_PX)
-        hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
+    if (maxcell <= HC_THREADS * HC_PX)
+        hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), dim3(HC_THREADS), 0, st, P, ref, bad, dirty, centres);
     else
         hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
     hipLaunchKernelGGL(k_hp_init_active, dim3(zm_div_up(P.ncell, 256)), b256, 0, st, P, centres, active, need, ntotal);
