@@ -3508,23 +3508,27 @@ __global__ __launch_bounds__(FD_THREADS, 4) void k_coadd_fused_own(
 #pragma unroll
             for (int e = 0; e < 4; ++e) xw[e] = XW[e * FO_PQ + lcol];      // weight e of the quad's four pixels
         }
-        // one chunk at a time, the next chunk's raw quads requested before the arithmetic of this one
-        float4 ra, rb, ry = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto fetch = [&](int k) __attribute__((always_inline)) {
+        // one chunk at a time, the next chunk's raw quads requested before the arithmetic of this one.  The (at most
+        // three) chunks of a wave are three copies of the code, not a loop: rolled, the look-ahead's twelve registers
+        // were copied from "next" to "current" every iteration - six v_mov_b64 and four zeroing moves per chunk, an
+        // eighth of the prep's vector instructions.
+        float4 ra[3], rb[3], ry[3];
+        auto fetch = [&](int j, int k) __attribute__((always_inline)) {
             const char* C = SL + k * FO_CHB;
-            ra = reinterpret_cast<const float4*>(C)[ln];
-            rb = reinterpret_cast<const float4*>(C + FO_CHB / 2)[ln];
-            if (has_y) ry = YT[min(FO_RPC * k + lrow, FO_YROWS - 1)];
+            ra[j] = reinterpret_cast<const float4*>(C)[ln];
+            rb[j] = reinterpret_cast<const float4*>(C + FO_CHB / 2)[ln];
+            ry[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_y) ry[j] = YT[min(FO_RPC * k + lrow, FO_YROWS - 1)];
         };
-        fetch(own0);
-#pragma unroll 1
-        for (int j = 0; j < ownn; ++j) {
+        fetch(0, own0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
             const int k = own0 + owns * j;
-            if (FO_RPC * k >= bh) break;
-            const float v[4] = {ra.x, ra.y, ra.z, ra.w};
-            const float w[4] = {rb.x, rb.y, rb.z, rb.w};
-            const float4 Y = ry;
-            if (j + 1 < ownn) fetch(k + owns);
+            if (j >= ownn || FO_RPC * k >= bh) break;
+            const float v[4] = {ra[j].x, ra[j].y, ra[j].z, ra[j].w};
+            const float w[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w};
+            const float4 Y = ry[j];
+            if (j + 1 < 3 && j + 1 < ownn) fetch(j + 1, k + owns);
             float bg[4] = {0.f, 0.f, 0.f, 0.f};
             if (has_y) {
                 // bk_xpart of the four pixels, two per packed instruction (k_coadd_fused_dma's sequence)
