@@ -18,7 +18,7 @@ d = json.loads([l for l in open(f'profiles/{tag}_bench.json') if l.startswith('{
 k = {a: round(b['ms_per_step'], 2) for a, b in d['kernels'].items()}
 n = d['nightly']
 row = (f"| {tag}_b (round {int(tag[1:])}, HEAD, the final kernel sources; `profiles/{tag}_*` are this call's; the boxes of this round "
-       f"spread over 6.73 - 6.95 ms) | {d['value']:,.0f} | {d['ms_per_step']:.2f} | coadd leg {d['legs']['coadd_ms']:.2f} ms (fused kernel "
+       f"spread over 6.68 - 6.95 ms) | {d['value']:,.0f} | {d['ms_per_step']:.2f} | coadd leg {d['legs']['coadd_ms']:.2f} ms (fused kernel "
        f"{k['coadd_fused']} ms: {d['roofline']['valu_insts_per_px']:.1f} instructions per pixel and frame, `roofline.frac` {d['roofline']['frac']:.3f}; "
        f"mesh statistics {k['mesh_stats']}; box-OR {k['mask_box']}), subtraction leg {d['legs']['subtract_ms']:.2f} ms (hp_solve {k['hp_solve']} of "
        f"which `k_chol_df` 6 x {d['solve_roofline']['avg_us']:.0f} us; vectors {k['hp_vectors']}, Gram {k['hp_gram']}, apply {k['hp_apply']}, median / MAD "
