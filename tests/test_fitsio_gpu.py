@@ -91,3 +91,135 @@ def test_coadd_from_files_equals_coadd_from_arrays(io, engine, tmp_path):
     torch.cuda.synchronize()
     assert np.array_equal(dc.img.cpu().numpy(), h_img) and np.array_equal(dc.wgt.cpu().numpy(), h_wgt)
     assert np.array_equal(dc.mask.cpu().numpy(), h_msk)
+
+
+# ---- the pipelined form (fitsring.FITSRing): same tensors in, same bytes out as the serial calls above -------------
+@pytest.fixture(scope='module')
+def ring():
+    m = importlib.import_module('zuds-pipeline_amd.fitsring')
+    r = m.FITSRing(0, nreaders=4, nwriters=3, pinned_in=8 << 20, pinned_out=4 << 20)
+    yield r
+    r.close()
+
+
+def test_ring_prefetch_equals_serial_load(io, ring, tmp_path):
+    import torch
+    z = pkg()
+    rng = np.random.default_rng(11)
+    wanted, want = [], []
+    for k in range(23):               # more files than readers and than pinned buffers: the ring turns over
+        kind = ('f32', 'mask', 'i32', 'u8', 'mask')[k % 5]
+        shape = (30 + k, 41 + 2 * k)
+        if kind == 'f32':
+            a = rng.normal(100, 30, shape).astype(np.float32)
+            a[0, 0] = np.nan
+        elif kind == 'u8':
+            a = (rng.uniform(size=shape) < 0.2).astype(np.uint8)
+        elif kind == 'i32':
+            a = rng.integers(-70000, 70000, shape).astype(np.int32)
+        else:                         # 'mask': BITPIX 16 stays int16, BITPIX 32 comes back int32
+            a = rng.integers(0, 3000, shape).astype(np.int16 if k % 2 else np.int32)
+        p = str(tmp_path / f'r{k:02d}.fits')
+        z.fits.write(p, a, {'MAGZP': 26.0 + 0.01 * k, 'OBJECT': f'o{k}'})
+        wanted.append((p, kind))
+        want.append(a)
+    stream = torch.cuda.Stream()
+    t1, t2 = ring.prefetch(wanted), ring.prefetch(wanted[::-1], full_header=[True] * len(wanted))   # two tickets queued
+    for ticket, order in ((t1, range(23)), (t2, range(22, -1, -1))):
+        got = ticket.result(stream)
+        stream.synchronize()
+        for j, (t, hdr) in zip(order, got):
+            a = want[j]
+            ser, shdr = io.load(wanted[j][0], wanted[j][1])
+            assert t.dtype == ser.dtype and np.array_equal(t.cpu().numpy(), ser.cpu().numpy(), equal_nan=True)
+            assert np.array_equal(t.cpu().numpy(), a, equal_nan=True)
+            if wanted[j][1] == 'f32' or ticket is t2:
+                assert hdr == shdr                 # the whole header
+            else:
+                assert hdr['BITPIX'] == shdr['BITPIX'] and hdr['NAXIS1'] == shdr['NAXIS1']
+    assert ring.stats['files_in'] == 46
+
+
+def test_ring_save_writes_the_bytes_of_the_serial_save(io, ring, engine, tmp_path):
+    import torch
+    rng = np.random.default_rng(12)
+    hdr = {'MAGZP': 26.5, 'SEEING': 2.1, 'FILTER': 'ZTF_r', 'FLAG': True}
+    stream = torch.cuda.Stream()
+    engine.set_stream(stream.cuda_stream)
+    futs, pairs = [], []
+    try:
+        for k in range(14):
+            shape = (40 + k, 56 + k)
+            a, bp = ((rng.normal(0, 50, shape).astype(np.float32), None),
+                     (rng.integers(0, 70000, shape).astype(np.int32), None),
+                     (rng.integers(0, 3000, shape).astype(np.int32), 16),
+                     ((rng.uniform(size=shape) < 0.3).astype(np.uint8), None))[k % 4]
+            with torch.cuda.stream(stream):
+                t = torch.from_numpy(a).cuda()
+            p1, p2 = str(tmp_path / f'ring{k}.fits'), str(tmp_path / f'serial{k}.fits')
+            h = dict(hdr, K=k)
+            if k % 2:
+                futs.append(ring.save(p1, t, h, bitpix=bp, engine=engine, stream=stream))   # behind the producer's stream
+                with torch.cuda.stream(stream):
+                    t.zero_()                    # the plane is the producer's again as soon as save returns
+            else:
+                stream.synchronize()
+                futs.append(ring.save(p1, t, h, bitpix=bp))                                  # the ring's own stream
+            h['K'] = -1                          # ... and so is the header dict
+            pairs.append((p1, p2, a, bp, dict(hdr, K=k)))
+        ring.flush()
+        assert all(f.done() for f in futs)
+    finally:
+        engine.set_stream(io.stream.cuda_stream)
+    for p1, p2, a, bp, h in pairs:
+        io.save(p2, torch.from_numpy(a).cuda(), h, bitpix=bp)
+        assert open(p1, 'rb').read() == open(p2, 'rb').read()
+
+
+def test_ring_reports_reader_and_writer_errors(ring, tmp_path):
+    import torch
+    bad = str(tmp_path / 'short.fits')
+    pkg().fits.write(bad, np.zeros((8, 8), np.float32))
+    with open(bad, 'r+b') as f:
+        f.truncate(2880 + 16)
+    with pytest.raises(ValueError, match='truncated'):
+        ring.prefetch([(bad, 'f32')]).result()
+    with pytest.raises(FileNotFoundError):
+        ring.prefetch([(str(tmp_path / 'nope.fits'), 'f32')]).result()
+    ring.save(str(tmp_path / 'no_such_dir' / 'x.fits'), torch.zeros((4, 4), device='cuda'))
+    with pytest.raises(FileNotFoundError):
+        ring.flush()
+    # the ring is still usable afterwards
+    ok = str(tmp_path / 'ok.fits')
+    ring.save(ok, torch.ones((4, 4), device='cuda'))
+    ring.flush()
+    assert ring.prefetch([(ok, 'f32')]).result()[0][0].sum().item() == 16.0
+
+
+def test_coadd_from_ring_equals_coadd_from_serial_files(io, ring, engine, tmp_path):
+    z = pkg()
+    s = synth()
+    import torch
+    dev = importlib.import_module('zuds-pipeline_amd.device')
+    base = s.ztf_wcs(220, 180, tpv=True)
+    sci, wgt, msk = [], [], []
+    for i in range(3):
+        w = s.ztf_wcs(220, 180, dx=1.7 * i, dy=-1.1 * i, rot_deg=0.05 * i, tpv=True)
+        f = s.make_frame(220, 180, 30 + i, w, nstars=12, nbad=40, magzp=25.6 + 0.2 * i)
+        for lst, key, suffix in ((sci, 'img', 'sci'), (wgt, 'wgt', 'weight'), (msk, 'mask', 'mask')):
+            p = str(tmp_path / f'f{i}.{suffix}.fits')
+            z.fits.write(p, f[key] if key != 'mask' else f[key].astype(np.int16), f['header'])
+            lst.append(p)
+    p = z.coadd_params(combine='WEIGHTED', subtract_back=True, rescale_weights=True, back_size=64)
+    a = dev.DeviceCoadd(base, p, device=0, engine=engine, want_mask=True)
+    a.run(io.load_frames(sci, wgt, msk)[0])
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (a.img, a.wgt, a.mask)]
+    ticket = ring.prefetch_frames(sci, wgt, msk, extra=[(sci[0], 'f32')])
+    dfr, frames, extra = ring.frames(ticket, a.stream)
+    assert frames[1]['flxscale'] == pytest.approx(10 ** (-0.4 * (25.8 - 25.0)))
+    a.run(dfr)
+    torch.cuda.synchronize()
+    for w_, g in zip(want, (a.img, a.wgt, a.mask)):
+        assert torch.equal(w_, g)
+    assert torch.equal(extra[0][0], frames[0]['img'])
