@@ -9,7 +9,7 @@ module overlaps the three:
 * ``prefetch(wanted)`` returns at once.  ``nreaders`` threads read the data blocks of the NEXT step's files
   into a ring of pinned buffers (``readinto`` releases the GIL; reads out of the page cache scale with
   threads), a feeder thread sends each block over PCIe on the ring's own high-priority copy stream as soon
-  as it has arrived and decodes it there (an engine of the ring's own: a ``zm_ctx`` is bound to one stream),
+  as it has arrived and decodes it on a second one (an engine of the ring's own: a ``zm_ctx`` is bound to one stream),
   all while the caller's stream computes the CURRENT step.  ``Ticket.result(stream)`` orders the consumer's
   stream behind the last decode with an event - the host waits only for the files, never for the GPU.
 * ``save(path, tensor, ...)`` returns at once as well: the product is encoded into a device buffer of its
@@ -132,14 +132,14 @@ class Ticket(object):
     def __init__(self, n):
         self._fut = Future()
         self.n = n
-        self.arrived = None              # event on the ring's copy stream: the last decode
+        self.arrived = None              # event on the ring's decode stream: the last decode
 
     def result(self, stream=None, timeout=None):
         out = self._fut.result(timeout)
         if stream is not None:
             stream.wait_event(self.arrived)
             for t, _ in out:
-                t.record_stream(stream)          # (allocated on the copy stream, consumed on this one)
+                t.record_stream(stream)          # (allocated on the decode stream, consumed on this one)
         return out
 
     def done(self):
@@ -157,10 +157,11 @@ class FITSRing(object):
         self.nwriters = int(nwriters or min(6, max(2, nthr // 3)))
         # high-priority streams get hardware queues of their own: a copy never waits behind a kernel of the step it
         # is meant to overlap with (bench.py, data_movement_clocks)
-        self.cs = torch.cuda.Stream(self.device, priority=-1)          # H2D + decode
+        self.cs = torch.cuda.Stream(self.device, priority=-1)          # H2D, nothing else: copies back to back
+        self.xs = torch.cuda.Stream(self.device, priority=-1)          # decode, behind each copy's event
         self.ds = torch.cuda.Stream(self.device, priority=-1)          # D2H of encoded products
         self.ceng = Engine(device)
-        self.ceng.set_stream(self.cs.cuda_stream)
+        self.ceng.set_stream(self.xs.cuda_stream)
         self.deng = Engine(device)
         self.deng.set_stream(self.ds.cuda_stream)
         self._readers = ThreadPoolExecutor(self.nreaders, thread_name_prefix='zmfits-r')
@@ -217,25 +218,29 @@ class FITSRing(object):
             try:
                 futs = [self._readers.submit(self._read, p, fl) for (p, _), fl in zip(wanted, full)]
                 out = []
-                with torch.cuda.stream(self.cs):
-                    for (path, kind), fut in zip(wanted, futs):
-                        pin, hdr, info = fut.result()
-                        if kind == 'mask':
-                            kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
-                        dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]
-                        t = torch.empty(info['shape'], dtype=dt, device=self.device)
+                for (path, kind), fut in zip(wanted, futs):
+                    pin, hdr, info = fut.result()
+                    if kind == 'mask':
+                        kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
+                    dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]
+                    with torch.cuda.stream(self.cs):
                         d_raw = pin[:info['nbytes']].to(self.device, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(self.cs)
-                        self._pin_in.put(pin, ev)
+                        ev = self.cs.record_event()
+                    self._pin_in.put(pin, ev)
+                    # (the decode on a stream of its own: on the copy stream each kernel would hold up the next copy -
+                    # 99 copy -> kernel -> copy hand-overs per step, measured 50 GB/s against 56 for the copies alone)
+                    with torch.cuda.stream(self.xs):
+                        self.xs.wait_event(ev)
+                        t = torch.empty(info['shape'], dtype=dt, device=self.device)
                         check(self.ceng.L.zm_fits_decode_dev(self.ceng.ctx, d_raw.data_ptr(), info['bitpix'],
                                                              info['bscale'], info['bzero'], info['count'],
                                                              _KIND[kind], t.data_ptr()), 'zm_fits_decode_dev')
-                        del d_raw                 # (same stream: the allocator may reuse it behind the decode)
-                        out.append((t, hdr))
-                        self.stats['files_in'] += 1
-                        self.stats['bytes_in'] += info['nbytes']
-                    ticket.arrived = self.cs.record_event()
+                        d_raw.record_stream(self.xs)
+                    del d_raw
+                    out.append((t, hdr))
+                    self.stats['files_in'] += 1
+                    self.stats['bytes_in'] += info['nbytes']
+                ticket.arrived = self.xs.record_event()
                 ticket._fut.set_result(out)
             except BaseException as e:            # noqa: handed to whoever asks for the result
                 for fut in futs:
