@@ -73,6 +73,8 @@ def parse():
     ap.add_argument('--nightly-batches', default='1x8,1x16,2x8,2x16,3x8,3x11',
                     help='lanes x batch of the batched pools to time in the concurrent leg (SubtractionPool(J, batch=B): '
                          'the kernel fits of B jobs as one chain of launches); empty: none')
+    ap.add_argument('--nightly-files', default='2x8x16',
+                    help='lanes x fit batch x frames per file batch of the FITS-inclusive nightly clock (scripts/donightly.py)')
     ap.add_argument('--dump-coadd', default=None,
                     help='developer / tests: rank 0 saves the coadd planes [img, wgt] (.npy) after the run')
     ap.add_argument('--emulate-ranks', type=int, default=1,
@@ -1093,7 +1095,87 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
                                if '1' in out['pools'] else None}
     best = max(list(out['pools'].values()) + list(out['batched'].values()), key=lambda v: v['subtract_mpix_s'])
     out['subtract_mpix_s'] = best['subtract_mpix_s']
+    if not args.no_clocks:
+        try:
+            out['with_fits'] = nightly_files_clock(args, z, torch, base, jobs, ref, (ra, dec), npx, local)
+        except Exception as e:                               # noqa: report, do not fail the bench
+            out['with_fits'] = {'error': repr(e)}
     return out
+
+
+def nightly_files_clock(args, z, torch, base, jobs, ref, radec, npx, local):
+    """The same night on the clock a user of scripts/donightly.py lives on: science frames, masks and weight maps as
+    FITS files in, three products + a photometry table per subtraction out, through the driver's own loop
+    (`donightly.run_night`: the ring of fitsring.FITSRing reads batch b + 1 and writes batch b - 1 while the pool
+    subtracts batch b).  One untimed pass (allocations, pinned rings), the products removed, one timed pass."""
+    import importlib.util
+    import shutil
+    import tempfile
+    dev = importlib.import_module('zuds-pipeline_amd.device')
+    ringmod = importlib.import_module('zuds-pipeline_amd.fitsring')
+    nm = importlib.import_module('zuds-pipeline_amd.nightly')
+    spec = importlib.util.spec_from_file_location('donightly', os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                            'scripts', 'donightly.py'))
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)
+    lanes, fitb, batch = (int(v) for v in args.nightly_files.split('x'))
+    d = tempfile.mkdtemp(prefix='zmnight_', dir=os.environ.get('TMPDIR') or None)
+    ring = pool = None
+    try:
+        need = len(jobs) * npx * (4 + 4 + 2 + 12)
+        if shutil.disk_usage(d).free < 1.5 * need:
+            raise OSError(f'not enough free space under {d} for {need / 1e9:.1f} GB of FITS files')
+        ring = ringmod.FITSRing(local)
+        imgs = []
+        for i, job in enumerate(jobs):
+            sc = job.sci
+            hdr = dict(sc['wcs'].to_header(), NAXIS1=args.size, NAXIS2=args.size, MAGZP=26.0, SEEING=float(sc['seeing']),
+                       OBSJD=2458800.5 + 0.25 * i, FIELDID=651, CCDID=3, QID=1, FILTERID=1)
+            fn = os.path.join(d, f'ztf_n{i:03d}_000651_zg_c03_o_q1_sciimg.fits')
+            ring.save(fn, sc['img'], hdr)
+            ring.save(fn.replace('sciimg', 'mskimg'), sc['mask'], hdr, bitpix=16)       # (a ZTF mask file: BITPIX 16)
+            ring.save(fn.replace('.fits', '.weight.fits'), sc['wgt'], hdr)
+            imgs.append(fn)
+        refname = os.path.join(d, 'ref.000651_c03_q1_zg.fits')
+        rh = dict(base.to_header(), NAXIS1=args.size, NAXIS2=args.size, MAGZP=25.0)
+        ring.save(refname, ref['img'], rh)
+        wgt = torch.where(ref['rms'] < 200.0, 1.0 / (ref['rms'] * ref['rms']), torch.zeros_like(ref['rms']))
+        ring.save(refname.replace('.fits', '.weight.fits'), wgt, rh)
+        ring.save(refname.replace('.fits', '.mask.fits'), ref['mask'], rh)
+        ring.flush()
+        io = dev.FITSDeviceIO(local, engine=z.Engine(local))
+        rf = script.load_reference(io, refname)
+        pool = nm.SubtractionPool(lanes, device=local, batch=fitb)
+
+        def night():
+            t0 = time.perf_counter()
+            done = script.run_night(imgs, rf, pool, io, ring, radec, batch=batch, nreg_side=3)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, done
+        import contextlib
+        import io as _io
+        with contextlib.redirect_stdout(_io.StringIO()) as log:
+            _, done = night()
+            for out in done:
+                for sfx in ('.fits', '.rms.fits', '.mask.fits', '.phot.txt'):
+                    os.remove(out.replace('.fits', sfx))
+            dt, done = night()
+        bytes_in = sum(os.path.getsize(p) for fn in imgs for p, _ in script.science_files(fn))
+        bytes_out = sum(os.path.getsize(out.replace('.fits', sfx)) for out in done for sfx in ('.fits', '.rms.fits', '.mask.fits'))
+        return {'ms_per_subtraction': 1e3 * dt / max(len(done), 1), 'subtract_mpix_s': len(done) * npx / 1e6 / dt,
+                'subtractions': len(done), 'of': len(imgs), 'lanes_x_fitbatch_x_filebatch': args.nightly_files,
+                'files_in_per_subtraction': 3, 'files_out_per_subtraction': 4, 'bytes_in': bytes_in, 'bytes_out': bytes_out,
+                'in_GBs': bytes_in / dt / 1e9, 'out_GBs': bytes_out / dt / 1e9,
+                'readers': ring.nreaders, 'writers': ring.nwriters, 'page_cache': 'warm',
+                'driver': 'scripts/donightly.py run_night: reads of batch b + 1 and writes of batch b - 1 under the '
+                          'subtractions of batch b',
+                'log_tail': log.getvalue().strip().splitlines()[-2:]}
+    finally:
+        if pool is not None:
+            pool.close()
+        if ring is not None:
+            ring.close()
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_step=None):

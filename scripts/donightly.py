@@ -53,29 +53,43 @@ def load_reference(io, refname):
                 flxscale=float(hdr.get('FLXSCALE', 1.0)), header=hdr, path=refname)
 
 
-def load_science(io, fn):
+def science_files(fn):
+    """The three files of a science frame, as the ring / the device loader take them."""
+    return [(fn, 'f32'), (fn.replace('sciimg', 'mskimg'), 'i32'), (fn.replace('.fits', '.weight.fits'), 'f32')]
+
+
+def finish_science(io, fn, img, hdr, mask, wgt):
+    """Behind the loads, on ``io.stream`` (not waited for): rms = 1 / sqrt(w), BIG_RMS where the mask is bad or the
+    pixel saturated (zuds/image.py:173-208)."""
     import torch
-    img, hdr = io.load(fn, 'f32')
-    mask, _ = io.load(fn.replace('sciimg', 'mskimg'), 'i32')
-    wgt, _ = io.load(fn.replace('.fits', '.weight.fits'), 'f32')
+    if 'SEEING' not in hdr:
+        raise RuntimeError(f'{fn}: no SEEING card (run estimate_seeing on the frame first)')
     eng = io.engine
-    rms = torch.empty_like(img)
-    bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
+    eng.set_stream(io.stream.cuda_stream)
     with torch.cuda.stream(io.stream):
+        rms = torch.empty_like(img)
+        bad = torch.empty(mask.shape, dtype=torch.uint8, device=mask.device)
         zuds._lib.check(eng.L.zm_mask_bad_dev(eng.ctx, mask.data_ptr(), None, zuds.BAD_SUM, mask.numel(),
                                               None, bad.data_ptr()))
         zuds._lib.check(eng.L.zm_rms_from_weight_dev(eng.ctx, wgt.data_ptr(), bad.data_ptr(), wgt.numel(),
                                                      float(zuds.BIG_RMS), rms.data_ptr()))
         if 'SATURATE' in hdr:         # zuds/image.py:203-204
             rms = torch.where(img >= 0.9 * float(hdr['SATURATE']), torch.full_like(rms, float(zuds.BIG_RMS)), rms)
-    io.stream.synchronize()
-    if 'SEEING' not in hdr:
-        raise RuntimeError(f'{fn}: no SEEING card (run estimate_seeing on the frame first)')
     return dict(img=img, rms=rms, mask=mask, wgt=wgt, wcs=zuds.WCS.from_header(hdr),
                 seeing=float(hdr['SEEING']), header=hdr, path=fn)
 
 
+def load_science(io, fn):
+    """One frame, serially (the ring of ``run_night`` loads a batch ahead instead)."""
+    (img, hdr), (mask, _), (wgt, _) = (io.load(p, k) for p, k in science_files(fn))
+    sci = finish_science(io, fn, img, hdr, mask, wgt)
+    io.stream.synchronize()
+    return sci
+
+
 def write_products(io, sci, ref, res):
+    """``io``: anything with ``save(path, tensor, header)`` - the ring (files written behind the caller's back,
+    ``flush`` waits for them) or a ``FITSDeviceIO`` (each file written before the call returns)."""
     out = zuds.sub_name(sci['path'], ref['path'])
     hdr = dict(sci['header'])
     hdr.update(zuds.hotpants.info_cards(res['info']))    # KSUM00, NSTAMPS, ZMSTATUS, ZMUNSOLV, ZMRETRY
@@ -128,41 +142,72 @@ def main(argv=None):
     io = device.FITSDeviceIO(local, engine=zuds.Engine(local))
     ref = load_reference(io, args.refname)
     pool = nightly.SubtractionPool(args.jobs, device=local, batch=args.fit_batch)
-    done = []
+    ring = importlib.import_module('zuds-pipeline_amd.fitsring').FITSRing(local)
     try:
-        for b0 in range(0, len(imgs), args.batch):
-            t0 = time.time()
-            scis, jobs = [], []
-            for fn in imgs[b0:b0 + args.batch]:
-                if os.path.exists(zuds.sub_name(fn, args.refname)):
-                    print(f'{os.path.basename(fn)}: subtraction exists, skipping', flush=True)
-                    continue
-                try:
-                    sci = load_science(io, fn)
-                except Exception:
-                    traceback.print_exception(*sys.exc_info())
-                    continue
-                sci['radec'] = radec
-                scis.append(sci)
-                jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=args.nreg_side, tag=fn))
-            results = pool.map(jobs)
-            for sci, res in zip(scis, results):
-                if 'error' in res:
-                    # the job raised (the reference's drivers: try / except per image,
-                    # scripts/dosub.py:205-213): no products, the night goes on
-                    print(f'{os.path.basename(sci["path"])}: subtraction failed: {res["error"]}', flush=True)
-                    continue
-                if res['info']['status'] != 0:
-                    # some regions of the fit have no solution: their pixels carry the fill value and
-                    # bit 17; the products are written with ZMSTATUS / ZMUNSOLV in their headers
-                    print(f'{os.path.basename(sci["path"])}: {res["info"]["nunsolved"]} region(s) of the '
-                          f'kernel fit unsolved (status {res["info"]["status"]}, '
-                          f'{res["info"]["nstamps_used"]} stamps)', flush=True)
-                done.append(write_products(io, sci, ref, res))
-            if jobs:
-                print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)
+        return run_night(imgs, ref, pool, io, ring, radec, batch=args.batch, nreg_side=args.nreg_side)
     finally:
         pool.close()
+        ring.close()
+
+
+def run_night(imgs, ref, pool, io, ring, radec=None, batch=36, nreg_side=3):
+    """The images of this rank against one reference.  The files of batch b + 1 are read, sent and decoded by the
+    ring (fitsring.FITSRing: reader threads, copy stream) while the pool subtracts batch b; the products of batch b
+    are encoded on the device, copied back on a third stream and written by the ring's writer threads while
+    batch b + 1 runs.  Returns the paths of the difference images, in order."""
+    nightly = importlib.import_module('zuds-pipeline_amd.nightly')
+    refname = ref['path']
+    chunks = [imgs[b0:b0 + batch] for b0 in range(0, len(imgs), batch)]
+
+    def ask(b):
+        todo = []
+        for fn in chunks[b]:
+            if os.path.exists(zuds.sub_name(fn, refname)):
+                print(f'{os.path.basename(fn)}: subtraction exists, skipping', flush=True)
+            else:
+                todo.append(fn)
+        wanted = [w for fn in todo for w in science_files(fn)]
+        return todo, (ring.prefetch(wanted, [k == 'f32' and i % 3 == 0 for i, (_, k) in enumerate(wanted)],
+                                    return_exceptions=True) if wanted else None)
+    done = []
+    nxt = ask(0) if chunks else None
+    for b in range(len(chunks)):
+        t0 = time.time()
+        (todo, ticket), nxt = nxt, (ask(b + 1) if b + 1 < len(chunks) else None)
+        loaded = ticket.result(io.stream) if ticket is not None else []
+        scis, jobs = [], []
+        for k, fn in enumerate(todo):
+            trio = loaded[3 * k:3 * k + 3]
+            try:
+                for item in trio:
+                    if isinstance(item, BaseException):
+                        raise item
+                (img, hdr), (mask, _), (wgt, _) = trio
+                sci = finish_science(io, fn, img, hdr, mask, wgt)
+            except Exception:
+                # (the reference's drivers: try / except per image, scripts/dosub.py:205-213)
+                traceback.print_exception(*sys.exc_info())
+                continue
+            sci['radec'] = radec
+            scis.append(sci)
+            jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=nreg_side, tag=fn))
+        io.stream.synchronize()                  # (the rms maps; the pool's lanes read them on their own streams)
+        results = pool.map(jobs, sync=False)
+        for sci, res in zip(scis, results):
+            if 'error' in res:
+                # the job raised: no products, the night goes on
+                print(f'{os.path.basename(sci["path"])}: subtraction failed: {res["error"]}', flush=True)
+                continue
+            if res['info']['status'] != 0:
+                # some regions of the fit have no solution: their pixels carry the fill value and
+                # bit 17; the products are written with ZMSTATUS / ZMUNSOLV in their headers
+                print(f'{os.path.basename(sci["path"])}: {res["info"]["nunsolved"]} region(s) of the '
+                      f'kernel fit unsolved (status {res["info"]["status"]}, '
+                      f'{res["info"]["nstamps_used"]} stamps)', flush=True)
+            done.append(write_products(ring, sci, ref, res))
+        if jobs:
+            print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)
+    ring.flush()                                 # every product is on disk when this returns
     return done
 
 

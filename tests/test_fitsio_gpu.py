@@ -223,3 +223,18 @@ def test_coadd_from_ring_equals_coadd_from_serial_files(io, ring, engine, tmp_pa
     for w_, g in zip(want, (a.img, a.wgt, a.mask)):
         assert torch.equal(w_, g)
     assert torch.equal(extra[0][0], frames[0]['img'])
+
+
+def test_save_async_of_the_device_io_equals_save(io, tmp_path):
+    import torch
+    rng = np.random.default_rng(13)
+    a = rng.normal(0, 50, (64, 80)).astype(np.float32)
+    t = torch.from_numpy(a).cuda()
+    p1, p2 = str(tmp_path / 'a.fits'), str(tmp_path / 'b.fits')
+    fut = io.save_async(p1, t, {'MAGZP': 26.0})
+    t.zero_()
+    io.flush()
+    assert fut.result() == p1
+    io.save(p2, torch.from_numpy(a).cuda(), {'MAGZP': 26.0})
+    assert open(p1, 'rb').read() == open(p2, 'rb').read()
+    io.close()

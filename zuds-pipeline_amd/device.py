@@ -423,6 +423,32 @@ class FITSDeviceIO(object):
         self.stream.synchronize()
         fits.write_raw(path, pin[:nbytes].numpy(), tuple(t.shape), bp, header, comments)
 
+    @property
+    def ring(self):
+        """The pipelined form of this object (``fitsring.FITSRing``: reader / writer threads, copy and return
+        streams of its own), created on first use."""
+        if getattr(self, '_ring', None) is None:
+            from .fitsring import FITSRing
+            self._ring = FITSRing(self.device.index)
+        return self._ring
+
+    def save_async(self, path, tensor, header=None, comments=None, bitpix=None):
+        """``save`` without the wait: the plane is encoded behind the kernels already on this object's stream and may
+        be overwritten as soon as the call returns; copy-back and write happen on the ring's stream and threads.
+        Returns a Future of the path; ``flush()`` waits for all of them.  Same bytes as ``save``."""
+        self.engine.set_stream(self.stream.cuda_stream)
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return self.ring.save(path, tensor, header, comments, bitpix, engine=self.engine, stream=self.stream)
+
+    def flush(self):
+        if getattr(self, '_ring', None) is not None:
+            self._ring.flush()
+
+    def close(self):
+        if getattr(self, '_ring', None) is not None:
+            self._ring.close()
+            self._ring = None
+
     def load_many(self, wanted, nreaders=4):
         """[(path, kind), ...] -> [(tensor, header), ...] in order.  The files are read by `nreaders`
         threads into a pool of pinned buffers (reads from the page cache scale with threads: one reader moves

@@ -154,7 +154,7 @@ class FITSRing(object):
         self.device = torch.device('cuda', device)
         nthr = _default_threads()
         self.nreaders = int(nreaders or min(12, max(4, nthr - 4)))
-        self.nwriters = int(nwriters or min(6, max(2, nthr // 3)))
+        self.nwriters = int(nwriters or min(12, max(2, nthr // 3)))
         # high-priority streams get hardware queues of their own: a copy never waits behind a kernel of the step it
         # is meant to overlap with (bench.py, data_movement_clocks)
         self.cs = torch.cuda.Stream(self.device, priority=-1)          # H2D, nothing else: copies back to back
@@ -176,15 +176,17 @@ class FITSRing(object):
         self.stats = dict(files_in=0, bytes_in=0, files_out=0, bytes_out=0)
 
     # -- in ---------------------------------------------------------------------------------
-    def prefetch(self, wanted, full_header=None):
+    def prefetch(self, wanted, full_header=None, return_exceptions=False):
         """``wanted``: [(path, kind), ...] with kind 'f32', 'i32', 'u8', 'i16' or 'mask' ('i16' for a BITPIX 16
         file without scaling - a ZTF mask as its file holds it - else 'i32').  ``full_header``: per file, whether
-        the whole header is parsed (default: only for 'f32' planes; the others return the array's own cards)."""
+        the whole header is parsed (default: only for 'f32' planes; the others return the array's own cards).
+        ``return_exceptions``: a file that cannot be read puts its exception in its place of the result instead of
+        failing the ticket (a night goes on without the frame, ``scripts/dosub.py:205-213``)."""
         wanted = list(wanted)
         if full_header is None:
             full_header = [k == 'f32' for _, k in wanted]
         t = Ticket(len(wanted))
-        self._tickets.put((t, wanted, list(full_header)))
+        self._tickets.put((t, wanted, list(full_header), bool(return_exceptions)))
         return t
 
     def _read(self, path, full):
@@ -213,13 +215,19 @@ class FITSRing(object):
             item = self._tickets.get()
             if item is None:
                 return
-            ticket, wanted, full = item
+            ticket, wanted, full, tolerant = item
             futs = []
             try:
                 futs = [self._readers.submit(self._read, p, fl) for (p, _), fl in zip(wanted, full)]
                 out = []
                 for (path, kind), fut in zip(wanted, futs):
-                    pin, hdr, info = fut.result()
+                    try:
+                        pin, hdr, info = fut.result()
+                    except Exception as e:        # noqa
+                        if not tolerant:
+                            raise
+                        out.append(e)
+                        continue
                     if kind == 'mask':
                         kind = 'i16' if (info['bitpix'] == 16 and info['bscale'] == 1.0 and info['bzero'] == 0.0) else 'i32'
                     dt = {'f32': torch.float32, 'i32': torch.int32, 'u8': torch.uint8, 'i16': torch.int16}[kind]

@@ -301,11 +301,14 @@ class SubtractionPool(object):
                     outs.append(dict(tag=job.tag, error=str(exc)))
             return outs
 
-    def map(self, jobs, keep=True):
+    def map(self, jobs, keep=True, sync=True):
         """Run every job; results in job order.  ``keep``: clone diff / noise / mask of each job
-        out of the worker's planes (off for throughput runs that only want the photometry)."""
+        out of the worker's planes (off for throughput runs that only want the photometry).  ``sync=False``: the
+        caller has already waited for the streams that produced the inputs (scripts/donightly.py: a device-wide
+        wait here would also wait for the NEXT batch's copies on the ring's stream)."""
         import torch
-        torch.cuda.synchronize(self.device)               # inputs produced on other streams are complete
+        if sync:
+            torch.cuda.synchronize(self.device)           # inputs produced on other streams are complete
         jobs = list(jobs)
         if not self.batch:
             return list(self._pool.map(lambda j: self._run(j, keep), jobs))
