@@ -169,30 +169,12 @@ def run_night(imgs, ref, pool, io, ring, radec=None, batch=36, nreg_side=3):
         wanted = [w for fn in todo for w in science_files(fn)]
         return todo, (ring.prefetch(wanted, [k == 'f32' and i % 3 == 0 for i, (_, k) in enumerate(wanted)],
                                     return_exceptions=True) if wanted else None)
-    done = []
-    nxt = ask(0) if chunks else None
-    for b in range(len(chunks)):
-        t0 = time.time()
-        (todo, ticket), nxt = nxt, (ask(b + 1) if b + 1 < len(chunks) else None)
-        loaded = ticket.result(io.stream) if ticket is not None else []
-        scis, jobs = [], []
-        for k, fn in enumerate(todo):
-            trio = loaded[3 * k:3 * k + 3]
-            try:
-                for item in trio:
-                    if isinstance(item, BaseException):
-                        raise item
-                (img, hdr), (mask, _), (wgt, _) = trio
-                sci = finish_science(io, fn, img, hdr, mask, wgt)
-            except Exception:
-                # (the reference's drivers: try / except per image, scripts/dosub.py:205-213)
-                traceback.print_exception(*sys.exc_info())
-                continue
-            sci['radec'] = radec
-            scis.append(sci)
-            jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=nreg_side, tag=fn))
-        io.stream.synchronize()                  # (the rms maps; the pool's lanes read them on their own streams)
-        results = pool.map(jobs, sync=False)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def finish(scis, results):
+        # headers, photometry tables and the hand-over of the planes to the ring: host work of ~3 ms per image, done
+        # on a thread of its own while the pool is at the next batch
+        out = []
         for sci, res in zip(scis, results):
             if 'error' in res:
                 # the job raised: no products, the night goes on
@@ -204,9 +186,40 @@ def run_night(imgs, ref, pool, io, ring, radec=None, batch=36, nreg_side=3):
                 print(f'{os.path.basename(sci["path"])}: {res["info"]["nunsolved"]} region(s) of the '
                       f'kernel fit unsolved (status {res["info"]["status"]}, '
                       f'{res["info"]["nstamps_used"]} stamps)', flush=True)
-            done.append(write_products(ring, sci, ref, res))
-        if jobs:
-            print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)
+            out.append(write_products(ring, sci, ref, res))
+        return out
+    finisher = ThreadPoolExecutor(1, thread_name_prefix='zmnight-fin')
+    pending = []
+    try:
+        nxt = ask(0) if chunks else None
+        for b in range(len(chunks)):
+            t0 = time.time()
+            (todo, ticket), nxt = nxt, (ask(b + 1) if b + 1 < len(chunks) else None)
+            loaded = ticket.result(io.stream) if ticket is not None else []
+            scis, jobs = [], []
+            for k, fn in enumerate(todo):
+                trio = loaded[3 * k:3 * k + 3]
+                try:
+                    for item in trio:
+                        if isinstance(item, BaseException):
+                            raise item
+                    (img, hdr), (mask, _), (wgt, _) = trio
+                    sci = finish_science(io, fn, img, hdr, mask, wgt)
+                except Exception:
+                    # (the reference's drivers: try / except per image, scripts/dosub.py:205-213)
+                    traceback.print_exception(*sys.exc_info())
+                    continue
+                sci['radec'] = radec
+                scis.append(sci)
+                jobs.append(nightly.SubtractionJob(sci, ref, radec=radec, nreg_side=nreg_side, tag=fn))
+            io.stream.synchronize()              # (the rms maps; the pool's lanes read them on their own streams)
+            results = pool.map(jobs, sync=False)
+            pending.append(finisher.submit(finish, scis, results))
+            if jobs:
+                print(f'took {time.time() - t0:.2f} sec to make {len(jobs)} subtractions', flush=True)
+        done = [out for f in pending for out in f.result()]
+    finally:
+        finisher.shutdown(wait=True)
     ring.flush()                                 # every product is on disk when this returns
     return done
 
