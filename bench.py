@@ -1177,7 +1177,7 @@ def nightly_files_clock(args, z, torch, base, jobs, ref, radec, npx, local):
                 'readers': ring.nreaders, 'writers': ring.nwriters, 'page_cache': 'warm',
                 'driver': 'scripts/donightly.py run_night: reads of batch b + 1 and writes of batch b - 1 under the '
                           'subtractions of batch b',
-                'log_tail': log.getvalue().strip().splitlines()[-2:]}
+                'log_tail': log.getvalue().strip().splitlines()[-(14 if os.environ.get('ZM_NIGHT_TRACE') else 2):]}
     finally:
         if pool is not None:
             pool.close()
