@@ -31,8 +31,8 @@ def main():
             wanted.append((p, 'mask' if i % 3 == 2 else 'f32'))
         nbytes = sum(os.path.getsize(p) for p, _ in wanted)
         print(f'{nfiles} files, {nbytes / 1e9:.2f} GB, cores {len(os.sched_getaffinity(0))}', flush=True)
-        for nr in (4, 8, 12, 16, 24, 32):
-            for pinned in (3 << 29, 3 << 30):
+        for nr in (8, 12, 16):
+            for pinned in (3 << 29,):
                 ring = ringmod.FITSRing(0, nreaders=nr, nwriters=2, pinned_in=pinned)
                 ring.prefetch(wanted).result()
                 torch.cuda.synchronize()
@@ -52,19 +52,24 @@ def main():
                 print(f'readers {nr:2d} pinned {pinned / 2**30:.1f} GiB: reads alone {nbytes / t_read / 1e9:6.1f} GB/s, '
                       f'read + H2D + decode {nbytes / t_all / 1e9:6.1f} GB/s ({1e3 * t_all:.1f} ms)', flush=True)
                 ring.close()
+        nprod = int(os.environ.get('ZM_PROBE_PRODUCTS', '48'))
         prods = [torch.randn((size, size), device='cuda') for _ in range(6)]
-        for nw in (2, 4, 6, 8, 12):
+        for nw in (2, 3, 4, 5, 6, 8, 4, 6):
             ring = ringmod.FITSRing(0, nreaders=2, nwriters=nw)
-            for k, t in enumerate(prods):
-                ring.save(os.path.join(d, f'o{k}.fits'), t)
+            for k in range(nprod):
+                ring.save(os.path.join(d, f'o{k}.fits'), prods[k % 6])
             ring.flush()
+            for k in range(nprod):
+                os.remove(os.path.join(d, f'o{k}.fits'))
             t0 = time.perf_counter()
-            for rep in range(3):
-                for k, t in enumerate(prods):
-                    ring.save(os.path.join(d, f'o{k}.fits'), t)
-                ring.flush()
-            dt = (time.perf_counter() - t0) / 3
-            print(f'writers {nw:2d}: 6 products ({6 * size * size * 4 / 1e6:.0f} MB) in {1e3 * dt:.1f} ms', flush=True)
+            for k in range(nprod):
+                ring.save(os.path.join(d, f'o{k}.fits'), prods[k % 6])
+            ring.flush()
+            dt = time.perf_counter() - t0
+            for k in range(nprod):
+                os.remove(os.path.join(d, f'o{k}.fits'))
+            print(f'writers {nw:2d}: {nprod} new files ({nprod * size * size * 4 / 1e9:.2f} GB) in {1e3 * dt:.1f} ms = '
+                  f'{nprod * size * size * 4 / dt / 1e9:.1f} GB/s', flush=True)
             ring.close()
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -154,7 +154,8 @@ class FITSRing(object):
         self.device = torch.device('cuda', device)
         nthr = _default_threads()
         self.nreaders = int(nreaders or min(12, max(4, nthr - 4)))
-        self.nwriters = int(nwriters or min(32, max(2, nthr // 3)))     # (writes into the page cache: ~1.8 GB/s per thread)
+        self.nwriters = int(nwriters or min(6, max(2, nthr // 3)))      # (5 - 8 writers keep up with the D2H copies; more of
+        #  them contend in the page cache: 48 new 38 MB files at 42 GB/s with 8 threads, 20 GB/s with 32 - tools/ring_probe.py)
         # high-priority streams get hardware queues of their own: a copy never waits behind a kernel of the step it
         # is meant to overlap with (bench.py, data_movement_clocks)
         self.cs = torch.cuda.Stream(self.device, priority=-1)          # H2D, nothing else: copies back to back
