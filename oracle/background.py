@@ -249,3 +249,20 @@ def background(img, wgt=None, mesh=128, fsize=3):
     bkg = expand(bo, nx, ny, mesh)
     rms = expand(so, nx, ny, mesh)
     return bkg, rms, fqmedian(bo.ravel()), fqmedian(so.ravel()), bo, so
+
+
+def quick_background_estimate(data, mask):
+    """Restatement of ``zuds/utils.py:32-53`` without ``nsamp``: (median, 1.4826 * MAD) of the pixels whose mask is
+    0, in the reference's arithmetic - the median and the absolute deviations stay in the image's dtype (float32
+    for every frame on this path), the factor multiplies a float32 scalar as a float64 (numpy 1.x, which the
+    reference ran on).  PINNED: tests/golden/reference_python.json holds the outputs of the reference's own
+    function on 18 arrays (tests/golden/make_reference_python_golden.py); tests/test_golden.py compares bit for
+    bit.  An all-masked frame gives (nan, nan), as there."""
+    pix = np.asarray(data)[np.asarray(mask) == 0]
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            bkg = np.median(pix)
+            mad = np.median(np.abs(pix - bkg))
+    return bkg, 1.4826 * float(mad)

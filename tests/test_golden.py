@@ -232,3 +232,111 @@ def test_footprint_rule_per_axis_delta_kernels_keep_their_border():
         np.testing.assert_allclose(b[0], a[0], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
         assert np.array_equal(b[2], a[2])
+
+
+# ---- fixtures generated by the reference's own Python (tests/golden/make_reference_python_golden.py) -----------------
+# zuds/utils.py, zuds/mpi.py and zuds/constants.py of /root/reference, imported under /opt/conda's python 3.9 in the
+# build container; the JSON travels, the reference does not.
+def _refpy():
+    with open(os.path.join(GOLD, 'reference_python.json')) as f:
+        return json.load(f)
+
+
+def _f32(hexstr, shape=None):
+    a = np.frombuffer(bytes.fromhex(hexstr), dtype='<f4')
+    return a.reshape(shape) if shape else a
+
+
+def _i32(hexstr, shape=None):
+    a = np.frombuffer(bytes.fromhex(hexstr), dtype='<i4')
+    return a.reshape(shape) if shape else a
+
+
+def test_constants_equal_the_reference_modules_values():
+    """zuds/constants.py:3-46 as the reference's interpreter holds them."""
+    z = pkg()
+    c = _refpy()['constants']
+    k = z.constants
+    assert float(k.BIG_RMS) == c['BIG_RMS'] and k.BKG_BOX_SIZE == c['BKG_BOX_SIZE'] and k.MJD_TO_JD == c['MJD_TO_JD']
+    assert k.APER_KEY == c['APER_KEY'] and float(k.APERTURE_RADIUS) == c['APERTURE_RADIUS_PIX'] and c['APERTURE_RADIUS_UNIT'] == 'pix'
+    assert k.GROUP_PROPERTIES == c['GROUP_PROPERTIES'] and k.NTHREADS_PER_NODE == c['NTHREADS_PER_NODE']
+    assert k.MASK_BORDER == c['MASK_BORDER'] and k.BKG_VAL == c['BKG_VAL']
+    assert k.MASK_BITS == c['MASK_BITS'] and [int(v) for v in k.BAD_BITS] == c['BAD_BITS']
+    assert k.BAD_SUM == c['BAD_SUM'] == 198589
+    assert k.MASK_COMMENTS == c['MASK_COMMENTS'] and k.REFERENCE_VERSION == c['REFERENCE_VERSION']
+    assert z.utils.fid_map == {int(a): b for a, b in _refpy()['fid_map'].items()}
+
+
+def test_split_equals_the_reference_lambda():
+    """zuds/utils.py:63-65."""
+    z = pkg()
+    for case in _refpy()['split']:
+        got = z.utils._split(list(range(case['items'])), case['n'])
+        assert [list(p) for p in got] == case['pieces'], case
+
+
+def test_get_time_equals_the_reference():
+    """zuds/utils.py:11-25 (astropy.time behind it there, datetime arithmetic here)."""
+    z = pkg()
+    doc = _refpy()['get_time']
+
+    class Im(object):
+        basename = 'nokeys.fits'
+
+        def __init__(self, header):
+            self.header = header
+    for case in doc['cases']:
+        im = Im(case['header'])
+        assert z.get_time(im, 'mjd') == pytest.approx(case['mjd'], rel=0, abs=2e-9), case       # 0.2 ms of a day's fraction
+        assert z.get_time(im, 'jd') == pytest.approx(case['jd'], rel=0, abs=2e-9), case
+    with pytest.raises(ValueError) as e:
+        z.get_time(Im({'EXPTIME': 30.0}), 'mjd')
+    assert doc['no_keys']['raises'] == 'ValueError' and str(e.value) == doc['no_keys']['message']
+
+
+def test_job_sharding_equals_the_reference(tmp_path, monkeypatch):
+    """zuds/mpi.py:36-64: the fall-back is the reference's own output; the sharded branch is numpy's array_split in
+    the reference's order (Slurm array task, then rank) over what the reference's reader returned."""
+    z = pkg()
+    for k in ('RANK', 'WORLD_SIZE', 'SLURM_ARRAY_JOB_ID', 'SLURM_ARRAY_TASK_ID', 'SLURM_ARRAY_TASK_MAX'):
+        monkeypatch.delenv(k, raising=False)
+    for rec in _refpy()['get_my_share_of_work']:
+        names = rec['names']
+        path = tmp_path / f'jobs{rec["njobs"]}.txt'
+        path.write_text('\n'.join(names) + '\n')
+        whole = z.get_my_share_of_work(str(path))
+        assert [str(v) for v in whole] == [names[i] for i in rec['reference_fallback']]
+        assert whole.dtype.kind == rec['reader_dtype_kind']
+        for sp in rec['splits']:
+            ntasks, size = sp['array_tasks'], sp['world_size']
+            for task, shares in enumerate(sp['array_split']):
+                for rank, want in enumerate(shares):
+                    with monkeypatch.context() as m:
+                        m.setenv('RANK', str(rank))
+                        m.setenv('WORLD_SIZE', str(size))
+                        if ntasks is not None:
+                            m.setenv('SLURM_ARRAY_JOB_ID', '77')
+                            m.setenv('SLURM_ARRAY_TASK_ID', str(task))
+                            m.setenv('SLURM_ARRAY_TASK_MAX', str(ntasks - 1))
+                        got = z.get_my_share_of_work(str(path))
+                    assert [str(v) for v in got] == [names[i] for i in want], (rec['njobs'], ntasks, size, task, rank)
+
+
+def test_oracle_background_estimate_equals_the_reference_bit_for_bit():
+    """oracle/background.py quick_background_estimate against zuds/utils.py:32-53 run by the reference's interpreter."""
+    from oracle import background as ob
+    doc = _refpy()['quick_background_estimate']
+    assert len(doc['cases']) >= 18
+    for c in doc['cases']:
+        shape = tuple(c['shape'])
+        bkg, std = ob.quick_background_estimate(_f32(c['data_f32_hex'], shape), _i32(c['mask_i32_hex'], shape))
+        assert np.asarray(bkg).dtype == np.dtype(c['bkg_dtype'])
+        assert float(bkg) == c['bkg'] and float(std) == c['std'], c['name']
+        assert np.float32(bkg).tobytes().hex() == c['bkg_f32_hex']
+    e = doc['explicit_mask_image']
+    bkg, std = ob.quick_background_estimate(_f32(e['data_f32_hex'], (10, 10)), _i32(e['mask_image_i32_hex'], (10, 10)))
+    assert float(bkg) == e['bkg'] and float(std) == e['std']
+    am = doc['all_masked']
+    assert am['raised'] is None and am['bkg_is_nan'] and am['std_is_nan']
+    bkg, std = ob.quick_background_estimate(np.ones((4, 4), np.float32), np.ones((4, 4), np.int32))
+    assert np.isnan(bkg) and np.isnan(std)
