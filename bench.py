@@ -1315,6 +1315,19 @@ def object_api_clock(z, d, files, sci_paths, args, nref=8):
                     os.remove(sub.local_path.replace('.fits', sfx))
             res[route] = {'reference_from_images_ms': 1e3 * min(tc), 'subtraction_from_images_ms': 1e3 * min(ts),
                           'coadd_mpix_s': nref * args.size ** 2 / 1e6 / min(tc), 'subtract_mpix_s': args.size ** 2 / 1e6 / min(ts)}
+            # a science frame without a SEEING card (zuds/hotpants.py:38-44 measures it and goes on): round 6 keeps it on
+            # the device route (stars and moments on the planes in HBM); the host route measures on host arrays
+            tn = []
+            for rep in range(2):
+                sci = objects([sci_paths[0]], [sci_paths[1]], [sci_paths[2]])[0]
+                sci.header.pop('SEEING', None)
+                t2 = time.perf_counter()
+                sub = z.SingleEpochSubtraction.from_images(sci, ref, tmpdir=d)
+                tn.append(time.perf_counter() - t2)
+                for sfx in ('.fits', '.rms.fits', '.mask.fits'):
+                    os.remove(sub.local_path.replace('.fits', sfx))
+            res[route]['subtraction_without_seeing_card_ms'] = 1e3 * min(tn)
+            res[route]['measured_seeing_px'] = float(sub.header['SEEING'])
             if route == 'device':
                 # ... and COLD: the frames as ZTF delivers them - science image + mask, no
                 # .weight.fits / .rms.fits.  from_images asks every frame for its weight map (zuds/swarp.py:43-51),

@@ -89,7 +89,11 @@ def test_coadd_from_images_device_route_equals_host_route(tmp_path, engine, kws)
     assert not np.array_equal(z.fits.read(mixed['device'].local_path)[0], z.fits.read(outs['device'].local_path)[0])
 
 
-def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine):
+@pytest.mark.parametrize('seeing_card', [True, False])
+def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine, seeing_card):
+    """``seeing_card=False``: the science frames carry no SEEING (zuds/hotpants.py:38-44 measures it and goes on):
+    round 6 keeps such a frame on the device route - the same measured value, the same cards, the same files as the
+    host route, and nothing written to the caller's object or file."""
     z, s = pkg(), synth()
     d = str(tmp_path)
     refims, rpaths = _scene(z, s, d, 640, 600, 3, 5300, '201912', fwhm=2.0)
@@ -97,7 +101,7 @@ def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine
     refname = os.path.join(d, 'ref.000651_c03_q1_zg.fits')
     route('device', lambda: z.ReferenceImage.from_images(reopen(z, rpaths), refname, sci_swarp_kws={'COMBINE_TYPE': 'WEIGHTED'}))
     sims, spaths = _scene(z, s, d, 640, 600, 2, 5400, '202003', fwhm=2.6,
-                          extra=lambda i: {'SEEING': 2.6, 'SATURATE': 40000.0})
+                          extra=lambda i: {'SEEING': 2.6, 'SATURATE': 40000.0} if seeing_card else {'SATURATE': 40000.0})
     with_weights(z, sims)
     for p in spaths:
         res = {}
@@ -107,8 +111,10 @@ def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine
             ref = z.ReferenceImage.from_file(refname, load_others=False)
             ref.mask_image = z.MaskImage.from_file(refname.replace('.fits', '.mask.fits'))
             ref._weightimg = z.FITSImage.from_file(refname.replace('.fits', '.weight.fits'))
+            before = open(p, 'rb').read()
             sub = route(name, lambda: z.SingleEpochSubtraction.from_images(sci, ref, nreg_side=1, tmpdir=d))
             res[name] = sub
+            assert ('SEEING' in sci.header) == seeing_card and open(p, 'rb').read() == before   # the caller's frame is untouched
             for sfx in ('.fits', '.rms.fits', '.mask.fits'):
                 os.replace(sub.local_path.replace('.fits', sfx), sub.local_path.replace('.fits', f'.{name}{sfx}'))
             for f in os.listdir(d):                  # (the host route leaves rms siblings of its inputs behind)
@@ -120,7 +126,12 @@ def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine
         h, v = res['host'], res['device']
         assert list(h.header.items()) == list(v.header.items())
         assert {k: h.hotpants_info[k] for k in h.hotpants_info} == {k: v.hotpants_info[k] for k in v.hotpants_info}
-        assert v.header['ZMSTATUS'] == 0 and v.hotpants_info['ncoeff'] > 0 and v.header['SEEING'] == 2.6
+        assert v.header['ZMSTATUS'] == 0 and v.hotpants_info['ncoeff'] > 0
+        if seeing_card:
+            assert v.header['SEEING'] == 2.6
+        else:       # measured from the pixels (stars of FWHM 2.6 px), recorded with the reference's comment
+            assert 2.2 < v.header['SEEING'] < 3.1 and v.header_comments['SEEING'] == 'FWHM of seeing in pixels (Goldstein)'
+            assert h.header_comments['SEEING'] == v.header_comments['SEEING']
 
 
 def drop_maps(d):

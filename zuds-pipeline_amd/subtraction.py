@@ -110,16 +110,35 @@ def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_n
         else:
             sci_rms, _ = rms_of(sci_img, sci_wgt, sci_mask, sci.header)
         ref_rms, ref_m32 = rms_of(ref_img, ref_wgt, ref_mask, ref.header)
+    sci_header = dict(sci.header)
+    sci_comments = dict(sci.header_comments or {})
+    if 'SEEING' not in sci_header:
+        # zuds/hotpants.py:38-44: a frame without the card gets its seeing measured and the subtraction goes on
+        # (round 6: on the planes already in HBM - the stars and moments of seeing.measure_seeing, the bad-pixel map
+        # of `mask.boolean` - instead of falling back to the host-pointer route; the card lands on the
+        # transaction's header, never on the caller's object or file, as there)
+        from .seeing import measure_seeing_dev
+        with torch.cuda.stream(oio.stream):
+            m32 = sci_mask
+            if sci_mask.dtype == torch.int16:
+                m32 = torch.empty(sci_mask.shape, dtype=torch.int32, device=sci_mask.device)
+                check(L.zm_mask_widen_dev(eng.ctx, sci_mask.data_ptr(), sci_mask.numel(), m32.data_ptr()), 'widen')
+            bad = torch.empty(sci_mask.shape, dtype=torch.uint8, device=sci_mask.device)
+            check(L.zm_mask_bad_dev(eng.ctx, m32.data_ptr(), None, BAD_SUM, m32.numel(), None, bad.data_ptr()), 'bpm')
+            sat = sci_header.get('SATURATE')
+            seeing, _ = measure_seeing_dev(sci_img, bad, float(sat) if sat else None, engine=eng)
+        sci_header['SEEING'] = float(seeing)
+        sci_comments['SEEING'] = 'FWHM of seeing in pixels (Goldstein)'
     chain = DeviceSubtraction(sci.wcs, ref.wcs, device=oio.device.index, engine=eng, stream=oio.stream)
     diff, noise, submask = chain.run(sci_img, sci_rms, sci_mask, sci_wgt, ref_img, ref_rms, ref_m32,
-                                     seeing=float(sci.header['SEEING']), nreg_side=nreg_side,
+                                     seeing=float(sci_header['SEEING']), nreg_side=nreg_side,
                                      subtract_back=subtract_new_back, hotpants_kws=hotpants_kws,
                                      ref_flxscale=float((ref.header or {}).get('FLXSCALE', 1.0)))
     info = {k: getattr(chain.info, k) for k, _ in chain.info._fields_}
     warn_unsolved(info, final_out)
     # cards: what hotpants.HotpantsCall.run writes, re-read, plus what from_images adds before its save()
     shape = tuple(chain.shape)
-    hdr0 = dict(sci.header)
+    hdr0 = dict(sci_header)
     hdr0.update(info_cards(info))
     hdr, com = objdev.written_header(hdr0, {}, shape, -32)          # (HotpantsCall.run writes the cards without comments)
     mh0 = dict(sci.mask_image.header or {})
@@ -134,8 +153,8 @@ def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_n
         if v is not None:
             hdr[prop.upper()] = v
             mhdr[prop.upper()] = v
-    hdr['SEEING'] = sci.header['SEEING']
-    com['SEEING'] = (sci.header_comments or {}).get('SEEING', '')
+    hdr['SEEING'] = sci_header['SEEING']
+    com['SEEING'] = sci_comments.get('SEEING', '')
     if issubclass(cls, CalibratedImage):
         for key in ('MAGZP', APER_KEY):
             if key in sci.header:
@@ -191,11 +210,11 @@ class Subtraction(HasWCS):
         outmask = final_out.replace('.fits', '.mask.fits')
 
         from . import objdev
-        if objdev.enabled() and 'SEEING' in sci.header and hasattr(ref, '_weightimg'):
+        if objdev.enabled() and hasattr(ref, '_weightimg'):
             # the device route (objdev): raw FITS blocks -> HBM -> DeviceSubtraction -> encoded products; round 5:
             # also for a science frame that carries an rms map instead of a weight map - the cold case of
             # scripts/dosub.py:35-47, whose map `sci.rms_image` has just made on the device (objdev.derive_maps).
-            # (A science frame whose SEEING still has to be measured takes the host-pointer route below.)
+            # Round 6: a science frame whose SEEING still has to be measured stays on this route too.
             return _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_new_back,
                                        hotpants_kws)
 
