@@ -1059,6 +1059,7 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
 
     def timed_pool(J, batch):
         pool = nm.SubtractionPool(J, device=local, batch=batch)
+        shape = {'lanes': pool.njobs, 'fit_batch': pool.batch}       # (J in flight without a batch: the pool picks lanes x batch)
         try:
             pool.map(jobs[:min(max(J * max(batch, 1), 1), len(jobs))], keep=False)      # allocations, code objects
             torch.cuda.synchronize()
@@ -1073,7 +1074,7 @@ def nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, 
             pool.close()
         # (a job that raised comes back as {'tag', 'error'} without 'info': nightly.SubtractionPool._run)
         bad = [r for r in res if 'error' in r or r['info']['status'] != 0]
-        rec = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt,
+        rec = {'ms_per_subtraction': 1e3 * dt / njobs, 'subtract_mpix_s': njobs * npx / 1e6 / dt, **shape,
                'passes_ms': [1e3 * t / njobs for t in reps], 'failed': len(bad)}
         errs = [r['error'] for r in bad if 'error' in r]
         if errs:

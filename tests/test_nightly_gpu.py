@@ -53,15 +53,20 @@ def test_pool_of_four_equals_one_at_a_time(engine):
     one = nm.SubtractionPool(1)
     a = one.map(jobs)
     one.close()
-    four = nm.SubtractionPool(4)
+    four = nm.SubtractionPool(4, batch=1)                 # four separate chains, one host thread each
+    assert four.batch == 0 and four.njobs == 4
     b = four.map(jobs)
     c = four.map(jobs[::-1])[::-1]                        # another assignment of jobs to workers
     four.close()
-    for x, y, y2 in zip(a, b, c):
-        assert x['tag'] == y['tag'] == y2['tag']
-        assert x['info'] == y['info'] == y2['info'] and x['info']['status'] == 0
+    auto = nm.SubtractionPool(4)                          # round 6: four in flight = two lanes of two batched fits
+    assert (auto.njobs, auto.batch) == (2, 2) and (nm.SubtractionPool(2).njobs, nm.SubtractionPool(3).batch) == (1, 3)
+    e = auto.map(jobs)
+    auto.close()
+    for x, y, y2, y3 in zip(a, b, c, e):
+        assert x['tag'] == y['tag'] == y2['tag'] == y3['tag']
+        assert x['info'] == y['info'] == y2['info'] == y3['info'] and x['info']['status'] == 0
         for k in ('diff', 'noise', 'mask'):
-            assert torch.equal(x[k], y[k]) and torch.equal(x[k], y2[k]), k
+            assert torch.equal(x[k], y[k]) and torch.equal(x[k], y2[k]) and torch.equal(x[k], y3[k]), k
         for k in ('flux', 'fluxerr', 'flags'):
             assert np.array_equal(x['phot'][k], y['phot'][k], equal_nan=True), k
     assert len({float(r['info']['kernel_sum']) for r in a}) > 1       # different jobs, really
@@ -86,7 +91,7 @@ def test_pool_at_the_reference_parameters(engine):
     one = nm.SubtractionPool(1)
     a = one.map(jobs)
     one.close()
-    three = nm.SubtractionPool(3)
+    three = nm.SubtractionPool(3, batch=1)
     b = three.map(jobs)
     three.close()
     for x, y in zip(a, b):

@@ -101,7 +101,12 @@ def test_subtraction_from_images_device_route_equals_host_route(tmp_path, engine
     refname = os.path.join(d, 'ref.000651_c03_q1_zg.fits')
     route('device', lambda: z.ReferenceImage.from_images(reopen(z, rpaths), refname, sci_swarp_kws={'COMBINE_TYPE': 'WEIGHTED'}))
     sims, spaths = _scene(z, s, d, 640, 600, 2, 5400, '202003', fwhm=2.6,
-                          extra=lambda i: {'SEEING': 2.6, 'SATURATE': 40000.0} if seeing_card else {'SATURATE': 40000.0})
+                          extra=lambda i: {'SEEING': 2.6, 'SATURATE': 40000.0})
+    if not seeing_card:
+        for p in spaths:                 # (synth frames carry the card: take it out of the files)
+            data, hdr, com = z.fits.read(p)
+            hdr.pop('SEEING')
+            z.fits.write(p, data, hdr, com)
     with_weights(z, sims)
     for p in spaths:
         res = {}

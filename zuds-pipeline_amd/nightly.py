@@ -247,8 +247,9 @@ class _BatchLane(object):
 
 
 class SubtractionPool(object):
-    """``njobs`` subtraction chains running side by side on one GPU; with ``batch`` >= 2, ``njobs`` lanes of
-    ``batch`` chains each whose kernel fits run as one batch (module docstring)."""
+    """``njobs`` subtractions in flight on one GPU.  ``batch`` >= 2: ``njobs`` lanes of ``batch`` chains each whose
+    kernel fits run as one batch (module docstring); ``batch`` = 0 (default): lanes and batch chosen for ``njobs`` jobs
+    in flight; ``batch`` = 1: ``njobs`` separate chains, one host thread each (rounds 3 - 5)."""
 
     def __init__(self, njobs=8, device=0, batch=0):
         if not 1 <= njobs <= 64:
@@ -257,6 +258,16 @@ class SubtractionPool(object):
             raise ValueError('batch must be in 0 .. 64')
         self.njobs, self.device = int(njobs), int(device)
         self.batch = int(batch) if int(batch) >= 2 else 0
+        if int(batch) == 0 and self.njobs >= 2:
+            # Round 6: `njobs` subtractions in flight without a word about batches are run as lanes of batched fits -
+            # one lane of two or three, two lanes of njobs / 2 from four on.  Separate chains flip every job to the
+            # one-workgroup-per-region factorisation (1.1 ms instead of 0.22) and were SLOWER than one worker at
+            # njobs = 2 (4.85 against 3.8 ms per subtraction, 3.4 - 3.6 at 4 - 8: BENCH_r05); a batch pays that
+            # factorisation once for all its jobs.  Same products bit for bit (tests/test_nightly_gpu.py).
+            # `batch=1` asks for the separate chains explicitly (A / B, tests).
+            lanes = 1 if self.njobs < 4 else 2
+            self.batch = -(-self.njobs // lanes)
+            self.njobs = lanes
         # share >= 2 selects the one-workgroup-per-region form of the kernel fit's factorisation, which
         # claims nothing for itself (a lone job keeps the many-workgroup form); ZM_POOL_SHARE overrides
         # (developer: with ZM_CHOL_FORM=lat it is the fraction of the CUs each job's resident grid gets)
