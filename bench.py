@@ -827,6 +827,11 @@ def main():
                 roofline['valu_insts_per_px'] = kp.get('valu_insts_per_px')
                 roofline['lds_insts_per_px'] = kp.get('lds_insts_per_px')
                 roofline['valu_busy_frac'] = kp.get('valu_busy_frac')
+                # what BINDS this kernel, beside the HBM fraction it is priced against - the share of
+                # its wave cycles in which a SIMD issues a vector instruction (SQ_ACTIVE_INST_VALU x 4 waves /
+                # SQ_WAVE_CYCLES); the exact 6 x 6 two-plane filter in fp32 leaves no way to 0.60 of HBM
+                roofline['valu_issue_frac'] = kp.get('valu_busy_frac')
+                roofline['binding'] = 'vector issue (valu_issue_frac), not HBM (frac)'
             if fused and sum_type and 'coadd_ms' in legs:
                 # the whole coadd leg against the same roof: + the estimation read of the mesh statistics (image +
                 # weight, 8 B per input pixel) and the mask words the box pre-pass reads
