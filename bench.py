@@ -43,7 +43,7 @@ VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (packed 
 MFMA_F64_PEAK_TFLOPS = 78.6
 RESAMPLE_BYTES_PER_OUTPX = 16  # img+var read, img+var write
 MASK_BYTES_PER_OUTPX = 8       # + 4 B in / 4 B out when int32 masks ride along
-PMC_PROFILES = ['r05_pmc.json', 'r04_pmc.json']     # newest first; each stamped with the hash of the kernel sources it measured
+PMC_PROFILES = ['r06_pmc.json', 'r05_pmc.json']     # newest first; each stamped with the hash of the kernel sources it measured
 
 
 def parse():
@@ -781,10 +781,9 @@ def main():
                 pass
         roofline = None
         pmc = pmc_profile(args)
-        # (which form of the fused kernel ran: the owner-staged one where the footprints fit its slot - this stack's do -
-        # unless ZM_FF_FORM / ZM_FF_DMA say otherwise)
-        ff_kernel = 'k_coadd_fused_own' if (os.environ.get('ZM_FF_FORM', 'own') != 'dma' and os.environ.get('ZM_FF_DMA', '1') != '0') else \
-            ('k_coadd_fused_dma' if os.environ.get('ZM_FF_DMA', '1') != '0' else 'k_coadd_fused')
+        # which form of the fused kernel the launcher chose for this stack (zm_ctx_query: the owner-staged one where
+        # every planned footprint fits its fixed slot, else the LDS-DMA staged one)
+        ff_kernel = {1: 'k_coadd_fused_dma', 2: 'k_coadd_fused_own'}.get(eng.query('fused_form'), 'k_coadd_fused_own')
         m = 0 if args.no_mask else 1
         mask_in = 0 if not m else (2 if args.mask_dtype == 'int16' else 4)      # bytes per input pixel of a mask plane
         if roof_scope in kt:

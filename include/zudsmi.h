@@ -68,6 +68,12 @@ int zm_ctx_synchronize(zm_ctx* ctx);
 int zm_ctx_set_share(zm_ctx* ctx, int nctx);
 const char* zm_last_error(void);
 const char* zm_version(void);
+/* What the context last did / how the library was built, by name (-> *out; unknown name: error):
+ *   "fused_form"  the fused resample -> coadd kernel the last coadd of this context launched: 0 none yet,
+ *                 1 k_coadd_fused_dma, 2 k_coadd_fused_own (bench.py labels its roofline with it)
+ *   "dev_build"   1 when the library was compiled with -DZM_DEV (developer switches are read), else 0
+ * No counterpart in the reference (its tools report through their logs, zuds/astromatic/makecoadd/default.swarp:111). */
+int zm_ctx_query(zm_ctx* ctx, const char* what, int64_t* out);
 
 /* ---- WCS helpers (host, fp64) ------------------------------------------ */
 /* Output grid of a coadd: SWarp CENTER_TYPE ALL / PIXELSCALE_TYPE MEDIAN /

@@ -269,18 +269,34 @@ def test_differential_fuzz_against_the_k_resample_path(engine):
     assert mod.run(80, 2026, eng=engine, verbose=False) == 0
 
 
-@pytest.mark.parametrize('variant', [{'ZM_FF_DMA': '0'}, {'ZM_FF_RAW': '0'}, {'ZM_FF_DMA': '0', 'ZM_FF_RAW': '0'},
-                                     {'ZM_FF_FORK': '0'}, {'ZM_FF_FORM': 'dma'}, {'ZM_FF_FORM': 'dma', 'ZM_FF_RAW': '0'},
-                                     {'ZM_FF_YIELD': '2'}, {'ZM_FF_YIELD': '1', 'ZM_FF_FORM': 'dma'},
+DEV_ONLY = ('ZM_FF_FORK', 'ZM_FF_YIELD', 'ZM_FF_PROF', 'ZM_FF_DEAL', 'ZM_FF_PRIO')
+
+
+@pytest.mark.parametrize('variant', [{'ZM_FF_RAW': '0'}, {'ZM_FF_FORM': 'dma'}, {'ZM_FF_FORM': 'dma', 'ZM_FF_RAW': '0'},
+                                     {'share': 2}, {'share': 2, 'ZM_FF_FORM': 'dma'},
+                                     {'ZM_FF_FORK': '0'}, {'ZM_FF_YIELD': '1', 'ZM_FF_FORM': 'dma'},
                                      {'ZM_FF_PROF': '1', 'ZM_FF_DEAL': '0'}, {'ZM_FF_PROF': '1', 'ZM_FF_DEAL': '2', 'ZM_FF_PRIO': '10'}])
 def test_kernel_variants_behind_the_switches(engine, monkeypatch, variant):
-    """The library ships three fused kernels (the owner-staged one - in-place prep, one barrier per item -
-    wherever the footprints fit its fixed slot; the LDS-DMA staged one elsewhere or with ZM_FF_FORM=dma; the
-    register-staged one: ZM_FF_DMA=0) and two ways to feed them (raw planes prepped in the kernel, the default,
-    and planes prepped ahead: ZM_FF_RAW=0, also what frames without 16-byte rows or with large footprints take);
-    the yield mode of a context that shares the GPU (ZM_FF_YIELD: workgroups retire after a few tiles); the
-    developer instances with their switches (ZM_FF_PROF: phase clocks; ZM_FF_DEAL: who stages what; ZM_FF_PRIO:
-    wave priorities).  Every combination gives the bits of the materialised path, on interior and edge tiles."""
+    """The library ships two fused kernels (the owner-staged one - in-place prep, one barrier per item - wherever the
+    footprints fit its fixed slot; the LDS-DMA staged one elsewhere or with ZM_FF_FORM=dma; round 6 removed the
+    register-staged one) and two ways to feed them (raw planes prepped in the kernel, the default, and planes
+    prepped ahead: ZM_FF_RAW=0, also what frames without 16-byte rows or with large footprints take); the yield mode
+    of a context that shares the GPU (zm_ctx_set_share >= 2: workgroups retire after two tiles).  A developer build
+    (-DZM_DEV) adds instances with phase clocks and staging deals behind ZM_FF_PROF / ZM_FF_DEAL / ZM_FF_PRIO /
+    ZM_FF_YIELD / ZM_FF_FORK, which the shipped library does not read.  Every combination gives the bits of the
+    materialised path, on interior and edge tiles."""
+    if any(k in DEV_ONLY for k in variant) and not engine.query('dev_build'):
+        pytest.skip('developer switch: the library was not built with -DZM_DEV')
+    variant = dict(variant)
+    share = variant.pop('share', 1)
+    engine.set_share(share)
+    try:
+        _variant_body(engine, monkeypatch, variant, 'dma' if variant.get('ZM_FF_FORM') == 'dma' else 'own')
+    finally:
+        engine.set_share(1)
+
+
+def _variant_body(engine, monkeypatch, variant, form):
     z = pkg()
     for k, v in variant.items():
         monkeypatch.setenv(k, v)
@@ -288,6 +304,9 @@ def test_kernel_variants_behind_the_switches(engine, monkeypatch, variant):
     p = z.coadd_params(combine='WEIGHTED', mask_combine='OR', subtract_back=True, rescale_weights=True, back_size=128)
     a, b = run_both(engine, frames, wout, p)
     assert_same(a, b)
+    # which kernel the launcher chose is the context's to say (zm_ctx_query; ADVICE r5: bench.py labels its roofline
+    # with it): near-unit scale footprints fit the owner-staged slots
+    assert engine.query('fused_form') == {'own': 2, 'dma': 1}[form]
     frames, _ = stack(4, 520, 480, 320, dither=50.0, rot=0.3)
     wout = engine.autogrid([f['wcs'] for f in frames])
     p = z.coadd_params(combine='AVERAGE', mask_combine='AND', subtract_back=False, rescale_weights=False)

@@ -1,7 +1,6 @@
 """Static check of the hand-counted LDS pipelines of the fused coadd kernels (CPU: needs hipcc, no GPU).
 
-k_coadd_fused_own / _dma / k_coadd_fused read their filter windows (and, in the register-staged form, the tap-table
-nodes) with inline-asm ``ds_read`` sequences and wait for them with COUNTED ``s_waitcnt lgkmcnt(N)``: row r + 1 is
+k_coadd_fused_own / _dma read their filter windows with inline-asm ``ds_read`` sequences and wait for them with COUNTED ``s_waitcnt lgkmcnt(N)``: row r + 1 is
 in flight while row r is applied.  lgkmcnt also counts scalar loads and any LDS operation the compiler emits, and
 scalar loads return out of order: ONE such instruction between two counted waits lets a wait pass early and the
 pixel work on stale registers - wrong values on some waves of some launches, no fault.  Round 5 met exactly that:
@@ -10,48 +9,38 @@ k_resample comparison caught it (nondeterministic differences in the last pixel 
 
 The sources bracket each counted region with ``; ZM_LGKM_BEGIN`` / ``; ZM_LGKM_END`` comments; between them only the
 kernels' own asm statements (``;;#ASMSTART`` ... ``;;#ASMEND``) may touch the lgkm counter."""
+import importlib
 import os
-import re
 import shutil
 import subprocess
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'zuds-pipeline_amd', 'csrc', 'resample.hip')
-# what increments lgkmcnt: LDS / GDS, scalar memory, messages; flat accesses count in both counters
-LGKM = re.compile(r'^(ds_|s_load|s_buffer_load|s_scratch_load|s_store|s_buffer_store|s_dcache|s_sendmsg|s_memtime|'
-                  r's_memrealtime|s_atc_probe|flat_)')
+CSRC = os.path.join(ROOT, 'zuds-pipeline_amd', 'csrc')
+checks = importlib.import_module('zuds-pipeline_amd.isa_checks')
+build = importlib.import_module('zuds-pipeline_amd.build')
+lint, dpp_lint = checks.lgkm_lint, checks.dpp_lint
+HAVE_HIPCC = shutil.which('hipcc') is not None or os.path.exists('/opt/rocm/bin/hipcc')
 
 
-def lint(asm_text):
-    """[(kernel, line number, instruction)] of compiler-made lgkm operations inside a counted region."""
-    bad, regions = [], 0
-    kernel, inside, in_asm = None, False, False
-    for n, line in enumerate(asm_text.split('\n'), 1):
-        t = line.strip()
-        m = re.match(r'^(_Z\w+):', t)
-        if m:
-            kernel = m.group(1)
-        if 'ZM_LGKM_BEGIN' in t:
-            assert not inside, f'nested ZM_LGKM_BEGIN at line {n}'
-            inside = True
-            regions += 1
-            continue
-        if 'ZM_LGKM_END' in t:
-            assert inside, f'ZM_LGKM_END without a BEGIN at line {n}'
-            inside = False
-            continue
-        if t.startswith(';;#ASMSTART'):
-            in_asm = True
-            continue
-        if t.startswith(';;#ASMEND'):
-            in_asm = False
-            continue
-        if inside and not in_asm and LGKM.match(t):
-            bad.append((kernel, n, t))
-    assert not inside, 'ZM_LGKM_BEGIN without an END'
-    return bad, regions
+def built_asm(src, tmp_path):
+    """The device assembly of a translation unit: the file the build kept next to the object when it is at least as
+    new as the source (the instructions that are in libzudsmi.so), else a compile with the build's own flags."""
+    objdir = build.LIBDIR / 'obj'
+    asm = build.device_asm(objdir, src)
+    path = os.path.join(CSRC, src)
+    if asm.exists() and asm.stat().st_mtime >= os.path.getmtime(path):
+        return asm.read_text()
+    out = tmp_path / (src + '.s')
+    subprocess.check_call([build._hipcc()] + build.FLAGS + ['--cuda-device-only', '-I', os.path.join(ROOT, 'include'),
+                                                            '-S', path, '-o', str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+LGKM_SOURCES = ['fused_dma.hip', 'fused_own.hip']
+MIN_LGKM_REGIONS = 2 * 9
+DPP_SOURCES = ['hotpants.hip']
 
 
 def test_lint_sees_a_planted_scalar_load():
@@ -61,15 +50,15 @@ def test_lint_sees_a_planted_scalar_load():
     assert regions == 1 and [b[2].split()[0] for b in bad] == ['s_load_dword']
 
 
-@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+@pytest.mark.skipif(not HAVE_HIPCC, reason='needs hipcc')
 def test_no_compiler_made_lgkm_operation_inside_the_counted_pipelines(tmp_path):
-    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    out = tmp_path / 'resample.s'
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', SRC,
-                           '-o', str(out)], stderr=subprocess.DEVNULL)
-    bad, regions = lint(out.read_text())
-    # every instance of the three kernels carries one region (the register-staged form wraps its tap loop too)
-    assert regions >= 3 * 9, regions
+    regions, bad = 0, []
+    for src in LGKM_SOURCES:
+        b, r = lint(built_asm(src, tmp_path))
+        regions += r
+        bad += b
+    # every instance of the fused kernels carries one region
+    assert regions >= MIN_LGKM_REGIONS, regions
     assert not bad, bad[:5]
 
 
@@ -80,57 +69,6 @@ def test_no_compiler_made_lgkm_operation_inside_the_counted_pipelines(tmp_path):
 # on some lanes.  The asm statements keep their own distance; what they cannot see is an instruction the compiler
 # puts between them (a register copy, a re-materialised constant).  This lint walks the assembly: for every DPP
 # instruction, no vector instruction among the preceding two wait states may write its DPP source.
-HOT = os.path.join(ROOT, 'zuds-pipeline_amd', 'csrc', 'hotpants.hip')
-VREG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
-
-
-def vregs(operand):
-    m = VREG.search(operand)
-    if not m:
-        return set()
-    if m.group(3) is not None:
-        return {int(m.group(3))}
-    return set(range(int(m.group(1)), int(m.group(2)) + 1))
-
-
-def dpp_lint(asm_text):
-    """[(kernel, line number, dpp instruction, offending writer)]; also the number of DPP instructions seen."""
-    bad, ndpp = [], 0
-    kernel = None
-    window = []                  # (wait states this instruction is worth, registers it writes if it is a VALU op, text)
-    for n, line in enumerate(asm_text.split('\n'), 1):
-        t = line.strip()
-        m = re.match(r'^(_Z\w+):', t)
-        if m:
-            kernel, window = m.group(1), []
-            continue
-        if not t or t.startswith(';') or t.startswith('.') or t.endswith(':'):
-            continue
-        op = t.split()[0]
-        args = t[len(op):].split(';')[0]
-        ops = [a.strip() for a in args.split(',')]
-        if op in ('v_fmac_f64_dpp', 'v_mov_b64_dpp'):
-            ndpp += 1
-            src = vregs(ops[1].lstrip('-|'))
-            need = 2
-            for ws, wr, txt in reversed(window):
-                if need <= 0:
-                    break
-                if wr & src:
-                    bad.append((kernel, n, t, txt))
-                    break
-                need -= ws
-        if op == 's_nop':
-            window.append((int(ops[0]) + 1, set(), t))
-        elif op.startswith('v_') and not op.startswith('v_cmp') and not op.startswith('v_readlane') \
-                and not op.startswith('v_readfirstlane'):
-            window.append((1, vregs(ops[0]), t))          # a VALU instruction: its destination is its first operand
-        else:
-            window.append((1, set(), t))
-        window = window[-8:]
-    return bad, ndpp
-
-
 def test_dpp_lint_sees_a_planted_hazard_and_accepts_the_distance():
     head = ['_Z1kv:', '\tv_mul_f64 v[2:3], v[6:7], v[8:9]']
     dpp = '\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf'
@@ -143,13 +81,41 @@ def test_dpp_lint_sees_a_planted_hazard_and_accepts_the_distance():
         assert not bad, filler
 
 
-@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+def test_dpp_lint_restarts_its_window_at_a_label():
+    """a writer reached through a back-edge or a branch target is not in the text above the label."""
+    dpp = '\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf'
+    far = ['_Z1kv:', '\tv_mul_f64 v[2:3], v[6:7], v[8:9]', '\ts_nop 1']
+    assert not dpp_lint('\n'.join(far + [dpp]))[0]
+    bad, _ = dpp_lint('\n'.join(far + ['.LBB0_3:', dpp]))                 # straight behind a join: unknown
+    assert len(bad) == 1 and 'label' in bad[0][3]
+    bad, _ = dpp_lint('\n'.join(far + ['.LBB0_3:', '\tv_add_f32_e32 v9, v9, v9', dpp]))
+    assert len(bad) == 1
+    assert not dpp_lint('\n'.join(far + ['.LBB0_3:', '\ts_nop 1', dpp]))[0]
+    assert not dpp_lint('\n'.join(far + ['.LBB0_3:', '\tv_add_f32_e32 v9, v9, v9', '\tv_add_f32_e32 v9, v9, v9', dpp]))[0]
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason='needs hipcc')
 def test_no_vector_write_within_two_wait_states_of_a_dpp_read_in_the_solver(tmp_path):
-    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    out = tmp_path / 'hotpants.s'
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only',
-                           '-I', os.path.join(ROOT, 'include'), '-S', HOT, '-o', str(out)], stderr=subprocess.DEVNULL)
-    bad, ndpp = dpp_lint(out.read_text())
+    ndpp, bad = 0, []
+    for src in DPP_SOURCES:
+        b, n = dpp_lint(built_asm(src, tmp_path))
+        ndpp += n
+        bad += b
     # the diagonal factor (144 per inlined copy) and the panel chains of every form: thousands of them
     assert ndpp > 2000, ndpp
     assert not bad, bad[:5]
+
+
+def test_the_build_runs_both_checks_on_what_it_compiled(tmp_path):
+    """build.lint_built: a finding fails the build and removes the object (CPU: no compiler needed)."""
+    objdir = tmp_path
+    asm = build.device_asm(objdir, 'x.hip')
+    (objdir / 'x.o').write_bytes(b'')
+    asm.write_text('\n'.join(['_Z1kv:', '\tv_mul_f64 v[2:3], v[6:7], v[8:9]',
+                               '\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf']))
+    with pytest.raises(RuntimeError, match='isa_checks'):
+        build.lint_built(objdir, ['x.hip'], verbose=False)
+    assert not (objdir / 'x.o').exists()
+    asm.write_text('\n'.join(['_Z1kv:', '\tv_mul_f64 v[2:3], v[6:7], v[8:9]', '\ts_nop 1',
+                               '\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf']))
+    build.lint_built(objdir, ['x.hip'], verbose=False)

@@ -291,18 +291,13 @@ def test_throughput_form_of_the_factorisation_gives_the_same_bits(engine, monkey
     d0, n0, i0 = engine.subtract(*data, **kw)
     monkeypatch.setenv('ZM_CHOL_FORM', 'tp')
     d1, n1, i1 = engine.subtract(*data, **kw)
-    # ... and the many-workgroup form with 64-column super-steps (k_chol_fused2, opt-in: round 4's experiment)
-    monkeypatch.setenv('ZM_CHOL_FORM', 'lat')
-    monkeypatch.setenv('ZM_CHOL_STEP', '64')
-    d2, n2, i2 = engine.subtract(*data, **kw)
-    monkeypatch.delenv('ZM_CHOL_STEP')
     # ... and the data-flow form (k_chol_df: resident tiles, flags instead of barriers; sizes whose tiles do not
     # fit three per workgroup run k_chol_fused under this switch)
     monkeypatch.setenv('ZM_CHOL_FORM', 'df')
     d3, n3, i3 = engine.subtract(*data, **kw)
     monkeypatch.delenv('ZM_CHOL_FORM')
     d4, n4, i4 = engine.subtract(*data, **kw)            # the default choice
-    for d, n, i in ((d1, n1, i1), (d2, n2, i2), (d3, n3, i3), (d4, n4, i4)):
+    for d, n, i in ((d1, n1, i1), (d3, n3, i3), (d4, n4, i4)):
         assert i0['status'] == 0 and i['status'] == 0 and i0['retries'] == 0 and i['retries'] == 0
         assert np.array_equal(d0, d) and np.array_equal(n0, n)
         for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):

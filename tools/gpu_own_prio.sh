@@ -24,7 +24,7 @@ done
 B="bench.py --steps 10 --warmup 2 --no-clocks --no-cpu-baseline --no-secondary --no-nightly --no-pipelined"
 for c in $profs; do
     d=${c%%:*}; pr=${c##*:}
-    ZM_FF_DEAL=$d ZM_FF_PRIO=$pr ZM_FF_PROF=2 timeout -k 10 300 python3 $B --no-subtract --steps 2 > $out/prof_own_$d_$pr.json 2> $out/prof_own_${d}_$pr.err
+    ZM_FF_DEAL=$d ZM_FF_PRIO=$pr ZM_FF_PROF=2 timeout -k 10 300 python3 $B --no-subtract --steps 2 > $out/prof_own_${d}_${pr}.json 2> $out/prof_own_${d}_$pr.err
     echo "-- per-wave phase clocks, deal $d prio $pr"
     grep -A8 phases $out/prof_own_${d}_$pr.err | tail -9
 done

@@ -31,13 +31,13 @@ done
 python3 tools/pmc_summary.py $(find $out/pmc_weighted_* -name '*counter_collection.csv') > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $(find $out/pmc_clipped_* -name '*counter_collection.csv') > $out/pmc_summary_clipped.txt
 grep -E "k_coadd_fused|k_mask_box|k_mesh_stats|k_chol_df|k_hp_apply" $out/pmc_summary.txt | grep -E "FETCH|WRITE|INSTS_VALU"
-cp $out/tests.log $out/tests_tail.log 2>/dev/null; tail -3 $out/tests.log > $out/tests_tail.log 2>/dev/null
+if [ "${2:-tests}" = tests ]; then tail -3 $out/tests.log > $out/tests_tail.log; else echo "tests not run in this call (notests mode)" > $out/tests_tail.log; fi
 grep -E "k_coadd_fused|k_combine" $out/pmc_summary_clipped.txt | grep -E "FETCH|WRITE"
 # the counter profile bench.py quotes, stamped with the hash of these kernel sources (copy it to profiles/)
 python3 tools/make_pmc_json.py $out $out/pmc.json
 # ... and the full bench line LAST, with this round's counter profile in the place bench.py reads it from (on
 # this box's copy of the tree), so that the committed line quotes counters taken at its own commit
-cp $out/pmc.json profiles/r05_pmc.json
+cp $out/pmc.json profiles/r06_pmc.json
 cp $out/bench.json $out/bench_short.json
 rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_SQ $out/prof    # (raw traces: tens of MB)
 timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }

@@ -257,14 +257,14 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
     }
     // one workgroup of 1 024 threads per CU (round 5; rounds 1 - 4: two of 256 per CU; ZM_RS_THREADS / ZM_RS_GRID for A / B:
     // 256 x 512 214 us, 512 x 256 196, 512 x 512 191, 1024 x 128 182, 1024 x 256 177, 1024 x 64 286 per median + MAD of two frames)
-    static const int rs_threads = getenv("ZM_RS_THREADS") ? atoi(getenv("ZM_RS_THREADS")) : 1024;
-    static const int rs_grid = getenv("ZM_RS_GRID") ? atoi(getenv("ZM_RS_GRID")) : 256;
+    static const int rs_threads = ZM_DEVENV("ZM_RS_THREADS") ? atoi(ZM_DEVENV("ZM_RS_THREADS")) : 1024;
+    static const int rs_grid = ZM_DEVENV("ZM_RS_GRID") ? atoi(ZM_DEVENV("ZM_RS_GRID")) : 256;
     int grid = (int)std::min<int64_t>((n / 4 + rs_threads - 1) / rs_threads, rs_grid);
     if (grid < 1) grid = 1;
     // the validity bit plane: where the vector path runs and there is a mask to save (ZM_RS_BITS=0: masks every pass)
     bool any_mask = false;
     for (int i = 0; i < nimg; ++i) any_mask = any_mask || ims[i].mask != nullptr;
-    static const bool bits_off = getenv("ZM_RS_BITS") && getenv("ZM_RS_BITS")[0] == '0';
+    static const bool bits_off = ZM_DEVENV("ZM_RS_BITS") && ZM_DEVENV("ZM_RS_BITS")[0] == '0';
     if (vec_ok && any_mask && n >= 4096 && !bits_off)
         ZM_TRY(ctx->get("rs_vbits", sizeof(unsigned long long) * 4 * (size_t)((n / 4 + 63) / 64) * ZM_RS_MAXIMG, (void**)&d_vbits));
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};

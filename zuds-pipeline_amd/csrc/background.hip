@@ -1113,7 +1113,7 @@ int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* c
     }
     zm_scope_timer t(ctx, "mesh_stats");
     if (mesh <= 128) {
-        static const int dbg = getenv("ZM_DBG_BK") ? atoi(getenv("ZM_DBG_BK")) : 0;
+        static const int dbg = ZM_DEVENV("ZM_DBG_BK") ? atoi(ZM_DEVENV("ZM_DBG_BK")) : 0;
         for (int f0 = 0; f0 < nf; f0 += BK_BATCH) {
             const int nb = std::min(BK_BATCH, nf - f0);
             bk_batch B;

@@ -125,6 +125,14 @@ extern "C" int zm_ctx_set_share(zm_ctx* ctx, int nctx) {
     return 0;
 }
 
+extern "C" int zm_ctx_query(zm_ctx* ctx, const char* what, int64_t* out) {
+    ZM_CHECK(ctx && what && out, "zm_ctx_query: null argument");
+    if (!strcmp(what, "fused_form")) *out = ctx->ff_last_form;
+    else if (!strcmp(what, "dev_build")) *out = ZM_DEV_BUILD;
+    else ZM_CHECK(false, "zm_ctx_query: unknown item \"%s\"", what);
+    return 0;
+}
+
 int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out) {
     while ((int)ctx->sync_events.size() < n) {
         hipEvent_t e = nullptr;

@@ -158,7 +158,7 @@ extern "C" int zm_copy_probe_dev(zm_ctx* ctx, const void* src, void* dst, int64_
     const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)ncu * 8);
     // (developer: ZM_COPY_FORM = loads in flight per thread (4, 8) + 'n' for non-temporal loads, e.g. "8n")
     // (measured, GB/s read + write on one box: 4: 5558, 4n: 5865, 8: 5323, 8n: 5681 - the default is 4n)
-    const char* cf = getenv("ZM_COPY_FORM");
+    const char* cf = ZM_DEVENV("ZM_COPY_FORM");
     const int u = cf ? atoi(cf) : 4;
     const bool ntl = cf ? strchr(cf, 'n') != nullptr : true;
     if (u == 8 && ntl) hipLaunchKernelGGL((k_copy4<8, true>), dim3(grid), dim3(256), 0, ctx->stream, (const float4*)src, (float4*)dst, n4);

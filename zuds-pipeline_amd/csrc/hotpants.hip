@@ -21,37 +21,8 @@
 //   k_hp_merit / k_hp_reject    stamp figure of merit, sigma clip, next substamp
 //   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
 //                   fp32 convolution of template and template variance
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-
-#include "zm_internal.h"
+#include "hp_dev.h"
 #include "chol_diag.h"
-
-#define HP_MAXX 64        // rows of the Gram tile (nc + nbg + 1 <= 64)
-#define HP_MAXPOLY 28     // (ko + 1)(ko + 2) / 2 for ko <= 6
-#define HP_MAXNSS 8
-#define HP_MAXREG 64
-#define CF_BAR_STRIDE 32                // one k_chol_fused barrier counter per region, 128 B apart
-#define HP_MAXF1 32       // distinct 1-D filters
-#define HP_RIDGE 1e-10
-
-struct hp_plan {
-    int nx, ny, hwk, hwss, hw, step, sw, npix, npixp, pw;   // sw = 2 hwss + 1, pw = 2 hw + 1
-    int nc, nbg, nE, nX, nkp, nunk, ko, bgo;
-    int nrx, nry, nsx, nsy, nss, nreg, ncellr, ncell, nf1;
-    int normalize;
-    double tu, tl, iu, il, ft, ks;
-    float fi, fin;
-    int rx0[HP_MAXREG], rx1[HP_MAXREG], ry0[HP_MAXREG], ry1[HP_MAXREG];
-    // basis term tables
-    int tfx[HP_MAXX], tfy[HP_MAXX], tsub0[HP_MAXX];
-    double tscale[HP_MAXX];
-    int kpi[HP_MAXPOLY], kpj[HP_MAXPOLY];   // kernel spatial terms x^i y^j
-    int bpi[16], bpj[16];                   // background terms
-    int ngauss, gdeg[4], gbase[4], gterm0[4];   // per Gaussian: degree, first 1-D filter, first term
-    int tf0[HP_MAXF1], tfn[HP_MAXF1];           // terms whose x filter is f: tf0[f] .. tf0[f] + tfn[f] - 1 (consecutive)
-};
 
 // ---------------------------------------------------------------------------
 // lim != nullptr (zm_hp_params.limits_dev): the lower limits come from the background estimates that
@@ -244,39 +215,6 @@ __global__ __launch_bounds__(256) void k_hp_colany4(const uint8_t* __restrict__ 
             for (int k = 0; k < 4; ++k) cnt[k] += nz(wa[u], k) - nz(ws[u], k);
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-__device__ inline double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// the same sum for NW waves (a power of two): pairwise - waves that contribute 0 leave the bits alone
-template <int NW>
-__device__ inline double block_sum_waves(double v, double* red) {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    // (pairwise, block_sum256's grouping for the first four waves)
-    double t[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t[w] = red[w];
-#pragma unroll
-    for (int step = 1; step < NW; step *= 2)
-#pragma unroll
-        for (int w = 0; w + step < NW; w += 2 * step) t[w] += t[w + step];
-    return t[0];
-}
-
-__device__ inline double block_sum256(double v, double* red) {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // One workgroup per stamp cell.  centres[cell * nss + k] = (x, y) or (-1, -1).
@@ -495,263 +433,6 @@ __global__ __launch_bounds__(HC_THREADS, 4) void k_hp_cells_reg(const hp_plan P,
 // need[cell] = vectors / Gram must be (re)computed this round.
 // X layout: [cell][nX][npixp] fp64, rows 0..nc-1 kernel vectors, nc..nE-1
 // background terms, nE the science pixels; columns >= npix are zero.
-// x^n for the small non-negative integer exponents of the spatial polynomials: a handful of
-// multiplications instead of the ~200 instructions of a general fp64 pow()
-__device__ inline double ipowd(double x, int n) {
-    double r = 1.0;
-    for (int k = 0; k < n; ++k) r *= x;
-    return r;
-}
-
-#define HV_R 8     // outputs per thread along the filter direction (register sliding window)
-// Workgroups per cell (blockIdx.y): the x filters in use are dealt round-robin, each
-// workgroup runs its x passes and the y passes of the terms built on them.  After the first
-// round only the few cells with a replaced substamp are recomputed, so a cell's latency,
-// not the throughput, sets the kernel time: the first round runs HV_SPLIT_ALL parts per cell
-// (less of term 0 rebuilt), the later ones HV_SPLIT_FEW.
-#define HV_SPLIT_ALL 5
-#define HV_SPLIT_FEW 16   // later rounds: part 0 = the science / background rows and the spatial terms, 15 parts of filters
-
-// Round 4: 512 threads per workgroup.  A pass has 343 (y) or 483 (x) work items of eight outputs: with 256 threads
-// it ran as two rounds, the second a third full, and after the first rejection round the latency of one cell's
-// passes is the kernel time (38 us); the LDS footprint (70 KB) allows two workgroups per CU either way, so 512
-// threads also double the waves that cover each other's LDS reads in the first round.
-#define HV_THREADS 512
-#define HP_MAX_HWK 20                    // kernel half widths 1 .. 20 (41 x 41 taps), substamp half widths 1 .. 60: SEEING up to
-#define HP_MAX_HWSS 60                   // 8 px at hotpants' -r 2.5 SEEING -rss 6 SEEING (zuds/hotpants.py:42-44)
-// LDS plan of k_hp_vectors for a substamp geometry: resident form where everything fits, else term 0 in global memory
-// and, if still too large, the x-filtered patch in column chunks
-struct hv_cfg { bool big; bool w0_global; int cw; size_t shmem; };
-static inline hv_cfg hp_vectors_cfg(int pw, int sw, int npix) {
-    const size_t lim = 160 * 1024, patch = sizeof(float) * (size_t)pw * (pw + 8) + 16;   // (HV_R = 8)
-    const size_t fast = sizeof(double) * ((size_t)(pw + 8) * sw + npix + 8) + patch;
-    if (fast <= lim) return {false, false, sw, fast};
-    const size_t full = sizeof(double) * ((size_t)(pw + 8) * sw + 8) + patch;
-    if (full <= lim) return {true, true, sw, full};
-    if (patch + sizeof(double) * 8 + sizeof(double) * (size_t)(pw + 8) * 8 > lim) return {true, true, 0, 0};   // (does not fit at all)
-    int cw = (int)((lim - patch - sizeof(double) * 8) / (sizeof(double) * (size_t)(pw + 8)));
-    cw &= ~7;
-    return {true, true, cw, sizeof(double) * ((size_t)(pw + 8) * cw + 8) + patch};
-}
-// BIG (round 5: half widths up to 20, substamps up to 60 - hotpants takes -r 2.5 SEEING, -rss 6 SEEING unclamped,
-// zuds/hotpants.py:42-44): where the x-filtered patch, term 0 and the template patch do not fit 160 KB of LDS
-// together, the x-filtered patch is built and consumed in chunks of `cwarg` substamp columns (a column's y pass
-// needs that column only) and term 0 lives in global memory (`w0g`: one vector per workgroup of the launch, written
-// and read by that workgroup alone, a barrier between).  Per entry the sums are those of the resident form.
-template <int HWK, bool BIG = false>
-static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const float* __restrict__ sci,
-                                                    const float* __restrict__ ref,
-                                                    const float* __restrict__ srms,
-                                                    const float* __restrict__ trms,
-                                                    const double* __restrict__ filt,   // [nf1][step]
-                                                    const int2* __restrict__ centres,
-                                                    const int* __restrict__ active,
-                                                    const int* __restrict__ need,
-                                                    double* __restrict__ X,
-                                                    double* __restrict__ phi,         // [cell][nkp]
-                                                    double* __restrict__ vbar, const int* __restrict__ guard,
-                                                    double* __restrict__ phiold, const int* __restrict__ list,
-                                                    int special, int cwarg = 0, double* __restrict__ w0g = nullptr) {
-    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
-    extern __shared__ double hp_smem[];
-    constexpr int STEP = 2 * HWK + 1;
-    constexpr int WIN = HV_R + 2 * HWK;
-    const int tid = threadIdx.x;
-    const int part = blockIdx.y, nparts = gridDim.y;
-    // cells: every cell of the grid (first round: list == nullptr), or the cells the last rejection gave a new
-    // substamp (`list`: [count, cells ...], written by k_hp_reject*) - a grid over all 900 cells of which a
-    // handful have work spent a third of the launch dispatching workgroups that return at once
-    const int ncl = list ? list[0] : (BIG ? P.ncell : (int)gridDim.x);   // (BIG: a capped grid whose workgroups loop)
-#pragma unroll 1
-    for (int ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-    const int cell = list ? list[1 + ci] : ci;
-    __syncthreads();                                     // (the LDS of the cell before is consumed)
-    if (!need[cell]) continue;
-    const int act = active[cell];
-    if (act < 0) continue;
-    const int2 cc = centres[cell * P.nss + act];
-    const int r = cell / P.ncellr;
-    const int pw = P.pw, sw = P.sw, hwss = P.hwss;
-    // `special` (the later rounds, where a handful of cells is all there is and the slowest workgroup of a cell is
-    // the kernel time): part 0 does nothing but the science row, the background rows, the variance mean and the
-    // spatial terms - ~11 us of loads and a serial loop of one thread that used to sit on top of its share of the
-    // filters - and the filters are dealt to the other parts
-    const bool only_special = special && part == 0;
-    const int fpart = special ? part - 1 : part, fparts = special ? nparts - 1 : nparts;
-    // xp has HV_R zero rows below, patch HV_R zero columns to the right of the data: the register
-    // windows of the two passes run over the edge unconditionally (a conditional LDS read is
-    // waited for one by one)
-    const int pp = pw + HV_R;                           // patch row pitch
-    const int cw = BIG ? cwarg : P.sw;                  // columns of the x-filtered patch held at a time (a multiple of HV_R, or sw)
-    double* xp = hp_smem;                               // [pw + HV_R][cw]
-    double* w0 = (BIG && w0g) ? w0g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)P.npix
-                              : xp + (size_t)(pw + HV_R) * cw;         // [npix]
-    double* red = (BIG && w0g) ? xp + (size_t)(pw + HV_R) * cw : w0 + P.npix;   // [8]
-    float* patch = reinterpret_cast<float*>(red + 8);   // [pw][pp]
-    // (loads in batches, stores after: a loop of load -> store pays one memory latency per
-    // iteration, and after the first round a cell's latency is the kernel time)
-    for (int k0 = tid; !only_special && k0 < pw * pw; k0 += HV_THREADS * 10) {
-        float t[10];
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            const int k = k0 + HV_THREADS * u;
-            const int yy = k / pw, xx = k - yy * pw;
-            t[u] = (k < pw * pw) ? ref[(size_t)(cc.y - P.hw + yy) * P.nx + (cc.x - P.hw + xx)] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-            const int k = k0 + HV_THREADS * u;
-            const int yy = k / pw, xx = k - yy * pw;
-            if (k < pw * pw) patch[yy * pp + xx] = t[u];
-        }
-    }
-    for (int k = tid; k < pw * HV_R; k += HV_THREADS) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
-    for (int k = tid; k < HV_R * cw; k += HV_THREADS) xp[(size_t)pw * cw + k] = 0.0;
-    const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
-    const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
-    double* Xc = X + (size_t)cell * P.nX * P.npixp;
-    // science row, background rows, variance mean, zero padding: part 0
-    double vs = 0.0;
-    // (the first 256 threads, as before: the partial sums of the variance mean keep their grouping)
-    for (int k0 = tid; part == 0 && tid < 256 && k0 < P.npixp; k0 += 256 * 5) {
-        float ts[5], ta[5], tb[5];
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = k0 + 256 * u;
-            ts[u] = ta[u] = tb[u] = 0.f;
-            if (k < P.npix) {
-                const int i = k / sw, j = k - i * sw;
-                const size_t idx = (size_t)(cc.y - hwss + i) * P.nx + (cc.x - hwss + j);
-                ts[u] = sci[idx];
-                ta[u] = srms[idx];
-                tb[u] = trms[idx];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = k0 + 256 * u;
-            if (k < P.npix) {
-                const int i = k / sw, j = k - i * sw;
-                const int x = cc.x - hwss + j, y = cc.y - hwss + i;
-                Xc[(size_t)P.nE * P.npixp + k] = (double)ts[u];
-                const double a = ta[u], b = tb[u];
-                vs += a * a + b * b;
-                const double xf = (x - xc) / hx, yf = (y - yc) / hy;
-                for (int q = 0; q < P.nbg; ++q)
-                    Xc[(size_t)(P.nc + q) * P.npixp + k] = ipowd(xf, P.bpi[q]) * ipowd(yf, P.bpj[q]);
-            } else if (k < P.npixp) {
-                for (int q = 0; q < P.nX; ++q) Xc[(size_t)q * P.npixp + k] = 0.0;
-            }
-        }
-    }
-    vs = block_sum_waves<HV_THREADS / 64>(vs, red);
-    if (tid == 0 && part == 0) {
-        vbar[cell] = vs / P.npix;
-        double fx = (cc.x - xc) / hx, fy = (cc.y - yc) / hy;
-        // (the spatial terms of the substamp this one replaces stay available to the fused normal-matrix update)
-        // (one thread: the exponent tables sit in the kernel-argument segment - indexed by a lane they are copied
-        // to scratch by every thread of the launch, and the first round took 365 us instead of 220)
-        if (phiold)
-            for (int p = 0; p < P.nkp; ++p) phiold[(size_t)cell * P.nkp + p] = phi[(size_t)cell * P.nkp + p];
-        for (int p = 0; p < P.nkp; ++p)
-            phi[(size_t)cell * P.nkp + p] = ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
-    }
-    __syncthreads();
-    if (only_special) continue;
-    const int nstrip = (sw + HV_R - 1) / HV_R;
-    // basis vectors: for each x filter, one x pass, then a y pass per term using it.
-    // Both passes slide a register window: HV_R outputs share HV_R + 2 HWK loads.
-    // term 0 (subtracted from the later terms, P.tsub0) is built by every part for itself;
-    // only the owner of its x filter stores it
-    int fidx = 0;
-    for (int f = 0; f < P.nf1; ++f) {
-        // (the per-filter term ranges come from the plan: scanning the term table here costs a
-        // scalar load and its latency per entry, 15 x 49 of them per workgroup)
-        const int tn0 = P.tf0[f], tn1 = tn0 + P.tfn[f];
-        if (tn1 == tn0) continue;
-        const bool mine = (fidx % fparts) == fpart;
-        ++fidx;
-        const bool for_w0 = (P.tfx[0] == f);
-        if (!mine && !for_w0) continue;
-        const double* fxv = filt + f * STEP;            // uniform address: scalar loads, no LDS traffic
-        // (one chunk - a loop of constant trip count 1 over constants the compiler folds: the resident form keeps its
-        // 124 registers and two workgroups per CU - unless BIG.  Not a lambda: a closure takes the plan's address,
-        // and the batched kernel then keeps a copy of the plan in scratch - 3.5 KB per lane, the pool 2 x slower)
-        const int nchunks = BIG ? (sw + cw - 1) / cw : 1;
-        for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = BIG ? ch * cw : 0;
-        const int cwe = BIG ? min(cw, sw - c0) : sw;
-        const int nstripc = BIG ? (cwe + HV_R - 1) / HV_R : nstrip;
-        // x pass: xp[yy][j] = sum_m fx[2 HWK - m] patch[yy][j + m]
-        for (int e = tid; e < pw * nstripc; e += HV_THREADS) {
-            const int yy = e / nstripc, jl0 = (e - yy * nstripc) * HV_R, j0 = c0 + jl0;
-            const float* pr = patch + yy * pp + j0;
-            double wv[WIN];
-#pragma unroll
-            for (int k = 0; k < WIN; ++k) wv[k] = (double)pr[k];      // j0 + k < pw + HV_R: zeros beyond pw
-            double acc[HV_R];
-#pragma unroll
-            for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
-#pragma unroll
-            for (int m = 0; m < STEP; ++m) {
-                const double cf = fxv[2 * HWK - m];
-#pragma unroll
-                for (int q = 0; q < HV_R; ++q) acc[q] += cf * wv[q + m];
-            }
-#pragma unroll
-            for (int q = 0; q < HV_R; ++q)
-                if (j0 + q < sw) xp[yy * cw + jl0 + q] = acc[q];
-        }
-        __syncthreads();
-        for (int n = tn0; n < tn1; ++n) {
-            if (!mine && n != 0) continue;
-            const double* fyv = filt + P.tfy[n] * STEP;
-            const double sc = P.tscale[n];
-            const bool sub0 = n != 0 && P.tsub0[n] != 0;
-            // y pass: W[i][j] = sum_m fy[2 HWK - m] xp[i + m][j]
-            for (int e = tid; e < cwe * nstrip; e += HV_THREADS) {
-                const int s = e / cwe, jl = e - s * cwe, j = c0 + jl;      // consecutive lanes = consecutive columns
-                const int i0 = s * HV_R;
-                const double* col = xp + i0 * cw + jl;
-                double wv[WIN];
-#pragma unroll
-                for (int k = 0; k < WIN; ++k) wv[k] = col[k * cw];        // rows >= pw are zero
-                double acc[HV_R];
-#pragma unroll
-                for (int q = 0; q < HV_R; ++q) acc[q] = 0.0;
-#pragma unroll
-                for (int m = 0; m < STEP; ++m) {
-                    const double cf = fyv[2 * HWK - m];
-#pragma unroll
-                    for (int q = 0; q < HV_R; ++q) acc[q] += cf * wv[q + m];
-                }
-                // term 0's vector is read for all eight outputs at once, outside any per-pixel
-                // condition (rows beyond the stamp read a clamped, unused entry)
-                double wsub[HV_R];
-#pragma unroll
-                for (int q = 0; q < HV_R; ++q) wsub[q] = 0.0;
-                if (sub0) {
-#pragma unroll
-                    for (int q = 0; q < HV_R; ++q) wsub[q] = w0[min(i0 + q, sw - 1) * sw + j];
-                }
-#pragma unroll
-                for (int q = 0; q < HV_R; ++q) {
-                    const int i = i0 + q;
-                    const int k = i * sw + j;
-                    const double v = acc[q] * sc - wsub[q];
-                    if (i < sw) {
-                        if (n == 0) w0[k] = v;
-                        if (mine) Xc[(size_t)n * P.npixp + k] = v;
-                    }
-                }
-            }
-            if (n == 0) __syncthreads();
-        }
-        __syncthreads();
-        }   // column chunks
-    }
-    }   // cells
-}
 
 // ---------------------------------------------------------------------------
 // G = X X^T, 64 x 64 fp64, on the f64 matrix cores.
@@ -1704,587 +1385,9 @@ __global__ __launch_bounds__(256) void k_chol_fused(int n, int lda, int W, doubl
 #undef CF_TICK
 }
 
-// ---- the fused factorisation with 64-column super-steps (round 4) ---------------------------
-// k_chol_fused above spends a step of 32 columns on two cross-XCD hand-offs (panel barrier + panel
-// loads, update barrier + coefficient loads: ~10 of its 13 us) around ~3 us of arithmetic.  Here two
-// blocks share one pair of hand-offs:
-//   all    load the chain coefficients of blocks kb AND kb + 1 and the 32 x 32 block L21 between them
-//          (published by the look-ahead workgroup during the previous super-step) and solve their panel
-//          rows in two chained stages: X1 = B1 L_kb^-T; B2 - X1 L21^T on the matrix cores (what the tile
-//          update of step kb did to these columns); X2 = (...) L_kb+1^-T.                       | arrive b1
-//   wg 0   owns the 64 rows of the next TWO diagonal blocks: from its own X rows it forms, factors and
-//          publishes block kb + 2, solves the 32 rows of block kb + 3 against it (the next L21), forms,
-//          factors and publishes block kb + 3 - while
-//   wg>0   wait b1 and apply the rank-64 update to their 64 x 64 tiles (K = 64 per tile).       | barrier b2
-// Every entry sees the operations of k_chol_fused in the same order - the chain of its block column, the
-// matrix-core products in ascending chunks of four columns with the negated row operand - so the bits do
-// not change (tests/test_subtract_gpu.py compares the forms and k_chol_tp bit for bit).  A tail of fewer
-// than 64 full columns runs the one-block steps of k_chol_fused.  Four publish slots (blocks kb .. kb + 3).
-//
-// MEASURED (MI355X, 9 x 722 unknowns, W = 26; ZM_CHOL_PROF phase clocks): 301 us per factorisation against 263 us
-// for k_chol_fused - NOT faster, which is why it is opt-in (ZM_CHOL_STEP=64).  The super-step trades two
-// hand-offs of the other workgroups for a longer serial chain in the look-ahead workgroup, and that chain
-// becomes the critical path: per super-step its own 64 panel rows 10.2 us (eight half strips on four waves:
-// two rounds of chain 2.1 + products 0.5 + chain 2.1 + stores 0.4), first block 6.5 us (corner update 0.5,
-// 32 x 32 factor 4.7, publish 1.2), second block 10.8 us (update, solve, update, factor, publish), in all
-// ~30 us, while the other workgroups finish in ~18 us (load 4, panel 4, barrier 2, tiles 5 - 8) and wait
-// 9 - 14 us at the closing barrier.  Two one-block steps cost 2 x 11.4 us.  The floor of the look-ahead chain
-// (two 32 x 32 factors + the solve between them, ~17 us per 64 columns) is what the others' four hand-offs
-// cost: a super-step can only pay with a faster diagonal factor.  Kept as the record of that experiment and
-// as a second, independently written implementation the bit-identity tests run against.
-#define CF2_LDP (2 * CH_NB + 2)          // LDS pitch of the 64-column panels: conflict-free b64 operand reads
-struct cf2_lds {
-    double D[CH_NB][CH_NB + 1];
-    double2 Cf[2][CH_NB][16];             // chain coefficients of the two blocks of a super-step
-    double Rd[2][CH_NB];
-    double Lb[CH_NB][CH_NB + 2];          // L21: rows = columns of block kb + 1, columns = those of block kb
-    double Xs[4][16][CH_NB + 2];          // per wave: -X1 of its half strip (row operand of B2 - X1 L21^T)
-    double Li[64][CF2_LDP];               // tile panels (wg 0: its 64 X rows)
-    double Lj[64][CF2_LDP];               // (wg 0: scratch of the look-ahead solve)
-};
-
-template <bool PROF>
-__global__ __launch_bounds__(256) void k_chol_fused2(int n, int lda, int W, double* Aall, double* Dgall, int* fail,
-                                                     int* tmo, int spin_limit, unsigned* bar, long long* prof,
-                                                     const int* __restrict__ guard) {
-    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
-    long long pt[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // phase clocks (100 MHz), PROF only
-#define CF2_TICK(k) do { if (PROF) { long long t_ = wall_clock64(); pt[k] += t_ - tc; tc = t_; } } while (0)
-    if (PROF) tc = wall_clock64();
-    extern __shared__ double cf2_smem[];
-    cf2_lds& S = *reinterpret_cast<cf2_lds*>(cf2_smem);
-    const int reg = blockIdx.x / W, w = blockIdx.x - reg * W;
-    double* A = Aall + (size_t)reg * (size_t)(n + 1) * lda;
-    double* Dg4 = Dgall + (size_t)reg * 4 * CH_NB * (CH_NB + 1);
-    unsigned* ctr1 = bar + reg * CF_BAR_STRIDE;          // [0] panel barrier, [1] timed-out flag,
-    unsigned* ctr2 = ctr1 + 2;                           // [2] update barrier (its flag is [3])
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int nrows = n + 1;
-    const int nblk = (n + CH_NB - 1) / CH_NB;
-    unsigned gen1 = 0, gen2 = 0;
-    // factor the diagonal block held (unfactored, lower triangle) in S.D; publish it in slot `blk & 3`, keep the
-    // coefficients in S.Cf[ci] / S.Rd[ci]
-    auto factor_and_publish = [&](int kk0, int nb, int blk, int ci) {
-        double* Dg = Dg4 + (size_t)(blk & 3) * CH_NB * (CH_NB + 1);
-        __syncthreads();
-        if (tid < 64) chol_diag_wave_panel_t<0>(S.D, nb, &fail[reg]);
-        __syncthreads();
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int m = e >> 5, i = e & 31;                      // column m of row i
-            const double cv = (i > m) ? -(S.D[i][m] * S.D[m][CH_NB]) : 0.0;
-            reinterpret_cast<double*>(&S.Cf[ci][m][i & 15])[i >> 4] = cv;
-            st_sh(&Dg[2 * (m * 16 + (i & 15)) + (i >> 4)], cv);
-            if (i < nb && m <= i) st_sh(&A[(size_t)(kk0 + i) * lda + kk0 + m], S.D[i][m]);
-        }
-        if (tid < CH_NB) {
-            S.Rd[ci][tid] = S.D[tid][CH_NB];
-            st_sh(&Dg[CH_NB * CH_NB + tid], S.D[tid][CH_NB]);
-        }
-    };
-    // fetch the published coefficients of block `blk` into S.Cf[ci] / S.Rd[ci] (loads first, stores after)
-    auto coef_load = [&](int blk, double (&dv)[5]) {
-        const double* Dg = Dg4 + (size_t)(blk & 3) * CH_NB * (CH_NB + 1);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) dv[q] = ld_sh(&Dg[min(tid + 256 * q, CH_NB * (CH_NB + 1) - 1)]);
-    };
-    auto coef_put = [&](int ci, const double (&dv)[5]) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = tid + 256 * q;
-            if (e < CH_NB * CH_NB) reinterpret_cast<double*>(&S.Cf[ci][0][0])[e] = dv[q];
-            else if (e < CH_NB * (CH_NB + 1)) S.Rd[ci][e - CH_NB * CH_NB] = dv[q];
-        }
-    };
-    // wg 0: the second block of a pair.  Rows k + 32 .. k + 63 (k = first column of the pair): solve them against
-    // the factor in S.Cf[0] (-> the block L21 of the next super-step, to A and S.Lb), then form, factor and
-    // publish the diagonal block `blk` at k + 32.  withx: the rows carry the rank-64 update of the 64 X rows in
-    // S.Li (rows 0 .. 31 the first block's, 32 .. 63 this block's); without (the prologue) A is taken as it is.
-    auto second_block = [&](int k, int blk, bool withx, const double (&cB)[4], const double (&cD)[4]) {
-        const int ti = wave >> 1, tj = wave & 1;
-        {
-            double4_t c4 = {cB[0], cB[1], cB[2], cB[3]};
-            if (withx) {
-#pragma unroll
-                for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
-                    const double a = -S.Li[32 + 16 * ti + li][4 * kk + lk];
-                    const double b = S.Li[16 * tj + li][4 * kk + lk];
-                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) S.Lj[16 * ti + lk + 4 * q][16 * tj + li] = c4[q];
-        }
-        __syncthreads();
-        {
-            // four half strips on four waves: rows lk + 4 (2 half + h) of strip `strip`
-            const int strip = wave >> 1, half = wave & 1;
-            double xb[2][2], x0[2], x1[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) xb[c][h] = S.Lj[16 * strip + lk + 4 * (2 * half + h)][16 * c + li];
-            cf_chain(xb, S.Cf[0], S.Rd[0], li, x0, x1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 16 * strip + lk + 4 * (2 * half + h);
-                st_sh(&A[(size_t)(k + 32 + r) * lda + k + li], x0[h]);
-                st_sh(&A[(size_t)(k + 32 + r) * lda + k + 16 + li], x1[h]);
-                S.Lb[r][li] = x0[h];
-                S.Lb[r][16 + li] = x1[h];
-            }
-        }
-        __syncthreads();
-        {
-            double4_t c4 = {cD[0], cD[1], cD[2], cD[3]};
-            if (tj <= ti) {
-                if (withx) {
-#pragma unroll
-                    for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
-                        const double a = -S.Li[32 + 16 * ti + li][4 * kk + lk];
-                        const double b = S.Li[32 + 16 * tj + li][4 * kk + lk];
-                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int kk = 0; kk < CH_NB / 4; ++kk) {
-                    const double a = -S.Lb[16 * ti + li][4 * kk + lk];
-                    const double b = S.Lb[16 * tj + li][4 * kk + lk];
-                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
-                S.D[i][j] = (j <= i) ? c4[q] : 0.0;
-            }
-        }
-        factor_and_publish(k + 32, CH_NB, blk, 1);
-    };
-    // a 32 x 32 block of A at (r0, c0) in the accumulator layout, one 16 x 16 quadrant per wave; clamped, not masked
-    auto fetch_quadrant = [&](int r0, int c0, double (&c)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = 16 * (wave >> 1) + lk + 4 * q, j = 16 * (wave & 1) + li;
-            c[q] = ld_sh(&A[(size_t)min(r0 + i, nrows - 1) * lda + min(c0 + j, n - 1)]);
-        }
-    };
-    const bool pairs = n >= 2 * CH_NB;                   // at least one super-step
-    if (w == 0) {
-        const int nb0 = min(CH_NB, n);
-        double cB[4], cD[4];
-        if (pairs) { fetch_quadrant(CH_NB, 0, cB); fetch_quadrant(CH_NB, CH_NB, cD); }
-        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-            const int i = e >> 5, j = e & 31;
-            S.D[i][j] = (i < nb0 && j <= i) ? ld_sh(&A[(size_t)i * lda + j]) : (i == j ? 1.0 : 0.0);
-        }
-        factor_and_publish(0, nb0, 0, 0);
-        if (pairs) {
-            __syncthreads();
-            second_block(0, 1, false, cB, cD);
-        }
-    }
-    gen2 += W;
-    bool dead = region_barrier(ctr2, gen2, spin_limit);
-    int kb = 0;
-    while (kb < nblk && !dead) {
-        const int k0 = kb * CH_NB;
-        if (n - k0 >= 2 * CH_NB) {
-            // ================= a super-step: blocks kb and kb + 1 =================
-            const int k1 = k0 + CH_NB, k2 = k0 + 2 * CH_NB;
-            const int below = nrows - k2;                            // panel rows (>= 1: the rhs row)
-            const int nb2 = max(0, min(CH_NB, n - k2));              // size of block kb + 2
-            const bool next_pair = n - k2 >= 2 * CH_NB;              // the next step is a super-step too
-            const int r0n = min(next_pair ? 2 * CH_NB : CH_NB, below);
-            const int per = (below - r0n + W - 2) / (W - 1);
-            const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
-            const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
-            const int nslice = max(pend - pbeg, 0);
-            const int ntask = 2 * ((nslice + 15) >> 4);
-            // wg 0: the unfactored blocks it will need, fetched ahead (final since the last barrier)
-            double cD2[4] = {0, 0, 0, 0}, cB[4] = {0, 0, 0, 0}, cD3[4] = {0, 0, 0, 0};
-            if (w == 0 && nb2 > 0) {
-                fetch_quadrant(k2, k2, cD2);
-                if (next_pair) { fetch_quadrant(k2 + CH_NB, k2, cB); fetch_quadrant(k2 + CH_NB, k2 + CH_NB, cD3); }
-            }
-            // tiles of the trailing matrix (rows / columns >= k2), 64 x 64, K = 64; tile 0 is wg 0's when it
-            // holds both next blocks
-            const int T = (below + 63) / 64;
-            const int t0 = next_pair ? 1 : 0;
-            const int ntile = T * (T + 1) / 2;
-            const int Wu = W - 1, wu = w - 1;
-            auto tile_of = [&](int t, int& i0, int& j0) {
-                int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-                while (ti * (ti + 1) / 2 > t) --ti;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                i0 = k2 + ti * 64;
-                j0 = k2 + tj * 64;
-            };
-            double4_t accn[4];
-            double pa[16], pb[16];
-            auto tile_fetch_acc = [&](int t) {
-                int i0, j0;
-                tile_of(t, i0, j0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                        accn[c][rg] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
-                    }
-            };
-            auto tile_fetch_panels = [&](int t) {
-                int i0, j0;
-                tile_of(t, i0, j0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int e = tid + 256 * q, r = e >> 6, m = e & 63;
-                    pa[q] = ld_sh(&A[(size_t)min(i0 + r, nrows - 1) * lda + k0 + m]);
-                    pb[q] = ld_sh(&A[(size_t)min(j0 + r, nrows - 1) * lda + k0 + m]);
-                }
-            };
-            if (w != 0 && t0 + wu < ntile) tile_fetch_acc(t0 + wu);
-            // ---- phase A: the panel rows of this workgroup, two chained stages per half strip
-            double xb1[2][2], xb2[2][2];
-            auto panel_fetch = [&](int t, double (&a1)[2][2], double (&a2)[2][2]) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int prow = k2 + pbeg + 16 * (t >> 1) + lk + 4 * (2 * (t & 1) + h);
-                        const size_t ro = (size_t)min(prow, nrows - 1) * lda;
-                        a1[c][h] = ld_sh(&A[ro + k0 + 16 * c + li]);
-                        a2[c][h] = ld_sh(&A[ro + k1 + 16 * c + li]);
-                    }
-            };
-            if (wave < ntask) panel_fetch(wave, xb1, xb2);
-            __syncthreads();                                         // LDS of the previous step is consumed
-            if (w != 0) {
-                double dv0[5], dv1[5], lb[4];
-                coef_load(kb, dv0);
-                coef_load(kb + 1, dv1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = tid + 256 * q, r = e >> 5, m = e & 31;
-                    lb[q] = ld_sh(&A[(size_t)(k1 + r) * lda + k0 + m]);
-                }
-                coef_put(0, dv0);
-                coef_put(1, dv1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = tid + 256 * q;
-                    S.Lb[e >> 5][e & 31] = lb[q];
-                }
-            }
-            __syncthreads();
-            CF2_TICK(0);
-            for (int t = wave; t < ntask; t += 4) {
-                double x0[2], x1[2], y0[2], y1[2];
-                cf_chain(xb1, S.Cf[0], S.Rd[0], li, x0, x1);
-                const int half = t & 1;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int rr = lk + 4 * (2 * half + h);
-                    S.Xs[wave][rr][li] = -x0[h];
-                    S.Xs[wave][rr][16 + li] = -x1[h];
-                }
-                // B2 - X1 L21^T: the 16 x 32 product of the strip (the other half's rows are whatever the buffer
-                // holds: rows of a matrix-core product do not mix), accumulators = B2 in this wave's two rows
-                // (this wave's rows are accumulator rows 2 half, 2 half + 1; the other two start from the same values
-                // and end as garbage nobody reads - no register is indexed by `half`)
-                double4_t acc[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) acc[c] = double4_t{xb2[c][0], xb2[c][1], xb2[c][0], xb2[c][1]};
-#pragma unroll
-                for (int kk = 0; kk < CH_NB / 4; ++kk) {
-                    const double a = S.Xs[wave][li][4 * kk + lk];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const double b = S.Lb[16 * c + li][4 * kk + lk];
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    xb2[c][0] = half ? acc[c][2] : acc[c][0];
-                    xb2[c][1] = half ? acc[c][3] : acc[c][1];
-                }
-                cf_chain(xb2, S.Cf[1], S.Rd[1], li, y0, y1);
-                const int tcur = t;
-                if (t + 4 < ntask) panel_fetch(t + 4, xb1, xb2);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pr = 16 * (tcur >> 1) + lk + 4 * (2 * (tcur & 1) + h), p = pbeg + pr;
-                    if (pr < nslice) {
-                        double* row = &A[(size_t)(k2 + p) * lda];
-                        st_sh(&row[k0 + li], x0[h]);
-                        st_sh(&row[k0 + 16 + li], x1[h]);
-                        st_sh(&row[k1 + li], y0[h]);
-                        st_sh(&row[k1 + 16 + li], y1[h]);
-                    }
-                    if (w == 0 && p < 64) {
-                        const bool live = pr < nslice;
-                        S.Li[p][li] = live ? x0[h] : 0.0;
-                        S.Li[p][16 + li] = live ? x1[h] : 0.0;
-                        S.Li[p][32 + li] = live ? y0[h] : 0.0;
-                        S.Li[p][48 + li] = live ? y1[h] : 0.0;
-                    }
-                }
-            }
-            CF2_TICK(2);
-            if (w == 0) {
-                // panel rows published: arrive, do not wait
-                region_arrive(ctr1);
-                gen1 += W;
-                for (int p = max(pend, 0); p < 64; ++p)              // rows this slice does not have
-                    if (tid < 64) S.Li[p][tid] = 0.0;
-                __syncthreads();
-                if (nb2 > 0) {
-                    {
-                        const int ti = wave >> 1, tj = wave & 1;
-                        double4_t c4 = {cD2[0], cD2[1], cD2[2], cD2[3]};
-                        if (tj <= ti) {
-#pragma unroll
-                            for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
-                                const double a = -S.Li[16 * ti + li][4 * kk + lk];
-                                const double b = S.Li[16 * tj + li][4 * kk + lk];
-                                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
-                            S.D[i][j] = (i < nb2 && j <= i) ? c4[q] : ((i == j) ? 1.0 : 0.0);
-                        }
-                    }
-                    factor_and_publish(k2, nb2, kb + 2, 0);
-                    if (next_pair) {
-                        __syncthreads();
-                        CF2_TICK(3);
-                        second_block(k2, kb + 3, true, cB, cD3);
-                    }
-                }
-                CF2_TICK(4);
-            } else {
-                gen1 += W;
-                dead = region_barrier(ctr1, gen1, spin_limit);
-                CF2_TICK(3);
-                if (dead) break;
-                int t = t0 + wu;
-                if (t < ntile) tile_fetch_panels(t);
-                while (t < ntile) {
-                    int i0, j0;
-                    tile_of(t, i0, j0);
-                    double4_t acc[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = accn[c];
-                    __syncthreads();                       // the previous tile's panels are consumed
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int e = tid + 256 * q, r = e >> 6, m = e & 63;
-                        S.Li[r][m] = -pa[q];
-                        S.Lj[r][m] = pb[q];
-                    }
-                    __syncthreads();
-                    CF2_TICK(1);
-                    const int tn = t + Wu;
-                    if (tn < ntile) { tile_fetch_acc(tn); tile_fetch_panels(tn); }
-#pragma unroll
-                    for (int kk = 0; kk < 2 * CH_NB / 4; ++kk) {
-                        const double a = S.Li[16 * wave + li][4 * kk + lk];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const double b = S.Lj[16 * c + li][4 * kk + lk];
-                            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                            const bool corner = (t == 0) && i < k2 + nb2;              // wg 0's: stored factored instead
-                            if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * lda + j], acc[c][rg]);
-                        }
-                    t = tn;
-                }
-                CF2_TICK(4);
-            }
-            gen2 += W;
-            dead = region_barrier(ctr2, gen2, spin_limit);
-            CF2_TICK(5);
-            kb += 2;
-            continue;
-        }
-        // ================= a one-block step (the tail): k_chol_fused's, on this kernel's buffers =================
-        const int nb = min(CH_NB, n - k0);
-        const int k1 = k0 + nb;                                  // first trailing row / column
-        const int below = nrows - k1;                            // panel rows (the rhs row included)
-        const int nbn = max(0, min(CH_NB, n - k1));              // size of the next diagonal block
-        const int r0n = min(CH_NB, below);
-        const int per = (below - r0n + W - 2) / (W - 1);
-        const int pbeg = (w == 0) ? 0 : r0n + (w - 1) * per;
-        const int pend = (w == 0) ? r0n : min(r0n + w * per, below);
-        double cpre[4] = {0.0, 0.0, 0.0, 0.0};
-        if (w == 0 && nb == CH_NB) fetch_quadrant(k1, k1, cpre);
-        const int T = (max(below, 0) + 63) / 64;
-        const int ntile = T * (T + 1) / 2;
-        const int Wu = W - 1, wu = w - 1;
-        auto tile_of = [&](int t, int& i0, int& j0) {
-            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-            while (ti * (ti + 1) / 2 > t) --ti;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            const int tj = t - ti * (ti + 1) / 2;
-            i0 = k1 + ti * 64;
-            j0 = k1 + tj * 64;
-        };
-        double4_t accn[4];
-        double pa[8], pb[8];
-        auto tile_fetch_acc = [&](int t) {
-            int i0, j0;
-            tile_of(t, i0, j0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                    accn[c][rg] = ld_sh(&A[(size_t)min(i, nrows - 1) * lda + min(j, n - 1)]);
-                }
-        };
-        auto tile_fetch_panels = [&](int t) {
-            int i0, j0;
-            tile_of(t, i0, j0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = tid + 256 * q, r = e >> 5, m = e & 31;
-                pa[q] = ld_sh(&A[(size_t)min(i0 + r, nrows - 1) * lda + k0 + m]);
-                pb[q] = ld_sh(&A[(size_t)min(j0 + r, nrows - 1) * lda + k0 + m]);
-            }
-        };
-        if (w != 0 && nb == CH_NB && wu < ntile) tile_fetch_acc(wu);
-        const int nslice = max(pend - pbeg, 0);
-        const int ntask = 2 * ((nslice + 15) >> 4);
-        double xb[2][2];
-        auto panel_fetch = [&](int t) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int prow = k1 + pbeg + 16 * (t >> 1) + lk + 4 * (2 * (t & 1) + h);
-                    xb[c][h] = ld_sh(&A[(size_t)min(prow, nrows - 1) * lda + min(k0 + 16 * c + li, n - 1)]);
-                }
-        };
-        if (wave < ntask) panel_fetch(wave);
-        __syncthreads();
-        if (w != 0) {
-            double dv[5];
-            coef_load(kb, dv);
-            coef_put(0, dv);
-        }
-        __syncthreads();
-        for (int t = wave; t < ntask; t += 4) {
-            if (nb < CH_NB) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) xb[c][h] = (16 * c + li < nb) ? xb[c][h] : 0.0;
-            }
-            double x0[2], x1[2];
-            cf_chain(xb, S.Cf[0], S.Rd[0], li, x0, x1);
-            const int tcur = t;
-            if (t + 4 < ntask) panel_fetch(t + 4);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pr = 16 * (tcur >> 1) + lk + 4 * (2 * (tcur & 1) + h), p = pbeg + pr;
-                if (pr < nslice) {
-                    if (li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + li], x0[h]);
-                    if (16 + li < nb) st_sh(&A[(size_t)(k1 + p) * lda + k0 + 16 + li], x1[h]);
-                }
-                if (w == 0 && p < CH_NB) {
-                    S.Li[p][li] = (pr < nslice) ? x0[h] : 0.0;
-                    S.Li[p][16 + li] = (pr < nslice) ? x1[h] : 0.0;
-                }
-            }
-        }
-        if (below <= 0 || nb < CH_NB) break;      // nothing trails the last (partial) block
-        if (w == 0) {
-            region_arrive(ctr1);
-            gen1 += W;
-            for (int p = pend; p < CH_NB; ++p)                   // rows this slice does not have
-                if (tid < CH_NB) S.Li[p][tid] = 0.0;
-            __syncthreads();
-            {
-                const int ti = wave >> 1, tj = wave & 1;
-                double4_t c4 = {cpre[0], cpre[1], cpre[2], cpre[3]};
-                if (tj <= ti) {
-#pragma unroll
-                    for (int kk = 0; kk < CH_NB / 4; ++kk) {
-                        const double a = -S.Li[16 * ti + li][4 * kk + lk];
-                        const double b = S.Li[16 * tj + li][4 * kk + lk];
-                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 16 * ti + lk + 4 * q, j = 16 * tj + li;
-                    S.D[i][j] = (i < nbn && j <= i) ? c4[q] : ((i == j) ? 1.0 : 0.0);
-                }
-            }
-            factor_and_publish(k1, nbn, kb + 1, 0);
-        } else {
-            gen1 += W;
-            dead = region_barrier(ctr1, gen1, spin_limit);
-            if (dead) break;
-            int t = wu;
-            if (t < ntile) tile_fetch_panels(t);
-            while (t < ntile) {
-                int i0, j0;
-                tile_of(t, i0, j0);
-                double4_t acc[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = accn[c];
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = tid + 256 * q, r = e >> 5, m = e & 31;
-                    S.Li[r][m] = -pa[q];
-                    S.Lj[r][m] = pb[q];
-                }
-                __syncthreads();
-                const int tn = t + Wu;
-                if (tn < ntile) { tile_fetch_acc(tn); tile_fetch_panels(tn); }
-#pragma unroll
-                for (int kk = 0; kk < CH_NB / 4; ++kk) {
-                    const double a = S.Li[16 * wave + li][4 * kk + lk];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const double b = S.Lj[16 * c + li][4 * kk + lk];
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int i = i0 + 16 * wave + lk + 4 * rg, j = j0 + 16 * c + li;
-                        const bool corner = (t == 0) && i < k1 + nbn;
-                        if (i < nrows && j < n && j <= i && !corner) st_sh(&A[(size_t)i * lda + j], acc[c][rg]);
-                    }
-                t = tn;
-            }
-        }
-        gen2 += W;
-        dead = region_barrier(ctr2, gen2, spin_limit);
-        kb += 1;
-    }
-    if (dead && tid == 0) atomicAdd(&tmo[reg], 1);
-    if (PROF && prof && tid == 0) {
-        // (the panel phase of this wave in detail: chain 1, products, chain 2, stores; folded into slot 2 for the host's table)
-        for (int k = 0; k < 6; ++k) prof[blockIdx.x * 6 + k] = pt[k];
-    }
-#undef CF2_TICK
-}
-
+// (Round 4 also built this factorisation with 64-column super-steps, k_chol_fused2: the same bits, 301 against 263 us -
+// the look-ahead workgroup became the critical path.  Measured, written down in DESIGN.md section 4, removed in
+// round 6.)
 // ---- the same factorisation, cheap in CU-time instead of short --------------------------
 // ---- the factorisation as a data-flow of resident tiles (round 4) ---------------------------
 // k_chol_fused moves every trailing entry through memory once per block step (accumulators in, accumulators
@@ -3365,652 +2468,6 @@ __global__ void k_hp_init_active(const hp_plan P, const int2* __restrict__ centr
     if (has) atomicAdd(&ntotal[cell / P.ncellr], 1);
 }
 
-// background coefficient t of a region's solution vector
-__device__ inline double xs_bg(const double* __restrict__ xsol, int reg, const hp_plan& P, int t) {
-    return xsol[(size_t)reg * P.nunk + 1 + (size_t)(P.nc - 1) * P.nkp + t];
-}
-
-// ---------------------------------------------------------------------------
-// Apply.  One workgroup = NB consecutive kernel blocks of one block row; each lane
-// owns R consecutive output pixels of one row of one block and slides a register
-// window over the LDS tile; kernel taps come from LDS (few distinct addresses per
-// wave: broadcast).  Template and template-variance planes are convolved together.
-// worst number of lanes of a half wave that meet in one of the 64 LDS banks when lane l reads the
-// float2 at (l / lpr) * pitch + (l % lpr) * r: the window loads of the convolution
-constexpr int apply_bank_passes(int pitch, int lpr, int r, int step) {
-    int worst = 0;
-    for (int half = 0; half < 2; ++half) {
-        int cnt[64] = {};
-        for (int l = 32 * half; l < 32 * half + 32; ++l) {
-            const int row = l / lpr, strip = l % lpr;
-            if (row >= step) continue;
-            const int e = row * pitch + strip * r;
-            ++cnt[(2 * e) % 64];
-            ++cnt[(2 * e + 1) % 64];
-        }
-        for (int b = 0; b < 64; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
-    }
-    return worst;
-}
-// smallest row pitch >= width (at most 16 more) with the fewest bank conflicts
-constexpr int apply_pitch(int width, int lpr, int r, int step) {
-    int best = width, bw = apply_bank_passes(width, lpr, r, step);
-    for (int p = width + 1; p <= width + 16; ++p) {
-        const int w = apply_bank_passes(p, lpr, r, step);
-        if (w < bw) { bw = w; best = p; }
-    }
-    return best;
-}
-
-constexpr int apply_pitch_n(int width, int lpr, int r, int step, int range) {
-    int best = width, bw = apply_bank_passes(width, lpr, r, step);
-    for (int p = width + 1; p <= width + range; ++p) {
-        const int w = apply_bank_passes(p, lpr, r, step);
-        if (w < bw) { bw = w; best = p; }
-    }
-    return best;
-}
-
-template <int HWK> struct apply_cfg {
-    enum { STEP = 2 * HWK + 1,
-           LPR = (STEP <= 11) ? 1 : (STEP <= 22 ? 2 : 3),   // lanes per block row
-           R = (STEP + LPR - 1) / LPR,
-           LPB = STEP * LPR,                 // lanes per block
-           NB = 256 / LPB > 0 ? 256 / LPB : 1,
-           TW = NB * STEP + 2 * HWK,         // tile width
-           TP = apply_pitch(NB * STEP + 2 * HWK, LPR, (STEP + LPR - 1) / LPR, STEP) };   // tile row pitch
-};
-
-template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply(const hp_plan P, const unsigned long long* __restrict__ solved_mask,
-                                                  const float* __restrict__ sci,
-                                                  const float* __restrict__ ref,
-                                                  const float* __restrict__ srms,
-                                                  const float* __restrict__ trms,
-                                                  const uint8_t* __restrict__ outbad,
-                                                  const double* __restrict__ filt,    // [nf1][STEP] 1-D filters
-                                                  const double* __restrict__ xsol,
-                                                  float* __restrict__ diff,
-                                                  float* __restrict__ noise,
-                                                  int* __restrict__ nmasked) {
-    // every region in one launch: blockIdx.z = region (the grid covers the largest one)
-    const int reg = blockIdx.z;
-    const int solved = (int)((*solved_mask >> reg) & 1ull);      // (k_hp_solved: the fit's outcome, read on the device)
-    typedef apply_cfg<HWK> C;
-    constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, LPB = C::LPB, NB = C::NB;
-    constexpr int TW = C::TW;                 // tile width
-    constexpr int TP = C::TP;                 // row pitch of the tile in LDS (bank-conflict padding)
-    constexpr int TH = STEP + 2 * HWK;
-    // LDS: template and template variance interleaved ({T, V} pairs), the per-block kernel as
-    // {k, k^2} pairs: one v_pk_fma_f32 per tap and pixel feeds both planes, one ds_read_b64 per
-    // operand
-    typedef float ap_v2f __attribute__((ext_vector_type(2)));
-    extern __shared__ float ap_smem[];
-    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(ap_smem);              // [TH][TP]
-    // the tile's space first serves the kernel evaluation (solution vector, term scales, 1-D
-    // filters, g_f, s0: nunk + nc + (NB + 1) nf1 STEP + NB doubles) and last the output staging
-    const int tvn = max(TH * TP, P.nunk + 2 * P.nc + (NB + 1) * P.nf1 * STEP + NB + 2 * NB * P.nkp);
-    ap_v2f* kc = tTV + tvn;                                        // [NB][STEP*STEP]
-    double* cf = reinterpret_cast<double*>(kc + NB * STEP * STEP);  // [NB][nc]
-    __shared__ int wmask[4];
-    double* xs = reinterpret_cast<double*>(ap_smem);                // [nunk] this region's solution
-    double* ts = xs + P.nunk;                                       // [nc] term scales
-    double* sb = ts + P.nc;                                         // [nc] 1.0 where term 0 is subtracted, else 0.0
-    double* fl = sb + P.nc;                                         // [nf1][STEP]
-    double* gf = fl + P.nf1 * STEP;                                 // [NB][nf1][STEP]
-    double* s0v = gf + NB * P.nf1 * STEP;                           // [NB] sum of the c_n with sub0_n
-    double* pxy = s0v + NB;                                         // [NB][nkp][2] x^i, y^j at the block centres
-    const int tid = threadIdx.x;
-    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
-    const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
-    const int gy0 = y0r + blockIdx.y * STEP;
-    if (gx0 >= x1r || gy0 >= y1r) return;              // beyond this (smaller) region
-    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
-    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
-    const double* x = xsol + (size_t)reg * P.nunk;
-    // tables into LDS, every load of a thread issued before its first store (a copy loop pays a
-    // memory latency per iteration; the exponent tables sit in the kernel-argument segment, and
-    // indexing them inside the polynomial loop below would cost two latencies per term)
-    for (int e0 = tid; e0 < P.nunk; e0 += 256 * 4) {
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = (e0 + 256 * u < P.nunk) ? x[e0 + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + 256 * u < P.nunk) xs[e0 + 256 * u] = t[u];
-    }
-    for (int e0 = tid; e0 < P.nf1 * STEP; e0 += 256 * 4) {
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = (e0 + 256 * u < P.nf1 * STEP) ? filt[e0 + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + 256 * u < P.nf1 * STEP) fl[e0 + 256 * u] = t[u];
-    }
-    for (int e = tid; e < P.nc; e += 256) { ts[e] = P.tscale[e]; sb[e] = P.tsub0[e] ? 1.0 : 0.0; }
-    for (int e = tid; e < NB * P.nkp; e += 256) {
-        const int b = e / P.nkp, pp = e - b * P.nkp;
-        const double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
-        pxy[2 * e] = ipowd(fx, P.kpi[pp]);
-        pxy[2 * e + 1] = ipowd(fy, P.kpj[pp]);
-    }
-    __syncthreads();
-    // per-block basis coefficients at the nominal block centre (fp64)
-    for (int e = tid; e < NB * P.nc; e += 256) {
-        int b = e / P.nc, n = e - b * P.nc;
-        double v;
-        if (n == 0) v = xs[0];
-        else {
-            v = 0.0;
-            const double* xb = xs + 1 + (n - 1) * P.nkp;
-            const double* pb = pxy + 2 * b * P.nkp;
-            for (int p = 0; p < P.nkp; ++p) v += xb[p] * pb[2 * p] * pb[2 * p + 1];
-        }
-        cf[e] = v;
-    }
-    __syncthreads();
-    if (tid < NB) {
-        // (flags staged in LDS with the scales: a scalar table load per term would sit in this
-        // loop's critical path while the rest of the workgroup waits at the barrier)
-        double t = 0.0;
-        for (int n = 0; n < P.nc; ++n) t += cf[tid * P.nc + n] * sb[n];
-        s0v[tid] = t;
-    }
-    __syncthreads();
-    // the block kernels from the separable form of the basis, all operands in LDS:
-    //   K[v][u] = sum_n c_n (s_n fy_n[v] fx_n[u] - [sub0_n] s_0 fy_0[v] fx_0[u]) = sum_f fx_f[u] g_f[v],
-    //   g_f[v] = sum_{n: fx_n = f} c_n s_n fy_n[v]  -  [f = fx_0] (sum_{n: sub0_n} c_n) s_0 fy_0[v]
-    // 15 terms per tap instead of 49 fp64 rows of the 2-D basis fetched from L2.  The terms of
-    // Gaussian g are ordered (a, b): those sharing the x filter base_g + a are consecutive.
-    for (int e = tid; e < NB * STEP * P.ngauss; e += 256) {
-        const int g = e / (NB * STEP), r = e - g * NB * STEP;
-        const int b = r / STEP, v = r - b * STEP;
-        const double* cb = cf + b * P.nc;
-        const int deg = P.gdeg[g], fb = P.gbase[g];
-        int n = P.gterm0[g];
-        for (int a = 0; a <= deg; ++a) {
-            double acc = 0.0;
-            for (int bb = 0; bb <= deg - a; ++bb, ++n) acc += cb[n] * ts[n] * fl[(fb + bb) * STEP + v];
-            if (fb + a == P.tfx[0])                                 // the x filter of term 0
-                acc -= s0v[b] * ts[0] * fl[P.tfy[0] * STEP + v];
-            gf[((size_t)b * P.nf1 + fb + a) * STEP + v] = acc;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < NB * STEP * STEP; e += 256) {
-        const int b = e / (STEP * STEP), tap = e - b * STEP * STEP;
-        const int v = tap / STEP, u = tap - v * STEP;
-        const double* gb = gf + (size_t)b * P.nf1 * STEP + v;
-        double acc = 0.0;
-#pragma unroll 5
-        for (int f = 0; f < P.nf1; ++f) acc += fl[f * STEP + u] * gb[f * STEP];
-        const float k = (float)acc;
-        kc[e] = (ap_v2f){k, k * k};
-    }
-    const double bg0 = xs[1 + (size_t)(P.nc - 1) * P.nkp];       // constant background term
-    const float norm = P.normalize ? (float)(1.0 / xs[0]) : 1.f;
-    __syncthreads();                                   // the evaluation scratch is free
-    // tile of template and template variance (zeros outside the frame / non-finite)
-    // (every load of a thread goes out before the first LDS store: one memory latency per
-    // workgroup instead of one per loop iteration)
-    {
-        constexpr int NIT = (TH * TW + 255) / 256;
-        float tt[NIT], tr[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + 256 * it;
-            const int yy = e / TW, xx = e - yy * TW;
-            const int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
-            tt[it] = 0.f;
-            tr[it] = 0.f;
-            if (e < TH * TW && gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
-                const size_t idx = (size_t)gy * P.nx + gx;
-                tt[it] = ref[idx];
-                tr[it] = trms[idx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + 256 * it;
-            float t = tt[it], v = tr[it] * tr[it];
-            if (!(fabsf(t) < 3e38f)) t = 0.f;
-            if (!(fabsf(v) < 3e38f)) v = 0.f;
-            if (e < TH * TW) tTV[(e / TW) * TP + e % TW] = (ap_v2f){t, v};
-        }
-    }
-    __syncthreads();
-    const int b = tid / LPB;
-    const int l = tid - b * LPB;
-    const int row = l / LPR, strip = l - row * LPR;
-    const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
-    const bool live = b < NB && gy0 + row < y1r && gy0 + row < P.ny;
-    ap_v2f acc2[R];                                    // {sum k T, sum k^2 V}
-#pragma unroll
-    for (int q = 0; q < R; ++q) acc2[q] = (ap_v2f){0.f, 0.f};
-    if (live) {
-        const ap_v2f* kb = kc + b * STEP * STEP;
-        // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
-        for (int v = -HWK; v <= HWK; ++v) {
-            const ap_v2f* rt = tTV + (row + HWK - v) * TP + ox0;    // T(x - u): column ox0 + q + HWK - u
-            ap_v2f w2[R + 2 * HWK];
-#pragma unroll
-            for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[q];
-            const ap_v2f* kr = kb + (v + HWK) * STEP;
-#pragma unroll
-            for (int u = -HWK; u <= HWK; ++u) {
-                const ap_v2f k2 = kr[u + HWK];
-#pragma unroll
-                for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
-            }
-        }
-    }
-    // the sums go through LDS (the tile's space) so that the science / noise planes are read and
-    // the outputs written along rows: NB STEP consecutive pixels per row instead of R per thread
-    constexpr int OW = NB * STEP;
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-            if (strip * R + q < STEP) tTV[row * OW + ox0 + q] = acc2[q];
-    }
-    __syncthreads();
-    int masked = 0;
-    {
-        constexpr int NE = (STEP * OW + 255) / 256;
-        float es[NE], er[NE];
-        bool eb[NE], ein[NE];
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            const int e = tid + 256 * it;
-            const int orow = e / OW, ocol = e - orow * OW;
-            const int gx = gx0 + ocol, gy = gy0 + orow;
-            ein[it] = e < STEP * OW && gx < x1r && gx < P.nx && gy < y1r && gy < P.ny;
-            es[it] = er[it] = 0.f;
-            eb[it] = true;
-            if (ein[it]) {
-                const size_t idx = (size_t)gy * P.nx + gx;
-                eb[it] = outbad[idx] != 0;
-                es[it] = sci[idx];
-                er[it] = srms[idx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            if (!ein[it]) continue;
-            const int e = tid + 256 * it;
-            const int orow = e / OW, ocol = e - orow * OW;
-            const int gx = gx0 + ocol, gy = gy0 + orow;
-            const size_t idx = (size_t)gy * P.nx + gx;
-            float d = P.fi, nz = P.fin;
-            if (solved && !eb[it]) {
-                double bg = bg0;
-                if (P.nbg > 1) {
-                    const double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
-                    bg = 0.0;
-                    for (int t = 0; t < P.nbg; ++t)
-                        bg += xs_bg(xsol, reg, P, t) * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
-                }
-                const ap_v2f a = tTV[e];
-                d = (es[it] - a.x - (float)bg) * norm;
-                nz = sqrtf(fmaxf(er[it] * er[it] + a.y, 0.f)) * fabsf(norm);
-            } else {
-                masked += 1;
-            }
-            diff[idx] = d;
-            noise[idx] = nz;
-        }
-    }
-    // one atomic per workgroup
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) masked += __shfl_xor(masked, o);
-    if ((tid & 63) == 0) wmask[tid >> 6] = masked;
-    __syncthreads();
-    if (tid == 0) {
-        const int tot = wmask[0] + wmask[1] + wmask[2] + wmask[3];
-        if (tot) atomicAdd(nmasked, tot);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Apply, one wave per kernel block (round 4).  k_hp_apply above spends more time around its convolution than in
-// it (41 % of the vector issue slots at 3 waves per SIMD): every workgroup first evaluates its blocks' kernels in
-// fp64 behind five barriers, the {k, k^2} taps take a third of the LDS reads of the inner loop (a block is 42
-// lanes: a wave straddles two blocks, the taps are not uniform), and 70 KB of LDS per workgroup leave two
-// workgroups per CU.  Here:
-//   * the block kernels are evaluated once by a kernel of their own (k_hp_kernels: the arithmetic of k_hp_apply's
-//     prologue, the same bits) into a {k, k^2} table in global memory, 3.5 KB per block;
-//   * a wave owns ONE block (STEP rows x LPR strips of R columns <= 64 lanes), so its taps are wave-uniform: they
-//     arrive through the scalar cache (s_load_dwordx16, a tap row ahead) and enter v_pk_fma_f32 as a scalar
-//     operand - no LDS read, no vector register;
-//   * LDS holds the {T, V} tile only (34 KB for four blocks of 21): four workgroups per CU.
-// The sums run in k_hp_apply's order (v outer, u inner, one packed FMA per tap and pixel): the same bits.
-template <int HWK> struct applyw_cfg {
-    enum { STEP = 2 * HWK + 1,
-           LPR = 64 / STEP > 0 ? 64 / STEP : 1,          // lanes per block row (strips)
-           R = (STEP + LPR - 1) / LPR,                   // output pixels per lane
-           NBW = 4,                                      // blocks (= waves) per workgroup
-           TW = NBW * STEP + 2 * HWK,
-           TH = STEP + 2 * HWK,
-           // tile row pitch in float2 units: the window loads of a wave (lane = (row, strip)) free of bank
-           // conflicts where a pitch within 32 of the width allows it (HWK 10: 117 - with 105 every load took
-           // two passes and the kernel was bound by the LDS pipe: 308 us)
-           TP = apply_pitch_n(NBW * STEP + 2 * HWK, 64 / STEP > 0 ? 64 / STEP : 1,
-                              (STEP + (64 / STEP > 0 ? 64 / STEP : 1) - 1) / (64 / STEP > 0 ? 64 / STEP : 1), STEP, 32) };
-    // lanes doing useful work x columns doing useful work, in percent
-    enum { EFF = (100 * STEP * LPR / 64) * STEP / (LPR * R) };
-};
-
-// The table of block kernels.  k_hp_apply evaluates a block's kernel as K = sum_n c_n B_n with the coefficients
-// c_n = sum_p x[n, p] X^i_p Y^j_p taken at the block centre first - per block a chain of small fp64 stages behind
-// five barriers (as a kernel of its own: 115 us per frame, all latency).  The same sum with the spatial terms
-// outside, K = x_0 B_0 + sum_p (X^i_p Y^j_p) M_p, M_p = sum_n x[n, p] B_n, has per-REGION matrices M_p
-// (k_hp_kbasis, a few hundred thousand products per subtraction) and leaves nkp fused multiply-adds per tap and
-// block (k_hp_ktable: a thread keeps the M_p of its taps in registers and walks along a row of blocks).  Equal to
-// k_hp_apply's kernels up to fp64 rounding of the reordered sums, i.e. to the last bit of the fp32 taps in all but
-// ~1e-8 of them.
-#define HPK_MAXP 15   // spatial terms the register path holds (ko <= 4); more: k_hp_apply
-#define HPK_NBK 16    // blocks per workgroup of k_hp_ktable
-template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_kbasis(const hp_plan P, const double* __restrict__ filt,
-                                                   const double* __restrict__ xsol, double* __restrict__ Mt) {
-    constexpr int STEP = 2 * HWK + 1, NT = STEP * STEP;
-    const int reg = blockIdx.y, p = blockIdx.x;          // p == HPK_MAXP: the constant part x_0 B_0
-    const double* x = xsol + (size_t)reg * P.nunk;
-    // the term tables, this spatial term's coefficients and the 1-D filters in LDS first (read through the
-    // kernel-argument segment and global memory inside the sum, every term paid two dependent latencies: 17 us)
-    __shared__ double xq[HP_MAXX], sn[HP_MAXX], flt[HP_MAXF1 * STEP];
-    __shared__ int txn[HP_MAXX], tyn[HP_MAXX], sbn[HP_MAXX];
-    const int tid = threadIdx.x;
-    for (int n = tid; n < P.nc; n += 256) {
-        sn[n] = P.tscale[n];
-        txn[n] = P.tfx[n] * STEP;
-        tyn[n] = P.tfy[n] * STEP;
-        sbn[n] = P.tsub0[n];
-        xq[n] = (n >= 1 && p < P.nkp) ? x[1 + (size_t)(n - 1) * P.nkp + p] : 0.0;
-    }
-    for (int e = tid; e < P.nf1 * STEP; e += 256) flt[e] = filt[e];
-    __syncthreads();
-    for (int tap = tid; tap < NT; tap += 256) {
-        const int v = tap / STEP, u = tap - v * STEP;
-        const double b0 = sn[0] * flt[tyn[0] + v] * flt[txn[0] + u];
-        double acc = 0.0;
-        if (p == HPK_MAXP) {
-            acc = x[0] * (b0 - (sbn[0] ? b0 : 0.0));
-        } else if (p < P.nkp) {
-#pragma unroll 8
-            for (int n = 1; n < P.nc; ++n) {
-                const double bn = sn[n] * flt[tyn[n] + v] * flt[txn[n] + u];
-                acc += xq[n] * (bn - (sbn[n] ? b0 : 0.0));
-            }
-        }
-        Mt[((size_t)reg * (HPK_MAXP + 1) + p) * NT + tap] = acc;
-    }
-}
-
-template <int HWK>
-__global__ __launch_bounds__(512) void k_hp_ktable(const hp_plan P, const double* __restrict__ Mt, int maxbx, int maxby,
-                                                   float2* __restrict__ kcg) {
-    constexpr int STEP = 2 * HWK + 1, NT = STEP * STEP, TPT = (NT + 511) / 512;
-    __shared__ double W[HPK_NBK][HPK_MAXP + 1];
-    const int reg = blockIdx.z, tid = threadIdx.x;
-    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
-    const int bx0 = blockIdx.x * HPK_NBK;
-    const int gx0 = x0r + bx0 * STEP, gy0 = y0r + blockIdx.y * STEP;
-    if (gx0 >= x1r || gy0 >= y1r) return;
-    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
-    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
-    // the spatial terms at the nominal block centres (k_hp_apply's coordinates)
-    for (int e = tid; e < HPK_NBK * (HPK_MAXP + 1); e += 512) {
-        const int b = e / (HPK_MAXP + 1), pp = e - b * (HPK_MAXP + 1);
-        double w = 0.0;
-        if (pp < P.nkp) {
-            const double fx = (gx0 + b * STEP + HWK - xc) / hx, fy = (gy0 + HWK - yc) / hy;
-            w = ipowd(fx, P.kpi[pp]) * ipowd(fy, P.kpj[pp]);
-        }
-        W[b][pp] = w;
-    }
-    double m[TPT][HPK_MAXP + 1];
-#pragma unroll
-    for (int t = 0; t < TPT; ++t)
-#pragma unroll
-        for (int pp = 0; pp <= HPK_MAXP; ++pp) {
-            const int tap = min(tid + 512 * t, NT - 1);
-            m[t][pp] = Mt[((size_t)reg * (HPK_MAXP + 1) + pp) * NT + tap];
-        }
-    __syncthreads();
-    for (int b = 0; b < HPK_NBK; ++b) {
-        const int bx = bx0 + b;
-        if (bx >= maxbx || gx0 + b * STEP >= x1r) break;
-        float2* out = kcg + (((size_t)reg * maxby + blockIdx.y) * maxbx + bx) * NT;
-        double w[HPK_MAXP];
-#pragma unroll
-        for (int pp = 0; pp < HPK_MAXP; ++pp) w[pp] = W[b][pp];
-#pragma unroll
-        for (int t = 0; t < TPT; ++t) {
-            double acc = m[t][HPK_MAXP];
-#pragma unroll
-            for (int pp = 0; pp < HPK_MAXP; ++pp) acc = fma(w[pp], m[t][pp], acc);
-            const float k = (float)acc;
-            const int tap = tid + 512 * t;
-            if (tap < NT) out[tap] = make_float2(k, k * k);
-        }
-    }
-}
-
-template <int HWK>
-__global__ __launch_bounds__(256) void k_hp_apply_w(const hp_plan P, const unsigned long long* __restrict__ solved_mask,
-                                                    const float* __restrict__ sci,
-                                                    const float* __restrict__ ref,
-                                                    const float* __restrict__ srms,
-                                                    const float* __restrict__ trms,
-                                                    const uint8_t* __restrict__ outbad,
-                                                    const double* __restrict__ xsol,
-                                                    const float2* __restrict__ kcg, int maxbx, int maxby,
-                                                    float* __restrict__ diff,
-                                                    float* __restrict__ noise,
-                                                    int* __restrict__ nmasked) {
-    const int reg = blockIdx.z;
-    const int solved = (int)((*solved_mask >> reg) & 1ull);      // (k_hp_solved: the fit's outcome, read on the device)
-    typedef applyw_cfg<HWK> C;
-    constexpr int STEP = C::STEP, R = C::R, LPR = C::LPR, NB = C::NBW, TW = C::TW, TP = C::TP, TH = C::TH;
-    typedef float ap_v2f __attribute__((ext_vector_type(2)));
-    extern __shared__ float apw_smem[];
-    ap_v2f* tTV = reinterpret_cast<ap_v2f*>(apw_smem);             // [TH][TP]
-    __shared__ int wmask[4];
-    const int tid = threadIdx.x;
-    const int x0r = P.rx0[reg], x1r = P.rx1[reg], y0r = P.ry0[reg], y1r = P.ry1[reg];
-    const int gx0 = x0r + blockIdx.x * NB * STEP;      // first block of this workgroup
-    const int gy0 = y0r + blockIdx.y * STEP;
-    if (gx0 >= x1r || gy0 >= y1r) return;              // beyond this (smaller) region
-    const double xc = x0r + 0.5 * (x1r - x0r), hx = 0.5 * (x1r - x0r);
-    const double yc = y0r + 0.5 * (y1r - y0r), hy = 0.5 * (y1r - y0r);
-    const double bg0 = xsol[(size_t)reg * P.nunk + 1 + (size_t)(P.nc - 1) * P.nkp];     // constant background term
-    const float norm = P.normalize ? (float)(1.0 / xsol[(size_t)reg * P.nunk]) : 1.f;
-    // tile of template and template variance (zeros outside the frame / non-finite), every load of a thread
-    // ahead of its first LDS store
-    {
-        constexpr int NIT = (TH * TW + 255) / 256;
-        float tt[NIT], tr[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + 256 * it;
-            const int yy = e / TW, xx = e - yy * TW;
-            const int gx = gx0 - HWK + xx, gy = gy0 - HWK + yy;
-            tt[it] = 0.f;
-            tr[it] = 0.f;
-            if (e < TH * TW && gx >= 0 && gx < P.nx && gy >= 0 && gy < P.ny) {
-                const size_t idx = (size_t)gy * P.nx + gx;
-                tt[it] = ref[idx];
-                tr[it] = trms[idx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + 256 * it;
-            float t = tt[it], v = tr[it] * tr[it];
-            if (!(fabsf(t) < 3e38f)) t = 0.f;
-            if (!(fabsf(v) < 3e38f)) v = 0.f;
-            if (e < TH * TW) tTV[(e / TW) * TP + e % TW] = (ap_v2f){t, v};
-        }
-    }
-    __syncthreads();
-    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);        // this wave's block
-    const int l = tid & 63;
-    const int row = l / LPR, strip = l - row * LPR;
-    const int ox0 = b * STEP + strip * R;              // tile-relative (without halo) x of first px
-    const bool live = row < STEP && gx0 + b * STEP < x1r && gy0 + row < y1r && gy0 + row < P.ny;
-    ap_v2f acc2[R];                                    // {sum k T, sum k^2 V}
-#pragma unroll
-    for (int q = 0; q < R; ++q) acc2[q] = (ap_v2f){0.f, 0.f};
-    {
-        // (every lane runs the loop - rows beyond the block read a clamped tile row - so that the taps stay
-        // wave-uniform scalar loads; dead lanes do not store)
-        const int bxi = min((int)blockIdx.x * NB + b, maxbx - 1);
-        const ap_v2f* kb = reinterpret_cast<const ap_v2f*>(kcg) +
-                           (((size_t)reg * maxby + blockIdx.y) * maxbx + bxi) * (STEP * STEP);
-        const int rowc = min(row, STEP - 1);
-        // true convolution: out(x, y) = sum_{u,v} K[v][u] T(x - u, y - v); K index (v + HWK, u + HWK)
-#pragma unroll 1
-        for (int v = -HWK; v <= HWK; ++v) {
-            const ap_v2f* rt = tTV + (rowc + HWK - v) * TP + ox0;    // T(x - u): column ox0 + q + HWK - u
-            ap_v2f w2[R + 2 * HWK];
-            // (strips that reach beyond the block's last column - LPR R > STEP - stay inside the tile row)
-#pragma unroll
-            for (int q = 0; q < R + 2 * HWK; ++q) w2[q] = rt[(LPR * R == STEP) ? q : min(q, TW - 1 - ox0)];
-            const ap_v2f* kr = kb + (v + HWK) * STEP;
-#pragma unroll
-            for (int u = -HWK; u <= HWK; ++u) {
-                const ap_v2f k2 = kr[u + HWK];
-#pragma unroll
-                for (int q = 0; q < R; ++q) acc2[q] = __builtin_elementwise_fma(k2, w2[q + HWK - u], acc2[q]);
-            }
-        }
-    }
-    // the sums go through LDS (the tile's space) so that the science / noise planes are read and
-    // the outputs written along rows: NB STEP consecutive pixels per row instead of R per thread
-    constexpr int OW = NB * STEP;
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-            if (strip * R + q < STEP) tTV[row * OW + ox0 + q] = acc2[q];
-    }
-    __syncthreads();
-    int masked = 0;
-    {
-        constexpr int NE = (STEP * OW + 255) / 256;
-        float es[NE], er[NE];
-        bool eb[NE], ein[NE];
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            const int e = tid + 256 * it;
-            const int orow = e / OW, ocol = e - orow * OW;
-            const int gx = gx0 + ocol, gy = gy0 + orow;
-            ein[it] = e < STEP * OW && gx < x1r && gx < P.nx && gy < y1r && gy < P.ny;
-            es[it] = er[it] = 0.f;
-            eb[it] = true;
-            if (ein[it]) {
-                const size_t idx = (size_t)gy * P.nx + gx;
-                eb[it] = outbad[idx] != 0;
-                es[it] = sci[idx];
-                er[it] = srms[idx];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            if (!ein[it]) continue;
-            const int e = tid + 256 * it;
-            const int orow = e / OW, ocol = e - orow * OW;
-            const int gx = gx0 + ocol, gy = gy0 + orow;
-            const size_t idx = (size_t)gy * P.nx + gx;
-            float d = P.fi, nz = P.fin;
-            if (solved && !eb[it]) {
-                double bg = bg0;
-                if (P.nbg > 1) {
-                    const double xf = (gx - xc) / hx, yf = (gy - yc) / hy;
-                    bg = 0.0;
-                    for (int t = 0; t < P.nbg; ++t)
-                        bg += xs_bg(xsol, reg, P, t) * ipowd(xf, P.bpi[t]) * ipowd(yf, P.bpj[t]);
-                }
-                const ap_v2f a = tTV[e];
-                d = (es[it] - a.x - (float)bg) * norm;
-                nz = sqrtf(fmaxf(er[it] * er[it] + a.y, 0.f)) * fabsf(norm);
-            } else {
-                masked += 1;
-            }
-            diff[idx] = d;
-            noise[idx] = nz;
-        }
-    }
-    // one atomic per workgroup
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) masked += __shfl_xor(masked, o);
-    if ((tid & 63) == 0) wmask[tid >> 6] = masked;
-    __syncthreads();
-    if (tid == 0) {
-        const int tot = wmask[0] + wmask[1] + wmask[2] + wmask[3];
-        if (tot) atomicAdd(nmasked, tot);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The kernels of the fit, twice: for ONE subtraction (the arguments are that job's buffers), and for a BATCH of
-// subtractions in one launch (`*_b`: one more grid dimension picks the job, whose buffers come from a table in device
-// memory, read through the scalar cache; its guard is the job's own round flag, so a job that has converged costs
-// empty workgroups while the others go on).  Both forms inline the same body: the same bits per job.
-struct hp_job {                      // one job of a batched fit: its planes and its slice of the batch's scratch
-    const float *sci, *ref, *srms, *trms;
-    int2* centres;
-    int *active, *need, *needlist, *chg, *ibuf, *rflags;
-    double *X, *G, *Gp, *Gold, *phi, *phiold, *vbar, *A, *AT, *rhs, *A0, *rhs0, *dsc, *merit, *stats;
-    unsigned long long* smask;
-};
-#define HPJ_NREJ(J) ((J).ibuf)
-#define HPJ_NTOTAL(J) ((J).ibuf + HP_MAXREG)
-#define HPJ_FAIL(J) ((J).ibuf + 2 * HP_MAXREG)
-#define HPJ_NMASKED(J) ((J).ibuf + 3 * HP_MAXREG)
-#define HPJ_TMO(J) ((J).ibuf + 3 * HP_MAXREG + 4)
-#define HPJ_GUARD(J, round) ((round) > 1 ? (J).rflags + ((round) - 1) : nullptr)
-// A region whose last rejection changed nothing keeps its normal matrix, hence its factor and its solution: from the
-// second round on the scaling, the factorisation and the back substitution of such a region are skipped (the list of
-// changed cells of a region, k_hp_reject*: chg[ncell + reg (ncellr + 1)] is its length) - the same bits, fewer
-// workgroups holding a CU each while other jobs' kernels wait
-#define HPJ_REGION_IDLE(J, round, reg, ncell, ncellr) ((round) > 1 && (J).chg[(ncell) + (reg) * ((ncellr) + 1)] == 0)
-
-template <int HWK>
-__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors(const hp_plan P, const float* __restrict__ sci,
-                                                    const float* __restrict__ ref, const float* __restrict__ srms,
-                                                    const float* __restrict__ trms, const double* __restrict__ filt,
-                                                    const int2* __restrict__ centres, const int* __restrict__ active,
-                                                    const int* __restrict__ need, double* __restrict__ X,
-                                                    double* __restrict__ phi, double* __restrict__ vbar,
-                                                    const int* __restrict__ guard, double* __restrict__ phiold,
-                                                    const int* __restrict__ list, int special) {
-    hp_vectors_body<HWK>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special);
-}
-template <int HWK>
-__global__ __launch_bounds__(HV_THREADS) void k_hp_vectors_big(const hp_plan P, const float* __restrict__ sci,
-                                                    const float* __restrict__ ref, const float* __restrict__ srms,
-                                                    const float* __restrict__ trms, const double* __restrict__ filt,
-                                                    const int2* __restrict__ centres, const int* __restrict__ active,
-                                                    const int* __restrict__ need, double* __restrict__ X,
-                                                    double* __restrict__ phi, double* __restrict__ vbar,
-                                                    const int* __restrict__ guard, double* __restrict__ phiold,
-                                                    const int* __restrict__ list, int special, int cw, double* __restrict__ w0g) {
-    hp_vectors_body<HWK, true>(P, sci, ref, srms, trms, filt, centres, active, need, X, phi, vbar, guard, phiold, list, special,
-                               cw, w0g);
-}
-// (four waves per SIMD - two workgroups per CU - like the one-job kernel: without the bound the job table's pointers
-// push this instance to 131 registers, one workgroup per CU, and the first round of a batch ran 40 % slower per job;
-// half widths above 11 need more than 128 registers in the one-job kernel too)
-template <int HWK>
-__global__ __launch_bounds__(HV_THREADS, (HWK <= 11 ? 4 : 2)) void k_hp_vectors_b(const hp_plan P, const hp_job* __restrict__ jobs,
-                                                      const double* __restrict__ filt, int round) {
-    const hp_job& J = jobs[blockIdx.z];
-    hp_vectors_body<HWK>(P, J.sci, J.ref, J.srms, J.trms, filt, J.centres, J.active, J.need, J.X, J.phi, J.vbar,
-                         HPJ_GUARD(J, round), J.phiold, round > 1 ? J.needlist : nullptr, round > 1 ? 1 : 0);
-}
-
 __global__ __launch_bounds__(256) void k_hp_gram(const hp_plan P, const double* __restrict__ X,
                                                  const int* __restrict__ need, const int* __restrict__ active,
                                                  double* __restrict__ Gp, const int* __restrict__ guard,
@@ -4337,63 +2794,6 @@ __global__ void k_hp_solved(int nreg, int nunk, const double* __restrict__ stats
 }
 
 
-template <int HWK>
-static int launch_apply(zm_ctx* ctx, const hp_plan& P, const unsigned long long* solved_mask, const float* sci,
-                        const float* ref, const float* srms, const float* trms, const uint8_t* outbad,
-                        const double* filt, const double* xsol, float* diff, float* noise,
-                        int* nmasked) {
-    typedef apply_cfg<HWK> C;
-    constexpr int STEP = C::STEP, NB = C::NB;
-    constexpr int TP = C::TP, TH = STEP + 2 * HWK;
-    const size_t tvn = std::max((size_t)TH * TP, (size_t)P.nunk + 2 * (size_t)P.nc + (size_t)(NB + 1) * P.nf1 * STEP + NB + (size_t)2 * NB * P.nkp);
-    size_t fl = 2 * tvn + (size_t)2 * NB * STEP * STEP;      // {T, V} tile (or the evaluation scratch) + {k, k^2} kernels
-    size_t shmem = fl * sizeof(float) + (size_t)NB * P.nc * sizeof(double);
-    // (remembered per context and kernel instance, not per process: contexts may sit on
-    // different devices)
-    size_t& set_max = ctx->hp_set_max[HWK];
-    if (set_max < 65536) set_max = 65536;
-    if (shmem > set_max) {
-        ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply<HWK>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        set_max = shmem;
-    }
-    int W = 0, H = 0;
-    for (int reg = 0; reg < P.nreg; ++reg) {
-        W = std::max(W, P.rx1[reg] - P.rx0[reg]);
-        H = std::max(H, P.ry1[reg] - P.ry0[reg]);
-    }
-    // Round 4: one wave per block with the taps as scalar operands (k_hp_kernels + k_hp_apply_w) where a block
-    // fills most of a wave; ZM_APPLY_FORM=tile runs the workgroup-per-six-blocks kernel (A / B, tests).
-    typedef applyw_cfg<HWK> CW;
-    const char* form = getenv("ZM_APPLY_FORM");
-    const bool wave_form = (form ? !strcmp(form, "wave") : (CW::EFF >= 60 && HWK >= 4)) && P.nkp <= HPK_MAXP;
-    if (wave_form && !(form && !strcmp(form, "tile"))) {
-        const int maxbx = zm_div_up(W, STEP), maxby = zm_div_up(H, STEP);
-        float2* kcg = nullptr;
-        ZM_TRY(ctx->get("hp_kcg", sizeof(float2) * (size_t)P.nreg * maxby * maxbx * STEP * STEP, (void**)&kcg));
-        double* Mt = nullptr;
-        ZM_TRY(ctx->get("hp_kmt", sizeof(double) * (size_t)P.nreg * (HPK_MAXP + 1) * STEP * STEP, (void**)&Mt));
-        hipLaunchKernelGGL(k_hp_kbasis<HWK>, dim3(HPK_MAXP + 1, P.nreg), dim3(256), 0, ctx->stream, P, filt, xsol, Mt);
-        hipLaunchKernelGGL(k_hp_ktable<HWK>, dim3(zm_div_up(maxbx, HPK_NBK), maxby, P.nreg), dim3(512), 0, ctx->stream,
-                           P, Mt, maxbx, maxby, kcg);
-        const size_t wsh = sizeof(float2) * (size_t)CW::TH * CW::TP;
-        static bool wset[HP_MAX_HWK + 1][64] = {};
-        if (wsh > 65536 && !wset[HWK][ctx->device & 63]) {
-            ZM_HIP(hipFuncSetAttribute((const void*)k_hp_apply_w<HWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsh));
-            wset[HWK][ctx->device & 63] = true;
-        }
-        hipLaunchKernelGGL(k_hp_apply_w<HWK>, dim3(zm_div_up(maxbx, CW::NBW), maxby, P.nreg), dim3(256), wsh, ctx->stream,
-                           P, solved_mask, sci, ref, srms, trms, outbad, xsol, kcg, maxbx, maxby, diff, noise, nmasked);
-        ZM_HIP(hipGetLastError());
-        return 0;
-    }
-    dim3 grd(zm_div_up(zm_div_up(W, STEP), NB), zm_div_up(H, STEP), P.nreg);
-    hipLaunchKernelGGL(k_hp_apply<HWK>, grd, dim3(256), shmem, ctx->stream, P, solved_mask, sci, ref, srms,
-                       trms, outbad, filt, xsol, diff, noise, nmasked);
-    ZM_HIP(hipGetLastError());
-    return 0;
-}
-
 // The validity mask of a subtraction and its two dilations (substamp footprint: `dirty`; kernel footprint: `outbad`)
 static int hp_launch_masks(zm_ctx* ctx, const hp_plan& P, const zm_hp_params* hp, const float* sci, const float* ref,
                            const uint8_t* bpm, uint8_t* bad, uint8_t* tmp8, uint8_t* dirty, uint8_t* outbad) {
@@ -4415,7 +2815,7 @@ static int hp_launch_masks(zm_ctx* ctx, const hp_plan& P, const zm_hp_params* hp
     const bool col4 = (nx % 4 == 0) && (((uintptr_t)tmp8 | (uintptr_t)dirty | (uintptr_t)outbad) & 3) == 0;
     dim3 gc4(zm_div_up(nx / 4, 256), zm_div_up(ny, HP_COLSTRIP4));
     // validity + both row dilations in one pass (k_hp_valid_rows); ZM_HP_MASKS=split: the five launches of rounds 1 - 3
-    static const bool split = getenv("ZM_HP_MASKS") && !strcmp(getenv("ZM_HP_MASKS"), "split");
+    static const bool split = ZM_DEVENV("ZM_HP_MASKS") && !strcmp(ZM_DEVENV("ZM_HP_MASKS"), "split");
     uint8_t* tmp8b = nullptr;
     if (!split) ZM_TRY(ctx->get("hp_tmp8b", np, (void**)&tmp8b));
     if (!split && (((uintptr_t)tmp8b & 3) == 0)) {
@@ -4620,32 +3020,8 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         }
         {
             zm_scope_timer t(ctx, "hp_vectors");
-#define HP_VEC_CASE(H) case H: \
-    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors<H>, dim3(rounds == 1 ? P.ncell : ncl_grid, rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist, rounds == 1 ? 0 : 1); break;
-#define HP_VECBIG_CASE(H) case H: \
-    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_big<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors_big<H>, dim3(rounds == 1 ? hv_gx : std::min(ncl_grid, hv_gx), rounds == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW), dim3(HV_THREADS), vsh, st, P, sci, ref, sci_rms, ref_rms, d_filt, \
-                       centres, active, need, X, phi, vbar, guard, phiold, rounds == 1 ? nullptr : needlist, rounds == 1 ? 0 : 1, hvc.cw, hv_w0g); break;
-            if (hvc.big) {
-                switch (P.hwk) {
-                    HP_VECBIG_CASE(1) HP_VECBIG_CASE(2) HP_VECBIG_CASE(3) HP_VECBIG_CASE(4) HP_VECBIG_CASE(5)
-                    HP_VECBIG_CASE(6) HP_VECBIG_CASE(7) HP_VECBIG_CASE(8) HP_VECBIG_CASE(9) HP_VECBIG_CASE(10)
-                    HP_VECBIG_CASE(11) HP_VECBIG_CASE(12) HP_VECBIG_CASE(13) HP_VECBIG_CASE(14) HP_VECBIG_CASE(15)
-                    HP_VECBIG_CASE(16) HP_VECBIG_CASE(17) HP_VECBIG_CASE(18) HP_VECBIG_CASE(19) HP_VECBIG_CASE(20)
-                    default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-                }
-            } else
-            switch (P.hwk) {
-                HP_VEC_CASE(1) HP_VEC_CASE(2) HP_VEC_CASE(3) HP_VEC_CASE(4) HP_VEC_CASE(5)
-                HP_VEC_CASE(6) HP_VEC_CASE(7) HP_VEC_CASE(8) HP_VEC_CASE(9) HP_VEC_CASE(10)
-                HP_VEC_CASE(11) HP_VEC_CASE(12) HP_VEC_CASE(13) HP_VEC_CASE(14) HP_VEC_CASE(15)
-                HP_VEC_CASE(16) HP_VEC_CASE(17) HP_VEC_CASE(18) HP_VEC_CASE(19) HP_VEC_CASE(20)
-                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-            }
-#undef HP_VEC_CASE
-#undef HP_VECBIG_CASE
+            ZM_TRY(zm_hp_launch_vectors(ctx, st, P, hvc, rounds, ncl_grid, hv_gx, sci, ref, sci_rms, ref_rms, d_filt, centres, active,
+                                        need, X, phi, vbar, guard, phiold, needlist, hv_w0g));
             ZM_HIP(hipGetLastError());
         }
         {
@@ -4676,15 +3052,14 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 ZM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_chol_fused, 256, 0));
                 ZM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
                 ctx->hp_wg_cap = std::max(1, std::min(occ, 1) * (ncu - ncu / 16));
-                if (getenv("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
+                if (ZM_DEVENV("ZM_CHOL_PROF")) fprintf(stderr, "chol: occupancy %d x %d CUs\n", occ, ncu);
             }
             // this context's share of the resident workgroups: each of `share` contexts keeps its launch fully resident
             const int wg_cap = ctx->hp_wg_cap / std::max(ctx->share, 1);
             const int W = std::max(2, std::min(68, wg_cap / P.nreg));
             const int nunk = P.nunk;
-            static const bool want_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
-            const bool want_df = !tp && !(form_env && !strcmp(form_env, "lat")) && 2 * P.nreg <= wg_cap && W <= 128 &&
-                                 !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
+            static const bool want_prof = ZM_DEVENV("ZM_CHOL_PROF") && atoi(ZM_DEVENV("ZM_CHOL_PROF")) != 0;
+            const bool want_df = !tp && !(form_env && !strcmp(form_env, "lat")) && 2 * P.nreg <= wg_cap && W <= 128;
             const int ndff = hp_df_nflags(P.nunk);
             unsigned* dff = nullptr;
             double* dfdg = nullptr;
@@ -4719,7 +3094,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 ZM_TRY(ctx->get("hp_dfdg", sizeof(double) * (size_t)P.nreg * zm_div_up(P.nunk, CH_NB) * CH_NB * (CH_NB + 1),
                                 (void**)&dfdg));
             }
-            static const bool build_scalar = getenv("ZM_BUILD_FORM") && !strcmp(getenv("ZM_BUILD_FORM"), "scalar");
+            static const bool build_scalar = ZM_DEVENV("ZM_BUILD_FORM") && !strcmp(ZM_DEVENV("ZM_BUILD_FORM"), "scalar");
             if (P.nkp <= 15 && rounds == 1 && !build_scalar)
                 hipLaunchKernelGGL(k_hp_build_mfma, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg), b256, 0, st, P, G, phi, active,
                                    A0, rhs0, dff, ndff);
@@ -4737,7 +3112,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             }
             {
                 if (tp) {
-                    static const bool tp_prof = getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) != 0;
+                    static const bool tp_prof = ZM_DEVENV("ZM_CHOL_PROF") && atoi(ZM_DEVENV("ZM_CHOL_PROF")) != 0;
                     long long* parg = nullptr;
                     if (tp_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 5 * P.nreg, (void**)&parg));
                     const int ldt = (P.nunk + 1 + 15) & ~15;
@@ -4769,14 +3144,15 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                 long long* parg = nullptr;
                 const int nblkp = zm_div_up(nunk, CH_NB);
                 if (want_prof) ZM_TRY(ctx->get("hp_cprof", sizeof(long long) * 8 * ((size_t)P.nreg * W + (size_t)P.nreg * nblkp), (void**)&parg));
-                // ZM_CHOL_STEP=64: the 64-column super-steps (k_chol_fused2: same bits; measured, not faster - see its
-                // header)
-                const bool step32 = !(getenv("ZM_CHOL_STEP") && atoi(getenv("ZM_CHOL_STEP")) == 64);
                 {
                     zm_scope_timer tc(ctx, "hp_chol");             // (inside hp_solve: the factorisation alone)
                     if (df) {
-                        static const int prof_mode = want_prof ? std::min(2, atoi(getenv("ZM_CHOL_PROF"))) : 0;
+                        static const int prof_mode = want_prof ? std::min(2, atoi(ZM_DEVENV("ZM_CHOL_PROF"))) : 0;
+#ifdef ZM_DEV
                         auto kf = prof_mode == 2 ? k_chol_df<2> : prof_mode == 1 ? k_chol_df<1> : k_chol_df<0>;
+#else
+                        auto kf = k_chol_df<0>;
+#endif
                         static bool df_attr[3][64] = {};
                         if (!df_attr[prof_mode][ctx->device & 63]) {
                             ZM_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4785,19 +3161,9 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                         }
                         hipLaunchKernelGGL(kf, dim3(P.nreg * W), dim3(DF_THREADS), sizeof(df_lds), st, nunk, lda, W, A,
                                            dfdg, fail, tmo, spin_limit, dff, dftiles, guard, A0, rhs0, dsc, parg);
-                    } else if (step32) {
+                    } else {
                         hipLaunchKernelGGL(k_chol_fused, dim3(P.nreg * W), b256, 0, st, nunk, lda, W, A, cdg, fail, tmo,
                                            spin_limit, cbar, parg, guard);
-                    } else {
-                        auto kf = want_prof ? k_chol_fused2<true> : k_chol_fused2<false>;
-                        static bool attr_set[2][64] = {};
-                        if (!attr_set[want_prof][ctx->device & 63]) {
-                            ZM_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)sizeof(cf2_lds)));
-                            attr_set[want_prof][ctx->device & 63] = true;
-                        }
-                        hipLaunchKernelGGL(kf, dim3(P.nreg * W), b256, sizeof(cf2_lds), st, nunk, lda, W, A, cdg,
-                                           fail, tmo, spin_limit, cbar, parg, guard);
                     }
                 }
                 ZM_HIP(hipGetLastError());
@@ -4817,7 +3183,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                             fprintf(stderr, " %s %.1f us", df ? nm8[k] : nm6[k], hp[(size_t)wg * nprof + k] * 0.01);
                         fprintf(stderr, "\n");
                     }
-                    if (df && getenv("ZM_CHOL_PROF") && atoi(getenv("ZM_CHOL_PROF")) >= 2) {
+                    if (df && ZM_DEVENV("ZM_CHOL_PROF") && atoi(ZM_DEVENV("ZM_CHOL_PROF")) >= 2) {
                         // region 0: the chain per block, microseconds since the first block was taken up
                         const long long* ts = hp.data() + (size_t)8 * P.nreg * W;
                         for (int kb = 0; kb < nblkp; ++kb) {
@@ -4871,15 +3237,7 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
         ZM_TRY(ctx->get("hp_smask", sizeof(unsigned long long), (void**)&smask));
         hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, st, P.nreg, P.nunk, stats, fail, tmo, rhs, smask, x0sum);
         {
-#define HP_APPLY_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, P, smask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked)); break;
-            switch (P.hwk) {
-                HP_APPLY_CASE(1) HP_APPLY_CASE(2) HP_APPLY_CASE(3) HP_APPLY_CASE(4) HP_APPLY_CASE(5)
-                HP_APPLY_CASE(6) HP_APPLY_CASE(7) HP_APPLY_CASE(8) HP_APPLY_CASE(9) HP_APPLY_CASE(10)
-                HP_APPLY_CASE(11) HP_APPLY_CASE(12) HP_APPLY_CASE(13) HP_APPLY_CASE(14) HP_APPLY_CASE(15)
-                HP_APPLY_CASE(16) HP_APPLY_CASE(17) HP_APPLY_CASE(18) HP_APPLY_CASE(19) HP_APPLY_CASE(20)
-                default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-            }
-#undef HP_APPLY_CASE
+            ZM_TRY(zm_hp_launch_apply(ctx, P, smask, sci, ref, sci_rms, ref_rms, outbad, d_filt, rhs, out_diff, out_rms, nmasked));
         }
     }
     // what the reference does behind hotpants - bit 17 where the fill value landed - enqueued here when asked for
@@ -5092,20 +3450,10 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         // dozen per job here, where the lone subtraction takes 48: the batch pays for every empty workgroup J times)
         const int ncl_grid = std::min(P.ncell, 12);
         const unsigned gcells = round == 1 ? P.ncell : ncl_grid;
-#define HP_VECB_CASE(H) case H: \
-    ZM_HIP(hipFuncSetAttribute((const void*)k_hp_vectors_b<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vsh)); \
-    hipLaunchKernelGGL(k_hp_vectors_b<H>, dim3(gcells, round == 1 ? HV_SPLIT_ALL : HV_SPLIT_FEW, NJ), dim3(HV_THREADS), vsh, st, \
-                       P, d_tab, d_filt, round); break;
-        switch (P.hwk) {
-            HP_VECB_CASE(1) HP_VECB_CASE(2) HP_VECB_CASE(3) HP_VECB_CASE(4) HP_VECB_CASE(5)
-            HP_VECB_CASE(6) HP_VECB_CASE(7) HP_VECB_CASE(8) HP_VECB_CASE(9) HP_VECB_CASE(10)
-            HP_VECB_CASE(11) HP_VECB_CASE(12) HP_VECB_CASE(13) HP_VECB_CASE(14) HP_VECB_CASE(15)
-            default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-        }
-#undef HP_VECB_CASE
+        ZM_TRY(zm_hp_launch_vectors_b(ctx, st, P, vsh, gcells, NJ, d_tab, d_filt, round));
         hipLaunchKernelGGL(k_hp_gram_b, dim3(gcells, GR_SPLIT, NJ), b256, 0, st, P, d_tab, round);
         hipLaunchKernelGGL(k_hp_gram_sum_b, dim3(gcells, 1, NJ), dim3(GS_THREADS), 0, st, d_tab, round);
-        static const bool build_scalar = getenv("ZM_BUILD_FORM") && !strcmp(getenv("ZM_BUILD_FORM"), "scalar");
+        static const bool build_scalar = ZM_DEVENV("ZM_BUILD_FORM") && !strcmp(ZM_DEVENV("ZM_BUILD_FORM"), "scalar");
         if (round == 1 && !build_scalar)
             hipLaunchKernelGGL(k_hp_build_mfma_b, dim3(zm_div_up(P.nE * (P.nE + 1) / 2, 4), P.nreg, NJ), b256, 0, st, P, d_tab);
         else
@@ -5133,21 +3481,13 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
         const hp_job& J = h_jobs[j];
         hipLaunchKernelGGL(k_hp_solved, dim3(1), dim3(64), 0, ctx->stream, P.nreg, P.nunk, J.stats, HPJ_FAIL(J), HPJ_TMO(J),
                            J.rhs, J.smask, J.stats + 2 * HP_MAXREG);
-#define HP_APPLYB_CASE(H) case H: ZM_TRY(launch_apply<H>(ctx, Pj[j], J.smask, jobs[j].sci, jobs[j].ref, jobs[j].sci_rms, \
-    jobs[j].ref_rms, (uint8_t*)(sb + o_outbad), d_filt, J.rhs, jobs[j].out_diff, jobs[j].out_rms, HPJ_NMASKED(J))); break;
-        switch (P.hwk) {
-            HP_APPLYB_CASE(1) HP_APPLYB_CASE(2) HP_APPLYB_CASE(3) HP_APPLYB_CASE(4) HP_APPLYB_CASE(5)
-            HP_APPLYB_CASE(6) HP_APPLYB_CASE(7) HP_APPLYB_CASE(8) HP_APPLYB_CASE(9) HP_APPLYB_CASE(10)
-            HP_APPLYB_CASE(11) HP_APPLYB_CASE(12) HP_APPLYB_CASE(13) HP_APPLYB_CASE(14) HP_APPLYB_CASE(15)
-            HP_APPLYB_CASE(16) HP_APPLYB_CASE(17) HP_APPLYB_CASE(18) HP_APPLYB_CASE(19) HP_APPLYB_CASE(20)
-            default: zm_set_error("zm_subtract: unsupported kernel half width %d", P.hwk); return 2;
-        }
-#undef HP_APPLYB_CASE
+        ZM_TRY(zm_hp_launch_apply(ctx, Pj[j], J.smask, jobs[j].sci, jobs[j].ref, jobs[j].sci_rms, jobs[j].ref_rms,
+                                  (uint8_t*)(sb + o_outbad), d_filt, J.rhs, jobs[j].out_diff, jobs[j].out_rms, HPJ_NMASKED(J)));
         if (jobs[j].params->flag_mask_dev)
             ZM_TRY(zm_mask_flag_dev(ctx, jobs[j].params->flag_mask_dev, jobs[j].out_diff, 1e-30f, jobs[j].params->flag_bit, np));
         return 0;
     };
-    static const bool apply_beside = !(getenv("ZM_BATCH_APPLY") && !strcmp(getenv("ZM_BATCH_APPLY"), "after"));
+    static const bool apply_beside = !(ZM_DEVENV("ZM_BATCH_APPLY") && !strcmp(ZM_DEVENV("ZM_BATCH_APPLY"), "after"));
     struct stream_swap {                                  // (launch_apply and the timers enqueue on ctx->stream)
         zm_ctx* c; hipStream_t keep;
         stream_swap(zm_ctx* cc, hipStream_t s) : c(cc), keep(cc->stream) { c->stream = s; }
@@ -5289,3 +3629,4 @@ extern "C" int zm_subtract_batch(zm_ctx* ctx, int njobs, const zm_sub_job* jobs,
     ZM_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+

@@ -17,6 +17,17 @@
 
 void zm_set_error(const char* fmt, ...);
 
+// Developer switches (ablations, phase clocks, A / B forms that lost) are read from the environment only in a
+// -DZM_DEV build (ZM_HIPCC_FLAGS=-DZM_DEV python -m zuds-pipeline_amd.build --force); the shipped library reads the
+// handful of switches that select between forms it actually carries (README.md) and nothing else.
+#ifdef ZM_DEV
+#define ZM_DEVENV(name) getenv(name)
+#define ZM_DEV_BUILD 1
+#else
+#define ZM_DEVENV(name) ((const char*)nullptr)
+#define ZM_DEV_BUILD 0
+#endif
+
 #define ZM_HIP(call)                                                         \
     do {                                                                     \
         hipError_t e_ = (call);                                              \
@@ -76,6 +87,7 @@ struct zm_ctx {
     bool ff_pre_valid = false;
     int ff_pre_nfr = 0, ff_pre_onx = 0, ff_pre_ony = 0, ff_pre_lds = 0;
     bool ff_pre_own = false;
+    int ff_last_form = 0;                      // the fused kernel the last zm_launch_coadd_fused ran: 1 _dma, 2 _own (zm_ctx_query)
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed

@@ -89,6 +89,12 @@ class Engine(object):
         each): every engine then sizes its kernel-fit launches to 1 / nctx of the GPU."""
         check(self.L.zm_ctx_set_share(self._ctx, int(nctx)), 'zm_ctx_set_share')
 
+    def query(self, what):
+        """``zm_ctx_query``: 'fused_form' (0 none, 1 k_coadd_fused_dma, 2 k_coadd_fused_own), 'dev_build'."""
+        v = C.c_int64()
+        check(self.L.zm_ctx_query(self._ctx, what.encode(), C.byref(v)), 'zm_ctx_query')
+        return v.value
+
     # -- timing ----------------------------------------------------------------
     def timing(self, on=True, only=None):
         """HIP-event timers around the launches; ``only``: time just that scope."""
