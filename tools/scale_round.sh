@@ -5,6 +5,7 @@
 # (ZM_NATIVE_RCCL=1, csrc/comm.hip), each line's per-rank step time and per-exchange wall clock collected into ONE
 # table with the figures the design expects beside them (tools/scale_table.py).
 #   usage (on an N-GPU node, from the repo root):  bash tools/scale_round.sh [tag] [max ranks, default: all GPUs]
+# ZM_SCALE_ARGS: extra bench.py arguments (a rehearsal: "--size 1024 --frames 8").
 # Nothing here runs on the one-GPU boxes of the build rounds except the rehearsal: `ZM_DIST_BACKEND=gloo bash
 # tools/scale_round.sh rehearsal 2` puts two ranks on one card over gloo (tests/test_bench_ranks_gpu.py does the same).
 set -o pipefail
@@ -22,11 +23,11 @@ run() {   # run <name> <ranks> <env...> -- <bench args...>
     shift
     local port=$((29600 + RANDOM % 300))
     if [ "$n" = 1 ]; then
-        env "${envs[@]}" timeout -k 10 900 python3 bench.py --gpus 1 --steps $STEPS --warmup 3 --no-clocks --no-cpu-baseline --no-nightly --no-pipelined --no-secondary "$@" \
+        env "${envs[@]}" timeout -k 10 900 python3 bench.py --gpus 1 --steps $STEPS --warmup 3 --no-clocks --no-cpu-baseline --no-nightly --no-pipelined --no-secondary $ZM_SCALE_ARGS "$@" \
             > $out/$name.json 2> $out/$name.err
     else
         env "${envs[@]}" timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
-            bench.py --gpus $n --steps $STEPS --warmup 3 --no-clocks --no-cpu-baseline --no-nightly --no-pipelined --no-secondary "$@" \
+            bench.py --gpus $n --steps $STEPS --warmup 3 --no-clocks --no-cpu-baseline --no-nightly --no-pipelined --no-secondary $ZM_SCALE_ARGS "$@" \
             > $out/$name.json 2> $out/$name.err
     fi
     local rc=$?

@@ -259,15 +259,21 @@ class SubtractionPool(object):
         self.njobs, self.device = int(njobs), int(device)
         self.batch = int(batch) if int(batch) >= 2 else 0
         if int(batch) == 0 and self.njobs >= 2:
-            # Round 6: `njobs` subtractions in flight without a word about batches are run as lanes of batched fits -
-            # one lane of two or three, two lanes of njobs / 2 from four on.  Separate chains flip every job to the
-            # one-workgroup-per-region factorisation (1.1 ms instead of 0.22) and were SLOWER than one worker at
-            # njobs = 2 (4.85 against 3.8 ms per subtraction, 3.4 - 3.6 at 4 - 8: BENCH_r05); a batch pays that
-            # factorisation once for all its jobs.  Same products bit for bit (tests/test_nightly_gpu.py).
-            # `batch=1` asks for the separate chains explicitly (A / B, tests).
-            lanes = 1 if self.njobs < 4 else 2
-            self.batch = -(-self.njobs // lanes)
-            self.njobs = lanes
+            # Round 6: `njobs` subtractions in flight without a word about batches are run in the shape that was
+            # measured fastest for that many (bench.py --nightly-batches, 32 subtractions of 3072^2, ms per
+            # subtraction): separate chains flip every job to the one-workgroup-per-region factorisation (1.1 ms
+            # instead of 0.22) and were SLOWER than one worker at njobs = 2 (4.85 against 3.8; BENCH_r05), and so
+            # is a batch of two or three (1x2 5.8, 1x3 4.7: a batch pays that factorisation once, but for too few).
+            # Up to three in flight: ONE worker on the latency form, job after job (3.85); from four on: two lanes
+            # of njobs / 2 batched fits (2x2 3.4, 2x3 2.9, 2x4 2.5, 2x6 2.3); from twelve on three lanes (3x4 2.1).
+            # Same products bit for bit whatever the shape (tests/test_nightly_gpu.py).  `batch=1` asks for the
+            # separate chains explicitly (A / B, tests).
+            if self.njobs <= 3:
+                self.njobs = 1
+            else:
+                lanes = 2 if self.njobs < 12 else 3
+                self.batch = -(-self.njobs // lanes)
+                self.njobs = lanes
         # share >= 2 selects the one-workgroup-per-region form of the kernel fit's factorisation, which
         # claims nothing for itself (a lone job keeps the many-workgroup form); ZM_POOL_SHARE overrides
         # (developer: with ZM_CHOL_FORM=lat it is the fraction of the CUs each job's resident grid gets)
