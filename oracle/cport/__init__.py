@@ -13,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'zm_oracle.c')
+SOURCES = [SRC, os.path.join(HERE, 'zm_hotpants.c')]      # resample -> coadd leg; subtraction leg (round 6)
 NPV = 40
 
 
@@ -30,8 +31,8 @@ def build(native=False):
         os.makedirs(os.path.join(HERE, '_build'), exist_ok=True)
         out = os.path.join(HERE, '_build', 'libzmoracle.so')
         flags = ['-O3', '-fopenmp', '-fPIC']
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(SRC):
-        subprocess.check_call([os.environ.get('CC', 'gcc')] + flags + ['-shared', SRC, '-o', out, '-lm'])
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in SOURCES):
+        subprocess.check_call([os.environ.get('CC', 'gcc')] + flags + ['-shared'] + SOURCES + ['-o', out, '-lm'])
     return out
 
 
@@ -45,6 +46,17 @@ def _wcs(w):
     s.naxis[:] = [int(w.naxis[0]), int(w.naxis[1])]
     s.has_pv = int(bool(w.has_pv))
     return s
+
+
+class zo_hp_params(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks')] + \
+               [(k, C.c_int32) for k in ('nsx', 'nsy', 'nrx', 'nry', 'ko', 'bgo', 'nss', 'normalize', 'ngauss')] + \
+               [('deg', C.c_int32 * 4), ('sigma', C.c_double * 4)]
+
+
+class zo_hp_region(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ('solved', 'nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'pad_')] + \
+               [('kernel_sum', C.c_double), ('chi2', C.c_double)]
 
 
 class CPort(object):
@@ -104,6 +116,39 @@ class CPort(object):
                              None if bkg is None else bkg.ctypes.data, None if rms is None else rms.ctypes.data,
                              stats.ctypes.data, nb.ctypes.data, ns.ctypes.data)
         return bkg, rms, float(stats[0]), float(stats[1]), nb, ns
+
+    def hotpants(self, sci, ref, sci_rms, ref_rms, bpm=None, only_region=-1, **kw):
+        """oracle.hotpants.subtract in C (zm_hotpants.c): (diff, noise, info) with info = dict(regions=[dict or
+        None per region], nmasked).  ``only_region``: fit and apply that region alone."""
+        from oracle import hotpants as ohp
+        p = ohp.params(**kw)
+        if len(p['deg']) > 4:
+            raise ValueError('at most four Gaussians')
+        P = zo_hp_params()
+        for k in ('tu', 'tl', 'iu', 'il', 'r', 'rss', 'fin', 'fi', 'ft', 'ks'):
+            setattr(P, k, float(p[k]))
+        for k in ('nsx', 'nsy', 'nrx', 'nry', 'ko', 'bgo', 'nss', 'normalize'):
+            setattr(P, k, int(p[k]))
+        P.ngauss = len(p['deg'])
+        for i, (d, sg) in enumerate(zip(p['deg'], p['sigma'])):
+            P.deg[i], P.sigma[i] = int(d), float(sg)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (sci, ref, sci_rms, ref_rms)]
+        ny, nx = a[0].shape
+        b = None if bpm is None else np.ascontiguousarray(np.asarray(bpm) != 0, dtype=np.uint8)
+        diff, noise = np.empty((ny, nx)), np.empty((ny, nx))
+        nreg = P.nrx * P.nry
+        regs = (zo_hp_region * nreg)()
+        nm = C.c_int64()
+        self.L.zo_hotpants.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(zo_hp_params), C.c_int, C.c_void_p,
+                                                        C.c_void_p, C.POINTER(zo_hp_region), C.POINTER(C.c_int64)]
+        rc = self.L.zo_hotpants(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                None if b is None else b.ctypes.data, nx, ny, C.byref(P), int(only_region),
+                                diff.ctypes.data, noise.ctypes.data, regs, C.byref(nm))
+        if rc:
+            raise RuntimeError(f'zo_hotpants failed ({rc})')
+        infos = [dict(nstamps_total=r.nstamps_total, nstamps_used=r.nstamps_used, niter=r.niter, ncoeff=r.ncoeff,
+                      kernel_sum=r.kernel_sum, chi2=r.chi2) if r.solved else None for r in regs]
+        return diff, noise, dict(regions=infos, nmasked=int(nm.value))
 
     def combine(self, vals, wgts, kind='CLIPPED', clip_sigma=4.0, clip_ampfrac=0.3):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
