@@ -67,6 +67,7 @@ def parse():
     ap.add_argument('--no-nightly', action='store_true', help='skip the concurrent-subtraction leg')
     ap.add_argument('--no-pipelined', action='store_true', help='skip the software-pipelined rate')
     ap.add_argument('--pipelined-share', type=int, default=1, help='developer: zm_ctx_set_share of the subtraction contexts')
+    ap.add_argument('--pipelined-priority', type=int, default=0, help='developer: 1 = the subtraction chains of the pipelined leg on high-priority streams')
     ap.add_argument('--pipelined-depth', type=int, default=4, help='subtractions in flight in the pipelined leg')
     ap.add_argument('--nightly-jobs', type=int, default=32, help='subtractions of the concurrent leg')
     ap.add_argument('--nightly-pools', default='1,2,4,8,16', help='jobs in flight to time in the concurrent leg')
@@ -908,7 +909,10 @@ def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_ma
             e = z.Engine(local)
             e.set_share(max(args.pipelined_share, D))
             engs.append(e)
-            subs.append(dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=e))
+            st = torch.cuda.Stream(coadd.device, priority=-1) if args.pipelined_priority else None
+            if st is not None:
+                e.set_stream(st.cuda_stream)
+            subs.append(dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=e, stream=st))
         nset = D + 1
         snap = [dict(img=torch.empty_like(coadd.img), rms=torch.empty_like(coadd.img),
                      mask=torch.empty((args.size, args.size), dtype=torch.int32, device=coadd.img.device))

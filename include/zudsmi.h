@@ -75,6 +75,21 @@ const char* zm_version(void);
  * No counterpart in the reference (its tools report through their logs, zuds/astromatic/makecoadd/default.swarp:111). */
 int zm_ctx_query(zm_ctx* ctx, const char* what, int64_t* out);
 
+/* SWarp's own edge and mask conventions as options of every resample / coadd call of this context (defaults: the
+ * conventions of DESIGN.md section 2; both options are for pixel-for-pixel comparisons with real SWarp products and
+ * make a stack take the materialised path - INTEGRATION.md says when to pick them):
+ *   edge           ZM_EDGE_ZERO      an output pixel with a non-zero tap off the input frame gets value 0 / weight 0
+ *                  ZM_EDGE_TRUNCATE  SWarp's truncated kernel: a pixel whose position lies on the frame is computed
+ *                                    from the taps that are on it (zuds/astromatic/makecoadd/default.swarp:42-67)
+ *   mask_resample  ZM_MASKRES_OR             OR of the mask words under the non-zero taps
+ *                  ZM_MASKRES_LANCZOS_ROUND  the mask interpolated like an image and rounded, as SWarp does with
+ *                                            mask.swarp (zuds/astromatic/makecoadd/mask.swarp:25, zuds/swarp.py:141-152) */
+#define ZM_EDGE_ZERO 0
+#define ZM_EDGE_TRUNCATE 1
+#define ZM_MASKRES_OR 0
+#define ZM_MASKRES_LANCZOS_ROUND 1
+int zm_ctx_set_conventions(zm_ctx* ctx, int edge, int mask_resample);
+
 /* ---- WCS helpers (host, fp64) ------------------------------------------ */
 /* Output grid of a coadd: SWarp CENTER_TYPE ALL / PIXELSCALE_TYPE MEDIAN /
  * IMAGE_SIZE 0 (zuds/astromatic/makecoadd/default.swarp:40-49). */

@@ -27,6 +27,19 @@ Arithmetic (SWarp >= 2.38 ``interpolate.c`` as published; adopted conventions):
 Integer masks go through the same footprint (``mask.swarp`` keeps
 ``RESAMPLING_TYPE LANCZOS3``): output mask = bitwise OR of every input mask
 pixel whose tap weight is non-zero.  Chosen convention, see DESIGN.md.
+
+Round 6: the two places where SWarp's own behaviour is known to differ from the conventions above are
+OPTIONS (defaults unchanged), so that a pixel-for-pixel comparison with real SWarp output can pick them:
+
+* ``edge='truncate'`` (``EDGE_TRUNCATE``): SWarp's interpolation truncates the kernel at the frame edge - an output
+  pixel whose POSITION lies on the input frame (nearest input pixel on the frame) is computed from the taps that
+  are on the frame, the others dropped, nothing renormalised (flux falls off over the last three pixels, the
+  interpolated variance with it, so the weight grows: SWarp's weight maps show that rim); a dropped tap is not a
+  bad pixel.  Default ``edge='zero'``: such pixels get value 0 / weight 0 (=> bit 16).
+* ``mask_resample='lanczos_round'``: SWarp resamples an integer mask as the image it is (``mask.swarp:25`` changes
+  the combine type, not ``RESAMPLING_TYPE LANCZOS3``): the interpolated value of the integers, rounded to the
+  nearest integer (half to even, fp32 storage) - bit patterns that mean nothing where neighbouring pixels
+  differ; no weights are involved (``WEIGHT_TYPE NONE``).  Default ``'or'``.
 """
 import numpy as np
 
@@ -73,8 +86,21 @@ def on_frame(i, delta, n, kind):
     return np.where(delta, centre, full)
 
 
-def coverage(px, py, nx, ny, kind=LANCZOS3):
-    """Boolean map of the output pixels whose non-zero taps all lie on the nx x ny frame."""
+EDGE_ZERO, EDGE_TRUNCATE = 'zero', 'truncate'
+MASK_OR, MASK_LANCZOS_ROUND = 'or', 'lanczos_round'
+
+
+def position_on_frame(p, n):
+    """EDGE_TRUNCATE: the pixel nearest to the position lies on the axis of length n."""
+    j = np.floor(p + 0.5)
+    return (j >= 0) & (j < n)
+
+
+def coverage(px, py, nx, ny, kind=LANCZOS3, edge=EDGE_ZERO):
+    """Boolean map of the output pixels that get a value: all non-zero taps on the nx x ny frame (EDGE_ZERO) or
+    the position itself on the frame (EDGE_TRUNCATE)."""
+    if edge == EDGE_TRUNCATE:
+        return position_on_frame(px, nx) & position_on_frame(py, ny)
     ix, _, ddx = split_position(px)
     iy, _, ddy = split_position(py)
     return on_frame(ix, ddx, nx, kind) & on_frame(iy, ddy, ny, kind)
@@ -101,11 +127,13 @@ def positions(wout, win, onx, ony):
 
 
 def resample(img, wgt, px, py, kind=LANCZOS3, fscale=1.0, mask=None,
-             chunk=256):
+             chunk=256, edge=EDGE_ZERO, mask_resample=MASK_OR, debug=None):
     """Resample ``img`` (and weight map ``wgt`` = 1/var, may be None = all 1).
 
     px, py: 0-based input positions per output pixel.  Returns
-    (out_img, out_wgt, out_mask_or_None), float64 / int64.
+    (out_img, out_wgt, out_mask_or_None), float64 / int64.  ``edge`` / ``mask_resample``: module docstring.
+    ``debug``: a dict that receives 'mask_float', the interpolated mask before rounding (tests compare a device that
+    evaluates fp32 table taps with it: the integers agree except within rounding distance of a half).
     """
     img = np.asarray(img, dtype=np.float64)
     ny, nx = img.shape
@@ -142,23 +170,35 @@ def resample(img, wgt, px, py, kind=LANCZOS3, fscale=1.0, mask=None,
         nt = tx.shape[-1]
         x0 = ix + off
         y0 = iy + off
-        inb = on_frame(ix, ddx, nx, kind) & on_frame(iy, ddy, ny, kind)
+        trunc = edge == EDGE_TRUNCATE
+        if trunc:
+            inb = position_on_frame(px[sl], nx) & position_on_frame(py[sl], ny)
+        else:
+            inb = on_frame(ix, ddx, nx, kind) & on_frame(iy, ddy, ny, kind)
         acc = np.zeros(ix.shape)
         vacc = np.zeros(ix.shape)
         anybad = np.zeros(ix.shape, dtype=bool)
         macc = np.zeros(ix.shape, dtype=np.int64)
+        mflt = np.zeros(ix.shape)
         for r in range(nt):
             yy = np.clip(y0 + r, 0, ny - 1)
             for c in range(nt):
                 xx = np.clip(x0 + c, 0, nx - 1)
                 wt = ty[..., r] * tx[..., c]
+                if trunc:           # taps off the frame are dropped: they add nothing and flag nothing
+                    wt = np.where((y0 + r >= 0) & (y0 + r < ny) & (x0 + c >= 0) & (x0 + c < nx), wt, 0.0)
                 acc += wt * img[yy, xx]
                 vacc += wt * np.where(bad_in[yy, xx], 0.0, var[yy, xx])
                 nz = wt != 0.0
                 anybad |= nz & bad_in[yy, xx]
                 if mask is not None:
                     macc |= np.where(nz, mask[yy, xx], 0)
+                    mflt += wt * mask[yy, xx]            # (the mask as the image SWarp takes it for)
         good = inb & ~anybad & (vacc > 0)
+        if mask is not None and mask_resample == MASK_LANCZOS_ROUND:
+            macc = np.rint(mflt).astype(np.int64)
+            if debug is not None:
+                debug.setdefault('mask_float', np.zeros(oshape))[sl] = np.where(inb, mflt, 0.0)
         out[sl] = np.where(good, acc * fscale, 0.0)
         with np.errstate(divide='ignore', invalid='ignore'):
             outw[sl] = np.where(good, 1.0 / (vacc * fscale * fscale), 0.0)

@@ -340,3 +340,37 @@ def test_oracle_background_estimate_equals_the_reference_bit_for_bit():
     assert am['raised'] is None and am['bkg_is_nan'] and am['std_is_nan']
     bkg, std = ob.quick_background_estimate(np.ones((4, 4), np.float32), np.ones((4, 4), np.int32))
     assert np.isnan(bkg) and np.isnan(std)
+
+
+# ---- the oracle's two SWarp options (oracle/resample.py edge= / mask_resample=): analytic known answers ------------
+def test_oracle_edge_truncate_and_lanczos_round_known_answers():
+    from oracle import resample as ores
+    rng = np.random.default_rng(8)
+    img = rng.normal(100.0, 5.0, (40, 50))
+    yo, xo = np.mgrid[0:40, 0:50].astype(np.float64)
+    # an integer shift is exact under either rule (delta kernels: one tap); the rules differ only in what they call covered
+    a = ores.resample(img, None, xo + 3, yo - 2, edge='zero')
+    b = ores.resample(img, None, xo + 3, yo - 2, edge='truncate')
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # a fractional shift: the default blanks a 3-pixel border, the truncated kernel keeps every pixel whose position is on
+    # the frame, with less than the full tap sum (no renormalisation): a constant image falls off towards the edge
+    one = np.ones((40, 50))
+    z0, w0, _ = ores.resample(one, None, xo + 0.3, yo - 0.4, edge='zero')
+    z1, w1, _ = ores.resample(one, None, xo + 0.3, yo - 0.4, edge='truncate')
+    assert (w0 > 0).sum() == (40 - 5) * (50 - 5) and (w1 > 0).sum() == 40 * 50            # (every position is within half a pixel of the frame)
+    inner = w0 > 0
+    np.testing.assert_allclose(z0[inner], 1.0, rtol=1e-12)
+    np.testing.assert_allclose(z1[inner], z0[inner], rtol=0, atol=0)
+    rim = (w1 > 0) & ~inner
+    assert rim.sum() > 300 and np.abs(z1[rim] - 1.0).max() > 0.05 and np.abs(z1[rim] - 1.0).max() < 0.7
+    # masks: a constant mask interpolates to itself; an isolated flagged pixel rings (negative lobes) where OR spreads its bit
+    m = np.zeros((40, 50), dtype=np.int64)
+    m[20, 25] = 256
+    _, _, m_or = ores.resample(img, None, xo + 0.3, yo - 0.4, mask=m)
+    dbg = {}
+    _, _, m_lz = ores.resample(img, None, xo + 0.3, yo - 0.4, mask=m, mask_resample='lanczos_round', debug=dbg)
+    assert (m_or == 256).sum() == 36 and m_lz.min() < 0 and m_lz.max() < 256 and (m_lz != 0).sum() <= 36
+    assert np.array_equal(m_lz, np.rint(dbg['mask_float']).astype(np.int64))
+    assert abs(m_lz.sum() - 256) <= 18                   # unit-sum taps conserve the "flux" of the bit, up to 36 roundings
+    _, _, c_lz = ores.resample(img, None, xo + 0.3, yo - 0.4, mask=np.full((40, 50), 6141), mask_resample='lanczos_round')
+    assert (c_lz[inner] == 6141).all()

@@ -104,6 +104,7 @@ _SIGS = {
     'zm_ctx_synchronize': (C.c_int, [_P]),
     'zm_ctx_set_share': (C.c_int, [_P, C.c_int]),
     'zm_ctx_query': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    'zm_ctx_set_conventions': (C.c_int, [_P, C.c_int, C.c_int]),
     'zm_last_error': (C.c_char_p, []),
     'zm_version': (C.c_char_p, []),
     'zm_autogrid': (C.c_int, [C.c_int, C.POINTER(zm_wcs), C.POINTER(zm_wcs)]),

@@ -145,11 +145,13 @@ static int frame_mask_i32(zm_ctx* ctx, const zm_dframe* f, const char* slot, con
 // Also accumulates the mask coadd when acc_mask != NULL.
 static int resample_frames_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
                                  const zm_coadd_params* P, float2* stack, int32_t* acc_mask);
-static bool fused_stack_ok(const zm_coadd_params* P);
+// (a context with SWarp's own edge / mask conventions switched on takes the materialised path: csrc/resample_opts.hip)
+static bool default_conventions(const zm_ctx* ctx) { return ctx->edge == ZM_EDGE_ZERO && ctx->mask_resample == ZM_MASKRES_OR; }
+static bool fused_stack_ok(const zm_ctx* ctx, const zm_coadd_params* P);
 static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout,
                            const zm_coadd_params* P, float2* stack, int32_t* acc_mask,
                            int32_t mask_fill, int mask_kind) {
-    if (fused_stack_ok(P) && mask_fill == -1 && mask_kind == P->mask_combine)
+    if (fused_stack_ok(ctx, P) && mask_fill == -1 && mask_kind == P->mask_combine)
         return resample_frames_fused(ctx, n, fr, wout, P, stack, acc_mask);
     const int onx = wout->naxis[0], ony = wout->naxis[1];
     const int64_t opix = (int64_t)onx * ony;
@@ -218,12 +220,12 @@ static int resample_frames(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs
 // WEIGHTED / AVERAGE stacks with a Lanczos-3 kernel: every frame is prepped into its own plane
 // (N x 75 MB at 3072^2: the place the resampled stack took before), then ONE launch loops the
 // frames inside each output tile (k_coadd_fused, resample.hip).
-static bool fused_ok(const zm_coadd_params* P) {
+static bool fused_ok(const zm_ctx* ctx, const zm_coadd_params* P) {
     // ZM_COADD_FUSED=0 takes the materialised path (resampled stack + k_combine_sum): the
     // reference the fused kernel is tested against bit for bit (tests/test_coadd_gpu.py)
     const char* e = getenv("ZM_COADD_FUSED");
     const bool off = e && e[0] == '0';
-    return !off && P->resample == ZM_RESAMPLE_LANCZOS3 &&
+    return !off && default_conventions(ctx) && P->resample == ZM_RESAMPLE_LANCZOS3 &&
            (P->combine == ZM_COMBINE_WEIGHTED || P->combine == ZM_COMBINE_AVERAGE);
 }
 
@@ -396,11 +398,11 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     return 0;
 }
 
-static bool fused_stack_ok(const zm_coadd_params* P) {
+static bool fused_stack_ok(const zm_ctx* ctx, const zm_coadd_params* P) {
     // the stack of any Lanczos-3 coadd; ZM_COADD_FUSED=0: k_resample frame by frame (the reference
     // the fused machinery is tested against)
     const char* e = getenv("ZM_COADD_FUSED");
-    return !(e && e[0] == '0') && P->resample == ZM_RESAMPLE_LANCZOS3;
+    return !(e && e[0] == '0') && default_conventions(ctx) && P->resample == ZM_RESAMPLE_LANCZOS3;
 }
 
 static int coadd_fused(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* wout, const zm_coadd_params* P,
@@ -457,7 +459,7 @@ extern "C" int zm_coadd_dev(zm_ctx* ctx, int nframes, const zm_dframe* frames,
     ZM_HIP(hipSetDevice(ctx->device));
     ZM_TRY(check_wcs(wout, "output grid"));
     const int64_t opix = (int64_t)wout->naxis[0] * wout->naxis[1];
-    if (fused_ok(params))
+    if (fused_ok(ctx, params))
         return coadd_fused(ctx, nframes, frames, wout, params, partial, out_img, out_wgt, out_mask, out_mask_wgt);
     float2* stack = nullptr;
     ZM_TRY(ctx->get("stack", sizeof(float2) * (size_t)opix * nframes, (void**)&stack));

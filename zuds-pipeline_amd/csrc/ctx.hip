@@ -125,10 +125,22 @@ extern "C" int zm_ctx_set_share(zm_ctx* ctx, int nctx) {
     return 0;
 }
 
+extern "C" int zm_ctx_set_conventions(zm_ctx* ctx, int edge, int mask_resample) {
+    ZM_CHECK(ctx != nullptr, "zm_ctx_set_conventions: ctx is NULL");
+    ZM_CHECK(edge == ZM_EDGE_ZERO || edge == ZM_EDGE_TRUNCATE, "zm_ctx_set_conventions: unknown edge rule %d", edge);
+    ZM_CHECK(mask_resample == ZM_MASKRES_OR || mask_resample == ZM_MASKRES_LANCZOS_ROUND,
+             "zm_ctx_set_conventions: unknown mask rule %d", mask_resample);
+    ctx->edge = edge;
+    ctx->mask_resample = mask_resample;
+    return 0;
+}
+
 extern "C" int zm_ctx_query(zm_ctx* ctx, const char* what, int64_t* out) {
     ZM_CHECK(ctx && what && out, "zm_ctx_query: null argument");
     if (!strcmp(what, "fused_form")) *out = ctx->ff_last_form;
     else if (!strcmp(what, "dev_build")) *out = ZM_DEV_BUILD;
+    else if (!strcmp(what, "edge")) *out = ctx->edge;
+    else if (!strcmp(what, "mask_resample")) *out = ctx->mask_resample;
     else ZM_CHECK(false, "zm_ctx_query: unknown item \"%s\"", what);
     return 0;
 }

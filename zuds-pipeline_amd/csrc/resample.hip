@@ -22,7 +22,7 @@
 // ---------------------------------------------------------------------------
 // The map travels as a by-value kernel argument (1.5 KB): no host staging buffer
 // whose lifetime would have to outlive the enqueue.
-__global__ void k_lattice(const zm_map_params mp, int lnx, int lny, double2* __restrict__ lat) {
+__global__ __launch_bounds__(256) void k_lattice(const zm_map_params mp, int lnx, int lny, double2* __restrict__ lat) {
     int gx = blockIdx.x * blockDim.x + threadIdx.x;
     int gy = blockIdx.y * blockDim.y + threadIdx.y;
     if (gx >= lnx || gy >= lny) return;
@@ -647,14 +647,33 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
     if (!mask || !macc) mop = 0;
     if (lds_elems > RS_PFCAP) lds_elems = RS_PFCAP;      // what the prefetch registers can stage
     size_t shmem = (size_t)HDR_FLOATS * 4 + (size_t)lds_elems * sizeof(float2);
-    if (kernel == ZM_RESAMPLE_LANCZOS3)
-        return launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
-                                                          lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                          macc, mop, mkind, mfirst, plane_a, plane_b);
-    if (kernel == ZM_RESAMPLE_BILINEAR)
-        return launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
-                                                          lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                          macc, mop, mkind, mfirst, plane_a, plane_b);
+    if (kernel == ZM_RESAMPLE_LANCZOS3 || kernel == ZM_RESAMPLE_BILINEAR) {
+        // the conventions of the context (zm_ctx_set_conventions; defaults: none of this runs).  LANCZOS_ROUND: the
+        // image goes alone and the mask through the interpolating kernel; TRUNCATE: the rim is recomputed with per-tap
+        // bounds behind k_resample (csrc/resample_opts.hip)
+        const bool lz = mop && ctx->mask_resample == ZM_MASKRES_LANCZOS_ROUND, trunc = ctx->edge == ZM_EDGE_TRUNCATE;
+        const int mop_img = lz ? 0 : mop;
+        if (kernel == ZM_RESAMPLE_LANCZOS3)
+            ZM_TRY(launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
+                                                              lny, fscale, dst, onx, ony, lds_elems, mask,
+                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b));
+        else
+            ZM_TRY(launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
+                                                              lny, fscale, dst, onx, ony, lds_elems, mask,
+                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b));
+        if (trunc)
+            ZM_TRY(zm_launch_resample_rim(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, fscale, dst, plane_a, plane_b, onx,
+                                          ony, mask, macc, mop_img, mkind));
+        if (lz) {
+            const int64_t opix = (int64_t)onx * ony;
+            if (mop == 1) return zm_launch_resample_mask_opts(ctx, mask, nx, ny, lat, lnx, lny, kernel, macc, onx, ony, 0, 1, trunc);
+            int32_t* tmp = nullptr;
+            ZM_TRY(ctx->get("mask_tmp", sizeof(int32_t) * opix, (void**)&tmp));
+            ZM_TRY(zm_launch_resample_mask_opts(ctx, mask, nx, ny, lat, lnx, lny, kernel, tmp, onx, ony, -1, 1, trunc));
+            return zm_launch_mask_accum(ctx, macc, tmp, opix, mkind, mfirst);
+        }
+        return 0;
+    }
     if (kernel == ZM_RESAMPLE_NEAREST) {
         zm_scope_timer t(ctx, "resample");
         hipLaunchKernelGGL(k_resample_nearest, grd, blk, 0, ctx->stream, src, nx, ny, spitch, lat, lnx,
@@ -754,6 +773,9 @@ int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny, co
                             int lnx, int lny, int kernel, int32_t* dst, int onx, int ony,
                             int32_t fill) {
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
+    if (kernel != ZM_RESAMPLE_NEAREST && (ctx->edge == ZM_EDGE_TRUNCATE || ctx->mask_resample == ZM_MASKRES_LANCZOS_ROUND))
+        return zm_launch_resample_mask_opts(ctx, mask, nx, ny, lat, lnx, lny, kernel, dst, onx, ony, fill,
+                                            ctx->mask_resample == ZM_MASKRES_LANCZOS_ROUND, ctx->edge == ZM_EDGE_TRUNCATE);
     zm_scope_timer t(ctx, "resample_mask");
     if (kernel == ZM_RESAMPLE_LANCZOS3) {
         hipLaunchKernelGGL(k_resample_mask<ZM_RESAMPLE_LANCZOS3>, grd, blk, 0, ctx->stream, mask,

@@ -87,6 +87,9 @@ struct zm_ctx {
     bool ff_pre_valid = false;
     int ff_pre_nfr = 0, ff_pre_onx = 0, ff_pre_ony = 0, ff_pre_lds = 0;
     bool ff_pre_own = false;
+    // SWarp's own edge / mask conventions as options (zm_ctx_set_conventions; csrc/resample_opts.hip)
+    int edge = 0;                              // ZM_EDGE_ZERO / ZM_EDGE_TRUNCATE
+    int mask_resample = 0;                     // ZM_MASKRES_OR / ZM_MASKRES_LANCZOS_ROUND
     int ff_last_form = 0;                      // the fused kernel the last zm_launch_coadd_fused ran: 1 _dma, 2 _own (zm_ctx_query)
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
     bool timing = false;
@@ -208,6 +211,11 @@ int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny,
 int zm_launch_combine(zm_ctx* ctx, int n, const float2* stack, int64_t frame_stride,
                       int64_t npix, int kind, float clip_sigma, float clip_ampfrac,
                       float* out_img, float* out_wgt, int partial);
+int zm_launch_resample_rim(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch, const double2* lat, int lnx,
+                           int lny, int kernel, float fscale, float2* dst, float* plane_a, float* plane_b, int onx,
+                           int ony, const int32_t* mask, int32_t* macc, int mop, int mkind);
+int zm_launch_resample_mask_opts(zm_ctx* ctx, const int32_t* mask, int nx, int ny, const double2* lat, int lnx, int lny,
+                                 int kernel, int32_t* dst, int onx, int ony, int32_t fill, int lanczos, int trunc);
 int zm_launch_mask_accum(zm_ctx* ctx, int32_t* acc, const int32_t* m, int64_t npix, int kind,
                          int first);
 int zm_launch_mask_finalize(zm_ctx* ctx, int32_t* acc, float* cov, int64_t npix);

@@ -89,6 +89,17 @@ class Engine(object):
         each): every engine then sizes its kernel-fit launches to 1 / nctx of the GPU."""
         check(self.L.zm_ctx_set_share(self._ctx, int(nctx)), 'zm_ctx_set_share')
 
+    def set_conventions(self, edge='zero', mask_resample='or'):
+        """SWarp's own edge / mask conventions for every resample and coadd of this engine
+        (``zm_ctx_set_conventions``): ``edge`` 'zero' (default) or 'truncate' (kernel truncated at the frame edge),
+        ``mask_resample`` 'or' (default) or 'lanczos_round' (masks interpolated and rounded).  INTEGRATION.md."""
+        e = {'zero': 0, 'truncate': 1}
+        m = {'or': 0, 'lanczos_round': 1}
+        if str(edge).lower() not in e or str(mask_resample).lower() not in m:
+            raise ValueError(f'edge must be one of {list(e)}, mask_resample one of {list(m)}')
+        check(self.L.zm_ctx_set_conventions(self._ctx, e[str(edge).lower()], m[str(mask_resample).lower()]),
+              'zm_ctx_set_conventions')
+
     def query(self, what):
         """``zm_ctx_query``: 'fused_form' (0 none, 1 k_coadd_fused_dma, 2 k_coadd_fused_own), 'dev_build'."""
         v = C.c_int64()
