@@ -390,6 +390,15 @@ int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
                     const int32_t* mask, const zm_wcs* win, const zm_wcs* wout,
                     int kernel, double fscale, float* out_img, float* out_wgt,
                     int32_t* out_mask);
+
+/* Two images that share a geometry through one resampling launch (device pointers): what the reference does in two
+ * SWarp runs when it aligns a reference image and that image's rms map to a science grid (zuds/subtraction.py:109 ->
+ * zuds/fitsfile.py:290-314, zuds/hotpants.py:51).  img_a (optionally with its int32 mask: OR under the footprint,
+ * into out_mask) and img_b; no weights (WEIGHT_TYPE NONE); out_b is scaled by fscale_b.  Values equal those of two
+ * zm_resample_dev calls bit for bit; uncovered pixels are 0 in both outputs; no weight planes. */
+int zm_align_pair_dev(zm_ctx* ctx, const float* img_a, const float* img_b, const int32_t* mask,
+                      const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale_a, double fscale_b,
+                      float* out_a, float* out_b, int32_t* out_mask);
 /* zm_resample / zm_resample_dev for a BITPIX 16 mask plane (run_align on a ZTF mask, zuds/swarp.py:157-204):
  * the int16 plane crosses PCIe as it is and is widened on the device; out_mask stays int32 (bit 16 / 17 of
  * the products, zuds/mask.py:26-33, zuds/subtraction.py:170-171). */

@@ -344,7 +344,10 @@ def test_bit17_is_set_by_the_subtraction_itself_and_only_by_its_final_attempt(ch
 
 def test_aligned_reference_mask_has_no_bit16_and_uncovered_pixels_count(chain, device_sub):
     ds, diff, noise, submask = device_sub
-    uncovered = ds.ref_al_w.cpu().numpy() == 0
+    # (round 6: reference and rms map are aligned by one launch, which hands back no weight planes; an uncovered
+    # pixel is 0 in both outputs and the aligned rms is positive wherever there is data)
+    uncovered = ds.refrms_al.cpu().numpy() == 0
+    assert (ds.ref_al.cpu().numpy()[uncovered] == 0).all()
     assert 0.05 < uncovered.mean() < 0.3                  # the two strips
     refmask_al = ds.refmask_al.cpu().numpy()
     # bit 16 may arrive from the reference's own mask (its union grid has corners no input
@@ -380,3 +383,40 @@ def test_device_subtraction_matches_the_oracle_pipeline(chain, device_sub):
     assert (submask != r['mask']).mean() < 1e-4
     regs = [g for g in r['info']['regions'] if g is not None]
     assert ds.info.nstamps_used == sum(g['nstamps_used'] for g in regs)
+
+
+def test_pair_alignment_equals_the_two_alignments_bit_for_bit(env):
+    """zm_align_pair_dev (round 6: the reference and its rms map to the science grid in ONE resampling launch) against
+    zm_resample_dev twice, as zuds/subtraction.py:109 and zuds/hotpants.py:51 align them: every value the same bits, the
+    mask too; with a rotation, a fractional dither and a science grid that sticks out of the reference."""
+    z, torch, eng, stream = env
+    s = synth()
+    nx, ny = 700, 650
+    wref = s.ztf_wcs(nx, ny, tpv=True)
+    wsci = s.ztf_wcs(nx + 40, ny - 30, dx=-17.3, dy=9.6, rot_deg=0.4, tpv=True)
+    f = s.make_frame(nx, ny, 4242, wref, nstars=60, nbad=80)
+    rng = np.random.default_rng(5)
+    rms = np.where(f['mask'] != 0, np.float32(223.6068), rng.uniform(2.0, 6.0, (ny, nx)).astype(np.float32))
+    L, W = eng.L, z._lib.wcs_struct
+    a, b = W(wref), W(wsci)
+    oshape = (ny - 30, nx + 40)
+    for kern in ('LANCZOS3', 'BILINEAR'):
+        K = z._lib.RESAMPLE[kern]
+        with torch.cuda.stream(stream):
+            d_img, d_rms, d_msk = dev(torch, f['img']), dev(torch, rms), dev(torch, f['mask'].astype(np.int32))
+            o = [torch.empty(oshape, dtype=torch.float32, device='cuda') for _ in range(6)]
+            m = [torch.empty(oshape, dtype=torch.int32, device='cuda') for _ in range(2)]
+            z._lib.check(L.zm_resample_dev(eng.ctx, d_img.data_ptr(), None, d_msk.data_ptr(), C.byref(a), C.byref(b), K, 0.37,
+                                           o[0].data_ptr(), o[1].data_ptr(), m[0].data_ptr()))
+            z._lib.check(L.zm_resample_dev(eng.ctx, d_rms.data_ptr(), None, None, C.byref(a), C.byref(b), K, 0.61,
+                                           o[2].data_ptr(), o[3].data_ptr(), None))
+            z._lib.check(L.zm_align_pair_dev(eng.ctx, d_img.data_ptr(), d_rms.data_ptr(), d_msk.data_ptr(), C.byref(a), C.byref(b),
+                                             K, 0.37, 0.61, o[4].data_ptr(), o[5].data_ptr(), m[1].data_ptr()))
+        stream.synchronize()
+        assert torch.equal(o[0], o[4]) and torch.equal(o[2], o[5]) and torch.equal(m[0], m[1]), kern
+        assert (o[1] == 0).float().mean() > 0.02 and torch.equal(o[5] == 0, o[1] == 0)
+    # argument checks
+    assert L.zm_align_pair_dev(eng.ctx, d_img.data_ptr(), d_rms.data_ptr(), None, C.byref(a), C.byref(b), 0, 1.0, 1.0,
+                               o[4].data_ptr(), o[5].data_ptr(), None) != 0       # NEAREST has no pair form
+    assert L.zm_align_pair_dev(eng.ctx, d_img.data_ptr(), None, None, C.byref(a), C.byref(b), 3, 1.0, 1.0,
+                               o[4].data_ptr(), o[5].data_ptr(), None) != 0

@@ -117,6 +117,8 @@ _SIGS = {
     'zm_resample': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs),
                               C.POINTER(zm_wcs), C.c_int, C.c_double,
                               _P, _P, _P]),
+    'zm_align_pair_dev': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs), C.POINTER(zm_wcs), C.c_int, C.c_double,
+                                    C.c_double, _P, _P, _P]),
     'zm_resample_dev': (C.c_int, [_P, _P, _P, _P, C.POINTER(zm_wcs),
                                   C.POINTER(zm_wcs), C.c_int, C.c_double,
                                   _P, _P, _P]),

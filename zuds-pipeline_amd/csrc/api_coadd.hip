@@ -527,6 +527,40 @@ extern "C" int zm_resample_dev(zm_ctx* ctx, const float* img, const float* wgt,
     return 0;
 }
 
+// Two images on one geometry through ONE resampling launch: img_a (with its mask, optionally) and img_b go from `win`
+// to `wout` as zm_resample_dev would take each (no weights: WEIGHT_TYPE NONE, zuds/swarp.py:143-152), out_b scaled by
+// fscale_b.  The reference aligns its reference image and that image's rms map to the science grid in two SWarp runs
+// (zuds/subtraction.py:109 -> zuds/fitsfile.py:290-314, zuds/hotpants.py:51): same positions, same taps.  Per pixel the
+// values are those of the two separate calls, bit for bit (tests/test_device_chain_gpu.py); no weight planes come back
+// (uncovered pixels are 0 in both outputs).  Default conventions only (zm_ctx_set_conventions).
+extern "C" int zm_align_pair_dev(zm_ctx* ctx, const float* img_a, const float* img_b, const int32_t* mask,
+                                 const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale_a, double fscale_b,
+                                 float* out_a, float* out_b, int32_t* out_mask) {
+    ZM_CHECK(ctx && img_a && img_b && win && wout && out_a && out_b, "zm_align_pair_dev: null argument");
+    ZM_CHECK(!mask || out_mask, "zm_align_pair_dev: out_mask required");
+    ZM_CHECK(kernel == ZM_RESAMPLE_LANCZOS3 || kernel == ZM_RESAMPLE_BILINEAR, "zm_align_pair_dev: LANCZOS3 or BILINEAR (got %d)", kernel);
+    ZM_CHECK(fscale_b != 0.0, "zm_align_pair_dev: fscale_b must not be 0");
+    ZM_CHECK(ctx->edge == ZM_EDGE_ZERO && ctx->mask_resample == ZM_MASKRES_OR, "zm_align_pair_dev: default conventions only");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_TRY(check_wcs(win, "input frame"));
+    ZM_TRY(check_wcs(wout, "output grid"));
+    const int onx = wout->naxis[0], ony = wout->naxis[1];
+    const int nx = win->naxis[0], ny = win->naxis[1];
+    const int lnx = (onx - 1) / ZM_LATTICE_STEP + 2, lny = (ony - 1) / ZM_LATTICE_STEP + 2;
+    zm_map_params mp_host;
+    zm_make_map(wout, win, &mp_host);
+    const int lds = std::min(plan_lds(&mp_host, onx, ony, ntaps_of(kernel)), 8000);
+    double2* lat = nullptr;
+    ZM_TRY(ctx->get("lattice", sizeof(double2) * (size_t)lnx * lny, (void**)&lat));
+    ZM_TRY(zm_launch_lattice(ctx, &mp_host, lnx, lny, lat));
+    const int spitch = (nx + 1) & ~1;
+    float2* src = nullptr;
+    ZM_TRY(ctx->get("prep", sizeof(float2) * (size_t)spitch * ny, (void**)&src));
+    ZM_TRY(zm_launch_prep_pair(ctx, img_a, img_b, nx, ny, src, spitch));
+    return zm_launch_resample(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, (float)fscale_a, nullptr, onx, ony, lds,
+                              mask, out_mask, mask ? 1 : 0, 0, 1, out_a, out_b, (float)fscale_b);
+}
+
 extern "C" int zm_resample_i16_dev(zm_ctx* ctx, const float* img, const float* wgt, const int16_t* mask,
                                    const zm_wcs* win, const zm_wcs* wout, int kernel, double fscale,
                                    float* out_img, float* out_wgt, int32_t* out_mask) {

@@ -310,15 +310,34 @@ int zm_launch_prep(zm_ctx* ctx, const float* img, const float* wgt, int nx, int 
     return 0;
 }
 
+// two images that share a geometry as ONE pair plane {a, b} (pad column {0, 0}): zm_align_pair_dev
+__global__ __launch_bounds__(256) void k_prep_pair(const float* __restrict__ a, const float* __restrict__ b, int nx, int ny,
+                                                   float2* __restrict__ dst, int spitch) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= spitch) return;
+    const size_t k = (size_t)y * nx + x;
+    dst[(size_t)y * spitch + x] = x < nx ? make_float2(a[k], b[k]) : make_float2(0.f, 0.f);
+}
+int zm_launch_prep_pair(zm_ctx* ctx, const float* a, const float* b, int nx, int ny, float2* dst, int spitch) {
+    zm_scope_timer t(ctx, "prep");
+    hipLaunchKernelGGL(k_prep_pair, dim3(zm_div_up(spitch, 256), ny), dim3(256), 0, ctx->stream, a, b, nx, ny, dst, spitch);
+    ZM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int KIND, int MASKOP>
 __global__ __launch_bounds__(256, 4) void k_resample(
     const float2* __restrict__ src, int nx, int ny, int spitch, const double2* __restrict__ lat,
     int lnx, int lny, float fscale, float2* __restrict__ dst, int onx, int ony, int lds_cap,
     const int32_t* __restrict__ mask, const uint16_t* __restrict__ mbox, int32_t* __restrict__ macc,
     int mkind, int mfirst, int ntx, int ntiles, const float* __restrict__ taptab,
-    float* __restrict__ plane_a, float* __restrict__ plane_b) {
+    float* __restrict__ plane_a, float* __restrict__ plane_b, float pair_scale) {
     // (plane_a / plane_b: value and weight as two planes - what an alignment hands back - instead of the pair
     // plane `dst` that a stack keeps: no pass to split them afterwards)
+    // pair_scale != 0 (round 6, zm_align_pair_dev): the plane holds TWO images {a, b} that share the geometry - the
+    // reference and its rms map on their way to a science grid (zuds/subtraction.py:109, zuds/hotpants.py:51: two
+    // SWarp runs there, two launches here until now) - and both channels are values: b leaves scaled by pair_scale,
+    // nothing is a variance, validity is the footprint test alone.  Per channel the operations of a single alignment.
     extern __shared__ float4 smem4[];
     rs_hdr* HR = reinterpret_cast<rs_hdr*>(smem4);                 // ring of 3 headers
     // Lanczos-3: the tap table sits between the headers and the pixel tile
@@ -525,7 +544,10 @@ __global__ __launch_bounds__(256, 4) void k_resample(
                         p += spitch;
                     }
                 }
-                if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
+                if (pair_scale != 0.f) {
+                    res.x = acc * fscale;
+                    res.y = vacc * pair_scale;
+                } else if (vacc > 0.f && vacc < ZM_BADVAR_TEST) {
                     res.x = acc * fscale;
                     res.y = __builtin_amdgcn_rcpf(vacc * fscale2);      // 1 ulp: one instruction
                 }
@@ -601,7 +623,8 @@ template <int KIND>
 static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float2* src, int nx, int ny,
                                 int spitch, const double2* lat, int lnx, int lny, float fscale,
                                 float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
-                                int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b) {
+                                int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b,
+                                float pair_scale) {
     dim3 blk(256, 1, 1);
     const int ntx = grd.x, ntiles = grd.x * grd.y;
     uint16_t* mbox = nullptr;
@@ -625,13 +648,13 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
     dim3 pgrd(std::min(ntiles, 256 * 4), 1, 1);
     if (mop == 0)
         hipLaunchKernelGGL((k_resample<KIND, 0>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b, pair_scale);
     else if (mop == 1)
         hipLaunchKernelGGL((k_resample<KIND, 1>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b, pair_scale);
     else
         hipLaunchKernelGGL((k_resample<KIND, 2>), pgrd, blk, shmem, ctx->stream, src, nx, ny, spitch, lat,
-                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b);
+                           lnx, lny, fscale, dst, onx, ony, lds_elems, mask, mbox, macc, mkind, mfirst, ntx, ntiles, taptab, plane_a, plane_b, pair_scale);
     ZM_HIP(hipGetLastError());
     return 0;
 }
@@ -641,8 +664,10 @@ static int launch_resample_kind(zm_ctx* ctx, dim3 grd, size_t shmem, const float
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
                        float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
-                       int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b) {
+                       int32_t* macc, int mop, int mkind, int mfirst, float* plane_a, float* plane_b, float pair_scale) {
     dim3 blk(256, 1, 1), grd(zm_div_up(onx, TW), zm_div_up(ony, TH), 1);
+    ZM_CHECK(pair_scale == 0.f || (kernel != ZM_RESAMPLE_NEAREST && plane_a && plane_b && ctx->edge == ZM_EDGE_ZERO),
+             "zm_launch_resample: a pair of images takes LANCZOS3 / BILINEAR, two output planes and the default edge rule");
     dim3 rgrd(zm_div_up(onx, TW), zm_div_up(ony, RTH), 1);     // k_resample: 64 x 32 tiles
     if (!mask || !macc) mop = 0;
     if (lds_elems > RS_PFCAP) lds_elems = RS_PFCAP;      // what the prefetch registers can stage
@@ -656,11 +681,11 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
         if (kernel == ZM_RESAMPLE_LANCZOS3)
             ZM_TRY(launch_resample_kind<ZM_RESAMPLE_LANCZOS3>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                               lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b));
+                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b, pair_scale));
         else
             ZM_TRY(launch_resample_kind<ZM_RESAMPLE_BILINEAR>(ctx, rgrd, shmem, src, nx, ny, spitch, lat, lnx,
                                                               lny, fscale, dst, onx, ony, lds_elems, mask,
-                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b));
+                                                              macc, mop_img, mkind, mfirst, plane_a, plane_b, pair_scale));
         if (trunc)
             ZM_TRY(zm_launch_resample_rim(ctx, src, nx, ny, spitch, lat, lnx, lny, kernel, fscale, dst, plane_a, plane_b, onx,
                                           ony, mask, macc, mop_img, mkind));

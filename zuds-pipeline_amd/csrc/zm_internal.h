@@ -204,7 +204,8 @@ int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitc
                        const double2* lat, int lnx, int lny, int kernel, float fscale,
                        float2* dst, int onx, int ony, int lds_elems, const int32_t* mask,
                        int32_t* macc, int mop, int mkind, int mfirst,
-                       float* plane_a = nullptr, float* plane_b = nullptr);
+                       float* plane_a = nullptr, float* plane_b = nullptr, float pair_scale = 0.f);
+int zm_launch_prep_pair(zm_ctx* ctx, const float* a, const float* b, int nx, int ny, float2* dst, int spitch);
 int zm_launch_resample_mask(zm_ctx* ctx, const int32_t* mask, int nx, int ny,
                             const double2* lat, int lnx, int lny, int kernel,
                             int32_t* dst, int onx, int ony, int32_t fill);

@@ -251,10 +251,20 @@ class DeviceSubtraction(object):
             # (zuds/subtraction.py:94-99), so run_align does NOT add bit 16 to it
             # (zuds/swarp.py:186-191): uncovered pixels of the aligned mask stay 0, and
             # quick_background_estimate(ref) therefore counts them (zuds/hotpants.py:67).
-            check(L.zm_resample_dev(ctx, ref.data_ptr(), None, ref_mask.data_ptr(),
-                                    C.byref(self.wref), C.byref(self.wsci), LAN, fs.value,
-                                    self.ref_al.data_ptr(), self.ref_al_w.data_ptr(),
-                                    self.refmask_al.data_ptr()), 'align ref')
+            # Round 6: the reference and its rms map go to the science grid in ONE launch (zm_align_pair_dev: same
+            # positions, same taps, the values of the two separate alignments bit for bit; hotpants.py:51 for the rms)
+            pair = os.environ.get('ZM_ALIGN_PAIR', '1') != '0' and int(self.engine.query('edge')) == 0 and \
+                int(self.engine.query('mask_resample')) == 0
+            if pair:
+                check(L.zm_align_pair_dev(ctx, ref.data_ptr(), ref_rms.data_ptr(), ref_mask.data_ptr(),
+                                          C.byref(self.wref), C.byref(self.wsci), LAN, fs.value, fs_rms.value,
+                                          self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
+                                          self.refmask_al.data_ptr()), 'align ref + rms')
+            else:
+                check(L.zm_resample_dev(ctx, ref.data_ptr(), None, ref_mask.data_ptr(),
+                                        C.byref(self.wref), C.byref(self.wsci), LAN, fs.value,
+                                        self.ref_al.data_ptr(), self.ref_al_w.data_ptr(),
+                                        self.refmask_al.data_ptr()), 'align ref')
             # badpix = remapped_refmask | sci mask; boolean bpm (subtraction.py:135-142)
             check(L.zm_mask_bad_dev(ctx, self.refmask_al.data_ptr(), sci_mask.data_ptr(),
                                     self.BAD_SUM, self.n, self.submask.data_ptr(),
@@ -271,9 +281,10 @@ class DeviceSubtraction(object):
             else:
                 scim = sci
             # ref rms aligned to the science grid (hotpants.py:51)
-            check(L.zm_resample_dev(ctx, ref_rms.data_ptr(), None, None, C.byref(self.wref),
-                                    C.byref(self.wsci), LAN, fs_rms.value, self.refrms_al.data_ptr(),
-                                    self.refrms_al_w.data_ptr(), None), 'align ref rms')
+            if not pair:
+                check(L.zm_resample_dev(ctx, ref_rms.data_ptr(), None, None, C.byref(self.wref),
+                                        C.byref(self.wsci), LAN, fs_rms.value, self.refrms_al.data_ptr(),
+                                        self.refrms_al_w.data_ptr(), None), 'align ref rms')
             # quick_background_estimate x 2 (hotpants.py:65-67).  Round 4: the estimates stay on the device and
             # the subtraction takes its lower limits (median - 10 sigma, hotpants.py:69-72) from there - the fit is
             # enqueued behind them without the host reading them in between; `limits` fetches them afterwards.
