@@ -4,9 +4,8 @@ con = sqlite3.connect(sys.argv[1])
 rows = con.execute('select name, start, end from kernels order by start').fetchall()
 names = [re.sub(r'^void ', '', n).split('(')[0][:46] for n, _, _ in rows]
 # last step: from the last k_mesh_stats_fast start back to the previous
-idx = [i for i, n in enumerate(names) if n.startswith('k_mesh_stats_fast')]
-# steps have 1+ stats launches; find starts separated by > 1 ms
-starts = [i for k, i in enumerate(idx) if k == 0 or rows[i][1] - rows[idx[k-1]][1] > 1.5e6]
+# a step starts with the mesh statistics of the stack (k_mesh_stats_fast<2>: image + variance statistic of every frame)
+starts = [i for i, n in enumerate(names) if n.startswith('k_mesh_stats_fast<2>')]
 a, b = starts[-3], starts[-2]
 t0 = rows[a][1]
 last_end = t0

@@ -54,10 +54,11 @@ class ObjectIO(object):
         self._free = queue.Queue()
         self._pins = 0
         # planes that are already in HBM, by file: what derive_maps made (and wrote) or read on the way - the
-        # from_images call that follows takes them from here instead of the file (ZM_OBJDEV_CACHE_GB, default 12)
+        # from_images call that follows takes them from here instead of the file (ZM_OBJDEV_CACHE_GB, default 4: one from_images call of 32 frames)
         self._cache = {}
         self._cache_bytes = 0
-        self._cache_cap = int(float(os.environ.get('ZM_OBJDEV_CACHE_GB', '12')) * 1e9)
+        self._cache_cap = int(float(os.environ.get('ZM_OBJDEV_CACHE_GB', '4')) * 1e9)
+        self._prestamp = {}                 # (path, kind) -> the file's stamp taken BEFORE it was read
 
     # -- plane cache --------------------------------------------------------------------------
     @staticmethod
@@ -66,9 +67,15 @@ class ObjectIO(object):
         return (st.st_mtime_ns, st.st_size)
 
     def cache_put(self, path, kind, tensor):
-        """Remember that `tensor` is the decoded data of the file at `path` as it is on disk NOW."""
+        """Remember that `tensor` is the decoded data of the file at `path`.  The entry carries the file's stamp
+        (mtime in ns, size) from BEFORE the read that produced the plane (`planes` notes it) - a rewrite between the
+        read and this call then leaves a stale stamp behind and the entry is never served; a plane this process
+        wrote itself (derived maps) carries the stamp of the file as written.  Planes are handed out by reference:
+        READ-ONLY for every consumer (the kernels that take them only read; host code must clone before it changes
+        one)."""
         try:
-            key, stamp = (os.path.abspath(path), kind), self._stamp(path)
+            key = (os.path.abspath(path), kind)
+            stamp = self._prestamp.pop(key, None) or self._stamp(path)
         except OSError:
             return
         nbytes = tensor.numel() * tensor.element_size()
@@ -96,6 +103,7 @@ class ObjectIO(object):
         return hit[0]
 
     def cache_clear(self):
+        self._prestamp.clear()
         self._cache.clear()
         self._cache_bytes = 0
 
@@ -132,6 +140,10 @@ class ObjectIO(object):
                 out[i] = hit
             else:
                 files.append((i, obj.local_path, kind))
+                try:
+                    self._prestamp[(os.path.abspath(obj.local_path), kind)] = self._stamp(obj.local_path)
+                except OSError:
+                    pass
         for (i, p, k), (t, _) in zip(files, self.io.load_many([(p, k) for _, p, k in files], NREADERS)):
             out[i] = t
         with torch.cuda.stream(self.stream):
