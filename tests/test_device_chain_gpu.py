@@ -390,6 +390,7 @@ def test_pair_alignment_equals_the_two_alignments_bit_for_bit(env):
     zm_resample_dev twice, as zuds/subtraction.py:109 and zuds/hotpants.py:51 align them: every value the same bits, the
     mask too; with a rotation, a fractional dither and a science grid that sticks out of the reference."""
     z, torch, eng, stream = env
+    eng.set_stream(stream.cuda_stream)           # (the chains of this module bind the shared engine to streams of their own)
     s = synth()
     nx, ny = 700, 650
     wref = s.ztf_wcs(nx, ny, tpv=True)
