@@ -58,9 +58,9 @@ def test_pool_of_four_equals_one_at_a_time(engine):
     b = four.map(jobs)
     c = four.map(jobs[::-1])[::-1]                        # another assignment of jobs to workers
     four.close()
-    auto = nm.SubtractionPool(4)                          # round 6: four in flight = two lanes of two batched fits
-    assert (auto.njobs, auto.batch) == (2, 2)
-    two, twelve = nm.SubtractionPool(2), nm.SubtractionPool(12)
+    auto = nm.SubtractionPool(6)                          # round 6: six in flight = two lanes of three batched fits
+    assert (auto.njobs, auto.batch) == (2, 3)
+    two, twelve = nm.SubtractionPool(4), nm.SubtractionPool(12)
     assert (two.njobs, two.batch, twelve.njobs, twelve.batch) == (1, 0, 3, 4)      # (no thread or engine exists before map)
     two.close()
     twelve.close()

@@ -264,11 +264,12 @@ class SubtractionPool(object):
             # subtraction): separate chains flip every job to the one-workgroup-per-region factorisation (1.1 ms
             # instead of 0.22) and were SLOWER than one worker at njobs = 2 (4.85 against 3.8; BENCH_r05), and so
             # is a batch of two or three (1x2 5.8, 1x3 4.7: a batch pays that factorisation once, but for too few).
-            # Up to three in flight: ONE worker on the latency form, job after job (3.85); from four on: two lanes
-            # of njobs / 2 batched fits (2x2 3.4, 2x3 2.9, 2x4 2.5, 2x6 2.3); from twelve on three lanes (3x4 2.1).
+            # Up to five in flight: ONE worker on the latency form, job after job (3.7 - 3.85; 2x2 measured 3.4 on one
+            # box and 4.2 on another); from six on: two lanes of njobs / 2 batched fits (2x3 2.9, 2x4 2.5, 2x6 2.3);
+            # from twelve on three lanes (3x4 2.1).
             # Same products bit for bit whatever the shape (tests/test_nightly_gpu.py).  `batch=1` asks for the
             # separate chains explicitly (A / B, tests).
-            if self.njobs <= 3:
+            if self.njobs <= 5:
                 self.njobs = 1
             else:
                 lanes = 2 if self.njobs < 12 else 3
