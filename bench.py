@@ -711,11 +711,13 @@ def main():
     # engines, each with two streams, all mapped onto GPU_MAX_HW_QUEUES hardware queues - the copy stream created here
     # shared a queue with a compute stream and the H2D copies of step k + 1 queued behind the kernels of step k:
     # with_pcie_ms 56 -> 69 ms in the round-4 line, 1.00 x the copy alone again when measured on a fresh process.)
-    if world == 1 and rank == 0 and not args.no_clocks:
-        clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
-                                             ref_rms, step, timed, 1e3 * dt / args.steps)
-    if world == 1 and rank == 0 and not args.no_subtract and not args.no_pipelined and sum_type:
-        pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local)
+    order = os.environ.get('ZM_BENCH_ORDER', 'pipelined,clocks').split(',')
+    for leg in order:
+        if leg == 'clocks' and world == 1 and rank == 0 and not args.no_clocks:
+            clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
+                                                 ref_rms, step, timed, 1e3 * dt / args.steps)
+        if leg == 'pipelined' and world == 1 and rank == 0 and not args.no_subtract and not args.no_pipelined and sum_type:
+            pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local)
     nightly = None
     if world == 1 and rank == 0 and not args.no_subtract and not args.no_nightly:
         nightly = nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local)
