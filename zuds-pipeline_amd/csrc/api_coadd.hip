@@ -257,6 +257,7 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     ZM_HIP(hipMemsetAsync(boxflags, 0, sizeof(int) * (size_t)n, ctx->stream));
     ZM_HIP(hipEventRecord(evs[3], ctx->stream));
     bk_plan bp;
+    ctx->bk_stats_event_valid = false;
     ZM_TRY(frames_background(ctx, n, fr, P, &bp));
     const float wthresh = (float)P->weight_thresh;
     int ff_th = 32, ff_cap = 3700;
@@ -339,7 +340,14 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
         }
     }
     hipEvent_t boxes_done = nullptr;
-    ZM_TRY(zm_launch_mask_boxes(ctx, boxes.data(), (int)boxes.size(), evs[3], &boxes_done));
+    // Round 6: the box-OR pre-pass (1.2 GB, bandwidth-bound) no longer runs beside the mesh statistics - two
+    // bandwidth-bound kernels that stretched each other (statistics 0.74 -> 0.93 ms) - but behind them, beside the small
+    // latency-bound kernels that follow (k_mesh_guess, filter, variance scales, background rows: ~0.2 ms with the GPU
+    // nearly idle).  The second stream therefore takes the lattices and the item headers FIRST (they are light and
+    // still run beside the statistics; the headers no longer read the box flags: k_ff_vscale fills them in) and the
+    // boxes last, behind the event the statistics record (ZM_BOX_LATE=0, developer build: the old order).
+    static const bool box_late = !(ZM_DEVENV("ZM_BOX_LATE") && ZM_DEVENV("ZM_BOX_LATE")[0] == '0');
+    if (!box_late) ZM_TRY(zm_launch_mask_boxes(ctx, boxes.data(), (int)boxes.size(), evs[3], &boxes_done));
     ZM_TRY(zm_launch_lattice_batch(ctx, mp_host.data(), n, lnx, lny, lat, evs[3]));
     std::vector<zm_bkrows> rows;
     struct bkinfo { float* nodes; float* vscale; int nbx, nby; };
@@ -392,6 +400,9 @@ static int fused_prepare(zm_ctx* ctx, int n, const zm_dframe* fr, const zm_wcs* 
     // the descriptors are final: the item headers go out on the second stream, behind the box-OR planes and the
     // lattices they read, beside the background chain of the main stream
     ZM_TRY(zm_launch_fused_headers_early(ctx, ff.data(), n, lnx, lny, onx, ony, lds, S->fits_own));
+    if (box_late)
+        ZM_TRY(zm_launch_mask_boxes(ctx, boxes.data(), (int)boxes.size(), evs[3], &boxes_done,
+                                    ctx->bk_stats_event_valid ? ctx->bk_stats_event : nullptr));
     if (boxes_done) ZM_HIP(hipStreamWaitEvent(ctx->stream, boxes_done, 0));
     S->lds = lds;
     S->any_mask = any_mask;

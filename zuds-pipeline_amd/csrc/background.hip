@@ -1137,6 +1137,10 @@ int zm_batch_stats(zm_ctx* ctx, int nf, const float* const* imgs, const float* c
             else
                 hipLaunchKernelGGL(k_mesh_stats_fast<1>, grid, block, sizeof(meshf_lds), ctx->stream, B, nx, ny, mesh,
                                    nbx, nby, wthresh, vec_ok, dbg, dump);
+            // (the statistics are through: what wants to run beside the small kernels that follow can start)
+            if (!ctx->bk_stats_event) ZM_HIP(hipEventCreateWithFlags(&ctx->bk_stats_event, hipEventDisableTiming));
+            ZM_HIP(hipEventRecord(ctx->bk_stats_event, ctx->stream));
+            ctx->bk_stats_event_valid = true;
             hipLaunchKernelGGL(k_mesh_guess, dim3(n, nmode * nb, 1), dim3(64, 1, 1), 0, ctx->stream,
                                dump, n, nmode, nslot, raw + (size_t)f0 * 4 * nslot);
         }

@@ -67,6 +67,7 @@ void zm_ctx::release_all() {
     for (auto e : event_pool) (void)hipEventDestroy(e);
     event_pool.clear();
     for (auto e : sync_events) (void)hipEventDestroy(e);
+    if (bk_stats_event) { (void)hipEventDestroy(bk_stats_event); bk_stats_event = nullptr; }
     sync_events.clear();
 }
 

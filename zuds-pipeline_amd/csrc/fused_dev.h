@@ -143,7 +143,8 @@ __device__ inline void ff_build_header(const zm_ff* __restrict__ fr, int f, int 
         // not fast): what lies off the frame becomes {0, BIGVAR} at the store.
         H->fast = use_lds && inside;
         H->vscale = (F->vscale && !skip_vscale) ? *F->vscale : 1.f;     // (skip_vscale: k_ff_vscale fills it in later)
-        H->frame_raw = F->mboxflag ? *F->mboxflag : 1;
+        // (skip_vscale = the early headers: the box-OR planes may not be made yet - k_ff_vscale fills the flag in too)
+        H->frame_raw = skip_vscale ? 1 : (F->mboxflag ? *F->mboxflag : 1);
 #pragma unroll
         for (int u = 0; u < FF_NSUB; ++u) {
             H->sdx[u] = H->sub[u].bx0 - bx0;

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_ff_vscale(const zm_ff* __restrict__ fr,
     const int f = (int)(item % nfr);
     const float* vs = fr[f].vscale;
     reinterpret_cast<float*>(out)[item * FF_HDR_WORDS + offsetof(ff_hdr, vscale) / 4] = vs ? *vs : 1.f;
+    out[item * FF_HDR_WORDS + offsetof(ff_hdr, frame_raw) / 4] = fr[f].mboxflag ? *fr[f].mboxflag : 1;
 }
 
 // ---- the y part of the background spline, once per frame row and mesh column ---------------

@@ -246,7 +246,8 @@ static int box_kind(const zm_boxjob& b) {
 // older may still read the planes), and runs BESIDE those statistics - they are bound by their own moment /
 // histogram work at 2.5 TB/s, this kernel streams.  *joined receives the event the main stream has to wait
 // for before the planes are read (NULL: same stream, nothing to wait for).
-int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined) {
+int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined,
+                         hipEvent_t after2) {
     if (joined) *joined = nullptr;
     if (nboxes == 0) return 0;
     hipEvent_t* ev = nullptr;
@@ -270,6 +271,7 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
     const bool side = after != nullptr && joined != nullptr && ctx->aux != nullptr && !timed && !fork_off;
     hipStream_t s = side ? ctx->aux : ctx->stream;
     if (side) ZM_HIP(hipStreamWaitEvent(s, after, 0));
+    if (side && after2) ZM_HIP(hipStreamWaitEvent(s, after2, 0));      // (round 6: behind the mesh statistics, see api_coadd.hip)
     ZM_HIP(hipMemcpyAsync(dev, pin, bb, hipMemcpyHostToDevice, s));
     ZM_HIP(hipEventRecord(ev[7], s));
     int mx = 1, my = 1;

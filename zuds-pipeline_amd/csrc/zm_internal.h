@@ -92,6 +92,10 @@ struct zm_ctx {
     int mask_resample = 0;                     // ZM_MASKRES_OR / ZM_MASKRES_LANCZOS_ROUND
     int ff_last_form = 0;                      // the fused kernel the last zm_launch_coadd_fused ran: 1 _dma, 2 _own (zm_ctx_query)
     bool bk_stats_set = false, bk_filter_set = false;   // LDS opt-in of the background kernels
+    // recorded behind the last k_mesh_stats_fast launch of a stack (round 6): the box-OR pre-pass of a fused coadd waits
+    // for it and runs beside the small kernels that follow the statistics instead of beside the statistics themselves
+    hipEvent_t bk_stats_event = nullptr;
+    bool bk_stats_event_valid = false;
     bool timing = false;
     std::string timing_only;                   // non-empty: only this scope is timed
     std::map<std::string, zm_timer_slot> timers;
@@ -173,7 +177,8 @@ struct zm_boxjob {
 // the fused coadd's tile rows and LDS capacity in staged pixels (resample.hip: FT_H, FF_LDS_CAP)
 void zm_fused_geometry(int* tile_h, int* lds_cap);
 int zm_launch_fused_prepass(zm_ctx* ctx, const zm_bkrows* rows, int nrows);
-int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined);
+int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEvent_t after, hipEvent_t* joined,
+                         hipEvent_t after2 = nullptr);
 int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
                                   int lds_elems, bool fits_own);
 int zm_launch_coadd_fused(zm_ctx* ctx, const zm_ff* frames_host, int nfr, int lnx, int lny, int onx, int ony,
