@@ -528,7 +528,7 @@ def main():
     dframes = dev.DeviceFrames(frames, device)
     coadd = dev.DeviceCoadd(base, params, device=local, engine=eng, want_mask=not args.no_mask)
     sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng,
-                                stream=coadd.stream)
+                                stream=coadd.stream, overlap=True)
     ref_rms = torch.empty_like(coadd.wgt)
     npx = args.size * args.size
     L = eng.L
@@ -571,7 +571,8 @@ def main():
         # tests/test_device_chain_gpu.py)
         def one():
             sub.run(sc['img'], sc['rms'], sc['mask'], sc['wgt'], co.img, ref_rms,
-                    co.mask if co.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3)
+                    co.mask if co.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3,
+                    sci_ready=False if sub.overlap else None)      # (the science planes are resident)
         if not shared_card:
             return one()
         # rehearsal with several ranks on one card: the fused Cholesky sizes its grid for a GPU of

@@ -56,7 +56,9 @@ enum { ZM_MASK_AND = 0, ZM_MASK_OR = 1 };
 /* ---- context ---------------------------------------------------------- */
 int zm_ctx_create(int device, zm_ctx** out);
 int zm_ctx_destroy(zm_ctx* ctx);
-/* Use an external hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* Use an external hipStream_t (e.g. torch's current stream); NULL = own stream.  Binding the stream already bound is
+ * free; a change orders the new stream behind the work enqueued on the old one with an event (the context's scratch
+ * is shared) - the host never waits (round 6; rounds 1 - 5 synchronised the old stream here). */
 int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream);
 int zm_ctx_synchronize(zm_ctx* ctx);
 /* Several contexts (one host thread each) may subtract on one GPU at the same time - the

@@ -155,7 +155,7 @@ class DeviceSubtraction(object):
     ref_* live on the reference grid ``wref``; sci_* on the science grid ``wsci``.
     """
 
-    def __init__(self, wsci, wref, device=0, engine=None, stream=None):
+    def __init__(self, wsci, wref, device=0, engine=None, stream=None, overlap=False):
         from .constants import BAD_SUM, BIG_RMS, BKG_VAL
         torch = _torch()
         self.torch = torch
@@ -184,10 +184,16 @@ class DeviceSubtraction(object):
         self.noise = torch.empty(self.shape, **f32)
         self.BAD_SUM, self.BIG_RMS, self.BKG_VAL = BAD_SUM, float(BIG_RMS), float(BKG_VAL)
         self.info = _lib.zm_hp_info()
+        # overlap (round 6): the mesh background of the science frame (a chain of small launches on ONE frame: ~0.13 ms of
+        # latency) runs on a second context and stream beside the alignment of the reference (another ~0.13 ms) instead of
+        # behind it - for a lone subtraction, whose latency is the point; the lanes of a pool keep one context per chain
+        self.overlap = bool(overlap)
+        self._bk_engine = self._bk_stream = None
+        self._last_done = None              # event: the last subtraction of this chain has read its inputs
 
     def run(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
             nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
-            ref_rms_flxscale=None):
+            ref_rms_flxscale=None, sci_ready=None):
         """All arguments are torch tensors on this device; ``seeing`` is the
         science FWHM in pixels (header SEEING); ``ref_flxscale`` the FLXSCALE card of the
         reference (SWarp applies it on resampling, ``swarp.run_align``).
@@ -196,13 +202,15 @@ class DeviceSubtraction(object):
         ny, nx = self.shape
         scim, p = self.prepare(sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
                                nreg_side=nreg_side, subtract_back=subtract_back, hotpants_kws=hotpants_kws,
-                               ref_flxscale=ref_flxscale, ref_rms_flxscale=ref_rms_flxscale)
+                               ref_flxscale=ref_flxscale, ref_rms_flxscale=ref_rms_flxscale, sci_ready=sci_ready)
         with self.torch.cuda.stream(self.stream):
             check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
                                     self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
                                     self.bpm.data_ptr(), nx, ny, C.byref(p),
                                     self.diff.data_ptr(), self.noise.data_ptr(),
                                     C.byref(self.info)), 'zm_subtract_dev')
+            if self.overlap:
+                self._last_done = self.stream.record_event()
         self.check_limits()
         return self.finish()
 
@@ -219,7 +227,7 @@ class DeviceSubtraction(object):
 
     def prepare(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
                 nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
-                ref_rms_flxscale=None):
+                ref_rms_flxscale=None, sci_ready=None):
         """Everything in front of the hotpants step, enqueued on this chain's stream: alignment of the
         reference and its rms map, bad-pixel map, mesh background, the two background estimates.
         Returns (science frame minus background, the job's ``zm_hp_params``)."""
@@ -237,6 +245,32 @@ class DeviceSubtraction(object):
                               C.byref(fs_rms)), 'zm_flux_scale')
         self.engine.set_stream(self.stream.cuda_stream)
         self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        side = self.overlap and subtract_back
+        bk_done = None
+        if side:
+            if self._bk_engine is None:
+                from .engine import Engine
+                self._bk_engine = Engine(self.device.index)
+                self._bk_stream = self.torch.cuda.Stream(self.device)
+                self._bk_engine.set_stream(self._bk_stream.cuda_stream)
+            e2 = self._bk_engine
+            # What the background waits for: the science planes, and the previous subtraction of this chain (it read
+            # scibkgsub).  `sci_ready`: None - everything enqueued on this chain's stream so far (the planes may have
+            # been made there); an event - that event; False - the planes are resident (bench.py: the background of the
+            # science frame then runs beside whatever the chain's stream still has ahead of the subtraction, e.g. the
+            # coadd of the reference it will be subtracted from - which it does not depend on).
+            if sci_ready is None:
+                self._bk_stream.wait_stream(self.stream)
+            else:
+                if sci_ready is not False:
+                    self._bk_stream.wait_event(sci_ready)
+                if self._last_done is not None:
+                    self._bk_stream.wait_event(self._last_done)
+            with self.torch.cuda.stream(self._bk_stream):
+                check(L.zm_background_dev(e2.ctx, sci.data_ptr(), sci_wgt.data_ptr() if sci_wgt is not None else None,
+                                          nx, ny, 128, 3, None, None, self.scibkgsub.data_ptr(), None), 'sci background')
+                check(L.zm_add_scalar_dev(e2.ctx, self.scibkgsub.data_ptr(), self.BKG_VAL, self.n), 'pedestal')
+                bk_done = self._bk_stream.record_event()
         with self.torch.cuda.stream(self.stream):
             # an int16 science mask (a ZTF mask as its file holds it) is widened here, once: the
             # bookkeeping kernels below read int32 words
@@ -270,13 +304,16 @@ class DeviceSubtraction(object):
                                     self.BAD_SUM, self.n, self.submask.data_ptr(),
                                     self.bpm.data_ptr()), 'submask')
             # scimbkg = sci - mesh background + 150 (hotpants.py:27-32)
-            if subtract_back:
+            if subtract_back and not side:
                 check(L.zm_background_dev(ctx, sci.data_ptr(),
                                           sci_wgt.data_ptr() if sci_wgt is not None else None,
                                           nx, ny, 128, 3, None, None, self.scibkgsub.data_ptr(),
                                           None), 'sci background')
                 check(L.zm_add_scalar_dev(ctx, self.scibkgsub.data_ptr(), self.BKG_VAL, self.n),
                       'pedestal')
+                scim = self.scibkgsub
+            elif subtract_back:
+                self.stream.wait_event(bk_done)          # (made beside the alignment, above)
                 scim = self.scibkgsub
             else:
                 scim = sci

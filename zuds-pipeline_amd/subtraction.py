@@ -129,7 +129,7 @@ def _subtraction_device(cls, sci, ref, final_out, outmask, nreg_side, subtract_n
             seeing, _ = measure_seeing_dev(sci_img, bad, float(sat) if sat else None, engine=eng)
         sci_header['SEEING'] = float(seeing)
         sci_comments['SEEING'] = 'FWHM of seeing in pixels (Goldstein)'
-    chain = DeviceSubtraction(sci.wcs, ref.wcs, device=oio.device.index, engine=eng, stream=oio.stream)
+    chain = DeviceSubtraction(sci.wcs, ref.wcs, device=oio.device.index, engine=eng, stream=oio.stream, overlap=True)
     diff, noise, submask = chain.run(sci_img, sci_rms, sci_mask, sci_wgt, ref_img, ref_rms, ref_m32,
                                      seeing=float(sci_header['SEEING']), nreg_side=nreg_side,
                                      subtract_back=subtract_new_back, hotpants_kws=hotpants_kws,
