@@ -528,7 +528,7 @@ def main():
     dframes = dev.DeviceFrames(frames, device)
     coadd = dev.DeviceCoadd(base, params, device=local, engine=eng, want_mask=not args.no_mask)
     sub = dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=eng,
-                                stream=coadd.stream, overlap=True)
+                                stream=coadd.stream, overlap=os.environ.get('ZM_SUB_OVERLAP', '1') != '0')
     ref_rms = torch.empty_like(coadd.wgt)
     npx = args.size * args.size
     L = eng.L
@@ -566,13 +566,17 @@ def main():
             check(L.zm_add_scalar_dev(eng.ctx, co.img.data_ptr(), 150.0, npx))
             check(L.zm_rms_from_weight_dev(eng.ctx, co.wgt.data_ptr(), None, npx, big_rms, ref_rms.data_ptr()))
 
-    def sub_leg(co, sc):
+    def sub_leg(co, sc, resident=None):
         # SingleEpochSubtraction.from_images with the reference's defaults (the tested object:
-        # tests/test_device_chain_gpu.py)
+        # tests/test_device_chain_gpu.py).  resident: the science planes are the bench's resident ones (nothing on any
+        # stream still writes them): the background of the science frame may then start at once, beside the coadd
+        # (sci_ready=False); planes that are being copied in or decoded (the clocks) are waited for on the stream.
+        if resident is None:
+            resident = sc is sci
         def one():
             sub.run(sc['img'], sc['rms'], sc['mask'], sc['wgt'], co.img, ref_rms,
                     co.mask if co.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3,
-                    sci_ready=False if sub.overlap else None)      # (the science planes are resident)
+                    sci_ready=False if (sub.overlap and resident) else None)
         if not shared_card:
             return one()
         # rehearsal with several ranks on one card: the fused Cholesky sizes its grid for a GPU of
@@ -718,7 +722,7 @@ def main():
             clocks, tools = data_movement_clocks(args, z, dev, eng, torch, base, frames, sci, coadd, sub,
                                                  ref_rms, step, timed, 1e3 * dt / args.steps)
         if leg == 'pipelined' and world == 1 and rank == 0 and not args.no_subtract and not args.no_pipelined and sum_type:
-            pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local)
+            pipelined = pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local, main_sub=sub)
     nightly = None
     if world == 1 and rank == 0 and not args.no_subtract and not args.no_nightly:
         nightly = nightly_leg(args, z, torch, base, frames, coadd, ref_rms, no_ref_mask, npx, local)
@@ -888,7 +892,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local):
+def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_mask, npx, local, main_sub=None):
     """The same step with consecutive steps software-pipelined, reported beside `value`, never as
     it: the subtractions of steps k, k - 1, ... (D contexts, each with its own stream and host
     thread) run while the coadd of step k + 1 is computed - step k + 1's coadd does not depend on
@@ -909,12 +913,10 @@ def pipelined_leg(args, z, dev, torch, base, dframes, sci, coadd, eng, no_ref_ma
         if D >= 2:
             eng.set_share(D + 1)                     # the coadd context too: its fused kernel yields CU slots
         for _ in range(D):
-            e = z.Engine(local)
+            st = torch.cuda.Stream(coadd.device, priority=-1 if args.pipelined_priority else 0)
+            e = z.Engine(local, stream=st.cuda_stream)
             e.set_share(max(args.pipelined_share, D))
             engs.append(e)
-            st = torch.cuda.Stream(coadd.device, priority=-1) if args.pipelined_priority else None
-            if st is not None:
-                e.set_stream(st.cuda_stream)
             subs.append(dev.DeviceSubtraction(sci['wcs'], base, device=local, engine=e, stream=st))
         nset = D + 1
         snap = [dict(img=torch.empty_like(coadd.img), rms=torch.empty_like(coadd.img),

@@ -56,6 +56,10 @@ enum { ZM_MASK_AND = 0, ZM_MASK_OR = 1 };
 /* ---- context ---------------------------------------------------------- */
 int zm_ctx_create(int device, zm_ctx** out);
 int zm_ctx_destroy(zm_ctx* ctx);
+/* A context bound to the caller's hipStream_t from the start: it never creates a stream of its own (its second stream
+ * is made on first use).  For processes that run many contexts side by side on one GPU (scripts/donightly.py:21-40
+ * runs one process per job; here: one context per chain). */
+int zm_ctx_create_on_stream(int device, void* hip_stream, zm_ctx** out);
 /* Use an external hipStream_t (e.g. torch's current stream); NULL = own stream.  Binding the stream already bound is
  * free; a change orders the new stream behind the work enqueued on the old one with an event (the context's scratch
  * is shared) - the host never waits (round 6; rounds 1 - 5 synchronised the old stream here). */

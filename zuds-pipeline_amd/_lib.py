@@ -102,6 +102,7 @@ _SIGS = {
     'zm_ctx_destroy': (C.c_int, [_P]),
     'zm_ctx_set_stream': (C.c_int, [_P, _P]),
     'zm_ctx_synchronize': (C.c_int, [_P]),
+    'zm_ctx_create_on_stream': (C.c_int, [C.c_int, _P, C.POINTER(C.c_void_p)]),
     'zm_ctx_set_share': (C.c_int, [_P, C.c_int]),
     'zm_ctx_query': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     'zm_ctx_set_conventions': (C.c_int, [_P, C.c_int, C.c_int]),

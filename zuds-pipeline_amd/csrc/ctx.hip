@@ -86,8 +86,29 @@ extern "C" int zm_ctx_create(int device, zm_ctx** out) {
     zm_ctx* c = new zm_ctx();
     c->device = device;
     ZM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    ZM_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     c->own_stream = true;
+    *out = c;
+    return 0;
+}
+
+// A context that works on the caller's stream from the start and never creates one of its own (round 6): the chains of
+// a pool, the pipelined step and the I/O ring bind every context to a stream they already hold - created and destroyed
+// streams shift the runtime's mapping of streams onto hardware queues and with it which chains can run side by side.
+extern "C" int zm_ctx_create_on_stream(int device, void* hip_stream, zm_ctx** out) {
+    ZM_CHECK(out != nullptr && hip_stream != nullptr, "zm_ctx_create_on_stream: null argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        zm_set_error("zm_ctx_create_on_stream: no HIP device available (%s)",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return 3;
+    }
+    ZM_CHECK(device >= 0 && device < ndev, "zm_ctx_create_on_stream: device %d out of range [0,%d)", device, ndev);
+    ZM_HIP(hipSetDevice(device));
+    zm_ctx* c = new zm_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
     *out = c;
     return 0;
 }
@@ -111,6 +132,7 @@ extern "C" int zm_ctx_destroy(zm_ctx* ctx) {
 extern "C" int zm_ctx_set_stream(zm_ctx* ctx, void* hip_stream) {
     ZM_CHECK(ctx != nullptr, "zm_ctx_set_stream: ctx is NULL");
     ZM_HIP(hipSetDevice(ctx->device));
+    if (ZM_DEVENV("ZM_SET_STREAM_SYNC")) ZM_HIP(hipStreamSynchronize(ctx->stream));      // (developer: rounds 1 - 5)
     if (hip_stream != nullptr && (hipStream_t)hip_stream == ctx->stream) return 0;
     if (hip_stream == nullptr && ctx->own_stream) return 0;
     hipStream_t old = ctx->stream, next = (hipStream_t)hip_stream;
@@ -153,6 +175,17 @@ extern "C" int zm_ctx_query(zm_ctx* ctx, const char* what, int64_t* out) {
     else if (!strcmp(what, "mask_resample")) *out = ctx->mask_resample;
     else ZM_CHECK(false, "zm_ctx_query: unknown item \"%s\"", what);
     return 0;
+}
+
+// The context's second stream, made on first use (round 6): a context that only subtracts never needs one, and every
+// stream a process holds takes part in the runtime's mapping of streams onto its few hardware queues - the chains of a
+// pool or of the pipelined step lose their concurrency when idle streams push two busy ones onto one queue.
+hipStream_t zm_ctx_aux(zm_ctx* ctx) {
+    if (!ctx->aux) {
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) ctx->aux = nullptr;
+    }
+    return ctx->aux;
 }
 
 int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out) {

@@ -176,15 +176,15 @@ int zm_launch_fused_headers_early(zm_ctx* ctx, const zm_ff* frames_host, int nfr
                                   int lds_elems, bool fits_own) {
     ctx->ff_pre_valid = false;
     static const bool fork_off = ZM_DEVENV("ZM_FF_FORK") && ZM_DEVENV("ZM_FF_FORK")[0] == '0';
-    if (!ctx->aux || ctx->timing || fork_off) return 0;      // (scope timers keep a timed kernel on the main stream)
+    if (!zm_ctx_aux(ctx) || ctx->timing || fork_off) return 0;      // (scope timers keep a timed kernel on the main stream)
     ff_geom g;
     ZM_TRY(ff_geometry(ctx, onx, ony, lds_elems, fits_own, &g));
     zm_ff* dev = nullptr;
     int* ghdr = nullptr;
-    ZM_TRY(ff_upload_and_headers(ctx, frames_host, nfr, lnx, lny, onx, ony, g, ctx->aux, 1, &dev, &ghdr));
+    ZM_TRY(ff_upload_and_headers(ctx, frames_host, nfr, lnx, lny, onx, ony, g, zm_ctx_aux(ctx), 1, &dev, &ghdr));
     hipEvent_t* ev = nullptr;
     ZM_TRY(zm_get_sync_events(ctx, 10, &ev));
-    ZM_HIP(hipEventRecord(ev[9], ctx->aux));
+    ZM_HIP(hipEventRecord(ev[9], zm_ctx_aux(ctx)));
     ctx->ff_pre_valid = true;
     ctx->ff_pre_nfr = nfr;
     ctx->ff_pre_onx = onx;

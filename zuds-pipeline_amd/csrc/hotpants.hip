@@ -3516,7 +3516,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
             if (fl[16 * j + r] == 0 || r == 8) {
                 rounds[j] = r;
                 if (apply_beside) {
-                    stream_swap sw(ctx, ctx->aux);
+                    stream_swap sw(ctx, zm_ctx_aux(ctx));
                     join.armed = true;
                     ZM_TRY(enqueue_apply(j));
                 }
@@ -3529,7 +3529,7 @@ extern "C" int zm_subtract_batch_dev(zm_ctx* ctx, int njobs, const zm_sub_job* j
     fitting.release();
     if (apply_beside) {
         join.armed = false;
-        ZM_HIP(hipEventRecord(evs[0], ctx->aux));
+        ZM_HIP(hipEventRecord(evs[0], zm_ctx_aux(ctx)));
         ZM_HIP(hipStreamWaitEvent(st, evs[0], 0));
     } else {
         for (int j = 0; j < njobs; ++j) ZM_TRY(enqueue_apply(j));

@@ -268,8 +268,8 @@ int zm_launch_mask_boxes(zm_ctx* ctx, const zm_boxjob* boxes, int nboxes, hipEve
     // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
     const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "mask_box");
     static const bool fork_off = ZM_DEVENV("ZM_FF_FORK") && ZM_DEVENV("ZM_FF_FORK")[0] == '0';
-    const bool side = after != nullptr && joined != nullptr && ctx->aux != nullptr && !timed && !fork_off;
-    hipStream_t s = side ? ctx->aux : ctx->stream;
+    const bool side = after != nullptr && joined != nullptr && zm_ctx_aux(ctx) != nullptr && !timed && !fork_off;
+    hipStream_t s = side ? zm_ctx_aux(ctx) : ctx->stream;
     if (side) ZM_HIP(hipStreamWaitEvent(s, after, 0));
     if (side && after2) ZM_HIP(hipStreamWaitEvent(s, after2, 0));      // (round 6: behind the mesh statistics, see api_coadd.hip)
     ZM_HIP(hipMemcpyAsync(dev, pin, bb, hipMemcpyHostToDevice, s));

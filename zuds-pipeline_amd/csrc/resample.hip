@@ -62,8 +62,8 @@ int zm_launch_lattice_batch(zm_ctx* ctx, const zm_map_params* mp_host, int n, in
     memcpy(pin, mp_host, sizeof(zm_map_params) * (size_t)n);
     // (the scope timers record on the main stream: when this scope is being timed the kernel stays there)
     const bool timed = ctx->timing && (ctx->timing_only.empty() || ctx->timing_only == "lattice");
-    const bool side = after != nullptr && ctx->aux != nullptr && !timed;
-    hipStream_t s = side ? ctx->aux : ctx->stream;
+    const bool side = after != nullptr && zm_ctx_aux(ctx) != nullptr && !timed;
+    hipStream_t s = side ? zm_ctx_aux(ctx) : ctx->stream;
     if (side) ZM_HIP(hipStreamWaitEvent(s, after, 0));
     ZM_HIP(hipMemcpyAsync(dev, pin, sizeof(zm_map_params) * (size_t)n, hipMemcpyHostToDevice, s));
     ZM_HIP(hipEventRecord(ev[0], s));

@@ -66,7 +66,7 @@ struct zm_ctx {
     std::map<std::string, std::pair<void*, size_t>> scratch;
     // pinned host staging
     std::map<std::string, std::pair<void*, size_t>> pinned;
-    hipStream_t aux = nullptr;                 // second stream: background statistics run beside resampling
+    hipStream_t aux = nullptr;                 // second stream (zm_ctx_aux: made on first use): box-OR planes, lattices, item headers, batch convolutions
     std::vector<hipEvent_t> sync_events;       // cross-stream ordering (no timing)
     // set by zm_launch_prep when it also produced the box-OR plane of a mask (scratch slot
     // "mask_box"): zm_launch_resample then skips its own k_mask_box launch
@@ -204,6 +204,7 @@ int zm_frame_filter(zm_ctx* ctx, int nx, int ny, int mesh, int fsize, int nmode,
                     float** stats_dev, int* nbx_out, int* nby_out, const char* slot, int index,
                     int count);
 int zm_get_sync_events(zm_ctx* ctx, int n, hipEvent_t** out);
+hipStream_t zm_ctx_aux(zm_ctx* ctx);          // the context's second stream, created on first use (may return nullptr)
 int zm_launch_var_scale(zm_ctx* ctx, const float* bstats, const float* vstats, float* out);
 int zm_launch_resample(zm_ctx* ctx, const float2* src, int nx, int ny, int spitch,
                        const double2* lat, int lnx, int lny, int kernel, float fscale,

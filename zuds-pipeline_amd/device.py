@@ -214,6 +214,13 @@ class DeviceSubtraction(object):
         self.check_limits()
         return self.finish()
 
+    def release_overlap(self):
+        """Give the second context of ``overlap=True`` back (it is made again on the next run that wants it)."""
+        if self._bk_engine is not None:
+            self._bk_stream.synchronize()
+            self._bk_engine.close()
+        self._bk_engine = self._bk_stream = None
+
     def job(self, scim, sci_rms, p):
         """The ``zm_sub_job`` of a prepared chain (``zm_subtract_batch_dev``: many chains, one fit)."""
         return _lib.zm_sub_job(scim.data_ptr(), sci_rms.data_ptr(), self.ref_al.data_ptr(),
@@ -250,9 +257,8 @@ class DeviceSubtraction(object):
         if side:
             if self._bk_engine is None:
                 from .engine import Engine
-                self._bk_engine = Engine(self.device.index)
                 self._bk_stream = self.torch.cuda.Stream(self.device)
-                self._bk_engine.set_stream(self._bk_stream.cuda_stream)
+                self._bk_engine = Engine(self.device.index, stream=self._bk_stream.cuda_stream)
             e2 = self._bk_engine
             # What the background waits for: the science planes, and the previous subtraction of this chain (it read
             # scibkgsub).  `sci_ready`: None - everything enqueued on this chain's stream so far (the planes may have

@@ -56,11 +56,18 @@ def coadd_params(combine='CLIPPED', mask_combine='AND', resample='LANCZOS3',
 
 class Engine(object):
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """``stream``: a HIP stream handle (``torch.cuda.Stream(...).cuda_stream``) the context works on from the start -
+        it then never creates a stream of its own (``zm_ctx_create_on_stream``): what chains that run side by side on
+        one GPU want."""
         self.L = _lib.lib()
         self._ctx = C.c_void_p()
-        check(self.L.zm_ctx_create(int(device), C.byref(self._ctx)),
-              'zm_ctx_create')
+        if stream:
+            check(self.L.zm_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self._ctx)),
+                  'zm_ctx_create_on_stream')
+        else:
+            check(self.L.zm_ctx_create(int(device), C.byref(self._ctx)),
+                  'zm_ctx_create')
         self.device = int(device)
 
     def close(self):

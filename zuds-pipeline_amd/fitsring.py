@@ -161,10 +161,8 @@ class FITSRing(object):
         self.cs = torch.cuda.Stream(self.device, priority=-1)          # H2D, nothing else: copies back to back
         self.xs = torch.cuda.Stream(self.device, priority=-1)          # decode, behind each copy's event
         self.ds = torch.cuda.Stream(self.device, priority=-1)          # D2H of encoded products
-        self.ceng = Engine(device)
-        self.ceng.set_stream(self.xs.cuda_stream)
-        self.deng = Engine(device)
-        self.deng.set_stream(self.ds.cuda_stream)
+        self.ceng = Engine(device, stream=self.xs.cuda_stream)      # (contexts on the ring's streams: none of their own)
+        self.deng = Engine(device, stream=self.ds.cuda_stream)
         self._readers = ThreadPoolExecutor(self.nreaders, thread_name_prefix='zmfits-r')
         self._writers = ThreadPoolExecutor(self.nwriters, thread_name_prefix='zmfits-w')
         self._pin_in = _PinPool(torch, pinned_in)

@@ -59,10 +59,9 @@ class _Worker(object):
     def __init__(self, device, share):
         import torch
         self.torch = torch
-        self.engine = Engine(device)
-        self.engine.set_share(share)
         self.stream = torch.cuda.Stream(torch.device('cuda', device))
-        self.engine.set_stream(self.stream.cuda_stream)
+        self.engine = Engine(device, stream=self.stream.cuda_stream)
+        self.engine.set_share(share)
         self.device = device
         self.chain = None
         self.key = None
@@ -177,14 +176,13 @@ class _BatchLane(object):
     def __init__(self, device, batch, turn=None, share=1):
         import torch
         self.torch = torch
-        self.engine = Engine(device)
+        self.stream = torch.cuda.Stream(torch.device('cuda', device))
+        self.engine = Engine(device, stream=self.stream.cuda_stream)
         #  a chunk of ONE job - a fit-key group of size 1, the per-job repeat after a failed batch -
         # goes through zm_subtract_dev: with other lanes at work it must take the one-workgroup-per-region
         # factorisation like the workers of an unbatched pool, not the form that wants the GPU to itself
         if share >= 2:
             self.engine.set_share(share)
-        self.stream = torch.cuda.Stream(torch.device('cuda', device))
-        self.engine.set_stream(self.stream.cuda_stream)
         self.device, self.batch = device, batch
         self.chains, self.key = [], None
         # `turn` (a lock shared by the lanes of a pool): one lane at a time runs its preparation - kernels that
