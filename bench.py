@@ -729,7 +729,7 @@ def main():
     if world == 1 and rank == 0:
         if sum_type and not args.no_secondary:
             secondary = secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx,
-                                          full_step=None if args.no_subtract else (coadd_leg, sub_leg, sci))
+                                          full_step=None if args.no_subtract else (coadd_leg, sub_leg, sci), stream=coadd.stream)
 
     if rank == 0 and args.dump_coadd:
         torch.cuda.synchronize(device)
@@ -1155,14 +1155,15 @@ def nightly_files_clock(args, z, torch, base, jobs, ref, radec, npx, local):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_step=None):
+def secondary_clipped(args, z, dev, eng, base, dframes, local, timed, npx, full_step=None, stream=None):
     """The reference's DEFAULT operator in the headline's shadow: configs[1] with the science
     COMBINE_TYPE every from_images call runs unless told otherwise (CLIPPED 4.0 / 0.3,
     zuds/astromatic/makecoadd/default.swarp:24-31) - the resident-stack path: k_coadd_fused_dma in STACK mode
     (samples stored, not summed) + k_combine<32> - as a coadd leg and, with `full_step`, as the whole step
     (this coadd + the same subtraction against it), each of the two kernels with its own HBM roofline."""
     p = z.coadd_params(combine='CLIPPED', subtract_back=True, rescale_weights=True)
-    co = dev.DeviceCoadd(base, p, device=local, engine=eng, want_mask=not args.no_mask)
+    # (on the stream of the headline's coadd: one more stream would change which streams share a hardware queue)
+    co = dev.DeviceCoadd(base, p, device=local, engine=eng, want_mask=not args.no_mask, stream=stream)
     m = 0 if args.no_mask else 1
     pmc = pmc_profile(args)
     kern = (pmc.get('clipped') or {}).get('kernels') or {}
