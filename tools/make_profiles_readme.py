@@ -73,6 +73,12 @@ def main(tag):
           f'{ck.get("hbm_bytes_per_launch", 0) / 1e9:.2f} GB per launch |')
     print(f'| `{tag}_resource_usage.txt` | registers, spills, scratch and occupancy of every kernel as the compiler reports them '
           f'(`tools/resource_usage.py`, `hipcc -Rpass-analysis=kernel-resource-usage`) |')
+    extra = [('step_timeline.txt', 'one coadd leg kernel by kernel (start, length, gap to the previous end; `tools/step_timeline.py` on a kernel trace)'),
+             ('subtract_timeline.txt', 'one subtraction leg kernel by kernel with queue and stream ids (`tools/sub_timeline.py`)'),
+             ('pipelined_trace.txt', 'the pipelined step: what is in flight, what stretches, idle time (`tools/pipelined_trace.py`)')]
+    for name, what in extra:
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', f'{tag}_{name}')):
+            print(f'| `{tag}_{name}` | {what} |')
 
 
 if __name__ == '__main__':
