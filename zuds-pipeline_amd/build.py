@@ -15,7 +15,7 @@ LIBDIR = HERE / 'lib'
 LIBNAME = 'libzudsmi.so'
 
 SOURCES = ['ctx.hip', 'wcs_host.hip', 'resample.hip', 'resample_opts.hip', 'maskbox.hip', 'fused_host.hip', 'fused_dma.hip', 'fused_own.hip', 'combine.hip',
-           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'hp_vectors.hip', 'hp_apply.hip', 'api_subtract.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip', 'detect.hip', 'comm.hip']
+           'background.hip', 'api_coadd.hip', 'hotpants.hip', 'hp_vectors.hip', 'hp_apply.hip', 'api_subtract.hip', 'select_bracket.hip', 'elementwise.hip', 'photometry.hip', 'fitsio.hip', 'detect.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']
 # the device assembly of every translation unit stays next to its object (obj/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s):

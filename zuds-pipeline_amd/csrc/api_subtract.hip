@@ -7,30 +7,9 @@
 // prefix (for both middle ranks of an even count at once), so a median + MAD of
 // a 9.4 Mpx frame is 6 streaming passes and one 24-byte copy back, batched over
 // up to ZM_RS_MAXIMG images per launch (blockIdx.y).
-#include "zm_internal.h"
+#include "select_dev.h"
 
-#define ZM_RS_MAXIMG 4
 #define RS_BINS 2048
-
-__device__ inline uint32_t f2key(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__device__ inline float key2f_dev(uint32_t k) {
-    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
-struct rs_image {
-    const float* img;
-    const int32_t* mask;
-};
-
-struct rs_batch {
-    rs_image im[ZM_RS_MAXIMG];
-    int64_t n;
-};
 
 // per-image select state (device memory)
 struct rs_state {
@@ -269,6 +248,24 @@ static int median_mad_batch(zm_ctx* ctx, int nimg, const rs_image* ims, int64_t 
         ZM_TRY(ctx->get("rs_vbits", sizeof(unsigned long long) * 4 * (size_t)((n / 4 + 63) / 64) * ZM_RS_MAXIMG, (void**)&d_vbits));
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     hipStream_t s = ctx->stream;
+    // Round 6: frames of a megapixel and more go through the sample-bracketed select (select_bracket.hip: two
+    // streaming passes instead of six, the same bits); small or unaligned inputs keep the three-pass form below.
+    static const bool classic = ZM_DEVENV("ZM_RS_CLASSIC") && ZM_DEVENV("ZM_RS_CLASSIC")[0] == '1';
+    if (vec_ok && n >= ZM_RS2_MIN_N && !classic) {
+        double* d_out = out_dev;
+        if (!d_out) ZM_TRY(ctx->get("rs2_out", sizeof(double) * 3 * ZM_RS_MAXIMG, (void**)&d_out));
+        {
+            zm_scope_timer t(ctx, "median_mad");
+            ZM_TRY(zm_rs2_median_mad(ctx, nimg, B, d_vbits, d_out));
+        }
+        if (!out3) return 0;
+        double* h_out = nullptr;
+        ZM_TRY(ctx->get_pinned("rs2_out_h", sizeof(double) * 3 * ZM_RS_MAXIMG, (void**)&h_out));
+        ZM_HIP(hipMemcpyAsync(h_out, d_out, sizeof(double) * 3 * nimg, hipMemcpyDeviceToHost, s));
+        ZM_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < 3 * nimg; ++k) out3[k] = h_out[k];
+        return 0;
+    }
     {
         zm_scope_timer t(ctx, "median_mad");
         hipLaunchKernelGGL(k_rsel_init, dim3(nimg), dim3(256), 0, s, d_st, d_hist);
