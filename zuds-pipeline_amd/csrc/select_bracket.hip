@@ -14,10 +14,11 @@
 //                    intervals) is the answer, otherwise the bin's ~3 000 keys come from the 256 segments into LDS
 //                    and the rank is selected there, 8 bits per step; for the median it goes on to bracket
 //                    |v - median| from the SAME sample (kept in HBM) for the second pass;
-//   k_rsel2_rescue   writes the outputs; when a bracket missed its rank or the segment of a needed bin overflowed -
-//                    a flag in the state - it repeats the select with the three-pass form in ONE workgroup: slow
-//                    (milliseconds), exact, and no launch depends on the host seeing the flag.
-// Six launches, the same bits as numpy.median on float32 (tests/test_select_bracket_gpu.py forces the rescue with an
+//                    after the MAD it writes the outputs; when a bracket missed its rank or the keys of a needed
+//                    bin are not all there - a flag in the state - it first repeats the select with the three-pass
+//                    form in ONE workgroup: slow (milliseconds), exact, and no launch depends on the host seeing
+//                    the flag.
+// Five launches, the same bits as numpy.median on float32 (tests/test_select_bracket_gpu.py forces the rescue with an
 // adversarial frame built from the sample positions below).
 #include "select_dev.h"
 
@@ -31,7 +32,7 @@
 #define RS2_SUB 40                              // slots per workgroup, image and bin (expected ~13: the bins are equal
                                                 // shares of the interval, not powers of two)
 #define RS2_LIST 8192
-#define RS2_UNROLL 4
+#define RS2_UNROLL 2
 #define RS2_FAIL_MED 1u
 #define RS2_FAIL_MAD 2u
 
@@ -268,9 +269,9 @@ __global__ __launch_bounds__(RS2_THREADS) void k_rsel2_sample(const rs_batch B, 
 // may exceed RS2_SUB: the bin's bit in ovf says so).
 // The loads of RS2_UNROLL iterations are issued together: with one in flight per thread a pass waited for memory
 // nine times over (measured: 30 us for 78 MB).
-template <int VMODE>                     // 0: no bit plane, 1: masks read, bits written, 2: bits read
+template <int VMODE, int MODE>           // VMODE 0: no bit plane, 1: masks read, bits written, 2: bits read
 __global__ __launch_bounds__(RS2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32_t* __restrict__ seg,
+void k_rsel2_pass(const rs_batch B, rs2_state* __restrict__ st, uint32_t* __restrict__ seg,
                   unsigned int* __restrict__ wcnt, unsigned long long* __restrict__ vbits) {
     __shared__ unsigned int lh[RS2_BINS];
     __shared__ uint32_t lmin[RS2_BINS], lmax[RS2_BINS];
@@ -290,33 +291,41 @@ void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32
     unsigned int nvalid = 0, nbelow = 0;
     // One float4 group: ok[c] = the wave's ballot of "pixel c of my group is valid".  The four atomics of a group
     // are issued before the first returned slot is needed.
+    // Lane masks stay what they are - scalar register pairs: validity is the ballot the caller has, "below" and
+    // "inside" are compares whose result IS a mask (v_cmp -> SGPR pair, combined and counted on the scalar unit), and
+    // __builtin_amdgcn_inverse_ballot_w64 turns a mask back into the branch condition.  Per pixel the vector unit does:
+    // [subtract / abs], two for the key, the difference from lo, two compares - and, where a wave holds a candidate
+    // (nearly always: 9 % of 64 lanes), the bin, its atomic and the staging store.
     auto group = [&](const float4 v, const unsigned long long (&ok)[4]) {
         const float a[4] = {v.x, v.y, v.z, v.w};
-        uint32_t key[4];
-        unsigned int bin[4], slot[4];
-        bool cand[4];
-        bool any = false;
+        uint32_t d[4];
+        unsigned long long cm[4], anym = 0ull;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const bool okl = (ok[c] >> lane) & 1ull;
-            const float x = mode == 1 ? fabsf(a[c] - centre) : a[c];
-            key[c] = f2key(x);
-            nbelow += (unsigned int)__popcll(__ballot(okl && key[c] < lo));
-            const uint32_t d = key[c] - lo;                      // (wraps above span_m1 where key < lo)
-            cand[c] = okl && d <= span_m1;
-            bin[c] = mul ? __umulhi(d, mul) : d;
-            any = any || cand[c];
+            const float x = MODE == 1 ? fabsf(a[c] - centre) : a[c];
+            const uint32_t u = __float_as_uint(x);
+            const uint32_t key = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);       // f2key
+            nbelow += (unsigned int)__popcll(ok[c] & __builtin_amdgcn_ballot_w64(key < lo));
+            d[c] = key - lo;                                     // (wraps above span_m1 where key < lo)
+            cm[c] = ok[c] & __builtin_amdgcn_ballot_w64(d[c] <= span_m1);
+            anym |= cm[c];
             nvalid += (unsigned int)__popcll(ok[c]);
         }
-        if (__ballot(any)) {
+        if (anym) {
+            unsigned int bin[4], slot[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) slot[c] = cand[c] ? atomicAdd(&lh[bin[c]], 1u) : 0u;
+            for (int c = 0; c < 4; ++c) {
+                bin[c] = mul ? __umulhi(d[c], mul) : d[c];
+                slot[c] = 0u;
+                if (__builtin_amdgcn_inverse_ballot_w64(cm[c])) slot[c] = atomicAdd(&lh[bin[c]], 1u);
+            }
             if (mul) {                                           // (bins of one key each need no keys kept)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (cand[c]) {
-                        if (slot[c] < RS2_SUB) stage[bin[c] * RS2_SUB + slot[c]] = key[c];
-                        else { atomicMin(&lmin[bin[c]], key[c]); atomicMax(&lmax[bin[c]], key[c]); }
+                    if (__builtin_amdgcn_inverse_ballot_w64(cm[c])) {
+                        const uint32_t key = d[c] + lo;
+                        if (slot[c] < RS2_SUB) stage[bin[c] * RS2_SUB + slot[c]] = key;
+                        else { atomicMin(&lmin[bin[c]], key); atomicMax(&lmax[bin[c]], key); }
                     }
             }
         }
@@ -327,13 +336,13 @@ void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32
     unsigned long long* vb = VMODE ? vbits + (size_t)im * (size_t)((n4 + 63) / 64) * 4 : nullptr;
     // whole waves walk the loop together (the counts are per wave): the bound is rounded up to the wave
     const int64_t n4w = ((n4 + 63) / 64) * 64;
-    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + tid; q0 < n4w; q0 += RS2_UNROLL * stride) {
-        float4 v[RS2_UNROLL];
-        int4 m[RS2_UNROLL];
-        unsigned long long w[RS2_UNROLL][4];
-        // the bit words of the RS2_UNROLL groups: eight 32-bit halves each, ONE load - lane l fetches half l & 7 of
-        // group l >> 3 (q >> 6 is the same in every lane of a wave) - and readlane hands them to the scalar side
-        uint32_t xw = 0u;
+    // A batch = RS2_UNROLL float4 groups per thread (+ their masks or bit words).  The loads of batch k + 1 are in
+    // flight while batch k is worked on (two register sets, A and B): with every wave loading, then waiting, then
+    // computing, a pass took its memory time PLUS its compute time (28 us for 78 MB).
+    auto load = [&](int64_t q0, float4 (&v)[RS2_UNROLL], int4 (&m)[RS2_UNROLL], uint32_t& xw) {
+        // the bit words of the groups: eight 32-bit halves each, ONE load - lane l fetches half l & 7 of group
+        // l >> 3 (q >> 6 is the same in every lane of a wave) - and readlane hands them to the scalar side later
+        xw = 0u;
         if (VMODE == 2) {
             const int64_t qu = q0 + (int64_t)(lane >> 3) * stride;
             if (lane < 8 * RS2_UNROLL && qu < n4w)
@@ -345,31 +354,54 @@ void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             m[u] = make_int4(0, 0, 0, 0);
             if (q < n4) v[u] = reinterpret_cast<const float4*>(img)[q];
-            if (VMODE == 2) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    w[u][c] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)xw, 8 * u + 2 * c + 1) << 32) |
-                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)xw, 8 * u + 2 * c);
-            } else if (mask && q < n4) {
-                m[u] = reinterpret_cast<const int4*>(mask)[q];
-            }
+            if (VMODE != 2 && mask && q < n4) m[u] = reinterpret_cast<const int4*>(mask)[q];
         }
+    };
+    auto work = [&](int64_t q0, const float4 (&v)[RS2_UNROLL], const int4 (&m)[RS2_UNROLL], uint32_t xw) {
 #pragma unroll
         for (int u = 0; u < RS2_UNROLL; ++u) {
             const int64_t q = q0 + u * stride;
             if (q >= n4w) break;                                 // (uniform within the wave)
-            if (VMODE != 2) {
-                const bool in = q < n4;
-                w[u][0] = __ballot(in && m[u].x == 0 && v[u].x == v[u].x);
-                w[u][1] = __ballot(in && m[u].y == 0 && v[u].y == v[u].y);
-                w[u][2] = __ballot(in && m[u].z == 0 && v[u].z == v[u].z);
-                w[u][3] = __ballot(in && m[u].w == 0 && v[u].w == v[u].w);
+            unsigned long long w[4];
+            if (VMODE == 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    w[c] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)xw, 8 * u + 2 * c + 1) << 32) |
+                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)xw, 8 * u + 2 * c);
+            } else {
+                const unsigned long long inm = __builtin_amdgcn_ballot_w64(q < n4);
+                w[0] = inm & __builtin_amdgcn_ballot_w64(m[u].x == 0) & __builtin_amdgcn_ballot_w64(v[u].x == v[u].x);
+                w[1] = inm & __builtin_amdgcn_ballot_w64(m[u].y == 0) & __builtin_amdgcn_ballot_w64(v[u].y == v[u].y);
+                w[2] = inm & __builtin_amdgcn_ballot_w64(m[u].z == 0) & __builtin_amdgcn_ballot_w64(v[u].z == v[u].z);
+                w[3] = inm & __builtin_amdgcn_ballot_w64(m[u].w == 0) & __builtin_amdgcn_ballot_w64(v[u].w == v[u].w);
                 if (VMODE == 1 && lane == 0) {
                     unsigned long long* wp = vb + (q >> 6) * 4;
-                    wp[0] = w[u][0]; wp[1] = w[u][1]; wp[2] = w[u][2]; wp[3] = w[u][3];
+                    wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3];
                 }
             }
-            group(v[u], w[u]);
+            group(v[u], w);
+        }
+    };
+    {
+        float4 vA[RS2_UNROLL], vB[RS2_UNROLL];
+        int4 mA[RS2_UNROLL], mB[RS2_UNROLL];
+        uint32_t xA, xB;
+        const int64_t step = RS2_UNROLL * stride;
+        int64_t q = (int64_t)blockIdx.x * blockDim.x + tid;
+        if (q < n4w) {                                           // (whole waves: n4w is a multiple of 64)
+            load(q, vA, mA, xA);
+            while (true) {
+                const bool more = q + step < n4w;
+                if (more) load(q + step, vB, mB, xB);
+                work(q, vA, mA, xA);
+                if (!more) break;
+                q += step;
+                const bool more2 = q + step < n4w;
+                if (more2) load(q + step, vA, mA, xA);
+                work(q, vB, mB, xB);
+                if (!more2) break;
+                q += step;
+            }
         }
     }
     // the last n % 4 pixels: lanes 0 .. 2 of the first wave of the first workgroup
@@ -378,7 +410,7 @@ void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32
         const bool in = lane < (int)(n & 3);
         const float x = in ? img[p] : 0.f;
         const int mk = (in && mask) ? mask[p] : 0;
-        unsigned long long ok[4] = {__ballot(in && mk == 0 && x == x), 0ull, 0ull, 0ull};
+        unsigned long long ok[4] = {__builtin_amdgcn_ballot_w64(in && mk == 0 && x == x), 0ull, 0ull, 0ull};
         group(make_float4(x, 0.f, 0.f, 0.f), ok);
     }
     if (lane == 0) { red[0][wave] = nvalid; red[1][wave] = nbelow; }
@@ -395,18 +427,18 @@ void k_rsel2_pass(const rs_batch B, int mode, rs2_state* __restrict__ st, uint32
         wc[k] = c;
         if (c) {
             atomicAdd(&S->hist[k], c);
-            if (mul) {
-                // the extremes of the bin: the keys kept + those that found no slot (lmin / lmax)
+            if (mul && c > RS2_SUB) {
+                // a bin with more keys than slots (ties, as a rule): its extremes over ALL the keys this workgroup
+                // saw - the kept ones and those that found no slot - so that the finish can tell a bin of one key
                 uint32_t mn = lmin[k], mx = lmax[k];
-                const unsigned int kept = c < RS2_SUB ? c : RS2_SUB;
-                for (unsigned int i = 0; i < kept; ++i) {
+                for (unsigned int i = 0; i < RS2_SUB; ++i) {
                     const uint32_t kk = stage[k * RS2_SUB + i];
                     mn = min(mn, kk);
                     mx = max(mx, kk);
                 }
                 atomicMin(&S->kmin[k], mn);
                 atomicMax(&S->kmax[k], mx);
-                if (c > RS2_SUB) atomicOr(&S->ovf[k >> 5], 1u << (k & 31));
+                atomicOr(&S->ovf[k >> 5], 1u << (k & 31));
             }
         }
     }
@@ -442,108 +474,6 @@ __device__ inline uint32_t select_in_list(const uint32_t* list, unsigned int m, 
         __syncthreads();
     }
     return base;
-}
-
-// grid: nimg.  Resolves the two middle ranks of the pass that ran; after the median (mode 0) it brackets the MAD.
-__global__ __launch_bounds__(RS2_THREADS) void k_rsel2_finish(int mode, rs2_state* __restrict__ st,
-                                                              const uint32_t* __restrict__ seg,
-                                                              const unsigned int* __restrict__ wcnt,
-                                                              const float* __restrict__ samp) {
-    __shared__ rs2_lds L;
-    __shared__ unsigned int h256[RS2_BINS];
-    __shared__ uint32_t list[RS2_LIST];
-    __shared__ unsigned int ln;
-    __shared__ unsigned long long res[2][3];
-    __shared__ unsigned long long res2[3];
-    __shared__ int failed;
-    const int im = blockIdx.x, tid = threadIdx.x;
-    rs2_state* S = st + im;
-    const uint32_t lo = S->lo, mul = S->mul;
-    const unsigned long long below = S->below;
-    const unsigned long long count = mode == 0 ? S->valid : S->count;
-    const uint32_t failbit = mode ? RS2_FAIL_MAD : RS2_FAIL_MED;
-    for (int k = tid; k < RS2_BINS; k += RS2_THREADS) h256[k] = S->hist[k];
-    if (tid == 0) {
-        failed = (S->fail & failbit) ? 1 : 0;
-        for (int t = 0; t < 2; ++t) { res[t][0] = 0; res[t][1] = 0; res[t][2] = 0; }
-    }
-    __syncthreads();
-    const unsigned long long k0 = count ? (count - 1) / 2 : 0, k1 = count ? count / 2 : 0;
-    float med = 0.f;
-    if (count > 0) {
-        if (tid < 64) {
-            wave_find_256(h256, k0 >= below ? k0 - below : ~0ull, res[0]);
-            wave_find_256(h256, k1 >= below ? k1 - below : ~0ull, res[1]);
-        }
-        __syncthreads();
-        const unsigned long long inside = res[0][2];
-        if (tid == 0 && !(k0 >= below && k1 - below < inside)) failed = 1;
-        __syncthreads();
-        uint32_t keyout[2] = {0u, 0u};
-        int have = -1;                                     // the bin whose keys are in `list`
-        unsigned int m = 0;
-        for (int t = 0; t < 2 && !failed; ++t) {
-            if (t == 1 && k1 == k0) { keyout[1] = keyout[0]; break; }
-            const unsigned int b = (unsigned int)res[t][0];
-            const unsigned long long r = (t ? k1 : k0) - below - res[t][1];
-            if (mul == 0) { keyout[t] = lo + b; continue; }
-            const uint32_t bmin = S->kmin[b], bmax = S->kmax[b];
-            if (bmin == bmax) { keyout[t] = bmin; continue; }           // (a bin of one key: ties)
-            if ((int)b != have) {
-                const unsigned int total = S->hist[b];
-                const bool over = (S->ovf[b >> 5] >> (b & 31)) & 1u;
-                __syncthreads();
-                if (tid == 0) {
-                    ln = 0;
-                    if (over || total > RS2_LIST) failed = 1;
-                }
-                __syncthreads();
-                if (failed) break;
-                // the keys of bin b: four threads per workgroup segment
-                {
-                    const int w = tid >> 2, part = tid & 3;
-                    const unsigned int c = wcnt[((size_t)im * RS2_GRID + w) * RS2_BINS + b];
-                    const uint32_t* __restrict__ sgb = seg + (((size_t)im * RS2_GRID + w) * RS2_BINS + b) * RS2_SUB;
-                    for (unsigned int i = part; i < c; i += 4) {
-                        const uint32_t kk = sgb[i];
-                        const unsigned int slot = atomicAdd(&ln, 1u);
-                        if (slot < RS2_LIST) list[slot] = kk;
-                    }
-                }
-                __syncthreads();
-                m = ln;
-                have = (int)b;
-            }
-            keyout[t] = select_in_list(list, m, bmin, nbits(bmax - bmin), r, h256, res2);
-        }
-        if (!failed) med = 0.5f * (key2f_dev(keyout[0]) + key2f_dev(keyout[1]));
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (failed) atomicOr(&S->fail, failbit);
-        if (mode == 0) {
-            S->count = count;
-            S->median = med;
-            S->centre = med;
-            S->out[0] = med;
-            S->out[2] = (double)count;
-        } else {
-            S->out[1] = 1.4826 * (double)med;
-        }
-    }
-    if (mode == 1) return;
-    // the MAD's bracket from the same sample: |v - median| of its valid pixels
-    const float4 v = (reinterpret_cast<const float4*>(samp) + (size_t)im * RS2_SAMPLE4)[tid];
-    const float a[4] = {v.x, v.y, v.z, v.w};
-    uint32_t key[RS2_NK];
-    uint32_t vm = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (a[c] == a[c]) vm |= 1u << c;
-        key[c] = f2key(fabsf(a[c] - med));
-    }
-    __syncthreads();
-    bracket_from_sample(key, vm, S, L);
 }
 
 // The three-pass select in one workgroup (k_rsel_hist / k_rsel_scan of api_subtract.hip, restated for 1 024 threads):
@@ -622,30 +552,158 @@ __device__ inline float rescue_select(const float* __restrict__ img, const int32
     return 0.5f * (key2f_dev(prefix[0]) + key2f_dev(prefix[1]));
 }
 
-// grid: nimg.  The outputs; behind a failed bracket, the select again.
-__global__ __launch_bounds__(RS2_THREADS) void k_rsel2_rescue(const rs_batch B, rs2_state* __restrict__ st,
-                                                              double* __restrict__ out) {
-    __shared__ rs2_rescue_lds L;
+// grid: nimg.  Resolves the two middle ranks of the pass that ran; after the median (mode 0) it brackets the MAD;
+// after the MAD (mode 1) it writes the outputs - behind a failed bracket, after the select in its three-pass form.
+__global__ __launch_bounds__(RS2_THREADS) void k_rsel2_finish(int mode, const rs_batch B, rs2_state* __restrict__ st,
+                                                              const uint32_t* __restrict__ seg,
+                                                              const unsigned int* __restrict__ wcnt,
+                                                              const float* __restrict__ samp, double* __restrict__ out) {
+    __shared__ rs2_lds L;
+    __shared__ rs2_rescue_lds R;
+    __shared__ uint32_t lfail;
+    __shared__ unsigned int h256[RS2_BINS];
+    __shared__ uint32_t list[RS2_LIST];
+    __shared__ unsigned int ln;
+    __shared__ unsigned long long res[2][3];
+    __shared__ unsigned long long res2[3];
+    __shared__ int failed;
     const int im = blockIdx.x, tid = threadIdx.x;
     rs2_state* S = st + im;
-    const uint32_t fail = S->fail;
-    if (fail) {
-        unsigned long long count = S->count;
-        float med = S->median;
-        if (fail & RS2_FAIL_MED) med = rescue_select(B.im[im].img, B.im[im].mask, B.n, 0, 0.f, count, L);
-        __syncthreads();
-        unsigned long long c2 = 0;
-        const float mad = count ? rescue_select(B.im[im].img, B.im[im].mask, B.n, 1, med, c2, L) : 0.f;
-        if (tid == 0) {
-            S->count = count;
-            S->median = med;
-            S->out[0] = med;
-            S->out[1] = 1.4826 * (double)mad;
-            S->out[2] = (double)count;
+    const uint32_t lo = S->lo, mul = S->mul;
+    const unsigned long long below = S->below;
+    const unsigned long long count = mode == 0 ? S->valid : S->count;
+    const uint32_t failbit = mode ? RS2_FAIL_MAD : RS2_FAIL_MED;
+    for (int k = tid; k < RS2_BINS; k += RS2_THREADS) h256[k] = S->hist[k];
+    if (tid == 0) {
+        failed = (S->fail & failbit) ? 1 : 0;
+        for (int t = 0; t < 2; ++t) { res[t][0] = 0; res[t][1] = 0; res[t][2] = 0; }
+    }
+    __syncthreads();
+    const unsigned long long k0 = count ? (count - 1) / 2 : 0, k1 = count ? count / 2 : 0;
+    float med = 0.f;
+    if (count > 0) {
+        if (tid < 64) {
+            wave_find_256(h256, k0 >= below ? k0 - below : ~0ull, res[0]);
+            wave_find_256(h256, k1 >= below ? k1 - below : ~0ull, res[1]);
         }
         __syncthreads();
+        const unsigned long long inside = res[0][2];
+        if (tid == 0 && !(k0 >= below && k1 - below < inside)) failed = 1;
+        __syncthreads();
+        uint32_t keyout[2] = {0u, 0u};
+        int have = -1;                                     // the bin whose keys are in `list`
+        unsigned int m = 0;
+        uint32_t bmin = 0u, bmax = 0u;
+        bool whole = false;
+        for (int t = 0; t < 2 && !failed; ++t) {
+            if (t == 1 && k1 == k0) { keyout[1] = keyout[0]; break; }
+            const unsigned int b = (unsigned int)res[t][0];
+            const unsigned long long r = (t ? k1 : k0) - below - res[t][1];
+            if (mul == 0) { keyout[t] = lo + b; continue; }
+            if ((int)b != have) {
+                // the keys of bin b from the 256 segments: four threads per segment, the first sixteen entries
+                // requested at once; their extremes on the way (a bin of one key - ties - is its own answer)
+                const bool over = (S->ovf[b >> 5] >> (b & 31)) & 1u;
+                __syncthreads();
+                if (tid == 0) ln = 0;
+                __syncthreads();
+                uint32_t mn = 0xffffffffu, mx = 0u;
+                {
+                    const int w = tid >> 2, part = tid & 3;
+                    const uint32_t* __restrict__ sgb = seg + (((size_t)im * RS2_GRID + w) * RS2_BINS + b) * RS2_SUB;
+                    unsigned int c = wcnt[((size_t)im * RS2_GRID + w) * RS2_BINS + b];
+                    uint32_t first[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) first[j] = sgb[part + 4 * j];
+                    c = c < RS2_SUB ? c : RS2_SUB;
+                    auto take = [&](uint32_t kk) {
+                        mn = min(mn, kk);
+                        mx = max(mx, kk);
+                        const unsigned int slot = atomicAdd(&ln, 1u);
+                        if (slot < RS2_LIST) list[slot] = kk;
+                    };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((unsigned int)(part + 4 * j) < c) take(first[j]);
+                    for (unsigned int i = part + 16; i < c; i += 4) take(sgb[i]);
+                }
+#pragma unroll
+                for (int o = 32; o; o >>= 1) {
+                    mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                    mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+                }
+                if ((tid & 63) == 0) { L.red[1][tid >> 6] = mn; L.red[2][tid >> 6] = mx; }
+                __syncthreads();
+                mn = 0xffffffffu; mx = 0u;
+#pragma unroll
+                for (int w = 0; w < RS2_WAVES; ++w) { mn = min(mn, L.red[1][w]); mx = max(mx, L.red[2][w]); }
+                if (over) { mn = min(mn, S->kmin[b]); mx = max(mx, S->kmax[b]); }
+                m = ln;
+                bmin = mn;
+                bmax = mx;
+                whole = !over && m <= RS2_LIST;
+                have = (int)b;
+                __syncthreads();
+            }
+            if (bmin == bmax) { keyout[t] = bmin; continue; }
+            if (!whole) {                                      // (keys missing from the list: not a tie, not resolvable here)
+                __syncthreads();
+                if (tid == 0) failed = 1;
+                __syncthreads();
+                break;
+            }
+            keyout[t] = select_in_list(list, m, bmin, nbits(bmax - bmin), r, h256, res2);
+        }
+        if (!failed) med = 0.5f * (key2f_dev(keyout[0]) + key2f_dev(keyout[1]));
     }
-    if (tid < 3) out[3 * im + tid] = S->out[tid];
+    __syncthreads();
+    if (tid == 0) {
+        lfail = S->fail | (failed ? failbit : 0u);
+        if (failed) atomicOr(&S->fail, failbit);
+        if (mode == 0) {
+            S->count = count;
+            S->median = med;
+            S->centre = med;
+            S->out[0] = med;
+            S->out[2] = (double)count;
+        } else {
+            S->out[1] = 1.4826 * (double)med;
+        }
+    }
+    if (mode == 1) {
+        __syncthreads();
+        double o[3] = {S->out[0], 1.4826 * (double)med, S->out[2]};
+        if (lfail) {                                           // (uniform: shared)
+            unsigned long long cnt = S->count;
+            float m0 = S->median;
+            if (lfail & RS2_FAIL_MED) m0 = rescue_select(B.im[im].img, B.im[im].mask, B.n, 0, 0.f, cnt, R);
+            __syncthreads();
+            unsigned long long c2 = 0;
+            const float mad = cnt ? rescue_select(B.im[im].img, B.im[im].mask, B.n, 1, m0, c2, R) : 0.f;
+            o[0] = m0;
+            o[1] = 1.4826 * (double)mad;
+            o[2] = (double)cnt;
+            if (tid == 0) {
+                S->count = cnt;
+                S->median = m0;
+                S->out[0] = o[0]; S->out[1] = o[1]; S->out[2] = o[2];
+            }
+        }
+        if (tid < 3) out[3 * im + tid] = o[tid];
+        return;
+    }
+    // the MAD's bracket from the same sample: |v - median| of its valid pixels
+    const float4 v = (reinterpret_cast<const float4*>(samp) + (size_t)im * RS2_SAMPLE4)[tid];
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    uint32_t key[RS2_NK];
+    uint32_t vm = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (a[c] == a[c]) vm |= 1u << c;
+        key[c] = f2key(fabsf(a[c] - med));
+    }
+    __syncthreads();
+    bracket_from_sample(key, vm, S, L);
 }
 
 int zm_rs2_median_mad(zm_ctx* ctx, int nimg, const rs_batch& B, unsigned long long* d_vbits, double* out_dev) {
@@ -661,13 +719,12 @@ int zm_rs2_median_mad(zm_ctx* ctx, int nimg, const rs_batch& B, unsigned long lo
     const int grid = RS2_GRID;          // (every workgroup writes its row of counts: n >= ZM_RS2_MIN_N fills them all)
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(k_rsel2_sample, dim3(nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_samp);
-    if (d_vbits) hipLaunchKernelGGL(k_rsel2_pass<1>, dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, 0, d_st, d_seg, d_wcnt, d_vbits);
-    else hipLaunchKernelGGL(k_rsel2_pass<0>, dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, 0, d_st, d_seg, d_wcnt, d_vbits);
-    hipLaunchKernelGGL(k_rsel2_finish, dim3(nimg), dim3(RS2_THREADS), 0, s, 0, d_st, d_seg, d_wcnt, d_samp);
-    if (d_vbits) hipLaunchKernelGGL(k_rsel2_pass<2>, dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, 1, d_st, d_seg, d_wcnt, d_vbits);
-    else hipLaunchKernelGGL(k_rsel2_pass<0>, dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, 1, d_st, d_seg, d_wcnt, d_vbits);
-    hipLaunchKernelGGL(k_rsel2_finish, dim3(nimg), dim3(RS2_THREADS), 0, s, 1, d_st, d_seg, d_wcnt, d_samp);
-    hipLaunchKernelGGL(k_rsel2_rescue, dim3(nimg), dim3(RS2_THREADS), 0, s, B, d_st, out_dev);
+    if (d_vbits) hipLaunchKernelGGL((k_rsel2_pass<1, 0>), dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_seg, d_wcnt, d_vbits);
+    else hipLaunchKernelGGL((k_rsel2_pass<0, 0>), dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_seg, d_wcnt, d_vbits);
+    hipLaunchKernelGGL(k_rsel2_finish, dim3(nimg), dim3(RS2_THREADS), 0, s, 0, B, d_st, d_seg, d_wcnt, d_samp, out_dev);
+    if (d_vbits) hipLaunchKernelGGL((k_rsel2_pass<2, 1>), dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_seg, d_wcnt, d_vbits);
+    else hipLaunchKernelGGL((k_rsel2_pass<0, 1>), dim3(grid, nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_seg, d_wcnt, d_vbits);
+    hipLaunchKernelGGL(k_rsel2_finish, dim3(nimg), dim3(RS2_THREADS), 0, s, 1, B, d_st, d_seg, d_wcnt, d_samp, out_dev);
     ZM_HIP(hipGetLastError());
     return 0;
 }
