@@ -533,6 +533,7 @@ def main():
     npx = args.size * args.size
     L = eng.L
     big_rms = float(np.sqrt(50000.0))
+    sub_async = os.environ.get('ZM_SUB_ASYNC', '1') != '0'     # (0: every subtraction waits for its summary, rounds 1 - 5)
 
     sum_type = args.combine.upper() in ('WEIGHTED', 'AVERAGE')
     sharded = None
@@ -574,9 +575,12 @@ def main():
         if resident is None:
             resident = sc is sci
         def one():
+            # wait=False (round 6): the call returns when the fit's last round has been seen; the next step's coadd
+            # is enqueued while this step's convolution runs (same stream: nothing overlaps on the GPU), the summary
+            # of step k is read - and its checks made - when step k + 1 gets here, or by `sync` below
             sub.run(sc['img'], sc['rms'], sc['mask'], sc['wgt'], co.img, ref_rms,
                     co.mask if co.mask is not None else no_ref_mask, seeing=args.seeing, nreg_side=3,
-                    sci_ready=False if (sub.overlap and resident) else None)
+                    sci_ready=False if (sub.overlap and resident) else None, wait=not sub_async)
         if not shared_card:
             return one()
         # rehearsal with several ranks on one card: the fused Cholesky sizes its grid for a GPU of
@@ -594,6 +598,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
+        sub.result()                                    # (the last subtraction's summary and checks, if it was left pending)
         if multi:
             dist.barrier(device_ids=[local]) if backend == 'nccl' else dist.barrier()
             torch.cuda.synchronize(device)

@@ -210,7 +210,14 @@ typedef struct zm_hp_params {
      * launching zm_mask_flag_dev after the call has returned (a launch with the GPU idle).  NULL: nothing. */
     int32_t* flag_mask_dev;
     int32_t flag_bit;
-    int32_t pad2_;
+    /* Round 6: 1 = zm_subtract_dev returns when the LAST REJECTION ROUND has been seen by the host - the convolution,
+     * the bit-17 pass and the copy of the fit summary are enqueued behind it, not waited for.  out_info then carries
+     * status = ZM_HP_PENDING (niter, ncoeff, retries are final); zm_subtract_info(ctx, &info) waits for the rest and
+     * fills it in.  The caller's next launches on the stream (the next coadd, the next job's alignment) are enqueued
+     * while the convolution runs.  A barrier time-out of the solver makes the call fall back to the synchronous
+     * form (the fit is repeated, as ever).  0 (zm_hp_params_default): wait, as rounds 1 - 5 did.  Device entry
+     * point only; zm_subtract ignores it. */
+    int32_t async_info;
 } zm_hp_params;
 
 void zm_hp_params_default(zm_hp_params* p);
@@ -233,6 +240,7 @@ typedef struct zm_hp_info {
  * has no barrier that could time out - `retries` counts such repeats. */
 #define ZM_HP_UNSOLVED 1
 #define ZM_HP_TIMEOUT 2
+#define ZM_HP_PENDING 4       /* zm_hp_params.async_info: the summary is still on its way - zm_subtract_info */
 
 /* Replaces the hotpants run of Subtraction.from_images
  * (zuds/subtraction.py:144-162; flags zuds/hotpants.py:77-93): convolve the
@@ -362,6 +370,11 @@ int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms,
                     const float* ref, const float* ref_rms, const uint8_t* bpm,
                     int nx, int ny, const zm_hp_params* params, float* out_diff,
                     float* out_rms, zm_hp_info* out_info_host);
+/* The summary of the subtraction this context last ran with zm_hp_params.async_info = 1: waits for its convolution
+ * and the copy of the summary, then fills out_info as the synchronous call would have.  An error when nothing is
+ * pending.  (What `hotpants` prints at its end and Subtraction.from_images keeps in the header:
+ * zuds/subtraction.py:144-177.) */
+int zm_subtract_info(zm_ctx* ctx, zm_hp_info* out_info);
 /* Many subtractions, one call (round 4; the reference runs one hotpants process per job, 64 per node:
  * nersc/controller.py:101, scripts/donightly.py:21-40 -> zuds/subtraction.py:144-162).  Every job is what
  * zm_subtract_dev takes - planes of nx x ny pixels in device memory, its own flags (`params`: the data limits

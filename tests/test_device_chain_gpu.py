@@ -342,6 +342,55 @@ def test_bit17_is_set_by_the_subtraction_itself_and_only_by_its_final_attempt(ch
     assert np.array_equal(submask.cpu().numpy(), submask0)
 
 
+def test_a_subtraction_that_does_not_wait_delivers_the_same_products_and_summary(chain, device_sub, engine, monkeypatch):
+    """Round 6: ``run(wait=False)`` (``zm_hp_params.async_info``) returns when the last rejection round has been
+    seen; the convolution, bit 17 and the fit summary follow on the stream, ``result()`` (``zm_subtract_info``) waits
+    for them.  Same planes, same summary as the call that waits; two calls in a row resolve the first summary before
+    the second fit starts; a solver barrier that times out is heard of with the round's flag (the fit is repeated); a
+    frame without a valid pixel is refused by ``result()``."""
+    z, torch = chain['z'], chain['torch']
+    dmod = __import__('importlib').import_module('zuds-pipeline_amd.device')
+    ds0, diff0, noise0, submask0 = device_sub
+    ref, sci, f = chain['ref'], chain['ims'][3], chain['frames'][3]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to('cuda:0')
+    args = (t(f['img'], np.float32), t(sci.rms_image.data, np.float32), t(f['mask'], np.int32),
+            t(sci.weight_image.data, np.float32), t(ref.data, np.float32),
+            t(ref.rms_image.data, np.float32), t(ref.mask_image.data, np.int32))
+    kw = dict(seeing=2.0, nreg_side=1, hotpants_kws=chain['kws'], ref_flxscale=float(ref.header.get('FLXSCALE', 1.0)))
+    want = {k: getattr(ds0.info, k) for k, _ in ds0.info._fields_}
+    ds = dmod.DeviceSubtraction(sci.wcs, ref.wcs, device=0, engine=engine)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        diff, noise, submask = ds.run(*args, wait=False, **kw)
+        assert ds.info.status == z._lib.HP_PENDING and ds.info.niter == want['niter'] and ds._pending
+    info = ds.result()
+    assert not ds._pending and {k: getattr(info, k) for k, _ in info._fields_} == want
+    assert ds.result() is info                                   # (nothing pending: a no-op)
+    ds.stream.synchronize()
+    assert np.array_equal(diff.cpu().numpy(), diff0) and np.array_equal(noise.cpu().numpy(), noise0)
+    assert np.array_equal(submask.cpu().numpy(), submask0)
+    with pytest.raises(z._lib.ZMError, match='no subtraction with async_info is pending'):
+        z._lib.check(engine.L.zm_subtract_info(engine.ctx, C.byref(ds.info)))
+    # a barrier time-out: the host hears of it with the round's flag, waits for that attempt and repeats the fit on the
+    # form without barriers - whose tail is then left pending like any other
+    monkeypatch.setenv('ZM_CHOL_SPIN_LIMIT', '0')
+    diff, noise, submask = ds.run(*args, wait=False, **kw)
+    monkeypatch.delenv('ZM_CHOL_SPIN_LIMIT')
+    assert ds.info.retries == 1
+    info = ds.result()
+    assert info.retries == 1 and info.status == 0 and info.nstamps_used == want['nstamps_used']
+    ds.stream.synchronize()
+    assert np.array_equal(diff.cpu().numpy(), diff0) and np.array_equal(submask.cpu().numpy(), submask0)
+    # every pixel masked: refused when the summary is asked for
+    bad = list(args)
+    bad[2] = t(np.full(f['mask'].shape, 256, np.int32), np.int32)
+    ds.run(*bad, wait=False, **kw)
+    with pytest.raises(z._lib.ZMError, match='every pixel is masked'):
+        ds.result()
+    ds.stream.synchronize()
+    engine.set_stream(0)
+
+
 def test_aligned_reference_mask_has_no_bit16_and_uncovered_pixels_count(chain, device_sub):
     ds, diff, noise, submask = device_sub
     # (round 6: reference and rms map are aligned by one launch, which hands back no weight planes; an uncovered

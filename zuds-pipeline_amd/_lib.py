@@ -64,7 +64,7 @@ class zm_hp_params(C.Structure):
                 ('pad_', C.c_int32 * 3),
                 ('sigma', C.c_double * 4),
                 ('limits_dev', C.c_void_p), ('limits_nsigma', C.c_double),
-                ('flag_mask_dev', C.c_void_p), ('flag_bit', C.c_int32), ('pad2_', C.c_int32)]
+                ('flag_mask_dev', C.c_void_p), ('flag_bit', C.c_int32), ('async_info', C.c_int32)]
 
 
 class zm_sub_job(C.Structure):
@@ -93,7 +93,7 @@ class zm_mask_plan(C.Structure):
                 ('gather_off', C.c_int64 * COMM_MAX_RANKS)]
 
 
-HP_UNSOLVED, HP_TIMEOUT = 1, 2          # zm_hp_info.status bits (include/zudsmi.h)
+HP_UNSOLVED, HP_TIMEOUT, HP_PENDING = 1, 2, 4          # zm_hp_info.status bits (include/zudsmi.h)
 
 
 _P = C.c_void_p
@@ -153,6 +153,7 @@ _SIGS = {
     'zm_subtract_dev': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.POINTER(zm_hp_params), _P, _P,
                                   C.POINTER(zm_hp_info)]),
+    'zm_subtract_info': (C.c_int, [_P, C.POINTER(zm_hp_info)]),
     'zm_subtract_batch_dev': (C.c_int, [_P, C.c_int, C.POINTER(zm_sub_job), C.c_int, C.c_int,
                                         C.POINTER(zm_hp_info)]),
     'zm_subtract_batch': (C.c_int, [_P, C.c_int, C.POINTER(zm_sub_job), C.c_int, C.c_int,

@@ -68,6 +68,7 @@ void zm_ctx::release_all() {
     event_pool.clear();
     for (auto e : sync_events) (void)hipEventDestroy(e);
     if (bk_stats_event) { (void)hipEventDestroy(bk_stats_event); bk_stats_event = nullptr; }
+    if (hp_done) { (void)hipEventDestroy(hp_done); hp_done = nullptr; }
     sync_events.clear();
 }
 

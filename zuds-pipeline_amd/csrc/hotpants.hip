@@ -2293,12 +2293,15 @@ static __device__ __forceinline__ void hp_merit_body(const hp_plan& P, const dou
 }
 
 // one workgroup per region: clipped moments of the merits, reject, advance
+// bit of a round's flag: a barrier of the many-workgroup factorisation timed out in this attempt (the flag is then
+// not 0, later rounds are not void: their work is thrown away with the attempt)
+#define HP_RFLAG_TMO (1 << 30)
 __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double* __restrict__ merit,
                                                    const int2* __restrict__ centres,
                                                    int* __restrict__ active, int* __restrict__ need,
                                                    int* __restrict__ chg, int* __restrict__ nrej,
                                                    double* __restrict__ stats, const int* __restrict__ guard, int* __restrict__ round_flag,
-                                                   int* __restrict__ needlist) {
+                                                   int* __restrict__ needlist, const int* __restrict__ tmo = nullptr) {
     if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
     __shared__ double red[4];
     const int reg = blockIdx.x, tid = threadIdx.x;
@@ -2352,6 +2355,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
     if (tid == 0) {
         nrej[reg] = (int)cnt;
         if (cnt > 0) atomicAdd(round_flag, (int)cnt);        // any rejection: the next round is live
+        if (tmo && tmo[reg]) atomicOr(round_flag, HP_RFLAG_TMO);   // (the host hears of a barrier time-out with the round)
         stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
         stats[reg * 2 + 1] = used;
     }
@@ -2375,7 +2379,8 @@ static __device__ __forceinline__ void hp_reject_wave_body(const hp_plan& P, con
                                                        int* __restrict__ active, int* __restrict__ need,
                                                        int* __restrict__ chg, int* __restrict__ nrej,
                                                        double* __restrict__ stats, const int* __restrict__ guard,
-                                                       int* __restrict__ round_flag, int* __restrict__ needlist) {
+                                                       int* __restrict__ round_flag, int* __restrict__ needlist,
+                                                       const int* __restrict__ tmo = nullptr) {
     if (guard && *guard == 0) return;
     const int reg = blockIdx.x, lane = threadIdx.x;
     double mv[4];
@@ -2441,6 +2446,7 @@ static __device__ __forceinline__ void hp_reject_wave_body(const hp_plan& P, con
     if (lane == 0) {
         nrej[reg] = (int)cnt;
         if (cnt > 0) atomicAdd(round_flag, (int)cnt);        // any rejection: the next round is live
+        if (tmo && tmo[reg]) atomicOr(round_flag, HP_RFLAG_TMO);   // (the host hears of a barrier time-out with the round)
         stats[reg * 2 + 0] = used > 0 ? msum / used : 0.0;   // mean merit of the stamps fitted
         stats[reg * 2 + 1] = used;
     }
@@ -2626,8 +2632,8 @@ __global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const do
                                                        int* __restrict__ need, int* __restrict__ chg,
                                                        int* __restrict__ nrej, double* __restrict__ stats,
                                                        const int* __restrict__ guard, int* __restrict__ round_flag,
-                                                       int* __restrict__ needlist) {
-    hp_reject_wave_body(P, merit, centres, active, need, chg, nrej, stats, guard, round_flag, needlist);
+                                                       int* __restrict__ needlist, const int* __restrict__ tmo) {
+    hp_reject_wave_body(P, merit, centres, active, need, chg, nrej, stats, guard, round_flag, needlist, tmo);
 }
 __global__ __launch_bounds__(64) void k_hp_reject_wave_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
     const hp_job& J = jobs[blockIdx.z];
@@ -2872,6 +2878,45 @@ struct hp_fit_guard {
     void release() { if (c) c->fetch_sub(1); c = nullptr; }
     ~hp_fit_guard() { release(); }
 };
+
+// The fit summary as the host reads it (one pinned buffer: counters, stamp statistics, the regions' kernel sums).
+#define HP_NIBUF_ (4 * HP_MAXREG + 4)
+#define HP_SUMBYTES_ (sizeof(int) * HP_NIBUF_ + sizeof(double) * 3 * HP_MAXREG)
+static void hp_fill_info(const char* h_sum, int nreg, int nunk, int rounds, int retries, zm_hp_info* info) {
+    const int* h_int = reinterpret_cast<const int*>(h_sum);
+    const double* h_stats = reinterpret_cast<const double*>(h_sum + sizeof(int) * HP_NIBUF_);
+    const double* h_x0 = h_stats + 2 * HP_MAXREG;
+    // a region is solved when it fitted at least one stamp and the factorisation held (k_hp_solved's rule)
+    auto reg_solved = [&](int reg) {
+        return h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
+               h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x0[reg]);
+    };
+    memset(info, 0, sizeof(*info));
+    double ks = 0, chi = 0;
+    int nsolved = 0;
+    for (int r = 0; r < nreg; ++r) {
+        info->nstamps_total += h_int[HP_MAXREG + r];
+        info->nstamps_used += (int)h_stats[2 * r + 1];
+        if (reg_solved(r)) {
+            ks += h_x0[r];
+            chi += h_stats[2 * r];
+            ++nsolved;
+        }
+    }
+    info->niter = rounds;
+    info->ncoeff = nunk;
+    info->kernel_sum = nsolved ? ks / nsolved : 0.0;
+    info->chi2 = nsolved ? chi / nsolved : 0.0;
+    info->nmasked = h_int[3 * HP_MAXREG];
+    // status bits: ZM_HP_UNSOLVED - a region without a usable fit (no stamps left / normal matrix
+    // not positive definite: its pixels carry the fill value).  ZM_HP_TIMEOUT is reserved: barrier
+    // time-outs can only happen in the first attempt (k_chol_fused); the repeat runs k_chol_tp, which
+    // has no barrier between workgroups and therefore nothing that could time out - `retries` says
+    // that a repeat happened, a hung device surfaces as a HIP error of the stream synchronisation.
+    info->status = (nsolved == nreg ? 0 : ZM_HP_UNSOLVED);
+    info->nunsolved = nreg - nsolved;
+    info->retries = retries;
+}
 
 extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_rms, const float* ref,
                                const float* ref_rms, const uint8_t* bpm, int nx, int ny,
@@ -3212,10 +3257,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard, needlist);
             if (P.ncellr <= 256)
                 hipLaunchKernelGGL(k_hp_reject_wave, dim3(P.nreg), dim3(64), 0, st, P, merit, centres, active, need,
-                                   chg, nrej, stats, guard, rflags + rounds, needlist);
+                                   chg, nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo);
             else
                 hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
-                                   nrej, stats, guard, rflags + rounds, needlist);
+                                   nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo);
             ZM_HIP(hipGetLastError());
         }
         ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -3224,11 +3269,13 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     };
     rounds = 0;
     ZM_TRY(enqueue_round(1));
+    bool tmo_seen = false;
     for (int r = 1; r <= 8; ++r) {
         if (r < 8) ZM_TRY(enqueue_round(r + 1));          // void if round r rejects nothing
         ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
         rounds = r;
-        if (h_rflags[r] == 0) break;
+        tmo_seen = tmo_seen || (h_rflags[r] & HP_RFLAG_TMO);
+        if ((h_rflags[r] & ~HP_RFLAG_TMO) == 0 || tmo_seen) break;
     }
     // the convolution behind the last round, on the device's own view of which regions are solved
     {
@@ -3250,6 +3297,28 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     // ... and ONE read of the fit summary (counters incl. the convolution's masked-pixel count, stamp statistics,
     // the regions' kernel sums), one copy, when everything is done
     ZM_HIP(hipMemcpyAsync(h_sum, sumbuf, HP_SUMBYTES, hipMemcpyDeviceToHost, st));
+    // zm_hp_params.async_info: the rounds are over (the host has seen the last flag, and no time-out with it), what is
+    // left - convolution, bit 17, the summary's copy - is enqueued: return, zm_subtract_info waits for the rest.  The
+    // host then enqueues whatever comes next (the next coadd's statistics, the next job's alignment) while the
+    // convolution runs, instead of starting on it when the summary has arrived.
+    if (hp->async_info && !tmo_seen) {
+        if (!ctx->hp_done) ZM_HIP(hipEventCreateWithFlags(&ctx->hp_done, hipEventDisableTiming));
+        ZM_HIP(hipEventRecord(ctx->hp_done, st));
+        ctx->hp_pending = true;
+        ctx->hp_pend_rounds = rounds;
+        ctx->hp_pend_retries = retries;
+        ctx->hp_pend_nreg = P.nreg;
+        ctx->hp_pend_nunk = P.nunk;
+        fitting.release();
+        if (info) {
+            memset(info, 0, sizeof(*info));
+            info->status = ZM_HP_PENDING;
+            info->niter = rounds;
+            info->ncoeff = P.nunk;
+            info->retries = retries;
+        }
+        return 0;
+    }
     ZM_HIP(hipStreamSynchronize(st));
     ntimeouts = 0;
     for (int reg = 0; reg < P.nreg; ++reg) ntimeouts += h_int[3 * HP_MAXREG + 4 + reg];
@@ -3262,38 +3331,23 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     }
     }   // attempts
     fitting.release();
-    // a region is solved when it fitted at least one stamp and the factorisation held (k_hp_solved's rule)
-    auto reg_solved = [&](int reg) {
-        return h_stats[2 * reg + 1] >= 1.0 && h_int[2 * HP_MAXREG + reg] == 0 &&
-               h_int[3 * HP_MAXREG + 4 + reg] == 0 && std::isfinite(h_x0[reg]);
-    };
-    if (info) {
-        memset(info, 0, sizeof(*info));
-        double ks = 0, chi = 0;
-        int nsolved = 0;
-        for (int r = 0; r < P.nreg; ++r) {
-            info->nstamps_total += h_int[HP_MAXREG + r];
-            info->nstamps_used += (int)h_stats[2 * r + 1];
-            if (reg_solved(r)) {
-                ks += h_x0[r];
-                chi += h_stats[2 * r];
-                ++nsolved;
-            }
-        }
-        info->niter = rounds;
-        info->ncoeff = P.nunk;
-        info->kernel_sum = nsolved ? ks / nsolved : 0.0;
-        info->chi2 = nsolved ? chi / nsolved : 0.0;
-        info->nmasked = h_int[3 * HP_MAXREG];
-        // status bits: ZM_HP_UNSOLVED - a region without a usable fit (no stamps left / normal matrix
-        // not positive definite: its pixels carry the fill value).  ZM_HP_TIMEOUT is reserved: barrier
-        // time-outs can only happen in the first attempt (k_chol_fused); the repeat runs k_chol_tp, which
-        // has no barrier between workgroups and therefore nothing that could time out - `retries` says
-        // that a repeat happened, a hung device surfaces as a HIP error of the stream synchronisation.
-        info->status = (nsolved == P.nreg ? 0 : ZM_HP_UNSOLVED);
-        info->nunsolved = P.nreg - nsolved;
-        info->retries = retries;
-    }
+    ctx->hp_pending = false;
+    if (info) hp_fill_info(h_sum, P.nreg, P.nunk, rounds, retries, info);
+    return 0;
+}
+
+extern "C" int zm_subtract_info(zm_ctx* ctx, zm_hp_info* info) {
+    ZM_CHECK(ctx && info, "zm_subtract_info: null argument");
+    ZM_CHECK(ctx->hp_pending, "zm_subtract_info: no subtraction with async_info is pending on this context");
+    ZM_HIP(hipSetDevice(ctx->device));
+    ZM_HIP(hipEventSynchronize(ctx->hp_done));
+    ctx->hp_pending = false;
+    char* h_sum = nullptr;
+    ZM_TRY(ctx->get_pinned("hp_summary_h", HP_SUMBYTES_, (void**)&h_sum));
+    const int* h_int = reinterpret_cast<const int*>(h_sum);
+    for (int reg = 0; reg < ctx->hp_pend_nreg; ++reg)
+        ZM_CHECK(h_int[3 * HP_MAXREG + 4 + reg] == 0, "zm_subtract_info: a barrier time-out went unnoticed (region %d)", reg);
+    hp_fill_info(h_sum, ctx->hp_pend_nreg, ctx->hp_pend_nunk, ctx->hp_pend_rounds, ctx->hp_pend_retries, info);
     return 0;
 }
 
@@ -3586,7 +3640,9 @@ extern "C" int zm_subtract(zm_ctx* ctx, const float* sci, const float* sci_rms, 
         ZM_TRY(ctx->get("hs_bpm", np, (void**)&d_bpm));
         ZM_HIP(hipMemcpyAsync(d_bpm, bpm, np, hipMemcpyHostToDevice, ctx->stream));
     }
-    ZM_TRY(zm_subtract_dev(ctx, d[0], d[1], d[2], d[3], d_bpm, nx, ny, hp, d[4], d[5], info));
+    zm_hp_params hps = *hp;
+    hps.async_info = 0;                          // (host entry point: the planes are copied back below, the summary with them)
+    ZM_TRY(zm_subtract_dev(ctx, d[0], d[1], d[2], d[3], d_bpm, nx, ny, &hps, d[4], d[5], info));
     ZM_HIP(hipMemcpyAsync(out_diff, d[4], np * 4, hipMemcpyDeviceToHost, ctx->stream));
     ZM_HIP(hipMemcpyAsync(out_rms, d[5], np * 4, hipMemcpyDeviceToHost, ctx->stream));
     ZM_HIP(hipStreamSynchronize(ctx->stream));

@@ -80,6 +80,11 @@ struct zm_ctx {
     // per context, not per process - contexts may sit on different devices
     int hp_wg_cap = 0;
     bool hp_rset = false, hp_bset = false;
+    // a subtraction that returned before its convolution had run (zm_hp_params.async_info): what zm_subtract_info
+    // needs to finish the job
+    hipEvent_t hp_done = nullptr;
+    bool hp_pending = false;
+    int hp_pend_rounds = 0, hp_pend_retries = 0, hp_pend_nreg = 0, hp_pend_nunk = 0;
     std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
     std::vector<double> hp_filt_host;          // the 1-D filter table the device copy (scratch slot "hp_filt") holds
     const void* hp_filt_dev = nullptr;

@@ -190,19 +190,29 @@ class DeviceSubtraction(object):
         self.overlap = bool(overlap)
         self._bk_engine = self._bk_stream = None
         self._last_done = None              # event: the last subtraction of this chain has read its inputs
+        self._pending = False               # run(wait=False): the fit summary has not been fetched yet
 
     def run(self, sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
             nreg_side=3, subtract_back=True, hotpants_kws=None, ref_flxscale=1.0,
-            ref_rms_flxscale=None, sci_ready=None):
+            ref_rms_flxscale=None, sci_ready=None, wait=True):
         """All arguments are torch tensors on this device; ``seeing`` is the
         science FWHM in pixels (header SEEING); ``ref_flxscale`` the FLXSCALE card of the
         reference (SWarp applies it on resampling, ``swarp.run_align``).
-        Returns (diff, noise, submask)."""
+        Returns (diff, noise, submask).
+
+        ``wait=False`` (round 6; ``zm_hp_params.async_info``): return when the fit's last rejection round has been
+        seen - the convolution, bit 17 and the fit summary are enqueued on this chain's stream, not waited for, so the
+        caller's next launches (the next coadd, the next frame's alignment) are enqueued while the convolution runs.
+        The planes returned are then valid for work on this stream; ``result()`` waits for the summary, fills
+        ``self.info`` and makes the checks ``run`` otherwise makes before it returns."""
         L, ctx = self.engine.L, self.engine.ctx
         ny, nx = self.shape
         scim, p = self.prepare(sci, sci_rms, sci_mask, sci_wgt, ref, ref_rms, ref_mask, seeing,
                                nreg_side=nreg_side, subtract_back=subtract_back, hotpants_kws=hotpants_kws,
                                ref_flxscale=ref_flxscale, ref_rms_flxscale=ref_rms_flxscale, sci_ready=sci_ready)
+        if self._pending:
+            self.result()                                 # (one summary buffer per context: the last one is read first)
+        p.async_info = 0 if wait else 1
         with self.torch.cuda.stream(self.stream):
             check(L.zm_subtract_dev(ctx, scim.data_ptr(), sci_rms.data_ptr(),
                                     self.ref_al.data_ptr(), self.refrms_al.data_ptr(),
@@ -211,8 +221,20 @@ class DeviceSubtraction(object):
                                     C.byref(self.info)), 'zm_subtract_dev')
             if self.overlap:
                 self._last_done = self.stream.record_event()
-        self.check_limits()
+        self._pending = bool(self.info.status & _lib.HP_PENDING)
+        if not self._pending:
+            self.check_limits()
         return self.finish()
+
+    def result(self):
+        """Behind ``run(..., wait=False)``: wait for the convolution and the fit summary, fill ``self.info``, raise what
+        ``run`` would have raised (a frame without a valid pixel).  Returns ``self.info``; a no-op when nothing is
+        pending."""
+        if self._pending:
+            check(self.engine.L.zm_subtract_info(self.engine.ctx, C.byref(self.info)), 'zm_subtract_info')
+            self._pending = False
+            self.check_limits()
+        return self.info
 
     def release_overlap(self):
         """Give the second context of ``overlap=True`` back (it is made again on the next run that wants it)."""

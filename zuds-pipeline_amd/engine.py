@@ -383,8 +383,8 @@ def hp_params(**kw):
             p.limits_dev = int(v) if v else None       # device address of the six doubles of zm_median_mad2_async_dev
         elif k == 'flag_mask_dev':
             p.flag_mask_dev = int(v) if v else None    # device address of the int32 mask plane that takes flag_bit
-        elif k == 'flag_bit':
-            p.flag_bit = int(v)
+        elif k in ('flag_bit', 'async_info'):
+            setattr(p, k, int(v))
         elif hasattr(p, k):
             setattr(p, k, float(v))
         else:
