@@ -92,10 +92,16 @@ def build(force=False, verbose=True):
             procs.append((src, subprocess.Popen(cmd)))
         elif verbose:
             print(f'up to date: {o.name} (newer than {src} and the headers)', flush=True)
-    failed = [src for src, p in procs if p.wait() != 0]
+    rc = {src: p.wait() for src, p in procs}
+    failed = [src for src in rc if rc[src] != 0]
+    # the units that did compile are checked (and their intermediate files removed) whether or not another one failed:
+    # their objects are up to date from now on and would never be looked at again
+    lint_built(objdir, [src for src in rc if rc[src] == 0], verbose)
     if failed:
+        for src in failed:
+            for junk in list(objdir.glob(Path(src).stem + '-*')) + list(objdir.glob(Path(src).stem + '.hip-*')):
+                junk.unlink()
         raise RuntimeError(f'hipcc failed on {", ".join(failed)}')
-    lint_built(objdir, [src for src, _ in procs], verbose)
     lib = LIBDIR / LIBNAME
     if force or procs or _stale(lib, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o',

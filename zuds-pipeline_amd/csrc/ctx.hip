@@ -69,6 +69,7 @@ void zm_ctx::release_all() {
     for (auto e : sync_events) (void)hipEventDestroy(e);
     if (bk_stats_event) { (void)hipEventDestroy(bk_stats_event); bk_stats_event = nullptr; }
     if (hp_done) { (void)hipEventDestroy(hp_done); hp_done = nullptr; }
+    if (hp_sig_h) { (void)hipHostFree(hp_sig_h); hp_sig_h = hp_sig_d = nullptr; }
     sync_events.clear();
 }
 

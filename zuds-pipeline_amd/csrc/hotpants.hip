@@ -2296,13 +2296,38 @@ static __device__ __forceinline__ void hp_merit_body(const hp_plan& P, const dou
 // bit of a round's flag: a barrier of the many-workgroup factorisation timed out in this attempt (the flag is then
 // not 0, later rounds are not void: their work is thrown away with the attempt)
 #define HP_RFLAG_TMO (1 << 30)
+// Round 6: the host hears of a round's flag from the rejection kernel itself - the last of its workgroups to finish
+// writes {generation, flag | HP_RFLAG_DONE} into a word of coherent pinned memory the host spins on - instead of a
+// 4-byte copy behind the kernel and an event (a blit kernel of 4 us and a barrier packet of 6 per round: 70 us of a
+// subtraction).  `host` NULL (the batch's kernels): nothing.
+#define HP_RFLAG_DONE 0x80000000u
+struct hp_sig {
+    int* done;                     // device counter of the round: workgroups that have finished
+    unsigned long long* host;      // the round's word, as the device addresses it
+    unsigned seq;                  // generation of the attempt (words are not reset between calls)
+};
+static __device__ __forceinline__ void hp_round_signal(const hp_sig& sg, int* round_flag, int nblocks) {
+    if (!sg.host) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(sg.done, 1) == nblocks - 1) {
+        const unsigned v = (unsigned)atomicAdd(round_flag, 0);
+        __threadfence_system();
+        __hip_atomic_store(sg.host, ((unsigned long long)sg.seq << 32) | v | HP_RFLAG_DONE, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double* __restrict__ merit,
                                                    const int2* __restrict__ centres,
                                                    int* __restrict__ active, int* __restrict__ need,
                                                    int* __restrict__ chg, int* __restrict__ nrej,
                                                    double* __restrict__ stats, const int* __restrict__ guard, int* __restrict__ round_flag,
-                                                   int* __restrict__ needlist, const int* __restrict__ tmo = nullptr) {
-    if (guard && *guard == 0) return;                    // the previous round rejected nothing: this round is void
+                                                   int* __restrict__ needlist, const int* __restrict__ tmo = nullptr,
+                                                   const hp_sig sig = hp_sig{nullptr, nullptr, 0u}) {
+    if (guard && *guard == 0) {                          // the previous round rejected nothing: this round is void
+        hp_round_signal(sig, round_flag, gridDim.x);
+        return;
+    }
     __shared__ double red[4];
     const int reg = blockIdx.x, tid = threadIdx.x;
     double m = 0.0, s = 0.0;
@@ -2369,6 +2394,7 @@ __global__ __launch_bounds__(256) void k_hp_reject(const hp_plan P, const double
             if (chg[reg * P.ncellr + c]) list[1 + k++] = reg * P.ncellr + c;
         list[0] = k;
     }
+    hp_round_signal(sig, round_flag, gridDim.x);
 }
 
 // The same for regions of at most 256 cells, by one wave: lane l keeps cells l, l + 64, l + 128,
@@ -2632,8 +2658,10 @@ __global__ __launch_bounds__(64) void k_hp_reject_wave(const hp_plan P, const do
                                                        int* __restrict__ need, int* __restrict__ chg,
                                                        int* __restrict__ nrej, double* __restrict__ stats,
                                                        const int* __restrict__ guard, int* __restrict__ round_flag,
-                                                       int* __restrict__ needlist, const int* __restrict__ tmo) {
+                                                       int* __restrict__ needlist, const int* __restrict__ tmo,
+                                                       const hp_sig sig) {
     hp_reject_wave_body(P, merit, centres, active, need, chg, nrej, stats, guard, round_flag, needlist, tmo);
+    hp_round_signal(sig, round_flag, gridDim.x);
 }
 __global__ __launch_bounds__(64) void k_hp_reject_wave_b(const hp_plan P, const hp_job* __restrict__ jobs, int round) {
     const hp_job& J = jobs[blockIdx.z];
@@ -3045,10 +3073,19 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
     int* rflags = nullptr;
     int* h_rflags = nullptr;
     hipEvent_t* evs = nullptr;
-    ZM_TRY(ctx->get("hp_rflags", sizeof(int) * 16, (void**)&rflags));
+    ZM_TRY(ctx->get("hp_rflags", sizeof(int) * 32, (void**)&rflags));        // [16] flags, [16] finished-workgroup counters
     ZM_TRY(ctx->get_pinned("hp_rflags_h", sizeof(int) * 16, (void**)&h_rflags));
     ZM_TRY(zm_get_sync_events(ctx, 3, &evs));
-    ZM_HIP(hipMemsetAsync(rflags, 0, sizeof(int) * 16, st));
+    ZM_HIP(hipMemsetAsync(rflags, 0, sizeof(int) * 32, st));
+    // the words the rejection kernels signal through (coherent, mapped; one per round; never reset: a word counts
+    // when it carries this attempt's generation)
+    if (!ctx->hp_sig_h) {
+        ZM_HIP(hipHostMalloc((void**)&ctx->hp_sig_h, sizeof(unsigned long long) * 16, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(ctx->hp_sig_h, 0, sizeof(unsigned long long) * 16);
+        ZM_HIP(hipHostGetDevicePointer((void**)&ctx->hp_sig_d, ctx->hp_sig_h, 0));
+    }
+    static const bool sig_off = ZM_DEVENV("ZM_HP_SIGNAL") && ZM_DEVENV("ZM_HP_SIGNAL")[0] == '0';   // (developer build, 0: the copy + event of rounds 1 - 5)
+    const unsigned seq = ++ctx->hp_seq;
     auto enqueue_round = [&](const int rounds) -> int {
         const int* guard = rounds > 1 ? rflags + (rounds - 1) : nullptr;
         // later rounds: the vector / Gram kernels run over the list of cells with a new substamp; this many
@@ -3255,27 +3292,57 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     hipLaunchKernelGGL(k_chol_back, dim3(P.nreg), dim3(1024), bsh, st, P.nunk, lda, A, dsc, rhs, guard);
             }
             hipLaunchKernelGGL(k_hp_merit, dim3(P.ncell), dim3(64), 0, st, P, G, phi, vbar, active, rhs, merit, guard, needlist);
+            const hp_sig sig = sig_off ? hp_sig{nullptr, nullptr, 0u} : hp_sig{rflags + 16 + rounds, ctx->hp_sig_d + rounds, seq};
             if (P.ncellr <= 256)
                 hipLaunchKernelGGL(k_hp_reject_wave, dim3(P.nreg), dim3(64), 0, st, P, merit, centres, active, need,
-                                   chg, nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo);
+                                   chg, nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo, sig);
             else
                 hipLaunchKernelGGL(k_hp_reject, dim3(P.nreg), b256, 0, st, P, merit, centres, active, need, chg,
-                                   nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo);
+                                   nrej, stats, guard, rflags + rounds, needlist, (const int*)tmo, sig);
             ZM_HIP(hipGetLastError());
         }
-        ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
-        ZM_HIP(hipEventRecord(evs[1 + (rounds & 1)], st));
+        if (sig_off) {
+            ZM_HIP(hipMemcpyAsync(h_rflags + rounds, rflags + rounds, sizeof(int), hipMemcpyDeviceToHost, st));
+            ZM_HIP(hipEventRecord(evs[1 + (rounds & 1)], st));
+        }
         return 0;
+    };
+    // the flag of round r as the host learns it
+    auto wait_round = [&](int r, int* flag) -> int {
+        if (sig_off) {
+            ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
+            *flag = h_rflags[r];
+            return 0;
+        }
+        for (unsigned long spins = 1;; ++spins) {
+            const unsigned long long w = __atomic_load_n(&ctx->hp_sig_h[r], __ATOMIC_ACQUIRE);
+            if ((unsigned)(w >> 32) == seq && ((unsigned)w & HP_RFLAG_DONE)) {
+                *flag = (int)((unsigned)w & ~HP_RFLAG_DONE);
+                return 0;
+            }
+            if ((spins & 0x3ffff) == 0) {                // now and then: is the stream still alive?
+                const hipError_t e = hipStreamQuery(st);
+                if (e == hipSuccess) {                   // everything enqueued has run: the word must be there
+                    const unsigned long long w2 = __atomic_load_n(&ctx->hp_sig_h[r], __ATOMIC_ACQUIRE);
+                    ZM_CHECK((unsigned)(w2 >> 32) == seq && ((unsigned)w2 & HP_RFLAG_DONE),
+                             "zm_subtract: round %d finished without signalling the host", r);
+                } else if (e != hipErrorNotReady) {
+                    ZM_HIP(e);
+                }
+            }
+            __builtin_ia32_pause();
+        }
     };
     rounds = 0;
     ZM_TRY(enqueue_round(1));
     bool tmo_seen = false;
     for (int r = 1; r <= 8; ++r) {
         if (r < 8) ZM_TRY(enqueue_round(r + 1));          // void if round r rejects nothing
-        ZM_HIP(hipEventSynchronize(evs[1 + (r & 1)]));
+        int flag = 0;
+        ZM_TRY(wait_round(r, &flag));
         rounds = r;
-        tmo_seen = tmo_seen || (h_rflags[r] & HP_RFLAG_TMO);
-        if ((h_rflags[r] & ~HP_RFLAG_TMO) == 0 || tmo_seen) break;
+        tmo_seen = tmo_seen || (flag & HP_RFLAG_TMO);
+        if ((flag & ~HP_RFLAG_TMO) == 0 || tmo_seen) break;
     }
     // the convolution behind the last round, on the device's own view of which regions are solved
     {

@@ -83,6 +83,9 @@ struct zm_ctx {
     // a subtraction that returned before its convolution had run (zm_hp_params.async_info): what zm_subtract_info
     // needs to finish the job
     hipEvent_t hp_done = nullptr;
+    // the words the rejection rounds signal the host through (hotpants.hip: hp_round_signal)
+    unsigned long long *hp_sig_h = nullptr, *hp_sig_d = nullptr;
+    unsigned hp_seq = 0;
     bool hp_pending = false;
     int hp_pend_rounds = 0, hp_pend_retries = 0, hp_pend_nreg = 0, hp_pend_nunk = 0;
     std::map<int, size_t> hp_set_max;          // LDS opt-in of k_hp_apply<half width>
