@@ -36,6 +36,23 @@ def test_background_matches_oracle(engine, shape, mesh):
     assert abs(stats[0] - r_mean) < 2e-3 and abs(stats[1] - r_sig) < 1e-3
 
 
+@pytest.mark.parametrize('fsize', [1, 5, 7])
+@pytest.mark.parametrize('shape,mesh', [((512, 480), 64), ((560, 540), 16), ((300, 100), 128)])
+def test_other_filter_sizes_match_the_oracle(engine, shape, mesh, fsize):
+    """BACK_FILTERSIZE other than the reference's 3 (``sextractor.conf:70``): the window median by rank counting on
+    the staged maps (round 6: no per-thread window), clipped windows at the borders included (300 x 100 at 128: a
+    3 x 1 mesh map, every window clipped); a mesh masked out so that the fill runs in front of the filter."""
+    nx, ny = shape
+    f = make(nx, ny, 7 * fsize + mesh)
+    w = f['wgt'].copy()
+    w[:mesh, :mesh] = 0
+    bkg, rms, _, stats = engine.background(f['img'], w, mesh=mesh, filtersize=fsize)
+    r_bkg, r_rms, r_mean, r_sig, _, _ = oback.background(f['img'].astype(np.float64), w.astype(np.float64), mesh, fsize)
+    assert_close_masked(bkg, r_bkg, 2e-5, 1e-3, 'background')
+    assert_close_masked(rms, r_rms, 1e-4, 1e-4, 'background rms')
+    assert abs(stats[0] - r_mean) < 2e-3 and abs(stats[1] - r_sig) < 1e-3
+
+
 def test_no_weight_map_and_flat_image(engine):
     img = np.full((256, 256), 42.0, dtype=np.float32)
     bkg, rms, sub, stats = engine.background(img, None, mesh=64)

@@ -766,14 +766,27 @@ __global__ __launch_bounds__(BK_THREADS) void k_mesh_stats(const float* __restri
 }
 
 // ---------------------------------------------------------------------------
-__device__ inline float small_median(float* v, int n) {
-    for (int i = 1; i < n; ++i) {
-        float t = v[i];
-        int j = i - 1;
-        while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; --j; }
-        v[j + 1] = t;
-    }
-    return (n & 1) ? v[n / 2] : 0.5f * (v[n / 2 - 1] + v[n / 2]);
+// Median of the window [j0, j1] x [i0, i1] of a staged map without a copy of the window: the rank of an element is the
+// number of smaller ones plus the equal ones before it in window order (what an insertion sort's position is);
+// the median is (n & 1) ? v[n / 2] : 0.5 (v[n / 2 - 1] + v[n / 2]) of the sorted window (SExtractor's back filter).
+__device__ inline float window_median(const float* m, int nbx, int j0, int j1, int i0, int i1) {
+    const int c = (j1 - j0 + 1) * (i1 - i0 + 1);
+    const int r0 = (c - 1) >> 1, r1 = c >> 1;
+    float lo = 0.f, hi = 0.f;
+    int e = 0;
+    for (int jj = j0; jj <= j1; ++jj)
+        for (int ii = i0; ii <= i1; ++ii, ++e) {
+            const float v = m[jj * nbx + ii];
+            int rank = 0, f = 0;
+            for (int pj = j0; pj <= j1; ++pj)
+                for (int pi = i0; pi <= i1; ++pi, ++f) {
+                    const float w = m[pj * nbx + pi];
+                    rank += (w < v || (w == v && f < e)) ? 1 : 0;
+                }
+            if (rank == r0) lo = v;
+            if (rank == r1) hi = v;
+        }
+    return (c & 1) ? lo : 0.5f * (lo + hi);
 }
 
 // 9-element sorting network (25 compare-exchanges) and a register pick
@@ -795,7 +808,12 @@ __device__ inline void sort9(float (&a)[9]) {
 __device__ inline float pick9(const float (&a)[9], int idx) {
     float r = a[0];
 #pragma unroll
-    for (int i = 1; i < 9; ++i) r = (i == idx) ? a[i] : r;
+    for (int i = 1; i < 9; ++i) {
+        r = (i == idx) ? a[i] : r;
+        // (kept a chain of selects: without the barrier the compiler turns it back into a[idx] - the array then
+        // lives in scratch memory, 96 bytes per thread in both instances of k_mesh_filter)
+        asm volatile("" : "+v"(r));
+    }
     return r;
 }
 
@@ -915,13 +933,11 @@ __global__ __launch_bounds__(1024) void k_mesh_filter(const float* __restrict__ 
             fb0[k] = 0.5f * (pick9(a, (c - 1) >> 1) + pick9(a, c >> 1));
             fb1[k] = 0.5f * (pick9(b, (c - 1) >> 1) + pick9(b, c >> 1));
         } else if (fsize > 1) {
-            float w0[49], w1[49];
-            int c = 0;
-            for (int jj = max(j - hb, 0); jj <= min(j + hb, nby - 1); ++jj)
-                for (int ii = max(i - hb, 0); ii <= min(i + hb, nbx - 1); ++ii)
-                    if (c < 49) { w0[c] = sb0[jj * nbx + ii]; w1[c] = sb1[jj * nbx + ii]; ++c; }
-            fb0[k] = small_median(w0, c);
-            fb1[k] = small_median(w1, c);
+            // any other window (5 x 5, 7 x 7): the two middle ranks by counting, straight from the staged maps - a
+            // per-thread window of 2 x 49 floats was 416 bytes of scratch in every instance of this kernel (round 6)
+            const int j0 = max(j - hb, 0), j1 = min(j + hb, nby - 1), i0 = max(i - hb, 0), i1 = min(i + hb, nbx - 1);
+            fb0[k] = window_median(sb0, nbx, j0, j1, i0, i1);
+            fb1[k] = window_median(sb1, nbx, j0, j1, i0, i1);
         } else {
             fb0[k] = sb0[k]; fb1[k] = sb1[k];
         }

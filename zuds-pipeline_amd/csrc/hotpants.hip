@@ -2060,8 +2060,10 @@ static __device__ __forceinline__ void chol_tp_body(int n, int lda, int ldt, dou
     double* AT = ATall + (size_t)reg * (size_t)n * ldt;
     const int wave = threadIdx.x >> 6;
     const int nblk = (n + CH_NB - 1) / CH_NB;
+    // (phase clocks: developer build only - the array's address is taken, it lived in 48 bytes of scratch memory of
+    // the shipped k_chol_tp whether or not anybody asked for the clocks)
     long long ptv[5] = {0, 0, 0, 0, 0};
-    long long* pt = prof ? ptv : nullptr;
+    long long* pt = (ZM_DEV_BUILD && prof) ? ptv : nullptr;
     for (int kb = 0; kb < nblk; ++kb) {
         const int ns = (n + 1 - kb * CH_NB + 15) >> 4;       // 16-row strips from row k0 down
         const int npass = (ns + CT_NQ * CT_WAVES - 1) / (CT_NQ * CT_WAVES);
@@ -2077,7 +2079,7 @@ static __device__ __forceinline__ void chol_tp_body(int n, int lda, int ldt, dou
             }
         }
     }
-    if (prof && threadIdx.x == 0)
+    if (ZM_DEV_BUILD && prof && threadIdx.x == 0)
         for (int k = 0; k < 5; ++k) prof[blockIdx.x * 5 + k] = ptv[k];
 }
 

@@ -89,12 +89,17 @@ class _Worker(object):
             self.chain.wsci = _lib.wcs_struct(sci['wcs'])
             self.chain.wref = _lib.wcs_struct(ref['wcs'])
         ch = self.chain
+        # (round 6: the call returns when the fit's last round has been seen; the photometry's host work - sky to
+        # pixel positions, its buffers - and its launches are made while the convolution runs, the fit summary is
+        # read behind the synchronisation)
         diff, noise, mask = ch.run(sci['img'], sci['rms'], sci['mask'], sci.get('wgt'), ref['img'],
                                    ref['rms'], ref['mask'], seeing=float(sci['seeing']),
                                    nreg_side=job.nreg_side, hotpants_kws=job.hotpants_kws,
-                                   ref_flxscale=float(ref.get('flxscale', 1.0)))
-        out = _collect(self, ch, job, ch.info, diff, noise, mask, keep)
+                                   ref_flxscale=float(ref.get('flxscale', 1.0)), wait=False)
+        out = _collect(self, ch, job, None, diff, noise, mask, keep)
         self.stream.synchronize()
+        info = ch.result()
+        out['info'] = {k: getattr(info, k) for k, _ in info._fields_}
         return _settle(out)
 
 
@@ -103,7 +108,7 @@ def _collect(w, ch, job, info, diff, noise, mask, keep):
     still in HBM (scripts/dophot.py:131-133) and, with ``keep``, copies of the three products.  Enqueued on
     the worker's stream; the caller synchronises."""
     torch, sci = w.torch, job.sci
-    out = dict(tag=job.tag, info={k: getattr(info, k) for k, _ in info._fields_})
+    out = dict(tag=job.tag, info=None if info is None else {k: getattr(info, k) for k, _ in info._fields_})
     if job.radec is not None:
         ra, dec = (np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in job.radec)
         x, y = sci['wcs'].all_world2pix(ra, dec, 0)
