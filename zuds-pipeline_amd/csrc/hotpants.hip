@@ -22,6 +22,7 @@
 //   k_hp_apply<HWK> per output block kernel evaluation (fp64) + register-tiled
 //                   fp32 convolution of template and template variance
 #include "hp_dev.h"
+#include <sched.h>
 #include "chol_diag.h"
 
 // ---------------------------------------------------------------------------
@@ -3332,7 +3333,10 @@ extern "C" int zm_subtract_dev(zm_ctx* ctx, const float* sci, const float* sci_r
                     ZM_HIP(e);
                 }
             }
-            __builtin_ia32_pause();
+            // (a round takes 0.2 - 0.4 ms: a short busy wait, then the core is offered to whoever wants it - a pool
+            // of sixteen chains has sixteen threads here, beside the readers and writers of the file ring)
+            if (spins < 4096) __builtin_ia32_pause();
+            else sched_yield();
         }
     };
     rounds = 0;

@@ -74,7 +74,11 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
             if (k < pw * pw) patch[yy * pp + xx] = t[u];
         }
     }
+    // (two short zeroing loops: interleaved eight-fold by the compiler, their hoisted addresses and trip counts were
+    // what k_hp_vectors_b<10, 11> spilled to scratch memory)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int k = tid; k < pw * HV_R; k += HV_THREADS) patch[(k / HV_R) * pp + pw + k % HV_R] = 0.f;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int k = tid; k < HV_R * cw; k += HV_THREADS) xp[(size_t)pw * cw + k] = 0.0;
     const double xc = P.rx0[r] + 0.5 * (P.rx1[r] - P.rx0[r]), hx = 0.5 * (P.rx1[r] - P.rx0[r]);
     const double yc = P.ry0[r] + 0.5 * (P.ry1[r] - P.ry0[r]), hy = 0.5 * (P.ry1[r] - P.ry0[r]);
@@ -98,7 +102,10 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
         }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
-            const int k = k0 + 256 * u;
+            int k = k0 + 256 * u;
+            // (opaque to the compiler: it otherwise keeps five 64-bit store addresses of this batch alive across the
+            // whole cell loop - and spills two of them in k_hp_vectors_b<11>)
+            asm volatile("" : "+v"(k));
             if (k < P.npix) {
                 const int i = k / sw, j = k - i * sw;
                 const int x = cc.x - hwss + j, y = cc.y - hwss + i;
@@ -120,8 +127,13 @@ static __device__ __forceinline__ void hp_vectors_body(const hp_plan& P, const f
         // (the spatial terms of the substamp this one replaces stay available to the fused normal-matrix update)
         // (one thread: the exponent tables sit in the kernel-argument segment - indexed by a lane they are copied
         // to scratch by every thread of the launch, and the first round took 365 us instead of 220)
-        if (phiold)
+        // (plain loops of one thread: vectorised and interleaved by the compiler they cost the batched kernel its
+        // last registers - k_hp_vectors_b<10, 11> spilled 3 and 6 of them to scratch memory)
+        if (phiold) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
             for (int p = 0; p < P.nkp; ++p) phiold[(size_t)cell * P.nkp + p] = phi[(size_t)cell * P.nkp + p];
+        }
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (int p = 0; p < P.nkp; ++p)
             phi[(size_t)cell * P.nkp + p] = ipowd(fx, P.kpi[p]) * ipowd(fy, P.kpj[p]);
     }
