@@ -233,6 +233,24 @@ def test_config2_parameters_against_the_oracle(engine, ko):
     assert abs(info['kernel_sum'] - 1.3) < 2e-3
 
 
+@pytest.mark.parametrize('seed', [21, 33, 47])
+def test_both_stamp_search_kernels_pick_the_same_substamps(engine, monkeypatch, seed):
+    """``k_hp_cells_reg`` (cells of at most 12 288 px, pixels in registers) and ``k_hp_cells`` (larger cells,
+    pixels in global memory) sum a cell's mean and sigma in different orders; the greedy substamp picks hang on a
+    threshold made of them.  The same cells through both kernels (``ZM_CELLS_FORM=global``): the same centres - seen
+    through everything that follows from them: stamp counts, rounds, kernel sum, every pixel of both products."""
+    data = scene(nx=900, ny=840, seed=seed, nstars=900, gradient=0.2, nbad=40)
+    kw = dict(r=6.0, rss=15.0, nsx=8, nsy=8, nrx=2, nry=2, ko=2, bgo=1, **COMMON)
+    d0, n0, i0 = engine.subtract(*data, **kw)
+    monkeypatch.setenv('ZM_CELLS_FORM', 'global')
+    d1, n1, i1 = engine.subtract(*data, **kw)
+    monkeypatch.delenv('ZM_CELLS_FORM')
+    assert i0['status'] == 0 and i0['nstamps_total'] > 100
+    for k in ('nstamps_total', 'nstamps_used', 'niter', 'ncoeff', 'kernel_sum', 'chi2', 'nmasked'):
+        assert i0[k] == i1[k], k
+    assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
+
+
 def test_barrier_timeout_is_retried_on_the_safe_path_and_reported(engine, monkeypatch, tmp_path):
     """a barrier of the fused factorisation that gives up (its workgroups were
     not all resident) used to look like a singular fit.  Now the time-outs are counted apart from bad

@@ -2888,7 +2888,11 @@ static int hp_launch_cells(zm_ctx* ctx, const hp_plan& P, const float* ref, cons
     int maxcell = 0;
     for (int r = 0; r < P.nreg; ++r)
         maxcell = std::max(maxcell, ((P.rx1[r] - P.rx0[r]) / P.nsx) * ((P.ry1[r] - P.ry0[r]) / P.nsy));
-    if (maxcell <= HC_THREADS * HC_PX)
+    // ZM_CELLS_FORM=global (tests): every cell through the kernel that keeps its pixels in global memory, whatever its
+    // size - ADVICE r5: the two kernels sum a cell's moments in different orders, tests/test_subtract_gpu.py holds
+    // their picks against each other on the same cells
+    const char* cf = getenv("ZM_CELLS_FORM");
+    if (maxcell <= HC_THREADS * HC_PX && !(cf && !strcmp(cf, "global")))
         hipLaunchKernelGGL(k_hp_cells_reg, dim3(P.ncell), dim3(HC_THREADS), 0, st, P, ref, bad, dirty, centres);
     else
         hipLaunchKernelGGL(k_hp_cells, dim3(P.ncell), b256, 0, st, P, ref, bad, dirty, centres);
