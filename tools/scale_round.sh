@@ -5,7 +5,10 @@
 # (ZM_NATIVE_RCCL=1, csrc/comm.hip), each line's per-rank step time and per-exchange wall clock collected into ONE
 # table with the figures the design expects beside them (tools/scale_table.py).
 #   usage (on an N-GPU node, from the repo root):  bash tools/scale_round.sh [tag] [max ranks, default: all GPUs]
-# ZM_SCALE_ARGS: extra bench.py arguments (a rehearsal: "--size 1024 --frames 8").
+# ZM_SCALE_ARGS: extra bench.py arguments.  The rehearsal that was run (round 6, one card, two gloo ranks, 3.5 min):
+#   ZM_DIST_BACKEND=gloo ZM_SCALE_ARGS="--size 2048 --frames 8 --no-subtract" ZM_SCALE_STEPS=3 bash tools/scale_round.sh rehearsal 2
+# (--no-subtract: a 2048-px frame cut into the full-size job's 3 x 3 regions has regions without usable stamps, which
+# bench.py reports as a failure; the exchanges being rehearsed are the coadd's).
 # Nothing here runs on the one-GPU boxes of the build rounds except the rehearsal: `ZM_DIST_BACKEND=gloo bash
 # tools/scale_round.sh rehearsal 2` puts two ranks on one card over gloo (tests/test_bench_ranks_gpu.py does the same).
 set -o pipefail
