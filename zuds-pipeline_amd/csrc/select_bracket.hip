@@ -712,10 +712,12 @@ int zm_rs2_median_mad(zm_ctx* ctx, int nimg, const rs_batch& B, unsigned long lo
     float* d_samp = nullptr;
     uint32_t* d_seg = nullptr;
     unsigned int* d_wcnt = nullptr;
+    // (sized for the images of this call - 10.5 MB of candidate segments each; a later call with more of them grows
+    // the buffers)
     ZM_TRY(ctx->get("rs2_state", sizeof(rs2_state) * ZM_RS_MAXIMG, (void**)&d_st));
-    ZM_TRY(ctx->get("rs2_samp", sizeof(float) * 4 * RS2_SAMPLE4 * ZM_RS_MAXIMG, (void**)&d_samp));
-    ZM_TRY(ctx->get("rs2_seg", sizeof(uint32_t) * (size_t)RS2_SUB * RS2_BINS * RS2_GRID * ZM_RS_MAXIMG, (void**)&d_seg));
-    ZM_TRY(ctx->get("rs2_wcnt", sizeof(unsigned int) * (size_t)RS2_BINS * RS2_GRID * ZM_RS_MAXIMG, (void**)&d_wcnt));
+    ZM_TRY(ctx->get("rs2_samp", sizeof(float) * 4 * RS2_SAMPLE4 * (size_t)nimg, (void**)&d_samp));
+    ZM_TRY(ctx->get("rs2_seg", sizeof(uint32_t) * (size_t)RS2_SUB * RS2_BINS * RS2_GRID * (size_t)nimg, (void**)&d_seg));
+    ZM_TRY(ctx->get("rs2_wcnt", sizeof(unsigned int) * (size_t)RS2_BINS * RS2_GRID * (size_t)nimg, (void**)&d_wcnt));
     const int grid = RS2_GRID;          // (every workgroup writes its row of counts: n >= ZM_RS2_MIN_N fills them all)
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(k_rsel2_sample, dim3(nimg), dim3(RS2_THREADS), 0, s, B, d_st, d_samp);
