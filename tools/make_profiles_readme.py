@@ -73,7 +73,8 @@ def main(tag):
           f'{ck.get("hbm_bytes_per_launch", 0) / 1e9:.2f} GB per launch |')
     print(f'| `{tag}_resource_usage.txt` | registers, spills, scratch and occupancy of every kernel as the compiler reports them '
           f'(`tools/resource_usage.py`, `hipcc -Rpass-analysis=kernel-resource-usage`) |')
-    extra = [('step_timeline.txt', 'one coadd leg kernel by kernel (start, length, gap to the previous end; `tools/step_timeline.py` on a kernel trace)'),
+    extra = [('fuzz.txt', 'the long differential fuzz runs at the final sources (`tools/gpu_fuzz_long.sh`): coadd forms against each other, subtraction forms against each other, random configurations against the oracle'),
+             ('step_timeline.txt', 'one coadd leg kernel by kernel (start, length, gap to the previous end; `tools/step_timeline.py` on a kernel trace)'),
              ('subtract_timeline.txt', 'one subtraction leg kernel by kernel with queue and stream ids (`tools/sub_timeline.py`)'),
              ('pipelined_trace.txt', 'the pipelined step: what is in flight, what stretches, idle time (`tools/pipelined_trace.py`)')]
     for name, what in extra:
